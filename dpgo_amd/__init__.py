@@ -1,0 +1,400 @@
+"""dpgo_amd -- MI355X-native DPGO hot path (ctypes binding of libdpgo_amd.so).
+
+The host-side mirror of the reference's C++ interface for the per-node MM / AMM
+inner step of ``dist_pgo``:
+
+  reference (C++/DPGO/include/DPGO)              here
+  ---------------------------------------------  --------------------------------
+  DPGO::read_g2o            DPGO_utils.h:49-51    read_g2o(filename, num_nodes) -> Graph
+  DPGO::Options             DPGO_types.h:78-201   Options (same field names/defaults)
+  DPGOHash(node, meas, opt) DPGOHash.h:13-107     NodeGroup(graph, node_ids, opt)[k] -> DPGOHash view
+    initialize/update/iterate/communicate           same names, return 0 / -1
+    results()               DPGO_types.h:204-322  .results() (scalars), .Xk(), .Xak()
+  dist_pgo driver loop      dist_pgo.cpp:446-531  DistPGO
+
+All compute runs in hand-written HIP kernels behind the C ABI of
+include/dpgo_amd.h.  There is NO CPU fallback: creating a NodeGroup without a
+HIP device raises.  numpy is used only to hold host matrices.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdpgo_amd.so")
+
+LOSS_NONE, LOSS_HUBER, LOSS_GM, LOSS_WELSCH = 0, 1, 2, 3
+LOSS_NAMES = {"trivial": 0, "none": 0, "huber": 1, "gm": 2, "welsch": 3}
+SCHEME_MM, SCHEME_AMM = 0, 1
+
+
+class Options(C.Structure):
+    """DPGO::Options (C++/DPGO/include/DPGO/DPGO_types.h:78-201)."""
+    _fields_ = [
+        ("scheme", C.c_int), ("regularizer", C.c_double), ("accepted_delta", C.c_double),
+        ("eta", C.c_double * 2), ("psi", C.c_double), ("phi", C.c_double),
+        ("max_soft_restart_hits", C.c_int * 2), ("oscillation_cnt_period", C.c_int),
+        ("max_oscillations", C.c_int), ("loss", C.c_int), ("loss_reg", C.c_double),
+        ("grad_norm_tol", C.c_double), ("rel_func_decrease_tol", C.c_double), ("stepsize_tol", C.c_double),
+        ("max_iterations", C.c_int), ("max_iterations_accepted", C.c_int),
+        ("reg_Cholesky_precon_max_condition_number", C.c_double),
+        ("preconditioned_grad_norm_tol", C.c_double), ("max_tCG_iterations", C.c_int),
+        ("STPCG_kappa", C.c_double), ("STPCG_theta", C.c_double), ("preconditioner", C.c_int),
+    ]
+
+    def __init__(self, **kw):
+        super().__init__()
+        lib().dpgo_options_default(C.byref(self))
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    @staticmethod
+    def driver(loss=LOSS_NONE, accelerated=True, **kw):
+        """The hard-coded options of C++/examples/dist_pgo.cpp:103-120."""
+        o = Options()
+        lib().dpgo_options_driver(C.byref(o), int(loss), int(bool(accelerated)))
+        for k, v in kw.items():
+            setattr(o, k, v)
+        return o
+
+
+class Results(C.Structure):
+    """Scalar part of DPGOResult (C++/DPGO/include/DPGO/DPGO_types.h:204-322)."""
+    _fields_ = [
+        ("updated", C.c_int), ("iters", C.c_int), ("gradFnorm", C.c_double), ("fobjE", C.c_double),
+        ("Fk", C.c_double * 2), ("Gk", C.c_double), ("Gkh", C.c_double), ("fobj", C.c_double),
+        ("f", C.c_double), ("gamma", C.c_double), ("s", C.c_double * 2),
+        ("soft_restart_hits", C.c_int * 2), ("num_oscillations", C.c_int), ("refined", C.c_int),
+        ("tnt_status", C.c_int), ("tnt_inner_iterations", C.c_int), ("restarts", C.c_int),
+    ]
+
+
+_lib = None
+_DP = C.POINTER(C.c_double)
+_IP = C.POINTER(C.c_int)
+
+# every symbol of include/dpgo_amd.h: (restype, argtypes)
+SYMBOLS = {
+    "dpgo_options_default": (None, [C.POINTER(Options)]),
+    "dpgo_options_driver": (None, [C.POINTER(Options), C.c_int, C.c_int]),
+    "dpgo_read_g2o": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "dpgo_graph_from_edges": (C.c_int, [C.c_int, C.c_int, C.c_int, _IP, _IP, _DP, _DP, _DP, _DP, C.c_int,
+                                        C.POINTER(C.c_void_p)]),
+    "dpgo_graph_free": (None, [C.c_void_p]),
+    "dpgo_graph_info": (C.c_int, [C.c_void_p, _IP, _IP, _IP, _IP]),
+    "dpgo_graph_edges": (C.c_int, [C.c_void_p, _IP, _IP, _DP, _DP, _DP, _DP]),
+    "dpgo_graph_node_sizes": (C.c_int, [C.c_void_p, C.c_int, _IP, _IP, _IP, _IP]),
+    "dpgo_graph_node_neighbours": (C.c_int, [C.c_void_p, C.c_int, _IP, _IP]),
+    "dpgo_graph_node_offset": (C.c_int, [C.c_void_p, C.c_int]),
+    "dpgo_chordal_initialization": (C.c_int, [C.c_void_p, _DP, C.c_int]),
+    "dpgo_group_create": (C.c_int, [C.c_void_p, _IP, C.c_int, C.POINTER(Options), C.c_int, C.POINTER(C.c_void_p)]),
+    "dpgo_group_free": (None, [C.c_void_p]),
+    "dpgo_group_initialize": (C.c_int, [C.c_void_p, C.c_int, _DP, C.c_int]),
+    "dpgo_group_initialize_global": (C.c_int, [C.c_void_p, _DP, C.c_int]),
+    "dpgo_group_update": (C.c_int, [C.c_void_p, _IP, C.c_int]),
+    "dpgo_group_iterate": (C.c_int, [C.c_void_p, _IP, C.c_int]),
+    "dpgo_group_communicate_local": (C.c_int, [C.c_void_p]),
+    "dpgo_group_num_sent": (C.c_int, [C.c_void_p]),
+    "dpgo_group_sent_keys": (C.c_int, [C.c_void_p, _IP, _IP]),
+    "dpgo_group_set_recv_layout": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _IP, _IP, _IP]),
+    "dpgo_group_pack_sent": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dpgo_group_unpack_recv": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dpgo_group_get_Xk": (C.c_int, [C.c_void_p, C.c_int, _DP, C.c_int]),
+    "dpgo_group_get_Xak": (C.c_int, [C.c_void_p, C.c_int, _DP, C.c_int]),
+    "dpgo_group_scatter_global": (C.c_int, [C.c_void_p, _DP, C.c_int]),
+    "dpgo_group_results": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Results)]),
+    "dpgo_group_node_id": (C.c_int, [C.c_void_p, C.c_int]),
+    "dpgo_group_sync": (C.c_int, [C.c_void_p]),
+    "dpgo_group_stream": (C.c_void_p, [C.c_void_p]),
+    "dpgo_debug_node_matrix": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Options), C.c_char_p, _IP, _IP, _DP]),
+    "dpgo_debug_node_proximal": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Options), _DP, _DP, _DP]),
+    "dpgo_debug_spd_solve": (C.c_int, [C.c_int, _IP, _IP, _DP, _DP, C.c_int, C.c_int]),
+    "dpgo_group_debug_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, _DP, C.c_int, _DP, C.c_int]),
+}
+
+
+def lib():
+    """Load libdpgo_amd.so (built by dpgo_amd/csrc/Makefile).  Fails loudly if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("dpgo_amd: %s not found -- build it with __graft_entry__.build() "
+                               "(make -C dpgo_amd/csrc); there is no fallback path" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(_DP)
+
+
+def _ip(a):
+    return a.ctypes.data_as(_IP)
+
+
+def _fcol(X):
+    """Column-major float64 copy/view and its leading dimension."""
+    X = np.asfortranarray(X, dtype=np.float64)
+    return X, X.shape[0]
+
+
+class Graph:
+    """Result of DPGO::read_g2o: measurements partitioned over num_nodes."""
+
+    def __init__(self, handle):
+        self._h = handle
+        d, n, k, m = (C.c_int() for _ in range(4))
+        lib().dpgo_graph_info(self._h, C.byref(d), C.byref(n), C.byref(k), C.byref(m))
+        self.d, self.num_poses, self.num_nodes, self.num_edges = d.value, n.value, k.value, m.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().dpgo_graph_free(self._h)
+            self._h = None
+
+    def edges(self):
+        d, m = self.d, self.num_edges
+        I, J = np.empty(m, np.int32), np.empty(m, np.int32)
+        R, t = np.empty((m, d, d)), np.empty((m, d))
+        kap, tau = np.empty(m), np.empty(m)
+        lib().dpgo_graph_edges(self._h, _ip(I), _ip(J), _dp(R), _dp(t), _dp(kap), _dp(tau))
+        return I, J, R, t, kap, tau
+
+    def node_sizes(self, node):
+        v = [C.c_int() for _ in range(4)]
+        if lib().dpgo_graph_node_sizes(self._h, node, *[C.byref(x) for x in v]) != 0:
+            raise ValueError("node %d" % node)
+        return tuple(x.value for x in v)   # n0, n1, m0, m1
+
+    def node_neighbours(self, node):
+        n1 = self.node_sizes(node)[1]
+        a, b = np.empty(n1, np.int32), np.empty(n1, np.int32)
+        lib().dpgo_graph_node_neighbours(self._h, node, _ip(a), _ip(b))
+        return a, b
+
+    def node_offset(self, node):
+        return lib().dpgo_graph_node_offset(self._h, node)
+
+    def chordal_initialization(self):
+        """Centralised chordal init (dist_pgo.cpp:416-444): X, (d+1)N x d, reference layout."""
+        X = np.zeros(((self.d + 1) * self.num_poses, self.d), order="F")
+        if lib().dpgo_chordal_initialization(self._h, _dp(X), X.shape[0]) != 0:
+            raise RuntimeError("chordal initialisation failed")
+        return X
+
+    def node_matrix(self, node, opt, name):
+        """Assembled operator in the reference's row order, as a scipy COO matrix (test hook)."""
+        import scipy.sparse as sp
+        cnt = lib().dpgo_debug_node_matrix(self._h, node, C.byref(opt), name.encode(), None, None, None)
+        if cnt < 0:
+            raise ValueError(name)
+        r, c, v = np.empty(cnt, np.int32), np.empty(cnt, np.int32), np.empty(cnt)
+        lib().dpgo_debug_node_matrix(self._h, node, C.byref(opt), name.encode(), _ip(r), _ip(c), _dp(v))
+        n0, n1, _, _ = self.node_sizes(node)
+        D1 = self.d + 1
+        shape = {"G": (D1 * n0, D1 * n0), "D": (D1 * n0, D1 * n0), "S": (D1 * n0, D1 * (n0 + n1))}.get(
+            name, (D1 * (n0 + n1), D1 * (n0 + n1)))
+        return sp.coo_matrix((v, (r, c)), shape=shape).tocsr()
+
+    def node_proximal(self, node, opt):
+        n0 = self.node_sizes(node)[0]
+        d = self.d
+        T, N, V = np.empty(n0), np.empty((n0, d)), np.empty((n0, d, d))
+        lib().dpgo_debug_node_proximal(self._h, node, C.byref(opt), _dp(T), _dp(N), _dp(V))
+        return T, N, V
+
+
+def read_g2o(filename, num_nodes):
+    """DPGO::read_g2o (C++/DPGO/src/DPGO_utils.cpp:140-202)."""
+    h = C.c_void_p()
+    if lib().dpgo_read_g2o(os.fsencode(filename), int(num_nodes), C.byref(h)) != 0:
+        raise IOError("read_g2o failed for %s" % filename)
+    return Graph(h)
+
+
+def graph_from_edges(d, num_poses, I, J, R, t, kappa, tau, num_nodes):
+    I, J = np.ascontiguousarray(I, np.int32), np.ascontiguousarray(J, np.int32)
+    R, t = np.ascontiguousarray(R, np.float64), np.ascontiguousarray(t, np.float64)
+    kappa, tau = np.ascontiguousarray(kappa, np.float64), np.ascontiguousarray(tau, np.float64)
+    h = C.c_void_p()
+    if lib().dpgo_graph_from_edges(d, num_poses, len(I), _ip(I), _ip(J), _dp(R), _dp(t), _dp(kappa), _dp(tau),
+                                   int(num_nodes), C.byref(h)) != 0:
+        raise ValueError("graph_from_edges failed")
+    return Graph(h)
+
+
+def spd_solve_host(A_csr, B, leaf=32):
+    """Host multifrontal factor + solve (test hook for the solver set-up path)."""
+    A = A_csr.tocsr()
+    A.sort_indices()
+    ptr, col = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+    val = A.data.astype(np.float64)
+    X = np.ascontiguousarray(B, np.float64).copy()
+    if X.ndim == 1:
+        X = X[:, None]
+    if lib().dpgo_debug_spd_solve(A.shape[0], _ip(ptr), _ip(col), _dp(val), _dp(X), X.shape[1], leaf) != 0:
+        raise RuntimeError("spd solve failed")
+    return X
+
+
+class NodeGroup:
+    """The DPGOHash objects of the nodes hosted by one GPU (one process)."""
+
+    def __init__(self, graph, node_ids, options, device=0):
+        self.graph, self.options = graph, options
+        self.node_ids = [int(a) for a in node_ids]
+        ids = np.asarray(self.node_ids, np.int32)
+        h = C.c_void_p()
+        if lib().dpgo_group_create(graph._h, _ip(ids), len(ids), C.byref(options), int(device), C.byref(h)) != 0:
+            raise RuntimeError("dpgo_group_create failed (no HIP device, or inconsistent input); "
+                               "the DPGO hot path has no CPU fallback")
+        self._h = h
+        self.d = graph.d
+        self.sizes = [graph.node_sizes(a) for a in self.node_ids]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().dpgo_group_free(self._h)
+            self._h = None
+
+    def __len__(self):
+        return len(self.node_ids)
+
+    def __getitem__(self, k):
+        return DPGOHash(self, k)
+
+    def _sel(self, locals_):
+        if locals_ is None:
+            return None, 0
+        a = np.asarray(list(locals_), np.int32)
+        return _ip(a), len(a)
+
+    def initialize_global(self, X):
+        X, ld = _fcol(X)
+        return lib().dpgo_group_initialize_global(self._h, _dp(X), ld)
+
+    def update(self, locals_=None):
+        p, n = self._sel(locals_)
+        return lib().dpgo_group_update(self._h, p, n)
+
+    def iterate(self, locals_=None):
+        p, n = self._sel(locals_)
+        return lib().dpgo_group_iterate(self._h, p, n)
+
+    def communicate_local(self):
+        return lib().dpgo_group_communicate_local(self._h)
+
+    def sync(self):
+        return lib().dpgo_group_sync(self._h)
+
+    def stream(self):
+        return lib().dpgo_group_stream(self._h)
+
+    # boundary exchange across groups
+    def sent_keys(self):
+        n = lib().dpgo_group_num_sent(self._h)
+        a, b = np.empty(n, np.int32), np.empty(n, np.int32)
+        lib().dpgo_group_sent_keys(self._h, _ip(a), _ip(b))
+        return a, b
+
+    def set_recv_layout(self, stride, keys_per_rank):
+        counts = np.asarray([len(k[0]) for k in keys_per_rank], np.int32)
+        nodes = np.ascontiguousarray(np.concatenate([k[0] for k in keys_per_rank]) if len(counts) else [], np.int32)
+        poses = np.ascontiguousarray(np.concatenate([k[1] for k in keys_per_rank]) if len(counts) else [], np.int32)
+        return lib().dpgo_group_set_recv_layout(self._h, len(counts), int(stride), _ip(counts), _ip(nodes), _ip(poses))
+
+    def pack_sent(self, dev_ptr):
+        return lib().dpgo_group_pack_sent(self._h, C.c_void_p(dev_ptr))
+
+    def unpack_recv(self, dev_ptr):
+        return lib().dpgo_group_unpack_recv(self._h, C.c_void_p(dev_ptr))
+
+    def scatter_global(self, X):
+        assert X.flags.f_contiguous
+        return lib().dpgo_group_scatter_global(self._h, _dp(X), X.shape[0])
+
+    def results(self, k):
+        r = Results()
+        lib().dpgo_group_results(self._h, k, C.byref(r))
+        return r
+
+    def debug_apply(self, k, op, X, out_rows):
+        X, ld = _fcol(X)
+        out = np.zeros((out_rows, self.d), order="F")
+        if lib().dpgo_group_debug_apply(self._h, k, op.encode(), _dp(X), ld, _dp(out), out.shape[0]) != 0:
+            raise RuntimeError("debug_apply(%s) failed" % op)
+        return out
+
+
+class DPGOHash:
+    """View of one node of a NodeGroup with the reference's DPGOHash method names
+    (C++/DPGO/include/DPGO/DPGOHash.h:13-107)."""
+
+    def __init__(self, group, local):
+        self.group, self.local = group, local
+        self.node = group.node_ids[local]
+        self.n = group.sizes[local][:2]
+        self.m = group.sizes[local][2:]
+        self.d = group.d
+
+    def initialize(self, X):
+        X, ld = _fcol(X)
+        if X.shape != ((self.d + 1) * (self.n[0] + self.n[1]), self.d):
+            return -1
+        return lib().dpgo_group_initialize(self.group._h, self.local, _dp(X), ld)
+
+    def update(self):
+        return self.group.update([self.local])
+
+    def iterate(self):
+        return self.group.iterate([self.local])
+
+    def results(self):
+        return self.group.results(self.local)
+
+    def Xk(self):
+        X = np.zeros(((self.d + 1) * (self.n[0] + self.n[1]), self.d), order="F")
+        lib().dpgo_group_get_Xk(self.group._h, self.local, _dp(X), X.shape[0])
+        return X
+
+    def Xak(self):
+        X = np.zeros(((self.d + 1) * self.n[0], self.d), order="F")
+        lib().dpgo_group_get_Xak(self.group._h, self.local, _dp(X), X.shape[0])
+        return X
+
+
+class DistPGO:
+    """Single-process dist_pgo driver loop (C++/examples/dist_pgo.cpp:446-531): every node of the graph
+    hosted by one GPU.  bench.py holds the multi-process (one rank per GPU) variant."""
+
+    def __init__(self, graph, options, X0=None, device=0):
+        self.graph, self.options = graph, options
+        self.group = NodeGroup(graph, range(graph.num_nodes), options, device)
+        self.X0 = graph.chordal_initialization() if X0 is None else np.asfortranarray(X0)
+        if self.group.initialize_global(self.X0) != 0:
+            raise RuntimeError("initialize failed")
+        self.group.update()
+
+    def step(self):
+        g = self.group
+        rc = g.iterate()
+        rc |= g.communicate_local()
+        rc |= g.update()
+        return rc
+
+    def X(self):
+        X = np.zeros(((self.graph.d + 1) * self.graph.num_poses, self.graph.d), order="F")
+        self.group.scatter_global(X)
+        return X
+
+    def sum_fobj(self):
+        """sum_a fobj^a == F(X_k) (invariant 1)."""
+        return sum(self.group.results(k).fobj for k in range(len(self.group)))

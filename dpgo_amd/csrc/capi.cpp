@@ -1,0 +1,291 @@
+// C ABI (include/dpgo_amd.h) over the C++ host layer.
+#include "../../include/dpgo_amd.h"
+
+#include <cstring>
+#include <map>
+#include <numeric>
+
+#include "group.h"
+
+namespace dpgo {
+int chordal_initialization(const Graph &g, double *X, int ld);
+}
+
+struct dpgo_graph {
+  dpgo::Graph g;
+};
+struct dpgo_group {
+  dpgo::Group *grp = nullptr;
+  std::vector<int> all;
+};
+
+static dpgo::Options to_cpp(const dpgo_options_t &o) {
+  dpgo::Options r;
+  r.scheme = o.scheme; r.regularizer = o.regularizer; r.accepted_delta = o.accepted_delta;
+  r.eta[0] = o.eta[0]; r.eta[1] = o.eta[1]; r.psi = o.psi; r.phi = o.phi;
+  r.max_soft_restart_hits[0] = o.max_soft_restart_hits[0]; r.max_soft_restart_hits[1] = o.max_soft_restart_hits[1];
+  r.oscillation_cnt_period = o.oscillation_cnt_period; r.max_oscillations = o.max_oscillations;
+  r.loss = o.loss; r.loss_reg = o.loss_reg; r.grad_norm_tol = o.grad_norm_tol;
+  r.rel_func_decrease_tol = o.rel_func_decrease_tol; r.stepsize_tol = o.stepsize_tol;
+  r.max_iterations = o.max_iterations; r.max_iterations_accepted = o.max_iterations_accepted;
+  r.reg_Cholesky_precon_max_condition_number = o.reg_Cholesky_precon_max_condition_number;
+  r.preconditioned_grad_norm_tol = o.preconditioned_grad_norm_tol; r.max_tCG_iterations = o.max_tCG_iterations;
+  r.STPCG_kappa = o.STPCG_kappa; r.STPCG_theta = o.STPCG_theta; r.preconditioner = o.preconditioner;
+  return r;
+}
+
+extern "C" {
+
+void dpgo_options_default(dpgo_options_t *o) {
+  const dpgo::Options d;
+  o->scheme = d.scheme; o->regularizer = d.regularizer; o->accepted_delta = d.accepted_delta;
+  o->eta[0] = d.eta[0]; o->eta[1] = d.eta[1]; o->psi = d.psi; o->phi = d.phi;
+  o->max_soft_restart_hits[0] = d.max_soft_restart_hits[0]; o->max_soft_restart_hits[1] = d.max_soft_restart_hits[1];
+  o->oscillation_cnt_period = d.oscillation_cnt_period; o->max_oscillations = d.max_oscillations;
+  o->loss = d.loss; o->loss_reg = d.loss_reg; o->grad_norm_tol = d.grad_norm_tol;
+  o->rel_func_decrease_tol = d.rel_func_decrease_tol; o->stepsize_tol = d.stepsize_tol;
+  o->max_iterations = d.max_iterations; o->max_iterations_accepted = d.max_iterations_accepted;
+  o->reg_Cholesky_precon_max_condition_number = d.reg_Cholesky_precon_max_condition_number;
+  o->preconditioned_grad_norm_tol = d.preconditioned_grad_norm_tol; o->max_tCG_iterations = d.max_tCG_iterations;
+  o->STPCG_kappa = d.STPCG_kappa; o->STPCG_theta = d.STPCG_theta; o->preconditioner = d.preconditioner;
+}
+
+void dpgo_options_driver(dpgo_options_t *o, int loss, int accelerated) {
+  // C++/examples/dist_pgo.cpp:103-120
+  dpgo_options_default(o);
+  o->loss = loss;
+  o->loss_reg = 0.25;
+  o->scheme = accelerated ? 1 : 0;
+  o->STPCG_kappa = 0.05;
+  o->STPCG_theta = 0.9;
+  o->eta[0] = 5e-4; o->eta[1] = 2.5e-2;
+  o->max_soft_restart_hits[0] = 10; o->max_soft_restart_hits[1] = 25;
+  o->max_iterations = 10;
+  o->max_iterations_accepted = 1;
+  o->grad_norm_tol = 1e-3;
+  o->preconditioned_grad_norm_tol = 1e-4;
+  o->regularizer = 1e-11;
+}
+
+int dpgo_read_g2o(const char *filename, int num_nodes, dpgo_graph_t **out) {
+  auto *g = new dpgo_graph();
+  if (dpgo::read_g2o(filename, num_nodes, g->g) != 0) { delete g; *out = nullptr; return -1; }
+  *out = g;
+  return 0;
+}
+
+int dpgo_graph_from_edges(int d, int num_poses, int m, const int *I, const int *J, const double *R, const double *t,
+                          const double *kappa, const double *tau, int num_nodes, dpgo_graph_t **out) {
+  if ((d != 2 && d != 3) || m <= 0) return -1;
+  auto *g = new dpgo_graph();
+  g->g.d = d;
+  g->g.num_poses = num_poses;
+  g->g.all.resize(m);
+  for (int e = 0; e < m; e++) {
+    dpgo::Measurement &mm = g->g.all[e];
+    std::memset(&mm, 0, sizeof(mm));
+    mm.ipose = I[e]; mm.jpose = J[e];
+    for (int k = 0; k < d * d; k++) mm.R[k] = R[(size_t)e * d * d + k];
+    for (int k = 0; k < d; k++) mm.t[k] = t[(size_t)e * d + k];
+    mm.kappa = kappa[e]; mm.tau = tau[e];
+  }
+  if (dpgo::partition(g->g, num_nodes) != 0) { delete g; *out = nullptr; return -1; }
+  *out = g;
+  return 0;
+}
+
+void dpgo_graph_free(dpgo_graph_t *g) { delete g; }
+
+int dpgo_graph_info(const dpgo_graph_t *g, int *d, int *num_poses, int *num_nodes, int *num_edges) {
+  if (!g) return -1;
+  if (d) *d = g->g.d;
+  if (num_poses) *num_poses = g->g.num_poses;
+  if (num_nodes) *num_nodes = g->g.num_nodes;
+  if (num_edges) *num_edges = (int)g->g.all.size();
+  return 0;
+}
+
+int dpgo_graph_edges(const dpgo_graph_t *g, int *I, int *J, double *R, double *t, double *kappa, double *tau) {
+  if (!g) return -1;
+  const int d = g->g.d;
+  for (size_t e = 0; e < g->g.all.size(); e++) {
+    const auto &m = g->g.all[e];
+    if (I) I[e] = m.ipose;
+    if (J) J[e] = m.jpose;
+    if (R) for (int k = 0; k < d * d; k++) R[e * d * d + k] = m.R[k];
+    if (t) for (int k = 0; k < d; k++) t[e * d + k] = m.t[k];
+    if (kappa) kappa[e] = m.kappa;
+    if (tau) tau[e] = m.tau;
+  }
+  return 0;
+}
+
+static int node_info(const dpgo_graph_t *g, int node, dpgo::DataInfo &info) {
+  if (!g || node < 0 || node >= g->g.num_nodes) return -1;
+  return dpgo::generate_data_info(node, g->g.d, g->g.measurements[node], info);
+}
+
+int dpgo_graph_node_sizes(const dpgo_graph_t *g, int node, int *n0, int *n1, int *m0, int *m1) {
+  dpgo::DataInfo info;
+  if (node_info(g, node, info) != 0) return -1;
+  if (n0) *n0 = info.n[0];
+  if (n1) *n1 = info.n[1];
+  if (m0) *m0 = info.m[0];
+  if (m1) *m1 = info.m[1];
+  return 0;
+}
+
+int dpgo_graph_node_neighbours(const dpgo_graph_t *g, int node, int *nbr_node, int *nbr_pose) {
+  dpgo::DataInfo info;
+  if (node_info(g, node, info) != 0) return -1;
+  for (int k = 0; k < info.n[1]; k++) {
+    nbr_node[k] = info.nbr_key[k].first;
+    nbr_pose[k] = info.nbr_key[k].second;
+  }
+  return 0;
+}
+
+int dpgo_graph_node_offset(const dpgo_graph_t *g, int node) {
+  if (!g || node < 0 || node >= g->g.num_nodes || g->g.g_index[node].empty()) return -1;
+  return g->g.g_index[node].begin()->second;
+}
+
+int dpgo_chordal_initialization(const dpgo_graph_t *g, double *X, int ld) {
+  if (!g) return -1;
+  return dpgo::chordal_initialization(g->g, X, ld);
+}
+
+int dpgo_group_create(const dpgo_graph_t *g, const int *node_ids, int num_local, const dpgo_options_t *opt,
+                      int device, dpgo_group_t **out) {
+  *out = nullptr;
+  if (!g || num_local <= 0) return -1;
+  std::vector<int> ids(node_ids, node_ids + num_local);
+  for (int id : ids)
+    if (id < 0 || id >= g->g.num_nodes) return -1;
+  auto *h = new dpgo_group();
+  h->grp = new dpgo::Group(g->g, ids, to_cpp(*opt), device);
+  if (!h->grp->ok()) {
+    delete h->grp;
+    delete h;
+    return -1;
+  }
+  h->all.resize(num_local);
+  std::iota(h->all.begin(), h->all.end(), 0);
+  *out = h;
+  return 0;
+}
+
+void dpgo_group_free(dpgo_group_t *h) {
+  if (!h) return;
+  delete h->grp;
+  delete h;
+}
+
+static std::vector<int> sel(const dpgo_group_t *h, const int *locals, int n) {
+  if (!locals || n <= 0) return h->all;
+  return std::vector<int>(locals, locals + n);
+}
+
+int dpgo_group_initialize(dpgo_group_t *h, int local, const double *X, int ld) { return h->grp->initialize(local, X, ld); }
+int dpgo_group_initialize_global(dpgo_group_t *h, const double *X, int ld) { return h->grp->initialize_global(X, ld); }
+int dpgo_group_update(dpgo_group_t *h, const int *locals, int n) { return h->grp->update(sel(h, locals, n)); }
+int dpgo_group_iterate(dpgo_group_t *h, const int *locals, int n) { return h->grp->iterate(sel(h, locals, n)); }
+int dpgo_group_communicate_local(dpgo_group_t *h) { return h->grp->communicate_local(); }
+int dpgo_group_num_sent(const dpgo_group_t *h) { return h->grp->num_sent(); }
+int dpgo_group_sent_keys(const dpgo_group_t *h, int *nodes, int *poses) {
+  const auto &k = h->grp->sent_keys();
+  for (size_t i = 0; i < k.size(); i++) { nodes[i] = k[i].first; poses[i] = k[i].second; }
+  return 0;
+}
+int dpgo_group_set_recv_layout(dpgo_group_t *h, int nranks, int stride, const int *counts, const int *nodes,
+                               const int *poses) {
+  return h->grp->set_recv_layout(nranks, stride, counts, nodes, poses);
+}
+int dpgo_group_pack_sent(dpgo_group_t *h, void *buf) { return h->grp->pack_sent((double *)buf); }
+int dpgo_group_unpack_recv(dpgo_group_t *h, const void *buf) { return h->grp->unpack_recv((const double *)buf); }
+int dpgo_group_get_Xk(const dpgo_group_t *h, int local, double *X, int ld) { return h->grp->get_Xk(local, X, ld); }
+int dpgo_group_get_Xak(const dpgo_group_t *h, int local, double *X, int ld) { return h->grp->get_X_own(local, X, ld); }
+int dpgo_group_scatter_global(const dpgo_group_t *h, double *X, int ld) { return h->grp->scatter_global(X, ld); }
+int dpgo_group_node_id(const dpgo_group_t *h, int local) { return h->grp->node_id(local); }
+int dpgo_group_sync(const dpgo_group_t *h) { h->grp->sync(); return 0; }
+void *dpgo_group_stream(const dpgo_group_t *h) { return (void *)h->grp->stream(); }
+
+int dpgo_group_results(const dpgo_group_t *h, int local, dpgo_results_t *o) {
+  if (local < 0 || local >= h->grp->num_local()) return -1;
+  const dpgo::NodeResults &r = h->grp->results(local);
+  o->updated = r.updated; o->iters = r.iters; o->gradFnorm = r.gradFnorm; o->fobjE = r.fobjE;
+  o->Fk[0] = r.Fk[0]; o->Fk[1] = r.Fk[1]; o->Gk = r.Gk; o->Gkh = r.Gkh; o->fobj = r.fobj; o->f = r.f;
+  o->gamma = r.gamma; o->s[0] = r.s0; o->s[1] = r.s1;
+  o->soft_restart_hits[0] = r.soft_restart_hits[0]; o->soft_restart_hits[1] = r.soft_restart_hits[1];
+  o->num_oscillations = r.num_oscillations; o->refined = r.refined; o->tnt_status = r.tnt_status;
+  o->tnt_inner_iterations = r.tnt_inner; o->restarts = r.restarts;
+  return 0;
+}
+
+// ---- test hooks ----
+static int ref_row(int d, int n0, int n1, int p, int slot) {
+  if (p < n0) return slot == 0 ? p : n0 + p * d + slot - 1;
+  const int k = p - n0;
+  return slot == 0 ? (d + 1) * n0 + k : (d + 1) * n0 + n1 + k * d + slot - 1;
+}
+
+int dpgo_debug_node_matrix(const dpgo_graph_t *g, int node, const dpgo_options_t *opt, const char *name, int *rows,
+                           int *cols, double *vals) {
+  dpgo::DataInfo info;
+  if (node_info(g, node, info) != 0) return -1;
+  dpgo::NodeOperators ops;
+  const bool trivial = opt->loss == 0;
+  if (dpgo::assemble_node(info, opt->regularizer, trivial, ops) != 0) return -1;
+  const int d = info.d, B = d + 1, n0 = info.n[0], n1 = info.n[1];
+  const std::string nm(name);
+  int cnt = 0;
+  auto emit = [&](int p, int q, const double *blk) {
+    for (int r = 0; r < B; r++)
+      for (int c = 0; c < B; c++) {
+        if (blk[r * B + c] == 0.0) continue;
+        if (rows) { rows[cnt] = ref_row(d, n0, n1, p, r); cols[cnt] = ref_row(d, n0, n1, q, c); vals[cnt] = blk[r * B + c]; }
+        cnt++;
+      }
+  };
+  if (nm == "D") {
+    for (int p = 0; p < n0; p++) emit(p, p, &ops.D[(size_t)p * B * B]);
+    return cnt;
+  }
+  const dpgo::BsrMatrix *M = nm == "G" ? &ops.G : nm == "S" ? &ops.S : nm == "P" ? &ops.P : nm == "P0" ? &ops.P0
+                                                                                    : nm == "Q" ? &ops.Q : nullptr;
+  if (!M || M->B == 0) return -1;
+  for (int p = 0; p < M->nrows; p++)
+    for (int k = M->ptr[p]; k < M->ptr[p + 1]; k++) emit(p, M->col[k], &M->val[(size_t)k * B * B]);
+  return cnt;
+}
+
+int dpgo_debug_node_proximal(const dpgo_graph_t *g, int node, const dpgo_options_t *opt, double *T, double *N,
+                             double *V) {
+  dpgo::DataInfo info;
+  if (node_info(g, node, info) != 0) return -1;
+  dpgo::NodeOperators ops;
+  if (dpgo::assemble_node(info, opt->regularizer, opt->loss == 0, ops) != 0) return -1;
+  std::copy(ops.Tinv.begin(), ops.Tinv.end(), T);
+  std::copy(ops.N.begin(), ops.N.end(), N);
+  std::copy(ops.V.begin(), ops.V.end(), V);
+  return 0;
+}
+
+int dpgo_debug_spd_solve(int n, const int *ptr, const int *col, const double *val, double *X, int ncols, int leaf) {
+  dpgo::CsrMatrix A;
+  A.n = n;
+  A.ptr.assign(ptr, ptr + n + 1);
+  A.col.assign(col, col + ptr[n]);
+  A.val.assign(val, val + ptr[n]);
+  dpgo::SpdFactor F;
+  if (dpgo::spd_factor(A, F, leaf) != 0) return -1;
+  dpgo::spd_solve_host(F, X, ncols);
+  return 0;
+}
+
+int dpgo_group_debug_apply(dpgo_group_t *h, int local, const char *op, const double *in, int ld_in, double *out,
+                           int ld_out) {
+  return h->grp->debug_apply(local, op, in, ld_in, out, ld_out);
+}
+
+}  // extern "C"

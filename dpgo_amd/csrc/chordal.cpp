@@ -1,0 +1,233 @@
+// Centralised chordal initialisation (host, set-up only, untimed in the driver).
+//
+// Same least-squares problems as the reference's --dist_init false branch
+// (C++/examples/dist_pgo.cpp:416-444 -> C++/SESync/src/SESync_utils.cpp:573-652):
+//   rotations   : min sum kappa |R_ij^T Y_i - Y_j|_F^2  with Y_0 = I, then per-block SO(d) projection
+//   translations: min sum tau |x_i - x_j + t_ij^T Y_i|^2 with x_0 = 0
+// The reference solves them with SPQR; here the normal equations are solved
+// matrix-free by Jacobi-preconditioned CG to 1e-13 (same minimiser).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+#include "graph.h"
+
+namespace dpgo {
+
+namespace {
+
+// nearest rotation of a d x d block (host; Jacobi eigen-decomposition of M^T M, as the device kernel)
+void project_block(int d, double *M) {
+  if (d == 2) {
+    double c = M[0] + M[3], s = M[2] - M[1], n2 = c * c + s * s;
+    if (n2 < 1e-32) { c = 1; s = 0; n2 = 1; }
+    const double inv = 1.0 / std::sqrt(n2);
+    M[0] = c * inv; M[1] = -s * inv; M[2] = s * inv; M[3] = c * inv;
+    return;
+  }
+  double S[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      double a = 0;
+      for (int k = 0; k < 3; k++) a += M[k * 3 + r] * M[k * 3 + c];
+      S[r * 3 + c] = a;
+    }
+  for (int sweep = 0; sweep < 30; sweep++) {
+    double off = std::fabs(S[1]) + std::fabs(S[2]) + std::fabs(S[5]);
+    if (off < 1e-300) break;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        if (std::fabs(S[p * 3 + q]) < 1e-300) continue;
+        double th = (S[q * 3 + q] - S[p * 3 + p]) / (2 * S[p * 3 + q]);
+        double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1));
+        double c = 1 / std::sqrt(t * t + 1), s = t * c;
+        for (int k = 0; k < 3; k++) {  // S <- S J
+          double a = S[k * 3 + p], b = S[k * 3 + q];
+          S[k * 3 + p] = c * a - s * b; S[k * 3 + q] = s * a + c * b;
+        }
+        for (int k = 0; k < 3; k++) {  // S <- J^T S
+          double a = S[p * 3 + k], b = S[q * 3 + k];
+          S[p * 3 + k] = c * a - s * b; S[q * 3 + k] = s * a + c * b;
+        }
+        for (int k = 0; k < 3; k++) {
+          double a = V[k * 3 + p], b = V[k * 3 + q];
+          V[k * 3 + p] = c * a - s * b; V[k * 3 + q] = s * a + c * b;
+        }
+      }
+  }
+  double Bm[9], nrm[3];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) Bm[r * 3 + c] = M[r * 3] * V[c] + M[r * 3 + 1] * V[3 + c] + M[r * 3 + 2] * V[6 + c];
+  for (int c = 0; c < 3; c++) nrm[c] = Bm[c] * Bm[c] + Bm[3 + c] * Bm[3 + c] + Bm[6 + c] * Bm[6 + c];
+  int o[3] = {0, 1, 2};
+  std::sort(o, o + 3, [&](int a, int b) { return nrm[a] > nrm[b]; });
+  double u1[3], u2[3], u3[3], v[3][3];
+  for (int k = 0; k < 3; k++) { u1[k] = Bm[k * 3 + o[0]]; u2[k] = Bm[k * 3 + o[1]]; for (int j = 0; j < 3; j++) v[j][k] = V[k * 3 + o[j]]; }
+  double n1 = std::sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+  if (n1 < 1e-150) { for (int k = 0; k < 9; k++) M[k] = (k % 4 == 0); return; }
+  for (double &x : u1) x /= n1;
+  double pr = u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2];
+  for (int k = 0; k < 3; k++) u2[k] -= pr * u1[k];
+  double n2 = std::sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+  if (n2 < 1e-14 * n1) {
+    double e[3] = {0, 0, 0};
+    int mi = 0;
+    for (int k = 1; k < 3; k++) if (std::fabs(u1[k]) < std::fabs(u1[mi])) mi = k;
+    e[mi] = 1;
+    u2[0] = u1[1] * e[2] - u1[2] * e[1]; u2[1] = u1[2] * e[0] - u1[0] * e[2]; u2[2] = u1[0] * e[1] - u1[1] * e[0];
+    n2 = std::sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+  }
+  for (double &x : u2) x /= n2;
+  u3[0] = u1[1] * u2[2] - u1[2] * u2[1]; u3[1] = u1[2] * u2[0] - u1[0] * u2[2]; u3[2] = u1[0] * u2[1] - u1[1] * u2[0];
+  // v3 must complete a right-handed frame with v1, v2 so that det V = +1
+  double v3[3] = {v[0][1] * v[1][2] - v[0][2] * v[1][1], v[0][2] * v[1][0] - v[0][0] * v[1][2], v[0][0] * v[1][1] - v[0][1] * v[1][0]};
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) M[r * 3 + c] = u1[r] * v[0][c] + u2[r] * v[1][c] + u3[r] * v3[c];
+}
+
+template <class Apply>
+int pcg(int n, int nc, const Apply &A, const std::vector<double> &diag, const std::vector<double> &b,
+        std::vector<double> &x, double tol, int maxit) {
+  // all nc right-hand sides share the iteration (block of independent CGs)
+  std::vector<double> r = b, z(r.size()), p(r.size()), Ap(r.size());
+  x.assign(b.size(), 0.0);
+  std::vector<double> rz(nc, 0), b2(nc, 0);
+  for (int i = 0; i < n; i++)
+    for (int c = 0; c < nc; c++) {
+      z[i * nc + c] = r[i * nc + c] / diag[i];
+      rz[c] += r[i * nc + c] * z[i * nc + c];
+      b2[c] += b[i * nc + c] * b[i * nc + c];
+    }
+  p = z;
+  int it = 0;
+  for (; it < maxit; it++) {
+    A(p, Ap);
+    std::vector<double> pAp(nc, 0), r2(nc, 0), rz_new(nc, 0);
+    for (int i = 0; i < n; i++)
+      for (int c = 0; c < nc; c++) pAp[c] += p[i * nc + c] * Ap[i * nc + c];
+    for (int i = 0; i < n; i++)
+      for (int c = 0; c < nc; c++) {
+        const double al = pAp[c] > 0 ? rz[c] / pAp[c] : 0.0;
+        x[i * nc + c] += al * p[i * nc + c];
+        r[i * nc + c] -= al * Ap[i * nc + c];
+        r2[c] += r[i * nc + c] * r[i * nc + c];
+      }
+    bool done = true;
+    for (int c = 0; c < nc; c++) done = done && (r2[c] <= tol * tol * std::max(b2[c], 1e-300));
+    if (done) break;
+    for (int i = 0; i < n; i++)
+      for (int c = 0; c < nc; c++) {
+        z[i * nc + c] = r[i * nc + c] / diag[i];
+        rz_new[c] += r[i * nc + c] * z[i * nc + c];
+      }
+    for (int i = 0; i < n; i++)
+      for (int c = 0; c < nc; c++) {
+        const double be = rz[c] > 0 ? rz_new[c] / rz[c] : 0.0;
+        p[i * nc + c] = z[i * nc + c] + be * p[i * nc + c];
+      }
+    rz = rz_new;
+  }
+  return it;
+}
+
+}  // namespace
+
+int chordal_initialization(const Graph &g, double *X, int ld) {
+  const int d = g.d, N = g.num_poses;
+  const auto &E = g.all;
+  if (ld < (d + 1) * N) return -1;
+  // ---- rotations: unknown Y (d N x d row-major), rows of pose 0 fixed to I
+  const int nr = d * N;
+  auto applyR = [&](const std::vector<double> &v, std::vector<double> &out) {
+    std::fill(out.begin(), out.end(), 0.0);
+    for (const auto &m : E) {
+      const int i = m.ipose, j = m.jpose;
+      double W[9];
+      for (int r = 0; r < d; r++)
+        for (int c = 0; c < d; c++) {
+          double a = -v[(j * d + r) * d + c];
+          for (int k = 0; k < d; k++) a += m.R[k * d + r] * v[(i * d + k) * d + c];
+          W[r * d + c] = m.kappa * a;
+        }
+      for (int r = 0; r < d; r++)
+        for (int c = 0; c < d; c++) {
+          out[(j * d + r) * d + c] -= W[r * d + c];
+          double a = 0;
+          for (int k = 0; k < d; k++) a += m.R[r * d + k] * W[k * d + c];
+          out[(i * d + r) * d + c] += a;
+        }
+    }
+  };
+  std::vector<double> Y0((size_t)nr * d, 0.0), LY0(Y0.size()), b(Y0.size()), Ysol, diag(nr, 0.0);
+  for (int k = 0; k < d; k++) Y0[k * d + k] = 1.0;
+  applyR(Y0, LY0);
+  for (size_t k = 0; k < b.size(); k++) b[k] = -LY0[k];
+  for (const auto &m : E)
+    for (int r = 0; r < d; r++) {
+      double rr = 0;
+      for (int k = 0; k < d; k++) rr += m.R[r * d + k] * m.R[r * d + k];
+      diag[m.ipose * d + r] += m.kappa * rr;
+      diag[m.jpose * d + r] += m.kappa;
+    }
+  // pin pose 0: identity rows in the operator
+  auto applyRp = [&](const std::vector<double> &v, std::vector<double> &out) {
+    std::vector<double> vv = v;
+    for (int k = 0; k < d * d; k++) vv[k] = 0.0;
+    applyR(vv, out);
+    for (int k = 0; k < d * d; k++) out[k] = v[k];
+  };
+  for (int k = 0; k < d * d; k++) b[k] = 0.0;
+  for (int r = 0; r < d; r++) diag[r] = 1.0;
+  int it1 = pcg(nr, d, applyRp, diag, b, Ysol, 1e-13, 50000);
+  for (int k = 0; k < d; k++)
+    for (int c = 0; c < d; c++) Ysol[k * d + c] = (k == c);
+  for (int i = 1; i < N; i++) {
+    // the reference projects R_i (= Y_i^T); projection commutes with transposition
+    project_block(d, &Ysol[(size_t)i * d * d]);
+  }
+  // ---- translations
+  std::vector<double> bt((size_t)N * d, 0.0), xsol, dg(N, 0.0);
+  for (const auto &m : E) {
+    const int i = m.ipose, j = m.jpose;
+    for (int c = 0; c < d; c++) {
+      double a = 0;
+      for (int k = 0; k < d; k++) a += m.t[k] * Ysol[((size_t)i * d + k) * d + c];
+      bt[i * d + c] -= m.tau * a;
+      bt[j * d + c] += m.tau * a;
+    }
+    dg[i] += m.tau;
+    dg[j] += m.tau;
+  }
+  auto applyT = [&](const std::vector<double> &v, std::vector<double> &out) {
+    std::fill(out.begin(), out.end(), 0.0);
+    for (const auto &m : E) {
+      const int i = m.ipose, j = m.jpose;
+      if (i == 0 || j == 0) {
+        for (int c = 0; c < d; c++) {
+          if (i != 0) out[i * d + c] += m.tau * v[i * d + c];
+          if (j != 0) out[j * d + c] += m.tau * v[j * d + c];
+        }
+        continue;
+      }
+      for (int c = 0; c < d; c++) {
+        const double a = m.tau * (v[i * d + c] - v[j * d + c]);
+        out[i * d + c] += a;
+        out[j * d + c] -= a;
+      }
+    }
+    for (int c = 0; c < d; c++) out[c] = v[c];
+  };
+  for (int c = 0; c < d; c++) bt[c] = 0.0;
+  dg[0] = 1.0;
+  int it2 = pcg(N, d, applyT, dg, bt, xsol, 1e-13, 50000);
+  (void)it1; (void)it2;
+  for (int i = 0; i < N; i++)
+    for (int c = 0; c < d; c++) {
+      X[(size_t)c * ld + i] = i == 0 ? 0.0 : xsol[i * d + c];
+      for (int r = 0; r < d; r++) X[(size_t)c * ld + N + i * d + r] = Ysol[((size_t)i * d + r) * d + c];
+    }
+  return 0;
+}
+
+}  // namespace dpgo

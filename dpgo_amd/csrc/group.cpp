@@ -1,0 +1,940 @@
+#include "group.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <set>
+
+namespace dpgo {
+
+#define HIP_CHECK(x)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (x);                                                                          \
+    if (e_ != hipSuccess) {                                                                       \
+      fprintf(stderr, "[dpgo_amd] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      abort();                                                                                    \
+    }                                                                                             \
+  } while (0)
+
+template <class T>
+void DevBuf<T>::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  n = 0;
+}
+template <class T>
+void DevBuf<T>::alloc(size_t count, bool zero) {
+  release();
+  n = count;
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  HIP_CHECK(hipMalloc((void **)&p, bytes));
+  if (zero) HIP_CHECK(hipMemset(p, 0, bytes));
+}
+template <class T>
+void DevBuf<T>::upload(const std::vector<T> &h) {
+  alloc(h.size(), h.empty());
+  if (!h.empty()) HIP_CHECK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+}
+template <class T>
+void DevBuf<T>::download(std::vector<T> &h) const {
+  h.resize(n);
+  if (n) HIP_CHECK(hipMemcpy(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost));
+}
+template struct DevBuf<int>;
+template struct DevBuf<double>;
+template struct DevBuf<int64_t>;
+template struct DevBuf<int4>;
+template struct DevBuf<Seg>;
+
+void SpdSolverDev::upload(int dcols) {
+  w.upload(F.w); u.upload(F.u); piv_ptr.upload(F.piv_ptr); piv_idx.upload(F.piv_idx);
+  upd_ptr.upload(F.upd_ptr); upd_idx.upload(F.upd_idx); pos_off.upload(F.pos_off); ubuf_off.upload(F.ubuf_off);
+  asm_ptr.upload(F.asm_ptr); asm_src.upload(F.asm_src); w_off.upload(F.w_off); W.upload(F.W); WT.upload(F.WT);
+  ubuf.alloc((size_t)std::max(F.total_upd, 1) * dcols);
+  ytmp.alloc((size_t)std::max(F.n, 1) * dcols);
+  std::vector<int4> fi, bi;
+  fwd_level_ptr.assign(1, 0);
+  for (const auto &lvl : F.by_height) {
+    for (int f : lvl) {
+      const int m = F.w[f] + F.u[f];
+      for (int r = 0; r < m; r += 64) fi.push_back(make_int4(f, r, std::min(64, m - r), 0));
+    }
+    fwd_level_ptr.push_back((int)fi.size());
+  }
+  bwd_level_ptr.assign(1, 0);
+  for (const auto &lvl : F.by_depth) {
+    for (int f : lvl)
+      for (int c = 0; c < F.w[f]; c += 64) bi.push_back(make_int4(f, c, std::min(64, F.w[f] - c), 0));
+    bwd_level_ptr.push_back((int)bi.size());
+  }
+  fwd_items.upload(fi);
+  bwd_items.upload(bi);
+  dev.nfronts = F.nfronts;
+  dev.w = w.p; dev.u = u.p; dev.piv_ptr = piv_ptr.p; dev.piv_idx = piv_idx.p; dev.upd_ptr = upd_ptr.p;
+  dev.upd_idx = upd_idx.p; dev.pos_off = pos_off.p; dev.ubuf_off = ubuf_off.p; dev.asm_ptr = asm_ptr.p;
+  dev.asm_src = asm_src.p; dev.w_off = w_off.p; dev.W = W.p; dev.WT = WT.p; dev.fwd_items = fwd_items.p;
+  dev.bwd_items = bwd_items.p; dev.ubuf = ubuf.p;
+}
+
+// lambda_max of a symmetric matrix by Lanczos with full reorthogonalisation (stands in for the
+// Spectra call of DPGOProblem.cpp:106-118, tolerance 1e-4).
+static double lanczos_lambda_max(const CsrMatrix &A) {
+  const int n = A.n, kmax = std::min(n, 60);
+  if (n == 0) return 0.0;
+  std::vector<std::vector<double>> Q;
+  std::vector<double> alpha, beta, q(n), w(n);
+  for (int i = 0; i < n; i++) q[i] = 1.0 + 0.37 * std::sin(1.7 * i + 0.3);
+  double nrm = 0;
+  for (double v : q) nrm += v * v;
+  nrm = std::sqrt(nrm);
+  for (double &v : q) v /= nrm;
+  double lam_prev = 0, lam = 0;
+  for (int k = 0; k < kmax; k++) {
+    Q.push_back(q);
+    for (int i = 0; i < n; i++) {
+      double s = 0;
+      for (int e = A.ptr[i]; e < A.ptr[i + 1]; e++) s += A.val[e] * q[A.col[e]];
+      w[i] = s;
+    }
+    double a = 0;
+    for (int i = 0; i < n; i++) a += w[i] * q[i];
+    alpha.push_back(a);
+    for (int pass = 0; pass < 2; pass++)
+      for (const auto &qq : Q) {
+        double c = 0;
+        for (int i = 0; i < n; i++) c += w[i] * qq[i];
+        for (int i = 0; i < n; i++) w[i] -= c * qq[i];
+      }
+    double b = 0;
+    for (double v : w) b += v * v;
+    b = std::sqrt(b);
+    // largest eigenvalue of the tridiagonal (alpha, beta) by bisection on the Sturm sequence
+    const int m = (int)alpha.size();
+    double lo = -1e300, hi = -1e300;
+    for (int i = 0; i < m; i++) {
+      double r = (i > 0 ? std::fabs(beta[i - 1]) : 0) + (i < m - 1 ? std::fabs(beta[i]) : 0);
+      hi = std::max(hi, alpha[i] + r);
+      lo = std::max(lo, alpha[i] - r);
+    }
+    lo = std::min(lo, hi - 1.0);
+    for (int it = 0; it < 200; it++) {
+      const double mid = 0.5 * (lo + hi);
+      int neg = 0;   // number of eigenvalues < mid
+      double dd = 1.0;
+      for (int i = 0; i < m; i++) {
+        dd = alpha[i] - mid - (i > 0 ? beta[i - 1] * beta[i - 1] / dd : 0.0);
+        if (dd == 0.0) dd = 1e-300;
+        if (dd < 0) neg++;
+      }
+      if (neg == m) hi = mid; else lo = mid;
+      if (hi - lo <= 1e-14 * std::fabs(hi)) break;
+    }
+    lam = 0.5 * (lo + hi);
+    if (k > 3 && std::fabs(lam - lam_prev) <= 1e-6 * std::fabs(lam)) break;
+    lam_prev = lam;
+    if (b < 1e-12 * std::fabs(lam)) break;
+    beta.push_back(b);
+    for (int i = 0; i < n; i++) q[i] = w[i] / b;
+  }
+  return lam;
+}
+
+Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &opt, int device)
+    : d_(g.d), device_(device), opt_(opt), nodes_(node_ids) {
+  RS_ = (d_ + 1) * d_;
+  B_ = d_ + 1;
+  num_poses_global_ = g.num_poses;
+  num_nodes_total_ = g.num_nodes;
+  if (d_ != 2 && d_ != 3) {
+    fprintf(stderr, "[dpgo_amd] ERROR: d must be 2 or 3.\n");
+    return;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    fprintf(stderr, "[dpgo_amd] ERROR: no HIP device available; the DPGO hot path has no CPU fallback.\n");
+    return;
+  }
+  HIP_CHECK(hipSetDevice(device));
+  HIP_CHECK(hipStreamCreate(&st_));
+  const int L = (int)nodes_.size();
+  const bool trivial = (opt.loss == 0);
+  info_.resize(L);
+  ops_.resize(L);
+  res_.assign(L, NodeResults());
+  lambda_max_.assign(L, 0.0);
+  g_index_.resize(L);
+  own_off_.assign(L + 1, 0);
+  nbr_off_.assign(L + 1, 0);
+  for (int a = 0; a < L; a++) {
+    local_of_node_[nodes_[a]] = a;
+    if (generate_data_info(nodes_[a], d_, g.measurements[nodes_[a]], info_[a]) != 0) return;
+    if (assemble_node(info_[a], opt.regularizer, trivial, ops_[a]) != 0) return;
+    g_index_[a] = g.g_index[nodes_[a]];
+    own_off_[a + 1] = own_off_[a] + info_[a].n[0];
+    nbr_off_[a + 1] = nbr_off_[a] + info_[a].n[1];
+  }
+  P0_ = own_off_[L];
+  P1_ = nbr_off_[L];
+  auto uni = [&](int a, int p) { return p < info_[a].n[0] ? own_off_[a] + p : P0_ + nbr_off_[a] + (p - info_[a].n[0]); };
+
+  // ---- segments
+  {
+    std::vector<Seg> segs;
+    std::vector<int> optr(L + 1, 0), nptr(L + 1, 0);
+    for (int a = 0; a < L; a++) {
+      for (int r = own_off_[a]; r < own_off_[a + 1]; r += SEG_ROWS)
+        segs.push_back({r, std::min(r + SEG_ROWS, own_off_[a + 1]), a, 0});
+      optr[a + 1] = (int)segs.size();
+    }
+    const int nown = (int)segs.size();
+    for (int a = 0; a < L; a++) {
+      nptr[a] = (int)segs.size();
+      for (int r = nbr_off_[a]; r < nbr_off_[a + 1]; r += SEG_ROWS)
+        segs.push_back({P0_ + r, P0_ + std::min(r + SEG_ROWS, nbr_off_[a + 1]), a, 0});
+    }
+    nptr[L] = (int)segs.size();
+    // nbr_ptr is used as [nptr[a], nptr[a+1]) : make it monotone per node
+    segs_.upload(segs);
+    own_seg_ptr_.upload(optr);
+    nbr_seg_ptr_.upload(nptr);
+    T_.segs = segs_.p;
+    T_.nseg_own = nown;
+    T_.nseg_all = (int)segs.size();
+    T_.own_ptr = own_seg_ptr_.p;
+    T_.nbr_ptr = nbr_seg_ptr_.p;
+  }
+  mask_.alloc(L);
+  gamma_.alloc(L);
+  HIP_CHECK(hipHostMalloc((void **)&h_mask_, sizeof(int) * std::max(L, 1)));
+  HIP_CHECK(hipHostMalloc((void **)&h_scal_, sizeof(double) * std::max(L, 1) * MAX_SLOTS));
+  HIP_CHECK(hipHostMalloc((void **)&h_gamma_, sizeof(double) * std::max(L, 1)));
+  partials_.alloc((size_t)MAX_SLOTS * std::max(T_.nseg_all, 1));
+  node_scal_.alloc((size_t)L * MAX_SLOTS);
+
+  // ---- operators
+  {
+    std::vector<const BsrMatrix *> v(L);
+    for (int a = 0; a < L; a++) v[a] = &ops_[a].G;
+    upload_bsr(v, false, G_);
+    if (trivial) {
+      for (int a = 0; a < L; a++) v[a] = &ops_[a].S;
+      upload_bsr(v, false, S_);
+      for (int a = 0; a < L; a++) v[a] = &ops_[a].P;
+      upload_bsr(v, true, P_);
+      for (int a = 0; a < L; a++) v[a] = &ops_[a].P0;
+      upload_bsr(v, true, P0m_);
+      for (int a = 0; a < L; a++) v[a] = &ops_[a].Q;
+      upload_bsr(v, true, Q_);
+    }
+    std::vector<double> Dd((size_t)P0_ * B_ * B_), Ti(P0_), Nn((size_t)P0_ * d_), Vv((size_t)P0_ * d_ * d_);
+    std::vector<double> Qd((size_t)(P0_ + P1_) * B_ * B_, 0.0);
+    for (int a = 0; a < L; a++) {
+      const int n0 = info_[a].n[0];
+      std::copy(ops_[a].D.begin(), ops_[a].D.end(), Dd.begin() + (size_t)own_off_[a] * B_ * B_);
+      std::copy(ops_[a].Tinv.begin(), ops_[a].Tinv.end(), Ti.begin() + own_off_[a]);
+      std::copy(ops_[a].N.begin(), ops_[a].N.end(), Nn.begin() + (size_t)own_off_[a] * d_);
+      std::copy(ops_[a].V.begin(), ops_[a].V.end(), Vv.begin() + (size_t)own_off_[a] * d_ * d_);
+      if (!trivial) {   // robust Q is block diagonal
+        const BsrMatrix &Q = ops_[a].Q;
+        for (int r = 0; r < Q.nrows; r++)
+          for (int k = Q.ptr[r]; k < Q.ptr[r + 1]; k++)
+            if (Q.col[k] == r)
+              std::copy(&Q.val[(size_t)k * B_ * B_], &Q.val[(size_t)(k + 1) * B_ * B_],
+                        Qd.begin() + (size_t)uni(a, r) * B_ * B_);
+      }
+      (void)n0;
+    }
+    Dd_.upload(Dd); Tinv_.upload(Ti); N_.upload(Nn); V_.upload(Vv); Qd_.upload(Qd);
+  }
+  // ---- inter-node edges (residual form) and their incidence lists
+  {
+    std::vector<int> tail, head;
+    std::vector<double> R, t, kap, tau;
+    std::vector<std::vector<int>> inc(P0_ + P1_);
+    for (int a = 0; a < L; a++)
+      for (const auto &m : info_[a].inter) {
+        const int e = (int)tail.size();
+        const int p = uni(a, info_[a].tail(m)), q = uni(a, info_[a].head(m));
+        tail.push_back(p); head.push_back(q);
+        for (int k = 0; k < d_ * d_; k++) R.push_back(m.R[k]);
+        for (int k = 0; k < d_; k++) t.push_back(m.t[k]);
+        kap.push_back(m.kappa); tau.push_back(m.tau);
+        inc[p].push_back(2 * e); inc[q].push_back(2 * e + 1);
+      }
+    std::vector<int> iptr(P0_ + P1_ + 1, 0), iv;
+    for (int r = 0; r < P0_ + P1_; r++) {
+      iptr[r + 1] = iptr[r] + (int)inc[r].size();
+      iv.insert(iv.end(), inc[r].begin(), inc[r].end());
+    }
+    e_tail_.upload(tail); e_head_.upload(head); e_R_.upload(R); e_t_.upload(t); e_kappa_.upload(kap);
+    e_tau_.upload(tau); e_inc_ptr_.upload(iptr); e_inc_.upload(iv);
+    E_.m = (int)tail.size(); E_.tail = e_tail_.p; E_.head = e_head_.p; E_.R = e_R_.p; E_.t = e_t_.p;
+    E_.kappa = e_kappa_.p; E_.tau = e_tau_.p; E_.inc_ptr = e_inc_ptr_.p; E_.inc = e_inc_.p;
+  }
+  // ---- SPD solvers: one block-diagonal system over all local nodes
+  {
+    CsrMatrix Att, Arr;
+    Att.ptr.push_back(0);
+    Arr.ptr.push_back(0);
+    for (int a = 0; a < L; a++) {
+      const CsrMatrix &t = ops_[a].Gtt;
+      for (int i = 0; i < t.n; i++) {
+        for (int e = t.ptr[i]; e < t.ptr[i + 1]; e++) { Att.col.push_back(own_off_[a] + t.col[e]); Att.val.push_back(t.val[e]); }
+        Att.ptr.push_back((int)Att.col.size());
+      }
+      if (opt.preconditioner == 1 && opt.max_iterations > 0 && opt.max_iterations_accepted > 0) {
+        const CsrMatrix &r = ops_[a].GRR;
+        lambda_max_[a] = lanczos_lambda_max(r);
+        const double shift = lambda_max_[a] / opt.reg_Cholesky_precon_max_condition_number;  // DPGOProblem.cpp:119-123
+        for (int i = 0; i < r.n; i++) {
+          for (int e = r.ptr[i]; e < r.ptr[i + 1]; e++) {
+            Arr.col.push_back(own_off_[a] * d_ + r.col[e]);
+            Arr.val.push_back(r.val[e] + (r.col[e] == i ? shift : 0.0));
+          }
+          Arr.ptr.push_back((int)Arr.col.size());
+        }
+      }
+    }
+    Att.n = (int)Att.ptr.size() - 1;
+    Arr.n = (int)Arr.ptr.size() - 1;
+    if (spd_factor(Att, Ltt_.F, 32) != 0) return;
+    Ltt_.dof = 1;
+    Ltt_.upload(d_);
+    if (Arr.n > 0) {
+      if (spd_factor(Arr, Lrr_.F, 16) != 0) return;
+      Lrr_.dof = d_;
+      Lrr_.upload(d_);
+    }
+  }
+  // ---- halo lists
+  {
+    std::vector<int> gdst, gsrc;
+    std::set<std::pair<int, int>> sent;
+    for (int a = 0; a < L; a++) {
+      for (int k = 0; k < info_[a].n[1]; k++) {
+        const auto key = info_[a].nbr_key[k];
+        auto it = local_of_node_.find(key.first);
+        if (it != local_of_node_.end()) {
+          gdst.push_back(P0_ + nbr_off_[a] + k);
+          gsrc.push_back(own_off_[it->second] + info_[it->second].index.at(key));
+        }
+      }
+      for (const auto &s : info_[a].sent)
+        if (!local_of_node_.count(s.first))
+          for (int row : s.second) sent.insert({nodes_[a], row});
+    }
+    gather_dst_.upload(gdst);
+    gather_src_.upload(gsrc);
+    for (const auto &s : sent) {
+      const int a = local_of_node_.at(s.first);
+      sent_rows_.push_back(own_off_[a] + s.second);
+      sent_keys_.push_back({s.first, info_[a].own_pose[s.second]});
+    }
+    sent_rows_dev_.upload(sent_rows_);
+  }
+  // ---- vectors
+  const size_t nall = (size_t)(P0_ + P1_) * RS_, nown = (size_t)P0_ * RS_;
+  for (DevBuf<double> *b : {&Xk_, &Zc_, &Zp_, &Y_, &DfE_, &Tall_}) b->alloc(nall);
+  for (DevBuf<double> *b : {&Xak_, &Xakh_, &gc_, &gp_, &Dfc_, &Dfp_, &gx_, &Dfx_, &T1_}) b->alloc(nown);
+  for (auto &b : tmp_) b.alloc(nown);
+  HIP_CHECK(hipDeviceSynchronize());
+  ok_ = true;
+}
+
+Group::~Group() {
+  if (h_mask_) (void)hipHostFree(h_mask_);
+  if (h_scal_) (void)hipHostFree(h_scal_);
+  if (h_gamma_) (void)hipHostFree(h_gamma_);
+  if (st_) (void)hipStreamDestroy(st_);
+}
+
+void Group::upload_bsr(const std::vector<const BsrMatrix *> &per_node, bool rows_all, BsrBufs &out) {
+  const int L = (int)per_node.size();
+  const int nrows = rows_all ? P0_ + P1_ : P0_;
+  auto uni = [&](int a, int p) { return p < info_[a].n[0] ? own_off_[a] + p : P0_ + nbr_off_[a] + (p - info_[a].n[0]); };
+  std::vector<int> cnt(nrows, 0);
+  for (int a = 0; a < L; a++)
+    for (int r = 0; r < per_node[a]->nrows; r++) cnt[uni(a, r)] = per_node[a]->ptr[r + 1] - per_node[a]->ptr[r];
+  std::vector<int> ptr(nrows + 1, 0);
+  for (int r = 0; r < nrows; r++) ptr[r + 1] = ptr[r] + cnt[r];
+  std::vector<int> col(ptr[nrows]);
+  std::vector<double> val((size_t)ptr[nrows] * B_ * B_);
+  for (int a = 0; a < L; a++) {
+    const BsrMatrix &M = *per_node[a];
+    for (int r = 0; r < M.nrows; r++) {
+      int dst = ptr[uni(a, r)];
+      for (int k = M.ptr[r]; k < M.ptr[r + 1]; k++, dst++) {
+        col[dst] = uni(a, M.col[k]);
+        std::copy(&M.val[(size_t)k * B_ * B_], &M.val[(size_t)(k + 1) * B_ * B_], &val[(size_t)dst * B_ * B_]);
+      }
+    }
+  }
+  out.ptr.upload(ptr);
+  out.col.upload(col);
+  out.val.upload(val);
+  out.dev.nrows = nrows;
+  out.dev.ptr = out.ptr.p;
+  out.dev.col = out.col.p;
+  out.dev.val = out.val.p;
+}
+
+void Group::sync() const { HIP_CHECK(hipStreamSynchronize(st_)); }
+
+void Group::set_mask(const std::vector<int> &locals) {
+  // the previous mask upload may still be in flight: the stream orders uploads and kernels, and
+  // h_mask_ is only rewritten after a synchronising fetch() or at the start of an API call
+  if (locals == last_mask_) return;
+  last_mask_ = locals;
+  HIP_CHECK(hipStreamSynchronize(st_));
+  const int L = num_local();
+  for (int a = 0; a < L; a++) h_mask_[a] = 0;
+  for (int a : locals) h_mask_[a] = 1;
+  HIP_CHECK(hipMemcpyAsync(mask_.p, h_mask_, sizeof(int) * L, hipMemcpyHostToDevice, st_));
+}
+
+void Group::fetch(int nslots, bool all_rows) {
+  launch_reduce(st_, T_, num_local(), all_rows, nslots, partials_.p, node_scal_.p);
+  HIP_CHECK(hipMemcpyAsync(h_scal_, node_scal_.p, sizeof(double) * num_local() * MAX_SLOTS, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+}
+
+void Group::copy_rows(double *dst, const double *src, bool all_rows, int part) {
+  launch_axpby(d_, st_, T_, all_rows, mask_.p, 1.0, src, 0.0, nullptr, dst, part);
+}
+
+static void spd_run(int d, hipStream_t st, SpdSolverDev &S, double *vec, double scale) {
+  const int nf = (int)S.fwd_level_ptr.size() - 1;
+  for (int l = 0; l < nf; l++)
+    launch_spd_level(d, S.dof, st, S.dev, true, S.fwd_level_ptr[l], S.fwd_level_ptr[l + 1] - S.fwd_level_ptr[l], vec,
+                     S.ytmp.p, scale);
+  const int nb = (int)S.bwd_level_ptr.size() - 1;
+  for (int l = 0; l < nb; l++)
+    launch_spd_level(d, S.dof, st, S.dev, false, S.bwd_level_ptr[l], S.bwd_level_ptr[l + 1] - S.bwd_level_ptr[l], vec,
+                     S.ytmp.p, scale);
+}
+
+void Group::solve_tt(double *vec, double scale) { spd_run(d_, st_, Ltt_, vec, scale); }
+void Group::solve_rr(double *vec, double scale) { spd_run(d_, st_, Lrr_, vec, scale); }
+
+// X.t = -G_tt^-1 (g_t + G_tR X.R)    (DPGOProblem.h:275-294)
+void Group::recover_translations(double *X, const double *g) {
+  launch_bsr(d_, st_, T_, false, mask_.p, G_.dev, X, true, g, T1_.p, nullptr, 0.0, nullptr, nullptr, 0);
+  solve_tt(T1_.p, -1.0);
+  copy_rows(X, T1_.p, false, 1);
+}
+
+// partial[slot] = tr(X^T (g + 1/2 G X))     (DPGOProblem.cpp:180-205; + f on the host)
+void Group::eval_G(const double *X, const double *g, int slot) {
+  launch_bsr(d_, st_, T_, false, mask_.p, G_.dev, X, false, nullptr, nullptr, X, 0.5, g, partials_.p, slot);
+}
+
+// ---------------------------------------------------------------------------
+// layout conversion (reference column-major <-> pose records)
+// ---------------------------------------------------------------------------
+static void to_records(int d, int n, const double *X, int ld, int row_t0, int row_r0, double *rec) {
+  // X rows [row_t0, row_t0+n) translations, [row_r0 + d k, ...) rotation blocks
+  const int RS = (d + 1) * d;
+  for (int k = 0; k < n; k++)
+    for (int c = 0; c < d; c++) {
+      rec[(size_t)k * RS + c] = X[(size_t)c * ld + row_t0 + k];
+      for (int r = 0; r < d; r++) rec[(size_t)k * RS + d + r * d + c] = X[(size_t)c * ld + row_r0 + k * d + r];
+    }
+}
+static void from_records(int d, int n, const double *rec, double *X, int ld, int row_t0, int row_r0) {
+  const int RS = (d + 1) * d;
+  for (int k = 0; k < n; k++)
+    for (int c = 0; c < d; c++) {
+      X[(size_t)c * ld + row_t0 + k] = rec[(size_t)k * RS + c];
+      for (int r = 0; r < d; r++) X[(size_t)c * ld + row_r0 + k * d + r] = rec[(size_t)k * RS + d + r * d + c];
+    }
+}
+
+int Group::initialize(int a, const double *X, int ld) {
+  if (a < 0 || a >= num_local()) return -1;
+  const int n0 = info_[a].n[0], n1 = info_[a].n[1];
+  if (ld < (d_ + 1) * (n0 + n1)) {
+    fprintf(stderr, "[dpgo_amd] ERROR: initialize: inconsistent size of X for node %d.\n", nodes_[a]);
+    return -1;
+  }
+  sync();
+  std::vector<double> own((size_t)n0 * RS_), nbr((size_t)std::max(n1, 1) * RS_);
+  to_records(d_, n0, X, ld, 0, n0, own.data());
+  to_records(d_, n1, X, ld, (d_ + 1) * n0, (d_ + 1) * n0 + n1, nbr.data());
+  for (double *dst : {Xk_.p, Zc_.p, Zp_.p}) {
+    HIP_CHECK(hipMemcpy(dst + (size_t)own_off_[a] * RS_, own.data(), sizeof(double) * n0 * RS_, hipMemcpyHostToDevice));
+    if (n1) HIP_CHECK(hipMemcpy(dst + (size_t)(P0_ + nbr_off_[a]) * RS_, nbr.data(), sizeof(double) * n1 * RS_, hipMemcpyHostToDevice));
+  }
+  HIP_CHECK(hipMemcpy(Xak_.p + (size_t)own_off_[a] * RS_, own.data(), sizeof(double) * n0 * RS_, hipMemcpyHostToDevice));
+  for (double *dst : {gc_.p, gp_.p, Dfc_.p, Dfp_.p})
+    HIP_CHECK(hipMemset(dst + (size_t)own_off_[a] * RS_, 0, sizeof(double) * n0 * RS_));
+  res_[a] = NodeResults();
+  res_[a].updated = 0;
+  return 0;
+}
+
+int Group::initialize_global(const double *X, int ld) {
+  const int N = num_poses_global_;
+  if (ld < (d_ + 1) * N) return -1;
+  for (int a = 0; a < num_local(); a++) {
+    const int n0 = info_[a].n[0], n1 = info_[a].n[1], rows = (d_ + 1) * (n0 + n1);
+    std::vector<double> Z((size_t)rows * d_, 0.0);
+    auto put = [&](int trow, int rrow, int gid) {
+      for (int c = 0; c < d_; c++) {
+        Z[(size_t)c * rows + trow] = X[(size_t)c * ld + gid];
+        for (int r = 0; r < d_; r++) Z[(size_t)c * rows + rrow + r] = X[(size_t)c * ld + N + gid * d_ + r];
+      }
+    };
+    for (int k = 0; k < n0; k++) put(k, n0 + k * d_, g_index_[a].at(info_[a].own_pose[k]));
+    {
+      // neighbours: global id from the partition rule (DPGO_utils.cpp:147-158)
+      const int q = N / num_nodes_total_, inc_n = N - num_nodes_total_ * q;
+      for (int k = 0; k < n1; k++) {
+        const int node = info_[a].nbr_key[k].first, pose = info_[a].nbr_key[k].second;
+        const int start = node < inc_n ? node * (q + 1) : inc_n * (q + 1) + (node - inc_n) * q;
+        put((d_ + 1) * n0 + k, (d_ + 1) * n0 + n1 + k * d_, start + pose);
+      }
+    }
+    if (initialize(a, Z.data(), rows) != 0) return -1;
+  }
+  return 0;
+}
+
+int Group::get_Xk(int a, double *X, int ld) const {
+  if (a < 0 || a >= num_local()) return -1;
+  sync();
+  const int n0 = info_[a].n[0], n1 = info_[a].n[1];
+  std::vector<double> own((size_t)n0 * RS_), nbr((size_t)std::max(n1, 1) * RS_);
+  HIP_CHECK(hipMemcpy(own.data(), Xk_.p + (size_t)own_off_[a] * RS_, sizeof(double) * n0 * RS_, hipMemcpyDeviceToHost));
+  if (n1) HIP_CHECK(hipMemcpy(nbr.data(), Xk_.p + (size_t)(P0_ + nbr_off_[a]) * RS_, sizeof(double) * n1 * RS_, hipMemcpyDeviceToHost));
+  from_records(d_, n0, own.data(), X, ld, 0, n0);
+  from_records(d_, n1, nbr.data(), X, ld, (d_ + 1) * n0, (d_ + 1) * n0 + n1);
+  return 0;
+}
+
+int Group::get_X_own(int a, double *X, int ld) const {
+  if (a < 0 || a >= num_local()) return -1;
+  sync();
+  const int n0 = info_[a].n[0];
+  std::vector<double> own((size_t)n0 * RS_);
+  HIP_CHECK(hipMemcpy(own.data(), Xak_.p + (size_t)own_off_[a] * RS_, sizeof(double) * n0 * RS_, hipMemcpyDeviceToHost));
+  from_records(d_, n0, own.data(), X, ld, 0, n0);
+  return 0;
+}
+
+int Group::scatter_global(double *X, int ld) const {
+  sync();
+  const int N = num_poses_global_;
+  std::vector<double> own((size_t)P0_ * RS_);
+  HIP_CHECK(hipMemcpy(own.data(), Xk_.p, sizeof(double) * P0_ * RS_, hipMemcpyDeviceToHost));
+  for (int a = 0; a < num_local(); a++) {
+    for (int k = 0; k < info_[a].n[0]; k++) {
+      const int gid = g_index_[a].at(info_[a].own_pose[k]);
+      const double *rec = &own[(size_t)(own_off_[a] + k) * RS_];
+      for (int c = 0; c < d_; c++) {
+        X[(size_t)c * ld + gid] = rec[c];
+        for (int r = 0; r < d_; r++) X[(size_t)c * ld + N + gid * d_ + r] = rec[d_ + r * d_ + c];
+      }
+    }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// halo exchange
+// ---------------------------------------------------------------------------
+int Group::communicate_local() {
+  // neighbour rows whose owner lives in this group: one indexed device copy (DPGOHash.h:64-82)
+  launch_copy_indexed(d_, st_, (int)gather_dst_.n, gather_dst_.p, gather_src_.p, Xk_.p, Xk_.p);
+  return 0;
+}
+
+int Group::pack_sent(double *dev_buf) {
+  launch_copy_indexed(d_, st_, (int)sent_rows_.size(), nullptr, sent_rows_dev_.p, Xk_.p, dev_buf);
+  return 0;
+}
+
+int Group::set_recv_layout(int nranks, int stride, const int *counts, const int *nodes, const int *poses) {
+  std::map<std::pair<int, int>, int> slot;
+  int off = 0;
+  for (int r = 0; r < nranks; r++) {
+    for (int k = 0; k < counts[r]; k++) slot[{nodes[off + k], poses[off + k]}] = r * stride + k;
+    off += counts[r];
+  }
+  std::vector<int> dst, src;
+  for (int a = 0; a < num_local(); a++)
+    for (int k = 0; k < info_[a].n[1]; k++) {
+      const auto key = info_[a].nbr_key[k];
+      if (local_of_node_.count(key.first)) continue;
+      auto it = slot.find(key);
+      if (it == slot.end()) {
+        fprintf(stderr, "[dpgo_amd] ERROR: No information for pose [%d, %d].\n", key.first, key.second);
+        return -1;
+      }
+      dst.push_back(P0_ + nbr_off_[a] + k);
+      src.push_back(it->second);
+    }
+  recv_dst_.upload(dst);
+  recv_src_.upload(src);
+  return 0;
+}
+
+int Group::unpack_recv(const double *dev_gathered) {
+  launch_copy_indexed(d_, st_, (int)recv_dst_.n, recv_dst_.p, recv_src_.p, dev_gathered, Xk_.p);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// DPGOHash::update  (DPGOHash.cpp:84-228)
+// ---------------------------------------------------------------------------
+void Group::host_update_logic(int a, double fobj, double f, double gradFnorm) {
+  NodeResults &r = res_[a];
+  const Options &o = opt_;
+  const int it = r.iters;
+  r.fobj_prev = r.fobj;
+  r.fobj = fobj;
+  r.f = f;
+  r.gradFnorm = gradFnorm;
+  if (it == 0) {
+    r.Fk[0] = r.Fk[1] = fobj;
+    r.Gk = fobj;
+  }
+  if (o.scheme == 1) {
+    if (it == 0) {
+      r.s0 = 1.0;
+      r.oscillations.assign(1, 1);
+    } else {
+      r.s0 = r.s1;
+    }
+    r.s1 = 0.5 + 0.5 * std::sqrt(4.0 * r.s0 * r.s0 + 1.0);
+    r.gamma = (r.s0 - 1) / r.s1;
+    if (fobj <= r.Fk[1]) r.soft_restart_hits[0] = r.soft_restart_hits[0] > 2 ? r.soft_restart_hits[0] - 2 : 0;
+    else r.soft_restart_hits[0]++;
+    if (it > 0) {
+      if (fobj <= r.fobj_prev) { r.soft_restart_hits[1] = 0; r.oscillations.push_back(1); }
+      else { r.soft_restart_hits[1]++; r.oscillations.push_back(0); }
+      r.num_oscillations += (r.oscillations[it] != r.oscillations[it - 1]);
+    }
+    if (it > o.oscillation_cnt_period) {
+      const int k = it - o.oscillation_cnt_period;
+      r.num_oscillations -= (r.oscillations[k] != r.oscillations[k - 1]);
+    }
+    r.Fk[0] = r.Fk[0] * (1 - o.eta[0]) + fobj * o.eta[0];
+    r.Fk[1] = std::max(fobj, r.Fk[1] * (1 - o.eta[1]) + fobj * o.eta[1]);
+  } else {
+    r.Fk[0] = r.Fk[1] = fobj;
+    r.gamma = 0;
+  }
+  r.updated = 1;
+}
+
+int Group::update(const std::vector<int> &locals_in) {
+  std::vector<int> locals;
+  for (int a : locals_in)
+    if (!res_[a].updated) locals.push_back(a);
+  if (locals.empty()) return 0;
+  const bool trivial = (opt_.loss == 0);
+  set_mask(locals);
+  // history: X[iter-1] <- X[iter], X[iter] <- Xk ; same for g and Dfobj (masked nodes only)
+  copy_rows(Zp_.p, Zc_.p, true);
+  copy_rows(Zc_.p, Xk_.p, true);
+  copy_rows(gp_.p, gc_.p, false);
+  copy_rows(Dfp_.p, Dfc_.p, false);
+  std::vector<int> first, later;
+  for (int a : locals) (res_[a].iters == 0 ? first : later).push_back(a);
+  if (trivial) {
+    // g = S Z  (evaluate_none_g_and_f0 / _f, DPGOProblem.cpp:269-287, 516-542)
+    launch_bsr(d_, st_, T_, false, mask_.p, S_.dev, Zc_.p, false, nullptr, gc_.p, nullptr, 0, nullptr, nullptr, 0);
+    if (!first.empty()) {
+      set_mask(first);
+      launch_bsr(d_, st_, T_, true, mask_.p, P0m_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 0);
+      // fobj = G(Xak | g, f0): slot 1; also Dfobj = g + G Xak
+      launch_bsr(d_, st_, T_, false, mask_.p, G_.dev, Xak_.p, false, gc_.p, Dfc_.p, Xak_.p, 0.5, gc_.p, partials_.p, 1);
+      launch_tangent_full(d_, st_, T_, mask_.p, Xak_.p, Dfc_.p, nullptr, partials_.p, 2);
+      fetch(3, true);
+      for (int a : first) {
+        const double f0 = scal(a, 0);
+        host_update_logic(a, f0 + scal(a, 1), f0, std::sqrt(scal(a, 2)));
+      }
+    }
+    if (!later.empty()) {
+      set_mask(later);
+      launch_axpby(d_, st_, T_, true, mask_.p, 1.0, Zc_.p, -1.0, Zp_.p, Tall_.p, 0);
+      launch_bsr(d_, st_, T_, true, mask_.p, Q_.dev, Tall_.p, false, nullptr, nullptr, Tall_.p, 0.5, nullptr, partials_.p, 0);
+      launch_bsr(d_, st_, T_, true, mask_.p, P_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 1);
+      launch_bsr(d_, st_, T_, false, mask_.p, G_.dev, Xak_.p, false, gc_.p, Dfc_.p, nullptr, 0, nullptr, nullptr, 0);
+      launch_tangent_full(d_, st_, T_, mask_.p, Xak_.p, Dfc_.p, nullptr, partials_.p, 2);
+      fetch(3, true);
+      for (int a : later) {
+        const double fobj = res_[a].Gk + scal(a, 0);
+        host_update_logic(a, fobj, fobj + scal(a, 1), std::sqrt(scal(a, 2)));
+      }
+    }
+  } else {
+    // evaluate_g_and_f0 / evaluate_g_and_f (DPGOProblem.cpp:222-267, 360-424)
+    for (int pass = 0; pass < 2; pass++) {
+      const std::vector<int> &set = pass == 0 ? first : later;
+      if (set.empty()) continue;
+      set_mask(set);
+      launch_inter(d_, st_, T_, mask_.p, E_, opt_.loss, opt_.loss_reg, 0, pass == 1, Zc_.p, Zp_.p, Qd_.p, Dd_.p, DfE_.p,
+                   gc_.p, partials_.p);
+      launch_bsr(d_, st_, T_, false, mask_.p, G_.dev, Zc_.p, false, gc_.p, Dfc_.p, Zc_.p, 0.5, gc_.p, partials_.p, 2);
+      if (pass == 0) launch_bdiag_dot(d_, st_, T_, mask_.p, Dd_.p, Zc_.p, 0.5, DfE_.p, -1.0, partials_.p, 3);
+      launch_tangent_full(d_, st_, T_, mask_.p, Xak_.p, Dfc_.p, nullptr, partials_.p, 4);
+      fetch(5, true);
+      for (int a : set) {
+        NodeResults &r = res_[a];
+        const double fobjE = 0.5 * scal(a, 0);
+        double fobj, f;
+        if (pass == 0) {
+          f = 0.5 * fobjE + scal(a, 3);
+          fobj = f + scal(a, 2);
+        } else {
+          fobj = r.Gk - 0.5 * r.fobjE - 0.5 * scal(a, 1) + 0.5 * fobjE;
+          f = fobj - scal(a, 2);
+        }
+        r.fobjE = fobjE;
+        host_update_logic(a, fobj, f, std::sqrt(scal(a, 4)));
+      }
+    }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// DPGOHash::iterate  (DPGOHash.cpp:583-628)
+// ---------------------------------------------------------------------------
+int Group::iterate(const std::vector<int> &locals) {
+  for (int a : locals)
+    if (!res_[a].updated) {
+      fprintf(stderr, "[dpgo_amd] ERROR: The optimizer has not been updated (node %d).\n", nodes_[a]);
+      return -1;
+    }
+  if (locals.empty()) return 0;
+  const int rc = opt_.scheme == 1 ? amm(locals) : mm(locals);
+  if (rc != 0) return rc;
+  set_mask(locals);
+  copy_rows(Xk_.p, Xak_.p, false);   // Xk.top = Xak   (:614)
+  for (int a : locals) {
+    res_[a].iters++;
+    res_[a].updated = 0;
+  }
+  return 0;
+}
+
+// DPGOHash::mm_pgo  (DPGOHash.cpp:446-581)
+int Group::mm(const std::vector<int> &locals) {
+  const Options &o = opt_;
+  set_mask(locals);
+  launch_proximal(d_, st_, T_, mask_.p, Zc_.p, Dfc_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, nullptr, nullptr, 0);
+  recover_translations(Xakh_.p, gc_.p);
+  copy_rows(Xak_.p, Xakh_.p, false);
+  std::vector<int> plain;
+  for (int a : locals) {
+    NodeResults &r = res_[a];
+    r.refined = ((r.gradFnorm * r.gradFnorm / r.fobj) > o.accepted_delta) && o.max_iterations > 0 &&
+                o.max_iterations_accepted > 0;
+    if (!r.refined) plain.push_back(a);
+  }
+  for (int a : locals)
+    if (res_[a].refined) run_tnt(a, Xak_.p, gc_.p);   // sets Gk
+  if (!plain.empty()) {
+    set_mask(plain);
+    eval_G(Xak_.p, gc_.p, 0);
+    fetch(1, false);
+    for (int a : plain) res_[a].Gk = scal(a, 0) + res_[a].f;
+  }
+  return 0;
+}
+
+// DPGOHash::amm_pgo  (DPGOHash.cpp:230-444)
+int Group::amm(const std::vector<int> &locals) {
+  const Options &o = opt_;
+  const bool trivial = (o.loss == 0);
+  set_mask(locals);
+  for (int a = 0; a < num_local(); a++) h_gamma_[a] = res_[a].gamma;
+  HIP_CHECK(hipMemcpyAsync(gamma_.p, h_gamma_, sizeof(double) * num_local(), hipMemcpyHostToDevice, st_));
+  // Y = X[k] + gamma (X[k] - X[k-1]) on own AND neighbour rows (:255-256)
+  launch_extrapolate(d_, st_, T_, true, mask_.p, gamma_.p, Zc_.p, Zp_.p, Y_.p);
+  if (trivial) {
+    launch_extrapolate(d_, st_, T_, false, mask_.p, gamma_.p, gc_.p, gp_.p, gx_.p);      // :259-262
+    launch_extrapolate(d_, st_, T_, false, mask_.p, gamma_.p, Dfc_.p, Dfp_.p, Dfx_.p);
+  } else {
+    // evaluate_g_and_Df(Y) (:264 -> DPGOProblem.cpp:683-749)
+    launch_inter(d_, st_, T_, mask_.p, E_, o.loss, o.loss_reg, 1, false, Y_.p, nullptr, nullptr, Dd_.p, nullptr, gx_.p,
+                 partials_.p);
+    launch_bsr(d_, st_, T_, false, mask_.p, G_.dev, Y_.p, false, gx_.p, Dfx_.p, nullptr, 0, nullptr, nullptr, 0);
+  }
+  for (int a : locals) {
+    NodeResults &r = res_[a];
+    r.refined = (((r.gradFnorm * r.gradFnorm / r.fobj) > o.accepted_delta) || (r.num_oscillations >= o.max_oscillations)) &&
+                o.max_iterations > 0 && o.max_iterations_accepted > 0;   // :351-355
+  }
+  // Xakh = proximal(Y, Df); Gkh = G(Xakh | g[k], f); |Xakh - Xak|^2    (:363-367)
+  launch_proximal(d_, st_, T_, mask_.p, Y_.p, Dfx_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, Xak_.p, partials_.p, 0);
+  eval_G(Xakh_.p, gc_.p, 1);
+  // Xak.R = Xakh.R; Xak.t = recover(R, g)   (:369-372)
+  copy_rows(Xak_.p, Xakh_.p, false, 2);
+  recover_translations(Xak_.p, gx_.p);
+  std::vector<int> plain;
+  for (int a : locals)
+    if (!res_[a].refined) plain.push_back(a);
+  // Gk for nodes that are not refined; refined nodes run TNT first (:374-383)
+  eval_G(Xak_.p, gc_.p, 2);
+  fetch(3, false);
+  std::vector<double> Gkh(num_local(), 0.0), minG(num_local(), 0.0);
+  for (int a : locals) {
+    NodeResults &r = res_[a];
+    Gkh[a] = scal(a, 1) + r.f;
+    minG[a] = r.Fk[0] - o.psi * scal(a, 0);
+    if (!r.refined) r.Gk = scal(a, 2) + r.f;
+  }
+  for (int a : locals)
+    if (res_[a].refined) {
+      run_tnt(a, Xak_.p, gx_.p);
+      set_mask({a});
+      eval_G(Xak_.p, gc_.p, 0);
+      fetch(1, false);
+      res_[a].Gk = scal(a, 0) + res_[a].f;
+    }
+  // adaptive restart of the half step (:386-389)
+  std::vector<int> redo;
+  for (int a : locals)
+    if (Gkh[a] > minG[a]) redo.push_back(a);
+  if (!redo.empty()) {
+    set_mask(redo);
+    launch_proximal(d_, st_, T_, mask_.p, Zc_.p, Dfc_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, nullptr, nullptr, 0);
+    eval_G(Xakh_.p, gc_.p, 0);
+    fetch(1, false);
+    for (int a : redo) Gkh[a] = scal(a, 0) + res_[a].f;
+  }
+  // hard / soft restart (:391-432)
+  std::vector<int> restart, use_half, use_prox;
+  std::vector<char> hard(num_local(), 0);
+  for (int a : locals) {
+    NodeResults &r = res_[a];
+    const bool hr = r.Gk > r.Fk[0];
+    const bool sr = (r.Gk > r.Fk[1] && r.soft_restart_hits[0] >= o.max_soft_restart_hits[0]) ||
+                    (r.Gk > r.fobj && r.soft_restart_hits[1] > o.max_soft_restart_hits[1]);
+    if (hr || sr) {
+      restart.push_back(a);
+      hard[a] = hr;
+      (Gkh[a] <= r.fobj ? use_half : use_prox).push_back(a);
+    }
+  }
+  std::vector<char> g_is_current(num_local(), 0);
+  if (!restart.empty()) {
+    if (!use_half.empty()) {
+      set_mask(use_half);
+      copy_rows(Xak_.p, Xakh_.p, false);
+    }
+    if (!use_prox.empty()) {
+      set_mask(use_prox);
+      launch_proximal(d_, st_, T_, mask_.p, Zc_.p, Dfc_.p, Tinv_.p, N_.p, V_.p, Xak_.p, nullptr, nullptr, 0);
+    }
+    set_mask(restart);
+    recover_translations(Xak_.p, gc_.p);
+    std::vector<int> plain_r;
+    for (int a : restart) {
+      g_is_current[a] = 1;
+      res_[a].restarts++;
+      if (!res_[a].refined) plain_r.push_back(a);
+    }
+    for (int a : restart)
+      if (res_[a].refined) run_tnt(a, Xak_.p, gc_.p);   // Gk = Results.f (:420-421)
+    if (!plain_r.empty()) {
+      set_mask(plain_r);
+      eval_G(Xak_.p, gc_.p, 0);
+      fetch(1, false);
+      for (int a : plain_r) res_[a].Gk = scal(a, 0) + res_[a].f;
+    }
+    for (int a : restart) {
+      NodeResults &r = res_[a];
+      if (hard[a]) r.s1 = std::max(0.5 * r.s1, 1.0);
+      r.soft_restart_hits[0] /= 3;
+      r.soft_restart_hits[1] = 0;
+    }
+  }
+  // fall back to the proximal rotations when the refined step gains too little (:434-441)
+  std::vector<int> fb_x, fb_c;
+  for (int a : locals) {
+    NodeResults &r = res_[a];
+    if ((r.Fk[0] - r.Gk) < o.phi * (r.Fk[0] - Gkh[a])) (g_is_current[a] ? fb_c : fb_x).push_back(a);
+  }
+  for (int pass = 0; pass < 2; pass++) {
+    const std::vector<int> &set = pass == 0 ? fb_x : fb_c;
+    if (set.empty()) continue;
+    set_mask(set);
+    copy_rows(Xak_.p, Xakh_.p, false, 2);
+    recover_translations(Xak_.p, pass == 0 ? gx_.p : gc_.p);
+    eval_G(Xak_.p, gc_.p, 0);
+    fetch(1, false);
+    for (int a : set) res_[a].Gk = scal(a, 0) + res_[a].f;
+  }
+  for (int a : locals) res_[a].Gkh = Gkh[a];
+  return 0;
+}
+
+}  // namespace dpgo
+
+namespace dpgo {
+
+// Single operators on reference-layout inputs, for the parity tests.
+int Group::debug_apply(int a, const char *op_c, const double *in, int ld_in, double *out, int ld_out) {
+  if (a < 0 || a >= num_local()) return -1;
+  const std::string op(op_c);
+  const int n0 = info_[a].n[0], n1 = info_[a].n[1];
+  sync();
+  set_mask({a});
+  auto put_own = [&](double *dev, const double *X, int ld, int row_t0, int row_r0, bool has_t) {
+    std::vector<double> rec((size_t)n0 * RS_, 0.0);
+    for (int k = 0; k < n0; k++)
+      for (int c = 0; c < d_; c++) {
+        if (has_t) rec[(size_t)k * RS_ + c] = X[(size_t)c * ld + row_t0 + k];
+        for (int r = 0; r < d_; r++) rec[(size_t)k * RS_ + d_ + r * d_ + c] = X[(size_t)c * ld + row_r0 + k * d_ + r];
+      }
+    (void)hipMemcpy(dev + (size_t)own_off_[a] * RS_, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice);
+  };
+  auto get_own = [&](const double *dev, double *X, int ld, int row_t0, int row_r0, bool has_t) {
+    std::vector<double> rec((size_t)n0 * RS_);
+    sync();
+    (void)hipMemcpy(rec.data(), dev + (size_t)own_off_[a] * RS_, sizeof(double) * rec.size(), hipMemcpyDeviceToHost);
+    for (int k = 0; k < n0; k++)
+      for (int c = 0; c < d_; c++) {
+        if (has_t) X[(size_t)c * ld + row_t0 + k] = rec[(size_t)k * RS_ + c];
+        for (int r = 0; r < d_; r++) X[(size_t)c * ld + row_r0 + k * d_ + r] = rec[(size_t)k * RS_ + d_ + r * d_ + c];
+      }
+  };
+  double *A = tmp_[0].p, *Bv = tmp_[1].p, *C = tmp_[2].p;
+  if (op == "project") {
+    (void)hipMemset(A + (size_t)own_off_[a] * RS_, 0, sizeof(double) * n0 * RS_);
+    put_own(Bv, in, ld_in, 0, 0, false);
+    launch_retract_rot(d_, st_, T_, mask_.p, A, Bv, C);
+    get_own(C, out, ld_out, 0, 0, false);
+  } else if (op == "solve_tt" || op == "solve_rr") {
+    put_own(A, in, ld_in, 0, n0, true);
+    if (op == "solve_tt") solve_tt(A, 1.0);
+    else {
+      if (Lrr_.F.n == 0) return -1;
+      solve_rr(A, 1.0);
+    }
+    get_own(A, out, ld_out, 0, n0, true);
+  } else if (op == "G") {
+    put_own(A, in, ld_in, 0, n0, true);
+    launch_bsr(d_, st_, T_, false, mask_.p, G_.dev, A, false, nullptr, Bv, nullptr, 0, nullptr, nullptr, 0);
+    get_own(Bv, out, ld_out, 0, n0, true);
+  } else if (op == "proximal") {
+    // in = [Z ((d+1)(n0+n1) rows) ; Df ((d+1) n0 rows)]
+    const int zr = (d_ + 1) * (n0 + n1);
+    put_own(A, in, ld_in, 0, n0, true);
+    put_own(Bv, in, ld_in, zr, zr + n0, true);
+    launch_proximal(d_, st_, T_, mask_.p, A, Bv, Tinv_.p, N_.p, V_.p, C, nullptr, nullptr, 0);
+    get_own(C, out, ld_out, 0, n0, true);
+  } else {
+    fprintf(stderr, "[dpgo_amd] ERROR: debug_apply: unknown operator %s\n", op_c);
+    return -1;
+  }
+  return 0;
+}
+
+}  // namespace dpgo

@@ -1,0 +1,199 @@
+// A group of DPGO nodes hosted on one MI355X.
+//
+// Host-side mirror of the reference's per-node optimizer
+//   DPGOHash    C++/DPGO/src/DPGOHash.cpp (initialize :20-43, update :84-228,
+//               amm_pgo :230-444, mm_pgo :446-581, iterate :583-628),
+//               C++/DPGO/include/DPGO/DPGOHash.h:28-86 (communicate)
+//   DPGOProblem C++/DPGO/src/DPGOProblem.cpp (operators), DPGOProblem.h:275-294
+// with every vector operation batched over the nodes of the group and executed
+// by the kernels of kernels.hip.  The scalar state machine (Nesterov sequence,
+// adaptive-restart counters) stays on the host exactly as in the reference; a
+// per-node device mask lets nodes that take different branches share launches.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "assemble.h"
+#include "graph.h"
+#include "kernels.h"
+#include "spd.h"
+
+namespace dpgo {
+
+// DPGO::Options (C++/DPGO/include/DPGO/DPGO_types.h:78-201), plain data.
+struct Options {
+  int scheme = 1;  // 0 MM, 1 AMM
+  double regularizer = 1e-10;
+  double accepted_delta = 5e-4;
+  double eta[2] = {5e-4, 2.5e-2};
+  double psi = 1e-10;
+  double phi = 1e-6;
+  int max_soft_restart_hits[2] = {10, 25};
+  int oscillation_cnt_period = 15;
+  int max_oscillations = 12;
+  int loss = 0;  // 0 None, 1 Huber, 2 GemanMcClure, 3 Welsch
+  double loss_reg = 1.0;
+  double grad_norm_tol = 5e-3;
+  double rel_func_decrease_tol = 1e-6;
+  double stepsize_tol = 1e-4;
+  int max_iterations = 10;
+  int max_iterations_accepted = 1;
+  double reg_Cholesky_precon_max_condition_number = 1e6;
+  double preconditioned_grad_norm_tol = 1e-4;
+  int max_tCG_iterations = 10000;
+  double STPCG_kappa = 0.05;
+  double STPCG_theta = 0.9;
+  int preconditioner = 1;  // 0 None, 1 RegularizedCholesky
+};
+
+// The scalar fields of DPGOResult (DPGO_types.h:204-322) the state machine uses.
+struct NodeResults {
+  int updated = 1;
+  int iters = 0;
+  double gradFnorm = 0, fobjE = 0, Fk[2] = {0, 0}, Gk = 0, Gkh = 0;
+  double fobj = 0, fobj_prev = 0, f = 0, gamma = 0, s0 = 1, s1 = 1;
+  int soft_restart_hits[2] = {0, 0};
+  int num_oscillations = 0;
+  int refined = 0;
+  int tnt_status = -1;
+  int tnt_inner = 0;
+  int restarts = 0;
+  std::vector<int> oscillations;
+};
+
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() {}
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release();
+  void alloc(size_t count, bool zero = true);
+  void upload(const std::vector<T> &h);
+  void download(std::vector<T> &h) const;
+};
+
+struct SpdSolverDev {
+  SpdFactor F;   // host copy kept for sizes / host solves
+  DevBuf<int> w, u, piv_ptr, piv_idx, upd_ptr, upd_idx, pos_off, ubuf_off, asm_ptr, asm_src;
+  DevBuf<int64_t> w_off;
+  DevBuf<double> W, WT, ubuf, ytmp;
+  DevBuf<int4> fwd_items, bwd_items;
+  std::vector<int> fwd_level_ptr, bwd_level_ptr;  // item ranges per level
+  SpdDev dev;
+  int dof = 1;
+  void upload(int dcols);
+};
+
+class Group {
+ public:
+  Group(const Graph &g, const std::vector<int> &node_ids, const Options &opt, int device);
+  ~Group();
+  bool ok() const { return ok_; }
+  int d() const { return d_; }
+  int num_local() const { return (int)nodes_.size(); }
+  const DataInfo &info(int local) const { return info_[local]; }
+  const NodeResults &results(int local) const { return res_[local]; }
+  const Options &options() const { return opt_; }
+  int node_id(int local) const { return nodes_[local]; }
+
+  // X: (d+1)(n0+n1) x d column-major with leading dimension ld (DPGOHash::initialize)
+  int initialize(int local, const double *X, int ld);
+  // X: global (d+1)N x d column-major; fills own and neighbour rows of every local node
+  // (dist_pgo.cpp:435-446) and initialises them.
+  int initialize_global(const double *X, int ld);
+  int update(const std::vector<int> &locals);
+  int iterate(const std::vector<int> &locals);
+  int communicate_local();
+  // boundary exchange across groups: records of the poses other groups need
+  int num_sent() const { return (int)sent_rows_.size(); }
+  int pack_sent(double *dev_buf);                       // device buffer, num_sent()*RS doubles
+  // counts[r] keys of rank r (concatenated in nodes/poses); slot of key k of rank r = r*stride + k
+  int set_recv_layout(int nranks, int stride, const int *counts, const int *nodes, const int *poses);
+  int unpack_recv(const double *dev_gathered);          // gathered buffer of all groups
+  // results
+  int get_Xk(int local, double *X, int ld) const;       // (d+1)(n0+n1) x d column-major
+  int get_X_own(int local, double *X, int ld) const;    // Xak: (d+1) n0 x d
+  int scatter_global(double *X, int ld) const;          // writes own poses into the global layout
+  void sync() const;
+  hipStream_t stream() const { return st_; }
+
+  // test hooks (tests/ compare single operators with the oracle)
+  int debug_apply(int local, const char *op, const double *in, int ld_in, double *out, int ld_out);
+  const NodeOperators &host_ops(int local) const { return ops_[local]; }
+  const SpdFactor &factor_tt() const { return Ltt_.F; }
+  const SpdFactor &factor_rr() const { return Lrr_.F; }
+  double lambda_max(int local) const { return lambda_max_[local]; }
+  // (sent list across groups) unified own row of every boundary pose this group exports, with key
+  const std::vector<std::pair<int, int>> &sent_keys() const { return sent_keys_; }
+
+ private:
+  friend struct Tnt;
+  bool ok_ = false;
+  int d_ = 0, RS_ = 0, B_ = 0, device_ = 0;
+  Options opt_;
+  std::vector<int> nodes_;
+  std::map<int, int> local_of_node_;
+  std::vector<DataInfo> info_;
+  std::vector<NodeOperators> ops_;
+  std::vector<NodeResults> res_;
+  std::vector<double> lambda_max_;
+  std::vector<std::map<int, int>> g_index_;   // per local node: local pose -> global pose
+  int num_poses_global_ = 0, num_nodes_total_ = 1;
+  // unified rows
+  int P0_ = 0, P1_ = 0;
+  std::vector<int> own_off_, nbr_off_;
+  hipStream_t st_ = nullptr;
+
+  // device data
+  DevBuf<Seg> segs_;
+  DevBuf<int> own_seg_ptr_, nbr_seg_ptr_;
+  SegTable T_;
+  DevBuf<int> mask_;
+  int *h_mask_ = nullptr;          // pinned
+  double *h_scal_ = nullptr;       // pinned
+  double *h_gamma_ = nullptr;      // pinned
+  DevBuf<double> gamma_;
+  DevBuf<double> partials_, node_scal_;
+  struct BsrBufs { DevBuf<int> ptr, col; DevBuf<double> val; BsrDev dev; };
+  BsrBufs G_, S_, P_, P0m_, Q_;
+  DevBuf<double> Dd_, Qd_, Tinv_, N_, V_;
+  DevBuf<int> e_tail_, e_head_, e_inc_ptr_, e_inc_;
+  DevBuf<double> e_R_, e_t_, e_kappa_, e_tau_;
+  InterEdgesDev E_;
+  SpdSolverDev Ltt_, Lrr_;
+  // halo
+  DevBuf<int> local_src_;          // per neighbour row: unified own row on this device, or -1
+  DevBuf<int> gather_dst_, gather_src_;   // local halo copy lists
+  std::vector<int> sent_rows_;     // unified own rows exported to other groups
+  std::vector<std::pair<int, int>> sent_keys_;   // (node, pose) of each exported row
+  DevBuf<int> sent_rows_dev_;
+  DevBuf<int> recv_dst_, recv_src_;       // remote halo: nbr row <- gathered slot
+  // vectors (records)
+  DevBuf<double> Xk_, Zc_, Zp_, Y_, DfE_, Tall_;                 // P0+P1 rows
+  DevBuf<double> Xak_, Xakh_, gc_, gp_, Dfc_, Dfp_, gx_, Dfx_, T1_;   // P0 rows
+  DevBuf<double> tmp_[14];                                       // P0 rows, TNT work vectors
+  std::vector<int> last_mask_;
+
+  void upload_bsr(const std::vector<const BsrMatrix *> &per_node, bool rows_all, BsrBufs &out);
+  void set_mask(const std::vector<int> &locals);
+  void fetch(int nslots, bool all_rows);                  // -> h_scal_[local * MAX_SLOTS + s]
+  double scal(int local, int s) const { return h_scal_[local * MAX_SLOTS + s]; }
+  void copy_rows(double *dst, const double *src, bool all_rows, int part = 0);
+  void solve_tt(double *vec, double scale);               // in place on translation rows
+  void solve_rr(double *vec, double scale);               // in place on rotation rows
+  void recover_translations(double *X, const double *g);  // X.t = -Gtt^-1 (g_t + G_tR X.R) for masked nodes
+  void eval_G(const double *X, const double *g, int slot);
+  void host_update_logic(int local, double fobj, double f, double gradFnorm);
+  int amm(const std::vector<int> &locals);
+  int mm(const std::vector<int> &locals);
+  void run_tnt(int local, double *X, const double *g);   // refine X in place, sets Gk = f(X)
+};
+
+}  // namespace dpgo

@@ -1,0 +1,124 @@
+// Launch wrappers for the hand-written gfx950 kernels (kernels.hip).
+//
+// Conventions shared by every kernel:
+//  * A pose record z_p is (d+1) x d doubles, row-major: row 0 = translation
+//    x_p, rows 1..d = rows of Y_p = R_p^T.  RS = (d+1)*d doubles (96 B for SE(3),
+//    48 B for SE(2)), 16-byte aligned, poses contiguous.  The reference stores
+//    the same numbers as rows {p, n + d p .. n + d p + d - 1} of a column-major
+//    Eigen matrix (C++/DPGO/include/DPGO/DPGOProblem.h:167-171).
+//  * One device hosts several nodes.  Rows are "unified": own poses of all local
+//    nodes first (node by node), then all neighbour poses (node by node).
+//  * Work is cut into segments of <= SEG_ROWS rows that never straddle a node;
+//    one workgroup per segment.  Kernels that reduce write one partial per
+//    (slot, segment); k_reduce sums a node's partials in fixed order
+//    (deterministic, no atomics).
+//  * mask[node] == 0 makes every workgroup of that node exit early; this is how
+//    per-node branches of the AMM state machine run without splitting launches.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace dpgo {
+
+constexpr int SEG_ROWS = 256;
+constexpr int MAX_SLOTS = 8;
+
+struct Seg {
+  int begin, end, node, pad;
+};
+
+struct BsrDev {
+  int nrows = 0;
+  const int *ptr = nullptr, *col = nullptr;
+  const double *val = nullptr;
+};
+
+// Inter-node edges of the local nodes, B-form (residual) data.
+struct InterEdgesDev {
+  int m = 0;
+  const int *tail = nullptr, *head = nullptr;   // unified pose ids
+  const double *R = nullptr;                    // d*d row-major
+  const double *t = nullptr;                    // d
+  const double *kappa = nullptr, *tau = nullptr;
+  const int *inc_ptr = nullptr;                 // per unified row
+  const int *inc = nullptr;                     // edge*2 + (0 tail | 1 head)
+};
+
+struct SegTable {
+  const Seg *segs = nullptr;
+  int nseg_own = 0, nseg_all = 0;
+  const int *own_ptr = nullptr;   // per node: [own_ptr[a], own_ptr[a+1]) own segments
+  const int *nbr_ptr = nullptr;   // per node: [nbr_ptr[a], nbr_ptr[a+1]) neighbour segments (indices into segs)
+};
+
+// y = A x (+ addv) ; partial[slot] = sum_p < dotv_p , coef * (A x)_p + dotadd_p >
+// in_rot_only: the translation row of x is treated as zero (G_tR R products).
+void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, const int *mask, const BsrDev &A,
+                const double *x, bool in_rot_only, const double *addv, double *y, const double *dotv,
+                double coef, const double *dotadd, double *partials, int slot);
+
+// Robust inter-edge pass (B-form, DPGOProblem.cpp:634-725).
+//  mode 0 (update): all rows.  DfE <- B1^T W B1 Z; own rows also g <- DfE - D z.
+//     slot 0: sum of rho_e (tail incidences); if quad: slot 1 = sum tr(dZ^T (DfE_old + 1/2 Q dZ)).
+//  mode 1 (evaluate_g): own rows only, g <- (B1^T W B1 Z)_own - D z.
+void launch_inter(int d, hipStream_t st, const SegTable &T, const int *mask, const InterEdgesDev &E, int loss,
+                  double loss_reg, int mode, bool quad, const double *Z, const double *Zprev,
+                  const double *Qdiag, const double *Ddiag, double *DfE, double *g, double *partials);
+
+// Xout = proximal(Z, Df) per own pose (DPGOProblem.cpp:600-632); slot>=0: partial ||Xout - Xref||^2.
+void launch_proximal(int d, hipStream_t st, const SegTable &T, const int *mask, const double *Z, const double *Df,
+                     const double *Tinv, const double *N, const double *V, double *Xout, const double *Xref,
+                     double *partials, int slot);
+
+// out = a + gamma[node] * (a - b) over all rows (own + neighbour)      (DPGOHash.cpp:255-262)
+void launch_extrapolate(int d, hipStream_t st, const SegTable &T, bool all_rows, const int *mask,
+                        const double *gamma, const double *a, const double *b, double *out);
+// out = alpha * a + beta * b  (b may be null); parts: 0 whole record, 1 translation only, 2 rotation only
+void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, const int *mask, double alpha,
+                  const double *a, double beta, const double *b, double *out, int part);
+// partial[slot] = sum <a_p, b_p> over the selected part
+void launch_dot(int d, hipStream_t st, const SegTable &T, bool all_rows, const int *mask, const double *a,
+                const double *b, int part, double *partials, int slot);
+// gradF = [V.x ; Proj_R(V.Y)] (DPGOProblem.cpp:145-162); partial ||gradF||^2; out may be null
+void launch_tangent_full(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
+                         const double *V, double *out, double *partials, int slot);
+// out.Y = Proj_{X.Y}( in.Y - sym(sbdA.Y ... ) ) helpers for the Riemannian Hessian (DPGOProblem.cpp:552-577):
+//   out.Y = Proj_R( E.Y - sym(nabla.Y R^T) Rdot.Y ) with R = X.Y; translation row of out set to 0
+void launch_hess_epilogue(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
+                          const double *E, const double *nabla, const double *Rdot, double *out);
+// out.Y = Proj_R(in.Y), out.x = 0                                       (DPGOProblem.cpp:164-178)
+void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
+                        const double *in, double *out);
+// out.Y = proj_SO(d)(X.Y + V.Y); out.x = 0                              (SOdProduct.h:111-116)
+void launch_retract_rot(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
+                        const double *V, double *out);
+// dst[didx[k]] = src[sidx[k]] (didx may be null: dst[k]); halo copy, pack, unpack (DPGOHash.h:28-86)
+void launch_copy_indexed(int d, hipStream_t st, int count, const int *didx, const int *sidx, const double *src,
+                         double *dst);
+// partial[slot] = sum_p < x_p , coef * (D_p x_p) + addcoef * add_p > over own rows
+void launch_bdiag_dot(int d, hipStream_t st, const SegTable &T, const int *mask, const double *Dd, const double *x,
+                      double coef, const double *add, double addcoef, double *partials, int slot);
+
+// node_scalars[node * MAX_SLOTS + s] = sum of the node's partials, s < nslots
+void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows, int nslots,
+                   const double *partials, double *node_scalars);
+
+// ---- multifrontal SPD solve (spd.h) ----
+struct SpdDev {
+  int nfronts = 0;
+  const int *w = nullptr, *u = nullptr, *piv_ptr = nullptr, *piv_idx = nullptr, *upd_ptr = nullptr,
+            *upd_idx = nullptr, *pos_off = nullptr, *ubuf_off = nullptr, *asm_ptr = nullptr, *asm_src = nullptr;
+  const int64_t *w_off = nullptr;
+  const double *W = nullptr, *WT = nullptr;
+  const int4 *fwd_items = nullptr, *bwd_items = nullptr;   // {front, first row/col, count, 0}
+  double *ubuf = nullptr;
+};
+// One level of the forward / backward sweep.  dof = 1: unknown i is the translation of pose i;
+// dof = d: unknown i = (pose i / d, rotation row i % d).  vec is a record array, solved in place.
+// forward reads the right-hand side from vec and writes y to ytmp (n x d, matrix order); backward
+// reads ytmp and writes scale * A^-1 b into vec (scale must be +1 or -1).
+void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int item0, int nitems,
+                      double *vec, double *ytmp, double scale);
+
+}  // namespace dpgo

@@ -1,0 +1,881 @@
+// Hand-written gfx950 (CDNA4) kernels of the DPGO hot path.  fp64 throughout
+// (the reference is `typedef double Scalar`, C++/DPGO/include/DPGO/DPGO_types.h:12).
+//
+// Everything here is HBM/L2-latency bound graph work on 96-byte pose records;
+// the kernels are organised for coalesced 16-byte accesses, 64-wide wavefront
+// shuffles for the reductions and LDS staging for the dense front mat-vecs.
+// No atomics: every reduction is a fixed-order tree, so results are bitwise
+// reproducible run to run.
+#include "kernels.h"
+
+namespace dpgo {
+namespace {
+
+template <int D>
+struct Dim {
+  static constexpr int B = D + 1;
+  static constexpr int RS = (D + 1) * D;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// Sum NS per-thread values over a 256-thread workgroup and store to dst[s * stride].
+template <int NS>
+__device__ __forceinline__ void block_store(const double (&v)[NS], double *dst, int stride) {
+  __shared__ double sm[NS][4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int s = 0; s < NS; s++) {
+    double r = wave_sum(v[s]);
+    if (lane == 0) sm[s][wid] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int s = 0; s < NS; s++) dst[(size_t)s * stride] = (sm[s][0] + sm[s][1]) + (sm[s][2] + sm[s][3]);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void load_vec(const double *p, double (&r)[N]) {
+  if constexpr (N % 2 == 0) {   // records and SE(3) blocks: whole 16-byte loads
+    const double2 *q = reinterpret_cast<const double2 *>(p);
+#pragma unroll
+    for (int k = 0; k < N / 2; k++) {
+      double2 v = q[k];
+      r[2 * k] = v.x;
+      r[2 * k + 1] = v.y;
+    }
+  } else {                      // 3x3 blocks of SE(2): 72 bytes, only 8-byte aligned
+#pragma unroll
+    for (int k = 0; k < N; k++) r[k] = p[k];
+  }
+}
+template <int N>
+__device__ __forceinline__ void store_vec(double *p, const double (&r)[N]) {
+  static_assert(N % 2 == 0, "records are multiples of 16 bytes");
+  double2 *q = reinterpret_cast<double2 *>(p);
+#pragma unroll
+  for (int k = 0; k < N / 2; k++) q[k] = make_double2(r[2 * k], r[2 * k + 1]);
+}
+
+// out (B x D) += blk (B x B) * rec (B x D)
+template <int D, bool SKIP_T>
+__device__ __forceinline__ void blk_mul_acc(const double *blk, const double *rec, double *out) {
+  constexpr int B = D + 1;
+#pragma unroll
+  for (int r = 0; r < B; r++)
+#pragma unroll
+    for (int j = SKIP_T ? 1 : 0; j < B; j++) {
+      const double a = blk[r * B + j];
+#pragma unroll
+      for (int c = 0; c < D; c++) out[r * D + c] = fma(a, rec[j * D + c], out[r * D + c]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// SO(d) projection: nearest rotation in the Frobenius norm.
+// Replaces project_to_SO3 / project_to_SO2 (C++/DPGO/src/internal/project_to_SOd.cpp:27-33,121-196):
+// eigen-decompose M^T M with a fixed schedule of cyclic Jacobi rotations (no data-dependent
+// loop), form B = M V = U Sigma, rebuild U by Gram-Schmidt with u3 = u1 x u2, return U V^T.
+// u3 = u1 x u2 with det V = +1 is exactly the det(U V^T) fix of the reference's
+// JacobiSVD path (C++/DPGO/include/DPGO/DPGO_utils.h:485-514).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void jacobi_pair(double &app, double &aqq, double &apq, double &arp, double &arq,
+                                            double *V, int p, int q) {
+  const double tiny = 1e-300;
+  const bool go = fabs(apq) > tiny;
+  const double theta = (aqq - app) / (2.0 * (go ? apq : 1.0));
+  double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+  t = theta < 0.0 ? -t : t;
+  t = go ? t : 0.0;
+  const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+  app -= t * apq;
+  aqq += t * apq;
+  apq = 0.0;
+  const double rp = c * arp - s * arq, rq = s * arp + c * arq;
+  arp = rp;
+  arq = rq;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const double vp = V[k * 3 + p], vq = V[k * 3 + q];
+    V[k * 3 + p] = c * vp - s * vq;
+    V[k * 3 + q] = s * vp + c * vq;
+  }
+}
+
+__device__ __forceinline__ void swap_cols_neg(double *A, int a, int b, bool doit) {
+  // swap columns a and b, negating the one that lands in b: a proper rotation of the column space
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const double x = A[k * 3 + a], y = A[k * 3 + b];
+    A[k * 3 + a] = doit ? y : x;
+    A[k * 3 + b] = doit ? -x : y;
+  }
+}
+
+__device__ void project_so3(const double *M, double *R) {
+  // S = M^T M
+  double s00 = 0, s11 = 0, s22 = 0, s01 = 0, s02 = 0, s12 = 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    s00 = fma(M[k * 3 + 0], M[k * 3 + 0], s00);
+    s11 = fma(M[k * 3 + 1], M[k * 3 + 1], s11);
+    s22 = fma(M[k * 3 + 2], M[k * 3 + 2], s22);
+    s01 = fma(M[k * 3 + 0], M[k * 3 + 1], s01);
+    s02 = fma(M[k * 3 + 0], M[k * 3 + 2], s02);
+    s12 = fma(M[k * 3 + 1], M[k * 3 + 2], s12);
+  }
+  double V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int sweep = 0; sweep < 8; sweep++) {   // same sweep count as the reference's 8 x 3 conjugations
+    jacobi_pair(s00, s11, s01, s02, s12, V, 0, 1);
+    jacobi_pair(s00, s22, s02, s01, s12, V, 0, 2);
+    jacobi_pair(s11, s22, s12, s01, s02, V, 1, 2);
+  }
+  double Bm[9];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+      Bm[r * 3 + c] = M[r * 3 + 0] * V[0 * 3 + c] + M[r * 3 + 1] * V[1 * 3 + c] + M[r * 3 + 2] * V[2 * 3 + c];
+  double n0 = Bm[0] * Bm[0] + Bm[3] * Bm[3] + Bm[6] * Bm[6];
+  double n1 = Bm[1] * Bm[1] + Bm[4] * Bm[4] + Bm[7] * Bm[7];
+  double n2 = Bm[2] * Bm[2] + Bm[5] * Bm[5] + Bm[8] * Bm[8];
+  // sort columns by decreasing norm (3-element network), keeping det V = +1
+  bool sw = n0 < n1;
+  swap_cols_neg(Bm, 0, 1, sw); swap_cols_neg(V, 0, 1, sw);
+  { double a = sw ? n1 : n0, b = sw ? n0 : n1; n0 = a; n1 = b; }
+  sw = n0 < n2;
+  swap_cols_neg(Bm, 0, 2, sw); swap_cols_neg(V, 0, 2, sw);
+  { double a = sw ? n2 : n0, b = sw ? n0 : n2; n0 = a; n2 = b; }
+  sw = n1 < n2;
+  swap_cols_neg(Bm, 1, 2, sw); swap_cols_neg(V, 1, 2, sw);
+  { double a = sw ? n2 : n1, b = sw ? n1 : n2; n1 = a; n2 = b; }
+  double u1[3], u2[3], u3[3];
+  const bool ok1 = n0 > 1e-300;
+  const double i1 = 1.0 / sqrt(ok1 ? n0 : 1.0);
+  u1[0] = ok1 ? Bm[0] * i1 : 1.0; u1[1] = ok1 ? Bm[3] * i1 : 0.0; u1[2] = ok1 ? Bm[6] * i1 : 0.0;
+  const double pr = u1[0] * Bm[1] + u1[1] * Bm[4] + u1[2] * Bm[7];
+  u2[0] = Bm[1] - pr * u1[0]; u2[1] = Bm[4] - pr * u1[1]; u2[2] = Bm[7] - pr * u1[2];
+  double m2 = u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2];
+  if (!(m2 > 1e-28 * n0) || !ok1) {
+    // rank <= 1: any unit vector orthogonal to u1 completes a nearest rotation
+    const double ax = fabs(u1[0]), ay = fabs(u1[1]), az = fabs(u1[2]);
+    double e[3] = {0, 0, 0};
+    if (ax <= ay && ax <= az) e[0] = 1; else if (ay <= az) e[1] = 1; else e[2] = 1;
+    u2[0] = u1[1] * e[2] - u1[2] * e[1]; u2[1] = u1[2] * e[0] - u1[0] * e[2]; u2[2] = u1[0] * e[1] - u1[1] * e[0];
+    m2 = u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2];
+  }
+  const double i2 = 1.0 / sqrt(m2);
+  u2[0] *= i2; u2[1] *= i2; u2[2] *= i2;
+  u3[0] = u1[1] * u2[2] - u1[2] * u2[1];
+  u3[1] = u1[2] * u2[0] - u1[0] * u2[2];
+  u3[2] = u1[0] * u2[1] - u1[1] * u2[0];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) R[r * 3 + c] = u1[r] * V[c * 3 + 0] + u2[r] * V[c * 3 + 1] + u3[r] * V[c * 3 + 2];
+}
+
+__device__ __forceinline__ void project_so2(const double *M, double *R) {
+  // C++/DPGO/include/DPGO/internal/project_to_SO2.h:3-18, guard traits.cpp:10
+  double c = M[0] + M[3], s = M[2] - M[1];
+  double n2 = fma(s, s, c * c);
+  const bool ok = n2 >= 1.0e-32;
+  c = ok ? c : 1.0;
+  s = ok ? s : 0.0;
+  n2 = ok ? n2 : 1.0;
+  const double inv = 1.0 / sqrt(n2);
+  c *= inv;
+  s *= inv;
+  R[0] = c; R[1] = -s; R[2] = s; R[3] = c;
+}
+
+template <int D>
+__device__ __forceinline__ void project_sod(const double *M, double *R) {
+  if constexpr (D == 3) project_so3(M, R); else project_so2(M, R);
+}
+
+// out = F - sym(F Y^T) Y      (SOdProduct::Proj, C++/DPGO/include/DPGO/SOdProduct.h:96-103)
+template <int D>
+__device__ __forceinline__ void tangent_proj(const double *Y, const double *F, double *out) {
+  double G[D * D], S[D * D];
+#pragma unroll
+  for (int r = 0; r < D; r++)
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+      double a = 0;
+#pragma unroll
+      for (int k = 0; k < D; k++) a = fma(F[r * D + k], Y[c * D + k], a);
+      G[r * D + c] = a;
+    }
+#pragma unroll
+  for (int r = 0; r < D; r++)
+#pragma unroll
+    for (int c = 0; c < D; c++) S[r * D + c] = 0.5 * (G[r * D + c] + G[c * D + r]);
+#pragma unroll
+  for (int r = 0; r < D; r++)
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+      double a = F[r * D + c];
+#pragma unroll
+      for (int k = 0; k < D; k++) a = fma(-S[r * D + k], Y[k * D + c], a);
+      out[r * D + c] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Block-sparse operator apply over pose records.
+// ---------------------------------------------------------------------------
+template <int D, bool ROT_ONLY>
+__global__ __launch_bounds__(256) void k_bsr(const Seg *segs, const int *mask, BsrDev A, const double *x,
+                                             const double *addv, double *y, const double *dotv, double coef,
+                                             const double *dotadd, double *partial) {
+  constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
+  const Seg s = segs[blockIdx.x];
+  const bool active = (mask == nullptr) || (mask[s.node] != 0);
+  double part[1] = {0.0};
+  const int row = s.begin + threadIdx.x;
+  if (active && row < s.end) {
+    double acc[RS];
+#pragma unroll
+    for (int k = 0; k < RS; k++) acc[k] = 0.0;
+    const int k1 = A.ptr[row + 1];
+    for (int k = A.ptr[row]; k < k1; k++) {
+      const int q = A.col[k];
+      double xb[RS], blk[B * B];
+      load_vec<RS>(x + (size_t)q * RS, xb);
+      load_vec<B * B>(A.val + (size_t)k * B * B, blk);
+      blk_mul_acc<D, ROT_ONLY>(blk, xb, acc);
+    }
+    if (dotv) {
+      double v[RS], da[RS];
+      load_vec<RS>(dotv + (size_t)row * RS, v);
+      if (dotadd) load_vec<RS>(dotadd + (size_t)row * RS, da);
+      double p = 0;
+#pragma unroll
+      for (int k = 0; k < RS; k++) p = fma(v[k], fma(coef, acc[k], dotadd ? da[k] : 0.0), p);
+      part[0] = p;
+    }
+    if (y) {
+      if (addv) {
+        double av[RS];
+        load_vec<RS>(addv + (size_t)row * RS, av);
+#pragma unroll
+        for (int k = 0; k < RS; k++) acc[k] += av[k];
+      }
+      store_vec<RS>(y + (size_t)row * RS, acc);
+    }
+  }
+  if (partial) block_store<1>(part, partial + blockIdx.x, 0);
+}
+
+// ---------------------------------------------------------------------------
+// Robust inter-node edge pass (residual form).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void loss_weight(int loss, double dl, double s, double &w, double &rho) {
+  if (loss == 1) {          // Huber   (DPGOProblem.cpp:651-658)
+    const double rs = sqrt(fmax(s, dl)), sd = sqrt(dl);
+    w = sd / rs;
+    rho = fmin(2.0 * sd * rs - dl, s);
+  } else if (loss == 2) {   // Geman-McClure (:659-664)
+    const double q = s + dl;
+    w = dl * dl / (q * q);
+    rho = dl * (s / q);
+  } else if (loss == 3) {   // Welsch (:665-670)
+    w = exp(-s / dl);
+    rho = dl - dl * w;
+  } else {
+    w = 1.0;
+    rho = s;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_inter(const Seg *segs, const int *mask, InterEdgesDev E, int loss,
+                                               double dl, int mode, int quad, int nseg_own, const double *Z,
+                                               const double *Zprev, const double *Qd, const double *Dd,
+                                               double *DfE, double *g, double *partial, int pstride) {
+  constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
+  const Seg s = segs[blockIdx.x];
+  const bool active = (mask == nullptr) || (mask[s.node] != 0);
+  const bool own = blockIdx.x < nseg_own;
+  double part[2] = {0.0, 0.0};
+  const int row = s.begin + threadIdx.x;
+  if (active && row < s.end) {
+    double zp[RS], acc[RS];
+    load_vec<RS>(Z + (size_t)row * RS, zp);
+#pragma unroll
+    for (int k = 0; k < RS; k++) acc[k] = 0.0;
+    const int k1 = E.inc_ptr[row + 1];
+    for (int k = E.inc_ptr[row]; k < k1; k++) {
+      const int code = E.inc[k], e = code >> 1, role = code & 1;
+      const int other = role ? E.tail[e] : E.head[e];
+      double zo[RS], Re[D * D], te[D];
+      load_vec<RS>(Z + (size_t)other * RS, zo);
+#pragma unroll
+      for (int i = 0; i < D * D; i++) Re[i] = E.R[(size_t)e * D * D + i];
+#pragma unroll
+      for (int i = 0; i < D; i++) te[i] = E.t[(size_t)e * D + i];
+      const double tau = E.tau[e], kap = E.kappa[e];
+      const double *zi = role ? zo : zp;   // tail record
+      const double *zj = role ? zp : zo;   // head record
+      double u[D], W[D * D];
+      double sn = 0;
+#pragma unroll
+      for (int c = 0; c < D; c++) {
+        double a = zi[c] - zj[c];
+#pragma unroll
+        for (int q = 0; q < D; q++) a = fma(te[q], zi[D + q * D + c], a);
+        u[c] = a;
+        sn = fma(tau * a, a, sn);
+      }
+#pragma unroll
+      for (int r = 0; r < D; r++)
+#pragma unroll
+        for (int c = 0; c < D; c++) {
+          double a = -zj[D + r * D + c];
+#pragma unroll
+          for (int q = 0; q < D; q++) a = fma(Re[q * D + r], zi[D + q * D + c], a);
+          W[r * D + c] = a;
+          sn = fma(kap * a, a, sn);
+        }
+      double w, rho;
+      loss_weight(loss, dl, sn, w, rho);
+      if (role == 0) {
+        part[0] += rho;
+#pragma unroll
+        for (int c = 0; c < D; c++) acc[c] = fma(w * tau, u[c], acc[c]);
+#pragma unroll
+        for (int q = 0; q < D; q++)
+#pragma unroll
+          for (int c = 0; c < D; c++) {
+            double a = tau * te[q] * u[c];
+#pragma unroll
+            for (int r = 0; r < D; r++) a = fma(kap * Re[q * D + r], W[r * D + c], a);
+            acc[D + q * D + c] = fma(w, a, acc[D + q * D + c]);
+          }
+      } else {
+#pragma unroll
+        for (int c = 0; c < D; c++) acc[c] = fma(-w * tau, u[c], acc[c]);
+#pragma unroll
+        for (int i = 0; i < D * D; i++) acc[D + i] = fma(-w * kap, W[i], acc[D + i]);
+      }
+    }
+    if (mode == 0) {
+      if (quad) {
+        double zq[RS], old[RS], dz[RS], qz[RS];
+        load_vec<RS>(Zprev + (size_t)row * RS, zq);
+        load_vec<RS>(DfE + (size_t)row * RS, old);
+#pragma unroll
+        for (int k = 0; k < RS; k++) { dz[k] = zp[k] - zq[k]; qz[k] = 0.0; }
+        blk_mul_acc<D, false>(Qd + (size_t)row * B * B, dz, qz);
+        double p = 0;
+#pragma unroll
+        for (int k = 0; k < RS; k++) p = fma(dz[k], fma(0.5, qz[k], old[k]), p);
+        part[1] = p;
+      }
+      store_vec<RS>(DfE + (size_t)row * RS, acc);
+    }
+    if (own) {
+      double dz[RS];
+#pragma unroll
+      for (int k = 0; k < RS; k++) dz[k] = 0.0;
+      blk_mul_acc<D, false>(Dd + (size_t)row * B * B, zp, dz);
+#pragma unroll
+      for (int k = 0; k < RS; k++) acc[k] -= dz[k];
+      store_vec<RS>(g + (size_t)row * RS, acc);
+    }
+  }
+  block_store<2>(part, partial + blockIdx.x, pstride);
+}
+
+// ---------------------------------------------------------------------------
+// Per-pose kernels.
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_proximal(const Seg *segs, const int *mask, const double *Z,
+                                                  const double *Df, const double *Tinv, const double *Nv,
+                                                  const double *Vb, double *Xout, const double *Xref,
+                                                  double *partial) {
+  constexpr int RS = Dim<D>::RS;
+  const Seg s = segs[blockIdx.x];
+  const bool active = (mask == nullptr) || (mask[s.node] != 0);
+  double part[1] = {0.0};
+  const int row = s.begin + threadIdx.x;
+  if (active && row < s.end) {
+    double z[RS], df[RS], N[D], V[D * D], M[D * D], R[D * D], out[RS];
+    load_vec<RS>(Z + (size_t)row * RS, z);
+    load_vec<RS>(Df + (size_t)row * RS, df);
+#pragma unroll
+    for (int k = 0; k < D; k++) N[k] = Nv[(size_t)row * D + k];
+#pragma unroll
+    for (int k = 0; k < D * D; k++) V[k] = Vb[(size_t)row * D * D + k];
+    const double T = Tinv[row];
+    // M = -Df_R + N^T Df_t + V R0      (DPGOProblem.cpp:618-620)
+#pragma unroll
+    for (int r = 0; r < D; r++)
+#pragma unroll
+      for (int c = 0; c < D; c++) {
+        double a = fma(N[r], df[c], -df[D + r * D + c]);
+#pragma unroll
+        for (int k = 0; k < D; k++) a = fma(V[r * D + k], z[D + k * D + c], a);
+        M[r * D + c] = a;
+      }
+    project_sod<D>(M, R);
+    // t = t0 - N (R - R0) - T Df_t     (:627-629)
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+      double a = fma(-T, df[c], z[c]);
+#pragma unroll
+      for (int k = 0; k < D; k++) a = fma(-N[k], R[k * D + c] - z[D + k * D + c], a);
+      out[c] = a;
+    }
+#pragma unroll
+    for (int k = 0; k < D * D; k++) out[D + k] = R[k];
+    store_vec<RS>(Xout + (size_t)row * RS, out);
+    if (Xref) {
+      double ref[RS];
+      load_vec<RS>(Xref + (size_t)row * RS, ref);
+      double p = 0;
+#pragma unroll
+      for (int k = 0; k < RS; k++) { const double dd = out[k] - ref[k]; p = fma(dd, dd, p); }
+      part[0] = p;
+    }
+  }
+  if (partial) block_store<1>(part, partial + blockIdx.x, 0);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_extrapolate(const Seg *segs, const int *mask, const double *gamma,
+                                                     const double *a, const double *b, double *out) {
+  constexpr int RS = Dim<D>::RS;
+  const Seg s = segs[blockIdx.x];
+  if (mask && !mask[s.node]) return;
+  const int row = s.begin + threadIdx.x;
+  if (row >= s.end) return;
+  const double gm = gamma[s.node];
+  double va[RS], vb[RS];
+  load_vec<RS>(a + (size_t)row * RS, va);
+  load_vec<RS>(b + (size_t)row * RS, vb);
+#pragma unroll
+  for (int k = 0; k < RS; k++) va[k] = fma(gm, va[k] - vb[k], va[k]);
+  store_vec<RS>(out + (size_t)row * RS, va);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_axpby(const Seg *segs, const int *mask, double alpha, const double *a,
+                                               double beta, const double *b, double *out, int part) {
+  constexpr int RS = Dim<D>::RS;
+  const Seg s = segs[blockIdx.x];
+  if (mask && !mask[s.node]) return;
+  const int row = s.begin + threadIdx.x;
+  if (row >= s.end) return;
+  const int k0 = part == 2 ? D : 0, k1 = part == 1 ? D : RS;
+  for (int k = k0; k < k1; k++) {
+    double v = alpha * a[(size_t)row * RS + k];
+    if (b) v = fma(beta, b[(size_t)row * RS + k], v);
+    out[(size_t)row * RS + k] = v;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_dot(const Seg *segs, const int *mask, const double *a, const double *b,
+                                             int part, double *partial) {
+  constexpr int RS = Dim<D>::RS;
+  const Seg s = segs[blockIdx.x];
+  const bool active = (mask == nullptr) || (mask[s.node] != 0);
+  double pr[1] = {0.0};
+  const int row = s.begin + threadIdx.x;
+  if (active && row < s.end) {
+    double va[RS], vb[RS];
+    load_vec<RS>(a + (size_t)row * RS, va);
+    load_vec<RS>(b + (size_t)row * RS, vb);
+    const int k0 = part == 2 ? D : 0, k1 = part == 1 ? D : RS;
+    double p = 0;
+#pragma unroll
+    for (int k = 0; k < RS; k++) p = (k >= k0 && k < k1) ? fma(va[k], vb[k], p) : p;
+    pr[0] = p;
+  }
+  block_store<1>(pr, partial + blockIdx.x, 0);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_tangent_full(const Seg *segs, const int *mask, const double *X,
+                                                      const double *V, double *out, double *partial) {
+  constexpr int RS = Dim<D>::RS;
+  const Seg s = segs[blockIdx.x];
+  const bool active = (mask == nullptr) || (mask[s.node] != 0);
+  double pr[1] = {0.0};
+  const int row = s.begin + threadIdx.x;
+  if (active && row < s.end) {
+    double x[RS], v[RS], o[RS];
+    load_vec<RS>(X + (size_t)row * RS, x);
+    load_vec<RS>(V + (size_t)row * RS, v);
+#pragma unroll
+    for (int k = 0; k < D; k++) o[k] = v[k];
+    tangent_proj<D>(x + D, v + D, o + D);
+    double p = 0;
+#pragma unroll
+    for (int k = 0; k < RS; k++) p = fma(o[k], o[k], p);
+    pr[0] = p;
+    if (out) store_vec<RS>(out + (size_t)row * RS, o);
+  }
+  if (partial) block_store<1>(pr, partial + blockIdx.x, 0);
+}
+
+// mode 0: out.Y = Proj_R(in.Y)                         (reduced_tangent_space_projection)
+// mode 1: out.Y = Proj_R(E.Y - sym(nabla.Y R^T) Rdot.Y) (Hessian epilogue, DPGOProblem.cpp:570-574)
+// mode 2: out.Y = proj_SO(d)(R + in.Y)                  (SOdProduct::retract)
+template <int D>
+__global__ __launch_bounds__(256) void k_rot_op(const Seg *segs, const int *mask, int mode, const double *X,
+                                                const double *in, const double *nabla, const double *Rdot,
+                                                double *out) {
+  constexpr int RS = Dim<D>::RS;
+  const Seg s = segs[blockIdx.x];
+  if (mask && !mask[s.node]) return;
+  const int row = s.begin + threadIdx.x;
+  if (row >= s.end) return;
+  double x[RS], v[RS], o[RS];
+  load_vec<RS>(X + (size_t)row * RS, x);
+  load_vec<RS>(in + (size_t)row * RS, v);
+#pragma unroll
+  for (int k = 0; k < D; k++) o[k] = 0.0;
+  const double *R = x + D;
+  if (mode == 0) {
+    tangent_proj<D>(R, v + D, o + D);
+  } else if (mode == 1) {
+    double nb[RS], rd[RS], G[D * D], F[D * D];
+    load_vec<RS>(nabla + (size_t)row * RS, nb);
+    load_vec<RS>(Rdot + (size_t)row * RS, rd);
+    // sym(nabla R^T) Rdot      (SymBlockDiagProduct(A=Rdot, B=R, C=nabla), SOdProduct.h:64-89)
+#pragma unroll
+    for (int r = 0; r < D; r++)
+#pragma unroll
+      for (int c = 0; c < D; c++) {
+        double a = 0;
+#pragma unroll
+        for (int k = 0; k < D; k++) a = fma(nb[D + r * D + k], R[c * D + k], a);
+        G[r * D + c] = a;
+      }
+#pragma unroll
+    for (int r = 0; r < D; r++)
+#pragma unroll
+      for (int c = 0; c < D; c++) {
+        double a = v[D + r * D + c];
+#pragma unroll
+        for (int k = 0; k < D; k++) a = fma(-0.5 * (G[r * D + k] + G[k * D + r]), rd[D + k * D + c], a);
+        F[r * D + c] = a;
+      }
+    tangent_proj<D>(R, F, o + D);
+  } else {
+    double M[D * D];
+#pragma unroll
+    for (int k = 0; k < D * D; k++) M[k] = R[k] + v[D + k];
+    project_sod<D>(M, o + D);
+  }
+  store_vec<RS>(out + (size_t)row * RS, o);
+}
+
+// dst[didx[k]] = src[sidx[k]]  (didx == nullptr: dst[k]); halo copies, pack and unpack
+template <int D>
+__global__ __launch_bounds__(256) void k_copy_indexed(int count, const int *didx, const int *sidx,
+                                                      const double *src, double *dst) {
+  constexpr int RS = Dim<D>::RS;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= count) return;
+  double r[RS];
+  load_vec<RS>(src + (size_t)sidx[k] * RS, r);
+  store_vec<RS>(dst + (size_t)(didx ? didx[k] : k) * RS, r);
+}
+
+// partial = sum_p < x_p , coef * (D_p x_p) + addcoef * add_p >   (own rows, D block diagonal)
+template <int D>
+__global__ __launch_bounds__(256) void k_bdiag_dot(const Seg *segs, const int *mask, const double *Dd,
+                                                   const double *x, double coef, const double *add,
+                                                   double addcoef, double *partial) {
+  constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
+  const Seg s = segs[blockIdx.x];
+  const bool active = (mask == nullptr) || (mask[s.node] != 0);
+  double pr[1] = {0.0};
+  const int row = s.begin + threadIdx.x;
+  if (active && row < s.end) {
+    double xv[RS], dx[RS], av[RS];
+    load_vec<RS>(x + (size_t)row * RS, xv);
+    load_vec<RS>(add + (size_t)row * RS, av);
+#pragma unroll
+    for (int k = 0; k < RS; k++) dx[k] = 0.0;
+    blk_mul_acc<D, false>(Dd + (size_t)row * B * B, xv, dx);
+    double p = 0;
+#pragma unroll
+    for (int k = 0; k < RS; k++) p = fma(xv[k], fma(coef, dx[k], addcoef * av[k]), p);
+    pr[0] = p;
+  }
+  block_store<1>(pr, partial + blockIdx.x, 0);
+}
+
+__global__ __launch_bounds__(64) void k_reduce(SegTable T, int all_rows, int nslots, const double *partials,
+                                               double *node_scalars) {
+  const int a = blockIdx.x, lane = threadIdx.x;
+  for (int s = 0; s < nslots; s++) {
+    const double *p = partials + (size_t)s * T.nseg_all;
+    double v = 0;
+    for (int k = T.own_ptr[a] + lane; k < T.own_ptr[a + 1]; k += 64) v += p[k];
+    if (all_rows)
+      for (int k = T.nbr_ptr[a] + lane; k < T.nbr_ptr[a + 1]; k += 64) v += p[k];
+    v = wave_sum(v);
+    if (lane == 0) node_scalars[a * MAX_SLOTS + s] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Multifrontal SPD solve: one level of fronts per launch, one 64-lane wave per
+// (front, 64-row tile).  The front's right-hand side is staged through LDS in
+// chunks; W / WT are read coalesced (lane = row / column).
+// ---------------------------------------------------------------------------
+template <int D, int DOF>
+__device__ __forceinline__ size_t vaddr(int i) {
+  constexpr int RS = Dim<D>::RS;
+  if constexpr (DOF == 1) return (size_t)i * RS;
+  else return (size_t)(i / DOF) * RS + D + (size_t)(i % DOF) * D;
+}
+
+constexpr int SPD_CH = 128;
+
+template <int D, int DOF>
+__global__ __launch_bounds__(64) void k_spd_fwd(SpdDev S, int item0, const double *vec, double *ytmp) {
+  __shared__ double f[SPD_CH * D];
+  const int4 it = S.fwd_items[item0 + blockIdx.x];
+  const int s = it.x, tid = threadIdx.x, p = it.y + tid;
+  const bool valid = tid < it.z;
+  const int w = S.w[s], m = w + S.u[s];
+  const double *WT = S.WT + S.w_off[s];
+  const int *piv = S.piv_idx + S.piv_ptr[s];
+  const int pos0 = S.pos_off[s];
+  double acc[D];
+#pragma unroll
+  for (int c = 0; c < D; c++) acc[c] = 0.0;
+  for (int k0 = 0; k0 < w; k0 += SPD_CH) {
+    const int kn = min(SPD_CH, w - k0);
+    __syncthreads();
+    for (int kk = tid; kk < kn; kk += 64) {
+      const int k = k0 + kk;
+      double v[D];
+      const double *src = vec + vaddr<D, DOF>(piv[k]);
+#pragma unroll
+      for (int c = 0; c < D; c++) v[c] = src[c];
+      for (int a = S.asm_ptr[pos0 + k]; a < S.asm_ptr[pos0 + k + 1]; a++) {
+        const double *ub = S.ubuf + (size_t)S.asm_src[a] * D;
+#pragma unroll
+        for (int c = 0; c < D; c++) v[c] += ub[c];
+      }
+#pragma unroll
+      for (int c = 0; c < D; c++) f[kk * D + c] = v[c];
+    }
+    __syncthreads();
+    if (valid) {
+      const double *wp = WT + (size_t)k0 * m + p;
+      for (int kk = 0; kk < kn; kk++) {
+        const double wv = wp[(size_t)kk * m];
+#pragma unroll
+        for (int c = 0; c < D; c++) acc[c] = fma(wv, f[kk * D + c], acc[c]);
+      }
+    }
+  }
+  if (!valid) return;
+  if (p < w) {
+    double *dst = ytmp + (size_t)piv[p] * D;
+#pragma unroll
+    for (int c = 0; c < D; c++) dst[c] = acc[c];
+  } else {
+    for (int a = S.asm_ptr[pos0 + p]; a < S.asm_ptr[pos0 + p + 1]; a++) {
+      const double *ub = S.ubuf + (size_t)S.asm_src[a] * D;
+#pragma unroll
+      for (int c = 0; c < D; c++) acc[c] += ub[c];
+    }
+    double *dst = S.ubuf + (size_t)(S.ubuf_off[s] + p - w) * D;
+#pragma unroll
+    for (int c = 0; c < D; c++) dst[c] = acc[c];
+  }
+}
+
+template <int D, int DOF>
+__global__ __launch_bounds__(64) void k_spd_bwd(SpdDev S, int item0, double scale, const double *ytmp,
+                                                double *vec) {
+  __shared__ double f[SPD_CH * D];
+  const int4 it = S.bwd_items[item0 + blockIdx.x];
+  const int s = it.x, tid = threadIdx.x, k = it.y + tid;
+  const bool valid = tid < it.z;
+  const int w = S.w[s], m = w + S.u[s];
+  const double *W = S.W + S.w_off[s];
+  const int *piv = S.piv_idx + S.piv_ptr[s];
+  const int *upd = S.upd_idx + S.upd_ptr[s];
+  double acc[D];
+#pragma unroll
+  for (int c = 0; c < D; c++) acc[c] = 0.0;
+  for (int p0 = 0; p0 < m; p0 += SPD_CH) {
+    const int pn = min(SPD_CH, m - p0);
+    __syncthreads();
+    for (int pp = tid; pp < pn; pp += 64) {
+      const int p = p0 + pp;
+      // ancestors' entries were scaled when they were written: undo by linearity (scale is +-1)
+      const double sc = p < w ? 1.0 : scale;
+      const double *src = p < w ? ytmp + (size_t)piv[p] * D : vec + vaddr<D, DOF>(upd[p - w]);
+#pragma unroll
+      for (int c = 0; c < D; c++) f[pp * D + c] = sc * src[c];
+    }
+    __syncthreads();
+    if (valid) {
+      const double *wp = W + (size_t)p0 * w + k;
+      for (int pp = 0; pp < pn; pp++) {
+        const double wv = wp[(size_t)pp * w];
+#pragma unroll
+        for (int c = 0; c < D; c++) acc[c] = fma(wv, f[pp * D + c], acc[c]);
+      }
+    }
+  }
+  if (!valid) return;
+  double *dst = vec + vaddr<D, DOF>(piv[k]);
+#pragma unroll
+  for (int c = 0; c < D; c++) dst[c] = scale * acc[c];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// Launch wrappers
+// ---------------------------------------------------------------------------
+#define DPGO_DISPATCH_D(d, ...)            \
+  do {                                     \
+    if ((d) == 3) { constexpr int D = 3; __VA_ARGS__; } \
+    else { constexpr int D = 2; __VA_ARGS__; }          \
+  } while (0)
+
+static inline int nseg(const SegTable &T, bool all_rows) { return all_rows ? T.nseg_all : T.nseg_own; }
+
+void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, const int *mask, const BsrDev &A,
+                const double *x, bool in_rot_only, const double *addv, double *y, const double *dotv,
+                double coef, const double *dotadd, double *partials, int slot) {
+  const int nb = nseg(T, all_rows);
+  if (nb == 0) return;
+  double *part = (dotv && partials) ? partials + (size_t)slot * T.nseg_all : nullptr;
+  DPGO_DISPATCH_D(d, {
+    if (in_rot_only)
+      hipLaunchKernelGGL((k_bsr<D, true>), dim3(nb), dim3(256), 0, st, T.segs, mask, A, x, addv, y, dotv, coef,
+                         dotadd, part);
+    else
+      hipLaunchKernelGGL((k_bsr<D, false>), dim3(nb), dim3(256), 0, st, T.segs, mask, A, x, addv, y, dotv, coef,
+                         dotadd, part);
+  });
+}
+
+void launch_inter(int d, hipStream_t st, const SegTable &T, const int *mask, const InterEdgesDev &E, int loss,
+                  double loss_reg, int mode, bool quad, const double *Z, const double *Zprev,
+                  const double *Qdiag, const double *Ddiag, double *DfE, double *g, double *partials) {
+  const int nb = mode == 0 ? T.nseg_all : T.nseg_own;
+  if (nb == 0) return;
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_inter<D>), dim3(nb), dim3(256), 0, st, T.segs, mask, E, loss, loss_reg,
+                                        mode, quad ? 1 : 0, T.nseg_own, Z, Zprev, Qdiag, Ddiag, DfE, g, partials,
+                                        T.nseg_all));
+}
+
+void launch_proximal(int d, hipStream_t st, const SegTable &T, const int *mask, const double *Z, const double *Df,
+                     const double *Tinv, const double *N, const double *V, double *Xout, const double *Xref,
+                     double *partials, int slot) {
+  if (T.nseg_own == 0) return;
+  double *part = (Xref && partials) ? partials + (size_t)slot * T.nseg_all : nullptr;
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_proximal<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, Z, Df,
+                                        Tinv, N, V, Xout, part ? Xref : nullptr, part));
+}
+
+void launch_extrapolate(int d, hipStream_t st, const SegTable &T, bool all_rows, const int *mask,
+                        const double *gamma, const double *a, const double *b, double *out) {
+  const int nb = nseg(T, all_rows);
+  if (nb == 0) return;
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_extrapolate<D>), dim3(nb), dim3(256), 0, st, T.segs, mask, gamma, a, b,
+                                        out));
+}
+
+void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, const int *mask, double alpha,
+                  const double *a, double beta, const double *b, double *out, int part) {
+  const int nb = nseg(T, all_rows);
+  if (nb == 0) return;
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_axpby<D>), dim3(nb), dim3(256), 0, st, T.segs, mask, alpha, a, beta, b,
+                                        out, part));
+}
+
+void launch_dot(int d, hipStream_t st, const SegTable &T, bool all_rows, const int *mask, const double *a,
+                const double *b, int part, double *partials, int slot) {
+  const int nb = nseg(T, all_rows);
+  if (nb == 0) return;
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_dot<D>), dim3(nb), dim3(256), 0, st, T.segs, mask, a, b, part,
+                                        partials + (size_t)slot * T.nseg_all));
+}
+
+void launch_tangent_full(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
+                         const double *V, double *out, double *partials, int slot) {
+  if (T.nseg_own == 0) return;
+  double *part = partials ? partials + (size_t)slot * T.nseg_all : nullptr;
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_tangent_full<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, X,
+                                        V, out, part));
+}
+
+void launch_hess_epilogue(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
+                          const double *E, const double *nabla, const double *Rdot, double *out) {
+  if (T.nseg_own == 0) return;
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, 1, X, E,
+                                        nabla, Rdot, out));
+}
+
+void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
+                        const double *in, double *out) {
+  if (T.nseg_own == 0) return;
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, 0, X, in,
+                                        nullptr, nullptr, out));
+}
+
+void launch_retract_rot(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
+                        const double *V, double *out) {
+  if (T.nseg_own == 0) return;
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, 2, X, V,
+                                        nullptr, nullptr, out));
+}
+
+void launch_copy_indexed(int d, hipStream_t st, int count, const int *didx, const int *sidx, const double *src,
+                         double *dst) {
+  if (count == 0) return;
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_copy_indexed<D>), dim3((count + 255) / 256), dim3(256), 0, st, count,
+                                        didx, sidx, src, dst));
+}
+
+void launch_bdiag_dot(int d, hipStream_t st, const SegTable &T, const int *mask, const double *Dd, const double *x,
+                      double coef, const double *add, double addcoef, double *partials, int slot) {
+  if (T.nseg_own == 0) return;
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_bdiag_dot<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, Dd, x,
+                                        coef, add, addcoef, partials + (size_t)slot * T.nseg_all));
+}
+
+void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows, int nslots,
+                   const double *partials, double *node_scalars) {
+  hipLaunchKernelGGL(k_reduce, dim3(nnodes), dim3(64), 0, st, T, all_rows ? 1 : 0, nslots, partials, node_scalars);
+}
+
+void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int item0, int nitems,
+                      double *vec, double *ytmp, double scale) {
+  if (nitems == 0) return;
+  DPGO_DISPATCH_D(d, {
+    if (forward) {
+      if (dof == 1) hipLaunchKernelGGL((k_spd_fwd<D, 1>), dim3(nitems), dim3(64), 0, st, S, item0, vec, ytmp);
+      else hipLaunchKernelGGL((k_spd_fwd<D, D>), dim3(nitems), dim3(64), 0, st, S, item0, vec, ytmp);
+    } else {
+      if (dof == 1) hipLaunchKernelGGL((k_spd_bwd<D, 1>), dim3(nitems), dim3(64), 0, st, S, item0, scale, ytmp, vec);
+      else hipLaunchKernelGGL((k_spd_bwd<D, D>), dim3(nitems), dim3(64), 0, st, S, item0, scale, ytmp, vec);
+    }
+  });
+}
+
+}  // namespace dpgo

@@ -1,0 +1,391 @@
+#include "spd.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <functional>
+#include <numeric>
+#include <queue>
+
+namespace dpgo {
+namespace {
+
+struct TreeNode {
+  std::vector<int> verts;
+  int parent = -1;
+  std::vector<int> children;
+};
+
+// Nested dissection by BFS level structures (George's automatic ND): the middle
+// level of a breadth-first search from a pseudo-peripheral vertex is a vertex
+// separator, because edges only join equal or adjacent levels.
+struct Dissector {
+  const CsrMatrix &A;
+  int leaf;
+  std::vector<TreeNode> nodes;
+  std::vector<int> stamp, level, queue_;
+  int cur = 0;
+
+  Dissector(const CsrMatrix &A_, int leaf_) : A(A_), leaf(leaf_), stamp(A_.n, -1), level(A_.n, 0) {}
+
+  int make(std::vector<int> verts, int parent) {
+    TreeNode t;
+    t.verts = std::move(verts);
+    t.parent = parent;
+    nodes.push_back(std::move(t));
+    int id = (int)nodes.size() - 1;
+    if (parent >= 0) nodes[parent].children.push_back(id);
+    return id;
+  }
+
+  // BFS restricted to vertices with stamp == cur; returns number of levels and fills `order`.
+  int bfs(int root, std::vector<int> &order) {
+    order.clear();
+    order.push_back(root);
+    level[root] = 0;
+    stamp[root] = cur + 1;  // visited marker
+    size_t head = 0;
+    int maxlev = 0;
+    while (head < order.size()) {
+      int v = order[head++];
+      for (int k = A.ptr[v]; k < A.ptr[v + 1]; k++) {
+        int w = A.col[k];
+        if (stamp[w] != cur) continue;
+        stamp[w] = cur + 1;
+        level[w] = level[v] + 1;
+        maxlev = std::max(maxlev, level[w]);
+        order.push_back(w);
+      }
+    }
+    for (int v : order) stamp[v] = cur;  // unmark
+    return maxlev + 1;
+  }
+
+  void dissect(std::vector<int> verts, int parent) {
+    // split into connected components
+    cur += 2;
+    for (int v : verts) stamp[v] = cur;
+    std::vector<std::vector<int>> comps;
+    std::vector<int> order;
+    const int mark = cur;
+    for (int v : verts) {
+      if (stamp[v] != mark) continue;
+      bfs(v, order);
+      for (int w : order) stamp[w] = -1;  // remove from the set
+      comps.push_back(order);
+    }
+    for (auto &c : comps) dissect_connected(std::move(c), parent);
+  }
+
+  void dissect_connected(std::vector<int> verts, int parent) {
+    if ((int)verts.size() <= leaf) {
+      make(std::move(verts), parent);
+      return;
+    }
+    cur += 2;
+    for (int v : verts) stamp[v] = cur;
+    std::vector<int> order;
+    int root = verts[0];
+    int nlev = bfs(root, order);
+    for (int it = 0; it < 3; it++) {  // pseudo-peripheral vertex
+      int far = order.back();
+      int nl2 = bfs(far, order);
+      if (nl2 <= nlev) { nlev = nl2; break; }
+      nlev = nl2;
+    }
+    if (nlev < 3) {
+      make(std::move(verts), parent);
+      return;
+    }
+    std::vector<int> cnt(nlev, 0);
+    for (int v : order) cnt[level[v]]++;
+    const double total = (double)order.size();
+    int best = -1;
+    double cum = 0;
+    int half = 1;
+    for (int l = 0; l < nlev; l++) {
+      double lo = cum / total, hi = (cum + cnt[l]) / total;
+      if (lo <= 0.5 && hi >= 0.5) half = l;
+      if (l >= 1 && l <= nlev - 2 && lo >= 0.3 && hi <= 0.7) {
+        if (best < 0 || cnt[l] < cnt[best]) best = l;
+      }
+      cum += cnt[l];
+    }
+    if (best < 0) best = std::min(std::max(half, 1), nlev - 2);
+    std::vector<int> sep, lo, hi;
+    for (int v : order) {
+      if (level[v] == best) sep.push_back(v);
+      else if (level[v] < best) lo.push_back(v);
+      else hi.push_back(v);
+    }
+    int id = make(std::move(sep), parent);
+    dissect(std::move(lo), id);
+    dissect(std::move(hi), id);
+  }
+};
+
+}  // namespace
+
+int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf) {
+  const int n = A.n;
+  F = SpdFactor();
+  F.n = n;
+  // adjacency without the diagonal
+  CsrMatrix adj;
+  adj.n = n;
+  adj.ptr.assign(n + 1, 0);
+  for (int i = 0; i < n; i++)
+    for (int k = A.ptr[i]; k < A.ptr[i + 1]; k++)
+      if (A.col[k] != i) adj.ptr[i + 1]++;
+  for (int i = 0; i < n; i++) adj.ptr[i + 1] += adj.ptr[i];
+  adj.col.resize(adj.ptr[n]);
+  {
+    std::vector<int> pos(adj.ptr.begin(), adj.ptr.end() - 1);
+    for (int i = 0; i < n; i++)
+      for (int k = A.ptr[i]; k < A.ptr[i + 1]; k++)
+        if (A.col[k] != i) adj.col[pos[i]++] = A.col[k];
+  }
+  Dissector D(adj, leaf);
+  {
+    std::vector<int> all(n);
+    std::iota(all.begin(), all.end(), 0);
+    D.dissect(std::move(all), -1);
+  }
+  // drop empty separators (can appear when a level is empty) by keeping them: harmless (w = 0)
+  const int nt = (int)D.nodes.size();
+  // post-order
+  std::vector<int> post;  // tree node ids in post-order
+  post.reserve(nt);
+  {
+    std::vector<std::pair<int, int>> st;
+    for (int r = 0; r < nt; r++) {
+      if (D.nodes[r].parent != -1) continue;
+      st.push_back({r, 0});
+      while (!st.empty()) {
+        auto &top = st.back();
+        if (top.second < (int)D.nodes[top.first].children.size()) {
+          int c = D.nodes[top.first].children[top.second++];
+          st.push_back({c, 0});
+        } else {
+          post.push_back(top.first);
+          st.pop_back();
+        }
+      }
+    }
+  }
+  std::vector<int> fid_of_tree(nt);
+  for (int f = 0; f < nt; f++) fid_of_tree[post[f]] = f;
+  F.nfronts = nt;
+  F.w.resize(nt);
+  F.u.assign(nt, 0);
+  F.parent.assign(nt, -1);
+  std::vector<std::vector<int>> children(nt);
+  std::vector<int> front_of(n), elim_pos(n);
+  F.piv_ptr.assign(nt + 1, 0);
+  for (int f = 0; f < nt; f++) {
+    const TreeNode &t = D.nodes[post[f]];
+    F.w[f] = (int)t.verts.size();
+    F.piv_ptr[f + 1] = F.piv_ptr[f] + F.w[f];
+    if (t.parent >= 0) {
+      F.parent[f] = fid_of_tree[t.parent];
+      children[F.parent[f]].push_back(f);
+    }
+  }
+  F.piv_idx.resize(n);
+  for (int f = 0; f < nt; f++) {
+    std::vector<int> vs = D.nodes[post[f]].verts;
+    std::sort(vs.begin(), vs.end());
+    for (int k = 0; k < (int)vs.size(); k++) {
+      F.piv_idx[F.piv_ptr[f] + k] = vs[k];
+      front_of[vs[k]] = f;
+      elim_pos[vs[k]] = F.piv_ptr[f] + k;
+    }
+  }
+  // symbolic: update rows of each front, sorted by elimination position
+  std::vector<std::vector<int>> upd(nt);
+  {
+    std::vector<int> mark(n, -1);
+    for (int f = 0; f < nt; f++) {
+      std::vector<int> &us = upd[f];
+      for (int k = F.piv_ptr[f]; k < F.piv_ptr[f + 1]; k++) {
+        int v = F.piv_idx[k];
+        for (int e = adj.ptr[v]; e < adj.ptr[v + 1]; e++) {
+          int w = adj.col[e];
+          if (front_of[w] > f && mark[w] != f) { mark[w] = f; us.push_back(w); }
+        }
+      }
+      for (int c : children[f])
+        for (int w : upd[c])
+          if (front_of[w] > f && mark[w] != f) { mark[w] = f; us.push_back(w); }
+      std::sort(us.begin(), us.end(), [&](int a, int b) { return elim_pos[a] < elim_pos[b]; });
+      F.u[f] = (int)us.size();
+    }
+  }
+  F.upd_ptr.assign(nt + 1, 0);
+  F.w_off.assign(nt + 1, 0);
+  F.pos_off.assign(nt + 1, 0);
+  F.ubuf_off.assign(nt + 1, 0);
+  for (int f = 0; f < nt; f++) {
+    F.upd_ptr[f + 1] = F.upd_ptr[f] + F.u[f];
+    F.w_off[f + 1] = F.w_off[f] + (int64_t)(F.w[f] + F.u[f]) * F.w[f];
+    F.pos_off[f + 1] = F.pos_off[f] + F.w[f] + F.u[f];
+    F.ubuf_off[f + 1] = F.ubuf_off[f] + F.u[f];
+    F.max_front = std::max(F.max_front, F.w[f] + F.u[f]);
+  }
+  F.total_pos = F.pos_off[nt];
+  F.total_upd = F.ubuf_off[nt];
+  F.upd_idx.resize(F.upd_ptr[nt]);
+  for (int f = 0; f < nt; f++) std::copy(upd[f].begin(), upd[f].end(), F.upd_idx.begin() + F.upd_ptr[f]);
+  F.W.assign(F.w_off[nt], 0.0);
+  F.WT.assign(F.w_off[nt], 0.0);
+
+  // numeric multifrontal factorisation
+  std::vector<std::vector<double>> Umat(nt);
+  std::vector<int> loc(n, -1);
+  std::vector<std::vector<int>> asm_lists(F.total_pos);
+  std::vector<double> Fm, Linv, colk;
+  for (int f = 0; f < nt; f++) {
+    const int w = F.w[f], u = F.u[f], m = w + u;
+    const int *piv = &F.piv_idx[F.piv_ptr[f]];
+    const int *up = u ? &F.upd_idx[F.upd_ptr[f]] : nullptr;
+    for (int k = 0; k < w; k++) loc[piv[k]] = k;
+    for (int k = 0; k < u; k++) loc[up[k]] = w + k;
+    Fm.assign((size_t)m * m, 0.0);
+    for (int k = 0; k < w; k++) {
+      int v = piv[k];
+      for (int e = A.ptr[v]; e < A.ptr[v + 1]; e++) {
+        int l = loc[A.col[e]];
+        if (l >= k) Fm[(size_t)l * m + k] += A.val[e];
+      }
+    }
+    for (int c : children[f]) {
+      const int uc = F.u[c];
+      const int *upc = uc ? &F.upd_idx[F.upd_ptr[c]] : nullptr;
+      const std::vector<double> &Uc = Umat[c];
+      for (int a = 0; a < uc; a++) {
+        int la = loc[upc[a]];
+        asm_lists[F.pos_off[f] + la].push_back(F.ubuf_off[c] + a);
+        for (int b = 0; b <= a; b++) {
+          int lb = loc[upc[b]];
+          int r = std::max(la, lb), cc = std::min(la, lb);
+          Fm[(size_t)r * m + cc] += Uc[(size_t)a * uc + b];
+        }
+      }
+      std::vector<double>().swap(Umat[c]);
+    }
+    // dense partial Cholesky of the first w columns (lower triangle)
+    for (int k = 0; k < w; k++) {
+      double dkk = Fm[(size_t)k * m + k];
+      if (!(dkk > 0.0)) {
+        fprintf(stderr, "[dpgo_amd] ERROR: spd_factor: non-positive pivot %g (front %d, col %d)\n", dkk, f, k);
+        return -1;
+      }
+      double lkk = std::sqrt(dkk);
+      Fm[(size_t)k * m + k] = lkk;
+      double inv = 1.0 / lkk;
+      colk.resize(m);
+      for (int i = k + 1; i < m; i++) colk[i] = (Fm[(size_t)i * m + k] *= inv);
+      const double *ck = colk.data();
+#pragma omp parallel for schedule(static) if (m - k > 256)
+      for (int i = k + 1; i < m; i++) {
+        double lik = ck[i];
+        if (lik == 0.0) continue;
+        double *row = &Fm[(size_t)i * m];
+        for (int j = k + 1; j <= i; j++) row[j] -= lik * ck[j];
+      }
+    }
+    // Schur complement for the parent
+    if (u) {
+      Umat[f].resize((size_t)u * u);
+      for (int a = 0; a < u; a++)
+        for (int b = 0; b <= a; b++) Umat[f][(size_t)a * u + b] = Fm[(size_t)(w + a) * m + (w + b)];
+    }
+    // Linv = L11^-1 (lower triangular)
+    Linv.assign((size_t)w * w, 0.0);
+    for (int j = 0; j < w; j++) {
+      Linv[(size_t)j * w + j] = 1.0 / Fm[(size_t)j * m + j];
+      for (int i = j + 1; i < w; i++) {
+        double s = 0;
+        for (int k = j; k < i; k++) s += Fm[(size_t)i * m + k] * Linv[(size_t)k * w + j];
+        Linv[(size_t)i * w + j] = -s / Fm[(size_t)i * m + i];
+      }
+    }
+    double *Wf = &F.W[F.w_off[f]];
+    double *WTf = &F.WT[F.w_off[f]];
+    for (int i = 0; i < w; i++)
+      for (int j = 0; j <= i; j++) Wf[(size_t)i * w + j] = Linv[(size_t)i * w + j];
+    for (int a = 0; a < u; a++) {
+      const double *l21 = &Fm[(size_t)(w + a) * m];
+      for (int j = 0; j < w; j++) {
+        double s = 0;
+        for (int k = j; k < w; k++) s += l21[k] * Linv[(size_t)k * w + j];
+        Wf[(size_t)(w + a) * w + j] = -s;
+      }
+    }
+    for (int p = 0; p < m; p++)
+      for (int k = 0; k < w; k++) WTf[(size_t)k * m + p] = Wf[(size_t)p * w + k];
+    for (int k = 0; k < w; k++) loc[piv[k]] = -1;
+    for (int k = 0; k < u; k++) loc[up[k]] = -1;
+  }
+  F.asm_ptr.assign(F.total_pos + 1, 0);
+  for (int p = 0; p < F.total_pos; p++) F.asm_ptr[p + 1] = F.asm_ptr[p] + (int)asm_lists[p].size();
+  F.asm_src.resize(F.asm_ptr[F.total_pos]);
+  for (int p = 0; p < F.total_pos; p++)
+    std::copy(asm_lists[p].begin(), asm_lists[p].end(), F.asm_src.begin() + F.asm_ptr[p]);
+  // levels
+  F.height.assign(nt, 0);
+  F.depth.assign(nt, 0);
+  for (int f = 0; f < nt; f++)
+    if (F.parent[f] >= 0) F.height[F.parent[f]] = std::max(F.height[F.parent[f]], F.height[f] + 1);
+  for (int f = nt - 1; f >= 0; f--)
+    if (F.parent[f] >= 0) F.depth[f] = F.depth[F.parent[f]] + 1;
+  int maxh = 0, maxd = 0;
+  for (int f = 0; f < nt; f++) { maxh = std::max(maxh, F.height[f]); maxd = std::max(maxd, F.depth[f]); }
+  F.by_height.assign(maxh + 1, {});
+  F.by_depth.assign(maxd + 1, {});
+  for (int f = 0; f < nt; f++) {
+    if (F.w[f] == 0 && F.u[f] == 0) continue;
+    F.by_height[F.height[f]].push_back(f);
+    F.by_depth[F.depth[f]].push_back(f);
+  }
+  return 0;
+}
+
+void spd_solve_host(const SpdFactor &F, double *X, int nc) {
+  std::vector<double> ubuf((size_t)F.total_upd * nc, 0.0), f, out;
+  for (int s = 0; s < F.nfronts; s++) {  // post-order == forward order
+    const int w = F.w[s], u = F.u[s], m = w + u;
+    const int *piv = &F.piv_idx[F.piv_ptr[s]];
+    f.assign((size_t)m * nc, 0.0);
+    for (int p = 0; p < m; p++) {
+      for (int c = 0; c < nc; c++) f[(size_t)p * nc + c] = p < w ? X[(size_t)piv[p] * nc + c] : 0.0;
+      for (int a = F.asm_ptr[F.pos_off[s] + p]; a < F.asm_ptr[F.pos_off[s] + p + 1]; a++)
+        for (int c = 0; c < nc; c++) f[(size_t)p * nc + c] += ubuf[(size_t)F.asm_src[a] * nc + c];
+    }
+    const double *Wf = &F.W[F.w_off[s]];
+    for (int p = 0; p < m; p++)
+      for (int c = 0; c < nc; c++) {
+        double acc = p < w ? 0.0 : f[(size_t)p * nc + c];
+        for (int k = 0; k < w; k++) acc += Wf[(size_t)p * w + k] * f[(size_t)k * nc + c];
+        if (p < w) X[(size_t)piv[p] * nc + c] = acc;
+        else ubuf[(size_t)(F.ubuf_off[s] + p - w) * nc + c] = acc;
+      }
+  }
+  for (int s = F.nfronts - 1; s >= 0; s--) {
+    const int w = F.w[s], u = F.u[s], m = w + u;
+    const int *piv = &F.piv_idx[F.piv_ptr[s]];
+    const int *up = u ? &F.upd_idx[F.upd_ptr[s]] : nullptr;
+    f.assign((size_t)m * nc, 0.0);
+    for (int p = 0; p < m; p++)
+      for (int c = 0; c < nc; c++) f[(size_t)p * nc + c] = X[(size_t)(p < w ? piv[p] : up[p - w]) * nc + c];
+    const double *Wf = &F.W[F.w_off[s]];
+    out.assign((size_t)w * nc, 0.0);
+    for (int p = 0; p < m; p++)
+      for (int k = 0; k < w; k++)
+        for (int c = 0; c < nc; c++) out[(size_t)k * nc + c] += Wf[(size_t)p * w + k] * f[(size_t)p * nc + c];
+    for (int k = 0; k < w; k++)
+      for (int c = 0; c < nc; c++) X[(size_t)piv[k] * nc + c] = out[(size_t)k * nc + c];
+  }
+}
+
+}  // namespace dpgo

@@ -1,0 +1,56 @@
+// Sparse SPD direct solver: nested-dissection multifrontal Cholesky.
+//
+// Replaces the reference's CHOLMOD factorisations `L_` (of G_tt) and
+// `reg_Chol_precon_` (of G_RR + lambda I): C++/DPGO/src/DPGOProblem.cpp:93,119;
+// solves at DPGOProblem.h:291, DPGOProblem.cpp:140,568,592.
+//
+// MI355X-first design: the factorisation happens once on the host (setup, as in
+// the reference); what runs per MM iteration is the SOLVE, and a level-scheduled
+// sparse triangular solve is latency-poison on a GPU.  So every front s stores
+//     W_s = [ L11^-1 ; -L21 L11^-1 ]        ((w+u) x w, dense)
+// which turns both sweeps into dense mat-vecs with no triangular dependency
+// inside a front:
+//     forward :  [y_s ; dupd] = W_s f_s          (f_s = rhs + children's updates)
+//     backward:  x_s = W_s^T [y_s ; x_upd]
+// Fronts of the same tree height (forward) / depth (backward) are independent and
+// run in one launch; each front's update vector is pulled (not pushed) by its
+// parent through precomputed gather lists, so the solve is deterministic and
+// atomic-free.  W is kept in both orientations so both sweeps read coalesced.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace dpgo {
+
+struct CsrMatrix {
+  int n = 0;
+  std::vector<int> ptr, col;
+  std::vector<double> val;
+};
+
+struct SpdFactor {
+  int n = 0;
+  int nfronts = 0;
+  std::vector<int> w, u;                 // pivots / update rows per front
+  std::vector<int> piv_ptr, piv_idx;     // CSR: matrix indices of the pivots
+  std::vector<int> upd_ptr, upd_idx;     // CSR: matrix indices of the update rows
+  std::vector<int64_t> w_off;            // offset of W_s / WT_s in W / WT
+  std::vector<double> W;                 // (w+u) x w row-major per front
+  std::vector<double> WT;                // w x (w+u) row-major per front
+  std::vector<int> parent, height, depth;
+  std::vector<int> pos_off;              // first "front position" of each front (w+u positions each)
+  std::vector<int> ubuf_off;             // first row of each front's update vector in the update buffer
+  std::vector<int> asm_ptr, asm_src;     // per front position: rows of the update buffer to add
+  std::vector<std::vector<int>> by_height, by_depth;
+  int total_pos = 0, total_upd = 0, max_front = 0;
+  int64_t nnz() const { return (int64_t)W.size(); }
+};
+
+// Factor A (symmetric positive definite, full pattern in CSR).  leaf = max
+// vertices of a nested-dissection leaf.  Returns 0, or -1 if a pivot is not positive.
+int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf = 32);
+
+// Host solve (setup paths and tests): X (n x ncols, row-major) <- A^-1 X.
+void spd_solve_host(const SpdFactor &F, double *X, int ncols);
+
+}  // namespace dpgo

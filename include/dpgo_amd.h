@@ -1,0 +1,157 @@
+/* dpgo_amd -- C ABI of the MI355X-native DPGO hot path.
+ *
+ * Drop-in boundary for the per-node MM / AMM inner step of the reference's
+ * `dist_pgo` (MurpheyLab/DPGO).  Plain pointers and sizes only; the caller owns
+ * host buffers, the library owns device memory behind opaque handles.  Every
+ * function returns 0 on success and -1 on error (with a line on stderr), which
+ * is the reference's own convention (`return -1` + LOG(ERROR), e.g.
+ * C++/DPGO/include/DPGO/DPGOHash.h:43-47, C++/DPGO/include/DPGO/DPGO_utils.h:402-406).
+ *
+ * Matrices X are column-major with an explicit leading dimension, in the
+ * reference layout: rows [0,n) translations t_i^T, rows [n + d i, n + d i + d)
+ * the block R_i^T (C++/DPGO/include/DPGO/DPGOProblem.h:167-171).  The
+ * conversion to the pose-contiguous device layout happens inside the library.
+ *
+ * A "group" is the set of nodes hosted by one GPU / one process; it replaces a
+ * std::vector<std::shared_ptr<DPGOHash>> restricted to those nodes, and its
+ * batched calls replace the driver's `for (alpha...) dpgo_hash[alpha]->...()`
+ * loops (C++/examples/dist_pgo.cpp:455-462, 496-521).
+ */
+#ifndef DPGO_AMD_H
+#define DPGO_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* DPGO::Options -- C++/DPGO/include/DPGO/DPGO_types.h:78-201 (same names, same defaults). */
+typedef struct dpgo_options {
+  int scheme;                 /* 0 = Scheme::MM, 1 = Scheme::AMM */
+  double regularizer;
+  double accepted_delta;
+  double eta[2];
+  double psi;
+  double phi;
+  int max_soft_restart_hits[2];
+  int oscillation_cnt_period;
+  int max_oscillations;
+  int loss;                   /* 0 None, 1 Huber, 2 GemanMcClure, 3 Welsch */
+  double loss_reg;
+  double grad_norm_tol;
+  double rel_func_decrease_tol;
+  double stepsize_tol;
+  int max_iterations;
+  int max_iterations_accepted;
+  double reg_Cholesky_precon_max_condition_number;
+  double preconditioned_grad_norm_tol;
+  int max_tCG_iterations;
+  double STPCG_kappa;
+  double STPCG_theta;
+  int preconditioner;         /* 0 None, 1 RegularizedCholesky */
+} dpgo_options_t;
+
+/* The scalar part of DPGOResult -- C++/DPGO/include/DPGO/DPGO_types.h:204-322. */
+typedef struct dpgo_results {
+  int updated;
+  int iters;
+  double gradFnorm;
+  double fobjE;
+  double Fk[2];
+  double Gk;
+  double Gkh;
+  double fobj;                /* fobj[iters] */
+  double f;                   /* f[iters] */
+  double gamma;
+  double s[2];                /* s[iters], s[iters+1] */
+  int soft_restart_hits[2];
+  int num_oscillations;
+  int refined;                /* whether the last iterate() ran the TNT refinement */
+  int tnt_status;             /* TNTStatus of that run (TNT.h:134-164), -1 if none */
+  int tnt_inner_iterations;
+  int restarts;
+} dpgo_results_t;
+
+typedef struct dpgo_graph dpgo_graph_t;
+typedef struct dpgo_group dpgo_group_t;
+
+/* Options() defaults, and the overrides of C++/examples/dist_pgo.cpp:103-120. */
+void dpgo_options_default(dpgo_options_t *opt);
+void dpgo_options_driver(dpgo_options_t *opt, int loss, int accelerated);
+
+/* DPGO::read_g2o -- C++/DPGO/include/DPGO/DPGO_utils.h:49-51, C++/DPGO/src/DPGO_utils.cpp:140-202. */
+int dpgo_read_g2o(const char *filename, int num_nodes, dpgo_graph_t **out);
+/* The same partition applied to measurements already in memory (tail I, head J global pose ids,
+ * R row-major d x d, t d). */
+int dpgo_graph_from_edges(int d, int num_poses, int m, const int *I, const int *J, const double *R,
+                          const double *t, const double *kappa, const double *tau, int num_nodes,
+                          dpgo_graph_t **out);
+void dpgo_graph_free(dpgo_graph_t *g);
+int dpgo_graph_info(const dpgo_graph_t *g, int *d, int *num_poses, int *num_nodes, int *num_edges);
+/* copies the parsed measurements (file order); any output pointer may be NULL */
+int dpgo_graph_edges(const dpgo_graph_t *g, int *I, int *J, double *R, double *t, double *kappa, double *tau);
+/* DPGOProblem::n() / m() -- C++/DPGO/include/DPGO/DPGOProblem.h:241-248 (host only) */
+int dpgo_graph_node_sizes(const dpgo_graph_t *g, int node, int *n0, int *n1, int *m0, int *m1);
+/* neighbour ordering of generate_data_info (C++/DPGO/src/DPGO_utils.cpp:400-418): n1 (node, pose) pairs */
+int dpgo_graph_node_neighbours(const dpgo_graph_t *g, int node, int *nbr_node, int *nbr_pose);
+/* first global pose id of a node (g_index[node].begin()->second, dist_pgo.cpp:470) */
+int dpgo_graph_node_offset(const dpgo_graph_t *g, int node);
+/* Centralised chordal initialisation -- C++/examples/dist_pgo.cpp:416-444
+ * (C++/SESync/src/SESync_utils.cpp:573-652).  Host, set-up only.  X: (d+1)N x d. */
+int dpgo_chordal_initialization(const dpgo_graph_t *g, double *X, int ld);
+
+/* DPGOHash(node, measurements, options) for every node in node_ids -- C++/DPGO/src/DPGOHash.cpp:11-18,
+ * C++/DPGO/src/DPGOProblem.cpp:11-125.  Fails (-1) when no HIP device is present: there is no CPU path. */
+int dpgo_group_create(const dpgo_graph_t *g, const int *node_ids, int num_local, const dpgo_options_t *opt,
+                      int device, dpgo_group_t **out);
+void dpgo_group_free(dpgo_group_t *grp);
+
+/* DPGOHash::initialize -- C++/DPGO/src/DPGOHash.cpp:20-43.  X: (d+1)(n0+n1) x d. */
+int dpgo_group_initialize(dpgo_group_t *grp, int local, const double *X, int ld);
+/* Split a global X over the nodes and fill neighbour rows -- dist_pgo.cpp:435-446 + DPGO::communicate. */
+int dpgo_group_initialize_global(dpgo_group_t *grp, const double *X, int ld);
+/* DPGOHash::update / iterate -- C++/DPGO/src/DPGOHash.cpp:84-228, 583-628.  locals == NULL: every node. */
+int dpgo_group_update(dpgo_group_t *grp, const int *locals, int n);
+int dpgo_group_iterate(dpgo_group_t *grp, const int *locals, int n);
+/* DPGOHash::communicate -- C++/DPGO/include/DPGO/DPGOHash.h:28-86 -- for neighbours hosted by this group. */
+int dpgo_group_communicate_local(dpgo_group_t *grp);
+/* Boundary exchange with other groups (the message of DPGOHash::receive, DPGOHash.cpp:45-82):
+ * pack this group's exported poses into a device buffer of num_sent * (d+1)*d doubles, all-gather
+ * the buffers of all groups (RCCL), then unpack.  Keys are (node, pose). */
+int dpgo_group_num_sent(const dpgo_group_t *grp);
+int dpgo_group_sent_keys(const dpgo_group_t *grp, int *nodes, int *poses);
+int dpgo_group_set_recv_layout(dpgo_group_t *grp, int nranks, int stride, const int *counts, const int *nodes,
+                               const int *poses);
+int dpgo_group_pack_sent(dpgo_group_t *grp, void *device_buffer);
+int dpgo_group_unpack_recv(dpgo_group_t *grp, const void *device_gathered);
+
+/* results().Xk / results().Xak -- DPGO_types.h:207-214 */
+int dpgo_group_get_Xk(const dpgo_group_t *grp, int local, double *X, int ld);
+int dpgo_group_get_Xak(const dpgo_group_t *grp, int local, double *X, int ld);
+/* gather X^alpha into the global X -- dist_pgo.cpp:502-511 */
+int dpgo_group_scatter_global(const dpgo_group_t *grp, double *X, int ld);
+int dpgo_group_results(const dpgo_group_t *grp, int local, dpgo_results_t *out);
+int dpgo_group_node_id(const dpgo_group_t *grp, int local);
+int dpgo_group_sync(const dpgo_group_t *grp);
+void *dpgo_group_stream(const dpgo_group_t *grp);   /* hipStream_t all work is enqueued on */
+
+/* ---- test hooks ------------------------------------------------------------------------- */
+/* Host: the assembled operator `name` in {"G","S","P","P0","Q","D"} of a node as COO triplets in
+ * the REFERENCE row/column order.  Call with rows == NULL to get the count. */
+int dpgo_debug_node_matrix(const dpgo_graph_t *g, int node, const dpgo_options_t *opt, const char *name,
+                           int *rows, int *cols, double *vals);
+/* Host: the proximal coefficients T (n0), N (n0 x d), V (n0 x d x d). */
+int dpgo_debug_node_proximal(const dpgo_graph_t *g, int node, const dpgo_options_t *opt, double *T, double *N,
+                             double *V);
+/* Host: multifrontal factor + solve of a CSR SPD matrix, X (n x ncols row-major) <- A^-1 X. */
+int dpgo_debug_spd_solve(int n, const int *ptr, const int *col, const double *val, double *X, int ncols,
+                         int leaf);
+/* Device: single operators of one node on reference-layout inputs:
+ *  "project" (d n0 x d -> nearest rotations), "solve_tt" ((d+1) n0 x d, translation rows),
+ *  "solve_rr" (rotation rows), "G" ((d+1) n0 x d -> G X), "proximal" (in = [Z ; Df] stacked). */
+int dpgo_group_debug_apply(dpgo_group_t *grp, int local, const char *op, const double *in, int ld_in,
+                           double *out, int ld_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPGO_AMD_H */

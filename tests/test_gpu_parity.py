@@ -1,0 +1,164 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle on the same inputs."""
+import os
+
+import numpy as np
+import pytest
+
+import dpgo_amd
+from oracle import g2o as og
+from oracle.hash import Options as OOptions
+from oracle.problem import LOSS_HUBER, LOSS_NONE, LOSS_WELSCH, LOSS_GM, project_to_SOdn
+from oracle.star import DistPGO as ODistPGO, chordal_initialization
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_opts(loss, acc, **kw):
+    o = OOptions.driver(loss, acc)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def _pair(fixtures_dir, name, nn, loss, acc, **kw):
+    path = os.path.join(fixtures_dir, name + ".g2o")
+    num_poses, mm = og.read_g2o_file(path)
+    X0 = chordal_initialization(num_poses, mm)
+    orc = ODistPGO(path, nn, _oracle_opts(loss, acc, **kw), X0=X0, mm=mm, num_poses=num_poses)
+    G = dpgo_amd.read_g2o(path, nn)
+    gpu = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(loss, acc, **kw), X0=X0)
+    return orc, gpu
+
+
+def test_projection_kernel(fixtures_dir):
+    """k_rot_op(mode 2) == nearest rotation (polar factor with det fix), incl. reflections and
+    near-singular inputs.  Tolerance 1e-12 absolute on orthonormal outputs."""
+    G = dpgo_amd.read_g2o(os.path.join(fixtures_dir, "sphere2500.g2o"), 1)
+    grp = dpgo_amd.NodeGroup(G, [0], dpgo_amd.Options.driver())
+    n0 = 2500
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((n0, 3, 3))
+    A[:200] *= 1e-3
+    A[200:400] *= 1e3
+    q, _ = np.linalg.qr(rng.standard_normal((400, 3, 3)))
+    A[400:800] = q + 1e-6 * rng.standard_normal((400, 3, 3))       # near rotations / reflections
+    A[800:1000] = np.einsum("nij,nj->nij", q[:200], np.array([3.0, 2.0, 1e-9]))   # nearly rank 2
+    A[1000] = 2 * np.eye(3)
+    A[1001] = np.diag([1.0, 1.0, -1.0])
+    out = grp.debug_apply(0, "project", A.reshape(3 * n0, 3), 3 * n0).reshape(n0, 3, 3)
+    ref = project_to_SOdn(A.reshape(3 * n0, 3), 3).reshape(n0, 3, 3)
+    np.testing.assert_allclose(np.einsum("nij,nkj->nik", out, out), np.broadcast_to(np.eye(3), (n0, 3, 3)), atol=1e-13)
+    np.testing.assert_allclose(np.linalg.det(out), 1.0, atol=1e-13)
+    # where the projection is well conditioned the two must agree tightly
+    s = np.linalg.svd(A, compute_uv=False)
+    well = (s[:, 1] + s[:, 2] * np.sign(np.linalg.det(A))) > 1e-3 * s[:, 0]
+    assert well.sum() > 2000
+    np.testing.assert_allclose(out[well], ref[well], atol=1e-10)
+    # everywhere: same distance to the input (the projection may be non-unique, the distance is not)
+    d_out = np.linalg.norm((out - A).reshape(n0, -1), axis=1)
+    d_ref = np.linalg.norm((ref - A).reshape(n0, -1), axis=1)
+    np.testing.assert_allclose(d_out, d_ref, rtol=1e-9, atol=1e-12)
+
+
+def test_device_spd_solves_and_G(fixtures_dir):
+    from oracle.problem import DPGOProblem
+    path = os.path.join(fixtures_dir, "smallGrid3D.g2o")
+    num_poses, mm = og.read_g2o_file(path)
+    _, meas, _ = og.partition_measurements(num_poses, mm, 2)
+    G = dpgo_amd.read_g2o(path, 2)
+    opt = dpgo_amd.Options.driver()
+    grp = dpgo_amd.NodeGroup(G, [0, 1], opt)
+    rng = np.random.default_rng(2)
+    for a in range(2):
+        p = DPGOProblem(a, meas[a], opt.regularizer, LOSS_NONE, opt.reg_Cholesky_precon_max_condition_number, 0.25)
+        n0 = p.n[0]
+        X = rng.standard_normal((4 * n0, 3))
+        out = grp.debug_apply(a, "G", X, 4 * n0)
+        np.testing.assert_allclose(out, p.mat.G @ X, rtol=1e-12, atol=1e-9)
+        out = grp.debug_apply(a, "solve_tt", X, 4 * n0)
+        np.testing.assert_allclose(out[:n0], p.L.solve(X[:n0]), rtol=1e-9, atol=1e-9)
+        out = grp.debug_apply(a, "solve_rr", X, 4 * n0)
+        ref = p.precon.solve(X[n0:])
+        np.testing.assert_allclose(out[n0:], ref, rtol=1e-6, atol=1e-8 * abs(ref).max())
+
+
+CASES = [
+    ("smallGrid3D", 2, LOSS_NONE, False, 30),    # BASELINE config 1 (MM-PGO, trivial)
+    ("smallGrid3D", 2, LOSS_NONE, True, 40),
+    ("smallGrid3D", 3, LOSS_HUBER, True, 40),
+    ("smallGrid3D", 2, LOSS_WELSCH, True, 25),
+    ("tinyGrid3D", 2, LOSS_GM, True, 15),
+]
+
+
+@pytest.mark.parametrize("name,nn,loss,acc,iters", CASES)
+def test_trace_matches_oracle(fixtures_dir, name, nn, loss, acc, iters):
+    """Per-iteration parity of the whole state machine (TNT refinement included): per-node fobj, Gk,
+    gradFnorm within 1e-7 relative, poses within 1e-6 absolute, after every outer iteration."""
+    orc, gpu = _pair(fixtures_dir, name, nn, loss, acc)
+    for it in range(iters):
+        orc.step(evaluate=False)
+        assert gpu.step() == 0
+        for a in range(nn):
+            ro, rg = orc.nodes[a].results, gpu.group.results(a)
+            assert rg.iters == ro.iters
+            assert bool(rg.refined) == bool(ro.refined), (it, a)
+            np.testing.assert_allclose(rg.fobj, ro.fobj[0], rtol=1e-7, err_msg="fobj it=%d node=%d" % (it, a))
+            np.testing.assert_allclose(rg.Gk, ro.Gk, rtol=1e-7, err_msg="Gk it=%d node=%d" % (it, a))
+            np.testing.assert_allclose(rg.gradFnorm, ro.gradFnorm, rtol=1e-5, atol=1e-7)
+            assert list(rg.soft_restart_hits) == list(ro.soft_restart_hits)
+            np.testing.assert_allclose(gpu.group[a].Xk(), ro.Xk, atol=1e-6, err_msg="Xk it=%d node=%d" % (it, a))
+    Fo = orc.star.evaluate_f(orc.gather())
+    Fg = orc.star.evaluate_f(gpu.X())
+    assert abs(Fg - Fo) <= 1e-6 * abs(Fo)          # north_star: same objective within 1e-6 relative
+
+
+def test_no_refine_path(fixtures_dir):
+    """max_iterations = 0 disables the TNT branch (DPGOHash.cpp:351-355): pure proximal + solve path."""
+    orc, gpu = _pair(fixtures_dir, "smallGrid3D", 2, LOSS_HUBER, True, max_iterations=0)
+    for it in range(60):
+        orc.step(evaluate=False)
+        assert gpu.step() == 0
+    for a in range(2):
+        np.testing.assert_allclose(gpu.group.results(a).fobj, orc.nodes[a].results.fobj[0], rtol=1e-8)
+        np.testing.assert_allclose(gpu.group[a].Xk(), orc.nodes[a].results.Xk, atol=1e-7)
+
+
+def test_se2_path(fixtures_dir):
+    orc, gpu = _pair(fixtures_dir, "M3500", 4, LOSS_NONE, True)
+    for it in range(15):
+        orc.step(evaluate=False)
+        assert gpu.step() == 0
+    for a in range(4):
+        np.testing.assert_allclose(gpu.group.results(a).fobj, orc.nodes[a].results.fobj[0], rtol=1e-7)
+    Fo = orc.star.evaluate_f(orc.gather())
+    assert abs(orc.star.evaluate_f(gpu.X()) - Fo) <= 1e-6 * abs(Fo)
+
+
+def test_invariants_at_scale(fixtures_dir):
+    """Size-independent properties on sphere2500 / 4 nodes (no oracle trace): sum_a fobj^a == F(X)
+    (Appendix B-1), rotations stay in SO(3), MM-PGO decreases F monotonically (B-3)."""
+    path = os.path.join(fixtures_dir, "sphere2500.g2o")
+    G = dpgo_amd.read_g2o(path, 4)
+    gpu = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(LOSS_NONE, False))
+    num_poses, mm = og.read_g2o_file(path)
+    from oracle.star import GlobalProblem
+    star = GlobalProblem(num_poses, mm, 4, OOptions.driver(LOSS_NONE, False))
+    prev = np.inf
+    for it in range(12):
+        assert gpu.step() == 0
+        X = gpu.X()
+        F = star.evaluate_f(X)
+        assert abs(gpu.sum_fobj() - F) <= 1e-8 * F
+        assert F <= prev * (1 + 1e-12)
+        prev = F
+        R = X[num_poses:].reshape(num_poses, 3, 3)
+        np.testing.assert_allclose(np.einsum("nij,nkj->nik", R, R), np.broadcast_to(np.eye(3), R.shape), atol=1e-12)
+
+
+def test_error_conventions(fixtures_dir):
+    G = dpgo_amd.read_g2o(os.path.join(fixtures_dir, "tinyGrid3D.g2o"), 2)
+    grp = dpgo_amd.NodeGroup(G, [0, 1], dpgo_amd.Options.driver())
+    assert grp[0].initialize(np.zeros((3, 3))) == -1            # inconsistent size -> -1
+    with pytest.raises(IOError):
+        dpgo_amd.read_g2o("/nonexistent.g2o", 2)

@@ -1,0 +1,125 @@
+"""CPU tests of the product's HOST logic against the oracle (no GPU, no compute kernels):
+loader + partition, operator assembly, proximal coefficients, the multifrontal SPD solver's
+set-up path and the chordal initialisation.  Also checks that the C-ABI library loads and
+exports every symbol declared in include/dpgo_amd.h."""
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import dpgo_amd
+from oracle import g2o as og
+from oracle.assemble import assemble_node
+from oracle.problem import LOSS_HUBER, LOSS_NONE
+from oracle.star import chordal_initialization, GlobalProblem
+from oracle.hash import Options as OOptions
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(os.path.dirname(dpgo_amd._HERE), "include", "dpgo_amd.h")).read()
+    declared = set(re.findall(r"\b(dpgo_[a-z_A-Z0-9]+)\s*\(", hdr))
+    assert declared == set(dpgo_amd.SYMBOLS), declared ^ set(dpgo_amd.SYMBOLS)
+    L = dpgo_amd.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+@pytest.mark.parametrize("name,nn", [("tinyGrid3D", 2), ("smallGrid3D", 2), ("sphere2500", 3), ("M3500", 4)])
+def test_loader_and_partition(fixtures_dir, name, nn):
+    path = os.path.join(fixtures_dir, name + ".g2o")
+    G = dpgo_amd.read_g2o(path, nn)
+    num_poses, mm = og.read_g2o_file(path)
+    assert (G.d, G.num_poses, G.num_edges) == (mm.d, num_poses, len(mm))
+    I, J, R, t, kap, tau = G.edges()
+    np.testing.assert_array_equal(I, mm.ipose)
+    np.testing.assert_array_equal(J, mm.jpose)
+    np.testing.assert_allclose(R, mm.R, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(t, mm.t, rtol=0, atol=0)
+    np.testing.assert_allclose(kap, mm.kappa, rtol=1e-14)
+    np.testing.assert_allclose(tau, mm.tau, rtol=1e-14)
+    _, meas, g_index = og.partition_measurements(num_poses, mm, nn)
+    for a in range(nn):
+        info = og.generate_data_info(a, meas[a])
+        assert G.node_sizes(a) == (info.n[0], info.n[1], info.m[0], info.m[1])
+        nb_node, nb_pose = G.node_neighbours(a)
+        want = sorted((b, p) for b, v in info.index.items() if b != a for p in v)
+        assert list(zip(nb_node.tolist(), nb_pose.tolist())) == want
+        assert G.node_offset(a) == g_index[a][0]
+
+
+def test_appendix_c_partition_sizes(fixtures_dir):
+    """SURVEY.md Appendix C."""
+    G = dpgo_amd.read_g2o(os.path.join(fixtures_dir, "smallGrid3D.g2o"), 2)
+    assert [G.node_sizes(a) for a in range(2)] == [(63, 25, 135, 30), (62, 25, 132, 30)]
+    G = dpgo_amd.read_g2o(os.path.join(fixtures_dir, "M3500.g2o"), 4)
+    assert [G.node_sizes(a) for a in range(4)] == [(875, 203, 1259, 258), (875, 211, 1249, 285),
+                                                   (875, 255, 1161, 310), (875, 83, 1305, 105)]
+    G = dpgo_amd.read_g2o(os.path.join(fixtures_dir, "sphere2500.g2o"), 1)
+    assert G.node_sizes(0) == (2500, 0, 4949, 0)
+
+
+@pytest.mark.parametrize("name,nn,loss", [("smallGrid3D", 2, LOSS_NONE), ("smallGrid3D", 3, LOSS_HUBER),
+                                          ("M3500", 4, LOSS_NONE), ("M3500", 4, LOSS_HUBER)])
+def test_operator_assembly_matches_oracle(fixtures_dir, name, nn, loss):
+    path = os.path.join(fixtures_dir, name + ".g2o")
+    G = dpgo_amd.read_g2o(path, nn)
+    opt = dpgo_amd.Options.driver(loss)
+    num_poses, mm = og.read_g2o_file(path)
+    _, meas, _ = og.partition_measurements(num_poses, mm, nn)
+    for a in range(nn):
+        info = og.generate_data_info(a, meas[a])
+        ref = assemble_node(info, mm.d, opt.regularizer, loss == LOSS_NONE)
+        names = ["G", "D", "Q"] + (["S", "P", "P0"] if loss == LOSS_NONE else [])
+        for nm in names:
+            mine = G.node_matrix(a, opt, nm)
+            want = getattr(ref, nm)
+            diff = abs(mine - want)
+            scale = abs(want).max()
+            assert diff.max() <= 1e-13 * scale, (nm, a, diff.max(), scale)
+        T, N, V = G.node_proximal(a, opt)
+        n0, d = info.n[0], mm.d
+        np.testing.assert_allclose(T, ref.T, rtol=1e-13)
+        Nref = ref.N.toarray()
+        Vref = (ref.V if loss != LOSS_NONE else None)
+        for i in range(n0):
+            np.testing.assert_allclose(N[i], Nref[i, i * d:(i + 1) * d], rtol=1e-12, atol=1e-12)
+        if Vref is not None:
+            Vd = Vref.toarray()
+            for i in range(n0):
+                np.testing.assert_allclose(V[i], Vd[i * d:(i + 1) * d, i * d:(i + 1) * d], rtol=1e-12, atol=1e-9)
+
+
+def test_spd_solver_host_path(fixtures_dir):
+    """The multifrontal factorisation (set-up path) solves G_tt and G_RR + lambda I exactly."""
+    path = os.path.join(fixtures_dir, "sphere2500.g2o")
+    num_poses, mm = og.read_g2o_file(path)
+    _, meas, _ = og.partition_measurements(num_poses, mm, 2)
+    info = og.generate_data_info(1, meas[1])
+    ref = assemble_node(info, 3, 1e-11, True)
+    rng = np.random.default_rng(0)
+    for A in (ref.Gtt, ref.GRR + 1e-3 * sp.eye(ref.GRR.shape[0])):
+        B = rng.standard_normal((A.shape[0], 3))
+        X = dpgo_amd.spd_solve_host(A, B)
+        r = np.linalg.norm(A @ X - B) / np.linalg.norm(B)
+        assert r < 1e-11, r
+
+
+def test_spd_solver_disconnected_and_tiny():
+    A = sp.block_diag([sp.csr_matrix(np.array([[4.0, 1, 0], [1, 3, 1], [0, 1, 5]])), sp.csr_matrix([[2.0]])]).tocsr()
+    B = np.arange(8.0).reshape(4, 2)
+    X = dpgo_amd.spd_solve_host(A, B, leaf=1)
+    np.testing.assert_allclose(A @ X, B, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["smallGrid3D", "M3500"])
+def test_chordal_initialization_matches_oracle(fixtures_dir, name):
+    path = os.path.join(fixtures_dir, name + ".g2o")
+    G = dpgo_amd.read_g2o(path, 1)
+    X = G.chordal_initialization()
+    num_poses, mm = og.read_g2o_file(path)
+    Xo = chordal_initialization(num_poses, mm)
+    np.testing.assert_allclose(X, Xo, atol=2e-8)
+    star = GlobalProblem(num_poses, mm, 1, OOptions.driver())
+    assert abs(star.evaluate_f(X) - star.evaluate_f(Xo)) <= 1e-8 * abs(star.evaluate_f(Xo))
