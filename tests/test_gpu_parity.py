@@ -42,7 +42,7 @@ def test_projection_kernel(fixtures_dir):
     A[200:400] *= 1e3
     q, _ = np.linalg.qr(rng.standard_normal((400, 3, 3)))
     A[400:800] = q + 1e-6 * rng.standard_normal((400, 3, 3))       # near rotations / reflections
-    A[800:1000] = np.einsum("nij,nj->nij", q[:200], np.array([3.0, 2.0, 1e-9]))   # nearly rank 2
+    A[800:1000] = q[:200] * np.array([3.0, 2.0, 1e-9])   # nearly rank 2
     A[1000] = 2 * np.eye(3)
     A[1001] = np.diag([1.0, 1.0, -1.0])
     out = grp.debug_apply(0, "project", A.reshape(3 * n0, 3), 3 * n0).reshape(n0, 3, 3)
