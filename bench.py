@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- AMM-PGO# outer MM iterations per second on the headline synthetic pose graph.
+
+Workload (BASELINE.json config 4): synthetic SE(3) lattice 50x50x40 = 100 000
+poses / 400 000 edges, Huber loss (delta = 0.25, Static rescale), AMM-PGO#, num_nodes = 8 with the
+reference's contiguous partition, driver options of C++/examples/dist_pgo.cpp:103-120, centralised
+chordal initialisation (untimed set-up).  With N GPUs each rank hosts 8/N nodes, so every N runs the
+SAME algorithmic trajectory (scaling = "strong").  One step = one outer iteration of all 8 nodes:
+iterate() -> boundary-pose exchange -> update()  (dist_pgo.cpp:496-521).
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0) with the throughput, a `roofline` object for the dominant kernel family
+(per-launch durations measured with HIP events on the launch stream in an instrumented pass that
+repeats the timed region) and, at N = 1, a `cpu_baseline` object (the oracle timed on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nodes", type=int, default=8)
+    ap.add_argument("--grid", type=str, default="50,50,40,400000")
+    ap.add_argument("--loss", type=str, default="huber")
+    ap.add_argument("--prof-steps", type=int, default=5)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-prof", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import dpgo_amd
+    from dpgo_amd import synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.nodes % world != 0:
+        raise SystemExit("num_nodes must be divisible by the number of GPUs")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- set-up (untimed): graph, partition, chordal initialisation, operators, factorizations
+    t0 = time.time()
+    nx, ny, nz, ne = (int(v) for v in args.grid.split(","))
+    g = synthetic.grid(nx, ny, nz, ne, seed=synthetic.HEADLINE["seed"])
+    G = dpgo_amd.graph_from_edges(3, g["num_poses"], g["I"], g["J"], g["R"], g["t"], g["kappa"], g["tau"], args.nodes)
+    loss = dpgo_amd.LOSS_NAMES[args.loss]
+    opt = dpgo_amd.Options.driver(loss, True)
+    X0 = G.chordal_initialization()
+    t_init = time.time() - t0
+    per = args.nodes // world
+    my_nodes = list(range(rank * per, (rank + 1) * per))
+    t0 = time.time()
+    grp = dpgo_amd.NodeGroup(G, my_nodes, opt, device=local_rank)
+    t_group = time.time() - t0
+    if grp.initialize_global(X0) != 0:
+        raise SystemExit("initialize failed")
+
+    RS = (G.d + 1) * G.d
+    send = gathered = None
+    if world > 1:
+        keys = grp.sent_keys()
+        allkeys = [None] * world
+        dist.all_gather_object(allkeys, (keys[0].tolist(), keys[1].tolist()))
+        stride = max(max(len(k[0]) for k in allkeys), 1)
+        grp.set_recv_layout(stride, [(np.asarray(k[0], np.int32), np.asarray(k[1], np.int32)) for k in allkeys])
+        send = torch.zeros(stride * RS, dtype=torch.float64, device="cuda")
+        gathered = torch.zeros(world * stride * RS, dtype=torch.float64, device="cuda")
+
+    def exchange():
+        grp.communicate_local()
+        if world > 1:
+            grp.pack_sent(send.data_ptr())
+            grp.sync()                                   # pack runs on the group's stream
+            dist.all_gather_into_tensor(gathered, send)  # RCCL over xGMI
+            torch.cuda.current_stream().synchronize()
+            grp.unpack_recv(gathered.data_ptr())
+
+    def step():
+        rc = grp.iterate()
+        exchange()
+        rc |= grp.update()
+        if rc != 0:
+            raise SystemExit("step failed")
+
+    def barrier():
+        grp.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    grp.update()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    # objective after the timed region: sum_a fobj^a == F
+    fsum = sum(grp.results(k).fobj for k in range(len(grp)))
+    refined = sum(int(grp.results(k).refined) for k in range(len(grp)))
+    inner = sum(int(grp.results(k).tnt_inner_iterations) for k in range(len(grp)))
+    if world > 1:
+        tt = torch.tensor([fsum, refined, inner], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt)
+        fsum, refined, inner = (float(v) for v in tt.tolist())
+
+    # ---- instrumented pass: per-launch kernel durations with HIP events on the launch stream
+    roofline = None
+    kernels = {}
+    if not args.no_prof and args.prof_steps > 0:
+        dpgo_amd.prof_enable(True)
+        for _ in range(args.prof_steps):
+            step()
+        barrier()
+        stats = dpgo_amd.prof_collect()
+        dpgo_amd.prof_enable(False)
+        tot = sum(v[0] for v in stats.values())
+        for name, (ms, by, cnt) in sorted(stats.items(), key=lambda kv: -kv[1][0]):
+            if cnt:
+                kernels[name] = dict(ms_per_step=ms / args.prof_steps, launches_per_step=cnt / args.prof_steps,
+                                     avg_us=1e3 * ms / cnt, algo_MB_per_launch=by / cnt / 1e6,
+                                     GBps=(by / 1e9) / (ms / 1e3) if ms > 0 else 0.0, share=ms / tot)
+        dom = max(stats.items(), key=lambda kv: kv[1][0])
+        ms, by, cnt = dom[1]
+        ach = (by / 1e9) / (ms / 1e3)
+        roofline = dict(kernel=dom[0], bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=ach / HBM_PEAK_GBS, traffic=None, avg_launch_us=1e3 * ms / cnt,
+                        algorithmic_bytes_per_launch=by / cnt, launches_per_step=cnt / args.prof_steps)
+
+    # ---- CPU baseline: the oracle (numpy/scipy restatement) on a bounded sample, rank 0, N = 1 only
+    cpu = None
+    if world == 1 and not args.no_cpu and args.cpu_steps > 0:
+        cpu = cpu_baseline(g, args.nodes, loss, X0, args.cpu_steps)
+
+    if rank == 0:
+        out = {
+            "metric": "AMM-PGO# outer MM iterations/sec, SE(3) PGO, synthetic 100k-pose/400k-edge graph, 8 nodes",
+            "value": args.steps / elapsed, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "synthetic SE(3) lattice %dx%dx%d, %d poses / %d edges, %s loss, AMM-PGO#, "
+                                   "num_nodes=%d (%d per GPU), chordal init" % (nx, ny, nz, g["num_poses"], len(g["I"]),
+                                                                             args.loss, args.nodes, per),
+                       "num_nodes": args.nodes, "nodes_per_gpu": per, "loss": args.loss,
+                       "iterations_before_timed_region": args.warmup,
+                       "refined_nodes_last_step": refined, "tnt_inner_iterations_last_step": inner},
+            "objective_2F": 2 * fsum,
+            "setup_s": {"graph+chordal_init": t_init, "operators+factorizations": t_group},
+            "solver": grp.solver_stats(),
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(g, num_nodes, loss, X0, steps):
+    """The oracle timed on the host cores, bounded sample: ONE node (an interior slab) of the 8,
+    `steps` x (iterate + update), neighbour poses frozen.  Timing scope as in the reference driver
+    (sum of iterate()+update(), dist_pgo.cpp:496-521); whole-job rate = 1 / (num_nodes * t_node)."""
+    from oracle.g2o import Measurements, partition_measurements
+    from oracle.hash import DPGOHash, Options as OOptions
+    z = np.zeros(len(g["I"]), np.int64)
+    mm = Measurements(z, g["I"], z, g["J"], g["R"], g["t"], g["kappa"], g["tau"])
+    N, d = g["num_poses"], 3
+    _, meas, g_index = partition_measurements(N, mm, num_nodes)
+    a = num_nodes // 2
+    o = OOptions.driver(loss, True)
+    t0 = time.time()
+    nd = DPGOHash(a, meas[a], o)
+    t_setup = time.time() - t0
+    p = nd.problem
+    n0, n1 = p.n
+    Z = np.zeros(((d + 1) * (n0 + n1), d))
+    q, inc_n = N // num_nodes, N - num_nodes * (N // num_nodes)
+    start = lambda b: b * (q + 1) if b < inc_n else inc_n * (q + 1) + (b - inc_n) * q
+    for b, poses in p.info.index.items():
+        for pose, (blk, k) in poses.items():
+            gid = start(b) + pose
+            if blk == 0:
+                Z[k] = X0[gid]
+                Z[n0 + k * d: n0 + k * d + d] = X0[N + gid * d: N + gid * d + d]
+            else:
+                Z[(d + 1) * n0 + k] = X0[gid]
+                r0 = (d + 1) * n0 + n1 + k * d
+                Z[r0:r0 + d] = X0[N + gid * d: N + gid * d + d]
+    nd.initialize(Z)
+    nd.update()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        nd.iterate()
+        nd.update()
+    t_node = (time.perf_counter() - t0) / steps
+    return {"value": 1.0 / (num_nodes * t_node), "unit": "iters/s", "cores": 1, "kind": "port",
+            "sample": "oracle (numpy/scipy restatement), node %d of %d (n0=%d, n1=%d), %d x (iterate+update), "
+                      "neighbours frozen; whole-job rate = 1/(%d * %.3f s); oracle set-up %.1f s untimed"
+                      % (a, num_nodes, n0, n1, steps, num_nodes, t_node, t_setup)}
+
+
+if __name__ == "__main__":
+    main()

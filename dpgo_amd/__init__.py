@@ -109,6 +109,11 @@ SYMBOLS = {
     "dpgo_group_node_id": (C.c_int, [C.c_void_p, C.c_int]),
     "dpgo_group_sync": (C.c_int, [C.c_void_p]),
     "dpgo_group_stream": (C.c_void_p, [C.c_void_p]),
+    "dpgo_prof_enable": (C.c_int, [C.c_int]),
+    "dpgo_prof_num_kinds": (C.c_int, []),
+    "dpgo_prof_kind_name": (C.c_char_p, [C.c_int]),
+    "dpgo_prof_collect": (C.c_int, [_DP, _DP, C.POINTER(C.c_long)]),
+    "dpgo_group_solver_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long), _IP, _IP]),
     "dpgo_debug_node_matrix": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Options), C.c_char_p, _IP, _IP, _DP]),
     "dpgo_debug_node_proximal": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Options), _DP, _DP, _DP]),
     "dpgo_debug_spd_solve": (C.c_int, [C.c_int, _IP, _IP, _DP, _DP, C.c_int, C.c_int]),
@@ -245,6 +250,18 @@ def spd_solve_host(A_csr, B, leaf=32):
     return X
 
 
+def prof_enable(on):
+    lib().dpgo_prof_enable(int(bool(on)))
+
+
+def prof_collect():
+    """{kernel family: (total_ms, algorithmic_bytes, launches)} since prof_enable(True)."""
+    n = lib().dpgo_prof_num_kinds()
+    ms, by, cnt = np.zeros(n), np.zeros(n), np.zeros(n, np.int64)
+    lib().dpgo_prof_collect(_dp(ms), _dp(by), cnt.ctypes.data_as(C.POINTER(C.c_long)))
+    return {lib().dpgo_prof_kind_name(k).decode(): (float(ms[k]), float(by[k]), int(cnt[k])) for k in range(n)}
+
+
 class NodeGroup:
     """The DPGOHash objects of the nodes hosted by one GPU (one process)."""
 
@@ -325,6 +342,11 @@ class NodeGroup:
         r = Results()
         lib().dpgo_group_results(self._h, k, C.byref(r))
         return r
+
+    def solver_stats(self):
+        a, b, c, d = C.c_long(), C.c_long(), C.c_int(), C.c_int()
+        lib().dpgo_group_solver_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        return dict(nnz_tt=a.value, nnz_rr=b.value, levels_tt=c.value, levels_rr=d.value)
 
     def debug_apply(self, k, op, X, out_rows):
         X, ld = _fcol(X)

@@ -283,6 +283,22 @@ int dpgo_debug_spd_solve(int n, const int *ptr, const int *col, const double *va
   return 0;
 }
 
+int dpgo_prof_enable(int on) { dpgo::prof_enable(on != 0); if (on) dpgo::prof_reset(); return 0; }
+int dpgo_prof_num_kinds(void) { return dpgo::PK_COUNT; }
+const char *dpgo_prof_kind_name(int k) {
+  static const char *names[] = {"k_bsr", "k_inter", "k_proximal", "k_axpby", "k_dot", "k_rot_op", "k_copy_indexed",
+                                "k_bdiag_dot", "k_reduce", "k_spd_fwd", "k_spd_bwd"};
+  return (k >= 0 && k < dpgo::PK_COUNT) ? names[k] : "";
+}
+int dpgo_prof_collect(double *ms, double *bytes, long *count) { dpgo::prof_collect(ms, bytes, count); return 0; }
+int dpgo_group_solver_stats(const dpgo_group_t *h, long *nnz_tt, long *nnz_rr, int *levels_tt, int *levels_rr) {
+  *nnz_tt = (long)h->grp->factor_tt().nnz();
+  *nnz_rr = (long)h->grp->factor_rr().nnz();
+  *levels_tt = (int)h->grp->factor_tt().by_height.size();
+  *levels_rr = (int)h->grp->factor_rr().by_height.size();
+  return 0;
+}
+
 int dpgo_group_debug_apply(dpgo_group_t *h, int local, const char *op, const double *in, int ld_in, double *out,
                            int ld_out) {
   return h->grp->debug_apply(local, op, in, ld_in, out, ld_out);

@@ -55,17 +55,41 @@ void SpdSolverDev::upload(int dcols) {
   ytmp.alloc((size_t)std::max(F.n, 1) * dcols);
   std::vector<int4> fi, bi;
   fwd_level_ptr.assign(1, 0);
+  fwd_level_bytes.clear();
+  bwd_level_bytes.clear();
+  // algorithmic bytes of one level: every front entry once (8 B) + its in/out vector entries
+  auto lvl_bytes = [&](const std::vector<int> &lvl) {
+    double b = 0;
+    for (int f : lvl) b += 8.0 * (double)(F.w[f] + F.u[f]) * F.w[f] + 2.0 * 8.0 * dcols * (F.w[f] + F.u[f]);
+    return b;
+  };
+  for (const auto &lvl : F.by_height) fwd_level_bytes.push_back(lvl_bytes(lvl));
+  for (const auto &lvl : F.by_depth) bwd_level_bytes.push_back(lvl_bytes(lvl));
+  // per level: first the tiles of small fronts (one wave each), then the tiles of wide fronts
+  // (8 waves each, columns / rows split between the waves)
+  auto wide = [&](int f) { return F.w[f] > 2 * 128; };
+  fwd_big_ptr.clear();
+  bwd_big_ptr.clear();
   for (const auto &lvl : F.by_height) {
-    for (int f : lvl) {
-      const int m = F.w[f] + F.u[f];
-      for (int r = 0; r < m; r += 64) fi.push_back(make_int4(f, r, std::min(64, m - r), 0));
+    for (int pass = 0; pass < 2; pass++) {
+      if (pass == 1) fwd_big_ptr.push_back((int)fi.size());
+      for (int f : lvl) {
+        if ((int)wide(f) != pass) continue;
+        const int m = F.w[f] + F.u[f];
+        for (int r = 0; r < m; r += 64) fi.push_back(make_int4(f, r, std::min(64, m - r), 0));
+      }
     }
     fwd_level_ptr.push_back((int)fi.size());
   }
   bwd_level_ptr.assign(1, 0);
   for (const auto &lvl : F.by_depth) {
-    for (int f : lvl)
-      for (int c = 0; c < F.w[f]; c += 64) bi.push_back(make_int4(f, c, std::min(64, F.w[f] - c), 0));
+    for (int pass = 0; pass < 2; pass++) {
+      if (pass == 1) bwd_big_ptr.push_back((int)bi.size());
+      for (int f : lvl) {
+        if ((int)wide(f) != pass) continue;
+        for (int c = 0; c < F.w[f]; c += 64) bi.push_back(make_int4(f, c, std::min(64, F.w[f] - c), 0));
+      }
+    }
     bwd_level_ptr.push_back((int)bi.size());
   }
   fwd_items.upload(fi);
@@ -201,12 +225,17 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
     T_.segs = segs_.p;
     T_.nseg_own = nown;
     T_.nseg_all = (int)segs.size();
+    T_.rows_own = P0_;
+    T_.rows_all = P0_ + P1_;
     T_.own_ptr = own_seg_ptr_.p;
     T_.nbr_ptr = nbr_seg_ptr_.p;
   }
-  mask_.alloc(L);
+  mask_ring_.alloc((size_t)RING * L);
+  coef_ring_.alloc((size_t)RING * L);
   gamma_.alloc(L);
-  HIP_CHECK(hipHostMalloc((void **)&h_mask_, sizeof(int) * std::max(L, 1)));
+  HIP_CHECK(hipHostMalloc((void **)&h_mask_, sizeof(int) * std::max(L, 1) * RING));
+  HIP_CHECK(hipHostMalloc((void **)&h_coef_, sizeof(double) * std::max(L, 1) * RING));
+  cur_mask_ = mask_ring_.p;
   HIP_CHECK(hipHostMalloc((void **)&h_scal_, sizeof(double) * std::max(L, 1) * MAX_SLOTS));
   HIP_CHECK(hipHostMalloc((void **)&h_gamma_, sizeof(double) * std::max(L, 1)));
   partials_.alloc((size_t)MAX_SLOTS * std::max(T_.nseg_all, 1));
@@ -269,6 +298,7 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
     }
     e_tail_.upload(tail); e_head_.upload(head); e_R_.upload(R); e_t_.upload(t); e_kappa_.upload(kap);
     e_tau_.upload(tau); e_inc_ptr_.upload(iptr); e_inc_.upload(iv);
+    E_.nrows_own = P0_; E_.nrows_all = P0_ + P1_;
     E_.m = (int)tail.size(); E_.tail = e_tail_.p; E_.head = e_head_.p; E_.R = e_R_.p; E_.t = e_t_.p;
     E_.kappa = e_kappa_.p; E_.tau = e_tau_.p; E_.inc_ptr = e_inc_ptr_.p; E_.inc = e_inc_.p;
   }
@@ -344,6 +374,7 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
 
 Group::~Group() {
   if (h_mask_) (void)hipHostFree(h_mask_);
+  if (h_coef_) (void)hipHostFree(h_coef_);
   if (h_scal_) (void)hipHostFree(h_scal_);
   if (h_gamma_) (void)hipHostFree(h_gamma_);
   if (st_) (void)hipStreamDestroy(st_);
@@ -374,6 +405,7 @@ void Group::upload_bsr(const std::vector<const BsrMatrix *> &per_node, bool rows
   out.col.upload(col);
   out.val.upload(val);
   out.dev.nrows = nrows;
+  out.dev.nnzb = ptr[nrows];
   out.dev.ptr = out.ptr.p;
   out.dev.col = out.col.p;
   out.dev.val = out.val.p;
@@ -382,15 +414,26 @@ void Group::upload_bsr(const std::vector<const BsrMatrix *> &per_node, bool rows
 void Group::sync() const { HIP_CHECK(hipStreamSynchronize(st_)); }
 
 void Group::set_mask(const std::vector<int> &locals) {
-  // the previous mask upload may still be in flight: the stream orders uploads and kernels, and
-  // h_mask_ is only rewritten after a synchronising fetch() or at the start of an API call
   if (locals == last_mask_) return;
   last_mask_ = locals;
-  HIP_CHECK(hipStreamSynchronize(st_));
   const int L = num_local();
-  for (int a = 0; a < L; a++) h_mask_[a] = 0;
-  for (int a : locals) h_mask_[a] = 1;
-  HIP_CHECK(hipMemcpyAsync(mask_.p, h_mask_, sizeof(int) * L, hipMemcpyHostToDevice, st_));
+  mask_slot_ = (mask_slot_ + 1) % RING;
+  int *h = h_mask_ + (size_t)mask_slot_ * L;
+  for (int a = 0; a < L; a++) h[a] = 0;
+  for (int a : locals) h[a] = 1;
+  int *dptr = mask_ring_.p + (size_t)mask_slot_ * L;
+  HIP_CHECK(hipMemcpyAsync(dptr, h, sizeof(int) * L, hipMemcpyHostToDevice, st_));
+  cur_mask_ = dptr;
+}
+
+const double *Group::upload_coef(const std::vector<double> &per_node) {
+  const int L = num_local();
+  coef_slot_ = (coef_slot_ + 1) % RING;
+  double *h = h_coef_ + (size_t)coef_slot_ * L;
+  for (int a = 0; a < L; a++) h[a] = per_node[a];
+  double *dptr = coef_ring_.p + (size_t)coef_slot_ * L;
+  HIP_CHECK(hipMemcpyAsync(dptr, h, sizeof(double) * L, hipMemcpyHostToDevice, st_));
+  return dptr;
 }
 
 void Group::fetch(int nslots, bool all_rows) {
@@ -400,18 +443,24 @@ void Group::fetch(int nslots, bool all_rows) {
 }
 
 void Group::copy_rows(double *dst, const double *src, bool all_rows, int part) {
-  launch_axpby(d_, st_, T_, all_rows, mask_.p, 1.0, src, 0.0, nullptr, dst, part);
+  launch_axpby(d_, st_, T_, all_rows, cur_mask_, 1.0, src, 0.0, nullptr, dst, part);
 }
 
 static void spd_run(int d, hipStream_t st, SpdSolverDev &S, double *vec, double scale) {
   const int nf = (int)S.fwd_level_ptr.size() - 1;
-  for (int l = 0; l < nf; l++)
-    launch_spd_level(d, S.dof, st, S.dev, true, S.fwd_level_ptr[l], S.fwd_level_ptr[l + 1] - S.fwd_level_ptr[l], vec,
-                     S.ytmp.p, scale);
+  for (int l = 0; l < nf; l++) {
+    const int a = S.fwd_level_ptr[l], mid = S.fwd_big_ptr[l], b = S.fwd_level_ptr[l + 1];
+    const double bytes = S.fwd_level_bytes[l], tot = std::max(b - a, 1);
+    launch_spd_level(d, S.dof, st, S.dev, true, a, mid - a, vec, S.ytmp.p, scale, bytes * (mid - a) / tot, 1);
+    launch_spd_level(d, S.dof, st, S.dev, true, mid, b - mid, vec, S.ytmp.p, scale, bytes * (b - mid) / tot, 8);
+  }
   const int nb = (int)S.bwd_level_ptr.size() - 1;
-  for (int l = 0; l < nb; l++)
-    launch_spd_level(d, S.dof, st, S.dev, false, S.bwd_level_ptr[l], S.bwd_level_ptr[l + 1] - S.bwd_level_ptr[l], vec,
-                     S.ytmp.p, scale);
+  for (int l = 0; l < nb; l++) {
+    const int a = S.bwd_level_ptr[l], mid = S.bwd_big_ptr[l], b = S.bwd_level_ptr[l + 1];
+    const double bytes = S.bwd_level_bytes[l], tot = std::max(b - a, 1);
+    launch_spd_level(d, S.dof, st, S.dev, false, a, mid - a, vec, S.ytmp.p, scale, bytes * (mid - a) / tot, 1);
+    launch_spd_level(d, S.dof, st, S.dev, false, mid, b - mid, vec, S.ytmp.p, scale, bytes * (b - mid) / tot, 8);
+  }
 }
 
 void Group::solve_tt(double *vec, double scale) { spd_run(d_, st_, Ltt_, vec, scale); }
@@ -419,14 +468,14 @@ void Group::solve_rr(double *vec, double scale) { spd_run(d_, st_, Lrr_, vec, sc
 
 // X.t = -G_tt^-1 (g_t + G_tR X.R)    (DPGOProblem.h:275-294)
 void Group::recover_translations(double *X, const double *g) {
-  launch_bsr(d_, st_, T_, false, mask_.p, G_.dev, X, true, g, T1_.p, nullptr, 0.0, nullptr, nullptr, 0);
+  launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, X, true, g, T1_.p, nullptr, 0.0, nullptr, nullptr, 0);
   solve_tt(T1_.p, -1.0);
   copy_rows(X, T1_.p, false, 1);
 }
 
 // partial[slot] = tr(X^T (g + 1/2 G X))     (DPGOProblem.cpp:180-205; + f on the host)
 void Group::eval_G(const double *X, const double *g, int slot) {
-  launch_bsr(d_, st_, T_, false, mask_.p, G_.dev, X, false, nullptr, nullptr, X, 0.5, g, partials_.p, slot);
+  launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, X, false, nullptr, nullptr, X, 0.5, g, partials_.p, slot);
 }
 
 // ---------------------------------------------------------------------------
@@ -644,13 +693,13 @@ int Group::update(const std::vector<int> &locals_in) {
   for (int a : locals) (res_[a].iters == 0 ? first : later).push_back(a);
   if (trivial) {
     // g = S Z  (evaluate_none_g_and_f0 / _f, DPGOProblem.cpp:269-287, 516-542)
-    launch_bsr(d_, st_, T_, false, mask_.p, S_.dev, Zc_.p, false, nullptr, gc_.p, nullptr, 0, nullptr, nullptr, 0);
+    launch_bsr(d_, st_, T_, false, cur_mask_, S_.dev, Zc_.p, false, nullptr, gc_.p, nullptr, 0, nullptr, nullptr, 0);
     if (!first.empty()) {
       set_mask(first);
-      launch_bsr(d_, st_, T_, true, mask_.p, P0m_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 0);
+      launch_bsr(d_, st_, T_, true, cur_mask_, P0m_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 0);
       // fobj = G(Xak | g, f0): slot 1; also Dfobj = g + G Xak
-      launch_bsr(d_, st_, T_, false, mask_.p, G_.dev, Xak_.p, false, gc_.p, Dfc_.p, Xak_.p, 0.5, gc_.p, partials_.p, 1);
-      launch_tangent_full(d_, st_, T_, mask_.p, Xak_.p, Dfc_.p, nullptr, partials_.p, 2);
+      launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xak_.p, false, gc_.p, Dfc_.p, Xak_.p, 0.5, gc_.p, partials_.p, 1);
+      launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, Dfc_.p, nullptr, partials_.p, 2);
       fetch(3, true);
       for (int a : first) {
         const double f0 = scal(a, 0);
@@ -659,11 +708,11 @@ int Group::update(const std::vector<int> &locals_in) {
     }
     if (!later.empty()) {
       set_mask(later);
-      launch_axpby(d_, st_, T_, true, mask_.p, 1.0, Zc_.p, -1.0, Zp_.p, Tall_.p, 0);
-      launch_bsr(d_, st_, T_, true, mask_.p, Q_.dev, Tall_.p, false, nullptr, nullptr, Tall_.p, 0.5, nullptr, partials_.p, 0);
-      launch_bsr(d_, st_, T_, true, mask_.p, P_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 1);
-      launch_bsr(d_, st_, T_, false, mask_.p, G_.dev, Xak_.p, false, gc_.p, Dfc_.p, nullptr, 0, nullptr, nullptr, 0);
-      launch_tangent_full(d_, st_, T_, mask_.p, Xak_.p, Dfc_.p, nullptr, partials_.p, 2);
+      launch_axpby(d_, st_, T_, true, cur_mask_, 1.0, Zc_.p, -1.0, Zp_.p, Tall_.p, 0);
+      launch_bsr(d_, st_, T_, true, cur_mask_, Q_.dev, Tall_.p, false, nullptr, nullptr, Tall_.p, 0.5, nullptr, partials_.p, 0);
+      launch_bsr(d_, st_, T_, true, cur_mask_, P_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 1);
+      launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xak_.p, false, gc_.p, Dfc_.p, nullptr, 0, nullptr, nullptr, 0);
+      launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, Dfc_.p, nullptr, partials_.p, 2);
       fetch(3, true);
       for (int a : later) {
         const double fobj = res_[a].Gk + scal(a, 0);
@@ -676,11 +725,11 @@ int Group::update(const std::vector<int> &locals_in) {
       const std::vector<int> &set = pass == 0 ? first : later;
       if (set.empty()) continue;
       set_mask(set);
-      launch_inter(d_, st_, T_, mask_.p, E_, opt_.loss, opt_.loss_reg, 0, pass == 1, Zc_.p, Zp_.p, Qd_.p, Dd_.p, DfE_.p,
+      launch_inter(d_, st_, T_, cur_mask_, E_, opt_.loss, opt_.loss_reg, 0, pass == 1, Zc_.p, Zp_.p, Qd_.p, Dd_.p, DfE_.p,
                    gc_.p, partials_.p);
-      launch_bsr(d_, st_, T_, false, mask_.p, G_.dev, Zc_.p, false, gc_.p, Dfc_.p, Zc_.p, 0.5, gc_.p, partials_.p, 2);
-      if (pass == 0) launch_bdiag_dot(d_, st_, T_, mask_.p, Dd_.p, Zc_.p, 0.5, DfE_.p, -1.0, partials_.p, 3);
-      launch_tangent_full(d_, st_, T_, mask_.p, Xak_.p, Dfc_.p, nullptr, partials_.p, 4);
+      launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Zc_.p, false, gc_.p, Dfc_.p, Zc_.p, 0.5, gc_.p, partials_.p, 2);
+      if (pass == 0) launch_bdiag_dot(d_, st_, T_, cur_mask_, Dd_.p, Zc_.p, 0.5, DfE_.p, -1.0, partials_.p, 3);
+      launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, Dfc_.p, nullptr, partials_.p, 4);
       fetch(5, true);
       for (int a : set) {
         NodeResults &r = res_[a];
@@ -726,7 +775,7 @@ int Group::iterate(const std::vector<int> &locals) {
 int Group::mm(const std::vector<int> &locals) {
   const Options &o = opt_;
   set_mask(locals);
-  launch_proximal(d_, st_, T_, mask_.p, Zc_.p, Dfc_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, nullptr, nullptr, 0);
+  launch_proximal(d_, st_, T_, cur_mask_, Zc_.p, Dfc_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, nullptr, nullptr, 0);
   recover_translations(Xakh_.p, gc_.p);
   copy_rows(Xak_.p, Xakh_.p, false);
   std::vector<int> plain;
@@ -736,8 +785,12 @@ int Group::mm(const std::vector<int> &locals) {
                 o.max_iterations_accepted > 0;
     if (!r.refined) plain.push_back(a);
   }
-  for (int a : locals)
-    if (res_[a].refined) run_tnt(a, Xak_.p, gc_.p);   // sets Gk
+  {
+    std::vector<int> ref;
+    for (int a : locals)
+      if (res_[a].refined) ref.push_back(a);
+    if (!ref.empty()) run_tnt(ref, Xak_.p, gc_.p);   // sets Gk
+  }
   if (!plain.empty()) {
     set_mask(plain);
     eval_G(Xak_.p, gc_.p, 0);
@@ -755,15 +808,15 @@ int Group::amm(const std::vector<int> &locals) {
   for (int a = 0; a < num_local(); a++) h_gamma_[a] = res_[a].gamma;
   HIP_CHECK(hipMemcpyAsync(gamma_.p, h_gamma_, sizeof(double) * num_local(), hipMemcpyHostToDevice, st_));
   // Y = X[k] + gamma (X[k] - X[k-1]) on own AND neighbour rows (:255-256)
-  launch_extrapolate(d_, st_, T_, true, mask_.p, gamma_.p, Zc_.p, Zp_.p, Y_.p);
+  launch_extrapolate(d_, st_, T_, true, cur_mask_, gamma_.p, Zc_.p, Zp_.p, Y_.p);
   if (trivial) {
-    launch_extrapolate(d_, st_, T_, false, mask_.p, gamma_.p, gc_.p, gp_.p, gx_.p);      // :259-262
-    launch_extrapolate(d_, st_, T_, false, mask_.p, gamma_.p, Dfc_.p, Dfp_.p, Dfx_.p);
+    launch_extrapolate(d_, st_, T_, false, cur_mask_, gamma_.p, gc_.p, gp_.p, gx_.p);      // :259-262
+    launch_extrapolate(d_, st_, T_, false, cur_mask_, gamma_.p, Dfc_.p, Dfp_.p, Dfx_.p);
   } else {
     // evaluate_g_and_Df(Y) (:264 -> DPGOProblem.cpp:683-749)
-    launch_inter(d_, st_, T_, mask_.p, E_, o.loss, o.loss_reg, 1, false, Y_.p, nullptr, nullptr, Dd_.p, nullptr, gx_.p,
+    launch_inter(d_, st_, T_, cur_mask_, E_, o.loss, o.loss_reg, 1, false, Y_.p, nullptr, nullptr, Dd_.p, nullptr, gx_.p,
                  partials_.p);
-    launch_bsr(d_, st_, T_, false, mask_.p, G_.dev, Y_.p, false, gx_.p, Dfx_.p, nullptr, 0, nullptr, nullptr, 0);
+    launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Y_.p, false, gx_.p, Dfx_.p, nullptr, 0, nullptr, nullptr, 0);
   }
   for (int a : locals) {
     NodeResults &r = res_[a];
@@ -771,7 +824,7 @@ int Group::amm(const std::vector<int> &locals) {
                 o.max_iterations > 0 && o.max_iterations_accepted > 0;   // :351-355
   }
   // Xakh = proximal(Y, Df); Gkh = G(Xakh | g[k], f); |Xakh - Xak|^2    (:363-367)
-  launch_proximal(d_, st_, T_, mask_.p, Y_.p, Dfx_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, Xak_.p, partials_.p, 0);
+  launch_proximal(d_, st_, T_, cur_mask_, Y_.p, Dfx_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, Xak_.p, partials_.p, 0);
   eval_G(Xakh_.p, gc_.p, 1);
   // Xak.R = Xakh.R; Xak.t = recover(R, g)   (:369-372)
   copy_rows(Xak_.p, Xakh_.p, false, 2);
@@ -789,21 +842,25 @@ int Group::amm(const std::vector<int> &locals) {
     minG[a] = r.Fk[0] - o.psi * scal(a, 0);
     if (!r.refined) r.Gk = scal(a, 2) + r.f;
   }
-  for (int a : locals)
-    if (res_[a].refined) {
-      run_tnt(a, Xak_.p, gx_.p);
-      set_mask({a});
+  {
+    std::vector<int> ref;
+    for (int a : locals)
+      if (res_[a].refined) ref.push_back(a);
+    if (!ref.empty()) {
+      run_tnt(ref, Xak_.p, gx_.p);
+      set_mask(ref);
       eval_G(Xak_.p, gc_.p, 0);
       fetch(1, false);
-      res_[a].Gk = scal(a, 0) + res_[a].f;
+      for (int a : ref) res_[a].Gk = scal(a, 0) + res_[a].f;
     }
+  }
   // adaptive restart of the half step (:386-389)
   std::vector<int> redo;
   for (int a : locals)
     if (Gkh[a] > minG[a]) redo.push_back(a);
   if (!redo.empty()) {
     set_mask(redo);
-    launch_proximal(d_, st_, T_, mask_.p, Zc_.p, Dfc_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, nullptr, nullptr, 0);
+    launch_proximal(d_, st_, T_, cur_mask_, Zc_.p, Dfc_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, nullptr, nullptr, 0);
     eval_G(Xakh_.p, gc_.p, 0);
     fetch(1, false);
     for (int a : redo) Gkh[a] = scal(a, 0) + res_[a].f;
@@ -830,7 +887,7 @@ int Group::amm(const std::vector<int> &locals) {
     }
     if (!use_prox.empty()) {
       set_mask(use_prox);
-      launch_proximal(d_, st_, T_, mask_.p, Zc_.p, Dfc_.p, Tinv_.p, N_.p, V_.p, Xak_.p, nullptr, nullptr, 0);
+      launch_proximal(d_, st_, T_, cur_mask_, Zc_.p, Dfc_.p, Tinv_.p, N_.p, V_.p, Xak_.p, nullptr, nullptr, 0);
     }
     set_mask(restart);
     recover_translations(Xak_.p, gc_.p);
@@ -840,8 +897,12 @@ int Group::amm(const std::vector<int> &locals) {
       res_[a].restarts++;
       if (!res_[a].refined) plain_r.push_back(a);
     }
-    for (int a : restart)
-      if (res_[a].refined) run_tnt(a, Xak_.p, gc_.p);   // Gk = Results.f (:420-421)
+    {
+      std::vector<int> ref;
+      for (int a : restart)
+        if (res_[a].refined) ref.push_back(a);
+      if (!ref.empty()) run_tnt(ref, Xak_.p, gc_.p);   // Gk = Results.f (:420-421)
+    }
     if (!plain_r.empty()) {
       set_mask(plain_r);
       eval_G(Xak_.p, gc_.p, 0);
@@ -909,7 +970,7 @@ int Group::debug_apply(int a, const char *op_c, const double *in, int ld_in, dou
   if (op == "project") {
     (void)hipMemset(A + (size_t)own_off_[a] * RS_, 0, sizeof(double) * n0 * RS_);
     put_own(Bv, in, ld_in, 0, 0, false);
-    launch_retract_rot(d_, st_, T_, mask_.p, A, Bv, C);
+    launch_retract_rot(d_, st_, T_, cur_mask_, A, Bv, C);
     get_own(C, out, ld_out, 0, 0, false);
   } else if (op == "solve_tt" || op == "solve_rr") {
     put_own(A, in, ld_in, 0, n0, true);
@@ -921,14 +982,14 @@ int Group::debug_apply(int a, const char *op_c, const double *in, int ld_in, dou
     get_own(A, out, ld_out, 0, n0, true);
   } else if (op == "G") {
     put_own(A, in, ld_in, 0, n0, true);
-    launch_bsr(d_, st_, T_, false, mask_.p, G_.dev, A, false, nullptr, Bv, nullptr, 0, nullptr, nullptr, 0);
+    launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, A, false, nullptr, Bv, nullptr, 0, nullptr, nullptr, 0);
     get_own(Bv, out, ld_out, 0, n0, true);
   } else if (op == "proximal") {
     // in = [Z ((d+1)(n0+n1) rows) ; Df ((d+1) n0 rows)]
     const int zr = (d_ + 1) * (n0 + n1);
     put_own(A, in, ld_in, 0, n0, true);
     put_own(Bv, in, ld_in, zr, zr + n0, true);
-    launch_proximal(d_, st_, T_, mask_.p, A, Bv, Tinv_.p, N_.p, V_.p, C, nullptr, nullptr, 0);
+    launch_proximal(d_, st_, T_, cur_mask_, A, Bv, Tinv_.p, N_.p, V_.p, C, nullptr, nullptr, 0);
     get_own(C, out, ld_out, 0, n0, true);
   } else {
     fprintf(stderr, "[dpgo_amd] ERROR: debug_apply: unknown operator %s\n", op_c);

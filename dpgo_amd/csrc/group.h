@@ -86,6 +86,8 @@ struct SpdSolverDev {
   DevBuf<double> W, WT, ubuf, ytmp;
   DevBuf<int4> fwd_items, bwd_items;
   std::vector<int> fwd_level_ptr, bwd_level_ptr;  // item ranges per level
+  std::vector<int> fwd_big_ptr, bwd_big_ptr;      // first wide-front item of each level
+  std::vector<double> fwd_level_bytes, bwd_level_bytes;
   SpdDev dev;
   int dof = 1;
   void upload(int dcols);
@@ -155,8 +157,17 @@ class Group {
   DevBuf<Seg> segs_;
   DevBuf<int> own_seg_ptr_, nbr_seg_ptr_;
   SegTable T_;
-  DevBuf<int> mask_;
-  int *h_mask_ = nullptr;          // pinned
+  // masks and per-node coefficients live in rings (device + pinned host), so changing them never
+  // needs a stream synchronisation
+  static constexpr int RING = 512;
+  DevBuf<int> mask_ring_;
+  int *h_mask_ = nullptr;          // pinned, RING x L
+  int mask_slot_ = 0;
+  const int *cur_mask_ = nullptr;
+  DevBuf<double> coef_ring_;
+  double *h_coef_ = nullptr;       // pinned, RING x L
+  int coef_slot_ = 0;
+  const double *upload_coef(const std::vector<double> &per_node);
   double *h_scal_ = nullptr;       // pinned
   double *h_gamma_ = nullptr;      // pinned
   DevBuf<double> gamma_;
@@ -193,7 +204,7 @@ class Group {
   void host_update_logic(int local, double fobj, double f, double gradFnorm);
   int amm(const std::vector<int> &locals);
   int mm(const std::vector<int> &locals);
-  void run_tnt(int local, double *X, const double *g);   // refine X in place, sets Gk = f(X)
+  void run_tnt(const std::vector<int> &locals, double *X, const double *g);   // refine X in place, sets Gk = f(X)
 };
 
 }  // namespace dpgo

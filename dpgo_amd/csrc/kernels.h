@@ -29,14 +29,14 @@ struct Seg {
 };
 
 struct BsrDev {
-  int nrows = 0;
+  int nrows = 0, nnzb = 0;
   const int *ptr = nullptr, *col = nullptr;
   const double *val = nullptr;
 };
 
 // Inter-node edges of the local nodes, B-form (residual) data.
 struct InterEdgesDev {
-  int m = 0;
+  int m = 0, nrows_own = 0, nrows_all = 0;
   const int *tail = nullptr, *head = nullptr;   // unified pose ids
   const double *R = nullptr;                    // d*d row-major
   const double *t = nullptr;                    // d
@@ -48,6 +48,7 @@ struct InterEdgesDev {
 struct SegTable {
   const Seg *segs = nullptr;
   int nseg_own = 0, nseg_all = 0;
+  int rows_own = 0, rows_all = 0;
   const int *own_ptr = nullptr;   // per node: [own_ptr[a], own_ptr[a+1]) own segments
   const int *nbr_ptr = nullptr;   // per node: [nbr_ptr[a], nbr_ptr[a+1]) neighbour segments (indices into segs)
 };
@@ -77,6 +78,9 @@ void launch_extrapolate(int d, hipStream_t st, const SegTable &T, bool all_rows,
 // out = alpha * a + beta * b  (b may be null); parts: 0 whole record, 1 translation only, 2 rotation only
 void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, const int *mask, double alpha,
                   const double *a, double beta, const double *b, double *out, int part);
+// out = alpha[node] * a + beta[node] * b over own rows (per-node coefficients on the device)
+void launch_axpby_node(int d, hipStream_t st, const SegTable &T, const int *mask, const double *alpha,
+                       const double *a, const double *beta, const double *b, double *out);
 // partial[slot] = sum <a_p, b_p> over the selected part
 void launch_dot(int d, hipStream_t st, const SegTable &T, bool all_rows, const int *mask, const double *a,
                 const double *b, int part, double *partials, int slot);
@@ -119,6 +123,13 @@ struct SpdDev {
 // forward reads the right-hand side from vec and writes y to ytmp (n x d, matrix order); backward
 // reads ytmp and writes scale * A^-1 b into vec (scale must be +1 or -1).
 void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int item0, int nitems,
-                      double *vec, double *ytmp, double scale);
+                      double *vec, double *ytmp, double scale, double level_bytes = 0.0, int nwaves = 1);
+
+// ---- optional per-launch timing (HIP events on the launch stream), off by default ----
+enum ProfKind { PK_BSR = 0, PK_INTER, PK_PROX, PK_AXPBY, PK_DOT, PK_ROTOP, PK_COPYIDX, PK_BDIAG, PK_REDUCE,
+                PK_SPD_FWD, PK_SPD_BWD, PK_COUNT };
+void prof_enable(bool on);
+void prof_reset();
+void prof_collect(double *ms, double *bytes, long *count);
 
 }  // namespace dpgo

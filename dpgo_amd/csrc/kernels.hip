@@ -8,6 +8,8 @@
 // reproducible run to run.
 #include "kernels.h"
 
+#include <vector>
+
 namespace dpgo {
 namespace {
 
@@ -483,6 +485,25 @@ __global__ __launch_bounds__(256) void k_axpby(const Seg *segs, const int *mask,
   }
 }
 
+// out = alpha[node] * a + beta[node] * b  (per-node coefficients: batched CG updates)
+template <int D>
+__global__ __launch_bounds__(256) void k_axpby_node(const Seg *segs, const int *mask, const double *alpha,
+                                                    const double *a, const double *beta, const double *b,
+                                                    double *out) {
+  constexpr int RS = Dim<D>::RS;
+  const Seg s = segs[blockIdx.x];
+  if (mask && !mask[s.node]) return;
+  const int row = s.begin + threadIdx.x;
+  if (row >= s.end) return;
+  const double al = alpha[s.node], be = beta[s.node];
+  double va[RS], vb[RS];
+  load_vec<RS>(a + (size_t)row * RS, va);
+  load_vec<RS>(b + (size_t)row * RS, vb);
+#pragma unroll
+  for (int k = 0; k < RS; k++) va[k] = fma(be, vb[k], al * va[k]);
+  store_vec<RS>(out + (size_t)row * RS, va);
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void k_dot(const Seg *segs, const int *mask, const double *a, const double *b,
                                              int part, double *partial) {
@@ -646,12 +667,18 @@ __device__ __forceinline__ size_t vaddr(int i) {
 
 constexpr int SPD_CH = 128;
 
-template <int D, int DOF>
-__global__ __launch_bounds__(64) void k_spd_fwd(SpdDev S, int item0, const double *vec, double *ytmp) {
-  __shared__ double f[SPD_CH * D];
+// NW waves share one 64-row tile and split the front's columns (forward) / rows (backward) between
+// them chunk by chunk, then combine through LDS in a fixed order.  NW = 1 for the many small fronts
+// at the bottom of the tree, NW = 8 for the wide separator fronts at the top, where a single wave
+// per tile cannot keep enough loads in flight to use the HBM bandwidth.
+template <int D, int DOF, int NW>
+__global__ __launch_bounds__(64 * NW) void k_spd_fwd(SpdDev S, int item0, const double *vec, double *ytmp) {
+  __shared__ double f[NW][SPD_CH * D];
+  __shared__ double red[NW > 1 ? NW : 1][64 * D];
   const int4 it = S.fwd_items[item0 + blockIdx.x];
-  const int s = it.x, tid = threadIdx.x, p = it.y + tid;
-  const bool valid = tid < it.z;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s = it.x, p = it.y + lane;
+  const bool valid = lane < it.z;
   const int w = S.w[s], m = w + S.u[s];
   const double *WT = S.WT + S.w_off[s];
   const int *piv = S.piv_idx + S.piv_ptr[s];
@@ -659,10 +686,10 @@ __global__ __launch_bounds__(64) void k_spd_fwd(SpdDev S, int item0, const doubl
   double acc[D];
 #pragma unroll
   for (int c = 0; c < D; c++) acc[c] = 0.0;
-  for (int k0 = 0; k0 < w; k0 += SPD_CH) {
+  double *fw = f[wv];
+  for (int k0 = wv * SPD_CH; k0 < w; k0 += NW * SPD_CH) {
     const int kn = min(SPD_CH, w - k0);
-    __syncthreads();
-    for (int kk = tid; kk < kn; kk += 64) {
+    for (int kk = lane; kk < kn; kk += 64) {
       const int k = k0 + kk;
       double v[D];
       const double *src = vec + vaddr<D, DOF>(piv[k]);
@@ -674,16 +701,31 @@ __global__ __launch_bounds__(64) void k_spd_fwd(SpdDev S, int item0, const doubl
         for (int c = 0; c < D; c++) v[c] += ub[c];
       }
 #pragma unroll
-      for (int c = 0; c < D; c++) f[kk * D + c] = v[c];
+      for (int c = 0; c < D; c++) fw[kk * D + c] = v[c];
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (valid) {
       const double *wp = WT + (size_t)k0 * m + p;
+#pragma unroll 8
       for (int kk = 0; kk < kn; kk++) {
-        const double wv = wp[(size_t)kk * m];
+        const double wval = wp[(size_t)kk * m];
 #pragma unroll
-        for (int c = 0; c < D; c++) acc[c] = fma(wv, f[kk * D + c], acc[c]);
+        for (int c = 0; c < D; c++) acc[c] = fma(wval, fw[kk * D + c], acc[c]);
       }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if constexpr (NW > 1) {
+#pragma unroll
+    for (int c = 0; c < D; c++) red[wv][lane * D + c] = acc[c];
+    __syncthreads();
+    if (wv != 0) return;
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+      double a = red[0][lane * D + c];
+      for (int q = 1; q < NW; q++) a += red[q][lane * D + c];
+      acc[c] = a;
     }
   }
   if (!valid) return;
@@ -703,13 +745,15 @@ __global__ __launch_bounds__(64) void k_spd_fwd(SpdDev S, int item0, const doubl
   }
 }
 
-template <int D, int DOF>
-__global__ __launch_bounds__(64) void k_spd_bwd(SpdDev S, int item0, double scale, const double *ytmp,
-                                                double *vec) {
-  __shared__ double f[SPD_CH * D];
+template <int D, int DOF, int NW>
+__global__ __launch_bounds__(64 * NW) void k_spd_bwd(SpdDev S, int item0, double scale, const double *ytmp,
+                                                     double *vec) {
+  __shared__ double f[NW][SPD_CH * D];
+  __shared__ double red[NW > 1 ? NW : 1][64 * D];
   const int4 it = S.bwd_items[item0 + blockIdx.x];
-  const int s = it.x, tid = threadIdx.x, k = it.y + tid;
-  const bool valid = tid < it.z;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s = it.x, k = it.y + lane;
+  const bool valid = lane < it.z;
   const int w = S.w[s], m = w + S.u[s];
   const double *W = S.W + S.w_off[s];
   const int *piv = S.piv_idx + S.piv_ptr[s];
@@ -717,25 +761,40 @@ __global__ __launch_bounds__(64) void k_spd_bwd(SpdDev S, int item0, double scal
   double acc[D];
 #pragma unroll
   for (int c = 0; c < D; c++) acc[c] = 0.0;
-  for (int p0 = 0; p0 < m; p0 += SPD_CH) {
+  double *fw = f[wv];
+  for (int p0 = wv * SPD_CH; p0 < m; p0 += NW * SPD_CH) {
     const int pn = min(SPD_CH, m - p0);
-    __syncthreads();
-    for (int pp = tid; pp < pn; pp += 64) {
+    for (int pp = lane; pp < pn; pp += 64) {
       const int p = p0 + pp;
       // ancestors' entries were scaled when they were written: undo by linearity (scale is +-1)
       const double sc = p < w ? 1.0 : scale;
       const double *src = p < w ? ytmp + (size_t)piv[p] * D : vec + vaddr<D, DOF>(upd[p - w]);
 #pragma unroll
-      for (int c = 0; c < D; c++) f[pp * D + c] = sc * src[c];
+      for (int c = 0; c < D; c++) fw[pp * D + c] = sc * src[c];
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (valid) {
       const double *wp = W + (size_t)p0 * w + k;
+#pragma unroll 8
       for (int pp = 0; pp < pn; pp++) {
-        const double wv = wp[(size_t)pp * w];
+        const double wval = wp[(size_t)pp * w];
 #pragma unroll
-        for (int c = 0; c < D; c++) acc[c] = fma(wv, f[pp * D + c], acc[c]);
+        for (int c = 0; c < D; c++) acc[c] = fma(wval, fw[pp * D + c], acc[c]);
       }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if constexpr (NW > 1) {
+#pragma unroll
+    for (int c = 0; c < D; c++) red[wv][lane * D + c] = acc[c];
+    __syncthreads();
+    if (wv != 0) return;
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+      double a = red[0][lane * D + c];
+      for (int q = 1; q < NW; q++) a += red[q][lane * D + c];
+      acc[c] = a;
     }
   }
   if (!valid) return;
@@ -745,6 +804,74 @@ __global__ __launch_bounds__(64) void k_spd_bwd(SpdDev S, int item0, double scal
 }
 
 }  // namespace
+
+
+// ---------------------------------------------------------------------------
+// Optional per-launch timing with HIP events on the launch stream (bench.py's
+// roofline pass).  Disabled by default: no events are recorded in timed runs.
+// ---------------------------------------------------------------------------
+namespace {
+struct Prof {
+  bool on = false;
+  std::vector<hipEvent_t> ev;      // pairs
+  std::vector<int> kind;
+  size_t used = 0;
+  double ms[PK_COUNT] = {0};
+  double bytes[PK_COUNT] = {0};
+  long count[PK_COUNT] = {0};
+  void flush() {
+    if (!used) return;
+    (void)hipEventSynchronize(ev[2 * used - 1]);
+    for (size_t i = 0; i < used; i++) {
+      float t = 0;
+      (void)hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]);
+      ms[kind[i]] += t;
+    }
+    used = 0;
+  }
+};
+Prof g_prof;
+struct ProfScope {
+  hipStream_t st;
+  bool on;
+  ProfScope(int kind, hipStream_t s, double bytes) : st(s), on(g_prof.on) {
+    if (!on) return;
+    if (g_prof.used == g_prof.kind.size()) {
+      if (g_prof.kind.size() >= 32768) g_prof.flush();
+      else {
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        g_prof.ev.push_back(a);
+        g_prof.ev.push_back(b);
+        g_prof.kind.push_back(0);
+      }
+    }
+    g_prof.kind[g_prof.used] = kind;
+    g_prof.count[kind]++;
+    g_prof.bytes[kind] += bytes;
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
+    g_prof.used++;
+  }
+};
+}  // namespace
+
+void prof_enable(bool on) {
+  g_prof.flush();
+  g_prof.on = on;
+}
+void prof_reset() {
+  g_prof.flush();
+  for (int k = 0; k < PK_COUNT; k++) { g_prof.ms[k] = 0; g_prof.bytes[k] = 0; g_prof.count[k] = 0; }
+}
+void prof_collect(double *ms, double *bytes, long *count) {
+  g_prof.flush();
+  for (int k = 0; k < PK_COUNT; k++) { ms[k] = g_prof.ms[k]; bytes[k] = g_prof.bytes[k]; count[k] = g_prof.count[k]; }
+}
 
 // ---------------------------------------------------------------------------
 // Launch wrappers
@@ -763,6 +890,7 @@ void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, const i
   const int nb = nseg(T, all_rows);
   if (nb == 0) return;
   double *part = (dotv && partials) ? partials + (size_t)slot * T.nseg_all : nullptr;
+  ProfScope ps(PK_BSR, st, (double)A.nnzb * (8.0 * (d + 1) * (d + 1) + 4) + 2.0 * A.nrows * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, {
     if (in_rot_only)
       hipLaunchKernelGGL((k_bsr<D, true>), dim3(nb), dim3(256), 0, st, T.segs, mask, A, x, addv, y, dotv, coef,
@@ -778,6 +906,7 @@ void launch_inter(int d, hipStream_t st, const SegTable &T, const int *mask, con
                   const double *Qdiag, const double *Ddiag, double *DfE, double *g, double *partials) {
   const int nb = mode == 0 ? T.nseg_all : T.nseg_own;
   if (nb == 0) return;
+  ProfScope ps(PK_INTER, st, (double)E.m * (8.0 * (d * d + d + 2) + 8) + 2.0 * (mode == 0 ? E.nrows_all : E.nrows_own) * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_inter<D>), dim3(nb), dim3(256), 0, st, T.segs, mask, E, loss, loss_reg,
                                         mode, quad ? 1 : 0, T.nseg_own, Z, Zprev, Qdiag, Ddiag, DfE, g, partials,
                                         T.nseg_all));
@@ -788,6 +917,7 @@ void launch_proximal(int d, hipStream_t st, const SegTable &T, const int *mask, 
                      double *partials, int slot) {
   if (T.nseg_own == 0) return;
   double *part = (Xref && partials) ? partials + (size_t)slot * T.nseg_all : nullptr;
+  ProfScope ps(PK_PROX, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_proximal<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, Z, Df,
                                         Tinv, N, V, Xout, part ? Xref : nullptr, part));
 }
@@ -796,6 +926,7 @@ void launch_extrapolate(int d, hipStream_t st, const SegTable &T, bool all_rows,
                         const double *gamma, const double *a, const double *b, double *out) {
   const int nb = nseg(T, all_rows);
   if (nb == 0) return;
+  ProfScope ps(PK_AXPBY, st, 3.0 * (all_rows ? T.rows_all : T.rows_own) * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_extrapolate<D>), dim3(nb), dim3(256), 0, st, T.segs, mask, gamma, a, b,
                                         out));
 }
@@ -804,14 +935,24 @@ void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, const
                   const double *a, double beta, const double *b, double *out, int part) {
   const int nb = nseg(T, all_rows);
   if (nb == 0) return;
+  ProfScope ps(PK_AXPBY, st, (b ? 3.0 : 2.0) * (all_rows ? T.rows_all : T.rows_own) * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_axpby<D>), dim3(nb), dim3(256), 0, st, T.segs, mask, alpha, a, beta, b,
                                         out, part));
+}
+
+void launch_axpby_node(int d, hipStream_t st, const SegTable &T, const int *mask, const double *alpha,
+                       const double *a, const double *beta, const double *b, double *out) {
+  if (T.nseg_own == 0) return;
+  ProfScope ps(PK_AXPBY, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_axpby_node<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, alpha,
+                                        a, beta, b, out));
 }
 
 void launch_dot(int d, hipStream_t st, const SegTable &T, bool all_rows, const int *mask, const double *a,
                 const double *b, int part, double *partials, int slot) {
   const int nb = nseg(T, all_rows);
   if (nb == 0) return;
+  ProfScope ps(PK_DOT, st, 2.0 * (all_rows ? T.rows_all : T.rows_own) * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_dot<D>), dim3(nb), dim3(256), 0, st, T.segs, mask, a, b, part,
                                         partials + (size_t)slot * T.nseg_all));
 }
@@ -820,6 +961,7 @@ void launch_tangent_full(int d, hipStream_t st, const SegTable &T, const int *ma
                          const double *V, double *out, double *partials, int slot) {
   if (T.nseg_own == 0) return;
   double *part = partials ? partials + (size_t)slot * T.nseg_all : nullptr;
+  ProfScope ps(PK_ROTOP, st, 2.0 * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_tangent_full<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, X,
                                         V, out, part));
 }
@@ -827,6 +969,7 @@ void launch_tangent_full(int d, hipStream_t st, const SegTable &T, const int *ma
 void launch_hess_epilogue(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
                           const double *E, const double *nabla, const double *Rdot, double *out) {
   if (T.nseg_own == 0) return;
+  ProfScope ps(PK_ROTOP, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, 1, X, E,
                                         nabla, Rdot, out));
 }
@@ -834,6 +977,7 @@ void launch_hess_epilogue(int d, hipStream_t st, const SegTable &T, const int *m
 void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
                         const double *in, double *out) {
   if (T.nseg_own == 0) return;
+  ProfScope ps(PK_ROTOP, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, 0, X, in,
                                         nullptr, nullptr, out));
 }
@@ -841,6 +985,7 @@ void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, const int *mas
 void launch_retract_rot(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
                         const double *V, double *out) {
   if (T.nseg_own == 0) return;
+  ProfScope ps(PK_ROTOP, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, 2, X, V,
                                         nullptr, nullptr, out));
 }
@@ -848,6 +993,7 @@ void launch_retract_rot(int d, hipStream_t st, const SegTable &T, const int *mas
 void launch_copy_indexed(int d, hipStream_t st, int count, const int *didx, const int *sidx, const double *src,
                          double *dst) {
   if (count == 0) return;
+  ProfScope ps(PK_COPYIDX, st, 2.0 * count * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_copy_indexed<D>), dim3((count + 255) / 256), dim3(256), 0, st, count,
                                         didx, sidx, src, dst));
 }
@@ -855,27 +1001,33 @@ void launch_copy_indexed(int d, hipStream_t st, int count, const int *didx, cons
 void launch_bdiag_dot(int d, hipStream_t st, const SegTable &T, const int *mask, const double *Dd, const double *x,
                       double coef, const double *add, double addcoef, double *partials, int slot) {
   if (T.nseg_own == 0) return;
+  ProfScope ps(PK_BDIAG, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_bdiag_dot<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, Dd, x,
                                         coef, add, addcoef, partials + (size_t)slot * T.nseg_all));
 }
 
 void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows, int nslots,
                    const double *partials, double *node_scalars) {
+  ProfScope ps(PK_REDUCE, st, 8.0 * nslots * T.nseg_all);
   hipLaunchKernelGGL(k_reduce, dim3(nnodes), dim3(64), 0, st, T, all_rows ? 1 : 0, nslots, partials, node_scalars);
 }
 
 void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int item0, int nitems,
-                      double *vec, double *ytmp, double scale) {
+                      double *vec, double *ytmp, double scale, double level_bytes, int nwaves) {
   if (nitems == 0) return;
+  ProfScope ps(forward ? PK_SPD_FWD : PK_SPD_BWD, st, level_bytes);
+#define SPD_LAUNCH(DOFV, NWV)                                                                                  \
+  do {                                                                                                         \
+    if (forward)                                                                                               \
+      hipLaunchKernelGGL((k_spd_fwd<D, DOFV, NWV>), dim3(nitems), dim3(64 * NWV), 0, st, S, item0, vec, ytmp); \
+    else                                                                                                       \
+      hipLaunchKernelGGL((k_spd_bwd<D, DOFV, NWV>), dim3(nitems), dim3(64 * NWV), 0, st, S, item0, scale, ytmp, vec); \
+  } while (0)
   DPGO_DISPATCH_D(d, {
-    if (forward) {
-      if (dof == 1) hipLaunchKernelGGL((k_spd_fwd<D, 1>), dim3(nitems), dim3(64), 0, st, S, item0, vec, ytmp);
-      else hipLaunchKernelGGL((k_spd_fwd<D, D>), dim3(nitems), dim3(64), 0, st, S, item0, vec, ytmp);
-    } else {
-      if (dof == 1) hipLaunchKernelGGL((k_spd_bwd<D, 1>), dim3(nitems), dim3(64), 0, st, S, item0, scale, ytmp, vec);
-      else hipLaunchKernelGGL((k_spd_bwd<D, D>), dim3(nitems), dim3(64), 0, st, S, item0, scale, ytmp, vec);
-    }
+    if (dof == 1) { if (nwaves == 1) SPD_LAUNCH(1, 1); else SPD_LAUNCH(1, 8); }
+    else { if (nwaves == 1) SPD_LAUNCH(D, 1); else SPD_LAUNCH(D, 8); }
   });
+#undef SPD_LAUNCH
 }
 
 }  // namespace dpgo

@@ -239,13 +239,27 @@ int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf) {
   F.W.assign(F.w_off[nt], 0.0);
   F.WT.assign(F.w_off[nt], 0.0);
 
-  // numeric multifrontal factorisation
+  // numeric multifrontal factorisation, level by level: fronts of one tree height are independent.
+  // Small fronts are spread over threads; big fronts are factored one at a time with threads inside.
+  std::vector<int> height(nt, 0);
+  for (int f = 0; f < nt; f++)
+    if (F.parent[f] >= 0) height[F.parent[f]] = std::max(height[F.parent[f]], height[f] + 1);
+  int maxh_n = 0;
+  for (int f = 0; f < nt; f++) maxh_n = std::max(maxh_n, height[f]);
+  std::vector<std::vector<int>> lvl_fronts(maxh_n + 1);
+  for (int f = 0; f < nt; f++) lvl_fronts[height[f]].push_back(f);
   std::vector<std::vector<double>> Umat(nt);
-  std::vector<int> loc(n, -1);
   std::vector<std::vector<int>> asm_lists(F.total_pos);
-  std::vector<double> Fm, Linv, colk;
-  for (int f = 0; f < nt; f++) {
+  int fail = 0;
+  const int BIG = 384;
+
+  auto factor_front = [&](int f, std::vector<int> &loc, std::vector<double> &Fm, std::vector<double> &Linv,
+                          bool inner_par) {
     const int w = F.w[f], u = F.u[f], m = w + u;
+    if (w == 0) {
+      if (u > 0) fail = 1;
+      return;
+    }
     const int *piv = &F.piv_idx[F.piv_ptr[f]];
     const int *up = u ? &F.upd_idx[F.upd_ptr[f]] : nullptr;
     for (int k = 0; k < w; k++) loc[piv[k]] = k;
@@ -273,60 +287,122 @@ int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf) {
       }
       std::vector<double>().swap(Umat[c]);
     }
-    // dense partial Cholesky of the first w columns (lower triangle)
-    for (int k = 0; k < w; k++) {
-      double dkk = Fm[(size_t)k * m + k];
-      if (!(dkk > 0.0)) {
-        fprintf(stderr, "[dpgo_amd] ERROR: spd_factor: non-positive pivot %g (front %d, col %d)\n", dkk, f, k);
-        return -1;
+    // blocked right-looking partial Cholesky of the first w columns (lower triangle, row-major)
+    const int NB = 48;
+    for (int kb = 0; kb < w && !fail; kb += NB) {
+      const int ke = std::min(kb + NB, w);
+      for (int k = kb; k < ke; k++) {   // diagonal block, unblocked
+        double dkk = Fm[(size_t)k * m + k];
+        if (!(dkk > 0.0)) {
+          fprintf(stderr, "[dpgo_amd] ERROR: spd_factor: non-positive pivot %g (front %d, col %d)\n", dkk, f, k);
+          fail = 1;
+          break;
+        }
+        const double lkk = std::sqrt(dkk), inv = 1.0 / lkk;
+        Fm[(size_t)k * m + k] = lkk;
+        for (int i = k + 1; i < ke; i++) Fm[(size_t)i * m + k] *= inv;
+        for (int i = k + 1; i < ke; i++) {
+          const double lik = Fm[(size_t)i * m + k];
+          for (int j = k + 1; j <= i; j++) Fm[(size_t)i * m + j] -= lik * Fm[(size_t)j * m + k];
+        }
       }
-      double lkk = std::sqrt(dkk);
-      Fm[(size_t)k * m + k] = lkk;
-      double inv = 1.0 / lkk;
-      colk.resize(m);
-      for (int i = k + 1; i < m; i++) colk[i] = (Fm[(size_t)i * m + k] *= inv);
-      const double *ck = colk.data();
-#pragma omp parallel for schedule(static) if (m - k > 256)
-      for (int i = k + 1; i < m; i++) {
-        double lik = ck[i];
-        if (lik == 0.0) continue;
+      if (fail) break;
+      // panel: rows below the block, L[i, kb:ke] = F[i, kb:ke] L_kk^-T
+#pragma omp parallel for schedule(static) if (inner_par)
+      for (int i = ke; i < m; i++) {
         double *row = &Fm[(size_t)i * m];
-        for (int j = k + 1; j <= i; j++) row[j] -= lik * ck[j];
+        for (int k = kb; k < ke; k++) {
+          double s = row[k];
+          const double *lk = &Fm[(size_t)k * m];
+          for (int q = kb; q < k; q++) s -= row[q] * lk[q];
+          row[k] = s / lk[k];
+        }
+      }
+      // trailing update: F[i, j] -= L[i, kb:ke] . L[j, kb:ke] for ke <= j <= i
+      const int nbk = ke - kb;
+#pragma omp parallel for schedule(dynamic, 16) if (inner_par)
+      for (int i = ke; i < m; i++) {
+        double *row = &Fm[(size_t)i * m];
+        const double *li = row + kb;
+        for (int j = ke; j <= i; j++) {
+          const double *lj = &Fm[(size_t)j * m + kb];
+          double s = 0;
+          for (int q = 0; q < nbk; q++) s += li[q] * lj[q];
+          row[j] -= s;
+        }
       }
     }
-    // Schur complement for the parent
-    if (u) {
+    if (fail) return;
+    if (u) {   // Schur complement for the parent
       Umat[f].resize((size_t)u * u);
       for (int a = 0; a < u; a++)
         for (int b = 0; b <= a; b++) Umat[f][(size_t)a * u + b] = Fm[(size_t)(w + a) * m + (w + b)];
     }
-    // Linv = L11^-1 (lower triangular)
+    // Linv = L11^-1 by forward substitution on the identity, one row at a time:
+    //   Linv[i, :] = (e_i - sum_{k<i} L[i,k] Linv[k, :]) / L[i,i]; columns are independent
     Linv.assign((size_t)w * w, 0.0);
-    for (int j = 0; j < w; j++) {
-      Linv[(size_t)j * w + j] = 1.0 / Fm[(size_t)j * m + j];
-      for (int i = j + 1; i < w; i++) {
-        double s = 0;
-        for (int k = j; k < i; k++) s += Fm[(size_t)i * m + k] * Linv[(size_t)k * w + j];
-        Linv[(size_t)i * w + j] = -s / Fm[(size_t)i * m + i];
+    const int CB = 64;
+    const int ncb = (w + CB - 1) / CB;
+#pragma omp parallel for schedule(dynamic, 1) if (inner_par)
+    for (int cb = 0; cb < ncb; cb++) {
+      const int j0 = cb * CB, j1 = std::min(j0 + CB, w);
+      for (int i = j0; i < w; i++) {
+        double *ri = &Linv[(size_t)i * w];
+        const double *Li = &Fm[(size_t)i * m];
+        const int je = std::min(j1, i + 1);
+        if (i < j1) ri[i] = 1.0;
+        for (int k = j0; k < i; k++) {
+          const double lik = Li[k];
+          if (lik == 0.0) continue;
+          const double *rk = &Linv[(size_t)k * w];
+          const int jk = std::min(je, k + 1);
+          for (int j = j0; j < jk; j++) ri[j] -= lik * rk[j];
+        }
+        const double inv = 1.0 / Li[i];
+        for (int j = j0; j < je; j++) ri[j] *= inv;
       }
     }
     double *Wf = &F.W[F.w_off[f]];
     double *WTf = &F.WT[F.w_off[f]];
     for (int i = 0; i < w; i++)
       for (int j = 0; j <= i; j++) Wf[(size_t)i * w + j] = Linv[(size_t)i * w + j];
+    // W bottom = -L21 Linv, row-oriented: out[a, :] = -sum_k L21[a,k] Linv[k, 0..k]
+#pragma omp parallel for schedule(dynamic, 8) if (inner_par)
     for (int a = 0; a < u; a++) {
       const double *l21 = &Fm[(size_t)(w + a) * m];
-      for (int j = 0; j < w; j++) {
-        double s = 0;
-        for (int k = j; k < w; k++) s += l21[k] * Linv[(size_t)k * w + j];
-        Wf[(size_t)(w + a) * w + j] = -s;
+      double *out = &Wf[(size_t)(w + a) * w];
+      for (int j = 0; j < w; j++) out[j] = 0.0;
+      for (int k = 0; k < w; k++) {
+        const double l = l21[k];
+        if (l == 0.0) continue;
+        const double *rk = &Linv[(size_t)k * w];
+        for (int j = 0; j <= k; j++) out[j] -= l * rk[j];
       }
     }
-    for (int p = 0; p < m; p++)
-      for (int k = 0; k < w; k++) WTf[(size_t)k * m + p] = Wf[(size_t)p * w + k];
+#pragma omp parallel for schedule(static) if (inner_par)
+    for (int k = 0; k < w; k++)
+      for (int p = 0; p < m; p++) WTf[(size_t)k * m + p] = Wf[(size_t)p * w + k];
     for (int k = 0; k < w; k++) loc[piv[k]] = -1;
     for (int k = 0; k < u; k++) loc[up[k]] = -1;
+  };
+
+  for (int h = 0; h <= maxh_n && !fail; h++) {
+    std::vector<int> small, big;
+    for (int f : lvl_fronts[h]) (F.w[f] + F.u[f] >= BIG ? big : small).push_back(f);
+#pragma omp parallel
+    {
+      std::vector<int> loc(n, -1);
+      std::vector<double> Fm, Linv;
+#pragma omp for schedule(dynamic, 1)
+      for (int i = 0; i < (int)small.size(); i++) factor_front(small[i], loc, Fm, Linv, false);
+    }
+    if (!big.empty()) {
+      std::vector<int> loc(n, -1);
+      std::vector<double> Fm, Linv;
+      for (int f : big) factor_front(f, loc, Fm, Linv, true);
+    }
   }
+  if (fail) return -1;
   F.asm_ptr.assign(F.total_pos + 1, 0);
   for (int p = 0; p < F.total_pos; p++) F.asm_ptr[p + 1] = F.asm_ptr[p] + (int)asm_lists[p].size();
   F.asm_src.resize(F.asm_ptr[F.total_pos]);

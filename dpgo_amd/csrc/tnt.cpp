@@ -1,5 +1,5 @@
-// Riemannian truncated-Newton trust-region refinement of one node on device
-// vectors.
+// Riemannian truncated-Newton trust-region refinement on device vectors,
+// batched over the nodes of a group.
 //
 // Same algorithm as the reference's generic solvers
 //   TNT    C++/Optimization/include/Optimization/Riemannian/TNT.h:242-693
@@ -12,9 +12,12 @@
 //   precon      = Proj_R((G_RR + lambda I)^-1 v)    DPGOProblem.cpp:579-598
 //   retraction  = [ -G_tt^-1(g_t + G_tR R+) ; R+ = proj(R + V) ]   DPGOProblem.cpp:127-143
 //   metric      = sum V1 .* V2                      DPGOHash.cpp:307-310
-// The control flow (a handful of scalars per CG step) runs on the host; every
-// vector lives in HBM and is touched only by kernels, restricted to the node by
-// the device mask.
+//
+// Every node runs the reference's control flow with its OWN scalars (step
+// lengths, trust-region radius, stopping tests); the nodes advance in lockstep so
+// that one launch serves all of them.  Per-node step lengths live in a device
+// ring (upload_coef), per-node branches are device masks, and the handful of
+// reductions per CG step come back through one pinned-memory fetch.
 #include <cmath>
 #include <cstdio>
 #include <limits>
@@ -25,39 +28,44 @@ namespace dpgo {
 
 namespace {
 enum { ST_GRADIENT = 0, ST_PRECON_GRADIENT, ST_REL_DECREASE, ST_STEPSIZE, ST_TRUST_REGION, ST_ITER_LIMIT };
-}
 
-void Group::run_tnt(int a, double *X, const double *g) {
+struct NodeTnt {
+  bool active = true;       // outer trust-region loop still running
+  int status = ST_ITER_LIMIT;
+  double fx = 0, gnorm = 0, pgnorm = 0, Delta = 1.0;   // TNTParams::Delta0 (TNT.h:81)
+  int iteration = 0, accepted = 0, inner_total = 0;
+  // STPCG state (IterativeSolvers.h:207-283)
+  bool cg = false;
+  double sk_M_pk = 0, sk_M_2 = 0, pk_M_2 = 0, rv = 0, Delta_2 = 0, target = 0, h_M_norm = 0;
+  int cg_it = 0;
+};
+}  // namespace
+
+void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g) {
   const Options &o = opt_;
-  NodeResults &res = res_[a];
-  set_mask({a});
+  const int L = num_local();
   const bool use_precon = (o.preconditioner == 1) && Lrr_.F.n > 0;
-  // work vectors (own rows; only node a's rows are touched)
   double *nabla = tmp_[0].p, *grad = tmp_[1].p, *sk = tmp_[2].p, *rk = tmp_[3].p, *vk = tmp_[4].p, *pk = tmp_[5].p,
          *Hp = tmp_[6].p, *xprop = tmp_[7].p, *w1 = tmp_[8].p, *w2 = tmp_[9].p, *pg = tmp_[10].p, *hh = tmp_[11].p;
-  const double fconst = res.f;
+  std::vector<NodeTnt> S(L);
+  for (auto &s : S) s.active = false;
+  for (int a : nodes) S[a] = NodeTnt();
 
-  auto dots = [&](std::initializer_list<std::pair<const double *, const double *>> prs, double *out) {
+  auto dots = [&](std::initializer_list<std::pair<const double *, const double *>> prs) {
     int s = 0;
-    for (const auto &pr : prs) launch_dot(d_, st_, T_, false, mask_.p, pr.first, pr.second, 2, partials_.p, s++);
+    for (const auto &pr : prs) launch_dot(d_, st_, T_, false, cur_mask_, pr.first, pr.second, 2, partials_.p, s++);
     fetch(s, false);
-    for (int k = 0; k < s; k++) out[k] = scal(a, k);
-  };
-  auto fval = [&](const double *Y) {
-    eval_G(Y, g, 0);
-    fetch(1, false);
-    return scal(a, 0) + fconst;
   };
   auto quad_model = [&](const double *Y) {   // nabla, grad at Y
-    launch_bsr(d_, st_, T_, false, mask_.p, G_.dev, Y, false, g, nabla, nullptr, 0, nullptr, nullptr, 0);
-    launch_tangent_rot(d_, st_, T_, mask_.p, Y, nabla, grad);
+    launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Y, false, g, nabla, nullptr, 0, nullptr, nullptr, 0);
+    launch_tangent_rot(d_, st_, T_, cur_mask_, Y, nabla, grad);
   };
   auto hess = [&](const double *Y, const double *v, double *out) {
-    launch_bsr(d_, st_, T_, false, mask_.p, G_.dev, v, true, nullptr, w1, nullptr, 0, nullptr, nullptr, 0);
+    launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, v, true, nullptr, w1, nullptr, 0, nullptr, nullptr, 0);
     solve_tt(w1, -1.0);                       // w1.t = tdot
     copy_rows(w1, v, false, 2);               // w1 = [tdot ; Rdot]
-    launch_bsr(d_, st_, T_, false, mask_.p, G_.dev, w1, false, nullptr, w2, nullptr, 0, nullptr, nullptr, 0);
-    launch_hess_epilogue(d_, st_, T_, mask_.p, Y, w2, nabla, v, out);
+    launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, w1, false, nullptr, w2, nullptr, 0, nullptr, nullptr, 0);
+    launch_hess_epilogue(d_, st_, T_, cur_mask_, Y, w2, nabla, v, out);
   };
   auto precon = [&](const double *Y, const double *v, double *out) {
     if (!use_precon) {
@@ -66,125 +74,176 @@ void Group::run_tnt(int a, double *X, const double *g) {
     }
     copy_rows(w1, v, false, 0);
     solve_rr(w1, 1.0);
-    launch_tangent_rot(d_, st_, T_, mask_.p, Y, w1, out);
+    launch_tangent_rot(d_, st_, T_, cur_mask_, Y, w1, out);
   };
-  auto retract = [&](const double *Y, const double *v, double *out) {
-    launch_retract_rot(d_, st_, T_, mask_.p, Y, v, out);
-    recover_translations(out, g);
-  };
-  auto axpby = [&](double al, const double *x, double be, const double *y, double *out) {
-    launch_axpby(d_, st_, T_, false, mask_.p, al, x, be, y, out, 0);
+  auto norms = [&](const std::vector<int> &set) {   // gnorm, pgnorm of the nodes in `set` (mask == set)
+    dots({{grad, grad}});
+    for (int a : set) S[a].gnorm = S[a].pgnorm = std::sqrt(scal(a, 0));
+    if (use_precon) {
+      precon(X, grad, pg);
+      dots({{pg, pg}});
+      for (int a : set) S[a].pgnorm = std::sqrt(scal(a, 0));
+    }
   };
 
   const double sqrt_eps = std::sqrt(std::numeric_limits<double>::epsilon());
-  int status = ST_ITER_LIMIT;
-  double fx = fval(X);
+  const double eta1 = .05, eta2 = .9, alpha1 = .25, alpha2 = 2.5, Delta_tol = 1e-6;   // TNT.h:83-97,129
+  set_mask(nodes);
+  eval_G(X, g, 0);
+  fetch(1, false);
+  for (int a : nodes) S[a].fx = scal(a, 0) + res_[a].f;
   quad_model(X);
-  double sc[4];
-  dots({{grad, grad}}, sc);
-  double gnorm = std::sqrt(sc[0]), pgnorm = gnorm;
-  if (use_precon) {
-    precon(X, grad, pg);
-    dots({{pg, pg}}, sc);
-    pgnorm = std::sqrt(sc[0]);
-  }
-  double Delta = 1.0;   // TNTParams::Delta0 (TNT.h:81)
-  const double eta1 = .05, eta2 = .9, alpha1 = .25, alpha2 = 2.5, Delta_tol = 1e-6;
-  int accepted = 0, inner_total = 0;
-  for (int iteration = 0; iteration < o.max_iterations && accepted < o.max_iterations_accepted; ++iteration) {
-    if (gnorm < o.grad_norm_tol) { status = ST_GRADIENT; break; }
-    if (pgnorm < o.preconditioned_grad_norm_tol) { status = ST_PRECON_GRADIENT; break; }
+  norms(nodes);
+
+  std::vector<double> c1(L, 0.0), c2(L, 0.0), ones(L, 1.0), mones(L, -1.0), zeros(L, 0.0);
+  for (;;) {
+    // ---- nodes that start another trust-region iteration (TNT.h:446-484)
+    std::vector<int> A;
+    for (int a : nodes) {
+      NodeTnt &s = S[a];
+      if (!s.active) continue;
+      if (!(s.iteration < o.max_iterations && s.accepted < o.max_iterations_accepted)) { s.active = false; continue; }
+      if (s.gnorm < o.grad_norm_tol) { s.status = ST_GRADIENT; s.active = false; continue; }
+      if (s.pgnorm < o.preconditioned_grad_norm_tol) { s.status = ST_PRECON_GRADIENT; s.active = false; continue; }
+      A.push_back(a);
+    }
+    if (A.empty()) break;
     // ---- STPCG (IterativeSolvers.h:207-426)
-    double h_M_norm = 0;
-    {
-      axpby(0.0, grad, 0.0, nullptr, sk);
-      copy_rows(rk, grad, false, 0);
-      if (use_precon) precon(X, rk, vk); else copy_rows(vk, rk, false, 0);
-      axpby(-1.0, vk, 0.0, nullptr, pk);
-      double sk_M_pk = 0, sk_M_2 = 0;
-      dots({{rk, vk}}, sc);
-      double rv = sc[0];
-      double pk_M_2 = rv;
-      const double Delta_2 = Delta * Delta;
-      const double r0 = std::sqrt(rv);
-      const double target = r0 * std::min(o.STPCG_kappa, std::pow(r0, o.STPCG_theta));
-      bool done = false;
-      int it = 0;
-      for (; it < o.max_tCG_iterations; ++it) {
-        if (std::sqrt(rv) <= target) break;
-        hess(X, pk, Hp);
-        dots({{pk, Hp}, {Hp, Hp}, {pk, pk}, {pk, rk}}, sc);
-        const double kappa_k = sc[0];
-        if (std::sqrt(sc[1]) / std::sqrt(sc[2]) < 1e-8) {   // :305-338
+    set_mask(A);
+    launch_axpby(d_, st_, T_, false, cur_mask_, 0.0, grad, 0.0, nullptr, sk, 0);
+    copy_rows(rk, grad, false, 0);
+    if (use_precon) precon(X, rk, vk); else copy_rows(vk, rk, false, 0);
+    launch_axpby(d_, st_, T_, false, cur_mask_, -1.0, vk, 0.0, nullptr, pk, 0);
+    dots({{rk, vk}});
+    for (int a : A) {
+      NodeTnt &s = S[a];
+      s.cg = true;
+      s.cg_it = 0;
+      s.sk_M_pk = s.sk_M_2 = 0;
+      s.rv = s.pk_M_2 = scal(a, 0);
+      s.Delta_2 = s.Delta * s.Delta;
+      const double r0 = std::sqrt(s.rv);
+      s.target = r0 * std::min(o.STPCG_kappa, std::pow(r0, o.STPCG_theta));
+      s.h_M_norm = 0;
+    }
+    for (;;) {
+      std::vector<int> C;
+      for (int a : A) {
+        NodeTnt &s = S[a];
+        if (!s.cg) continue;
+        if (s.cg_it >= o.max_tCG_iterations || std::sqrt(s.rv) <= s.target) {   // :285-291
+          s.h_M_norm = std::sqrt(s.sk_M_2);
+          s.cg = false;
+          continue;
+        }
+        C.push_back(a);
+      }
+      if (C.empty()) break;
+      set_mask(C);
+      hess(X, pk, Hp);
+      dots({{pk, Hp}, {Hp, Hp}, {pk, pk}, {pk, rk}});
+      std::vector<int> cont;
+      for (int a : C) {
+        NodeTnt &s = S[a];
+        const double kappa_k = scal(a, 0);
+        c1[a] = 0.0;   // coefficient of p_k in s_k += c1 p_k
+        if (std::sqrt(scal(a, 1)) / std::sqrt(scal(a, 2)) < 1e-8) {   // :305-338
           double sgn = 1.0;
-          if (sc[3] < 0) { sgn = -1.0; sk_M_pk = -sk_M_pk; }
-          const double sigma = (-sk_M_pk + std::sqrt(sk_M_pk * sk_M_pk + pk_M_2 * (Delta_2 - sk_M_2))) / pk_M_2;
-          axpby(1.0, sk, sgn * sigma, pk, sk);
-          h_M_norm = Delta;
-          done = true;
-          break;
+          if (scal(a, 3) < 0) { sgn = -1.0; s.sk_M_pk = -s.sk_M_pk; }
+          const double sigma = (-s.sk_M_pk + std::sqrt(s.sk_M_pk * s.sk_M_pk + s.pk_M_2 * (s.Delta_2 - s.sk_M_2))) / s.pk_M_2;
+          c1[a] = sgn * sigma;
+          s.h_M_norm = s.Delta;
+          s.cg = false;
+          continue;
         }
-        const double alpha = rv / kappa_k;
-        const double skp1 = sk_M_2 + 2 * alpha * sk_M_pk + alpha * alpha * pk_M_2;
-        if (kappa_k <= 0 || skp1 > Delta_2) {               // :347-362
-          const double sigma = (-sk_M_pk + std::sqrt(sk_M_pk * sk_M_pk + pk_M_2 * (Delta_2 - sk_M_2))) / pk_M_2;
-          axpby(1.0, sk, sigma, pk, sk);
-          h_M_norm = Delta;
-          done = true;
-          break;
+        const double alpha = s.rv / kappa_k;
+        const double skp1 = s.sk_M_2 + 2 * alpha * s.sk_M_pk + alpha * alpha * s.pk_M_2;
+        if (kappa_k <= 0 || skp1 > s.Delta_2) {   // :347-362
+          c1[a] = (-s.sk_M_pk + std::sqrt(s.sk_M_pk * s.sk_M_pk + s.pk_M_2 * (s.Delta_2 - s.sk_M_2))) / s.pk_M_2;
+          s.h_M_norm = s.Delta;
+          s.cg = false;
+          continue;
         }
-        axpby(1.0, sk, alpha, pk, sk);
-        axpby(1.0, rk, alpha, Hp, rk);
-        if (use_precon) precon(X, rk, vk); else copy_rows(vk, rk, false, 0);
-        dots({{rk, vk}}, sc);
-        const double rk_vk = sc[0];
-        const double beta = rk_vk / (alpha * kappa_k);
-        sk_M_2 = skp1;
-        sk_M_pk = beta * (sk_M_pk + alpha * pk_M_2);
-        pk_M_2 = rk_vk + beta * beta * pk_M_2;
-        axpby(-1.0, vk, beta, pk, pk);
-        rv = rk_vk;
+        c1[a] = alpha;
+        c2[a] = kappa_k;   // kept for beta
+        s.sk_M_2 = skp1;   // provisional: committed below together with sk_M_pk / pk_M_2
+        cont.push_back(a);
       }
-      if (!done) h_M_norm = std::sqrt(sk_M_2);
-      inner_total += it;
+      // s_k += c1 p_k for every node of C (final boundary step or regular step)
+      launch_axpby_node(d_, st_, T_, cur_mask_, upload_coef(ones), sk, upload_coef(c1), pk, sk);
+      if (cont.empty()) continue;
+      set_mask(cont);
+      launch_axpby_node(d_, st_, T_, cur_mask_, upload_coef(ones), rk, upload_coef(c1), Hp, rk);
+      if (use_precon) precon(X, rk, vk); else copy_rows(vk, rk, false, 0);
+      dots({{rk, vk}});
+      std::vector<double> beta(L, 0.0);
+      for (int a : cont) {
+        NodeTnt &s = S[a];
+        const double alpha = c1[a], kappa_k = c2[a], rk_vk = scal(a, 0);
+        const double be = rk_vk / (alpha * kappa_k);
+        s.sk_M_pk = be * (s.sk_M_pk + alpha * s.pk_M_2);
+        s.pk_M_2 = rk_vk + be * be * s.pk_M_2;
+        s.rv = rk_vk;
+        s.cg_it++;
+        beta[a] = be;
+      }
+      launch_axpby_node(d_, st_, T_, cur_mask_, upload_coef(mones), vk, upload_coef(beta), pk, pk);
     }
+    for (int a : A) S[a].inner_total += S[a].cg_it;
     // ---- trial point (TNT.h:505-536)
-    retract(X, sk, xprop);
-    const double fx_prop = fval(xprop);
+    set_mask(A);
+    launch_retract_rot(d_, st_, T_, cur_mask_, X, sk, xprop);
+    recover_translations(xprop, g);
+    eval_G(xprop, g, 4);
     hess(X, sk, hh);
-    dots({{sk, sk}, {grad, sk}, {sk, hh}}, sc);
-    const double h_norm = std::sqrt(sc[0]);
-    const double dm = -sc[1] - 0.5 * sc[2];
-    const double df = fx - fx_prop;
-    const double rel_dec = df / (sqrt_eps + std::fabs(fx));
-    const double rho = df / dm;
-    const bool step_accepted = (!std::isnan(rho)) && rho > eta1;
-    accepted += step_accepted;
-    if (step_accepted) {
-      copy_rows(X, xprop, false, 0);
-      fx = fx_prop;
-      if (rel_dec < o.rel_func_decrease_tol) { status = ST_REL_DECREASE; break; }
-      if (h_norm < o.stepsize_tol) { status = ST_STEPSIZE; break; }
-      quad_model(X);
-      dots({{grad, grad}}, sc);
-      gnorm = std::sqrt(sc[0]);
-      pgnorm = gnorm;
-      if (use_precon) {
-        precon(X, grad, pg);
-        dots({{pg, pg}}, sc);
-        pgnorm = std::sqrt(sc[0]);
+    launch_dot(d_, st_, T_, false, cur_mask_, sk, sk, 2, partials_.p, 0);
+    launch_dot(d_, st_, T_, false, cur_mask_, grad, sk, 2, partials_.p, 1);
+    launch_dot(d_, st_, T_, false, cur_mask_, sk, hh, 2, partials_.p, 2);
+    fetch(5, false);
+    std::vector<int> acc, requad;
+    for (int a : A) {
+      NodeTnt &s = S[a];
+      const double fx_prop = scal(a, 4) + res_[a].f;
+      const double h_norm = std::sqrt(scal(a, 0));
+      const double dm = -scal(a, 1) - 0.5 * scal(a, 2);
+      const double df = s.fx - fx_prop;
+      const double rel_dec = df / (sqrt_eps + std::fabs(s.fx));
+      const double rho = df / dm;
+      const bool ok = (!std::isnan(rho)) && rho > eta1;
+      s.accepted += ok;
+      bool stop = false;
+      if (ok) {
+        acc.push_back(a);
+        s.fx = fx_prop;
+        if (rel_dec < o.rel_func_decrease_tol) { s.status = ST_REL_DECREASE; stop = true; }
+        else if (h_norm < o.stepsize_tol) { s.status = ST_STEPSIZE; stop = true; }
+        else requad.push_back(a);
       }
+      if (!stop) {   // trust-region update (TNT.h:593-607)
+        if ((!std::isnan(rho)) && rho >= eta2) s.Delta = std::max(alpha2 * s.h_M_norm, s.Delta);
+        else if (std::isnan(rho) || rho < eta1) {
+          s.Delta = alpha1 * s.h_M_norm;
+          if (s.Delta < Delta_tol) { s.status = ST_TRUST_REGION; stop = true; }
+        }
+      }
+      if (stop) s.active = false;
+      else s.iteration++;
     }
-    if ((!std::isnan(rho)) && rho >= eta2) {
-      Delta = std::max(alpha2 * h_M_norm, Delta);
-    } else if (std::isnan(rho) || rho < eta1) {
-      Delta = alpha1 * h_M_norm;
-      if (Delta < Delta_tol) { status = ST_TRUST_REGION; break; }
+    if (!acc.empty()) {
+      set_mask(acc);
+      copy_rows(X, xprop, false, 0);
+    }
+    if (!requad.empty()) {
+      set_mask(requad);
+      quad_model(X);
+      norms(requad);
     }
   }
-  res.Gk = fx;
-  res.tnt_status = status;
-  res.tnt_inner = inner_total;
+  for (int a : nodes) {
+    res_[a].Gk = S[a].fx;
+    res_[a].tnt_status = S[a].status;
+    res_[a].tnt_inner = S[a].inner_total;
+  }
 }
 
 }  // namespace dpgo

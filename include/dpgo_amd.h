@@ -134,6 +134,15 @@ int dpgo_group_node_id(const dpgo_group_t *grp, int local);
 int dpgo_group_sync(const dpgo_group_t *grp);
 void *dpgo_group_stream(const dpgo_group_t *grp);   /* hipStream_t all work is enqueued on */
 
+/* ---- measurement hooks (bench.py) --------------------------------------------------------
+ * Per-launch timing of every kernel family with HIP events on the launch stream.  Off by default. */
+int dpgo_prof_enable(int on);
+int dpgo_prof_num_kinds(void);
+const char *dpgo_prof_kind_name(int kind);
+int dpgo_prof_collect(double *ms, double *bytes, long *count);   /* arrays of dpgo_prof_num_kinds() */
+/* size of the two multifrontal factors: dense front entries and number of tree levels */
+int dpgo_group_solver_stats(const dpgo_group_t *grp, long *nnz_tt, long *nnz_rr, int *levels_tt, int *levels_rr);
+
 /* ---- test hooks ------------------------------------------------------------------------- */
 /* Host: the assembled operator `name` in {"G","S","P","P0","Q","D"} of a node as COO triplets in
  * the REFERENCE row/column order.  Call with rows == NULL to get the count. */
