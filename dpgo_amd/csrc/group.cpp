@@ -67,14 +67,16 @@ void SpdSolverDev::upload(int dcols) {
   for (const auto &lvl : F.by_depth) bwd_level_bytes.push_back(lvl_bytes(lvl));
   // per level: first the tiles of small fronts (one wave each), then the tiles of wide fronts
   // (8 waves each, columns / rows split between the waves)
-  auto wide = [&](int f) { return F.w[f] > 2 * 128; };
+  // the reduction length decides: columns (w) in the forward sweep, rows (w+u) in the backward sweep
+  auto wide_fwd = [&](int f) { return F.w[f] > 96; };
+  auto wide_bwd = [&](int f) { return F.w[f] + F.u[f] > 96; };
   fwd_big_ptr.clear();
   bwd_big_ptr.clear();
   for (const auto &lvl : F.by_height) {
     for (int pass = 0; pass < 2; pass++) {
       if (pass == 1) fwd_big_ptr.push_back((int)fi.size());
       for (int f : lvl) {
-        if ((int)wide(f) != pass) continue;
+        if ((int)wide_fwd(f) != pass) continue;
         const int m = F.w[f] + F.u[f];
         for (int r = 0; r < m; r += 64) fi.push_back(make_int4(f, r, std::min(64, m - r), 0));
       }
@@ -86,7 +88,7 @@ void SpdSolverDev::upload(int dcols) {
     for (int pass = 0; pass < 2; pass++) {
       if (pass == 1) bwd_big_ptr.push_back((int)bi.size());
       for (int f : lvl) {
-        if ((int)wide(f) != pass) continue;
+        if ((int)wide_bwd(f) != pass) continue;
         for (int c = 0; c < F.w[f]; c += 64) bi.push_back(make_int4(f, c, std::min(64, F.w[f] - c), 0));
       }
     }

@@ -706,9 +706,19 @@ __global__ __launch_bounds__(64 * NW) void k_spd_fwd(SpdDev S, int item0, const 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (valid) {
+      // batches of 16 independent loads in flight per lane before the first use
       const double *wp = WT + (size_t)k0 * m + p;
-#pragma unroll 8
-      for (int kk = 0; kk < kn; kk++) {
+      int kk = 0;
+      for (; kk + 16 <= kn; kk += 16) {
+        double wv16[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) wv16[q] = wp[(size_t)(kk + q) * m];
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+#pragma unroll
+          for (int c = 0; c < D; c++) acc[c] = fma(wv16[q], fw[(kk + q) * D + c], acc[c]);
+      }
+      for (; kk < kn; kk++) {
         const double wval = wp[(size_t)kk * m];
 #pragma unroll
         for (int c = 0; c < D; c++) acc[c] = fma(wval, fw[kk * D + c], acc[c]);
@@ -776,8 +786,17 @@ __global__ __launch_bounds__(64 * NW) void k_spd_bwd(SpdDev S, int item0, double
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (valid) {
       const double *wp = W + (size_t)p0 * w + k;
-#pragma unroll 8
-      for (int pp = 0; pp < pn; pp++) {
+      int pp = 0;
+      for (; pp + 16 <= pn; pp += 16) {
+        double wv16[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) wv16[q] = wp[(size_t)(pp + q) * w];
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+#pragma unroll
+          for (int c = 0; c < D; c++) acc[c] = fma(wv16[q], fw[(pp + q) * D + c], acc[c]);
+      }
+      for (; pp < pn; pp++) {
         const double wval = wp[(size_t)pp * w];
 #pragma unroll
         for (int c = 0; c < D; c++) acc[c] = fma(wval, fw[pp * D + c], acc[c]);
