@@ -21,6 +21,24 @@ import os
 import sys
 import time
 
+
+def _host_cores():
+    """CPU cores this process may really use (cgroup quota), for thread-pool sizing."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(p)))
+    except Exception:
+        pass
+    return n
+
+
+# keep BLAS / OpenMP pools inside the CPU quota (the GPU boxes show 256 CPUs behind a 16-core quota)
+_share = max(1, min(_host_cores(), 32) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))))
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "DPGO_HOST_THREADS"):
+    os.environ.setdefault(_v, str(_share))
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -89,6 +89,7 @@ SYMBOLS = {
     "dpgo_graph_node_sizes": (C.c_int, [C.c_void_p, C.c_int, _IP, _IP, _IP, _IP]),
     "dpgo_graph_node_neighbours": (C.c_int, [C.c_void_p, C.c_int, _IP, _IP]),
     "dpgo_graph_node_offset": (C.c_int, [C.c_void_p, C.c_int]),
+    "dpgo_graph_exchange_plan": (C.c_int, [C.c_void_p, _IP, C.c_int, _IP, _IP, _IP, _IP, _IP]),
     "dpgo_chordal_initialization": (C.c_int, [C.c_void_p, _DP, C.c_int]),
     "dpgo_group_create": (C.c_int, [C.c_void_p, _IP, C.c_int, C.POINTER(Options), C.c_int, C.POINTER(C.c_void_p)]),
     "dpgo_group_free": (None, [C.c_void_p]),
@@ -187,6 +188,16 @@ class Graph:
 
     def node_offset(self, node):
         return lib().dpgo_graph_node_offset(self._h, node)
+
+    def exchange_plan(self, node_ids):
+        """(sent (node, pose) keys, recv (node, pose) keys) of a group hosting node_ids (host only)."""
+        ids = np.asarray(list(node_ids), np.int32)
+        cnt = np.zeros(2, np.int32)
+        if lib().dpgo_graph_exchange_plan(self._h, _ip(ids), len(ids), None, None, None, None, _ip(cnt)) != 0:
+            raise ValueError("exchange_plan")
+        sn, sp_, rn, rp = (np.empty(c, np.int32) for c in (cnt[0], cnt[0], cnt[1], cnt[1]))
+        lib().dpgo_graph_exchange_plan(self._h, _ip(ids), len(ids), _ip(sn), _ip(sp_), _ip(rn), _ip(rp), _ip(cnt))
+        return (sn, sp_), (rn, rp)
 
     def chordal_initialization(self):
         """Centralised chordal init (dist_pgo.cpp:416-444): X, (d+1)N x d, reference layout."""

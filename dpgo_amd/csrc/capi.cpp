@@ -4,6 +4,7 @@
 #include <cstring>
 #include <map>
 #include <numeric>
+#include <set>
 
 #include "group.h"
 
@@ -148,6 +149,31 @@ int dpgo_graph_node_neighbours(const dpgo_graph_t *g, int node, int *nbr_node, i
 int dpgo_graph_node_offset(const dpgo_graph_t *g, int node) {
   if (!g || node < 0 || node >= g->g.num_nodes || g->g.g_index[node].empty()) return -1;
   return g->g.g_index[node].begin()->second;
+}
+
+int dpgo_graph_exchange_plan(const dpgo_graph_t *g, const int *node_ids, int num_local, int *sent_nodes,
+                             int *sent_poses, int *recv_nodes, int *recv_poses, int *counts) {
+  // which own poses the nodes of this group export to nodes outside it, and which neighbour poses
+  // they import from outside (sorted by (node, pose)); pointers may be NULL to query the counts
+  if (!g || num_local <= 0) return -1;
+  std::set<int> local(node_ids, node_ids + num_local);
+  std::set<std::pair<int, int>> sent, recv;
+  for (int k = 0; k < num_local; k++) {
+    dpgo::DataInfo info;
+    if (node_info(g, node_ids[k], info) != 0) return -1;
+    for (const auto &s : info.sent)
+      if (!local.count(s.first))
+        for (int row : s.second) sent.insert({node_ids[k], info.own_pose[row]});
+    for (const auto &key : info.nbr_key)
+      if (!local.count(key.first)) recv.insert(key);
+  }
+  counts[0] = (int)sent.size();
+  counts[1] = (int)recv.size();
+  int i = 0;
+  if (sent_nodes) for (const auto &s : sent) { sent_nodes[i] = s.first; sent_poses[i] = s.second; i++; }
+  i = 0;
+  if (recv_nodes) for (const auto &s : recv) { recv_nodes[i] = s.first; recv_poses[i] = s.second; i++; }
+  return 0;
 }
 
 int dpgo_chordal_initialization(const dpgo_graph_t *g, double *X, int ld) {

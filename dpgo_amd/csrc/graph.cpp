@@ -3,11 +3,47 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <set>
 #include <sstream>
+#include <thread>
+
+#include <sched.h>
 
 namespace dpgo {
+
+int host_threads() {
+  static int cached = 0;
+  if (cached) return cached;
+  if (const char *e = getenv("DPGO_HOST_THREADS")) {
+    const int v = atoi(e);
+    if (v > 0) return cached = v;
+  }
+  int n = (int)std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64];
+    long period = 0;
+    if (fscanf(f, "%63s %ld", q, &period) == 2 && q[0] != 'm' && period > 0) {
+      long quota = atol(q);
+      if (quota > 0) n = std::min<long>(n, std::max<long>(1, quota / period));
+    }
+    fclose(f);
+  } else if (FILE *f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+    long quota = -1, period = 100000;
+    if (fscanf(f1, "%ld", &quota) != 1) quota = -1;
+    fclose(f1);
+    if (FILE *f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (fscanf(f2, "%ld", &period) != 1) period = 100000;
+      fclose(f2);
+    }
+    if (quota > 0 && period > 0) n = std::min<long>(n, std::max<long>(1, quota / period));
+  }
+  cached = std::max(1, std::min(n, 64));
+  return cached;
+}
 
 static double trace_inv3(const double a[9]) {
   // trace of the inverse of a 3x3 matrix = (sum of principal 2x2 minors) / det

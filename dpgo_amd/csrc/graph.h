@@ -58,4 +58,9 @@ struct DataInfo {
 };
 int generate_data_info(int a, int d, const measurements_t &meas, DataInfo &info);
 
+// Host threads this process may really use: min(cgroup CPU quota, affinity mask), at least 1.
+// (The GPU boxes expose 256 logical CPUs behind a 16-core quota; spinning 256 OpenMP threads there
+// is an order of magnitude slower than 16.)
+int host_threads();
+
 }  // namespace dpgo

@@ -1,5 +1,9 @@
 #include "spd.h"
 
+#include <omp.h>
+
+#include "graph.h"
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -128,6 +132,7 @@ struct Dissector {
 
 int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf) {
   const int n = A.n;
+  omp_set_num_threads(host_threads());
   F = SpdFactor();
   F.n = n;
   // adjacency without the diagonal

@@ -95,6 +95,11 @@ int dpgo_graph_node_sizes(const dpgo_graph_t *g, int node, int *n0, int *n1, int
 int dpgo_graph_node_neighbours(const dpgo_graph_t *g, int node, int *nbr_node, int *nbr_pose);
 /* first global pose id of a node (g_index[node].begin()->second, dist_pgo.cpp:470) */
 int dpgo_graph_node_offset(const dpgo_graph_t *g, int node);
+/* Boundary-exchange plan of a group of nodes (host only): the (node, pose) keys it exports to and
+ * imports from nodes outside the group, both sorted.  counts[0] = exported, counts[1] = imported; the
+ * key arrays may be NULL to query the counts.  (sent_ / recv_ of C++/DPGO/src/DPGO_utils.cpp:428-435.) */
+int dpgo_graph_exchange_plan(const dpgo_graph_t *g, const int *node_ids, int num_local, int *sent_nodes,
+                             int *sent_poses, int *recv_nodes, int *recv_poses, int *counts);
 /* Centralised chordal initialisation -- C++/examples/dist_pgo.cpp:416-444
  * (C++/SESync/src/SESync_utils.cpp:573-652).  Host, set-up only.  X: (d+1)N x d. */
 int dpgo_chordal_initialization(const dpgo_graph_t *g, double *X, int ld);
