@@ -47,6 +47,9 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g) {
   const bool use_precon = (o.preconditioner == 1) && Lrr_.F.n > 0;
   double *nabla = tmp_[0].p, *grad = tmp_[1].p, *sk = tmp_[2].p, *rk = tmp_[3].p, *vk = tmp_[4].p, *pk = tmp_[5].p,
          *Hp = tmp_[6].p, *xprop = tmp_[7].p, *w1 = tmp_[8].p, *w2 = tmp_[9].p, *pg = tmp_[10].p, *hh = tmp_[11].p;
+  // hh accumulates H s_k alongside s_k (every step s_k += c p_k is mirrored by hh += c H p_k), so the
+  // predicted decrease needs no extra Hessian-vector product: same value as Hess(x, h) of TNT.h:514-515
+  // up to rounding of the CG recurrence.
   std::vector<NodeTnt> S(L);
   for (auto &s : S) s.active = false;
   for (int a : nodes) S[a] = NodeTnt();
@@ -111,8 +114,10 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g) {
     // ---- STPCG (IterativeSolvers.h:207-426)
     set_mask(A);
     launch_axpby(d_, st_, T_, false, cur_mask_, 0.0, grad, 0.0, nullptr, sk, 0);
+    launch_axpby(d_, st_, T_, false, cur_mask_, 0.0, grad, 0.0, nullptr, hh, 0);
     copy_rows(rk, grad, false, 0);
-    if (use_precon) precon(X, rk, vk); else copy_rows(vk, rk, false, 0);
+    // v_0 = P(r_0) = P(grad): already computed for the preconditioned gradient norm (pg)
+    copy_rows(vk, use_precon ? pg : rk, false, 0);
     launch_axpby(d_, st_, T_, false, cur_mask_, -1.0, vk, 0.0, nullptr, pk, 0);
     dots({{rk, vk}});
     for (int a : A) {
@@ -170,7 +175,11 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g) {
         cont.push_back(a);
       }
       // s_k += c1 p_k for every node of C (final boundary step or regular step)
-      launch_axpby_node(d_, st_, T_, cur_mask_, upload_coef(ones), sk, upload_coef(c1), pk, sk);
+      {
+        const double *one_d = upload_coef(ones), *c1_d = upload_coef(c1);
+        launch_axpby_node(d_, st_, T_, cur_mask_, one_d, sk, c1_d, pk, sk);
+        launch_axpby_node(d_, st_, T_, cur_mask_, one_d, hh, c1_d, Hp, hh);
+      }
       if (cont.empty()) continue;
       set_mask(cont);
       launch_axpby_node(d_, st_, T_, cur_mask_, upload_coef(ones), rk, upload_coef(c1), Hp, rk);
@@ -195,7 +204,6 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g) {
     launch_retract_rot(d_, st_, T_, cur_mask_, X, sk, xprop);
     recover_translations(xprop, g);
     eval_G(xprop, g, 4);
-    hess(X, sk, hh);
     launch_dot(d_, st_, T_, false, cur_mask_, sk, sk, 2, partials_.p, 0);
     launch_dot(d_, st_, T_, false, cur_mask_, grad, sk, 2, partials_.p, 1);
     launch_dot(d_, st_, T_, false, cur_mask_, sk, hh, 2, partials_.p, 2);
@@ -217,7 +225,8 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g) {
         s.fx = fx_prop;
         if (rel_dec < o.rel_func_decrease_tol) { s.status = ST_REL_DECREASE; stop = true; }
         else if (h_norm < o.stepsize_tol) { s.status = ST_STEPSIZE; stop = true; }
-        else requad.push_back(a);
+        else if (s.iteration + 1 < o.max_iterations && s.accepted < o.max_iterations_accepted)
+          requad.push_back(a);   // the new model is only needed if another iteration follows (TNT.h:446-449)
       }
       if (!stop) {   // trust-region update (TNT.h:593-607)
         if ((!std::isnan(rho)) && rho >= eta2) s.Delta = std::max(alpha2 * s.h_M_norm, s.Delta);
