@@ -59,6 +59,10 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--backend", type=str, default="nccl",
+                    help="nccl (RCCL over xGMI, one GPU per rank) or gloo (host-staged; lets several ranks share one "
+                         "GPU, used by the tests to exercise the multi-process path on a 1-GPU box)")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use GPU 0 (gloo backend only)")
     args = ap.parse_args()
 
     import torch
@@ -72,12 +76,19 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.nodes % world != 0:
         raise SystemExit("num_nodes must be divisible by the number of GPUs")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    host_staged = args.backend == "gloo"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if host_staged:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    cdev = "cpu" if host_staged else "cuda"
 
     # ---- set-up (untimed): graph, partition, chordal initialisation, operators, factorizations
     t0 = time.time()
@@ -106,13 +117,21 @@ def main():
         grp.set_recv_layout(stride, [(np.asarray(k[0], np.int32), np.asarray(k[1], np.int32)) for k in allkeys])
         send = torch.zeros(stride * RS, dtype=torch.float64, device="cuda")
         gathered = torch.zeros(world * stride * RS, dtype=torch.float64, device="cuda")
+        if host_staged:
+            send_h = torch.zeros(stride * RS, dtype=torch.float64)
+            gathered_h = torch.zeros(world * stride * RS, dtype=torch.float64)
 
     def exchange():
         grp.communicate_local()
         if world > 1:
             grp.pack_sent(send.data_ptr())
             grp.sync()                                   # pack runs on the group's stream
-            dist.all_gather_into_tensor(gathered, send)  # RCCL over xGMI
+            if host_staged:
+                send_h.copy_(send)
+                dist.all_gather_into_tensor(gathered_h, send_h)
+                gathered.copy_(gathered_h)
+            else:
+                dist.all_gather_into_tensor(gathered, send)  # RCCL over xGMI
             torch.cuda.current_stream().synchronize()
             grp.unpack_recv(gathered.data_ptr())
 
@@ -140,7 +159,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     # objective after the timed region: sum_a fobj^a == F
@@ -148,7 +167,7 @@ def main():
     refined = sum(int(grp.results(k).refined) for k in range(len(grp)))
     inner = sum(int(grp.results(k).tnt_inner_iterations) for k in range(len(grp)))
     if world > 1:
-        tt = torch.tensor([fsum, refined, inner], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([fsum, refined, inner], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt)
         fsum, refined, inner = (float(v) for v in tt.tolist())
 

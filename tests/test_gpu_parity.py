@@ -162,3 +162,25 @@ def test_error_conventions(fixtures_dir):
     assert grp[0].initialize(np.zeros((3, 3))) == -1            # inconsistent size -> -1
     with pytest.raises(IOError):
         dpgo_amd.read_g2o("/nonexistent.g2o", 2)
+
+
+def test_multiprocess_path_matches_single_process(tmp_path):
+    """bench.py with 2 ranks (gloo-staged exchange, both ranks on the one GPU of the test box) must follow
+    the SAME trajectory as the single-process run: the pack / all-gather / unpack path is exact."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--grid", "10,10,8,2400", "--steps", "6", "--warmup", "2", "--no-prof", "--no-cpu"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True,
+                         timeout=600, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--backend", "gloo", "--share-gpu"] + common,
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert two.returncode == 0, two.stderr[-3000:]
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert j2["n_gpus"] == 2 and j2["config"]["nodes_per_gpu"] == 4
+    assert abs(j1["objective_2F"] - j2["objective_2F"]) <= 1e-10 * abs(j1["objective_2F"])
