@@ -113,6 +113,91 @@ def test_trace_matches_oracle(fixtures_dir, name, nn, loss, acc, iters):
     assert abs(Fg - Fo) <= 1e-6 * abs(Fo)          # north_star: same objective within 1e-6 relative
 
 
+BASELINE_CASES = [
+    ("sphere2500", 1, LOSS_NONE, True, 25),     # BASELINE config 2: AMM-PGO#, num_nodes = 1
+    ("torus3D", 8, LOSS_NONE, True, 20),        # BASELINE config 3
+    ("city10000", 8, LOSS_NONE, True, 12),      # BASELINE config 3 (SE(2))
+    ("torus3D", 8, LOSS_HUBER, True, 15),
+    ("city10000", 8, LOSS_HUBER, True, 10),
+]
+
+
+@pytest.mark.parametrize("name,nn,loss,acc,iters", BASELINE_CASES)
+def test_baseline_configs_match_oracle(fixtures_dir, name, nn, loss, acc, iters):
+    """The BASELINE.json datasets: per-node objective trace within 1e-7 relative, final global objective
+    within 1e-6 relative (north_star), rotations within 1e-6.  With one node G_tt = Laplacian + 1e-11 I is
+    numerically singular along the constant vector (the gauge), so translations are compared after
+    removing their mean."""
+    orc, gpu = _pair(fixtures_dir, name, nn, loss, acc)
+    d = orc.d
+    diverged = False
+    for it in range(iters):
+        # the refine decision of the NEXT iterate() is a threshold test (DPGOHash.cpp:351-355); when the
+        # oracle sits within 5 % of the threshold a rounding-level difference may flip it, after which the
+        # two runs follow different (equally valid) trajectories to the same optimum
+        near = False
+        for a in range(nn):
+            ro, rg = orc.nodes[a].results, gpu.group.results(a)
+            ratio = ro.gradFnorm ** 2 / ro.fobj[0]
+            near = near or abs(ratio / orc.options.accepted_delta - 1) < 0.05
+            # ... and once converged, fobj[k] <= fobj[k-1] (restart / oscillation counters,
+            # DPGOHash.cpp:181-204) is decided by rounding noise
+            near = near or abs(ro.fobj[0] - ro.fobj[1]) <= 1e-9 * abs(ro.fobj[0])
+        orc.step(evaluate=False)
+        assert gpu.step() == 0
+        for a in range(nn):
+            ro, rg = orc.nodes[a].results, gpu.group.results(a)
+            if bool(rg.refined) != bool(ro.refined):
+                assert near, "refine decision differs away from the threshold (it=%d node=%d)" % (it, a)
+                diverged = True
+        if diverged:
+            break
+        for a in range(nn):
+            ro, rg = orc.nodes[a].results, gpu.group.results(a)
+            np.testing.assert_allclose(rg.fobj, ro.fobj[0], rtol=1e-7, err_msg="fobj it=%d node=%d" % (it, a))
+            np.testing.assert_allclose(rg.Gk, ro.Gk, rtol=1e-7, err_msg="Gk it=%d node=%d" % (it, a))
+    if diverged:
+        assert it >= 8      # a long common prefix was compared before the flip
+        for _ in range(120):
+            orc.step(evaluate=False)
+            assert gpu.step() == 0
+        Fo = orc.star.evaluate_f(orc.gather())
+        assert abs(orc.star.evaluate_f(gpu.X()) - Fo) <= 1e-6 * abs(Fo)
+        return
+    for a in range(nn):
+        n0 = orc.nodes[a].problem.n[0]
+        Xg, Xo = gpu.group[a].Xk(), orc.nodes[a].results.Xk
+        np.testing.assert_allclose(Xg[n0:n0 + d * n0], Xo[n0:n0 + d * n0], atol=1e-6)
+        tg, to = Xg[:n0], Xo[:n0]
+        if nn == 1:
+            tg, to = tg - tg.mean(0), to - to.mean(0)
+        np.testing.assert_allclose(tg, to, atol=1e-5)
+    Fo = orc.star.evaluate_f(orc.gather())
+    assert abs(orc.star.evaluate_f(gpu.X()) - Fo) <= 1e-6 * abs(Fo)
+
+
+def test_synthetic_lattice_matches_oracle():
+    """Scaled-down instance of the headline workload (same generator, Huber, AMM-PGO#, 8 nodes)."""
+    from dpgo_amd import synthetic
+    from oracle.g2o import Measurements
+    g = synthetic.grid(12, 12, 8, 4000)
+    z = np.zeros(len(g["I"]), np.int64)
+    mm = Measurements(z, g["I"], z, g["J"], g["R"], g["t"], g["kappa"], g["tau"])
+    G = dpgo_amd.graph_from_edges(3, g["num_poses"], g["I"], g["J"], g["R"], g["t"], g["kappa"], g["tau"], 8)
+    X0 = G.chordal_initialization()
+    orc = ODistPGO(None, 8, _oracle_opts(LOSS_HUBER, True), X0=X0, mm=mm, num_poses=g["num_poses"])
+    gpu = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(LOSS_HUBER, True), X0=X0)
+    for it in range(25):
+        orc.step(evaluate=False)
+        assert gpu.step() == 0
+        for a in range(8):
+            np.testing.assert_allclose(gpu.group.results(a).fobj, orc.nodes[a].results.fobj[0], rtol=1e-7,
+                                       err_msg="it=%d node=%d" % (it, a))
+    Fo = orc.star.evaluate_f(orc.gather())
+    assert abs(orc.star.evaluate_f(gpu.X()) - Fo) <= 1e-6 * abs(Fo)
+    assert abs(gpu.sum_fobj() - Fo) <= 1e-6 * abs(Fo)
+
+
 def test_no_refine_path(fixtures_dir):
     """max_iterations = 0 disables the TNT branch (DPGOHash.cpp:351-355): pure proximal + solve path."""
     orc, gpu = _pair(fixtures_dir, "smallGrid3D", 2, LOSS_HUBER, True, max_iterations=0)
