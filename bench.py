@@ -63,6 +63,10 @@ def main():
                     help="nccl (RCCL over xGMI, one GPU per rank) or gloo (host-staged; lets several ranks share one "
                          "GPU, used by the tests to exercise the multi-process path on a 1-GPU box)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use GPU 0 (gloo backend only)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="diagnostic: host only the nodes rank --emulate-rank would own in an N-GPU run, with frozen "
+                         "neighbours and no exchange, to see the per-GPU step time of that run on one GPU")
+    ap.add_argument("--emulate-rank", type=int, default=0)
     args = ap.parse_args()
 
     import torch
@@ -101,6 +105,9 @@ def main():
     t_init = time.time() - t0
     per = args.nodes // world
     my_nodes = list(range(rank * per, (rank + 1) * per))
+    if args.emulate_world:
+        per = args.nodes // args.emulate_world
+        my_nodes = list(range(args.emulate_rank * per, (args.emulate_rank + 1) * per))
     t0 = time.time()
     grp = dpgo_amd.NodeGroup(G, my_nodes, opt, device=local_rank)
     t_group = time.time() - t0
@@ -205,6 +212,7 @@ def main():
             "value": args.steps / elapsed, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "diagnostic_emulated_rank": ("%d of %d" % (args.emulate_rank, args.emulate_world)) if args.emulate_world else None,
             "config": {"workload": "synthetic SE(3) lattice %dx%dx%d, %d poses / %d edges, %s loss, AMM-PGO#, "
                                    "num_nodes=%d (%d per GPU), chordal init" % (nx, ny, nz, g["num_poses"], len(g["I"]),
                                                                              args.loss, args.nodes, per),

@@ -118,6 +118,7 @@ SYMBOLS = {
     "dpgo_debug_node_matrix": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Options), C.c_char_p, _IP, _IP, _DP]),
     "dpgo_debug_node_proximal": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Options), _DP, _DP, _DP]),
     "dpgo_debug_spd_solve": (C.c_int, [C.c_int, _IP, _IP, _DP, _DP, C.c_int, C.c_int]),
+    "dpgo_debug_spd_stats": (C.c_int, [C.c_int, _IP, _IP, _DP, C.c_int, C.POINTER(C.c_long), _IP, _IP]),
     "dpgo_group_debug_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, _DP, C.c_int, _DP, C.c_int]),
 }
 
@@ -271,6 +272,16 @@ def prof_collect():
     ms, by, cnt = np.zeros(n), np.zeros(n), np.zeros(n, np.int64)
     lib().dpgo_prof_collect(_dp(ms), _dp(by), cnt.ctypes.data_as(C.POINTER(C.c_long)))
     return {lib().dpgo_prof_kind_name(k).decode(): (float(ms[k]), float(by[k]), int(cnt[k])) for k in range(n)}
+
+
+def spd_stats(A_csr, leaf):
+    A = A_csr.tocsr()
+    A.sort_indices()
+    ptr, col, val = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    nnz, lv, mf = C.c_long(), C.c_int(), C.c_int()
+    if lib().dpgo_debug_spd_stats(A.shape[0], _ip(ptr), _ip(col), _dp(val), leaf, C.byref(nnz), C.byref(lv), C.byref(mf)) != 0:
+        raise RuntimeError("spd_stats failed")
+    return nnz.value, lv.value, mf.value
 
 
 class NodeGroup:

@@ -325,6 +325,21 @@ int dpgo_group_solver_stats(const dpgo_group_t *h, long *nnz_tt, long *nnz_rr, i
   return 0;
 }
 
+int dpgo_debug_spd_stats(int n, const int *ptr, const int *col, const double *val, int leaf, long *nnz, int *levels,
+                         int *max_front) {
+  dpgo::CsrMatrix A;
+  A.n = n;
+  A.ptr.assign(ptr, ptr + n + 1);
+  A.col.assign(col, col + ptr[n]);
+  A.val.assign(val, val + ptr[n]);
+  dpgo::SpdFactor F;
+  if (dpgo::spd_factor(A, F, leaf) != 0) return -1;
+  *nnz = (long)F.nnz();
+  *levels = (int)F.by_height.size();
+  *max_front = F.max_front;
+  return 0;
+}
+
 int dpgo_group_debug_apply(dpgo_group_t *h, int local, const char *op, const double *in, int ld_in, double *out,
                            int ld_out) {
   return h->grp->debug_apply(local, op, in, ld_in, out, ld_out);

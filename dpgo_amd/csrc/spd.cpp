@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <numeric>
 #include <queue>
@@ -130,7 +131,7 @@ struct Dissector {
 
 }  // namespace
 
-int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf) {
+static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int collapse, bool symbolic_only) {
   const int n = A.n;
   omp_set_num_threads(host_threads());
   F = SpdFactor();
@@ -156,7 +157,39 @@ int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf) {
     std::iota(all.begin(), all.end(), 0);
     D.dissect(std::move(all), -1);
   }
-  // drop empty separators (can appear when a level is empty) by keeping them: harmless (w = 0)
+  // Level collapsing: absorb every tree node whose depth is not a multiple of `collapse` into its
+  // nearest ancestor whose depth is.  The merged front factors the absorbed separators together as one
+  // dense block (a few structural zeros become explicit), which divides the number of tree levels --
+  // i.e. of dependent kernel launches per solve -- by `collapse`.  On the GPU a level costs ~10 us of
+  // latency regardless of its size, so fewer and fatter levels win until the extra bytes dominate.
+  if (collapse > 1) {
+    const int n0 = (int)D.nodes.size();
+    std::vector<int> depth(n0, 0), keeper(n0, 0);
+    // parents are created before their children, so a forward pass sees parents first
+    for (int t = 0; t < n0; t++) {
+      const int p = D.nodes[t].parent;
+      depth[t] = p < 0 ? 0 : depth[p] + 1;
+      keeper[t] = (depth[t] % collapse == 0) ? t : keeper[p];
+    }
+    std::vector<TreeNode> merged;
+    std::vector<int> new_id(n0, -1);
+    for (int t = 0; t < n0; t++)
+      if (keeper[t] == t) {
+        new_id[t] = (int)merged.size();
+        merged.push_back(TreeNode());
+      }
+    for (int t = 0; t < n0; t++) {
+      TreeNode &dst = merged[new_id[keeper[t]]];
+      dst.verts.insert(dst.verts.end(), D.nodes[t].verts.begin(), D.nodes[t].verts.end());
+      if (keeper[t] == t) {
+        const int p = D.nodes[t].parent;
+        dst.parent = p < 0 ? -1 : new_id[keeper[p]];
+      }
+    }
+    for (int k = 0; k < (int)merged.size(); k++)
+      if (merged[k].parent >= 0) merged[merged[k].parent].children.push_back(k);
+    D.nodes.swap(merged);
+  }
   const int nt = (int)D.nodes.size();
   // post-order
   std::vector<int> post;  // tree node ids in post-order
@@ -241,6 +274,15 @@ int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf) {
   F.total_upd = F.ubuf_off[nt];
   F.upd_idx.resize(F.upd_ptr[nt]);
   for (int f = 0; f < nt; f++) std::copy(upd[f].begin(), upd[f].end(), F.upd_idx.begin() + F.upd_ptr[f]);
+  if (symbolic_only) {
+    F.height.assign(nt, 0);
+    for (int f = 0; f < nt; f++)
+      if (F.parent[f] >= 0) F.height[F.parent[f]] = std::max(F.height[F.parent[f]], F.height[f] + 1);
+    int mh = 0;
+    for (int f = 0; f < nt; f++) mh = std::max(mh, F.height[f]);
+    F.by_height.assign(mh + 1, {});
+    return 0;
+  }
   F.W.assign(F.w_off[nt], 0.0);
   F.WT.assign(F.w_off[nt], 0.0);
 
@@ -430,6 +472,24 @@ int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf) {
     F.by_depth[F.depth[f]].push_back(f);
   }
   return 0;
+}
+
+int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf, int collapse) {
+  if (const char *e = getenv("DPGO_SPD_COLLAPSE")) collapse = atoi(e);
+  if (collapse <= 0) {
+    // choose the number of merged levels from a latency + bandwidth model of one sweep on MI355X:
+    // every tree level is one dependent launch (~12 us, measured), every factor entry is read once
+    double best = 1e300;
+    int best_c = 1;
+    for (int c = 1; c <= 3; c++) {
+      SpdFactor S;
+      if (spd_factor_impl(A, S, leaf, c, true) != 0) continue;
+      const double t = 12e-6 * (double)S.by_height.size() + 8.0 * (double)S.w_off.back() / 3.0e12;
+      if (t < best) { best = t; best_c = c; }
+    }
+    collapse = best_c;
+  }
+  return spd_factor_impl(A, F, leaf, collapse, false);
 }
 
 void spd_solve_host(const SpdFactor &F, double *X, int nc) {

@@ -48,7 +48,9 @@ struct SpdFactor {
 
 // Factor A (symmetric positive definite, full pattern in CSR).  leaf = max
 // vertices of a nested-dissection leaf.  Returns 0, or -1 if a pivot is not positive.
-int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf = 32);
+// collapse = number of nested-dissection levels merged into one front (1 = plain binary tree,
+// 0 = choose 1..3 from a latency + bandwidth model of the device solve).
+int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf = 32, int collapse = 0);
 
 // Host solve (setup paths and tests): X (n x ncols, row-major) <- A^-1 X.
 void spd_solve_host(const SpdFactor &F, double *X, int ncols);

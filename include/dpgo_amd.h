@@ -159,6 +159,9 @@ int dpgo_debug_node_proximal(const dpgo_graph_t *g, int node, const dpgo_options
 /* Host: multifrontal factor + solve of a CSR SPD matrix, X (n x ncols row-major) <- A^-1 X. */
 int dpgo_debug_spd_solve(int n, const int *ptr, const int *col, const double *val, double *X, int ncols,
                          int leaf);
+/* Host: size of the multifrontal factor of a CSR SPD matrix for a given nested-dissection leaf size. */
+int dpgo_debug_spd_stats(int n, const int *ptr, const int *col, const double *val, int leaf, long *nnz, int *levels,
+                         int *max_front);
 /* Device: single operators of one node on reference-layout inputs:
  *  "project" (d n0 x d -> nearest rotations), "solve_tt" ((d+1) n0 x d, translation rows),
  *  "solve_rr" (rotation rows), "G" ((d+1) n0 x d -> G X), "proximal" (in = [Z ; Df] stacked). */
