@@ -687,10 +687,18 @@ int Group::update(const std::vector<int> &locals_in) {
   const bool trivial = (opt_.loss == 0);
   set_mask(locals);
   // history: X[iter-1] <- X[iter], X[iter] <- Xk ; same for g and Dfobj (masked nodes only)
-  copy_rows(Zp_.p, Zc_.p, true);
-  copy_rows(Zc_.p, Xk_.p, true);
-  copy_rows(gp_.p, gc_.p, false);
-  copy_rows(Dfp_.p, Dfc_.p, false);
+  if ((int)locals.size() == num_local()) {
+    // every node advances: rotate the buffers instead of copying them
+    Zp_.swap(Zc_);
+    gp_.swap(gc_);
+    Dfp_.swap(Dfc_);
+    copy_rows(Zc_.p, Xk_.p, true);
+  } else {
+    copy_rows(Zp_.p, Zc_.p, true);
+    copy_rows(Zc_.p, Xk_.p, true);
+    copy_rows(gp_.p, gc_.p, false);
+    copy_rows(Dfp_.p, Dfc_.p, false);
+  }
   std::vector<int> first, later;
   for (int a : locals) (res_[a].iters == 0 ? first : later).push_back(a);
   if (trivial) {
@@ -835,7 +843,7 @@ int Group::amm(const std::vector<int> &locals) {
   for (int a : locals)
     if (!res_[a].refined) plain.push_back(a);
   // Gk for nodes that are not refined; refined nodes run TNT first (:374-383)
-  eval_G(Xak_.p, gc_.p, 2);
+  if (!plain.empty()) eval_G(Xak_.p, gc_.p, 2);
   fetch(3, false);
   std::vector<double> Gkh(num_local(), 0.0), minG(num_local(), 0.0);
   for (int a : locals) {

@@ -14,6 +14,7 @@
 
 #include <cstdint>
 #include <map>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -74,6 +75,7 @@ struct DevBuf {
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { release(); }
   void release();
+  void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
   void alloc(size_t count, bool zero = true);
   void upload(const std::vector<T> &h);
   void download(std::vector<T> &h) const;

@@ -84,6 +84,9 @@ void launch_axpby_node(int d, hipStream_t st, const SegTable &T, const int *mask
 // partial[slot] = sum <a_p, b_p> over the selected part
 void launch_dot(int d, hipStream_t st, const SegTable &T, bool all_rows, const int *mask, const double *a,
                 const double *b, int part, double *partials, int slot);
+// n <= 4 dot products in one pass over own rows: partial[slot0 + q] = sum <a_q, b_q> (always writes 4 slots)
+void launch_dots(int d, hipStream_t st, const SegTable &T, const int *mask, int n, const double *const *a,
+                 const double *const *b, int part, double *partials, int slot0);
 // gradF = [V.x ; Proj_R(V.Y)] (DPGOProblem.cpp:145-162); partial ||gradF||^2; out may be null
 void launch_tangent_full(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
                          const double *V, double *out, double *partials, int slot);

@@ -525,6 +525,35 @@ __global__ __launch_bounds__(256) void k_dot(const Seg *segs, const int *mask, c
   block_store<1>(pr, partial + blockIdx.x, 0);
 }
 
+// up to 4 dot products over the rotation part in one pass (TNT / CG scalars)
+struct DotPairs {
+  const double *a[4];
+  const double *b[4];
+  int n;
+};
+template <int D>
+__global__ __launch_bounds__(256) void k_dots(const Seg *segs, const int *mask, DotPairs P, int part,
+                                              double *partial, int pstride) {
+  constexpr int RS = Dim<D>::RS;
+  const Seg s = segs[blockIdx.x];
+  const bool active = (mask == nullptr) || (mask[s.node] != 0);
+  double pr[4] = {0.0, 0.0, 0.0, 0.0};
+  const int row = s.begin + threadIdx.x;
+  if (active && row < s.end) {
+    const int k0 = part == 2 ? D : 0, k1 = part == 1 ? D : RS;
+    for (int q = 0; q < P.n; q++) {
+      double va[RS], vb[RS];
+      load_vec<RS>(P.a[q] + (size_t)row * RS, va);
+      load_vec<RS>(P.b[q] + (size_t)row * RS, vb);
+      double p = 0;
+#pragma unroll
+      for (int k = 0; k < RS; k++) p = (k >= k0 && k < k1) ? fma(va[k], vb[k], p) : p;
+      pr[q] = p;
+    }
+  }
+  block_store<4>(pr, partial + blockIdx.x, pstride);
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void k_tangent_full(const Seg *segs, const int *mask, const double *X,
                                                       const double *V, double *out, double *partial) {
@@ -665,13 +694,12 @@ __device__ __forceinline__ size_t vaddr(int i) {
   else return (size_t)(i / DOF) * RS + D + (size_t)(i % DOF) * D;
 }
 
-constexpr int SPD_CH = 128;
 
 // NW waves share one 64-row tile and split the front's columns (forward) / rows (backward) between
 // them chunk by chunk, then combine through LDS in a fixed order.  NW = 1 for the many small fronts
 // at the bottom of the tree, NW = 8 for the wide separator fronts at the top, where a single wave
 // per tile cannot keep enough loads in flight to use the HBM bandwidth.
-template <int D, int DOF, int NW>
+template <int D, int DOF, int NW, int SPD_CH>
 __global__ __launch_bounds__(64 * NW) void k_spd_fwd(SpdDev S, int item0, const double *vec, double *ytmp) {
   __shared__ double f[NW][SPD_CH * D];
   __shared__ double red[NW > 1 ? NW : 1][64 * D];
@@ -755,7 +783,7 @@ __global__ __launch_bounds__(64 * NW) void k_spd_fwd(SpdDev S, int item0, const 
   }
 }
 
-template <int D, int DOF, int NW>
+template <int D, int DOF, int NW, int SPD_CH>
 __global__ __launch_bounds__(64 * NW) void k_spd_bwd(SpdDev S, int item0, double scale, const double *ytmp,
                                                      double *vec) {
   __shared__ double f[NW][SPD_CH * D];
@@ -976,6 +1004,17 @@ void launch_dot(int d, hipStream_t st, const SegTable &T, bool all_rows, const i
                                         partials + (size_t)slot * T.nseg_all));
 }
 
+void launch_dots(int d, hipStream_t st, const SegTable &T, const int *mask, int n, const double *const *a,
+                 const double *const *b, int part, double *partials, int slot0) {
+  if (T.nseg_own == 0 || n <= 0) return;
+  DotPairs P;
+  P.n = n;
+  for (int q = 0; q < 4; q++) { P.a[q] = a[q < n ? q : 0]; P.b[q] = b[q < n ? q : 0]; }
+  ProfScope ps(PK_DOT, st, 2.0 * n * T.rows_own * 8.0 * (d + 1) * d);
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_dots<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, P, part,
+                                        partials + (size_t)slot0 * T.nseg_all, T.nseg_all));
+}
+
 void launch_tangent_full(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
                          const double *V, double *out, double *partials, int slot) {
   if (T.nseg_own == 0) return;
@@ -1038,9 +1077,9 @@ void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forw
 #define SPD_LAUNCH(DOFV, NWV)                                                                                  \
   do {                                                                                                         \
     if (forward)                                                                                               \
-      hipLaunchKernelGGL((k_spd_fwd<D, DOFV, NWV>), dim3(nitems), dim3(64 * NWV), 0, st, S, item0, vec, ytmp); \
+      hipLaunchKernelGGL((k_spd_fwd<D, DOFV, NWV, 128>), dim3(nitems), dim3(64 * NWV), 0, st, S, item0, vec, ytmp); \
     else                                                                                                       \
-      hipLaunchKernelGGL((k_spd_bwd<D, DOFV, NWV>), dim3(nitems), dim3(64 * NWV), 0, st, S, item0, scale, ytmp, vec); \
+      hipLaunchKernelGGL((k_spd_bwd<D, DOFV, NWV, 128>), dim3(nitems), dim3(64 * NWV), 0, st, S, item0, scale, ytmp, vec); \
   } while (0)
   DPGO_DISPATCH_D(d, {
     if (dof == 1) { if (nwaves == 1) SPD_LAUNCH(1, 1); else SPD_LAUNCH(1, 8); }

@@ -55,8 +55,10 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g) {
   for (int a : nodes) S[a] = NodeTnt();
 
   auto dots = [&](std::initializer_list<std::pair<const double *, const double *>> prs) {
+    const double *pa[4], *pb[4];
     int s = 0;
-    for (const auto &pr : prs) launch_dot(d_, st_, T_, false, cur_mask_, pr.first, pr.second, 2, partials_.p, s++);
+    for (const auto &pr : prs) { pa[s] = pr.first; pb[s] = pr.second; s++; }
+    launch_dots(d_, st_, T_, cur_mask_, s, pa, pb, 2, partials_.p, 0);
     fetch(s, false);
   };
   auto quad_model = [&](const double *Y) {   // nabla, grad at Y
@@ -204,9 +206,10 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g) {
     launch_retract_rot(d_, st_, T_, cur_mask_, X, sk, xprop);
     recover_translations(xprop, g);
     eval_G(xprop, g, 4);
-    launch_dot(d_, st_, T_, false, cur_mask_, sk, sk, 2, partials_.p, 0);
-    launch_dot(d_, st_, T_, false, cur_mask_, grad, sk, 2, partials_.p, 1);
-    launch_dot(d_, st_, T_, false, cur_mask_, sk, hh, 2, partials_.p, 2);
+    {
+      const double *pa[4] = {sk, grad, sk, sk}, *pb[4] = {sk, sk, hh, sk};
+      launch_dots(d_, st_, T_, cur_mask_, 3, pa, pb, 2, partials_.p, 0);
+    }
     fetch(5, false);
     std::vector<int> acc, requad;
     for (int a : A) {
