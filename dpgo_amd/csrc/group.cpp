@@ -60,7 +60,8 @@ void SpdSolverDev::upload(int dcols) {
   // algorithmic bytes of one level: every front entry once (8 B) + its in/out vector entries
   auto lvl_bytes = [&](const std::vector<int> &lvl) {
     double b = 0;
-    for (int f : lvl) b += 8.0 * (double)(F.w[f] + F.u[f]) * F.w[f] + 2.0 * 8.0 * dcols * (F.w[f] + F.u[f]);
+    // (the pivot block L11^-1 is triangular: w(w+1)/2 entries)
+    for (int f : lvl) b += 8.0 * ((double)F.u[f] * F.w[f] + 0.5 * (double)F.w[f] * (F.w[f] + 1)) + 2.0 * 8.0 * dcols * (F.w[f] + F.u[f]);
     return b;
   };
   for (const auto &lvl : F.by_height) fwd_level_bytes.push_back(lvl_bytes(lvl));

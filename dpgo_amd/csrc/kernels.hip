@@ -715,8 +715,11 @@ __global__ __launch_bounds__(64 * NW) void k_spd_fwd(SpdDev S, int item0, const 
 #pragma unroll
   for (int c = 0; c < D; c++) acc[c] = 0.0;
   double *fw = f[wv];
-  for (int k0 = wv * SPD_CH; k0 < w; k0 += NW * SPD_CH) {
-    const int kn = min(SPD_CH, w - k0);
+  // the pivot block of W_s is L11^-1, lower triangular: rows of a tile that lies inside it only need
+  // the columns up to the tile's last row
+  const int kend = (it.y + 64 <= w) ? it.y + 64 : w;
+  for (int k0 = wv * SPD_CH; k0 < kend; k0 += NW * SPD_CH) {
+    const int kn = min(SPD_CH, kend - k0);
     for (int kk = lane; kk < kn; kk += 64) {
       const int k = k0 + kk;
       double v[D];
@@ -800,7 +803,8 @@ __global__ __launch_bounds__(64 * NW) void k_spd_bwd(SpdDev S, int item0, double
 #pragma unroll
   for (int c = 0; c < D; c++) acc[c] = 0.0;
   double *fw = f[wv];
-  for (int p0 = wv * SPD_CH; p0 < m; p0 += NW * SPD_CH) {
+  // columns of a tile starting at c0 are zero in the rows above c0 (L11^-1 is lower triangular)
+  for (int p0 = it.y + wv * SPD_CH; p0 < m; p0 += NW * SPD_CH) {
     const int pn = min(SPD_CH, m - p0);
     for (int pp = lane; pp < pn; pp += 64) {
       const int p = p0 + pp;
