@@ -197,8 +197,18 @@ def main():
         dom = max(stats.items(), key=lambda kv: kv[1][0])
         ms, by, cnt = dom[1]
         ach = (by / 1e9) / (ms / 1e3)
+        # HBM bytes per launch from the PMC counters: measured by separate rocprofv3 --pmc passes of this
+        # same command (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process); the committed
+        # summary (tools/pmc_summary.py) is quoted when it covers this workload and kernel
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
+            if pm.get("workload") == args.grid and pm.get("n_gpus") == world and not args.emulate_world:
+                traffic = pm["kernels"][dom[0]]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         roofline = dict(kernel=dom[0], bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=ach / HBM_PEAK_GBS, traffic=None, avg_launch_us=1e3 * ms / cnt,
+                        frac=ach / HBM_PEAK_GBS, traffic=traffic, avg_launch_us=1e3 * ms / cnt,
                         algorithmic_bytes_per_launch=by / cnt, launches_per_step=cnt / args.prof_steps)
 
     # ---- CPU baseline: the oracle (numpy/scipy restatement) on a bounded sample, rank 0, N = 1 only

@@ -442,3 +442,11 @@ class DistPGO:
     def sum_fobj(self):
         """sum_a fobj^a == F(X_k) (invariant 1)."""
         return sum(self.group.results(k).fobj for k in range(len(self.group)))
+
+    def evaluate(self):
+        """(2F, 2|grad F|) as printed by the reference driver (dist_pgo.cpp:477-481, 523-527), from the
+        per-node device reductions: F = sum_a fobj^a and |grad F|^2 = sum_a gradFnorm_a^2 (the rows of
+        the global Riemannian gradient that belong to node a are exactly Proj(Dfobj^a), SURVEY Appendix
+        B-1/B-4; DPGOStar::evaluate_f / evaluate_grad, DPGOStar.cpp:713-829)."""
+        r = [self.group.results(k) for k in range(len(self.group))]
+        return 2.0 * sum(x.fobj for x in r), 2.0 * float(np.sqrt(sum(x.gradFnorm ** 2 for x in r)))
