@@ -50,7 +50,7 @@ template struct DevBuf<Seg>;
 void SpdSolverDev::upload(int dcols) {
   w.upload(F.w); u.upload(F.u); piv_ptr.upload(F.piv_ptr); piv_idx.upload(F.piv_idx);
   upd_ptr.upload(F.upd_ptr); upd_idx.upload(F.upd_idx); pos_off.upload(F.pos_off); ubuf_off.upload(F.ubuf_off);
-  asm_ptr.upload(F.asm_ptr); asm_src.upload(F.asm_src); w_off.upload(F.w_off); W.upload(F.W); WT.upload(F.WT);
+  asm_ptr.upload(F.asm_ptr); asm_src.upload(F.asm_src); w_off.upload(F.w_off); wt_off.upload(F.wt_off); ldw.upload(F.ldw); ldm.upload(F.ldm); W.upload(F.W); WT.upload(F.WT);
   ubuf.alloc((size_t)std::max(F.total_upd, 1) * dcols);
   ytmp.alloc((size_t)std::max(F.n, 1) * dcols);
   std::vector<int4> fi, bi;
@@ -100,7 +100,7 @@ void SpdSolverDev::upload(int dcols) {
   dev.nfronts = F.nfronts;
   dev.w = w.p; dev.u = u.p; dev.piv_ptr = piv_ptr.p; dev.piv_idx = piv_idx.p; dev.upd_ptr = upd_ptr.p;
   dev.upd_idx = upd_idx.p; dev.pos_off = pos_off.p; dev.ubuf_off = ubuf_off.p; dev.asm_ptr = asm_ptr.p;
-  dev.asm_src = asm_src.p; dev.w_off = w_off.p; dev.W = W.p; dev.WT = WT.p; dev.fwd_items = fwd_items.p;
+  dev.asm_src = asm_src.p; dev.w_off = w_off.p; dev.wt_off = wt_off.p; dev.ldw = ldw.p; dev.ldm = ldm.p; dev.W = W.p; dev.WT = WT.p; dev.fwd_items = fwd_items.p;
   dev.bwd_items = bwd_items.p; dev.ubuf = ubuf.p;
 }
 

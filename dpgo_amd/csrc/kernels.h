@@ -116,7 +116,8 @@ struct SpdDev {
   int nfronts = 0;
   const int *w = nullptr, *u = nullptr, *piv_ptr = nullptr, *piv_idx = nullptr, *upd_ptr = nullptr,
             *upd_idx = nullptr, *pos_off = nullptr, *ubuf_off = nullptr, *asm_ptr = nullptr, *asm_src = nullptr;
-  const int64_t *w_off = nullptr;
+  const int64_t *w_off = nullptr, *wt_off = nullptr;
+  const int *ldw = nullptr, *ldm = nullptr;
   const double *W = nullptr, *WT = nullptr;
   const int4 *fwd_items = nullptr, *bwd_items = nullptr;   // {front, first row/col, count, 0}
   double *ubuf = nullptr;

@@ -708,7 +708,8 @@ __global__ __launch_bounds__(64 * NW) void k_spd_fwd(SpdDev S, int item0, const 
   const int s = it.x, p = it.y + lane;
   const bool valid = lane < it.z;
   const int w = S.w[s], m = w + S.u[s];
-  const double *WT = S.WT + S.w_off[s];
+  const double *WT = S.WT + S.wt_off[s];
+  const int ldm = S.ldm[s];
   const int *piv = S.piv_idx + S.piv_ptr[s];
   const int pos0 = S.pos_off[s];
   double acc[D];
@@ -738,19 +739,19 @@ __global__ __launch_bounds__(64 * NW) void k_spd_fwd(SpdDev S, int item0, const 
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (valid) {
       // batches of 16 independent loads in flight per lane before the first use
-      const double *wp = WT + (size_t)k0 * m + p;
+      const double *wp = WT + (size_t)k0 * ldm + p;
       int kk = 0;
       for (; kk + 16 <= kn; kk += 16) {
         double wv16[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) wv16[q] = wp[(size_t)(kk + q) * m];
+        for (int q = 0; q < 16; q++) wv16[q] = wp[(size_t)(kk + q) * ldm];
 #pragma unroll
         for (int q = 0; q < 16; q++)
 #pragma unroll
           for (int c = 0; c < D; c++) acc[c] = fma(wv16[q], fw[(kk + q) * D + c], acc[c]);
       }
       for (; kk < kn; kk++) {
-        const double wval = wp[(size_t)kk * m];
+        const double wval = wp[(size_t)kk * ldm];
 #pragma unroll
         for (int c = 0; c < D; c++) acc[c] = fma(wval, fw[kk * D + c], acc[c]);
       }
@@ -797,6 +798,7 @@ __global__ __launch_bounds__(64 * NW) void k_spd_bwd(SpdDev S, int item0, double
   const bool valid = lane < it.z;
   const int w = S.w[s], m = w + S.u[s];
   const double *W = S.W + S.w_off[s];
+  const int ldw = S.ldw[s];
   const int *piv = S.piv_idx + S.piv_ptr[s];
   const int *upd = S.upd_idx + S.upd_ptr[s];
   double acc[D];
@@ -817,19 +819,19 @@ __global__ __launch_bounds__(64 * NW) void k_spd_bwd(SpdDev S, int item0, double
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (valid) {
-      const double *wp = W + (size_t)p0 * w + k;
+      const double *wp = W + (size_t)p0 * ldw + k;
       int pp = 0;
       for (; pp + 16 <= pn; pp += 16) {
         double wv16[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) wv16[q] = wp[(size_t)(pp + q) * w];
+        for (int q = 0; q < 16; q++) wv16[q] = wp[(size_t)(pp + q) * ldw];
 #pragma unroll
         for (int q = 0; q < 16; q++)
 #pragma unroll
           for (int c = 0; c < D; c++) acc[c] = fma(wv16[q], fw[(pp + q) * D + c], acc[c]);
       }
       for (; pp < pn; pp++) {
-        const double wval = wp[(size_t)pp * w];
+        const double wval = wp[(size_t)pp * ldw];
 #pragma unroll
         for (int c = 0; c < D; c++) acc[c] = fma(wval, fw[pp * D + c], acc[c]);
       }

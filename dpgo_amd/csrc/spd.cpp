@@ -261,11 +261,20 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
   }
   F.upd_ptr.assign(nt + 1, 0);
   F.w_off.assign(nt + 1, 0);
+  F.wt_off.assign(nt + 1, 0);
+  F.ldw.assign(nt, 0);
+  F.ldm.assign(nt, 0);
+  F.entries = 0;
   F.pos_off.assign(nt + 1, 0);
   F.ubuf_off.assign(nt + 1, 0);
   for (int f = 0; f < nt; f++) {
     F.upd_ptr[f + 1] = F.upd_ptr[f] + F.u[f];
-    F.w_off[f + 1] = F.w_off[f] + (int64_t)(F.w[f] + F.u[f]) * F.w[f];
+    // leading dimensions padded to 16 doubles (128 B): every 64-lane tile of a row starts on a cache line
+    F.ldw[f] = (F.w[f] + 15) & ~15;
+    F.ldm[f] = (F.w[f] + F.u[f] + 15) & ~15;
+    F.w_off[f + 1] = F.w_off[f] + (int64_t)(F.w[f] + F.u[f]) * F.ldw[f];
+    F.wt_off[f + 1] = F.wt_off[f] + (int64_t)F.w[f] * F.ldm[f];
+    F.entries += (int64_t)(F.w[f] + F.u[f]) * F.w[f];
     F.pos_off[f + 1] = F.pos_off[f] + F.w[f] + F.u[f];
     F.ubuf_off[f + 1] = F.ubuf_off[f] + F.u[f];
     F.max_front = std::max(F.max_front, F.w[f] + F.u[f]);
@@ -284,7 +293,7 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
     return 0;
   }
   F.W.assign(F.w_off[nt], 0.0);
-  F.WT.assign(F.w_off[nt], 0.0);
+  F.WT.assign(F.wt_off[nt], 0.0);
 
   // numeric multifrontal factorisation, level by level: fronts of one tree height are independent.
   // Small fronts are spread over threads; big fronts are factored one at a time with threads inside.
@@ -410,14 +419,15 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
       }
     }
     double *Wf = &F.W[F.w_off[f]];
-    double *WTf = &F.WT[F.w_off[f]];
+    double *WTf = &F.WT[F.wt_off[f]];
+    const int ldw = F.ldw[f], ldm = F.ldm[f];
     for (int i = 0; i < w; i++)
-      for (int j = 0; j <= i; j++) Wf[(size_t)i * w + j] = Linv[(size_t)i * w + j];
+      for (int j = 0; j <= i; j++) Wf[(size_t)i * ldw + j] = Linv[(size_t)i * w + j];
     // W bottom = -L21 Linv, row-oriented: out[a, :] = -sum_k L21[a,k] Linv[k, 0..k]
 #pragma omp parallel for schedule(dynamic, 8) if (inner_par)
     for (int a = 0; a < u; a++) {
       const double *l21 = &Fm[(size_t)(w + a) * m];
-      double *out = &Wf[(size_t)(w + a) * w];
+      double *out = &Wf[(size_t)(w + a) * ldw];
       for (int j = 0; j < w; j++) out[j] = 0.0;
       for (int k = 0; k < w; k++) {
         const double l = l21[k];
@@ -428,7 +438,7 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
     }
 #pragma omp parallel for schedule(static) if (inner_par)
     for (int k = 0; k < w; k++)
-      for (int p = 0; p < m; p++) WTf[(size_t)k * m + p] = Wf[(size_t)p * w + k];
+      for (int p = 0; p < m; p++) WTf[(size_t)k * ldm + p] = Wf[(size_t)p * ldw + k];
     for (int k = 0; k < w; k++) loc[piv[k]] = -1;
     for (int k = 0; k < u; k++) loc[up[k]] = -1;
   };
@@ -484,7 +494,7 @@ int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf, int collapse) {
     for (int c = 1; c <= 3; c++) {
       SpdFactor S;
       if (spd_factor_impl(A, S, leaf, c, true) != 0) continue;
-      const double t = 12e-6 * (double)S.by_height.size() + 8.0 * (double)S.w_off.back() / 3.0e12;
+      const double t = 12e-6 * (double)S.by_height.size() + 8.0 * (double)S.entries / 3.0e12;
       if (t < best) { best = t; best_c = c; }
     }
     collapse = best_c;
@@ -507,7 +517,7 @@ void spd_solve_host(const SpdFactor &F, double *X, int nc) {
     for (int p = 0; p < m; p++)
       for (int c = 0; c < nc; c++) {
         double acc = p < w ? 0.0 : f[(size_t)p * nc + c];
-        for (int k = 0; k < w; k++) acc += Wf[(size_t)p * w + k] * f[(size_t)k * nc + c];
+        for (int k = 0; k < w; k++) acc += Wf[(size_t)p * F.ldw[s] + k] * f[(size_t)k * nc + c];
         if (p < w) X[(size_t)piv[p] * nc + c] = acc;
         else ubuf[(size_t)(F.ubuf_off[s] + p - w) * nc + c] = acc;
       }
@@ -523,7 +533,7 @@ void spd_solve_host(const SpdFactor &F, double *X, int nc) {
     out.assign((size_t)w * nc, 0.0);
     for (int p = 0; p < m; p++)
       for (int k = 0; k < w; k++)
-        for (int c = 0; c < nc; c++) out[(size_t)k * nc + c] += Wf[(size_t)p * w + k] * f[(size_t)p * nc + c];
+        for (int c = 0; c < nc; c++) out[(size_t)k * nc + c] += Wf[(size_t)p * F.ldw[s] + k] * f[(size_t)p * nc + c];
     for (int k = 0; k < w; k++)
       for (int c = 0; c < nc; c++) X[(size_t)piv[k] * nc + c] = out[(size_t)k * nc + c];
   }

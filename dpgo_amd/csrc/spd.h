@@ -34,16 +34,18 @@ struct SpdFactor {
   std::vector<int> w, u;                 // pivots / update rows per front
   std::vector<int> piv_ptr, piv_idx;     // CSR: matrix indices of the pivots
   std::vector<int> upd_ptr, upd_idx;     // CSR: matrix indices of the update rows
-  std::vector<int64_t> w_off;            // offset of W_s / WT_s in W / WT
-  std::vector<double> W;                 // (w+u) x w row-major per front
-  std::vector<double> WT;                // w x (w+u) row-major per front
+  std::vector<int64_t> w_off, wt_off;    // offset of W_s in W / of WT_s in WT
+  std::vector<int> ldw, ldm;             // padded leading dimensions of W_s (>= w) and WT_s (>= w+u)
+  int64_t entries = 0;                   // sum (w+u) w: factor entries without padding
+  std::vector<double> W;                 // (w+u) x ldw row-major per front
+  std::vector<double> WT;                // w x ldm row-major per front
   std::vector<int> parent, height, depth;
   std::vector<int> pos_off;              // first "front position" of each front (w+u positions each)
   std::vector<int> ubuf_off;             // first row of each front's update vector in the update buffer
   std::vector<int> asm_ptr, asm_src;     // per front position: rows of the update buffer to add
   std::vector<std::vector<int>> by_height, by_depth;
   int total_pos = 0, total_upd = 0, max_front = 0;
-  int64_t nnz() const { return (int64_t)W.size(); }
+  int64_t nnz() const { return entries; }
 };
 
 // Factor A (symmetric positive definite, full pattern in CSR).  leaf = max
