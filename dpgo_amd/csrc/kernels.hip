@@ -8,6 +8,7 @@
 // reproducible run to run.
 #include "kernels.h"
 
+#include <cstdlib>
 #include <vector>
 
 namespace dpgo {
@@ -1080,17 +1081,26 @@ void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forw
                       double *vec, double *ytmp, double scale, double level_bytes, int nwaves) {
   if (nitems == 0) return;
   ProfScope ps(forward ? PK_SPD_FWD : PK_SPD_BWD, st, level_bytes);
-#define SPD_LAUNCH(DOFV, NWV)                                                                                  \
+  static const int narrow_split = getenv("DPGO_SPD_NARROW") ? atoi(getenv("DPGO_SPD_NARROW")) : 0;
+  static const int wide_nw = getenv("DPGO_SPD_WIDE_NW") ? atoi(getenv("DPGO_SPD_WIDE_NW")) : 8;
+#define SPD_LAUNCH(DOFV, NWV, CHV)                                                                             \
   do {                                                                                                         \
     if (forward)                                                                                               \
-      hipLaunchKernelGGL((k_spd_fwd<D, DOFV, NWV, 128>), dim3(nitems), dim3(64 * NWV), 0, st, S, item0, vec, ytmp); \
+      hipLaunchKernelGGL((k_spd_fwd<D, DOFV, NWV, CHV>), dim3(nitems), dim3(64 * NWV), 0, st, S, item0, vec, ytmp); \
     else                                                                                                       \
-      hipLaunchKernelGGL((k_spd_bwd<D, DOFV, NWV, 128>), dim3(nitems), dim3(64 * NWV), 0, st, S, item0, scale, ytmp, vec); \
+      hipLaunchKernelGGL((k_spd_bwd<D, DOFV, NWV, CHV>), dim3(nitems), dim3(64 * NWV), 0, st, S, item0, scale, ytmp, vec); \
+  } while (0)
+#define SPD_PICK(DOFV)                                                                  \
+  do {                                                                                  \
+    if (nwaves == 1) { if (narrow_split) SPD_LAUNCH(DOFV, 8, 16); else SPD_LAUNCH(DOFV, 1, 128); } \
+    else if (wide_nw == 16) SPD_LAUNCH(DOFV, 16, 128);                                   \
+    else SPD_LAUNCH(DOFV, 8, 128);                                                      \
   } while (0)
   DPGO_DISPATCH_D(d, {
-    if (dof == 1) { if (nwaves == 1) SPD_LAUNCH(1, 1); else SPD_LAUNCH(1, 8); }
-    else { if (nwaves == 1) SPD_LAUNCH(D, 1); else SPD_LAUNCH(D, 8); }
+    if (dof == 1) SPD_PICK(1);
+    else SPD_PICK(D);
   });
+#undef SPD_PICK
 #undef SPD_LAUNCH
 }
 

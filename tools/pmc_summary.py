@@ -17,11 +17,13 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 
 def family(name):
-    n = name.split("(")[0].split("<")[0].split("::")[-1].strip()
+    m = re.search(r"\b(k_[a-z_0-9]+)", name)
+    n = m.group(1) if m else name
     return {"k_extrapolate": "k_axpby", "k_axpby_node": "k_axpby", "k_dots": "k_dot",
             "k_tangent_full": "k_rot_op"}.get(n, n)
 
@@ -40,6 +42,8 @@ def collect(d, counter):
 
 def main():
     fetch, write, out = sys.argv[1:4]
+    workload = sys.argv[4] if len(sys.argv) > 4 else "50,50,40,400000"
+    n_gpus = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     fa, wa = collect(fetch, "FETCH_SIZE"), collect(write, "WRITE_SIZE")
     res = {}
     for k in sorted(set(fa) | set(wa)):
@@ -54,7 +58,7 @@ def main():
                   "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
                   "hbm_bytes_per_launch": rd + wr}
     json.dump({"method": __doc__.strip().splitlines()[0], "corrections": "read = 2 x FETCH_SIZE x 1024; write = WRITE_SIZE x 1024",
-               "command": " ".join(sys.argv), "kernels": res}, open(out, "w"), indent=1)
+               "command": " ".join(sys.argv), "workload": workload, "n_gpus": n_gpus, "kernels": res}, open(out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_fetch_pass"]):
         print("%-16s launches %6d  HBM MB/launch %9.3f" % (k, v["launches_fetch_pass"], v["hbm_bytes_per_launch"] / 1e6))
 
