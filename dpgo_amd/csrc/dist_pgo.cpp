@@ -1,0 +1,146 @@
+// dist_pgo -- command-line driver with the reference's flags and outputs, on top of the C ABI.
+//
+// Mirrors C++/examples/dist_pgo.cpp:
+//   flags      --dataset --num_nodes --iters[1000] --dist_init[true] --loss[trivial|huber|welsch]
+//              --accelerated[true] --save[true]                                     (:23-47)
+//   options    the hard-coded overrides of :103-120 (dpgo_options_driver)
+//   loop       iterate -> gather -> communicate -> update, timing iterate + update only (:492-531)
+//   stdout     "<iter>: <fobj> <grad>" with 20 digits, then the final summary         (:493-494, 533-536)
+//   files      results_chordal_<N>_<amm|mm>.txt  (iter time fobj grad, 16 digits)     (:538-552)
+//              estimates_<loss>.txt  (X with t <- t - t_0, X <- X R_0)                (:554-567)
+// All nodes are hosted by one GPU (--gpu).  fobj = 2 F and grad = 2 |grad F| come from the per-node
+// device reductions (sum_a fobj^a = F, sum_a |Proj(Dfobj^a)|^2 = |grad F|^2; DPGOStar.cpp:713-829).
+// --dist_init true (the distributed chordal initialisation, C++/DChordal) is not part of this
+// library yet: the centralised chordal initialisation (:416-444) is used and a note is printed.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dpgo_amd.h"
+
+static bool parse_bool(const char *s) { return !(strcmp(s, "false") == 0 || strcmp(s, "0") == 0); }
+
+int main(int argc, char **argv) {
+  std::string dataset, loss_type = "trivial";
+  int num_nodes = -1, iters = 1000, gpu = 0;
+  bool dist_init = true, accelerated = true, save = true;
+  for (int i = 1; i < argc; i++) {
+    std::string a = argv[i];
+    auto val = [&](const char *name) -> const char * {
+      const size_t n = strlen(name);
+      if (a.compare(0, n, name) == 0 && a.size() > n && a[n] == '=') return argv[i] + n + 1;
+      if (a == name && i + 1 < argc) return argv[++i];
+      return nullptr;
+    };
+    if (a == "--help") {
+      printf("Program options:\n  --dataset arg\n  --num_nodes arg\n  --iters arg (=1000)\n  --dist_init arg (=true)\n"
+             "  --loss arg (=trivial)   trivial, huber or welsch\n  --accelerated arg (=true)\n  --save arg (=true)\n  --gpu arg (=0)\n");
+      return 0;
+    } else if (const char *v = val("--dataset")) dataset = v;
+    else if (const char *v = val("--num_nodes")) num_nodes = atoi(v);
+    else if (const char *v = val("--iters")) iters = atoi(v);
+    else if (const char *v = val("--dist_init")) dist_init = parse_bool(v);
+    else if (const char *v = val("--loss")) loss_type = v;
+    else if (const char *v = val("--accelerated")) accelerated = parse_bool(v);
+    else if (const char *v = val("--save")) save = parse_bool(v);
+    else if (const char *v = val("--gpu")) gpu = atoi(v);
+  }
+  if (dataset.empty()) { fprintf(stderr, "No dataset has been specfied.\n"); return -1; }
+  if (num_nodes < 1) { fprintf(stderr, "No number of nodes has been specfied.\n"); return -1; }
+  int loss;
+  if (loss_type == "trivial") loss = 0;
+  else if (loss_type == "huber") loss = 1;
+  else if (loss_type == "welsch") loss = 3;
+  else { fprintf(stderr, " The loss type can only be \"trivial\", \"huber\" or \"welsch\".\n"); return -1; }
+
+  dpgo_graph_t *g = nullptr;
+  if (dpgo_read_g2o(dataset.c_str(), num_nodes, &g) != 0) return -1;
+  int d, N, nn, m;
+  dpgo_graph_info(g, &d, &N, &nn, &m);
+  dpgo_options_t opt;
+  dpgo_options_driver(&opt, loss, accelerated);
+  if (dist_init)
+    printf("note: --dist_init true (distributed chordal initialisation) is not available; using the centralised "
+           "chordal initialisation of --dist_init false.\n");
+  printf("===============================================\nInitialization\n-----------------------------------------------\n");
+  const int ld = (d + 1) * N;
+  std::vector<double> X((size_t)ld * d, 0.0);
+  if (dpgo_chordal_initialization(g, X.data(), ld) != 0) return -1;
+  std::vector<int> ids(num_nodes);
+  for (int a = 0; a < num_nodes; a++) ids[a] = a;
+  dpgo_group_t *grp = nullptr;
+  if (dpgo_group_create(g, ids.data(), num_nodes, &opt, gpu, &grp) != 0) return -1;
+  if (dpgo_group_initialize_global(grp, X.data(), ld) != 0) return -1;
+  if (dpgo_group_update(grp, nullptr, 0) != 0) return -1;
+
+  auto evaluate = [&](double &fobj, double &grad) {
+    double f = 0, g2 = 0;
+    for (int a = 0; a < num_nodes; a++) {
+      dpgo_results_t r;
+      dpgo_group_results(grp, a, &r);
+      f += r.fobj;
+      g2 += r.gradFnorm * r.gradFnorm;
+    }
+    fobj = 2 * f;
+    grad = 2 * std::sqrt(g2);
+  };
+  double fobj, grad, time = 0;
+  evaluate(fobj, grad);
+  std::vector<std::vector<double>> results;
+  results.push_back({0, 0, fobj, grad});
+  printf("===============================================\nDistributed PGO\n-----------------------------------------------\n");
+  using clk = std::chrono::steady_clock;
+  for (int iter = 0; iter < iters; iter++) {
+    printf("%d: %.20g %.20g\n", iter, fobj, grad);
+    auto t0 = clk::now();
+    if (dpgo_group_iterate(grp, nullptr, 0) != 0) return -1;
+    dpgo_group_sync(grp);
+    time += std::chrono::duration<double>(clk::now() - t0).count();
+    dpgo_group_communicate_local(grp);
+    dpgo_group_sync(grp);
+    t0 = clk::now();
+    if (dpgo_group_update(grp, nullptr, 0) != 0) return -1;
+    dpgo_group_sync(grp);
+    time += std::chrono::duration<double>(clk::now() - t0).count();
+    evaluate(fobj, grad);
+    results.push_back({double(iter) + 1, time, fobj, grad});
+  }
+  printf("---------------------------------------\nfinal objective: %.20g\nfinal gradient: %.20g\ntime: %.20g s/node.\n", fobj,
+         grad, time / num_nodes);
+  if (save) {
+    const std::string resfile = "results_chordal_" + std::to_string(num_nodes) + "_" + (accelerated ? "amm" : "mm") + ".txt";
+    FILE *f = fopen(resfile.c_str(), "w");
+    if (!f) return -1;
+    for (const auto &r : results) fprintf(f, "%d %.16g %.16g %.16g\n", (int)r[0], r[1], r[2], r[3]);
+    fclose(f);
+    dpgo_group_scatter_global(grp, X.data(), ld);
+    // gauge fix (:554-558): t <- t - t_0 ; X <- X * R with R = X.middleRows(num_poses, d)^T
+    std::vector<double> R(d * d), t0v(d);
+    for (int c = 0; c < d; c++) {
+      t0v[c] = X[(size_t)c * ld + 0];
+      for (int r = 0; r < d; r++) R[r * d + c] = X[(size_t)r * ld + N + c];   // R(r,c) = block(c,r)
+    }
+    for (int i = 0; i < N; i++)
+      for (int c = 0; c < d; c++) X[(size_t)c * ld + i] -= t0v[c];
+    f = fopen(("./estimates_" + loss_type + ".txt").c_str(), "w");
+    if (!f) return -1;
+    std::vector<double> row(d);
+    for (int i = 0; i < ld; i++) {
+      for (int c = 0; c < d; c++) {
+        double s = 0;
+        for (int k = 0; k < d; k++) s += X[(size_t)k * ld + i] * R[k * d + c];
+        row[c] = s;
+      }
+      for (int c = 0; c < d; c++) fprintf(f, "%s%g", c ? " " : "", row[c]);
+      fprintf(f, "\n");
+    }
+    fclose(f);
+  }
+  dpgo_group_free(grp);
+  dpgo_graph_free(g);
+  return 0;
+}
