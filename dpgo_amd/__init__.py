@@ -98,6 +98,10 @@ SYMBOLS = {
     "dpgo_group_update": (C.c_int, [C.c_void_p, _IP, C.c_int]),
     "dpgo_group_iterate": (C.c_int, [C.c_void_p, _IP, C.c_int]),
     "dpgo_group_communicate_local": (C.c_int, [C.c_void_p]),
+    "dpgo_group_star_initialize": (C.c_int, [C.c_void_p, _DP, C.c_int]),
+    "dpgo_group_star_update": (C.c_int, [C.c_void_p]),
+    "dpgo_group_star_iterate": (C.c_int, [C.c_void_p]),
+    "dpgo_group_star_state": (C.c_int, [C.c_void_p, _DP, _DP, _DP, _IP]),
     "dpgo_group_num_sent": (C.c_int, [C.c_void_p]),
     "dpgo_group_sent_keys": (C.c_int, [C.c_void_p, _IP, _IP]),
     "dpgo_group_set_recv_layout": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _IP, _IP, _IP]),
@@ -450,3 +454,40 @@ class DistPGO:
         B-1/B-4; DPGOStar::evaluate_f / evaluate_grad, DPGOStar.cpp:713-829)."""
         r = [self.group.results(k) for k in range(len(self.group))]
         return 2.0 * sum(x.fobj for x in r), 2.0 * float(np.sqrt(sum(x.gradFnorm ** 2 for x in r)))
+
+
+class DPGOStar:
+    """AMM-PGO* with the method names of the reference's DPGOStar
+    (C++/DPGO/include/DPGO/DPGOStar.h:13-61): initialize / update / iterate / communicate.
+    All nodes are hosted by one GPU; the master's global objective is the sum of per-node
+    device reductions."""
+
+    def __init__(self, graph, options, device=0):
+        self.graph, self.options = graph, options
+        self.group = NodeGroup(graph, range(graph.num_nodes), options, device)
+
+    def initialize(self, X):
+        X, ld = _fcol(X)
+        return lib().dpgo_group_star_initialize(self.group._h, _dp(X), ld)
+
+    def update(self):
+        return lib().dpgo_group_star_update(self.group._h)
+
+    def iterate(self):
+        return lib().dpgo_group_star_iterate(self.group._h)
+
+    def communicate(self):
+        return self.group.communicate_local()
+
+    def state(self):
+        F, f, fh, b = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        lib().dpgo_group_star_state(self.group._h, C.byref(F), C.byref(f), C.byref(fh), C.byref(b))
+        return dict(F=F.value, fobj=f.value, fobjh=fh.value, branches=b.value)
+
+    def step(self):
+        return self.update() | self.iterate() | self.communicate()
+
+    def X(self):
+        X = np.zeros(((self.graph.d + 1) * self.graph.num_poses, self.graph.d), order="F")
+        self.group.scatter_global(X)
+        return X

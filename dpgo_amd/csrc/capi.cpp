@@ -217,6 +217,16 @@ int dpgo_group_initialize_global(dpgo_group_t *h, const double *X, int ld) { ret
 int dpgo_group_update(dpgo_group_t *h, const int *locals, int n) { return h->grp->update(sel(h, locals, n)); }
 int dpgo_group_iterate(dpgo_group_t *h, const int *locals, int n) { return h->grp->iterate(sel(h, locals, n)); }
 int dpgo_group_communicate_local(dpgo_group_t *h) { return h->grp->communicate_local(); }
+int dpgo_group_star_initialize(dpgo_group_t *h, const double *X, int ld) { return h->grp->star_initialize_global(X, ld); }
+int dpgo_group_star_update(dpgo_group_t *h) { return h->grp->star_update(); }
+int dpgo_group_star_iterate(dpgo_group_t *h) { return h->grp->star_iterate(); }
+int dpgo_group_star_state(const dpgo_group_t *h, double *F, double *fobj, double *fobjh, int *branches) {
+  if (F) *F = h->grp->star_F();
+  if (fobj) *fobj = h->grp->star_fobj();
+  if (fobjh) *fobjh = h->grp->star_fobjh();
+  if (branches) *branches = h->grp->star_branches();
+  return 0;
+}
 int dpgo_group_num_sent(const dpgo_group_t *h) { return h->grp->num_sent(); }
 int dpgo_group_sent_keys(const dpgo_group_t *h, int *nodes, int *poses) {
   const auto &k = h->grp->sent_keys();

@@ -305,6 +305,31 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
     E_.m = (int)tail.size(); E_.tail = e_tail_.p; E_.head = e_head_.p; E_.R = e_R_.p; E_.t = e_t_.p;
     E_.kappa = e_kappa_.p; E_.tau = e_tau_.p; E_.inc_ptr = e_inc_ptr_.p; E_.inc = e_inc_.p;
   }
+  {
+    std::vector<int> tail, head;
+    std::vector<double> R, t, kap, tau;
+    std::vector<std::vector<int>> inc(P0_);
+    for (int a = 0; a < L; a++)
+      for (const auto &m : info_[a].intra) {
+        const int e = (int)tail.size();
+        const int p = uni(a, info_[a].tail(m)), q = uni(a, info_[a].head(m));
+        tail.push_back(p); head.push_back(q);
+        for (int k = 0; k < d_ * d_; k++) R.push_back(m.R[k]);
+        for (int k = 0; k < d_; k++) t.push_back(m.t[k]);
+        kap.push_back(m.kappa); tau.push_back(m.tau);
+        inc[p].push_back(2 * e);
+      }
+    std::vector<int> iptr(P0_ + 1, 0), iv;
+    for (int r = 0; r < P0_; r++) {
+      iptr[r + 1] = iptr[r] + (int)inc[r].size();
+      iv.insert(iv.end(), inc[r].begin(), inc[r].end());
+    }
+    i_tail_.upload(tail); i_head_.upload(head); i_R_.upload(R); i_t_.upload(t); i_kappa_.upload(kap);
+    i_tau_.upload(tau); i_inc_ptr_.upload(iptr); i_inc_.upload(iv);
+    Ei_.nrows_own = P0_; Ei_.nrows_all = P0_;
+    Ei_.m = (int)tail.size(); Ei_.tail = i_tail_.p; Ei_.head = i_head_.p; Ei_.R = i_R_.p; Ei_.t = i_t_.p;
+    Ei_.kappa = i_kappa_.p; Ei_.tau = i_tau_.p; Ei_.inc_ptr = i_inc_ptr_.p; Ei_.inc = i_inc_.p;
+  }
   // ---- SPD solvers: one block-diagonal system over all local nodes
   {
     CsrMatrix Att, Arr;
@@ -647,6 +672,17 @@ void Group::host_update_logic(int a, double fobj, double f, double gradFnorm) {
   r.fobj = fobj;
   r.f = f;
   r.gradFnorm = gradFnorm;
+  if (star_) {   // update_n (DPGOStar.cpp:339-385): no restart counters, Gk = Fk = fobj every iteration
+    r.Gk = fobj;
+    if (o.scheme == 1) {
+      r.s0 = it == 0 ? 1.0 : r.s1;
+      r.s1 = 0.5 + 0.5 * std::sqrt(4.0 * r.s0 * r.s0 + 1.0);
+      r.gamma = (r.s0 - 1) / r.s1;
+    }
+    r.Fk[0] = r.Fk[1] = fobj;
+    r.updated = 1;
+    return;
+  }
   if (it == 0) {
     r.Fk[0] = r.Fk[1] = fobj;
     r.Gk = fobj;
@@ -701,7 +737,7 @@ int Group::update(const std::vector<int> &locals_in) {
     copy_rows(Dfp_.p, Dfc_.p, false);
   }
   std::vector<int> first, later;
-  for (int a : locals) (res_[a].iters == 0 ? first : later).push_back(a);
+  for (int a : locals) ((res_[a].iters == 0 || star_) ? first : later).push_back(a);
   if (trivial) {
     // g = S Z  (evaluate_none_g_and_f0 / _f, DPGOProblem.cpp:269-287, 516-542)
     launch_bsr(d_, st_, T_, false, cur_mask_, S_.dev, Zc_.p, false, nullptr, gc_.p, nullptr, 0, nullptr, nullptr, 0);
@@ -811,14 +847,13 @@ int Group::mm(const std::vector<int> &locals) {
   return 0;
 }
 
-// DPGOHash::amm_pgo  (DPGOHash.cpp:230-444)
-int Group::amm(const std::vector<int> &locals) {
+// Y = X[k] + gamma (X[k] - X[k-1]) and the surrogate gradient data at Y, for the masked nodes
+void Group::prepare_extrapolated() {
   const Options &o = opt_;
   const bool trivial = (o.loss == 0);
-  set_mask(locals);
   for (int a = 0; a < num_local(); a++) h_gamma_[a] = res_[a].gamma;
   HIP_CHECK(hipMemcpyAsync(gamma_.p, h_gamma_, sizeof(double) * num_local(), hipMemcpyHostToDevice, st_));
-  // Y = X[k] + gamma (X[k] - X[k-1]) on own AND neighbour rows (:255-256)
+  // own AND neighbour rows are extrapolated with the local gamma (DPGOHash.cpp:255-256)
   launch_extrapolate(d_, st_, T_, true, cur_mask_, gamma_.p, Zc_.p, Zp_.p, Y_.p);
   if (trivial) {
     launch_extrapolate(d_, st_, T_, false, cur_mask_, gamma_.p, gc_.p, gp_.p, gx_.p);      // :259-262
@@ -829,6 +864,14 @@ int Group::amm(const std::vector<int> &locals) {
                  partials_.p);
     launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Y_.p, false, gx_.p, Dfx_.p, nullptr, 0, nullptr, nullptr, 0);
   }
+}
+
+// DPGOHash::amm_pgo  (DPGOHash.cpp:230-444)
+int Group::amm(const std::vector<int> &locals) {
+  const Options &o = opt_;
+  const bool trivial = (o.loss == 0);
+  set_mask(locals);
+  prepare_extrapolated();
   for (int a : locals) {
     NodeResults &r = res_[a];
     r.refined = (((r.gradFnorm * r.gradFnorm / r.fobj) > o.accepted_delta) || (r.num_oscillations >= o.max_oscillations)) &&
@@ -1006,6 +1049,129 @@ int Group::debug_apply(int a, const char *op_c, const double *in, int ld_in, dou
     fprintf(stderr, "[dpgo_amd] ERROR: debug_apply: unknown operator %s\n", op_c);
     return -1;
   }
+  return 0;
+}
+
+}  // namespace dpgo
+
+
+namespace dpgo {
+
+// ---------------------------------------------------------------------------
+// AMM-PGO*  (DPGOStar, C++/DPGO/src/DPGOStar.cpp)
+// ---------------------------------------------------------------------------
+// Global objective F(X) (DPGOStar::evaluate_f, :713-761) at the point whose own rows are X_own:
+// neighbour rows are gathered from the same trial vector, every node evaluates its intra edges and
+// its inter edges (charged 1/2 per node), the host adds the per-node sums (the master's aggregate).
+double Group::global_objective(const double *X_own) {
+  std::vector<int> all(num_local());
+  for (int a = 0; a < num_local(); a++) all[a] = a;
+  set_mask(all);
+  copy_rows(Tall_.p, X_own, false, 0);
+  launch_copy_indexed(d_, st_, (int)gather_dst_.n, gather_dst_.p, gather_src_.p, Tall_.p, Tall_.p);
+  launch_cost(d_, st_, T_, cur_mask_, Ei_, E_, opt_.loss == 0, opt_.loss, opt_.loss_reg, Tall_.p, partials_.p, 0);
+  fetch(2, true);
+  double F = 0;
+  for (int a = 0; a < num_local(); a++) F += 0.5 * scal(a, 0) + 0.25 * scal(a, 1);
+  return F;
+}
+
+double Group::global_sqdist(const double *A_own, const double *B_own) {
+  launch_sqdist(d_, st_, T_, cur_mask_, A_own, B_own, partials_.p, 0);
+  fetch(1, false);
+  double s = 0;
+  for (int a = 0; a < num_local(); a++) s += scal(a, 0);
+  return s;
+}
+
+int Group::star_initialize_global(const double *X, int ld) {
+  if (num_local() != num_nodes_total_) {
+    fprintf(stderr, "[dpgo_amd] ERROR: AMM-PGO* needs every node of the graph in one group.\n");
+    return -1;
+  }
+  if (initialize_global(X, ld) != 0) return -1;
+  star_ = true;
+  star_fobj_ = global_objective(Xk_.p);
+  starF_ = star_fobj_;
+  star_fobjh_ = star_fobj_;
+  return 0;
+}
+
+int Group::star_update() {
+  if (!star_) return -1;
+  std::vector<int> all(num_local());
+  for (int a = 0; a < num_local(); a++) all[a] = a;
+  return update(all);
+}
+
+int Group::star_iterate() {
+  if (!star_) return -1;
+  const Options &o = opt_;
+  const int L = num_local();
+  std::vector<int> all(L);
+  for (int a = 0; a < L; a++) all[a] = a;
+  for (int a : all)
+    if (!res_[a].updated) {
+      fprintf(stderr, "[dpgo_amd] ERROR: The optimizer has not been updated (node %d).\n", nodes_[a]);
+      return -1;
+    }
+  star_branches_ = 0;
+  // ---- amm_pgo_n for every node (:392-550)
+  set_mask(all);
+  prepare_extrapolated();
+  std::vector<int> ref;
+  for (int a : all) {
+    NodeResults &r = res_[a];
+    r.refined = (r.gradFnorm * r.gradFnorm / r.fobj) > o.accepted_delta;   // :515-516
+    if (r.refined) ref.push_back(a);
+  }
+  launch_proximal(d_, st_, T_, cur_mask_, Y_.p, Dfx_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, nullptr, nullptr, 0);
+  copy_rows(Xak_.p, Xakh_.p, false, 2);
+  recover_translations(Xak_.p, gx_.p);
+  if (!ref.empty()) run_tnt(ref, Xak_.p, gx_.p);
+  // ---- the master's tests (:147-192); Xk = own rows of X[k] (Zc_)
+  double fobjh = global_objective(Xakh_.p);
+  set_mask(all);
+  if (fobjh > starF_ - o.psi * global_sqdist(Xakh_.p, Zc_.p)) {
+    star_branches_ |= 1;   // pm_pgo_n (:685-711)
+    launch_proximal(d_, st_, T_, cur_mask_, Zc_.p, Dfc_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, nullptr, nullptr, 0);
+    fobjh = global_objective(Xakh_.p);
+  }
+  double fobj = global_objective(Xak_.p);
+  set_mask(all);
+  if (fobj > starF_ - o.psi * global_sqdist(Xak_.p, Zc_.p)) {
+    star_branches_ |= 2;   // mm_pgo_n (:552-683) and halve s
+    copy_rows(Xak_.p, Xakh_.p, false, 2);
+    recover_translations(Xak_.p, gc_.p);
+    std::vector<int> plain;
+    for (int a : all)
+      if (!res_[a].refined) plain.push_back(a);
+    if (!ref.empty()) run_tnt(ref, Xak_.p, gc_.p);   // sets Gk = Results.f
+    if (!plain.empty()) {
+      set_mask(plain);
+      eval_G(Xak_.p, gc_.p, 0);
+      fetch(1, false);
+      for (int a : plain) res_[a].Gk = scal(a, 0) + res_[a].f;
+    }
+    for (int a : all) res_[a].s1 = std::max(0.5 * res_[a].s1, 1.0);
+    fobj = global_objective(Xak_.p);
+  }
+  if (starF_ - fobj < o.phi * (starF_ - fobjh)) {
+    star_branches_ |= 4;   // fall back to the proximal rotations (:171-192)
+    set_mask(all);
+    copy_rows(Xak_.p, Xakh_.p, false, 2);
+    recover_translations(Xak_.p, gc_.p);
+    fobj = global_objective(Xak_.p);
+  }
+  set_mask(all);
+  copy_rows(Xk_.p, Xak_.p, false);
+  for (int a : all) {
+    res_[a].iters++;
+    res_[a].updated = 0;
+  }
+  star_fobj_ = fobj;
+  star_fobjh_ = fobjh;
+  starF_ = starF_ * (1 - o.eta[0]) + fobj * o.eta[0];
   return 0;
 }
 

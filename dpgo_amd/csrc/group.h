@@ -116,6 +116,15 @@ class Group {
   int update(const std::vector<int> &locals);
   int iterate(const std::vector<int> &locals);
   int communicate_local();
+
+  // ---- AMM-PGO* (DPGOStar, C++/DPGO/src/DPGOStar.cpp:107-711); every node of the graph must be local
+  int star_initialize_global(const double *X, int ld);   // DPGOStar::initialize (:107-124)
+  int star_update();                                     // DPGOStar::update     (:306-313, update_n :315-390)
+  int star_iterate();                                    // DPGOStar::iterate    (:126-213)
+  double star_F() const { return starF_; }
+  double star_fobj() const { return star_fobj_; }
+  double star_fobjh() const { return star_fobjh_; }
+  int star_branches() const { return star_branches_; }   // bit 0 pm, bit 1 mm, bit 2 phi fallback
   // boundary exchange across groups: records of the poses other groups need
   int num_sent() const { return (int)sent_rows_.size(); }
   int pack_sent(double *dev_buf);                       // device buffer, num_sent()*RS doubles
@@ -181,6 +190,9 @@ class Group {
   DevBuf<int> e_tail_, e_head_, e_inc_ptr_, e_inc_;
   DevBuf<double> e_R_, e_t_, e_kappa_, e_tau_;
   InterEdgesDev E_;
+  DevBuf<int> i_tail_, i_head_, i_inc_ptr_, i_inc_;
+  DevBuf<double> i_R_, i_t_, i_kappa_, i_tau_;
+  InterEdgesDev Ei_;              // intra-node edges in residual form (objective evaluation only)
   SpdSolverDev Ltt_, Lrr_;
   // halo
   DevBuf<int> local_src_;          // per neighbour row: unified own row on this device, or -1
@@ -194,6 +206,12 @@ class Group {
   DevBuf<double> Xak_, Xakh_, gc_, gp_, Dfc_, Dfp_, gx_, Dfx_, T1_;   // P0 rows
   DevBuf<double> tmp_[14];                                       // P0 rows, TNT work vectors
   std::vector<int> last_mask_;
+  bool star_ = false;
+  double starF_ = 0, star_fobj_ = 0, star_fobjh_ = 0;
+  int star_branches_ = 0;
+  void prepare_extrapolated();                             // Y, g_x, Df_x for the masked nodes
+  double global_objective(const double *X_own);           // F at the point whose own rows are X_own
+  double global_sqdist(const double *A_own, const double *B_own);
 
   void upload_bsr(const std::vector<const BsrMatrix *> &per_node, bool rows_all, BsrBufs &out);
   void set_mask(const std::vector<int> &locals);

@@ -67,6 +67,14 @@ void launch_inter(int d, hipStream_t st, const SegTable &T, const int *mask, con
                   double loss_reg, int mode, bool quad, const double *Z, const double *Zprev,
                   const double *Qdiag, const double *Ddiag, double *DfE, double *g, double *partials);
 
+// Objective of every node at Z (own + neighbour rows): partial[slot0] = sum of intra-edge costs,
+// partial[slot0 + 1] = sum of rho over inter-edge costs; eform selects the data-matrix form (trivial loss).
+void launch_cost(int d, hipStream_t st, const SegTable &T, const int *mask, const InterEdgesDev &Ei,
+                 const InterEdgesDev &Ee, bool eform, int loss, double loss_reg, const double *Z, double *partials,
+                 int slot0);
+// partial[slot] = sum |a_p - b_p|^2 over own rows
+void launch_sqdist(int d, hipStream_t st, const SegTable &T, const int *mask, const double *a, const double *b,
+                   double *partials, int slot);
 // Xout = proximal(Z, Df) per own pose (DPGOProblem.cpp:600-632); slot>=0: partial ||Xout - Xref||^2.
 void launch_proximal(int d, hipStream_t st, const SegTable &T, const int *mask, const double *Z, const double *Df,
                      const double *Tinv, const double *N, const double *V, double *Xout, const double *Xref,

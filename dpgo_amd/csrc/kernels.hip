@@ -398,6 +398,110 @@ __global__ __launch_bounds__(256) void k_inter(const Seg *segs, const int *mask,
 }
 
 // ---------------------------------------------------------------------------
+// Objective of a node at an arbitrary point Z (DPGOStar::evaluate_f, C++/DPGO/src/DPGOStar.cpp:713-761).
+// Every edge is charged to its tail pose.  slot 0: sum over intra edges of the quadratic cost,
+// slot 1: sum over inter edges of rho(|r_e|^2).  eform = 1 uses the quadratic form of the data
+// matrix M (kappa |Y_i|^2 instead of kappa |R^T Y_i|^2: trivial loss, :722), eform = 0 the residual
+// form of B0 / B1 (robust losses, :729-736).
+// ---------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ double edge_cost(const InterEdgesDev &E, int e, const double *zi, const double *zj,
+                                            int eform) {
+  double Re[D * D], te[D];
+#pragma unroll
+  for (int i = 0; i < D * D; i++) Re[i] = E.R[(size_t)e * D * D + i];
+#pragma unroll
+  for (int i = 0; i < D; i++) te[i] = E.t[(size_t)e * D + i];
+  const double tau = E.tau[e], kap = E.kappa[e];
+  double sn = 0;
+#pragma unroll
+  for (int c = 0; c < D; c++) {
+    double a = zi[c] - zj[c];
+#pragma unroll
+    for (int q = 0; q < D; q++) a = fma(te[q], zi[D + q * D + c], a);
+    sn = fma(tau * a, a, sn);
+  }
+  if (eform) {
+    // kappa (|Y_i|^2 + |Y_j|^2 - 2 <Y_i, R Y_j>)
+    double s = 0;
+#pragma unroll
+    for (int q = 0; q < D; q++)
+#pragma unroll
+      for (int c = 0; c < D; c++) {
+        double ry = 0;
+#pragma unroll
+        for (int r = 0; r < D; r++) ry = fma(Re[q * D + r], zj[D + r * D + c], ry);
+        const double yi = zi[D + q * D + c], yj = zj[D + q * D + c];
+        s += yi * yi + yj * yj - 2.0 * yi * ry;
+      }
+    sn = fma(kap, s, sn);
+  } else {
+#pragma unroll
+    for (int r = 0; r < D; r++)
+#pragma unroll
+      for (int c = 0; c < D; c++) {
+        double a = -zj[D + r * D + c];
+#pragma unroll
+        for (int q = 0; q < D; q++) a = fma(Re[q * D + r], zi[D + q * D + c], a);
+        sn = fma(kap * a, a, sn);
+      }
+  }
+  return sn;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_cost(const Seg *segs, const int *mask, InterEdgesDev Ei, InterEdgesDev Ee,
+                                              int eform, int loss, double dl, const double *Z, double *partial,
+                                              int pstride) {
+  constexpr int RS = Dim<D>::RS;
+  const Seg s = segs[blockIdx.x];
+  const bool active = (mask == nullptr) || (mask[s.node] != 0);
+  double part[2] = {0.0, 0.0};
+  const int row = s.begin + threadIdx.x;
+  if (active && row < s.end) {
+    double zp[RS], zo[RS];
+    load_vec<RS>(Z + (size_t)row * RS, zp);
+    if (row < Ei.nrows_own)
+      for (int k = Ei.inc_ptr[row]; k < Ei.inc_ptr[row + 1]; k++) {
+        const int e = Ei.inc[k] >> 1;
+        load_vec<RS>(Z + (size_t)Ei.head[e] * RS, zo);
+        part[0] += edge_cost<D>(Ei, e, zp, zo, eform);
+      }
+    for (int k = Ee.inc_ptr[row]; k < Ee.inc_ptr[row + 1]; k++) {
+      const int code = Ee.inc[k];
+      if (code & 1) continue;   // charged to the tail only
+      const int e = code >> 1;
+      load_vec<RS>(Z + (size_t)Ee.head[e] * RS, zo);
+      double w, rho;
+      loss_weight(loss, dl, edge_cost<D>(Ee, e, zp, zo, eform), w, rho);
+      part[1] += rho;
+    }
+  }
+  block_store<2>(part, partial + blockIdx.x, pstride);
+}
+
+// partial = sum |a_p - b_p|^2 over own rows
+template <int D>
+__global__ __launch_bounds__(256) void k_sqdist(const Seg *segs, const int *mask, const double *a, const double *b,
+                                                double *partial) {
+  constexpr int RS = Dim<D>::RS;
+  const Seg s = segs[blockIdx.x];
+  const bool active = (mask == nullptr) || (mask[s.node] != 0);
+  double pr[1] = {0.0};
+  const int row = s.begin + threadIdx.x;
+  if (active && row < s.end) {
+    double va[RS], vb[RS];
+    load_vec<RS>(a + (size_t)row * RS, va);
+    load_vec<RS>(b + (size_t)row * RS, vb);
+    double p = 0;
+#pragma unroll
+    for (int k = 0; k < RS; k++) { const double dd = va[k] - vb[k]; p = fma(dd, dd, p); }
+    pr[0] = p;
+  }
+  block_store<1>(pr, partial + blockIdx.x, 0);
+}
+
+// ---------------------------------------------------------------------------
 // Per-pose kernels.
 // ---------------------------------------------------------------------------
 template <int D>
@@ -964,6 +1068,24 @@ void launch_inter(int d, hipStream_t st, const SegTable &T, const int *mask, con
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_inter<D>), dim3(nb), dim3(256), 0, st, T.segs, mask, E, loss, loss_reg,
                                         mode, quad ? 1 : 0, T.nseg_own, Z, Zprev, Qdiag, Ddiag, DfE, g, partials,
                                         T.nseg_all));
+}
+
+void launch_cost(int d, hipStream_t st, const SegTable &T, const int *mask, const InterEdgesDev &Ei,
+                 const InterEdgesDev &Ee, bool eform, int loss, double loss_reg, const double *Z, double *partials,
+                 int slot0) {
+  if (T.nseg_all == 0) return;
+  ProfScope ps(PK_INTER, st, (double)(Ei.m + Ee.m) * (8.0 * (d * d + d + 2) + 8) + 1.0 * T.rows_all * 8.0 * (d + 1) * d);
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cost<D>), dim3(T.nseg_all), dim3(256), 0, st, T.segs, mask, Ei, Ee,
+                                        eform ? 1 : 0, loss, loss_reg, Z, partials + (size_t)slot0 * T.nseg_all,
+                                        T.nseg_all));
+}
+
+void launch_sqdist(int d, hipStream_t st, const SegTable &T, const int *mask, const double *a, const double *b,
+                   double *partials, int slot) {
+  if (T.nseg_own == 0) return;
+  ProfScope ps(PK_DOT, st, 2.0 * T.rows_own * 8.0 * (d + 1) * d);
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_sqdist<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, a, b,
+                                        partials + (size_t)slot * T.nseg_all));
 }
 
 void launch_proximal(int d, hipStream_t st, const SegTable &T, const int *mask, const double *Z, const double *Df,

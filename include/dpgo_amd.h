@@ -119,6 +119,16 @@ int dpgo_group_update(dpgo_group_t *grp, const int *locals, int n);
 int dpgo_group_iterate(dpgo_group_t *grp, const int *locals, int n);
 /* DPGOHash::communicate -- C++/DPGO/include/DPGO/DPGOHash.h:28-86 -- for neighbours hosted by this group. */
 int dpgo_group_communicate_local(dpgo_group_t *grp);
+/* AMM-PGO* -- DPGOStar::{initialize, update, iterate} (C++/DPGO/src/DPGOStar.cpp:107-213; per-node
+ * helpers :215-711); communicate() is dpgo_group_communicate_local.  Every node of the graph must be in
+ * the group (the master's global objective is the sum of the per-node device reductions).  Loop:
+ * star_initialize(X); repeat { star_update; star_iterate; communicate_local }.
+ * star_state: F (running average, :210), fobj = F(X_k+1), fobjh = F(X_k+1/2), branches bit 0 = plain
+ * proximal redo (:149-155), bit 1 = MM redo (:159-169), bit 2 = proximal-rotation fallback (:171-192). */
+int dpgo_group_star_initialize(dpgo_group_t *grp, const double *X, int ld);
+int dpgo_group_star_update(dpgo_group_t *grp);
+int dpgo_group_star_iterate(dpgo_group_t *grp);
+int dpgo_group_star_state(const dpgo_group_t *grp, double *F, double *fobj, double *fobjh, int *branches);
 /* Boundary exchange with other groups (the message of DPGOHash::receive, DPGOHash.cpp:45-82):
  * pack this group's exported poses into a device buffer of num_sent * (d+1)*d doubles, all-gather
  * the buffers of all groups (RCCL), then unpack.  Keys are (node, pose). */

@@ -194,3 +194,192 @@ class DistPGO:
         for _ in range(iters):
             self.step(evaluate)
         return self.trace
+
+
+class DPGOStar:
+    """AMM-PGO* (master node aggregates the global objective).
+
+    Restates DPGOStar::{initialize, iterate, communicate, update} and the per-node
+    helpers {initialize_n, update_n, amm_pgo_n, mm_pgo_n, pm_pgo_n, communicate_n}
+    (C++/DPGO/src/DPGOStar.cpp:107-711).  Intended loop (asserts at :318, :393):
+    initialize(X); repeat { update(); iterate(); communicate() }."""
+
+    def __init__(self, filename, num_nodes, options=None, mm=None, num_poses=None):
+        from .hash import DPGOHash, Results
+        self.options = options or Options.driver()
+        if mm is None:
+            num_poses, mm = read_g2o_file(filename)
+        self.num_poses, self.mm, self.num_nodes, self.d = num_poses, mm, num_nodes, mm.d
+        _, self.measurements, self.g_index = partition_measurements(num_poses, mm, num_nodes)
+        # DPGOHash objects are used as containers of (problem, results); their own
+        # update()/iterate() are not called
+        self.nodes = [DPGOHash(a, self.measurements[a], self.options) for a in range(num_nodes)]
+        self.star = GlobalProblem(num_poses, mm, num_nodes, self.options)
+        self.Xk = self.Xkh = self.Xkp = None
+        self.F = self.fobj = 0.0
+
+    def _gid(self, node, pose):
+        return self.g_index[node][pose]
+
+    def _fill(self, a, X, own=True):
+        """initialize_n / communicate_n (:215-313): rows of node a's Z from the global X."""
+        nd = self.nodes[a]
+        p, d, N = nd.problem, self.d, self.num_poses
+        n0, n1 = p.n
+        Z = nd.results.Xk
+        for beta, poses in p.info.index.items():
+            if beta == a and not own:
+                continue
+            for j, (blk, k) in poses.items():
+                g = self._gid(beta, j)
+                s = 0 if blk == 0 else (d + 1) * n0
+                nn = n0 if blk == 0 else n1
+                Z[s + k] = X[g]
+                Z[s + nn + d * k: s + nn + d * k + d] = X[N + d * g: N + d * g + d]
+
+    def _put(self, a, Xglob, Xa):
+        """Write node a's own poses into a global matrix (:545-550)."""
+        n0, d, N = self.nodes[a].problem.n[0], self.d, self.num_poses
+        o = self.g_index[a][0]
+        Xglob[o:o + n0] = Xa[:n0]
+        Xglob[N + d * o: N + d * (o + n0)] = Xa[n0:]
+
+    def initialize(self, X):
+        from .hash import Results
+        d = self.d
+        for a, nd in enumerate(self.nodes):
+            n0, n1 = nd.problem.n
+            nd.results = Results()
+            nd.results.Xk = np.zeros(((d + 1) * (n0 + n1), d))
+            self._fill(a, X, own=True)
+            nd.results.Xak = nd.results.Xk[:(d + 1) * n0].copy()
+            nd.results.gamma = 0.0
+            nd.results.updated = False
+        self.Xk = X.copy()
+        self.Xkh = np.zeros_like(X)
+        self.Xkp = np.zeros_like(X)
+        self.fobj = self.star.evaluate_f(self.Xk)
+        self.F = self.fobj
+        return 0
+
+    def communicate(self):
+        for a, nd in enumerate(self.nodes):
+            self._fill(a, self.Xk, own=False)
+            nd.results.updated = False
+        return 0
+
+    def update(self):
+        """update_n for every node (:315-390): re-linearise from scratch every iteration."""
+        import math
+        for nd in self.nodes:
+            r, p, o = nd.results, nd.problem, self.options
+            if r.updated:
+                continue
+            it = r.iters
+            r.X = [r.Xk.copy(), r.X[0]]
+            if p.trivial:
+                g, f = p.evaluate_none_g_and_f0(r.X[0])
+                fobj = p.evaluate_G(r.Xak, g, f)
+                Dfobj, gradF = p.full_Riemannian_gradient_G(r.Xak, g)
+            else:
+                g, f, Dfobj, fobj, r.DfobjE, r.fobjE = p.evaluate_g_and_f0(r.X[0])
+                gradF = p.full_tangent_space_projection(r.Xak, Dfobj)
+            r.Gk = fobj
+            r.g = [g, r.g[0]]
+            r.Dfobj = [Dfobj, r.Dfobj[0]]
+            r.f = f
+            r.fobj = [fobj, r.fobj[0]]
+            r.gradFnorm = float(np.linalg.norm(gradF))
+            if o.scheme == 1:
+                r.s = [1.0, 1.0] if it == 0 else [r.s[1], 0.0]
+                r.s[1] = 0.5 + 0.5 * math.sqrt(4.0 * r.s[0] * r.s[0] + 1.0)
+                r.gamma = (r.s[0] - 1) / r.s[1]
+            r.Fk = [fobj, fobj]
+            r.updated = True
+        return 0
+
+    def _amm_n(self, a):
+        nd = self.nodes[a]
+        r, p, o = nd.results, nd.problem, self.options
+        n0 = p.n[0]
+        if r.iters == 0:
+            Y, g, Df = r.Xk, r.g[0], r.Dfobj[0]
+        else:
+            Y = r.X[0] + r.gamma * (r.X[0] - r.X[1])
+            if p.trivial:
+                g = r.g[0] + r.gamma * (r.g[0] - r.g[1])
+                Df = r.Dfobj[0] + r.gamma * (r.Dfobj[0] - r.Dfobj[1])
+            else:
+                g, Df = p.evaluate_g_and_Df(Y)
+        r.refined = (r.gradFnorm * r.gradFnorm / r.fobj[0]) > o.accepted_delta       # :515-516
+        r.Xakh = p.proximal(Y, Df)
+        R = r.Xakh[n0:].copy()
+        r.Xak = np.vstack([p.recover_translations(R, g), R])
+        if r.refined:
+            r.Xak = nd._tnt(r.Xak, g)["x"]
+        self._put(a, self.Xkh, r.Xakh)
+        self._put(a, self.Xkp, r.Xak)
+
+    def _pm_n(self, a):
+        nd = self.nodes[a]
+        r = nd.results
+        r.Xakh = nd.problem.proximal(r.Xk, r.Dfobj[0])
+        self._put(a, self.Xkh, r.Xakh)
+
+    def _mm_n(self, a):
+        nd = self.nodes[a]
+        r, p, o = nd.results, nd.problem, self.options
+        n0 = p.n[0]
+        g = r.g[0]
+        refined = (r.gradFnorm * r.gradFnorm / r.fobj[0]) > o.accepted_delta
+        R = r.Xakh[n0:].copy()
+        r.Xak = np.vstack([p.recover_translations(R, g), R])
+        if refined:
+            res = nd._tnt(r.Xak, g)
+            r.Xak, r.Gk = res["x"], res["f"]
+        else:
+            r.Gk = p.evaluate_G(r.Xak, g, r.f)
+        self._put(a, self.Xkp, r.Xak)
+
+    def iterate(self):
+        """DPGOStar::iterate (:126-213)."""
+        o = self.options
+        for a in range(self.num_nodes):
+            self._amm_n(a)
+        fobjh = self.star.evaluate_f(self.Xkh)
+        self.branches = []
+        if fobjh > self.F - o.psi * float(np.sum((self.Xkh - self.Xk) ** 2)):
+            self.branches.append("pm")
+            for a in range(self.num_nodes):
+                self._pm_n(a)
+            fobjh = self.star.evaluate_f(self.Xkh)
+        fobj = self.star.evaluate_f(self.Xkp)
+        if fobj > self.F - o.psi * float(np.sum((self.Xkp - self.Xk) ** 2)):
+            self.branches.append("mm")
+            for a, nd in enumerate(self.nodes):
+                self._mm_n(a)
+                nd.results.s[1] = max(0.5 * nd.results.s[1], 1.0)
+            fobj = self.star.evaluate_f(self.Xkp)
+        if self.F - fobj < o.phi * (self.F - fobjh):
+            self.branches.append("phi")
+            for a, nd in enumerate(self.nodes):
+                r, p = nd.results, nd.problem
+                n0 = p.n[0]
+                R = r.Xakh[n0:].copy()
+                r.Xak = np.vstack([p.recover_translations(R, r.g[0]), R])
+                self._put(a, self.Xkp, r.Xak)
+            fobj = self.star.evaluate_f(self.Xkp)
+        for nd in self.nodes:
+            r, p = nd.results, nd.problem
+            r.iters += 1
+            r.Xk[:(self.d + 1) * p.n[0]] = r.Xak
+            r.updated = False
+        self.Xk, self.Xkp = self.Xkp, self.Xk
+        self.fobj, self.fobjh = fobj, fobjh
+        self.F = self.F * (1 - o.eta[0]) + fobj * o.eta[0]
+        return 0
+
+    def step(self):
+        self.update()
+        self.iterate()
+        self.communicate()

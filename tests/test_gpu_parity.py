@@ -341,3 +341,32 @@ def test_dist_pgo_cli_matches_oracle(fixtures_dir, tmp_path):
     assert est.shape == (4 * num_poses, 3)
     np.testing.assert_allclose(est[0], 0, atol=1e-12)                      # t_0 = 0 after the gauge fix
     np.testing.assert_allclose(est[num_poses:num_poses + 3], np.eye(3), atol=1e-5)   # R_0 = I
+
+
+@pytest.mark.parametrize("name,nn,loss,iters", [("M3500", 4, LOSS_NONE, 25),      # BASELINE config 5 (AMM-PGO*)
+                                                 ("smallGrid3D", 3, LOSS_HUBER, 25),
+                                                 ("torus3D", 8, LOSS_WELSCH, 12)])
+def test_amm_pgo_star_matches_oracle(fixtures_dir, name, nn, loss, iters):
+    """AMM-PGO* (DPGOStar::iterate): global objective after every iteration within 1e-7 relative, same
+    branch decisions, final poses within 1e-6."""
+    from oracle.star import DPGOStar as OStar
+    path = os.path.join(fixtures_dir, name + ".g2o")
+    num_poses, mm = og.read_g2o_file(path)
+    X0 = chordal_initialization(num_poses, mm)
+    orc = OStar(path, nn, _oracle_opts(loss, True), mm=mm, num_poses=num_poses)
+    orc.initialize(X0)
+    gpu = dpgo_amd.DPGOStar(dpgo_amd.read_g2o(path, nn), dpgo_amd.Options.driver(loss, True))
+    assert gpu.initialize(X0) == 0
+    np.testing.assert_allclose(gpu.state()["fobj"], orc.fobj, rtol=1e-9)
+    names = {"pm": 1, "mm": 2, "phi": 4}
+    for it in range(iters):
+        orc.step()
+        assert gpu.step() == 0
+        st = gpu.state()
+        np.testing.assert_allclose(st["fobj"], orc.fobj, rtol=1e-7, err_msg="it=%d" % it)
+        np.testing.assert_allclose(st["fobjh"], orc.fobjh, rtol=1e-7, err_msg="it=%d" % it)
+        np.testing.assert_allclose(st["F"], orc.F, rtol=1e-9)
+        assert st["branches"] == sum(names[b] for b in orc.branches), (it, orc.branches)
+    np.testing.assert_allclose(gpu.X(), orc.Xk, atol=1e-6)
+    # iterate() without update() is an error
+    assert gpu.iterate() == -1
