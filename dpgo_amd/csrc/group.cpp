@@ -73,11 +73,20 @@ void SpdSolverDev::upload(int dcols) {
   auto wide_bwd = [&](int f) { return F.w[f] + F.u[f] > 96; };
   fwd_big_ptr.clear();
   bwd_big_ptr.clear();
+  // a level whose narrow class is small is not worth a launch of its own: its tiles join the wide class
+  auto tiles = [&](const std::vector<int> &lvl, bool fwd, bool want_wide) {
+    int cnt = 0;
+    for (int f : lvl)
+      if ((fwd ? wide_fwd(f) : wide_bwd(f)) == want_wide) cnt += ((fwd ? F.w[f] + F.u[f] : F.w[f]) + 63) / 64;
+    return cnt;
+  };
+  const int MERGE_BELOW = 1024;
   for (const auto &lvl : F.by_height) {
+    const bool merge = tiles(lvl, true, true) > 0 && tiles(lvl, true, false) < MERGE_BELOW;
     for (int pass = 0; pass < 2; pass++) {
       if (pass == 1) fwd_big_ptr.push_back((int)fi.size());
       for (int f : lvl) {
-        if ((int)wide_fwd(f) != pass) continue;
+        if ((int)(wide_fwd(f) || merge) != pass) continue;
         const int m = F.w[f] + F.u[f];
         for (int r = 0; r < m; r += 64) fi.push_back(make_int4(f, r, std::min(64, m - r), 0));
       }
@@ -86,10 +95,11 @@ void SpdSolverDev::upload(int dcols) {
   }
   bwd_level_ptr.assign(1, 0);
   for (const auto &lvl : F.by_depth) {
+    const bool merge = tiles(lvl, false, true) > 0 && tiles(lvl, false, false) < MERGE_BELOW;
     for (int pass = 0; pass < 2; pass++) {
       if (pass == 1) bwd_big_ptr.push_back((int)bi.size());
       for (int f : lvl) {
-        if ((int)wide_bwd(f) != pass) continue;
+        if ((int)(wide_bwd(f) || merge) != pass) continue;
         for (int c = 0; c < F.w[f]; c += 64) bi.push_back(make_int4(f, c, std::min(64, F.w[f] - c), 0));
       }
     }
