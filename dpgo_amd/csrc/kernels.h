@@ -21,7 +21,9 @@
 
 namespace dpgo {
 
-constexpr int SEG_ROWS = 256;
+// 64 rows per segment = one wavefront per workgroup for the row kernels: a node of 12.5 k poses still
+// yields ~200 workgroups, enough to spread over the 256 CUs when a GPU holds a single node.
+constexpr int SEG_ROWS = 64;
 constexpr int MAX_SLOTS = 8;
 
 struct Seg {

@@ -27,9 +27,17 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // Sum NS per-thread values over a 256-thread workgroup and store to dst[s * stride].
-template <int NS>
+template <int NS, int NWAVES = SEG_ROWS / 64>
 __device__ __forceinline__ void block_store(const double (&v)[NS], double *dst, int stride) {
-  __shared__ double sm[NS][4];
+  if constexpr (NWAVES == 1) {
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      const double r = wave_sum(v[s]);
+      if (threadIdx.x == 0) dst[(size_t)s * stride] = r;
+    }
+    return;
+  }
+  __shared__ double sm[NS][NWAVES];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
   for (int s = 0; s < NS; s++) {
@@ -39,7 +47,12 @@ __device__ __forceinline__ void block_store(const double (&v)[NS], double *dst, 
   __syncthreads();
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int s = 0; s < NS; s++) dst[(size_t)s * stride] = (sm[s][0] + sm[s][1]) + (sm[s][2] + sm[s][3]);
+    for (int s = 0; s < NS; s++) {
+      double a = 0;
+#pragma unroll
+      for (int q = 0; q < NWAVES; q += 4) a += (sm[s][q] + sm[s][q + 1]) + (sm[s][q + 2] + sm[s][q + 3]);
+      dst[(size_t)s * stride] = a;
+    }
   }
 }
 
@@ -234,47 +247,59 @@ __device__ __forceinline__ void tangent_proj(const double *Y, const double *F, d
 // ---------------------------------------------------------------------------
 // Block-sparse operator apply over pose records.
 // ---------------------------------------------------------------------------
+// Four lanes share one block row: lane j takes the blocks k = j (mod 4) of the row and the partial
+// (d+1) x d results are combined with two xor-shuffles.  A row has ~10 blocks, each needing two
+// dependent loads (column index, then record); splitting them over lanes cuts the serial latency of a
+// row by 4x, which is what bounds this kernel when a GPU holds a single node (12.5 k rows).
 template <int D, bool ROT_ONLY>
-__global__ __launch_bounds__(256) void k_bsr(const Seg *segs, const int *mask, BsrDev A, const double *x,
-                                             const double *addv, double *y, const double *dotv, double coef,
-                                             const double *dotadd, double *partial) {
+__global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr(const Seg *segs, const int *mask, BsrDev A, const double *x,
+                                              const double *addv, double *y, const double *dotv, double coef,
+                                              const double *dotadd, double *partial) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
   const Seg s = segs[blockIdx.x];
   const bool active = (mask == nullptr) || (mask[s.node] != 0);
   double part[1] = {0.0};
-  const int row = s.begin + threadIdx.x;
-  if (active && row < s.end) {
+  const int row = s.begin + (threadIdx.x >> 2), j = threadIdx.x & 3;
+  if (active) {   // uniform per workgroup; rows past the segment end simply have no blocks
     double acc[RS];
 #pragma unroll
     for (int k = 0; k < RS; k++) acc[k] = 0.0;
-    const int k1 = A.ptr[row + 1];
-    for (int k = A.ptr[row]; k < k1; k++) {
+    const bool inrow = row < s.end;
+    const int k1 = inrow ? A.ptr[row + 1] : 0;
+    for (int k = (inrow ? A.ptr[row] : 0) + j; k < k1; k += 4) {
       const int q = A.col[k];
       double xb[RS], blk[B * B];
       load_vec<RS>(x + (size_t)q * RS, xb);
       load_vec<B * B>(A.val + (size_t)k * B * B, blk);
       blk_mul_acc<D, ROT_ONLY>(blk, xb, acc);
     }
-    if (dotv) {
-      double v[RS], da[RS];
-      load_vec<RS>(dotv + (size_t)row * RS, v);
-      if (dotadd) load_vec<RS>(dotadd + (size_t)row * RS, da);
-      double p = 0;
 #pragma unroll
-      for (int k = 0; k < RS; k++) p = fma(v[k], fma(coef, acc[k], dotadd ? da[k] : 0.0), p);
-      part[0] = p;
+    for (int k = 0; k < RS; k++) {
+      acc[k] += __shfl_xor(acc[k], 1, 64);
+      acc[k] += __shfl_xor(acc[k], 2, 64);
     }
-    if (y) {
-      if (addv) {
-        double av[RS];
-        load_vec<RS>(addv + (size_t)row * RS, av);
+    if (inrow && j == 0) {
+      if (dotv) {
+        double v[RS], da[RS];
+        load_vec<RS>(dotv + (size_t)row * RS, v);
+        if (dotadd) load_vec<RS>(dotadd + (size_t)row * RS, da);
+        double p = 0;
 #pragma unroll
-        for (int k = 0; k < RS; k++) acc[k] += av[k];
+        for (int k = 0; k < RS; k++) p = fma(v[k], fma(coef, acc[k], dotadd ? da[k] : 0.0), p);
+        part[0] = p;
       }
-      store_vec<RS>(y + (size_t)row * RS, acc);
+      if (y) {
+        if (addv) {
+          double av[RS];
+          load_vec<RS>(addv + (size_t)row * RS, av);
+#pragma unroll
+          for (int k = 0; k < RS; k++) acc[k] += av[k];
+        }
+        store_vec<RS>(y + (size_t)row * RS, acc);
+      }
     }
   }
-  if (partial) block_store<1>(part, partial + blockIdx.x, 0);
+  if (partial) block_store<1, 4 * SEG_ROWS / 64>(part, partial + blockIdx.x, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -299,7 +324,7 @@ __device__ __forceinline__ void loss_weight(int loss, double dl, double s, doubl
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void k_inter(const Seg *segs, const int *mask, InterEdgesDev E, int loss,
+__global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, const int *mask, InterEdgesDev E, int loss,
                                                double dl, int mode, int quad, int nseg_own, const double *Z,
                                                const double *Zprev, const double *Qd, const double *Dd,
                                                double *DfE, double *g, double *partial, int pstride) {
@@ -450,7 +475,7 @@ __device__ __forceinline__ double edge_cost(const InterEdgesDev &E, int e, const
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void k_cost(const Seg *segs, const int *mask, InterEdgesDev Ei, InterEdgesDev Ee,
+__global__ __launch_bounds__(SEG_ROWS) void k_cost(const Seg *segs, const int *mask, InterEdgesDev Ei, InterEdgesDev Ee,
                                               int eform, int loss, double dl, const double *Z, double *partial,
                                               int pstride) {
   constexpr int RS = Dim<D>::RS;
@@ -482,7 +507,7 @@ __global__ __launch_bounds__(256) void k_cost(const Seg *segs, const int *mask, 
 
 // partial = sum |a_p - b_p|^2 over own rows
 template <int D>
-__global__ __launch_bounds__(256) void k_sqdist(const Seg *segs, const int *mask, const double *a, const double *b,
+__global__ __launch_bounds__(SEG_ROWS) void k_sqdist(const Seg *segs, const int *mask, const double *a, const double *b,
                                                 double *partial) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[blockIdx.x];
@@ -505,7 +530,7 @@ __global__ __launch_bounds__(256) void k_sqdist(const Seg *segs, const int *mask
 // Per-pose kernels.
 // ---------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256) void k_proximal(const Seg *segs, const int *mask, const double *Z,
+__global__ __launch_bounds__(SEG_ROWS) void k_proximal(const Seg *segs, const int *mask, const double *Z,
                                                   const double *Df, const double *Tinv, const double *Nv,
                                                   const double *Vb, double *Xout, const double *Xref,
                                                   double *partial) {
@@ -558,7 +583,7 @@ __global__ __launch_bounds__(256) void k_proximal(const Seg *segs, const int *ma
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void k_extrapolate(const Seg *segs, const int *mask, const double *gamma,
+__global__ __launch_bounds__(SEG_ROWS) void k_extrapolate(const Seg *segs, const int *mask, const double *gamma,
                                                      const double *a, const double *b, double *out) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[blockIdx.x];
@@ -575,7 +600,7 @@ __global__ __launch_bounds__(256) void k_extrapolate(const Seg *segs, const int 
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void k_axpby(const Seg *segs, const int *mask, double alpha, const double *a,
+__global__ __launch_bounds__(SEG_ROWS) void k_axpby(const Seg *segs, const int *mask, double alpha, const double *a,
                                                double beta, const double *b, double *out, int part) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[blockIdx.x];
@@ -592,7 +617,7 @@ __global__ __launch_bounds__(256) void k_axpby(const Seg *segs, const int *mask,
 
 // out = alpha[node] * a + beta[node] * b  (per-node coefficients: batched CG updates)
 template <int D>
-__global__ __launch_bounds__(256) void k_axpby_node(const Seg *segs, const int *mask, const double *alpha,
+__global__ __launch_bounds__(SEG_ROWS) void k_axpby_node(const Seg *segs, const int *mask, const double *alpha,
                                                     const double *a, const double *beta, const double *b,
                                                     double *out) {
   constexpr int RS = Dim<D>::RS;
@@ -610,7 +635,7 @@ __global__ __launch_bounds__(256) void k_axpby_node(const Seg *segs, const int *
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void k_dot(const Seg *segs, const int *mask, const double *a, const double *b,
+__global__ __launch_bounds__(SEG_ROWS) void k_dot(const Seg *segs, const int *mask, const double *a, const double *b,
                                              int part, double *partial) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[blockIdx.x];
@@ -637,7 +662,7 @@ struct DotPairs {
   int n;
 };
 template <int D>
-__global__ __launch_bounds__(256) void k_dots(const Seg *segs, const int *mask, DotPairs P, int part,
+__global__ __launch_bounds__(SEG_ROWS) void k_dots(const Seg *segs, const int *mask, DotPairs P, int part,
                                               double *partial, int pstride) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[blockIdx.x];
@@ -660,7 +685,7 @@ __global__ __launch_bounds__(256) void k_dots(const Seg *segs, const int *mask, 
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void k_tangent_full(const Seg *segs, const int *mask, const double *X,
+__global__ __launch_bounds__(SEG_ROWS) void k_tangent_full(const Seg *segs, const int *mask, const double *X,
                                                       const double *V, double *out, double *partial) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[blockIdx.x];
@@ -687,7 +712,7 @@ __global__ __launch_bounds__(256) void k_tangent_full(const Seg *segs, const int
 // mode 1: out.Y = Proj_R(E.Y - sym(nabla.Y R^T) Rdot.Y) (Hessian epilogue, DPGOProblem.cpp:570-574)
 // mode 2: out.Y = proj_SO(d)(R + in.Y)                  (SOdProduct::retract)
 template <int D>
-__global__ __launch_bounds__(256) void k_rot_op(const Seg *segs, const int *mask, int mode, const double *X,
+__global__ __launch_bounds__(SEG_ROWS) void k_rot_op(const Seg *segs, const int *mask, int mode, const double *X,
                                                 const double *in, const double *nabla, const double *Rdot,
                                                 double *out) {
   constexpr int RS = Dim<D>::RS;
@@ -750,7 +775,7 @@ __global__ __launch_bounds__(256) void k_copy_indexed(int count, const int *didx
 
 // partial = sum_p < x_p , coef * (D_p x_p) + addcoef * add_p >   (own rows, D block diagonal)
 template <int D>
-__global__ __launch_bounds__(256) void k_bdiag_dot(const Seg *segs, const int *mask, const double *Dd,
+__global__ __launch_bounds__(SEG_ROWS) void k_bdiag_dot(const Seg *segs, const int *mask, const double *Dd,
                                                    const double *x, double coef, const double *add,
                                                    double addcoef, double *partial) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
@@ -1051,10 +1076,10 @@ void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, const i
   ProfScope ps(PK_BSR, st, (double)A.nnzb * (8.0 * (d + 1) * (d + 1) + 4) + 2.0 * A.nrows * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, {
     if (in_rot_only)
-      hipLaunchKernelGGL((k_bsr<D, true>), dim3(nb), dim3(256), 0, st, T.segs, mask, A, x, addv, y, dotv, coef,
+      hipLaunchKernelGGL((k_bsr<D, true>), dim3(nb), dim3(4 * SEG_ROWS), 0, st, T.segs, mask, A, x, addv, y, dotv, coef,
                          dotadd, part);
     else
-      hipLaunchKernelGGL((k_bsr<D, false>), dim3(nb), dim3(256), 0, st, T.segs, mask, A, x, addv, y, dotv, coef,
+      hipLaunchKernelGGL((k_bsr<D, false>), dim3(nb), dim3(4 * SEG_ROWS), 0, st, T.segs, mask, A, x, addv, y, dotv, coef,
                          dotadd, part);
   });
 }
@@ -1065,7 +1090,7 @@ void launch_inter(int d, hipStream_t st, const SegTable &T, const int *mask, con
   const int nb = mode == 0 ? T.nseg_all : T.nseg_own;
   if (nb == 0) return;
   ProfScope ps(PK_INTER, st, (double)E.m * (8.0 * (d * d + d + 2) + 8) + 2.0 * (mode == 0 ? E.nrows_all : E.nrows_own) * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_inter<D>), dim3(nb), dim3(256), 0, st, T.segs, mask, E, loss, loss_reg,
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_inter<D>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, E, loss, loss_reg,
                                         mode, quad ? 1 : 0, T.nseg_own, Z, Zprev, Qdiag, Ddiag, DfE, g, partials,
                                         T.nseg_all));
 }
@@ -1075,7 +1100,7 @@ void launch_cost(int d, hipStream_t st, const SegTable &T, const int *mask, cons
                  int slot0) {
   if (T.nseg_all == 0) return;
   ProfScope ps(PK_INTER, st, (double)(Ei.m + Ee.m) * (8.0 * (d * d + d + 2) + 8) + 1.0 * T.rows_all * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cost<D>), dim3(T.nseg_all), dim3(256), 0, st, T.segs, mask, Ei, Ee,
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cost<D>), dim3(T.nseg_all), dim3(SEG_ROWS), 0, st, T.segs, mask, Ei, Ee,
                                         eform ? 1 : 0, loss, loss_reg, Z, partials + (size_t)slot0 * T.nseg_all,
                                         T.nseg_all));
 }
@@ -1084,7 +1109,7 @@ void launch_sqdist(int d, hipStream_t st, const SegTable &T, const int *mask, co
                    double *partials, int slot) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_DOT, st, 2.0 * T.rows_own * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_sqdist<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, a, b,
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_sqdist<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, a, b,
                                         partials + (size_t)slot * T.nseg_all));
 }
 
@@ -1094,7 +1119,7 @@ void launch_proximal(int d, hipStream_t st, const SegTable &T, const int *mask, 
   if (T.nseg_own == 0) return;
   double *part = (Xref && partials) ? partials + (size_t)slot * T.nseg_all : nullptr;
   ProfScope ps(PK_PROX, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_proximal<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, Z, Df,
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_proximal<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, Z, Df,
                                         Tinv, N, V, Xout, part ? Xref : nullptr, part));
 }
 
@@ -1103,7 +1128,7 @@ void launch_extrapolate(int d, hipStream_t st, const SegTable &T, bool all_rows,
   const int nb = nseg(T, all_rows);
   if (nb == 0) return;
   ProfScope ps(PK_AXPBY, st, 3.0 * (all_rows ? T.rows_all : T.rows_own) * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_extrapolate<D>), dim3(nb), dim3(256), 0, st, T.segs, mask, gamma, a, b,
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_extrapolate<D>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, gamma, a, b,
                                         out));
 }
 
@@ -1112,7 +1137,7 @@ void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, const
   const int nb = nseg(T, all_rows);
   if (nb == 0) return;
   ProfScope ps(PK_AXPBY, st, (b ? 3.0 : 2.0) * (all_rows ? T.rows_all : T.rows_own) * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_axpby<D>), dim3(nb), dim3(256), 0, st, T.segs, mask, alpha, a, beta, b,
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_axpby<D>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, alpha, a, beta, b,
                                         out, part));
 }
 
@@ -1120,7 +1145,7 @@ void launch_axpby_node(int d, hipStream_t st, const SegTable &T, const int *mask
                        const double *a, const double *beta, const double *b, double *out) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_AXPBY, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_axpby_node<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, alpha,
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_axpby_node<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, alpha,
                                         a, beta, b, out));
 }
 
@@ -1129,7 +1154,7 @@ void launch_dot(int d, hipStream_t st, const SegTable &T, bool all_rows, const i
   const int nb = nseg(T, all_rows);
   if (nb == 0) return;
   ProfScope ps(PK_DOT, st, 2.0 * (all_rows ? T.rows_all : T.rows_own) * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_dot<D>), dim3(nb), dim3(256), 0, st, T.segs, mask, a, b, part,
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_dot<D>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, a, b, part,
                                         partials + (size_t)slot * T.nseg_all));
 }
 
@@ -1140,7 +1165,7 @@ void launch_dots(int d, hipStream_t st, const SegTable &T, const int *mask, int 
   P.n = n;
   for (int q = 0; q < 4; q++) { P.a[q] = a[q < n ? q : 0]; P.b[q] = b[q < n ? q : 0]; }
   ProfScope ps(PK_DOT, st, 2.0 * n * T.rows_own * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_dots<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, P, part,
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_dots<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, P, part,
                                         partials + (size_t)slot0 * T.nseg_all, T.nseg_all));
 }
 
@@ -1149,7 +1174,7 @@ void launch_tangent_full(int d, hipStream_t st, const SegTable &T, const int *ma
   if (T.nseg_own == 0) return;
   double *part = partials ? partials + (size_t)slot * T.nseg_all : nullptr;
   ProfScope ps(PK_ROTOP, st, 2.0 * T.rows_own * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_tangent_full<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, X,
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_tangent_full<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, X,
                                         V, out, part));
 }
 
@@ -1157,7 +1182,7 @@ void launch_hess_epilogue(int d, hipStream_t st, const SegTable &T, const int *m
                           const double *E, const double *nabla, const double *Rdot, double *out) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_ROTOP, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, 1, X, E,
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, 1, X, E,
                                         nabla, Rdot, out));
 }
 
@@ -1165,7 +1190,7 @@ void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, const int *mas
                         const double *in, double *out) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_ROTOP, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, 0, X, in,
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, 0, X, in,
                                         nullptr, nullptr, out));
 }
 
@@ -1173,7 +1198,7 @@ void launch_retract_rot(int d, hipStream_t st, const SegTable &T, const int *mas
                         const double *V, double *out) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_ROTOP, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, 2, X, V,
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, 2, X, V,
                                         nullptr, nullptr, out));
 }
 
@@ -1189,7 +1214,7 @@ void launch_bdiag_dot(int d, hipStream_t st, const SegTable &T, const int *mask,
                       double coef, const double *add, double addcoef, double *partials, int slot) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_BDIAG, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_bdiag_dot<D>), dim3(T.nseg_own), dim3(256), 0, st, T.segs, mask, Dd, x,
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_bdiag_dot<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, Dd, x,
                                         coef, add, addcoef, partials + (size_t)slot * T.nseg_all));
 }
 
