@@ -80,15 +80,22 @@ void SpdSolverDev::upload(int dcols) {
       if ((fwd ? wide_fwd(f) : wide_bwd(f)) == want_wide) cnt += ((fwd ? F.w[f] + F.u[f] : F.w[f]) + 63) / 64;
     return cnt;
   };
-  const int MERGE_BELOW = 1024;
+  const int MERGE_BELOW = 1024, FINE_BELOW = 512;
+  fwd_rows.clear();
+  bwd_rows.clear();
   for (const auto &lvl : F.by_height) {
     const bool merge = tiles(lvl, true, true) > 0 && tiles(lvl, true, false) < MERGE_BELOW;
+    // few wide tiles at this level: 16-row tiles put 4x more workgroups (CUs) on them
+    const int wide_tiles = tiles(lvl, true, true) + (merge ? tiles(lvl, true, false) : 0);
+    const int rows = (wide_tiles > 0 && wide_tiles < FINE_BELOW) ? 16 : 64;
+    fwd_rows.push_back(rows);
     for (int pass = 0; pass < 2; pass++) {
       if (pass == 1) fwd_big_ptr.push_back((int)fi.size());
+      const int th = pass == 1 ? rows : 64;
       for (int f : lvl) {
         if ((int)(wide_fwd(f) || merge) != pass) continue;
         const int m = F.w[f] + F.u[f];
-        for (int r = 0; r < m; r += 64) fi.push_back(make_int4(f, r, std::min(64, m - r), 0));
+        for (int r = 0; r < m; r += th) fi.push_back(make_int4(f, r, std::min(th, m - r), 0));
       }
     }
     fwd_level_ptr.push_back((int)fi.size());
@@ -96,11 +103,15 @@ void SpdSolverDev::upload(int dcols) {
   bwd_level_ptr.assign(1, 0);
   for (const auto &lvl : F.by_depth) {
     const bool merge = tiles(lvl, false, true) > 0 && tiles(lvl, false, false) < MERGE_BELOW;
+    const int wide_tiles = tiles(lvl, false, true) + (merge ? tiles(lvl, false, false) : 0);
+    const int rows = (wide_tiles > 0 && wide_tiles < FINE_BELOW) ? 16 : 64;
+    bwd_rows.push_back(rows);
     for (int pass = 0; pass < 2; pass++) {
       if (pass == 1) bwd_big_ptr.push_back((int)bi.size());
+      const int th = pass == 1 ? rows : 64;
       for (int f : lvl) {
         if ((int)(wide_bwd(f) || merge) != pass) continue;
-        for (int c = 0; c < F.w[f]; c += 64) bi.push_back(make_int4(f, c, std::min(64, F.w[f] - c), 0));
+        for (int c = 0; c < F.w[f]; c += th) bi.push_back(make_int4(f, c, std::min(th, F.w[f] - c), 0));
       }
     }
     bwd_level_ptr.push_back((int)bi.size());
@@ -490,14 +501,16 @@ static void spd_run(int d, hipStream_t st, SpdSolverDev &S, double *vec, double 
     const int a = S.fwd_level_ptr[l], mid = S.fwd_big_ptr[l], b = S.fwd_level_ptr[l + 1];
     const double bytes = S.fwd_level_bytes[l], tot = std::max(b - a, 1);
     launch_spd_level(d, S.dof, st, S.dev, true, a, mid - a, vec, S.ytmp.p, scale, bytes * (mid - a) / tot, 1);
-    launch_spd_level(d, S.dof, st, S.dev, true, mid, b - mid, vec, S.ytmp.p, scale, bytes * (b - mid) / tot, 8);
+    launch_spd_level(d, S.dof, st, S.dev, true, mid, b - mid, vec, S.ytmp.p, scale, bytes * (b - mid) / tot,
+                     S.fwd_rows[l] == 16 ? -8 : 8);
   }
   const int nb = (int)S.bwd_level_ptr.size() - 1;
   for (int l = 0; l < nb; l++) {
     const int a = S.bwd_level_ptr[l], mid = S.bwd_big_ptr[l], b = S.bwd_level_ptr[l + 1];
     const double bytes = S.bwd_level_bytes[l], tot = std::max(b - a, 1);
     launch_spd_level(d, S.dof, st, S.dev, false, a, mid - a, vec, S.ytmp.p, scale, bytes * (mid - a) / tot, 1);
-    launch_spd_level(d, S.dof, st, S.dev, false, mid, b - mid, vec, S.ytmp.p, scale, bytes * (b - mid) / tot, 8);
+    launch_spd_level(d, S.dof, st, S.dev, false, mid, b - mid, vec, S.ytmp.p, scale, bytes * (b - mid) / tot,
+                     S.bwd_rows[l] == 16 ? -8 : 8);
   }
 }
 

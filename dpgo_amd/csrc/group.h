@@ -90,6 +90,7 @@ struct SpdSolverDev {
   DevBuf<int4> fwd_items, bwd_items;
   std::vector<int> fwd_level_ptr, bwd_level_ptr;  // item ranges per level
   std::vector<int> fwd_big_ptr, bwd_big_ptr;      // first wide-front item of each level
+  std::vector<int> fwd_rows, bwd_rows;            // tile height of the wide class per level (64 or 16)
   std::vector<double> fwd_level_bytes, bwd_level_bytes;
   SpdDev dev;
   int dof = 1;

@@ -825,19 +825,25 @@ __device__ __forceinline__ size_t vaddr(int i) {
 }
 
 
-// NW waves share one 64-row tile and split the front's columns (forward) / rows (backward) between
-// them chunk by chunk, then combine through LDS in a fixed order.  NW = 1 for the many small fronts
-// at the bottom of the tree, NW = 8 for the wide separator fronts at the top, where a single wave
-// per tile cannot keep enough loads in flight to use the HBM bandwidth.
-template <int D, int DOF, int NW, int SPD_CH>
+// NW waves share one tile of ROWS rows and split the front's columns (forward) / rows (backward)
+// between them chunk by chunk, then combine through LDS in a fixed order.
+//   NW = 1, ROWS = 64: the many small fronts at the bottom of the tree.
+//   NW = 8, ROWS = 64: wide separator fronts; a single wave per tile cannot keep enough loads in flight.
+//   NW = 8, ROWS = 16: the same for levels with only a few wide fronts (the top of the tree, or a GPU
+//       that holds a single node): 16-row tiles give 4x more workgroups, i.e. 4x more CUs pulling on the
+//       one big front; inside a wave the 64 lanes are 16 rows x 4 interleaved columns, combined by two
+//       xor-shuffles.  Rows are padded to 128 B, so a 16-row tile still reads whole cache lines.
+template <int D, int DOF, int NW, int SPD_CH, int ROWS>
 __global__ __launch_bounds__(64 * NW) void k_spd_fwd(SpdDev S, int item0, const double *vec, double *ytmp) {
+  constexpr int KQ = 64 / ROWS;
   __shared__ double f[NW][SPD_CH * D];
-  __shared__ double red[NW > 1 ? NW : 1][64 * D];
+  __shared__ double red[NW > 1 ? NW : 1][ROWS * D];
   const int4 it = S.fwd_items[item0 + blockIdx.x];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int s = it.x, p = it.y + lane;
-  const bool valid = lane < it.z;
-  const int w = S.w[s], m = w + S.u[s];
+  const int r = lane % ROWS, kq = lane / ROWS;
+  const int s = it.x, p = it.y + r;
+  const bool valid = r < it.z;
+  const int w = S.w[s];
   const double *WT = S.WT + S.wt_off[s];
   const int ldm = S.ldm[s];
   const int *piv = S.piv_idx + S.piv_ptr[s];
@@ -848,7 +854,7 @@ __global__ __launch_bounds__(64 * NW) void k_spd_fwd(SpdDev S, int item0, const 
   double *fw = f[wv];
   // the pivot block of W_s is L11^-1, lower triangular: rows of a tile that lies inside it only need
   // the columns up to the tile's last row
-  const int kend = (it.y + 64 <= w) ? it.y + 64 : w;
+  const int kend = (it.y + ROWS <= w) ? it.y + ROWS : w;
   for (int k0 = wv * SPD_CH; k0 < kend; k0 += NW * SPD_CH) {
     const int kn = min(SPD_CH, kend - k0);
     for (int kk = lane; kk < kn; kk += 64) {
@@ -870,17 +876,17 @@ __global__ __launch_bounds__(64 * NW) void k_spd_fwd(SpdDev S, int item0, const 
     if (valid) {
       // batches of 16 independent loads in flight per lane before the first use
       const double *wp = WT + (size_t)k0 * ldm + p;
-      int kk = 0;
-      for (; kk + 16 <= kn; kk += 16) {
+      int kk = kq;
+      for (; kk + 15 * KQ < kn; kk += 16 * KQ) {
         double wv16[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) wv16[q] = wp[(size_t)(kk + q) * ldm];
+        for (int q = 0; q < 16; q++) wv16[q] = wp[(size_t)(kk + q * KQ) * ldm];
 #pragma unroll
         for (int q = 0; q < 16; q++)
 #pragma unroll
-          for (int c = 0; c < D; c++) acc[c] = fma(wv16[q], fw[(kk + q) * D + c], acc[c]);
+          for (int c = 0; c < D; c++) acc[c] = fma(wv16[q], fw[(kk + q * KQ) * D + c], acc[c]);
       }
-      for (; kk < kn; kk++) {
+      for (; kk < kn; kk += KQ) {
         const double wval = wp[(size_t)kk * ldm];
 #pragma unroll
         for (int c = 0; c < D; c++) acc[c] = fma(wval, fw[kk * D + c], acc[c]);
@@ -888,19 +894,29 @@ __global__ __launch_bounds__(64 * NW) void k_spd_fwd(SpdDev S, int item0, const 
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if constexpr (NW > 1) {
+  if constexpr (KQ > 1) {
 #pragma unroll
-    for (int c = 0; c < D; c++) red[wv][lane * D + c] = acc[c];
+    for (int c = 0; c < D; c++)
+#pragma unroll
+      for (int o = ROWS; o < 64; o <<= 1) acc[c] += __shfl_xor(acc[c], o, 64);
+  }
+  if constexpr (NW > 1) {
+    if (kq == 0) {
+#pragma unroll
+      for (int c = 0; c < D; c++) red[wv][r * D + c] = acc[c];
+    }
     __syncthreads();
     if (wv != 0) return;
+    if (kq == 0) {
 #pragma unroll
-    for (int c = 0; c < D; c++) {
-      double a = red[0][lane * D + c];
-      for (int q = 1; q < NW; q++) a += red[q][lane * D + c];
-      acc[c] = a;
+      for (int c = 0; c < D; c++) {
+        double a = red[0][r * D + c];
+        for (int q = 1; q < NW; q++) a += red[q][r * D + c];
+        acc[c] = a;
+      }
     }
   }
-  if (!valid) return;
+  if (!valid || kq != 0) return;
   if (p < w) {
     double *dst = ytmp + (size_t)piv[p] * D;
 #pragma unroll
@@ -917,15 +933,17 @@ __global__ __launch_bounds__(64 * NW) void k_spd_fwd(SpdDev S, int item0, const 
   }
 }
 
-template <int D, int DOF, int NW, int SPD_CH>
+template <int D, int DOF, int NW, int SPD_CH, int ROWS>
 __global__ __launch_bounds__(64 * NW) void k_spd_bwd(SpdDev S, int item0, double scale, const double *ytmp,
                                                      double *vec) {
+  constexpr int KQ = 64 / ROWS;
   __shared__ double f[NW][SPD_CH * D];
-  __shared__ double red[NW > 1 ? NW : 1][64 * D];
+  __shared__ double red[NW > 1 ? NW : 1][ROWS * D];
   const int4 it = S.bwd_items[item0 + blockIdx.x];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int s = it.x, k = it.y + lane;
-  const bool valid = lane < it.z;
+  const int r = lane % ROWS, kq = lane / ROWS;
+  const int s = it.x, k = it.y + r;
+  const bool valid = r < it.z;
   const int w = S.w[s], m = w + S.u[s];
   const double *W = S.W + S.w_off[s];
   const int ldw = S.ldw[s];
@@ -950,17 +968,17 @@ __global__ __launch_bounds__(64 * NW) void k_spd_bwd(SpdDev S, int item0, double
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (valid) {
       const double *wp = W + (size_t)p0 * ldw + k;
-      int pp = 0;
-      for (; pp + 16 <= pn; pp += 16) {
+      int pp = kq;
+      for (; pp + 15 * KQ < pn; pp += 16 * KQ) {
         double wv16[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) wv16[q] = wp[(size_t)(pp + q) * ldw];
+        for (int q = 0; q < 16; q++) wv16[q] = wp[(size_t)(pp + q * KQ) * ldw];
 #pragma unroll
         for (int q = 0; q < 16; q++)
 #pragma unroll
-          for (int c = 0; c < D; c++) acc[c] = fma(wv16[q], fw[(pp + q) * D + c], acc[c]);
+          for (int c = 0; c < D; c++) acc[c] = fma(wv16[q], fw[(pp + q * KQ) * D + c], acc[c]);
       }
-      for (; pp < pn; pp++) {
+      for (; pp < pn; pp += KQ) {
         const double wval = wp[(size_t)pp * ldw];
 #pragma unroll
         for (int c = 0; c < D; c++) acc[c] = fma(wval, fw[pp * D + c], acc[c]);
@@ -968,19 +986,29 @@ __global__ __launch_bounds__(64 * NW) void k_spd_bwd(SpdDev S, int item0, double
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if constexpr (NW > 1) {
+  if constexpr (KQ > 1) {
 #pragma unroll
-    for (int c = 0; c < D; c++) red[wv][lane * D + c] = acc[c];
+    for (int c = 0; c < D; c++)
+#pragma unroll
+      for (int o = ROWS; o < 64; o <<= 1) acc[c] += __shfl_xor(acc[c], o, 64);
+  }
+  if constexpr (NW > 1) {
+    if (kq == 0) {
+#pragma unroll
+      for (int c = 0; c < D; c++) red[wv][r * D + c] = acc[c];
+    }
     __syncthreads();
     if (wv != 0) return;
+    if (kq == 0) {
 #pragma unroll
-    for (int c = 0; c < D; c++) {
-      double a = red[0][lane * D + c];
-      for (int q = 1; q < NW; q++) a += red[q][lane * D + c];
-      acc[c] = a;
+      for (int c = 0; c < D; c++) {
+        double a = red[0][r * D + c];
+        for (int q = 1; q < NW; q++) a += red[q][r * D + c];
+        acc[c] = a;
+      }
     }
   }
-  if (!valid) return;
+  if (!valid || kq != 0) return;
   double *dst = vec + vaddr<D, DOF>(piv[k]);
 #pragma unroll
   for (int c = 0; c < D; c++) dst[c] = scale * acc[c];
@@ -1226,22 +1254,22 @@ void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows,
 
 void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int item0, int nitems,
                       double *vec, double *ytmp, double scale, double level_bytes, int nwaves) {
+  // nwaves: 1 = narrow fronts (one wave per 64-row tile), 8 = wide fronts (8 waves per 64-row tile),
+  //         -8 = wide fronts of a sparsely populated level (8 waves per 16-row tile)
   if (nitems == 0) return;
   ProfScope ps(forward ? PK_SPD_FWD : PK_SPD_BWD, st, level_bytes);
-  static const int narrow_split = getenv("DPGO_SPD_NARROW") ? atoi(getenv("DPGO_SPD_NARROW")) : 0;
-  static const int wide_nw = getenv("DPGO_SPD_WIDE_NW") ? atoi(getenv("DPGO_SPD_WIDE_NW")) : 8;
-#define SPD_LAUNCH(DOFV, NWV, CHV)                                                                             \
+#define SPD_LAUNCH(DOFV, NWV, ROWSV)                                                                           \
   do {                                                                                                         \
     if (forward)                                                                                               \
-      hipLaunchKernelGGL((k_spd_fwd<D, DOFV, NWV, CHV>), dim3(nitems), dim3(64 * NWV), 0, st, S, item0, vec, ytmp); \
+      hipLaunchKernelGGL((k_spd_fwd<D, DOFV, NWV, 128, ROWSV>), dim3(nitems), dim3(64 * NWV), 0, st, S, item0, vec, ytmp); \
     else                                                                                                       \
-      hipLaunchKernelGGL((k_spd_bwd<D, DOFV, NWV, CHV>), dim3(nitems), dim3(64 * NWV), 0, st, S, item0, scale, ytmp, vec); \
+      hipLaunchKernelGGL((k_spd_bwd<D, DOFV, NWV, 128, ROWSV>), dim3(nitems), dim3(64 * NWV), 0, st, S, item0, scale, ytmp, vec); \
   } while (0)
-#define SPD_PICK(DOFV)                                                                  \
-  do {                                                                                  \
-    if (nwaves == 1) { if (narrow_split) SPD_LAUNCH(DOFV, 8, 16); else SPD_LAUNCH(DOFV, 1, 128); } \
-    else if (wide_nw == 16) SPD_LAUNCH(DOFV, 16, 128);                                   \
-    else SPD_LAUNCH(DOFV, 8, 128);                                                      \
+#define SPD_PICK(DOFV)                            \
+  do {                                            \
+    if (nwaves == 1) SPD_LAUNCH(DOFV, 1, 64);     \
+    else if (nwaves == -8) SPD_LAUNCH(DOFV, 8, 16); \
+    else SPD_LAUNCH(DOFV, 8, 64);                 \
   } while (0)
   DPGO_DISPATCH_D(d, {
     if (dof == 1) SPD_PICK(1);
