@@ -98,6 +98,9 @@ SYMBOLS = {
     "dpgo_group_update": (C.c_int, [C.c_void_p, _IP, C.c_int]),
     "dpgo_group_iterate": (C.c_int, [C.c_void_p, _IP, C.c_int]),
     "dpgo_group_communicate_local": (C.c_int, [C.c_void_p]),
+    "dpgo_group_message_sizes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _IP, _IP]),
+    "dpgo_group_send": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _DP, C.c_int]),
+    "dpgo_group_receive": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _DP, C.c_int]),
     "dpgo_group_star_initialize": (C.c_int, [C.c_void_p, _DP, C.c_int]),
     "dpgo_group_star_update": (C.c_int, [C.c_void_p]),
     "dpgo_group_star_iterate": (C.c_int, [C.c_void_p]),
@@ -407,6 +410,23 @@ class DPGOHash:
 
     def results(self):
         return self.group.results(self.local)
+
+    def message_for(self, beta):
+        """The message this node owes node beta: ((d+1) |sent[beta]|) x d, [t rows ; R rows]."""
+        ns = C.c_int()
+        if lib().dpgo_group_message_sizes(self.group._h, self.local, int(beta), C.byref(ns), None) != 0 or ns.value == 0:
+            return None
+        M = np.zeros(((self.d + 1) * ns.value, self.d), order="F")
+        lib().dpgo_group_send(self.group._h, self.local, int(beta), _dp(M), M.shape[0])
+        return M
+
+    def receive(self, msg):
+        """DPGOHash::receive(const std::map<int, Matrix>&)."""
+        rc = 0
+        for beta, M in msg.items():
+            M, ld = _fcol(M)
+            rc |= lib().dpgo_group_receive(self.group._h, self.local, int(beta), _dp(M), ld)
+        return rc
 
     def Xk(self):
         X = np.zeros(((self.d + 1) * (self.n[0] + self.n[1]), self.d), order="F")

@@ -227,6 +227,15 @@ int dpgo_group_star_state(const dpgo_group_t *h, double *F, double *fobj, double
   if (branches) *branches = h->grp->star_branches();
   return 0;
 }
+int dpgo_group_receive(dpgo_group_t *h, int local, int beta, const double *msg, int ld) { return h->grp->receive(local, beta, msg, ld); }
+int dpgo_group_send(const dpgo_group_t *h, int local, int beta, double *msg, int ld) { return h->grp->send(local, beta, msg, ld); }
+int dpgo_group_message_sizes(const dpgo_group_t *h, int local, int beta, int *num_send, int *num_recv) {
+  const int s = h->grp->num_send(local, beta), r = h->grp->num_recv(local, beta);
+  if (s < 0 || r < 0) return -1;
+  if (num_send) *num_send = s;
+  if (num_recv) *num_recv = r;
+  return 0;
+}
 int dpgo_group_num_sent(const dpgo_group_t *h) { return h->grp->num_sent(); }
 int dpgo_group_sent_keys(const dpgo_group_t *h, int *nodes, int *poses) {
   const auto &k = h->grp->sent_keys();

@@ -649,6 +649,60 @@ int Group::communicate_local() {
   return 0;
 }
 
+int Group::num_recv(int a, int beta) const {
+  if (a < 0 || a >= num_local()) return -1;
+  auto it = info_[a].recv.find(beta);
+  return it == info_[a].recv.end() ? 0 : (int)it->second.size();
+}
+int Group::num_send(int a, int beta) const {
+  if (a < 0 || a >= num_local()) return -1;
+  auto it = info_[a].sent.find(beta);
+  return it == info_[a].sent.end() ? 0 : (int)it->second.size();
+}
+
+int Group::receive(int a, int beta, const double *msg, int ld) {
+  if (a < 0 || a >= num_local()) return -1;
+  auto it = info_[a].recv.find(beta);
+  if (it == info_[a].recv.end()) {
+    fprintf(stderr, "[dpgo_amd] ERROR: Can not find information for node %d\n", beta);   // DPGOHash.cpp:77
+    return -1;
+  }
+  const int np = (int)it->second.size();
+  if (ld < (d_ + 1) * np) return -1;
+  sync();
+  // the poses of one neighbour occupy consecutive neighbour rows (ordering of generate_data_info)
+  std::vector<double> rec((size_t)np * RS_);
+  for (int k = 0; k < np; k++)
+    for (int c = 0; c < d_; c++) {
+      rec[(size_t)k * RS_ + c] = msg[(size_t)c * ld + k];
+      for (int r = 0; r < d_; r++) rec[(size_t)k * RS_ + d_ + r * d_ + c] = msg[(size_t)c * ld + np + k * d_ + r];
+    }
+  const int first = it->second.front().second;
+  HIP_CHECK(hipMemcpy(Xk_.p + (size_t)(P0_ + nbr_off_[a] + first) * RS_, rec.data(), sizeof(double) * rec.size(),
+                      hipMemcpyHostToDevice));
+  res_[a].updated = 0;
+  return 0;
+}
+
+int Group::send(int a, int beta, double *msg, int ld) const {
+  if (a < 0 || a >= num_local()) return -1;
+  auto it = info_[a].sent.find(beta);
+  if (it == info_[a].sent.end()) return -1;
+  const int np = (int)it->second.size();
+  if (ld < (d_ + 1) * np) return -1;
+  sync();
+  std::vector<double> own((size_t)info_[a].n[0] * RS_);
+  HIP_CHECK(hipMemcpy(own.data(), Xk_.p + (size_t)own_off_[a] * RS_, sizeof(double) * own.size(), hipMemcpyDeviceToHost));
+  for (int k = 0; k < np; k++) {
+    const double *rec = &own[(size_t)it->second[k] * RS_];
+    for (int c = 0; c < d_; c++) {
+      msg[(size_t)c * ld + k] = rec[c];
+      for (int r = 0; r < d_; r++) msg[(size_t)c * ld + np + k * d_ + r] = rec[d_ + r * d_ + c];
+    }
+  }
+  return 0;
+}
+
 int Group::pack_sent(double *dev_buf) {
   launch_copy_indexed(d_, st_, (int)sent_rows_.size(), nullptr, sent_rows_dev_.p, Xk_.p, dev_buf);
   return 0;

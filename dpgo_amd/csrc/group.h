@@ -117,6 +117,13 @@ class Group {
   int update(const std::vector<int> &locals);
   int iterate(const std::vector<int> &locals);
   int communicate_local();
+  // DPGOHash::receive (DPGOHash.cpp:45-82): msg for neighbour node beta is ((d+1) |recv[beta]|) x d,
+  // [t rows ; R rows], poses in the order of recv[beta]; send() builds the message node `local` owes beta
+  // from its current Xk (the poses of sent[beta], DPGO_utils.cpp:428-435)
+  int receive(int local, int beta, const double *msg, int ld);
+  int send(int local, int beta, double *msg, int ld) const;
+  int num_recv(int local, int beta) const;
+  int num_send(int local, int beta) const;
 
   // ---- AMM-PGO* (DPGOStar, C++/DPGO/src/DPGOStar.cpp:107-711); every node of the graph must be local
   int star_initialize_global(const double *X, int ld);   // DPGOStar::initialize (:107-124)

@@ -119,6 +119,13 @@ int dpgo_group_update(dpgo_group_t *grp, const int *locals, int n);
 int dpgo_group_iterate(dpgo_group_t *grp, const int *locals, int n);
 /* DPGOHash::communicate -- C++/DPGO/include/DPGO/DPGOHash.h:28-86 -- for neighbours hosted by this group. */
 int dpgo_group_communicate_local(dpgo_group_t *grp);
+/* DPGOHash::receive -- C++/DPGO/src/DPGOHash.cpp:45-82: one message per neighbour node beta, a
+ * ((d+1) |recv[beta]|) x d matrix [translation rows ; rotation rows] with the poses in the order of
+ * recv[beta].  dpgo_group_send builds the message node `local` owes node beta (the poses of sent[beta],
+ * C++/DPGO/src/DPGO_utils.cpp:428-435) from its current Xk.  Host matrices, column-major. */
+int dpgo_group_message_sizes(const dpgo_group_t *grp, int local, int beta, int *num_send, int *num_recv);
+int dpgo_group_send(const dpgo_group_t *grp, int local, int beta, double *msg, int ld);
+int dpgo_group_receive(dpgo_group_t *grp, int local, int beta, const double *msg, int ld);
 /* AMM-PGO* -- DPGOStar::{initialize, update, iterate} (C++/DPGO/src/DPGOStar.cpp:107-213; per-node
  * helpers :215-711); communicate() is dpgo_group_communicate_local.  Every node of the graph must be in
  * the group (the master's global objective is the sum of the per-node device reductions).  Loop:

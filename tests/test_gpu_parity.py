@@ -370,3 +370,31 @@ def test_amm_pgo_star_matches_oracle(fixtures_dir, name, nn, loss, iters):
     np.testing.assert_allclose(gpu.X(), orc.Xk, atol=1e-6)
     # iterate() without update() is an error
     assert gpu.iterate() == -1
+
+
+def test_receive_messages_equal_communicate(fixtures_dir):
+    """DPGOHash::receive with per-neighbour messages (DPGOHash.cpp:45-82) fills the same neighbour rows as
+    communicate() (DPGOHash.h:28-86)."""
+    path = os.path.join(fixtures_dir, "torus3D.g2o")
+    num_poses, mm = og.read_g2o_file(path)
+    X0 = chordal_initialization(num_poses, mm)
+    G = dpgo_amd.read_g2o(path, 4)
+    opt = dpgo_amd.Options.driver(LOSS_NONE, True)
+    a = dpgo_amd.DistPGO(G, opt, X0=X0)
+    b = dpgo_amd.DistPGO(G, opt, X0=X0)
+    for it in range(3):
+        assert a.step() == 0
+        assert b.group.iterate() == 0
+        msgs = {k: {} for k in range(4)}
+        for k in range(4):
+            for beta in range(4):
+                M = b.group[k].message_for(beta)
+                if M is not None:
+                    msgs[beta][k] = M
+        for k in range(4):
+            assert b.group[k].receive(msgs[k]) == 0
+        assert b.group.update() == 0
+        for k in range(4):
+            np.testing.assert_array_equal(a.group[k].Xk(), b.group[k].Xk())
+            assert a.group.results(k).fobj == b.group.results(k).fobj
+    assert b.group[0].receive({0: np.zeros((4, 3))}) == -1      # not a neighbour -> error, as LOG(ERROR) at :77
