@@ -156,7 +156,6 @@ class Group {
   const std::vector<std::pair<int, int>> &sent_keys() const { return sent_keys_; }
 
  private:
-  friend struct Tnt;
   bool ok_ = false;
   int d_ = 0, RS_ = 0, B_ = 0, device_ = 0;
   Options opt_;
@@ -203,7 +202,6 @@ class Group {
   InterEdgesDev Ei_;              // intra-node edges in residual form (objective evaluation only)
   SpdSolverDev Ltt_, Lrr_;
   // halo
-  DevBuf<int> local_src_;          // per neighbour row: unified own row on this device, or -1
   DevBuf<int> gather_dst_, gather_src_;   // local halo copy lists
   std::vector<int> sent_rows_;     // unified own rows exported to other groups
   std::vector<std::pair<int, int>> sent_keys_;   // (node, pose) of each exported row

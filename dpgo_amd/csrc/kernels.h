@@ -91,9 +91,6 @@ void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, const
 // out = alpha[node] * a + beta[node] * b over own rows (per-node coefficients on the device)
 void launch_axpby_node(int d, hipStream_t st, const SegTable &T, const int *mask, const double *alpha,
                        const double *a, const double *beta, const double *b, double *out);
-// partial[slot] = sum <a_p, b_p> over the selected part
-void launch_dot(int d, hipStream_t st, const SegTable &T, bool all_rows, const int *mask, const double *a,
-                const double *b, int part, double *partials, int slot);
 // n <= 4 dot products in one pass over own rows: partial[slot0 + q] = sum <a_q, b_q> (always writes 4 slots)
 void launch_dots(int d, hipStream_t st, const SegTable &T, const int *mask, int n, const double *const *a,
                  const double *const *b, int part, double *partials, int slot0);

@@ -634,27 +634,6 @@ __global__ __launch_bounds__(SEG_ROWS) void k_axpby_node(const Seg *segs, const 
   store_vec<RS>(out + (size_t)row * RS, va);
 }
 
-template <int D>
-__global__ __launch_bounds__(SEG_ROWS) void k_dot(const Seg *segs, const int *mask, const double *a, const double *b,
-                                             int part, double *partial) {
-  constexpr int RS = Dim<D>::RS;
-  const Seg s = segs[blockIdx.x];
-  const bool active = (mask == nullptr) || (mask[s.node] != 0);
-  double pr[1] = {0.0};
-  const int row = s.begin + threadIdx.x;
-  if (active && row < s.end) {
-    double va[RS], vb[RS];
-    load_vec<RS>(a + (size_t)row * RS, va);
-    load_vec<RS>(b + (size_t)row * RS, vb);
-    const int k0 = part == 2 ? D : 0, k1 = part == 1 ? D : RS;
-    double p = 0;
-#pragma unroll
-    for (int k = 0; k < RS; k++) p = (k >= k0 && k < k1) ? fma(va[k], vb[k], p) : p;
-    pr[0] = p;
-  }
-  block_store<1>(pr, partial + blockIdx.x, 0);
-}
-
 // up to 4 dot products over the rotation part in one pass (TNT / CG scalars)
 struct DotPairs {
   const double *a[4];
@@ -1175,15 +1154,6 @@ void launch_axpby_node(int d, hipStream_t st, const SegTable &T, const int *mask
   ProfScope ps(PK_AXPBY, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_axpby_node<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, alpha,
                                         a, beta, b, out));
-}
-
-void launch_dot(int d, hipStream_t st, const SegTable &T, bool all_rows, const int *mask, const double *a,
-                const double *b, int part, double *partials, int slot) {
-  const int nb = nseg(T, all_rows);
-  if (nb == 0) return;
-  ProfScope ps(PK_DOT, st, 2.0 * (all_rows ? T.rows_all : T.rows_own) * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_dot<D>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, a, b, part,
-                                        partials + (size_t)slot * T.nseg_all));
 }
 
 void launch_dots(int d, hipStream_t st, const SegTable &T, const int *mask, int n, const double *const *a,
