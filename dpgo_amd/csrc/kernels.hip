@@ -599,20 +599,27 @@ __global__ __launch_bounds__(SEG_ROWS) void k_extrapolate(const Seg *segs, const
   store_vec<RS>(out + (size_t)row * RS, va);
 }
 
-template <int D>
+// out = alpha a + beta b on the whole record (PART 0), the translation row (1) or the rotation rows (2);
+// whole 16-byte loads and stores, the untouched part of `out` is carried through registers
+template <int D, int PART>
 __global__ __launch_bounds__(SEG_ROWS) void k_axpby(const Seg *segs, const int *mask, double alpha, const double *a,
-                                               double beta, const double *b, double *out, int part) {
+                                                    double beta, const double *b, double *out) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[blockIdx.x];
   if (mask && !mask[s.node]) return;
   const int row = s.begin + threadIdx.x;
   if (row >= s.end) return;
-  const int k0 = part == 2 ? D : 0, k1 = part == 1 ? D : RS;
-  for (int k = k0; k < k1; k++) {
-    double v = alpha * a[(size_t)row * RS + k];
-    if (b) v = fma(beta, b[(size_t)row * RS + k], v);
-    out[(size_t)row * RS + k] = v;
+  double va[RS], vb[RS], vo[RS];
+  load_vec<RS>(a + (size_t)row * RS, va);
+  if (b) load_vec<RS>(b + (size_t)row * RS, vb);
+  if (PART != 0) load_vec<RS>(out + (size_t)row * RS, vo);
+#pragma unroll
+  for (int k = 0; k < RS; k++) {
+    const bool in = PART == 0 || (PART == 1 ? k < D : k >= D);
+    const double v = b ? fma(beta, vb[k], alpha * va[k]) : alpha * va[k];
+    va[k] = in ? v : vo[k];
   }
+  store_vec<RS>(out + (size_t)row * RS, va);
 }
 
 // out = alpha[node] * a + beta[node] * b  (per-node coefficients: batched CG updates)
@@ -1144,8 +1151,11 @@ void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, const
   const int nb = nseg(T, all_rows);
   if (nb == 0) return;
   ProfScope ps(PK_AXPBY, st, (b ? 3.0 : 2.0) * (all_rows ? T.rows_all : T.rows_own) * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_axpby<D>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, alpha, a, beta, b,
-                                        out, part));
+  DPGO_DISPATCH_D(d, {
+    if (part == 0) hipLaunchKernelGGL((k_axpby<D, 0>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, alpha, a, beta, b, out);
+    else if (part == 1) hipLaunchKernelGGL((k_axpby<D, 1>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, alpha, a, beta, b, out);
+    else hipLaunchKernelGGL((k_axpby<D, 2>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, alpha, a, beta, b, out);
+  });
 }
 
 void launch_axpby_node(int d, hipStream_t st, const SegTable &T, const int *mask, const double *alpha,

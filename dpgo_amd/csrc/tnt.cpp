@@ -81,24 +81,37 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g) {
     solve_rr(w1, 1.0);
     launch_tangent_rot(d_, st_, T_, cur_mask_, Y, w1, out);
   };
-  auto norms = [&](const std::vector<int> &set) {   // gnorm, pgnorm of the nodes in `set` (mask == set)
-    dots({{grad, grad}});
-    for (int a : set) S[a].gnorm = S[a].pgnorm = std::sqrt(scal(a, 0));
+  // gnorm, pgnorm (and rv0 = <grad, P grad>, the first CG scalar) of the nodes in `set` (mask == set);
+  // with_f also evaluates f(X) in the same read-back
+  std::vector<double> rv0(L, 0.0);
+  auto norms = [&](const std::vector<int> &set, bool with_f) {
+    if (with_f) eval_G(X, g, 5);   // k_dots stores 4 slots per launch (0..3, then 1..4): f goes behind them
+    {
+      const double *pa[4] = {grad, grad, grad, grad}, *pb[4] = {grad, grad, grad, grad};
+      launch_dots(d_, st_, T_, cur_mask_, 1, pa, pb, 2, partials_.p, 0);
+    }
     if (use_precon) {
       precon(X, grad, pg);
-      dots({{pg, pg}});
-      for (int a : set) S[a].pgnorm = std::sqrt(scal(a, 0));
+      const double *pa[4] = {pg, grad, pg, pg}, *pb[4] = {pg, pg, pg, pg};
+      launch_dots(d_, st_, T_, cur_mask_, 2, pa, pb, 2, partials_.p, 1);
+    }
+    fetch(with_f ? 6 : 3, false);
+    for (int a : set) {
+      S[a].gnorm = S[a].pgnorm = std::sqrt(scal(a, 0));
+      rv0[a] = scal(a, 0);
+      if (use_precon) {
+        S[a].pgnorm = std::sqrt(scal(a, 1));
+        rv0[a] = scal(a, 2);
+      }
+      if (with_f) S[a].fx = scal(a, 5) + res_[a].f;
     }
   };
 
   const double sqrt_eps = std::sqrt(std::numeric_limits<double>::epsilon());
   const double eta1 = .05, eta2 = .9, alpha1 = .25, alpha2 = 2.5, Delta_tol = 1e-6;   // TNT.h:83-97,129
   set_mask(nodes);
-  eval_G(X, g, 0);
-  fetch(1, false);
-  for (int a : nodes) S[a].fx = scal(a, 0) + res_[a].f;
   quad_model(X);
-  norms(nodes);
+  norms(nodes, true);
 
   std::vector<double> c1(L, 0.0), c2(L, 0.0), ones(L, 1.0), mones(L, -1.0), zeros(L, 0.0);
   for (;;) {
@@ -121,13 +134,12 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g) {
     // v_0 = P(r_0) = P(grad): already computed for the preconditioned gradient norm (pg)
     copy_rows(vk, use_precon ? pg : rk, false, 0);
     launch_axpby(d_, st_, T_, false, cur_mask_, -1.0, vk, 0.0, nullptr, pk, 0);
-    dots({{rk, vk}});
     for (int a : A) {
       NodeTnt &s = S[a];
       s.cg = true;
       s.cg_it = 0;
       s.sk_M_pk = s.sk_M_2 = 0;
-      s.rv = s.pk_M_2 = scal(a, 0);
+      s.rv = s.pk_M_2 = rv0[a];   // <r_0, v_0> = <grad, P grad>, read back together with the norms
       s.Delta_2 = s.Delta * s.Delta;
       const double r0 = std::sqrt(s.rv);
       s.target = r0 * std::min(o.STPCG_kappa, std::pow(r0, o.STPCG_theta));
@@ -248,7 +260,7 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g) {
     if (!requad.empty()) {
       set_mask(requad);
       quad_model(X);
-      norms(requad);
+      norms(requad, false);
     }
   }
   for (int a : nodes) {
