@@ -116,13 +116,73 @@ void SpdSolverDev::upload(int dcols) {
     }
     bwd_level_ptr.push_back((int)bi.size());
   }
-  fwd_items.upload(fi);
-  bwd_items.upload(bi);
+  // ---- dataflow work list: the same tiles, grouped into workgroup-sized packs in dependency order
+  const int nf = F.nfronts;
+  std::vector<int> ntf(nf, 0), ntb(nf, 0), nchild_tiles(nf, 0);
+  for (const int4 &it : fi) ntf[it.x]++;
+  for (const int4 &it : bi) ntb[it.x]++;
+  for (int f = 0; f < nf; f++)
+    if (F.parent[f] >= 0) nchild_tiles[F.parent[f]] += ntf[f];
+  // counters: [0, nf) forward tiles of the children, [nf, 2nf) own backward tiles, [2nf, 3nf) own forward tiles (roots)
+  auto make_item = [&](const int4 &t, bool fwd) {
+    const int f = t.x, par = F.parent[f];
+    SpdItem it;
+    it.front = f; it.first = t.y; it.count = t.z; it.w = F.w[f];
+    it.u = F.u[f]; it.ld = fwd ? F.ldm[f] : F.ldw[f]; it.piv_ptr = F.piv_ptr[f]; it.upd_ptr = F.upd_ptr[f];
+    it.pos_off = F.pos_off[f]; it.ubuf_off = F.ubuf_off[f];
+    it.mat_off = fwd ? F.wt_off[f] : F.w_off[f];
+    it.pad = 0;
+    if (fwd) {
+      it.wait_ctr = f; it.wait_cnt = nchild_tiles[f];
+      it.sig_ctr = par >= 0 ? par : 2 * nf + f;
+    } else {
+      it.wait_ctr = par >= 0 ? nf + par : 2 * nf + f;
+      it.wait_cnt = par >= 0 ? ntb[par] : ntf[f];
+      it.sig_ctr = nf + f;
+    }
+    return it;
+  };
+  std::vector<SpdItem> fitems, bitems;
+  for (const int4 &t : fi) fitems.push_back(make_item(t, true));
+  for (const int4 &t : bi) bitems.push_back(make_item(t, false));
+  fwd_items.upload(fitems);
+  bwd_items.upload(bitems);
+  {
+    std::vector<int4> packs;
+    auto add_level = [&](int a, int mid, int b, int rows, int backward) {
+      for (int i = a; i < mid; i += 8) packs.push_back(make_int4(i, std::min(8, mid - i), 0, backward));
+      for (int i = mid; i < b; i++) packs.push_back(make_int4(i, 1, rows == 16 ? 2 : 1, backward));
+    };
+    for (size_t l = 0; l + 1 < fwd_level_ptr.size(); l++)
+      add_level(fwd_level_ptr[l], fwd_big_ptr[l], fwd_level_ptr[l + 1], fwd_rows[l], 0);
+    for (size_t l = 0; l + 1 < bwd_level_ptr.size(); l++)
+      add_level(bwd_level_ptr[l], bwd_big_ptr[l], bwd_level_ptr[l + 1], bwd_rows[l], 1);
+    flow_packs.upload(packs);
+    flow_counters.alloc((size_t)3 * nf + 1);
+    HIP_CHECK(hipMemset(flow_counters.p, 0, sizeof(unsigned) * ((size_t)3 * nf + 1)));
+    if (!flow_error) {
+      HIP_CHECK(hipHostMalloc((void **)&flow_error, sizeof(int), hipHostMallocMapped));
+      *flow_error = 0;
+    }
+    flow.npacks = (int)packs.size();
+    flow.packs = flow_packs.p;
+    flow.counters = flow_counters.p;
+    flow.ticket = flow_counters.p + (size_t)3 * nf;
+    flow.error = flow_error;
+    flow_gen = 0;
+    flow_bytes = 0;
+    for (double b : fwd_level_bytes) flow_bytes += b;
+    for (double b : bwd_level_bytes) flow_bytes += b;
+  }
   dev.nfronts = F.nfronts;
   dev.w = w.p; dev.u = u.p; dev.piv_ptr = piv_ptr.p; dev.piv_idx = piv_idx.p; dev.upd_ptr = upd_ptr.p;
   dev.upd_idx = upd_idx.p; dev.pos_off = pos_off.p; dev.ubuf_off = ubuf_off.p; dev.asm_ptr = asm_ptr.p;
   dev.asm_src = asm_src.p; dev.w_off = w_off.p; dev.wt_off = wt_off.p; dev.ldw = ldw.p; dev.ldm = ldm.p; dev.W = W.p; dev.WT = WT.p; dev.fwd_items = fwd_items.p;
   dev.bwd_items = bwd_items.p; dev.ubuf = ubuf.p;
+}
+
+SpdSolverDev::~SpdSolverDev() {
+  if (flow_error) (void)hipHostFree(flow_error);
 }
 
 // lambda_max of a symmetric matrix by Lanczos with full reorthogonalisation (stands in for the
@@ -489,13 +549,29 @@ void Group::fetch(int nslots, bool all_rows) {
   launch_reduce(st_, T_, num_local(), all_rows, nslots, partials_.p, node_scal_.p);
   HIP_CHECK(hipMemcpyAsync(h_scal_, node_scal_.p, sizeof(double) * num_local() * MAX_SLOTS, hipMemcpyDeviceToHost, st_));
   HIP_CHECK(hipStreamSynchronize(st_));
+  if ((Ltt_.flow_error && *Ltt_.flow_error) || (Lrr_.flow_error && *Lrr_.flow_error)) {
+    fprintf(stderr, "[dpgo_amd] dataflow solve: a tile gave up waiting for its dependencies\n");
+    abort();
+  }
 }
 
 void Group::copy_rows(double *dst, const double *src, bool all_rows, int part) {
   launch_axpby(d_, st_, T_, all_rows, cur_mask_, 1.0, src, 0.0, nullptr, dst, part);
 }
 
+static bool spd_use_flow() {
+  static const bool on = [] {
+    const char *e = getenv("DPGO_SPD_FLOW");
+    return !e || atoi(e) != 0;
+  }();
+  return on;
+}
+
 static void spd_run(int d, hipStream_t st, SpdSolverDev &S, double *vec, double scale) {
+  if (spd_use_flow()) {
+    launch_spd_flow(d, S.dof, st, S.dev, S.flow, ++S.flow_gen, vec, S.ytmp.p, scale, S.flow_bytes);
+    return;
+  }
   const int nf = (int)S.fwd_level_ptr.size() - 1;
   for (int l = 0; l < nf; l++) {
     const int a = S.fwd_level_ptr[l], mid = S.fwd_big_ptr[l], b = S.fwd_level_ptr[l + 1];
@@ -946,7 +1022,6 @@ void Group::prepare_extrapolated() {
 // DPGOHash::amm_pgo  (DPGOHash.cpp:230-444)
 int Group::amm(const std::vector<int> &locals) {
   const Options &o = opt_;
-  const bool trivial = (o.loss == 0);
   set_mask(locals);
   prepare_extrapolated();
   for (int a : locals) {

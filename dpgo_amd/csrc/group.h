@@ -87,14 +87,22 @@ struct SpdSolverDev {
   DevBuf<int64_t> w_off, wt_off;
   DevBuf<int> ldw, ldm;
   DevBuf<double> W, WT, ubuf, ytmp;
-  DevBuf<int4> fwd_items, bwd_items;
+  DevBuf<SpdItem> fwd_items, bwd_items;
   std::vector<int> fwd_level_ptr, bwd_level_ptr;  // item ranges per level
   std::vector<int> fwd_big_ptr, bwd_big_ptr;      // first wide-front item of each level
   std::vector<int> fwd_rows, bwd_rows;            // tile height of the wide class per level (64 or 16)
   std::vector<double> fwd_level_bytes, bwd_level_bytes;
   SpdDev dev;
   int dof = 1;
+  // single-launch dataflow solve (k_spd_flow): packs of tiles in dependency order + per-tile wait / signal counters
+  DevBuf<int4> flow_packs;
+  DevBuf<unsigned> flow_counters;   // 3 * nfronts counters + 1 ticket
+  int *flow_error = nullptr;        // pinned, device-visible
+  SpdFlowDev flow;
+  unsigned flow_gen = 0;
+  double flow_bytes = 0;
   void upload(int dcols);
+  ~SpdSolverDev();
 };
 
 class Group {

@@ -119,6 +119,16 @@ void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows,
                    const double *partials, double *node_scalars);
 
 // ---- multifrontal SPD solve (spd.h) ----
+// One tile of the solve with everything it needs to know about its front: 64 bytes, one load.
+struct alignas(16) SpdItem {
+  int front, first, count, w;            // first row (forward) / pivot column (backward) of the tile, rows in it
+  int u, ld, piv_ptr, upd_ptr;           // ld: leading dimension of WT_s (forward) / W_s (backward)
+  int pos_off, ubuf_off, wait_ctr, wait_cnt;   // dataflow solve: counter to wait on, arrivals expected per solve
+  int64_t mat_off;                       // offset of WT_s (forward) / W_s (backward)
+  int sig_ctr, pad;                      // dataflow solve: counter to bump when the tile is done
+};
+static_assert(sizeof(SpdItem) == 64, "SpdItem is loaded as four int4");
+
 struct SpdDev {
   int nfronts = 0;
   const int *w = nullptr, *u = nullptr, *piv_ptr = nullptr, *piv_idx = nullptr, *upd_ptr = nullptr,
@@ -126,9 +136,20 @@ struct SpdDev {
   const int64_t *w_off = nullptr, *wt_off = nullptr;
   const int *ldw = nullptr, *ldm = nullptr;
   const double *W = nullptr, *WT = nullptr;
-  const int4 *fwd_items = nullptr, *bwd_items = nullptr;   // {front, first row/col, count, 0}
+  const SpdItem *fwd_items = nullptr, *bwd_items = nullptr;
   double *ubuf = nullptr;
 };
+// Work list of the single-launch dataflow solve (k_spd_flow).
+struct SpdFlowDev {
+  int npacks = 0;
+  const int4 *packs = nullptr;      // {first item, items (1..8), class 0 narrow / 1 wide 64-row / 2 wide 16-row, backward?}
+  unsigned *counters = nullptr;     // 3 per front: children's forward tiles, own backward tiles, own forward tiles
+  unsigned *ticket = nullptr;
+  int *error = nullptr;             // host-visible; set if a wait gives up
+};
+void launch_spd_flow(int d, int dof, hipStream_t st, const SpdDev &S, const SpdFlowDev &Fl, unsigned gen,
+                     double *vec, double *ytmp, double scale, double bytes);
+
 // One level of the forward / backward sweep.  dof = 1: unknown i is the translation of pose i;
 // dof = d: unknown i = (pose i / d, rotation row i % d).  vec is a record array, solved in place.
 // forward reads the right-hand side from vec and writes y to ytmp (n x d, matrix order); backward
@@ -138,7 +159,7 @@ void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forw
 
 // ---- optional per-launch timing (HIP events on the launch stream), off by default ----
 enum ProfKind { PK_BSR = 0, PK_INTER, PK_PROX, PK_AXPBY, PK_DOT, PK_ROTOP, PK_COPYIDX, PK_BDIAG, PK_REDUCE,
-                PK_SPD_FWD, PK_SPD_BWD, PK_COUNT };
+                PK_SPD_FWD, PK_SPD_BWD, PK_SPD_FLOW, PK_COUNT };
 void prof_enable(bool on);
 void prof_reset();
 void prof_collect(double *ms, double *bytes, long *count);

@@ -799,9 +799,17 @@ __global__ __launch_bounds__(64) void k_reduce(SegTable T, int all_rows, int nsl
 }
 
 // ---------------------------------------------------------------------------
-// Multifrontal SPD solve: one level of fronts per launch, one 64-lane wave per
-// (front, 64-row tile).  The front's right-hand side is staged through LDS in
-// chunks; W / WT are read coalesced (lane = row / column).
+// Multifrontal SPD solve.  A tile = ROWS rows (forward: rows of W_s^T's transpose, i.e. outputs
+// [y_s ; dupd]; backward: pivots x_s) of one front; NW waves share a tile and split the reduction
+// length between them chunk by chunk.  The front's input vector is staged through LDS in chunks;
+// W / WT are read coalesced (lane = row / column).
+//
+// What bounds a small level is not bytes but the chain of dependent loads inside a tile, so:
+//   * a tile's whole description (front sizes, offsets) travels in its 64-byte SpdItem: one load;
+//   * the first batch of matrix loads of every chunk is issued BEFORE the chunk's input vector is
+//     gathered (the two are independent), and in the dataflow kernel before the tile waits;
+//   * the pull lists (children's update rows to add) are read four entries at a time, added in
+//     list order (the order of the host solve: results do not depend on the schedule).
 // ---------------------------------------------------------------------------
 template <int D, int DOF>
 __device__ __forceinline__ size_t vaddr(int i) {
@@ -810,67 +818,118 @@ __device__ __forceinline__ size_t vaddr(int i) {
   else return (size_t)(i / DOF) * RS + D + (size_t)(i % DOF) * D;
 }
 
+__device__ __forceinline__ SpdItem load_item(const SpdItem *p) {
+  const int4 *q = reinterpret_cast<const int4 *>(p);
+  union { int4 v[4]; SpdItem it; } u;
+  u.v[0] = q[0]; u.v[1] = q[1]; u.v[2] = q[2]; u.v[3] = q[3];
+  return u.it;
+}
 
-// NW waves share one tile of ROWS rows and split the front's columns (forward) / rows (backward)
-// between them chunk by chunk, then combine through LDS in a fixed order.
-//   NW = 1, ROWS = 64: the many small fronts at the bottom of the tree.
-//   NW = 8, ROWS = 64: wide separator fronts; a single wave per tile cannot keep enough loads in flight.
-//   NW = 8, ROWS = 16: the same for levels with only a few wide fronts (the top of the tree, or a GPU
-//       that holds a single node): 16-row tiles give 4x more workgroups, i.e. 4x more CUs pulling on the
-//       one big front; inside a wave the 64 lanes are 16 rows x 4 interleaved columns, combined by two
-//       xor-shuffles.  Rows are padded to 128 B, so a 16-row tile still reads whole cache lines.
-template <int D, int DOF, int NW, int SPD_CH, int ROWS>
-__global__ __launch_bounds__(64 * NW) void k_spd_fwd(SpdDev S, int item0, const double *vec, double *ytmp) {
-  constexpr int KQ = 64 / ROWS;
-  __shared__ double f[NW][SPD_CH * D];
-  __shared__ double red[NW > 1 ? NW : 1][ROWS * D];
-  const int4 it = S.fwd_items[item0 + blockIdx.x];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+// COH: device-scope loads / stores for the vectors that tiles of one launch hand to each other (k_spd_flow)
+template <bool COH>
+__device__ __forceinline__ double ld_vec(const double *p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void st_vec(double *p, double v) {
+  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+// v += sum of the update-buffer rows listed for front position `pos`, in list order
+template <int D, bool COH>
+__device__ __forceinline__ void pull_updates(const SpdDev &S, int pos, double (&v)[D]) {
+  const int a0 = S.asm_ptr[pos], a1 = S.asm_ptr[pos + 1];
+  for (int a = a0; a < a1; a += 4) {
+    int idx[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) idx[q] = a + q < a1 ? S.asm_src[a + q] : -1;
+    double t[4][D];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (idx[q] >= 0) {
+#pragma unroll
+        for (int c = 0; c < D; c++) t[q][c] = ld_vec<COH>(S.ubuf + (size_t)idx[q] * D + c);
+      }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (idx[q] >= 0) {
+#pragma unroll
+        for (int c = 0; c < D; c++) v[c] += t[q][c];
+      }
+  }
+}
+
+struct NoWait {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+// fw: this wave's staging area (SPD_CH * D doubles); red: NW x (ROWS * D) doubles shared by the tile's waves.
+// wait(): called once, after the loads that do not depend on other tiles have been issued.
+template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool COH, class Wait>
+__device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it, const double *vec, double *ytmp,
+                                             double *fw, double *red, const int wv, const int lane, Wait wait) {
+  constexpr int KQ = 64 / ROWS, NB = 16;
   const int r = lane % ROWS, kq = lane / ROWS;
-  const int s = it.x, p = it.y + r;
-  const bool valid = r < it.z;
-  const int w = S.w[s];
-  const double *WT = S.WT + S.wt_off[s];
-  const int ldm = S.ldm[s];
-  const int *piv = S.piv_idx + S.piv_ptr[s];
-  const int pos0 = S.pos_off[s];
+  const int p = it.first + r;
+  const bool valid = r < it.count;
+  const int w = it.w;
+  const double *WT = S.WT + it.mat_off;
+  const int ldm = it.ld;
+  const int *piv = S.piv_idx + it.piv_ptr;
+  const int pos0 = it.pos_off;
   double acc[D];
 #pragma unroll
   for (int c = 0; c < D; c++) acc[c] = 0.0;
-  double *fw = f[wv];
   // the pivot block of W_s is L11^-1, lower triangular: rows of a tile that lies inside it only need
   // the columns up to the tile's last row
-  const int kend = (it.y + ROWS <= w) ? it.y + ROWS : w;
+  const int kend = (it.first + ROWS <= w) ? it.first + ROWS : w;
+  bool waited = false;
   for (int k0 = wv * SPD_CH; k0 < kend; k0 += NW * SPD_CH) {
     const int kn = min(SPD_CH, kend - k0);
+    // first batch of this chunk's matrix entries: in flight while the input vector is gathered
+    const double *wp = WT + (size_t)k0 * ldm + p;
+    double w0[NB];
+    const bool full0 = kq + (NB - 1) * KQ < kn;
+    if (valid && full0) {
+#pragma unroll
+      for (int q = 0; q < NB; q++) w0[q] = wp[(size_t)(kq + q * KQ) * ldm];
+    }
+    if (!waited) {
+      wait();
+      waited = true;
+    }
     for (int kk = lane; kk < kn; kk += 64) {
       const int k = k0 + kk;
       double v[D];
       const double *src = vec + vaddr<D, DOF>(piv[k]);
 #pragma unroll
-      for (int c = 0; c < D; c++) v[c] = src[c];
-      for (int a = S.asm_ptr[pos0 + k]; a < S.asm_ptr[pos0 + k + 1]; a++) {
-        const double *ub = S.ubuf + (size_t)S.asm_src[a] * D;
-#pragma unroll
-        for (int c = 0; c < D; c++) v[c] += ub[c];
-      }
+      for (int c = 0; c < D; c++) v[c] = ld_vec<COH>(src + c);
+      pull_updates<D, COH>(S, pos0 + k, v);
 #pragma unroll
       for (int c = 0; c < D; c++) fw[kk * D + c] = v[c];
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (valid) {
-      // batches of 16 independent loads in flight per lane before the first use
-      const double *wp = WT + (size_t)k0 * ldm + p;
       int kk = kq;
-      for (; kk + 15 * KQ < kn; kk += 16 * KQ) {
-        double wv16[16];
+      if (full0) {
 #pragma unroll
-        for (int q = 0; q < 16; q++) wv16[q] = wp[(size_t)(kk + q * KQ) * ldm];
+        for (int q = 0; q < NB; q++)
 #pragma unroll
-        for (int q = 0; q < 16; q++)
+          for (int c = 0; c < D; c++) acc[c] = fma(w0[q], fw[(kk + q * KQ) * D + c], acc[c]);
+        kk += NB * KQ;
+      }
+      // batches of 16 independent loads in flight per lane before the first use
+      for (; kk + (NB - 1) * KQ < kn; kk += NB * KQ) {
+        double wb[NB];
 #pragma unroll
-          for (int c = 0; c < D; c++) acc[c] = fma(wv16[q], fw[(kk + q * KQ) * D + c], acc[c]);
+        for (int q = 0; q < NB; q++) wb[q] = wp[(size_t)(kk + q * KQ) * ldm];
+#pragma unroll
+        for (int q = 0; q < NB; q++)
+#pragma unroll
+          for (int c = 0; c < D; c++) acc[c] = fma(wb[q], fw[(kk + q * KQ) * D + c], acc[c]);
       }
       for (; kk < kn; kk += KQ) {
         const double wval = wp[(size_t)kk * ldm];
@@ -880,89 +939,115 @@ __global__ __launch_bounds__(64 * NW) void k_spd_fwd(SpdDev S, int item0, const 
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (!waited) wait();   // (a wave without a chunk still takes part in the tile's barriers)
   if constexpr (KQ > 1) {
 #pragma unroll
     for (int c = 0; c < D; c++)
 #pragma unroll
       for (int o = ROWS; o < 64; o <<= 1) acc[c] += __shfl_xor(acc[c], o, 64);
   }
+  // update rows also receive the children's contributions for that row: fetched while the other
+  // waves finish
+  const bool writer = valid && kq == 0 && wv == 0;
+  double extra[D];
+#pragma unroll
+  for (int c = 0; c < D; c++) extra[c] = 0.0;
+  if (writer && p >= w) pull_updates<D, COH>(S, pos0 + p, extra);
   if constexpr (NW > 1) {
     if (kq == 0) {
 #pragma unroll
-      for (int c = 0; c < D; c++) red[wv][r * D + c] = acc[c];
+      for (int c = 0; c < D; c++) red[wv * ROWS * D + r * D + c] = acc[c];
     }
     __syncthreads();
     if (wv != 0) return;
     if (kq == 0) {
 #pragma unroll
       for (int c = 0; c < D; c++) {
-        double a = red[0][r * D + c];
-        for (int q = 1; q < NW; q++) a += red[q][r * D + c];
+        double a = red[r * D + c];
+        for (int q = 1; q < NW; q++) a += red[q * ROWS * D + r * D + c];
         acc[c] = a;
       }
     }
   }
-  if (!valid || kq != 0) return;
+  if (!writer) return;
   if (p < w) {
     double *dst = ytmp + (size_t)piv[p] * D;
 #pragma unroll
-    for (int c = 0; c < D; c++) dst[c] = acc[c];
+    for (int c = 0; c < D; c++) st_vec<COH>(dst + c, acc[c]);
   } else {
-    for (int a = S.asm_ptr[pos0 + p]; a < S.asm_ptr[pos0 + p + 1]; a++) {
-      const double *ub = S.ubuf + (size_t)S.asm_src[a] * D;
+    double *dst = S.ubuf + (size_t)(it.ubuf_off + p - w) * D;
 #pragma unroll
-      for (int c = 0; c < D; c++) acc[c] += ub[c];
-    }
-    double *dst = S.ubuf + (size_t)(S.ubuf_off[s] + p - w) * D;
-#pragma unroll
-    for (int c = 0; c < D; c++) dst[c] = acc[c];
+    for (int c = 0; c < D; c++) st_vec<COH>(dst + c, acc[c] + extra[c]);
   }
 }
 
 template <int D, int DOF, int NW, int SPD_CH, int ROWS>
-__global__ __launch_bounds__(64 * NW) void k_spd_bwd(SpdDev S, int item0, double scale, const double *ytmp,
-                                                     double *vec) {
-  constexpr int KQ = 64 / ROWS;
+__global__ __launch_bounds__(64 * NW) void k_spd_fwd(SpdDev S, int item0, const double *vec, double *ytmp) {
   __shared__ double f[NW][SPD_CH * D];
-  __shared__ double red[NW > 1 ? NW : 1][ROWS * D];
-  const int4 it = S.bwd_items[item0 + blockIdx.x];
+  __shared__ double red[(NW > 1 ? NW : 1) * ROWS * D];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const SpdItem it = load_item(S.fwd_items + item0 + blockIdx.x);
+  spd_fwd_tile<D, DOF, NW, SPD_CH, ROWS, false>(S, it, vec, ytmp, f[wv], red, wv, lane, NoWait());
+}
+
+template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool COH, class Wait>
+__device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it, double scale, const double *ytmp,
+                                             double *vec, double *fw, double *red, const int wv, const int lane,
+                                             Wait wait) {
+  constexpr int KQ = 64 / ROWS, NB = 16;
   const int r = lane % ROWS, kq = lane / ROWS;
-  const int s = it.x, k = it.y + r;
-  const bool valid = r < it.z;
-  const int w = S.w[s], m = w + S.u[s];
-  const double *W = S.W + S.w_off[s];
-  const int ldw = S.ldw[s];
-  const int *piv = S.piv_idx + S.piv_ptr[s];
-  const int *upd = S.upd_idx + S.upd_ptr[s];
+  const int k = it.first + r;
+  const bool valid = r < it.count;
+  const int w = it.w, m = w + it.u;
+  const double *W = S.W + it.mat_off;
+  const int ldw = it.ld;
+  const int *piv = S.piv_idx + it.piv_ptr;
+  const int *upd = S.upd_idx + it.upd_ptr;
   double acc[D];
 #pragma unroll
   for (int c = 0; c < D; c++) acc[c] = 0.0;
-  double *fw = f[wv];
+  bool waited = false;
   // columns of a tile starting at c0 are zero in the rows above c0 (L11^-1 is lower triangular)
-  for (int p0 = it.y + wv * SPD_CH; p0 < m; p0 += NW * SPD_CH) {
+  for (int p0 = it.first + wv * SPD_CH; p0 < m; p0 += NW * SPD_CH) {
     const int pn = min(SPD_CH, m - p0);
+    const double *wp = W + (size_t)p0 * ldw + k;
+    double w0[NB];
+    const bool full0 = kq + (NB - 1) * KQ < pn;
+    if (valid && full0) {
+#pragma unroll
+      for (int q = 0; q < NB; q++) w0[q] = wp[(size_t)(kq + q * KQ) * ldw];
+    }
+    if (!waited) {
+      wait();
+      waited = true;
+    }
     for (int pp = lane; pp < pn; pp += 64) {
       const int p = p0 + pp;
       // ancestors' entries were scaled when they were written: undo by linearity (scale is +-1)
       const double sc = p < w ? 1.0 : scale;
       const double *src = p < w ? ytmp + (size_t)piv[p] * D : vec + vaddr<D, DOF>(upd[p - w]);
 #pragma unroll
-      for (int c = 0; c < D; c++) fw[pp * D + c] = sc * src[c];
+      for (int c = 0; c < D; c++) fw[pp * D + c] = sc * ld_vec<COH>(src + c);
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (valid) {
-      const double *wp = W + (size_t)p0 * ldw + k;
       int pp = kq;
-      for (; pp + 15 * KQ < pn; pp += 16 * KQ) {
-        double wv16[16];
+      if (full0) {
 #pragma unroll
-        for (int q = 0; q < 16; q++) wv16[q] = wp[(size_t)(pp + q * KQ) * ldw];
+        for (int q = 0; q < NB; q++)
 #pragma unroll
-        for (int q = 0; q < 16; q++)
+          for (int c = 0; c < D; c++) acc[c] = fma(w0[q], fw[(pp + q * KQ) * D + c], acc[c]);
+        pp += NB * KQ;
+      }
+      for (; pp + (NB - 1) * KQ < pn; pp += NB * KQ) {
+        double wb[NB];
 #pragma unroll
-          for (int c = 0; c < D; c++) acc[c] = fma(wv16[q], fw[(pp + q * KQ) * D + c], acc[c]);
+        for (int q = 0; q < NB; q++) wb[q] = wp[(size_t)(pp + q * KQ) * ldw];
+#pragma unroll
+        for (int q = 0; q < NB; q++)
+#pragma unroll
+          for (int c = 0; c < D; c++) acc[c] = fma(wb[q], fw[(pp + q * KQ) * D + c], acc[c]);
       }
       for (; pp < pn; pp += KQ) {
         const double wval = wp[(size_t)pp * ldw];
@@ -972,6 +1057,7 @@ __global__ __launch_bounds__(64 * NW) void k_spd_bwd(SpdDev S, int item0, double
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (!waited) wait();
   if constexpr (KQ > 1) {
 #pragma unroll
     for (int c = 0; c < D; c++)
@@ -981,15 +1067,15 @@ __global__ __launch_bounds__(64 * NW) void k_spd_bwd(SpdDev S, int item0, double
   if constexpr (NW > 1) {
     if (kq == 0) {
 #pragma unroll
-      for (int c = 0; c < D; c++) red[wv][r * D + c] = acc[c];
+      for (int c = 0; c < D; c++) red[wv * ROWS * D + r * D + c] = acc[c];
     }
     __syncthreads();
     if (wv != 0) return;
     if (kq == 0) {
 #pragma unroll
       for (int c = 0; c < D; c++) {
-        double a = red[0][r * D + c];
-        for (int q = 1; q < NW; q++) a += red[q][r * D + c];
+        double a = red[r * D + c];
+        for (int q = 1; q < NW; q++) a += red[q * ROWS * D + r * D + c];
         acc[c] = a;
       }
     }
@@ -997,7 +1083,92 @@ __global__ __launch_bounds__(64 * NW) void k_spd_bwd(SpdDev S, int item0, double
   if (!valid || kq != 0) return;
   double *dst = vec + vaddr<D, DOF>(piv[k]);
 #pragma unroll
-  for (int c = 0; c < D; c++) dst[c] = scale * acc[c];
+  for (int c = 0; c < D; c++) st_vec<COH>(dst + c, scale * acc[c]);
+}
+
+template <int D, int DOF, int NW, int SPD_CH, int ROWS>
+__global__ __launch_bounds__(64 * NW) void k_spd_bwd(SpdDev S, int item0, double scale, const double *ytmp,
+                                                     double *vec) {
+  __shared__ double f[NW][SPD_CH * D];
+  __shared__ double red[(NW > 1 ? NW : 1) * ROWS * D];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const SpdItem it = load_item(S.bwd_items + item0 + blockIdx.x);
+  spd_bwd_tile<D, DOF, NW, SPD_CH, ROWS, false>(S, it, scale, ytmp, vec, f[wv], red, wv, lane, NoWait());
+}
+
+// ---------------------------------------------------------------------------
+// Dataflow solve: the whole forward + backward sweep in ONE launch.  Workgroups draw packs of tiles
+// from a ticket counter in dependency order (forward by height, then backward by depth), so every
+// tile a workgroup waits for was drawn by a workgroup that is already running: waiting cannot
+// deadlock, whatever the dispatch order.  A tile waits on one counter (forward: the tiles of all
+// children; backward: the tiles of the parent, or the front's own forward tiles for a root) and bumps
+// one counter when its results are visible device-wide.  The vectors tiles hand to each other
+// (rhs / solution records, ytmp, update buffer) are accessed with device-scope loads and stores only, so
+// no cache-wide write-back / invalidate is needed: producer = stores, s_waitcnt, atomic add; consumer =
+// poll, then loads.  Counters are never reset: solve number `gen` waits for gen * expected (mod 2^32).
+// The arithmetic of every tile is that of the level-scheduled kernels above, bit for bit.
+// ---------------------------------------------------------------------------
+struct FlowWait {
+  const SpdFlowDev &Fl;
+  int ctr, expected;
+  unsigned gen;
+  bool poller, block;   // poller: this thread polls; block: the tile's 8 waves wait together
+  __device__ __forceinline__ void operator()() const {
+    if (expected != 0) {
+      if (poller) {
+        const unsigned target = gen * (unsigned)expected;
+        unsigned spins = 0;
+        while (__hip_atomic_load(Fl.counters + ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != target) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1u << 24)) {   // never observed; turns a would-be hang into a reported error
+            *Fl.error = 1;
+            break;
+          }
+        }
+      }
+      if (block) __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+  }
+};
+
+template <int D, int DOF>
+__global__ __launch_bounds__(512) void k_spd_flow(SpdDev S, SpdFlowDev Fl, unsigned gen, unsigned ticket_base,
+                                                  double scale, double *vec, double *ytmp) {
+  constexpr int CH = 128;
+  __shared__ double f[8][CH * D];
+  __shared__ double red[8 * 64 * D];
+  __shared__ unsigned s_pack;
+  if (threadIdx.x == 0)
+    s_pack = __hip_atomic_fetch_add(Fl.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base;
+  __syncthreads();
+  const int4 pk = Fl.packs[s_pack];   // {first item, items, class, backward?}
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool bwd = pk.w != 0;
+  if (pk.z == 0) {
+    // narrow fronts: one wave per tile, waves are independent
+    if (wv >= pk.y) return;
+    const SpdItem it = load_item((bwd ? S.bwd_items : S.fwd_items) + pk.x + wv);
+    const FlowWait wait{Fl, it.wait_ctr, it.wait_cnt, gen, lane == 0, false};
+    if (bwd) spd_bwd_tile<D, DOF, 1, CH, 64, true>(S, it, scale, ytmp, vec, f[wv], red, 0, lane, wait);
+    else spd_fwd_tile<D, DOF, 1, CH, 64, true>(S, it, vec, ytmp, f[wv], red, 0, lane, wait);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt: the device-scope stores are complete
+    if (lane == 0) __hip_atomic_fetch_add(Fl.counters + it.sig_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  // wide fronts: the 8 waves share one tile
+  const SpdItem it = load_item((bwd ? S.bwd_items : S.fwd_items) + pk.x);
+  const FlowWait wait{Fl, it.wait_ctr, it.wait_cnt, gen, threadIdx.x == 0, true};
+  if (pk.z == 1) {
+    if (bwd) spd_bwd_tile<D, DOF, 8, CH, 64, true>(S, it, scale, ytmp, vec, f[wv], red, wv, lane, wait);
+    else spd_fwd_tile<D, DOF, 8, CH, 64, true>(S, it, vec, ytmp, f[wv], red, wv, lane, wait);
+  } else {
+    if (bwd) spd_bwd_tile<D, DOF, 8, CH, 16, true>(S, it, scale, ytmp, vec, f[wv], red, wv, lane, wait);
+    else spd_fwd_tile<D, DOF, 8, CH, 16, true>(S, it, vec, ytmp, f[wv], red, wv, lane, wait);
+  }
+  if (wv != 0) return;   // wave 0 wrote the tile's results
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_fetch_add(Fl.counters + it.sig_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace
@@ -1257,6 +1428,19 @@ void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forw
   });
 #undef SPD_PICK
 #undef SPD_LAUNCH
+}
+
+void launch_spd_flow(int d, int dof, hipStream_t st, const SpdDev &S, const SpdFlowDev &Fl, unsigned gen,
+                     double *vec, double *ytmp, double scale, double bytes) {
+  if (Fl.npacks == 0) return;
+  ProfScope ps(PK_SPD_FLOW, st, bytes);
+  const unsigned base = (gen - 1u) * (unsigned)Fl.npacks;
+  DPGO_DISPATCH_D(d, {
+    if (dof == 1)
+      hipLaunchKernelGGL((k_spd_flow<D, 1>), dim3(Fl.npacks), dim3(512), 0, st, S, Fl, gen, base, scale, vec, ytmp);
+    else
+      hipLaunchKernelGGL((k_spd_flow<D, D>), dim3(Fl.npacks), dim3(512), 0, st, S, Fl, gen, base, scale, vec, ytmp);
+  });
 }
 
 }  // namespace dpgo
