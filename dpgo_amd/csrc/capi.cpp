@@ -332,7 +332,7 @@ int dpgo_prof_enable(int on) { dpgo::prof_enable(on != 0); if (on) dpgo::prof_re
 int dpgo_prof_num_kinds(void) { return dpgo::PK_COUNT; }
 const char *dpgo_prof_kind_name(int k) {
   static const char *names[] = {"k_bsr", "k_inter", "k_proximal", "k_axpby", "k_dot", "k_rot_op", "k_copy_indexed",
-                                "k_bdiag_dot", "k_reduce", "k_spd_fwd", "k_spd_bwd", "k_spd_flow"};
+                                "k_bdiag_dot", "k_reduce", "k_spd_fwd", "k_spd_bwd"};
   return (k >= 0 && k < dpgo::PK_COUNT) ? names[k] : "";
 }
 int dpgo_prof_collect(double *ms, double *bytes, long *count) { dpgo::prof_collect(ms, bytes, count); return 0; }
@@ -353,6 +353,12 @@ int dpgo_debug_spd_stats(int n, const int *ptr, const int *col, const double *va
   A.val.assign(val, val + ptr[n]);
   dpgo::SpdFactor F;
   if (dpgo::spd_factor(A, F, leaf) != 0) return -1;
+  if (const char *path = getenv("DPGO_SPD_DUMP_FRONTS")) {   // analysis hook: w u height depth per front
+    if (FILE *fp = fopen(path, "w")) {
+      for (int f = 0; f < F.nfronts; f++) fprintf(fp, "%d %d %d %d\n", F.w[f], F.u[f], F.height[f], F.depth[f]);
+      fclose(fp);
+    }
+  }
   *nnz = (long)F.nnz();
   *levels = (int)F.by_height.size();
   *max_front = F.max_front;

@@ -116,30 +116,15 @@ void SpdSolverDev::upload(int dcols) {
     }
     bwd_level_ptr.push_back((int)bi.size());
   }
-  // ---- dataflow work list: the same tiles, grouped into workgroup-sized packs in dependency order
-  const int nf = F.nfronts;
-  std::vector<int> ntf(nf, 0), ntb(nf, 0), nchild_tiles(nf, 0);
-  for (const int4 &it : fi) ntf[it.x]++;
-  for (const int4 &it : bi) ntb[it.x]++;
-  for (int f = 0; f < nf; f++)
-    if (F.parent[f] >= 0) nchild_tiles[F.parent[f]] += ntf[f];
-  // counters: [0, nf) forward tiles of the children, [nf, 2nf) own backward tiles, [2nf, 3nf) own forward tiles (roots)
+  // every tile carries the description of its front (one 64-byte load instead of a chain of lookups)
   auto make_item = [&](const int4 &t, bool fwd) {
-    const int f = t.x, par = F.parent[f];
+    const int f = t.x;
     SpdItem it;
     it.front = f; it.first = t.y; it.count = t.z; it.w = F.w[f];
     it.u = F.u[f]; it.ld = fwd ? F.ldm[f] : F.ldw[f]; it.piv_ptr = F.piv_ptr[f]; it.upd_ptr = F.upd_ptr[f];
-    it.pos_off = F.pos_off[f]; it.ubuf_off = F.ubuf_off[f];
+    it.pos_off = F.pos_off[f]; it.ubuf_off = F.ubuf_off[f]; it.pad0 = it.pad1 = 0;
     it.mat_off = fwd ? F.wt_off[f] : F.w_off[f];
-    it.pad = 0;
-    if (fwd) {
-      it.wait_ctr = f; it.wait_cnt = nchild_tiles[f];
-      it.sig_ctr = par >= 0 ? par : 2 * nf + f;
-    } else {
-      it.wait_ctr = par >= 0 ? nf + par : 2 * nf + f;
-      it.wait_cnt = par >= 0 ? ntb[par] : ntf[f];
-      it.sig_ctr = nf + f;
-    }
+    it.pad2 = 0;
     return it;
   };
   std::vector<SpdItem> fitems, bitems;
@@ -147,33 +132,6 @@ void SpdSolverDev::upload(int dcols) {
   for (const int4 &t : bi) bitems.push_back(make_item(t, false));
   fwd_items.upload(fitems);
   bwd_items.upload(bitems);
-  {
-    std::vector<int4> packs;
-    auto add_level = [&](int a, int mid, int b, int rows, int backward) {
-      for (int i = a; i < mid; i += 8) packs.push_back(make_int4(i, std::min(8, mid - i), 0, backward));
-      for (int i = mid; i < b; i++) packs.push_back(make_int4(i, 1, rows == 16 ? 2 : 1, backward));
-    };
-    for (size_t l = 0; l + 1 < fwd_level_ptr.size(); l++)
-      add_level(fwd_level_ptr[l], fwd_big_ptr[l], fwd_level_ptr[l + 1], fwd_rows[l], 0);
-    for (size_t l = 0; l + 1 < bwd_level_ptr.size(); l++)
-      add_level(bwd_level_ptr[l], bwd_big_ptr[l], bwd_level_ptr[l + 1], bwd_rows[l], 1);
-    flow_packs.upload(packs);
-    flow_counters.alloc((size_t)3 * nf + 1);
-    HIP_CHECK(hipMemset(flow_counters.p, 0, sizeof(unsigned) * ((size_t)3 * nf + 1)));
-    if (!flow_error) {
-      HIP_CHECK(hipHostMalloc((void **)&flow_error, sizeof(int), hipHostMallocMapped));
-      *flow_error = 0;
-    }
-    flow.npacks = (int)packs.size();
-    flow.packs = flow_packs.p;
-    flow.counters = flow_counters.p;
-    flow.ticket = flow_counters.p + (size_t)3 * nf;
-    flow.error = flow_error;
-    flow_gen = 0;
-    flow_bytes = 0;
-    for (double b : fwd_level_bytes) flow_bytes += b;
-    for (double b : bwd_level_bytes) flow_bytes += b;
-  }
   dev.nfronts = F.nfronts;
   dev.w = w.p; dev.u = u.p; dev.piv_ptr = piv_ptr.p; dev.piv_idx = piv_idx.p; dev.upd_ptr = upd_ptr.p;
   dev.upd_idx = upd_idx.p; dev.pos_off = pos_off.p; dev.ubuf_off = ubuf_off.p; dev.asm_ptr = asm_ptr.p;
@@ -181,9 +139,7 @@ void SpdSolverDev::upload(int dcols) {
   dev.bwd_items = bwd_items.p; dev.ubuf = ubuf.p;
 }
 
-SpdSolverDev::~SpdSolverDev() {
-  if (flow_error) (void)hipHostFree(flow_error);
-}
+static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec);
 
 // lambda_max of a symmetric matrix by Lanczos with full reorthogonalisation (stands in for the
 // Spectra call of DPGOProblem.cpp:106-118, tolerance 1e-4).
@@ -477,6 +433,11 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   for (DevBuf<double> *b : {&Xk_, &Zc_, &Zp_, &Y_, &DfE_, &Tall_}) b->alloc(nall);
   for (DevBuf<double> *b : {&Xak_, &Xakh_, &gc_, &gp_, &Dfc_, &Dfp_, &gx_, &Dfx_, &T1_}) b->alloc(nown);
   for (auto &b : tmp_) b.alloc(nown);
+  if (getenv("DPGO_SPD_DUMP")) {
+    spd_profile(d_, st_, Ltt_, T1_.p);
+    if (Lrr_.F.n > 0) spd_profile(d_, st_, Lrr_, T1_.p);
+    HIP_CHECK(hipMemsetAsync(T1_.p, 0, sizeof(double) * nown, st_));
+  }
   HIP_CHECK(hipDeviceSynchronize());
   ok_ = true;
 }
@@ -546,32 +507,18 @@ const double *Group::upload_coef(const std::vector<double> &per_node) {
 }
 
 void Group::fetch(int nslots, bool all_rows) {
+  nslots = std::max(nslots, deferred_slots_);
+  deferred_slots_ = 0;
   launch_reduce(st_, T_, num_local(), all_rows, nslots, partials_.p, node_scal_.p);
   HIP_CHECK(hipMemcpyAsync(h_scal_, node_scal_.p, sizeof(double) * num_local() * MAX_SLOTS, hipMemcpyDeviceToHost, st_));
   HIP_CHECK(hipStreamSynchronize(st_));
-  if ((Ltt_.flow_error && *Ltt_.flow_error) || (Lrr_.flow_error && *Lrr_.flow_error)) {
-    fprintf(stderr, "[dpgo_amd] dataflow solve: a tile gave up waiting for its dependencies\n");
-    abort();
-  }
 }
 
 void Group::copy_rows(double *dst, const double *src, bool all_rows, int part) {
   launch_axpby(d_, st_, T_, all_rows, cur_mask_, 1.0, src, 0.0, nullptr, dst, part);
 }
 
-static bool spd_use_flow() {
-  static const bool on = [] {
-    const char *e = getenv("DPGO_SPD_FLOW");
-    return !e || atoi(e) != 0;
-  }();
-  return on;
-}
-
 static void spd_run(int d, hipStream_t st, SpdSolverDev &S, double *vec, double scale) {
-  if (spd_use_flow()) {
-    launch_spd_flow(d, S.dof, st, S.dev, S.flow, ++S.flow_gen, vec, S.ytmp.p, scale, S.flow_bytes);
-    return;
-  }
   const int nf = (int)S.fwd_level_ptr.size() - 1;
   for (int l = 0; l < nf; l++) {
     const int a = S.fwd_level_ptr[l], mid = S.fwd_big_ptr[l], b = S.fwd_level_ptr[l + 1];
@@ -588,6 +535,58 @@ static void spd_run(int d, hipStream_t st, SpdSolverDev &S, double *vec, double 
     launch_spd_level(d, S.dof, st, S.dev, false, mid, b - mid, vec, S.ytmp.p, scale, bytes * (b - mid) / tot,
                      S.bwd_rows[l] == 16 ? -8 : 8);
   }
+}
+
+// DPGO_SPD_DUMP=1: time every launch of one solve on a zero vector (HIP events, best of 5) and print its
+// algorithmic bytes and rate -- the per-level view behind bench.py's per-family roofline numbers.
+static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec) {
+  const SpdFactor &F = S.F;
+  hipEvent_t e0, e1;
+  HIP_CHECK(hipEventCreate(&e0));
+  HIP_CHECK(hipEventCreate(&e1));
+  double tot_us = 0, tot_mb = 0;
+  auto run = [&](bool fwd, size_t l, int a, int b, int nwaves, const char *cls, const std::vector<int> &fronts) {
+    if (b <= a) return;
+    // bytes of the fronts that own the tiles [a, b)
+    std::vector<SpdItem> items((size_t)(b - a));
+    HIP_CHECK(hipMemcpy(items.data(), (fwd ? S.fwd_items.p : S.bwd_items.p) + a, sizeof(SpdItem) * (b - a), hipMemcpyDeviceToHost));
+    double bytes = 0;
+    int wmax = 0, mmax = 0, last = -1, nfr = 0;
+    for (const SpdItem &it : items) {
+      if (it.front == last) continue;
+      last = it.front;
+      nfr++;
+      const double w = it.w, u = it.u;
+      bytes += 8.0 * (u * w + 0.5 * w * (w + 1)) + 2.0 * 8.0 * d * (w + u);
+      wmax = std::max(wmax, it.w);
+      mmax = std::max(mmax, it.w + it.u);
+    }
+    float best = 1e30f;
+    for (int rep = 0; rep < 6; rep++) {
+      HIP_CHECK(hipEventRecord(e0, st));
+      launch_spd_level(d, S.dof, st, S.dev, fwd, a, b - a, vec, S.ytmp.p, 1.0, 0.0, nwaves);
+      HIP_CHECK(hipEventRecord(e1, st));
+      HIP_CHECK(hipEventSynchronize(e1));
+      float ms;
+      HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep > 0) best = std::min(best, ms);
+    }
+    tot_us += best * 1e3;
+    tot_mb += bytes / 1e6;
+    fprintf(stderr, "[spd] dof %d %s level %2zu %-7s fronts %5d tiles %5d max_w %4d max_m %4d  %7.2f MB %6.1f us %6.0f GB/s\n",
+            S.dof, fwd ? "fwd" : "bwd", l, cls, nfr, b - a, wmax, mmax, bytes / 1e6, best * 1e3, bytes / (best * 1e-3) / 1e9);
+  };
+  for (size_t l = 0; l + 1 < S.fwd_level_ptr.size(); l++) {
+    run(true, l, S.fwd_level_ptr[l], S.fwd_big_ptr[l], 1, "narrow", F.by_height[l]);
+    run(true, l, S.fwd_big_ptr[l], S.fwd_level_ptr[l + 1], S.fwd_rows[l] == 16 ? -8 : 8, S.fwd_rows[l] == 16 ? "wide16" : "wide64", F.by_height[l]);
+  }
+  for (size_t l = 0; l + 1 < S.bwd_level_ptr.size(); l++) {
+    run(false, l, S.bwd_level_ptr[l], S.bwd_big_ptr[l], 1, "narrow", F.by_depth[l]);
+    run(false, l, S.bwd_big_ptr[l], S.bwd_level_ptr[l + 1], S.bwd_rows[l] == 16 ? -8 : 8, S.bwd_rows[l] == 16 ? "wide16" : "wide64", F.by_depth[l]);
+  }
+  fprintf(stderr, "[spd] dof %d total %.1f MB %.1f us %.0f GB/s (launches timed one by one)\n", S.dof, tot_mb, tot_us, tot_mb / tot_us * 1e3);
+  HIP_CHECK(hipEventDestroy(e0));
+  HIP_CHECK(hipEventDestroy(e1));
 }
 
 void Group::solve_tt(double *vec, double scale) { spd_run(d_, st_, Ltt_, vec, scale); }
@@ -1030,35 +1029,30 @@ int Group::amm(const std::vector<int> &locals) {
                 o.max_iterations > 0 && o.max_iterations_accepted > 0;   // :351-355
   }
   // Xakh = proximal(Y, Df); Gkh = G(Xakh | g[k], f); |Xakh - Xak|^2    (:363-367)
-  launch_proximal(d_, st_, T_, cur_mask_, Y_.p, Dfx_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, Xak_.p, partials_.p, 0);
-  eval_G(Xakh_.p, gc_.p, 1);
+  // (these three scalars sit in slots DS.. and are read back together with the first scalars of TNT)
+  constexpr int DS = 2 * MAX_DOTS;
+  launch_proximal(d_, st_, T_, cur_mask_, Y_.p, Dfx_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, Xak_.p, partials_.p, DS);
+  eval_G(Xakh_.p, gc_.p, DS + 1);
   // Xak.R = Xakh.R; Xak.t = recover(R, g)   (:369-372)
   copy_rows(Xak_.p, Xakh_.p, false, 2);
   recover_translations(Xak_.p, gx_.p);
-  std::vector<int> plain;
-  for (int a : locals)
-    if (!res_[a].refined) plain.push_back(a);
+  std::vector<int> plain, ref;
+  for (int a : locals) (res_[a].refined ? ref : plain).push_back(a);
   // Gk for nodes that are not refined; refined nodes run TNT first (:374-383)
-  if (!plain.empty()) eval_G(Xak_.p, gc_.p, 2);
-  fetch(3, false);
+  if (!plain.empty()) eval_G(Xak_.p, gc_.p, DS + 2);
+  deferred_slots_ = DS + 3;
+  if (ref.empty()) fetch(DS + 3, false);
+  else {
+    // TNT minimises G(. | g extrapolated); Gk is G(. | g[k]) at the refined point (:377-383)
+    run_tnt(ref, Xak_.p, gx_.p, gc_.p);
+    for (int a : ref) res_[a].Gk = res_[a].Gk_alt;
+  }
   std::vector<double> Gkh(num_local(), 0.0), minG(num_local(), 0.0);
   for (int a : locals) {
     NodeResults &r = res_[a];
-    Gkh[a] = scal(a, 1) + r.f;
-    minG[a] = r.Fk[0] - o.psi * scal(a, 0);
-    if (!r.refined) r.Gk = scal(a, 2) + r.f;
-  }
-  {
-    std::vector<int> ref;
-    for (int a : locals)
-      if (res_[a].refined) ref.push_back(a);
-    if (!ref.empty()) {
-      run_tnt(ref, Xak_.p, gx_.p);
-      set_mask(ref);
-      eval_G(Xak_.p, gc_.p, 0);
-      fetch(1, false);
-      for (int a : ref) res_[a].Gk = scal(a, 0) + res_[a].f;
-    }
+    Gkh[a] = scal(a, DS + 1) + r.f;
+    minG[a] = r.Fk[0] - o.psi * scal(a, DS);
+    if (!r.refined) r.Gk = scal(a, DS + 2) + r.f;
   }
   // adaptive restart of the half step (:386-389)
   std::vector<int> redo;

@@ -56,6 +56,7 @@ struct NodeResults {
   int updated = 1;
   int iters = 0;
   double gradFnorm = 0, fobjE = 0, Fk[2] = {0, 0}, Gk = 0, Gkh = 0;
+  double Gk_alt = 0;   // run_tnt: the refined point's surrogate value under the caller's second linear term
   double fobj = 0, fobj_prev = 0, f = 0, gamma = 0, s0 = 1, s1 = 1;
   int soft_restart_hits[2] = {0, 0};
   int num_oscillations = 0;
@@ -94,15 +95,7 @@ struct SpdSolverDev {
   std::vector<double> fwd_level_bytes, bwd_level_bytes;
   SpdDev dev;
   int dof = 1;
-  // single-launch dataflow solve (k_spd_flow): packs of tiles in dependency order + per-tile wait / signal counters
-  DevBuf<int4> flow_packs;
-  DevBuf<unsigned> flow_counters;   // 3 * nfronts counters + 1 ticket
-  int *flow_error = nullptr;        // pinned, device-visible
-  SpdFlowDev flow;
-  unsigned flow_gen = 0;
-  double flow_bytes = 0;
   void upload(int dcols);
-  ~SpdSolverDev();
 };
 
 class Group {
@@ -230,6 +223,7 @@ class Group {
   void upload_bsr(const std::vector<const BsrMatrix *> &per_node, bool rows_all, BsrBufs &out);
   void set_mask(const std::vector<int> &locals);
   void fetch(int nslots, bool all_rows);                  // -> h_scal_[local * MAX_SLOTS + s]
+  int deferred_slots_ = 0;   // slots written earlier that ride along with the next fetch (saves a host round trip)
   double scal(int local, int s) const { return h_scal_[local * MAX_SLOTS + s]; }
   void copy_rows(double *dst, const double *src, bool all_rows, int part = 0);
   void solve_tt(double *vec, double scale);               // in place on translation rows
@@ -239,7 +233,8 @@ class Group {
   void host_update_logic(int local, double fobj, double f, double gradFnorm);
   int amm(const std::vector<int> &locals);
   int mm(const std::vector<int> &locals);
-  void run_tnt(const std::vector<int> &locals, double *X, const double *g);   // refine X in place, sets Gk = f(X)
+  // refine X in place (TNT on G(. | g)); sets Gk = G(X | g) and, with g_alt, Gk_alt = G(X | g_alt)
+  void run_tnt(const std::vector<int> &locals, double *X, const double *g, const double *g_alt = nullptr);
 };
 
 }  // namespace dpgo

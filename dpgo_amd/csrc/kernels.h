@@ -24,7 +24,8 @@ namespace dpgo {
 // 64 rows per segment = one wavefront per workgroup for the row kernels: a node of 12.5 k poses still
 // yields ~200 workgroups, enough to spread over the 256 CUs when a GPU holds a single node.
 constexpr int SEG_ROWS = 64;
-constexpr int MAX_SLOTS = 8;
+constexpr int MAX_SLOTS = 16;   // per-node scalars one read-back can carry
+constexpr int MAX_DOTS = 6;     // dot products per k_dots launch (it stores MAX_DOTS consecutive slots)
 
 struct Seg {
   int begin, end, node, pad;
@@ -91,9 +92,13 @@ void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, const
 // out = alpha[node] * a + beta[node] * b over own rows (per-node coefficients on the device)
 void launch_axpby_node(int d, hipStream_t st, const SegTable &T, const int *mask, const double *alpha,
                        const double *a, const double *beta, const double *b, double *out);
-// n <= 4 dot products in one pass over own rows: partial[slot0 + q] = sum <a_q, b_q> (always writes 4 slots)
+// n <= MAX_DOTS dot products in one pass over own rows: partial[slot0 + q] = sum <a_q, b_q> over parts[q]
+// (0 whole record, 1 translation row, 2 rotation rows); always writes MAX_DOTS slots
 void launch_dots(int d, hipStream_t st, const SegTable &T, const int *mask, int n, const double *const *a,
-                 const double *const *b, int part, double *partials, int slot0);
+                 const double *const *b, const int *parts, double *partials, int slot0);
+// start of a truncated CG (IterativeSolvers.h:230-260): s = 0, hs = 0, r = grad, v = pgrad, p = -pgrad
+void launch_cg_init(int d, hipStream_t st, const SegTable &T, const int *mask, const double *grad, const double *pgrad,
+                    double *s, double *hs, double *r, double *v, double *p);
 // gradF = [V.x ; Proj_R(V.Y)] (DPGOProblem.cpp:145-162); partial ||gradF||^2; out may be null
 void launch_tangent_full(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
                          const double *V, double *out, double *partials, int slot);
@@ -123,9 +128,9 @@ void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows,
 struct alignas(16) SpdItem {
   int front, first, count, w;            // first row (forward) / pivot column (backward) of the tile, rows in it
   int u, ld, piv_ptr, upd_ptr;           // ld: leading dimension of WT_s (forward) / W_s (backward)
-  int pos_off, ubuf_off, wait_ctr, wait_cnt;   // dataflow solve: counter to wait on, arrivals expected per solve
+  int pos_off, ubuf_off, pad0, pad1;
   int64_t mat_off;                       // offset of WT_s (forward) / W_s (backward)
-  int sig_ctr, pad;                      // dataflow solve: counter to bump when the tile is done
+  int64_t pad2;
 };
 static_assert(sizeof(SpdItem) == 64, "SpdItem is loaded as four int4");
 
@@ -139,17 +144,6 @@ struct SpdDev {
   const SpdItem *fwd_items = nullptr, *bwd_items = nullptr;
   double *ubuf = nullptr;
 };
-// Work list of the single-launch dataflow solve (k_spd_flow).
-struct SpdFlowDev {
-  int npacks = 0;
-  const int4 *packs = nullptr;      // {first item, items (1..8), class 0 narrow / 1 wide 64-row / 2 wide 16-row, backward?}
-  unsigned *counters = nullptr;     // 3 per front: children's forward tiles, own backward tiles, own forward tiles
-  unsigned *ticket = nullptr;
-  int *error = nullptr;             // host-visible; set if a wait gives up
-};
-void launch_spd_flow(int d, int dof, hipStream_t st, const SpdDev &S, const SpdFlowDev &Fl, unsigned gen,
-                     double *vec, double *ytmp, double scale, double bytes);
-
 // One level of the forward / backward sweep.  dof = 1: unknown i is the translation of pose i;
 // dof = d: unknown i = (pose i / d, rotation row i % d).  vec is a record array, solved in place.
 // forward reads the right-hand side from vec and writes y to ytmp (n x d, matrix order); backward
@@ -159,7 +153,7 @@ void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forw
 
 // ---- optional per-launch timing (HIP events on the launch stream), off by default ----
 enum ProfKind { PK_BSR = 0, PK_INTER, PK_PROX, PK_AXPBY, PK_DOT, PK_ROTOP, PK_COPYIDX, PK_BDIAG, PK_REDUCE,
-                PK_SPD_FWD, PK_SPD_BWD, PK_SPD_FLOW, PK_COUNT };
+                PK_SPD_FWD, PK_SPD_BWD, PK_COUNT };
 void prof_enable(bool on);
 void prof_reset();
 void prof_collect(double *ms, double *bytes, long *count);

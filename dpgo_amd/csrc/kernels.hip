@@ -641,33 +641,62 @@ __global__ __launch_bounds__(SEG_ROWS) void k_axpby_node(const Seg *segs, const 
   store_vec<RS>(out + (size_t)row * RS, va);
 }
 
-// up to 4 dot products over the rotation part in one pass (TNT / CG scalars)
+template <int D>
+__global__ __launch_bounds__(SEG_ROWS) void k_cg_init(const Seg *segs, const int *mask, const double *grad,
+                                                      const double *pgrad, double *s, double *hs, double *r, double *v,
+                                                      double *p) {
+  constexpr int RS = Dim<D>::RS;
+  const Seg sg = segs[blockIdx.x];
+  if (mask && !mask[sg.node]) return;
+  const int row = sg.begin + threadIdx.x;
+  if (row >= sg.end) return;
+  double g[RS], pg[RS], z[RS];
+  load_vec<RS>(grad + (size_t)row * RS, g);
+  load_vec<RS>(pgrad + (size_t)row * RS, pg);
+#pragma unroll
+  for (int k = 0; k < RS; k++) z[k] = 0.0;
+  store_vec<RS>(s + (size_t)row * RS, z);
+  store_vec<RS>(hs + (size_t)row * RS, z);
+  store_vec<RS>(r + (size_t)row * RS, g);
+  store_vec<RS>(v + (size_t)row * RS, pg);
+#pragma unroll
+  for (int k = 0; k < RS; k++) pg[k] = -1.0 * pg[k];
+  store_vec<RS>(p + (size_t)row * RS, pg);
+}
+
+// up to MAX_DOTS dot products in one pass (TNT / CG scalars); part[q]: 0 whole record, 1 translation row,
+// 2 rotation rows.  Always stores MAX_DOTS slots (zeros behind the n-th).
 struct DotPairs {
-  const double *a[4];
-  const double *b[4];
+  const double *a[MAX_DOTS];
+  const double *b[MAX_DOTS];
+  int part[MAX_DOTS];
   int n;
 };
 template <int D>
-__global__ __launch_bounds__(SEG_ROWS) void k_dots(const Seg *segs, const int *mask, DotPairs P, int part,
-                                              double *partial, int pstride) {
+__global__ __launch_bounds__(SEG_ROWS) void k_dots(const Seg *segs, const int *mask, DotPairs P, double *partial,
+                                                   int pstride) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[blockIdx.x];
   const bool active = (mask == nullptr) || (mask[s.node] != 0);
-  double pr[4] = {0.0, 0.0, 0.0, 0.0};
+  double pr[MAX_DOTS];
+#pragma unroll
+  for (int q = 0; q < MAX_DOTS; q++) pr[q] = 0.0;
   const int row = s.begin + threadIdx.x;
   if (active && row < s.end) {
-    const int k0 = part == 2 ? D : 0, k1 = part == 1 ? D : RS;
-    for (int q = 0; q < P.n; q++) {
-      double va[RS], vb[RS];
-      load_vec<RS>(P.a[q] + (size_t)row * RS, va);
-      load_vec<RS>(P.b[q] + (size_t)row * RS, vb);
-      double p = 0;
 #pragma unroll
-      for (int k = 0; k < RS; k++) p = (k >= k0 && k < k1) ? fma(va[k], vb[k], p) : p;
-      pr[q] = p;
-    }
+    for (int q = 0; q < MAX_DOTS; q++)
+      if (q < P.n) {
+        const int k0 = P.part[q] == 2 ? D : 0, k1 = P.part[q] == 1 ? D : RS;
+        double va[RS], vb[RS];
+        load_vec<RS>(P.a[q] + (size_t)row * RS, va);
+        load_vec<RS>(P.b[q] + (size_t)row * RS, vb);
+        double p = 0;
+#pragma unroll
+        for (int k = 0; k < RS; k++) p = (k >= k0 && k < k1) ? fma(va[k], vb[k], p) : p;
+        pr[q] = p;
+      }
   }
-  block_store<4>(pr, partial + blockIdx.x, pstride);
+  block_store<MAX_DOTS>(pr, partial + blockIdx.x, pstride);
 }
 
 template <int D>
@@ -807,10 +836,13 @@ __global__ __launch_bounds__(64) void k_reduce(SegTable T, int all_rows, int nsl
 // What bounds a small level is not bytes but the chain of dependent loads inside a tile, so:
 //   * a tile's whole description (front sizes, offsets) travels in its 64-byte SpdItem: one load;
 //   * the first batch of matrix loads of every chunk is issued BEFORE the chunk's input vector is
-//     gathered (the two are independent), and in the dataflow kernel before the tile waits;
-//   * the pull lists (children's update rows to add) are read four entries at a time, added in
+//     gathered (the two are independent) where a level has few tiles;
+//   * the pull lists (children's update rows to add) are read two entries at a time, added in
 //     list order (the order of the host solve: results do not depend on the schedule).
 // ---------------------------------------------------------------------------
+#ifndef SPD_WPE
+#define SPD_WPE 8    // waves per SIMD the 64-row solve kernels are compiled for (register budget)
+#endif
 template <int D, int DOF>
 __device__ __forceinline__ size_t vaddr(int i) {
   constexpr int RS = Dim<D>::RS;
@@ -825,35 +857,24 @@ __device__ __forceinline__ SpdItem load_item(const SpdItem *p) {
   return u.it;
 }
 
-// COH: device-scope loads / stores for the vectors that tiles of one launch hand to each other (k_spd_flow)
-template <bool COH>
-__device__ __forceinline__ double ld_vec(const double *p) {
-  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else return *p;
-}
-template <bool COH>
-__device__ __forceinline__ void st_vec(double *p, double v) {
-  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
-
 // v += sum of the update-buffer rows listed for front position `pos`, in list order
-template <int D, bool COH>
+template <int D>
 __device__ __forceinline__ void pull_updates(const SpdDev &S, int pos, double (&v)[D]) {
   const int a0 = S.asm_ptr[pos], a1 = S.asm_ptr[pos + 1];
-  for (int a = a0; a < a1; a += 4) {
-    int idx[4];
+  constexpr int PB = 2;
+  for (int a = a0; a < a1; a += PB) {
+    int idx[PB];
 #pragma unroll
-    for (int q = 0; q < 4; q++) idx[q] = a + q < a1 ? S.asm_src[a + q] : -1;
-    double t[4][D];
+    for (int q = 0; q < PB; q++) idx[q] = a + q < a1 ? S.asm_src[a + q] : -1;
+    double t[PB][D];
 #pragma unroll
-    for (int q = 0; q < 4; q++)
+    for (int q = 0; q < PB; q++)
       if (idx[q] >= 0) {
 #pragma unroll
-        for (int c = 0; c < D; c++) t[q][c] = ld_vec<COH>(S.ubuf + (size_t)idx[q] * D + c);
+        for (int c = 0; c < D; c++) t[q][c] = *(S.ubuf + (size_t)idx[q] * D + c);
       }
 #pragma unroll
-    for (int q = 0; q < 4; q++)
+    for (int q = 0; q < PB; q++)
       if (idx[q] >= 0) {
 #pragma unroll
         for (int c = 0; c < D; c++) v[c] += t[q][c];
@@ -861,16 +882,12 @@ __device__ __forceinline__ void pull_updates(const SpdDev &S, int pos, double (&
   }
 }
 
-struct NoWait {
-  __device__ __forceinline__ void operator()() const {}
-};
-
 // fw: this wave's staging area (SPD_CH * D doubles); red: NW x (ROWS * D) doubles shared by the tile's waves.
-// wait(): called once, after the loads that do not depend on other tiles have been issued.
-template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool COH, class Wait>
+template <int D, int DOF, int NW, int SPD_CH, int ROWS>
 __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it, const double *vec, double *ytmp,
-                                             double *fw, double *red, const int wv, const int lane, Wait wait) {
+                                             double *fw, double *red, const int wv, const int lane) {
   constexpr int KQ = 64 / ROWS, NB = 16;
+  constexpr bool PRE = ROWS < 64;   // levels with few tiles: latency matters, registers do not
   const int r = lane % ROWS, kq = lane / ROWS;
   const int p = it.first + r;
   const bool valid = r < it.count;
@@ -885,28 +902,23 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
   // the pivot block of W_s is L11^-1, lower triangular: rows of a tile that lies inside it only need
   // the columns up to the tile's last row
   const int kend = (it.first + ROWS <= w) ? it.first + ROWS : w;
-  bool waited = false;
   for (int k0 = wv * SPD_CH; k0 < kend; k0 += NW * SPD_CH) {
     const int kn = min(SPD_CH, kend - k0);
     // first batch of this chunk's matrix entries: in flight while the input vector is gathered
     const double *wp = WT + (size_t)k0 * ldm + p;
     double w0[NB];
-    const bool full0 = kq + (NB - 1) * KQ < kn;
+    const bool full0 = PRE && kq + (NB - 1) * KQ < kn;
     if (valid && full0) {
 #pragma unroll
       for (int q = 0; q < NB; q++) w0[q] = wp[(size_t)(kq + q * KQ) * ldm];
-    }
-    if (!waited) {
-      wait();
-      waited = true;
     }
     for (int kk = lane; kk < kn; kk += 64) {
       const int k = k0 + kk;
       double v[D];
       const double *src = vec + vaddr<D, DOF>(piv[k]);
 #pragma unroll
-      for (int c = 0; c < D; c++) v[c] = ld_vec<COH>(src + c);
-      pull_updates<D, COH>(S, pos0 + k, v);
+      for (int c = 0; c < D; c++) v[c] = *(src + c);
+      pull_updates<D>(S, pos0 + k, v);
 #pragma unroll
       for (int c = 0; c < D; c++) fw[kk * D + c] = v[c];
     }
@@ -931,15 +943,20 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
 #pragma unroll
           for (int c = 0; c < D; c++) acc[c] = fma(wb[q], fw[(kk + q * KQ) * D + c], acc[c]);
       }
-      for (; kk < kn; kk += KQ) {
-        const double wval = wp[(size_t)kk * ldm];
+      if (kk < kn) {   // the rest: one predicated batch (the loads are independent, never one at a time)
+        double wb[NB];
 #pragma unroll
-        for (int c = 0; c < D; c++) acc[c] = fma(wval, fw[kk * D + c], acc[c]);
+        for (int q = 0; q < NB; q++) wb[q] = kk + q * KQ < kn ? wp[(size_t)(kk + q * KQ) * ldm] : 0.0;
+#pragma unroll
+        for (int q = 0; q < NB; q++)
+          if (kk + q * KQ < kn) {
+#pragma unroll
+            for (int c = 0; c < D; c++) acc[c] = fma(wb[q], fw[(kk + q * KQ) * D + c], acc[c]);
+          }
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (!waited) wait();   // (a wave without a chunk still takes part in the tile's barriers)
   if constexpr (KQ > 1) {
 #pragma unroll
     for (int c = 0; c < D; c++)
@@ -952,7 +969,7 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
   double extra[D];
 #pragma unroll
   for (int c = 0; c < D; c++) extra[c] = 0.0;
-  if (writer && p >= w) pull_updates<D, COH>(S, pos0 + p, extra);
+  if (writer && p >= w) pull_updates<D>(S, pos0 + p, extra);
   if constexpr (NW > 1) {
     if (kq == 0) {
 #pragma unroll
@@ -973,28 +990,28 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
   if (p < w) {
     double *dst = ytmp + (size_t)piv[p] * D;
 #pragma unroll
-    for (int c = 0; c < D; c++) st_vec<COH>(dst + c, acc[c]);
+    for (int c = 0; c < D; c++) *(dst + c) = (acc[c]);
   } else {
     double *dst = S.ubuf + (size_t)(it.ubuf_off + p - w) * D;
 #pragma unroll
-    for (int c = 0; c < D; c++) st_vec<COH>(dst + c, acc[c] + extra[c]);
+    for (int c = 0; c < D; c++) *(dst + c) = (acc[c] + extra[c]);
   }
 }
 
 template <int D, int DOF, int NW, int SPD_CH, int ROWS>
-__global__ __launch_bounds__(64 * NW) void k_spd_fwd(SpdDev S, int item0, const double *vec, double *ytmp) {
+__global__ __launch_bounds__(64 * NW, ROWS == 64 ? SPD_WPE : 4) void k_spd_fwd(SpdDev S, int item0, const double *vec, double *ytmp) {
   __shared__ double f[NW][SPD_CH * D];
   __shared__ double red[(NW > 1 ? NW : 1) * ROWS * D];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const SpdItem it = load_item(S.fwd_items + item0 + blockIdx.x);
-  spd_fwd_tile<D, DOF, NW, SPD_CH, ROWS, false>(S, it, vec, ytmp, f[wv], red, wv, lane, NoWait());
+  spd_fwd_tile<D, DOF, NW, SPD_CH, ROWS>(S, it, vec, ytmp, f[wv], red, wv, lane);
 }
 
-template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool COH, class Wait>
+template <int D, int DOF, int NW, int SPD_CH, int ROWS>
 __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it, double scale, const double *ytmp,
-                                             double *vec, double *fw, double *red, const int wv, const int lane,
-                                             Wait wait) {
+                                             double *vec, double *fw, double *red, const int wv, const int lane) {
   constexpr int KQ = 64 / ROWS, NB = 16;
+  constexpr bool PRE = ROWS < 64;   // levels with few tiles: latency matters, registers do not
   const int r = lane % ROWS, kq = lane / ROWS;
   const int k = it.first + r;
   const bool valid = r < it.count;
@@ -1006,20 +1023,15 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
   double acc[D];
 #pragma unroll
   for (int c = 0; c < D; c++) acc[c] = 0.0;
-  bool waited = false;
   // columns of a tile starting at c0 are zero in the rows above c0 (L11^-1 is lower triangular)
   for (int p0 = it.first + wv * SPD_CH; p0 < m; p0 += NW * SPD_CH) {
     const int pn = min(SPD_CH, m - p0);
     const double *wp = W + (size_t)p0 * ldw + k;
     double w0[NB];
-    const bool full0 = kq + (NB - 1) * KQ < pn;
+    const bool full0 = PRE && kq + (NB - 1) * KQ < pn;
     if (valid && full0) {
 #pragma unroll
       for (int q = 0; q < NB; q++) w0[q] = wp[(size_t)(kq + q * KQ) * ldw];
-    }
-    if (!waited) {
-      wait();
-      waited = true;
     }
     for (int pp = lane; pp < pn; pp += 64) {
       const int p = p0 + pp;
@@ -1027,7 +1039,7 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
       const double sc = p < w ? 1.0 : scale;
       const double *src = p < w ? ytmp + (size_t)piv[p] * D : vec + vaddr<D, DOF>(upd[p - w]);
 #pragma unroll
-      for (int c = 0; c < D; c++) fw[pp * D + c] = sc * ld_vec<COH>(src + c);
+      for (int c = 0; c < D; c++) fw[pp * D + c] = sc * *(src + c);
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1049,15 +1061,20 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
 #pragma unroll
           for (int c = 0; c < D; c++) acc[c] = fma(wb[q], fw[(pp + q * KQ) * D + c], acc[c]);
       }
-      for (; pp < pn; pp += KQ) {
-        const double wval = wp[(size_t)pp * ldw];
+      if (pp < pn) {
+        double wb[NB];
 #pragma unroll
-        for (int c = 0; c < D; c++) acc[c] = fma(wval, fw[pp * D + c], acc[c]);
+        for (int q = 0; q < NB; q++) wb[q] = pp + q * KQ < pn ? wp[(size_t)(pp + q * KQ) * ldw] : 0.0;
+#pragma unroll
+        for (int q = 0; q < NB; q++)
+          if (pp + q * KQ < pn) {
+#pragma unroll
+            for (int c = 0; c < D; c++) acc[c] = fma(wb[q], fw[(pp + q * KQ) * D + c], acc[c]);
+          }
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (!waited) wait();
   if constexpr (KQ > 1) {
 #pragma unroll
     for (int c = 0; c < D; c++)
@@ -1083,92 +1100,17 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
   if (!valid || kq != 0) return;
   double *dst = vec + vaddr<D, DOF>(piv[k]);
 #pragma unroll
-  for (int c = 0; c < D; c++) st_vec<COH>(dst + c, scale * acc[c]);
+  for (int c = 0; c < D; c++) *(dst + c) = (scale * acc[c]);
 }
 
 template <int D, int DOF, int NW, int SPD_CH, int ROWS>
-__global__ __launch_bounds__(64 * NW) void k_spd_bwd(SpdDev S, int item0, double scale, const double *ytmp,
+__global__ __launch_bounds__(64 * NW, ROWS == 64 ? SPD_WPE : 4) void k_spd_bwd(SpdDev S, int item0, double scale, const double *ytmp,
                                                      double *vec) {
   __shared__ double f[NW][SPD_CH * D];
   __shared__ double red[(NW > 1 ? NW : 1) * ROWS * D];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const SpdItem it = load_item(S.bwd_items + item0 + blockIdx.x);
-  spd_bwd_tile<D, DOF, NW, SPD_CH, ROWS, false>(S, it, scale, ytmp, vec, f[wv], red, wv, lane, NoWait());
-}
-
-// ---------------------------------------------------------------------------
-// Dataflow solve: the whole forward + backward sweep in ONE launch.  Workgroups draw packs of tiles
-// from a ticket counter in dependency order (forward by height, then backward by depth), so every
-// tile a workgroup waits for was drawn by a workgroup that is already running: waiting cannot
-// deadlock, whatever the dispatch order.  A tile waits on one counter (forward: the tiles of all
-// children; backward: the tiles of the parent, or the front's own forward tiles for a root) and bumps
-// one counter when its results are visible device-wide.  The vectors tiles hand to each other
-// (rhs / solution records, ytmp, update buffer) are accessed with device-scope loads and stores only, so
-// no cache-wide write-back / invalidate is needed: producer = stores, s_waitcnt, atomic add; consumer =
-// poll, then loads.  Counters are never reset: solve number `gen` waits for gen * expected (mod 2^32).
-// The arithmetic of every tile is that of the level-scheduled kernels above, bit for bit.
-// ---------------------------------------------------------------------------
-struct FlowWait {
-  const SpdFlowDev &Fl;
-  int ctr, expected;
-  unsigned gen;
-  bool poller, block;   // poller: this thread polls; block: the tile's 8 waves wait together
-  __device__ __forceinline__ void operator()() const {
-    if (expected != 0) {
-      if (poller) {
-        const unsigned target = gen * (unsigned)expected;
-        unsigned spins = 0;
-        while (__hip_atomic_load(Fl.counters + ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != target) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1u << 24)) {   // never observed; turns a would-be hang into a reported error
-            *Fl.error = 1;
-            break;
-          }
-        }
-      }
-      if (block) __syncthreads();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-  }
-};
-
-template <int D, int DOF>
-__global__ __launch_bounds__(512) void k_spd_flow(SpdDev S, SpdFlowDev Fl, unsigned gen, unsigned ticket_base,
-                                                  double scale, double *vec, double *ytmp) {
-  constexpr int CH = 128;
-  __shared__ double f[8][CH * D];
-  __shared__ double red[8 * 64 * D];
-  __shared__ unsigned s_pack;
-  if (threadIdx.x == 0)
-    s_pack = __hip_atomic_fetch_add(Fl.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base;
-  __syncthreads();
-  const int4 pk = Fl.packs[s_pack];   // {first item, items, class, backward?}
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const bool bwd = pk.w != 0;
-  if (pk.z == 0) {
-    // narrow fronts: one wave per tile, waves are independent
-    if (wv >= pk.y) return;
-    const SpdItem it = load_item((bwd ? S.bwd_items : S.fwd_items) + pk.x + wv);
-    const FlowWait wait{Fl, it.wait_ctr, it.wait_cnt, gen, lane == 0, false};
-    if (bwd) spd_bwd_tile<D, DOF, 1, CH, 64, true>(S, it, scale, ytmp, vec, f[wv], red, 0, lane, wait);
-    else spd_fwd_tile<D, DOF, 1, CH, 64, true>(S, it, vec, ytmp, f[wv], red, 0, lane, wait);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt: the device-scope stores are complete
-    if (lane == 0) __hip_atomic_fetch_add(Fl.counters + it.sig_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
-  }
-  // wide fronts: the 8 waves share one tile
-  const SpdItem it = load_item((bwd ? S.bwd_items : S.fwd_items) + pk.x);
-  const FlowWait wait{Fl, it.wait_ctr, it.wait_cnt, gen, threadIdx.x == 0, true};
-  if (pk.z == 1) {
-    if (bwd) spd_bwd_tile<D, DOF, 8, CH, 64, true>(S, it, scale, ytmp, vec, f[wv], red, wv, lane, wait);
-    else spd_fwd_tile<D, DOF, 8, CH, 64, true>(S, it, vec, ytmp, f[wv], red, wv, lane, wait);
-  } else {
-    if (bwd) spd_bwd_tile<D, DOF, 8, CH, 16, true>(S, it, scale, ytmp, vec, f[wv], red, wv, lane, wait);
-    else spd_fwd_tile<D, DOF, 8, CH, 16, true>(S, it, vec, ytmp, f[wv], red, wv, lane, wait);
-  }
-  if (wv != 0) return;   // wave 0 wrote the tile's results
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if (lane == 0) __hip_atomic_fetch_add(Fl.counters + it.sig_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  spd_bwd_tile<D, DOF, NW, SPD_CH, ROWS>(S, it, scale, ytmp, vec, f[wv], red, wv, lane);
 }
 
 }  // namespace
@@ -1338,14 +1280,26 @@ void launch_axpby_node(int d, hipStream_t st, const SegTable &T, const int *mask
 }
 
 void launch_dots(int d, hipStream_t st, const SegTable &T, const int *mask, int n, const double *const *a,
-                 const double *const *b, int part, double *partials, int slot0) {
+                 const double *const *b, const int *parts, double *partials, int slot0) {
   if (T.nseg_own == 0 || n <= 0) return;
   DotPairs P;
   P.n = n;
-  for (int q = 0; q < 4; q++) { P.a[q] = a[q < n ? q : 0]; P.b[q] = b[q < n ? q : 0]; }
+  for (int q = 0; q < MAX_DOTS; q++) {
+    P.a[q] = a[q < n ? q : 0];
+    P.b[q] = b[q < n ? q : 0];
+    P.part[q] = parts[q < n ? q : 0];
+  }
   ProfScope ps(PK_DOT, st, 2.0 * n * T.rows_own * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_dots<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, P, part,
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_dots<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, P,
                                         partials + (size_t)slot0 * T.nseg_all, T.nseg_all));
+}
+
+void launch_cg_init(int d, hipStream_t st, const SegTable &T, const int *mask, const double *grad, const double *pgrad,
+                    double *s, double *hs, double *r, double *v, double *p) {
+  if (T.nseg_own == 0) return;
+  ProfScope ps(PK_AXPBY, st, 7.0 * T.rows_own * 8.0 * (d + 1) * d);
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cg_init<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, grad,
+                                        pgrad, s, hs, r, v, p));
 }
 
 void launch_tangent_full(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
@@ -1428,19 +1382,6 @@ void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forw
   });
 #undef SPD_PICK
 #undef SPD_LAUNCH
-}
-
-void launch_spd_flow(int d, int dof, hipStream_t st, const SpdDev &S, const SpdFlowDev &Fl, unsigned gen,
-                     double *vec, double *ytmp, double scale, double bytes) {
-  if (Fl.npacks == 0) return;
-  ProfScope ps(PK_SPD_FLOW, st, bytes);
-  const unsigned base = (gen - 1u) * (unsigned)Fl.npacks;
-  DPGO_DISPATCH_D(d, {
-    if (dof == 1)
-      hipLaunchKernelGGL((k_spd_flow<D, 1>), dim3(Fl.npacks), dim3(512), 0, st, S, Fl, gen, base, scale, vec, ytmp);
-    else
-      hipLaunchKernelGGL((k_spd_flow<D, D>), dim3(Fl.npacks), dim3(512), 0, st, S, Fl, gen, base, scale, vec, ytmp);
-  });
 }
 
 }  // namespace dpgo

@@ -41,7 +41,7 @@ struct NodeTnt {
 };
 }  // namespace
 
-void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g) {
+void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, const double *g_alt) {
   const Options &o = opt_;
   const int L = num_local();
   const bool use_precon = (o.preconditioner == 1) && Lrr_.F.n > 0;
@@ -54,11 +54,12 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g) {
   for (auto &s : S) s.active = false;
   for (int a : nodes) S[a] = NodeTnt();
 
+  const int P2[MAX_DOTS] = {2, 2, 2, 2, 2, 2};
   auto dots = [&](std::initializer_list<std::pair<const double *, const double *>> prs) {
-    const double *pa[4], *pb[4];
+    const double *pa[MAX_DOTS], *pb[MAX_DOTS];
     int s = 0;
     for (const auto &pr : prs) { pa[s] = pr.first; pb[s] = pr.second; s++; }
-    launch_dots(d_, st_, T_, cur_mask_, s, pa, pb, 2, partials_.p, 0);
+    launch_dots(d_, st_, T_, cur_mask_, s, pa, pb, P2, partials_.p, 0);
     fetch(s, false);
   };
   auto quad_model = [&](const double *Y) {   // nabla, grad at Y
@@ -81,29 +82,36 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g) {
     solve_rr(w1, 1.0);
     launch_tangent_rot(d_, st_, T_, cur_mask_, Y, w1, out);
   };
-  // gnorm, pgnorm (and rv0 = <grad, P grad>, the first CG scalar) of the nodes in `set` (mask == set);
-  // with_f also evaluates f(X) in the same read-back
-  std::vector<double> rv0(L, 0.0);
+  // gnorm, pgnorm (and rv0 = <grad, P grad>, the first CG scalar) of the nodes in `set` (mask == set).
+  // with_f: f(X | g) in the same read-back, from the model gradient nabla = G X + g that is there anyway:
+  //   f = <X, g> + 1/2 <X, G X> = 1/2 (<X, nabla> + <X, g>)      (DPGOProblem.cpp:180-205)
+  // lin / lin_alt = <X, g> / <X, g_alt> let the caller re-base f on g_alt without another G X.
+  std::vector<double> rv0(L, 0.0), lin(L, 0.0), lin_alt(L, 0.0);
+  const double *ga = g_alt ? g_alt : g;
   auto norms = [&](const std::vector<int> &set, bool with_f) {
-    if (with_f) eval_G(X, g, 5);   // k_dots stores 4 slots per launch (0..3, then 1..4): f goes behind them
     {
-      const double *pa[4] = {grad, grad, grad, grad}, *pb[4] = {grad, grad, grad, grad};
-      launch_dots(d_, st_, T_, cur_mask_, 1, pa, pb, 2, partials_.p, 0);
+      const double *pa[MAX_DOTS] = {grad, X, X, X}, *pb[MAX_DOTS] = {grad, nabla, g, ga};
+      const int parts[MAX_DOTS] = {2, 0, 0, 0, 0, 0};
+      launch_dots(d_, st_, T_, cur_mask_, with_f ? 4 : 1, pa, pb, parts, partials_.p, 0);
     }
     if (use_precon) {
       precon(X, grad, pg);
-      const double *pa[4] = {pg, grad, pg, pg}, *pb[4] = {pg, pg, pg, pg};
-      launch_dots(d_, st_, T_, cur_mask_, 2, pa, pb, 2, partials_.p, 1);
+      const double *pa[MAX_DOTS] = {pg, grad}, *pb[MAX_DOTS] = {pg, pg};
+      launch_dots(d_, st_, T_, cur_mask_, 2, pa, pb, P2, partials_.p, MAX_DOTS);
     }
-    fetch(with_f ? 6 : 3, false);
+    fetch(MAX_DOTS + 2, false);
     for (int a : set) {
       S[a].gnorm = S[a].pgnorm = std::sqrt(scal(a, 0));
       rv0[a] = scal(a, 0);
       if (use_precon) {
-        S[a].pgnorm = std::sqrt(scal(a, 1));
-        rv0[a] = scal(a, 2);
+        S[a].pgnorm = std::sqrt(scal(a, MAX_DOTS));
+        rv0[a] = scal(a, MAX_DOTS + 1);
       }
-      if (with_f) S[a].fx = scal(a, 5) + res_[a].f;
+      if (with_f) {
+        S[a].fx = 0.5 * (scal(a, 1) + scal(a, 2)) + res_[a].f;
+        lin[a] = scal(a, 2);
+        lin_alt[a] = scal(a, 3);
+      }
     }
   };
 
@@ -128,12 +136,8 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g) {
     if (A.empty()) break;
     // ---- STPCG (IterativeSolvers.h:207-426)
     set_mask(A);
-    launch_axpby(d_, st_, T_, false, cur_mask_, 0.0, grad, 0.0, nullptr, sk, 0);
-    launch_axpby(d_, st_, T_, false, cur_mask_, 0.0, grad, 0.0, nullptr, hh, 0);
-    copy_rows(rk, grad, false, 0);
-    // v_0 = P(r_0) = P(grad): already computed for the preconditioned gradient norm (pg)
-    copy_rows(vk, use_precon ? pg : rk, false, 0);
-    launch_axpby(d_, st_, T_, false, cur_mask_, -1.0, vk, 0.0, nullptr, pk, 0);
+    // s_0 = 0, H s_0 = 0, r_0 = grad, v_0 = P(grad) (already there from the preconditioned gradient norm), p_0 = -v_0
+    launch_cg_init(d_, st_, T_, cur_mask_, grad, use_precon ? pg : grad, sk, hh, rk, vk, pk);
     for (int a : A) {
       NodeTnt &s = S[a];
       s.cg = true;
@@ -217,16 +221,17 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g) {
     set_mask(A);
     launch_retract_rot(d_, st_, T_, cur_mask_, X, sk, xprop);
     recover_translations(xprop, g);
-    eval_G(xprop, g, 4);
+    eval_G(xprop, g, MAX_DOTS);
     {
-      const double *pa[4] = {sk, grad, sk, sk}, *pb[4] = {sk, sk, hh, sk};
-      launch_dots(d_, st_, T_, cur_mask_, 3, pa, pb, 2, partials_.p, 0);
+      const double *pa[MAX_DOTS] = {sk, grad, sk, xprop, xprop}, *pb[MAX_DOTS] = {sk, sk, hh, g, ga};
+      const int parts[MAX_DOTS] = {2, 2, 2, 0, 0, 0};
+      launch_dots(d_, st_, T_, cur_mask_, 5, pa, pb, parts, partials_.p, 0);
     }
-    fetch(5, false);
+    fetch(MAX_DOTS + 1, false);
     std::vector<int> acc, requad;
     for (int a : A) {
       NodeTnt &s = S[a];
-      const double fx_prop = scal(a, 4) + res_[a].f;
+      const double fx_prop = scal(a, MAX_DOTS) + res_[a].f;
       const double h_norm = std::sqrt(scal(a, 0));
       const double dm = -scal(a, 1) - 0.5 * scal(a, 2);
       const double df = s.fx - fx_prop;
@@ -238,6 +243,8 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g) {
       if (ok) {
         acc.push_back(a);
         s.fx = fx_prop;
+        lin[a] = scal(a, 3);
+        lin_alt[a] = scal(a, 4);
         if (rel_dec < o.rel_func_decrease_tol) { s.status = ST_REL_DECREASE; stop = true; }
         else if (h_norm < o.stepsize_tol) { s.status = ST_STEPSIZE; stop = true; }
         else if (s.iteration + 1 < o.max_iterations && s.accepted < o.max_iterations_accepted)
@@ -265,6 +272,7 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g) {
   }
   for (int a : nodes) {
     res_[a].Gk = S[a].fx;
+    res_[a].Gk_alt = S[a].fx - lin[a] + lin_alt[a];   // f(X | g_alt): only the linear term depends on g
     res_[a].tnt_status = S[a].status;
     res_[a].tnt_inner = S[a].inner_total;
   }
