@@ -47,14 +47,21 @@ template struct DevBuf<int64_t>;
 template struct DevBuf<int4>;
 template struct DevBuf<Seg>;
 
+// Device layout of a factor.  The solve streams every W_s once per sweep, so the matrices are re-packed
+// into PANELS: the entries one tile reads, contiguous, in the order it reads them.
+//   forward tile (rows p0 .. p0+count of [y ; dupd], all columns k < kend):  panel[k][r] = WT_s[k][p0 + r]
+//   backward tile (pivot columns k0 .. k0+count, rows p >= k0):              panel[p - k0][r] = W_s[p][k0 + r]
+// (rows of a panel are ld = count rounded up to 16 doubles apart).  The zero triangle of L11^-1 is simply not
+// stored, a wave's consecutive loads are consecutive in memory, and every tile is a pure sequential stream.
+// Within a launch the tiles are ordered by decreasing length, so the long ones start first and the short
+// ones fill the tail.
 void SpdSolverDev::upload(int dcols) {
-  w.upload(F.w); u.upload(F.u); piv_ptr.upload(F.piv_ptr); piv_idx.upload(F.piv_idx);
-  upd_ptr.upload(F.upd_ptr); upd_idx.upload(F.upd_idx); pos_off.upload(F.pos_off); ubuf_off.upload(F.ubuf_off);
-  asm_ptr.upload(F.asm_ptr); asm_src.upload(F.asm_src); w_off.upload(F.w_off); wt_off.upload(F.wt_off); ldw.upload(F.ldw); ldm.upload(F.ldm); W.upload(F.W); WT.upload(F.WT);
+  piv_idx.upload(F.piv_idx);
+  upd_idx.upload(F.upd_idx);
+  asm_ptr.upload(F.asm_ptr);
+  asm_src.upload(F.asm_src);
   ubuf.alloc((size_t)std::max(F.total_upd, 1) * dcols);
   ytmp.alloc((size_t)std::max(F.n, 1) * dcols);
-  std::vector<int4> fi, bi;
-  fwd_level_ptr.assign(1, 0);
   fwd_level_bytes.clear();
   bwd_level_bytes.clear();
   // algorithmic bytes of one level: every front entry once (8 B) + its in/out vector entries
@@ -67,76 +74,89 @@ void SpdSolverDev::upload(int dcols) {
   for (const auto &lvl : F.by_height) fwd_level_bytes.push_back(lvl_bytes(lvl));
   for (const auto &lvl : F.by_depth) bwd_level_bytes.push_back(lvl_bytes(lvl));
   // per level: first the tiles of small fronts (one wave each), then the tiles of wide fronts
-  // (8 waves each, columns / rows split between the waves)
-  // the reduction length decides: columns (w) in the forward sweep, rows (w+u) in the backward sweep
-  auto wide_fwd = [&](int f) { return F.w[f] > 96; };
-  auto wide_bwd = [&](int f) { return F.w[f] + F.u[f] > 96; };
-  fwd_big_ptr.clear();
-  bwd_big_ptr.clear();
+  // (8 waves each, columns / rows split between the waves).
+  // The reduction length decides: columns (w) in the forward sweep, rows (w+u) in the backward sweep.
+  auto wide = [&](int f, bool fwd) { return (fwd ? F.w[f] : F.w[f] + F.u[f]) > 96; };
   // a level whose narrow class is small is not worth a launch of its own: its tiles join the wide class
-  auto tiles = [&](const std::vector<int> &lvl, bool fwd, bool want_wide) {
+  auto tiles64 = [&](const std::vector<int> &lvl, bool fwd, bool want_wide) {
     int cnt = 0;
     for (int f : lvl)
-      if ((fwd ? wide_fwd(f) : wide_bwd(f)) == want_wide) cnt += ((fwd ? F.w[f] + F.u[f] : F.w[f]) + 63) / 64;
+      if (wide(f, fwd) == want_wide) cnt += ((fwd ? F.w[f] + F.u[f] : F.w[f]) + 63) / 64;
     return cnt;
   };
   const int MERGE_BELOW = 1024, FINE_BELOW = 512;
-  fwd_rows.clear();
-  bwd_rows.clear();
-  for (const auto &lvl : F.by_height) {
-    const bool merge = tiles(lvl, true, true) > 0 && tiles(lvl, true, false) < MERGE_BELOW;
-    // few wide tiles at this level: 16-row tiles put 4x more workgroups (CUs) on them
-    const int wide_tiles = tiles(lvl, true, true) + (merge ? tiles(lvl, true, false) : 0);
-    const int rows = (wide_tiles > 0 && wide_tiles < FINE_BELOW) ? 16 : 64;
-    fwd_rows.push_back(rows);
-    for (int pass = 0; pass < 2; pass++) {
-      if (pass == 1) fwd_big_ptr.push_back((int)fi.size());
-      const int th = pass == 1 ? rows : 64;
-      for (int f : lvl) {
-        if ((int)(wide_fwd(f) || merge) != pass) continue;
-        const int m = F.w[f] + F.u[f];
-        for (int r = 0; r < m; r += th) fi.push_back(make_int4(f, r, std::min(th, m - r), 0));
+  struct Tile { int f, first, count, rows; int64_t len; };   // rows: tile height of its class; len: panel rows
+  auto sweep = [&](bool fwd, std::vector<int> &level_ptr, std::vector<int> &big_ptr, std::vector<int> &rows_of_level,
+                   DevBuf<SpdItem> &items_dev, DevBuf<double> &panels_dev) {
+    const auto &levels = fwd ? F.by_height : F.by_depth;
+    std::vector<Tile> tiles;
+    level_ptr.assign(1, 0);
+    big_ptr.clear();
+    rows_of_level.clear();
+    for (const auto &lvl : levels) {
+      const bool merge = tiles64(lvl, fwd, true) > 0 && tiles64(lvl, fwd, false) < MERGE_BELOW;
+      // few wide tiles at this level: 16-row tiles put 4x more workgroups (CUs) on them
+      const int wide_tiles = tiles64(lvl, fwd, true) + (merge ? tiles64(lvl, fwd, false) : 0);
+      const int rows = (wide_tiles > 0 && wide_tiles < FINE_BELOW) ? 16 : 64;
+      rows_of_level.push_back(rows);
+      for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1) big_ptr.push_back((int)tiles.size());
+        const size_t begin = tiles.size();
+        const int th = pass == 1 ? rows : 64;
+        for (int f : lvl) {
+          if ((int)(wide(f, fwd) || merge) != pass) continue;
+          const int w = F.w[f], m = w + F.u[f], ext = fwd ? m : w;
+          for (int r = 0; r < ext; r += th) {
+            const int cnt = std::min(th, ext - r);
+            // forward: columns k < kend of rows r..; backward: rows p >= r of columns r..
+            const int64_t len = fwd ? ((r + th <= w) ? r + th : w) : (m - r);
+            tiles.push_back({f, r, cnt, th, len});
+          }
+        }
+        std::stable_sort(tiles.begin() + begin, tiles.end(), [](const Tile &x, const Tile &y) { return x.len * x.count > y.len * y.count; });
+      }
+      level_ptr.push_back((int)tiles.size());
+    }
+    // panel offsets
+    std::vector<SpdItem> items(tiles.size());
+    int64_t total = 0;
+    for (size_t i = 0; i < tiles.size(); i++) {
+      const Tile &t = tiles[i];
+      const int f = t.f, ld = (t.count + 15) / 16 * 16;
+      SpdItem it;
+      it.front = f; it.first = t.first; it.count = t.count; it.w = F.w[f];
+      it.u = F.u[f]; it.ld = ld; it.piv_ptr = F.piv_ptr[f]; it.upd_ptr = F.upd_ptr[f];
+      it.pos_off = F.pos_off[f]; it.ubuf_off = F.ubuf_off[f]; it.pad0 = it.pad1 = 0;
+      it.mat_off = total;
+      it.pad2 = 0;
+      items[i] = it;
+      total += t.len * ld;
+    }
+    std::vector<double> panels((size_t)std::max<int64_t>(total, 1), 0.0);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (size_t i = 0; i < tiles.size(); i++) {
+      const Tile &t = tiles[i];
+      const SpdItem &it = items[i];
+      double *dst = panels.data() + it.mat_off;
+      if (fwd) {
+        const double *src = F.WT.data() + F.wt_off[t.f] + t.first;
+        const int ldm = F.ldm[t.f];
+        for (int64_t k = 0; k < t.len; k++)
+          for (int r = 0; r < t.count; r++) dst[k * it.ld + r] = src[(size_t)k * ldm + r];
+      } else {
+        const double *src = F.W.data() + F.w_off[t.f] + (size_t)t.first * F.ldw[t.f] + t.first;
+        const int ldw = F.ldw[t.f];
+        for (int64_t p = 0; p < t.len; p++)
+          for (int r = 0; r < t.count; r++) dst[p * it.ld + r] = src[(size_t)p * ldw + r];
       }
     }
-    fwd_level_ptr.push_back((int)fi.size());
-  }
-  bwd_level_ptr.assign(1, 0);
-  for (const auto &lvl : F.by_depth) {
-    const bool merge = tiles(lvl, false, true) > 0 && tiles(lvl, false, false) < MERGE_BELOW;
-    const int wide_tiles = tiles(lvl, false, true) + (merge ? tiles(lvl, false, false) : 0);
-    const int rows = (wide_tiles > 0 && wide_tiles < FINE_BELOW) ? 16 : 64;
-    bwd_rows.push_back(rows);
-    for (int pass = 0; pass < 2; pass++) {
-      if (pass == 1) bwd_big_ptr.push_back((int)bi.size());
-      const int th = pass == 1 ? rows : 64;
-      for (int f : lvl) {
-        if ((int)(wide_bwd(f) || merge) != pass) continue;
-        for (int c = 0; c < F.w[f]; c += th) bi.push_back(make_int4(f, c, std::min(th, F.w[f] - c), 0));
-      }
-    }
-    bwd_level_ptr.push_back((int)bi.size());
-  }
-  // every tile carries the description of its front (one 64-byte load instead of a chain of lookups)
-  auto make_item = [&](const int4 &t, bool fwd) {
-    const int f = t.x;
-    SpdItem it;
-    it.front = f; it.first = t.y; it.count = t.z; it.w = F.w[f];
-    it.u = F.u[f]; it.ld = fwd ? F.ldm[f] : F.ldw[f]; it.piv_ptr = F.piv_ptr[f]; it.upd_ptr = F.upd_ptr[f];
-    it.pos_off = F.pos_off[f]; it.ubuf_off = F.ubuf_off[f]; it.pad0 = it.pad1 = 0;
-    it.mat_off = fwd ? F.wt_off[f] : F.w_off[f];
-    it.pad2 = 0;
-    return it;
+    items_dev.upload(items);
+    panels_dev.upload(panels);
   };
-  std::vector<SpdItem> fitems, bitems;
-  for (const int4 &t : fi) fitems.push_back(make_item(t, true));
-  for (const int4 &t : bi) bitems.push_back(make_item(t, false));
-  fwd_items.upload(fitems);
-  bwd_items.upload(bitems);
-  dev.nfronts = F.nfronts;
-  dev.w = w.p; dev.u = u.p; dev.piv_ptr = piv_ptr.p; dev.piv_idx = piv_idx.p; dev.upd_ptr = upd_ptr.p;
-  dev.upd_idx = upd_idx.p; dev.pos_off = pos_off.p; dev.ubuf_off = ubuf_off.p; dev.asm_ptr = asm_ptr.p;
-  dev.asm_src = asm_src.p; dev.w_off = w_off.p; dev.wt_off = wt_off.p; dev.ldw = ldw.p; dev.ldm = ldm.p; dev.W = W.p; dev.WT = WT.p; dev.fwd_items = fwd_items.p;
-  dev.bwd_items = bwd_items.p; dev.ubuf = ubuf.p;
+  sweep(true, fwd_level_ptr, fwd_big_ptr, fwd_rows, fwd_items, WT);
+  sweep(false, bwd_level_ptr, bwd_big_ptr, bwd_rows, bwd_items, W);
+  dev.piv_idx = piv_idx.p; dev.upd_idx = upd_idx.p; dev.asm_ptr = asm_ptr.p; dev.asm_src = asm_src.p;
+  dev.W = W.p; dev.WT = WT.p; dev.fwd_items = fwd_items.p; dev.bwd_items = bwd_items.p; dev.ubuf = ubuf.p;
 }
 
 static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec);
@@ -551,10 +571,11 @@ static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec) {
     std::vector<SpdItem> items((size_t)(b - a));
     HIP_CHECK(hipMemcpy(items.data(), (fwd ? S.fwd_items.p : S.bwd_items.p) + a, sizeof(SpdItem) * (b - a), hipMemcpyDeviceToHost));
     double bytes = 0;
-    int wmax = 0, mmax = 0, last = -1, nfr = 0;
+    int wmax = 0, mmax = 0, nfr = 0;
+    std::vector<char> seen(F.nfronts, 0);
     for (const SpdItem &it : items) {
-      if (it.front == last) continue;
-      last = it.front;
+      if (seen[it.front]) continue;
+      seen[it.front] = 1;
       nfr++;
       const double w = it.w, u = it.u;
       bytes += 8.0 * (u * w + 0.5 * w * (w + 1)) + 2.0 * 8.0 * d * (w + u);

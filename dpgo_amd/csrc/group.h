@@ -84,10 +84,8 @@ struct DevBuf {
 
 struct SpdSolverDev {
   SpdFactor F;   // host copy kept for sizes / host solves
-  DevBuf<int> w, u, piv_ptr, piv_idx, upd_ptr, upd_idx, pos_off, ubuf_off, asm_ptr, asm_src;
-  DevBuf<int64_t> w_off, wt_off;
-  DevBuf<int> ldw, ldm;
-  DevBuf<double> W, WT, ubuf, ytmp;
+  DevBuf<int> piv_idx, upd_idx, asm_ptr, asm_src;
+  DevBuf<double> W, WT, ubuf, ytmp;   // W / WT: backward / forward panels (see upload)
   DevBuf<SpdItem> fwd_items, bwd_items;
   std::vector<int> fwd_level_ptr, bwd_level_ptr;  // item ranges per level
   std::vector<int> fwd_big_ptr, bwd_big_ptr;      // first wide-front item of each level

@@ -127,20 +127,17 @@ void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows,
 // One tile of the solve with everything it needs to know about its front: 64 bytes, one load.
 struct alignas(16) SpdItem {
   int front, first, count, w;            // first row (forward) / pivot column (backward) of the tile, rows in it
-  int u, ld, piv_ptr, upd_ptr;           // ld: leading dimension of WT_s (forward) / W_s (backward)
+  int u, ld, piv_ptr, upd_ptr;           // ld: doubles between consecutive rows of the tile's panel
   int pos_off, ubuf_off, pad0, pad1;
-  int64_t mat_off;                       // offset of WT_s (forward) / W_s (backward)
+  int64_t mat_off;                       // offset of the tile's panel
   int64_t pad2;
 };
 static_assert(sizeof(SpdItem) == 64, "SpdItem is loaded as four int4");
 
 struct SpdDev {
-  int nfronts = 0;
-  const int *w = nullptr, *u = nullptr, *piv_ptr = nullptr, *piv_idx = nullptr, *upd_ptr = nullptr,
-            *upd_idx = nullptr, *pos_off = nullptr, *ubuf_off = nullptr, *asm_ptr = nullptr, *asm_src = nullptr;
-  const int64_t *w_off = nullptr, *wt_off = nullptr;
-  const int *ldw = nullptr, *ldm = nullptr;
-  const double *W = nullptr, *WT = nullptr;
+  const int *piv_idx = nullptr, *upd_idx = nullptr;   // matrix indices of the pivots / update rows of every front
+  const int *asm_ptr = nullptr, *asm_src = nullptr;   // per front position: rows of the update buffer to add
+  const double *W = nullptr, *WT = nullptr;           // panels of the backward / forward tiles
   const SpdItem *fwd_items = nullptr, *bwd_items = nullptr;
   double *ubuf = nullptr;
 };

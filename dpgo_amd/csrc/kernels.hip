@@ -892,7 +892,7 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
   const int p = it.first + r;
   const bool valid = r < it.count;
   const int w = it.w;
-  const double *WT = S.WT + it.mat_off;
+  const double *WT = S.WT + it.mat_off + r;   // the tile's panel: [k][r], rows ldm apart
   const int ldm = it.ld;
   const int *piv = S.piv_idx + it.piv_ptr;
   const int pos0 = it.pos_off;
@@ -905,7 +905,7 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
   for (int k0 = wv * SPD_CH; k0 < kend; k0 += NW * SPD_CH) {
     const int kn = min(SPD_CH, kend - k0);
     // first batch of this chunk's matrix entries: in flight while the input vector is gathered
-    const double *wp = WT + (size_t)k0 * ldm + p;
+    const double *wp = WT + (size_t)k0 * ldm;
     double w0[NB];
     const bool full0 = PRE && kq + (NB - 1) * KQ < kn;
     if (valid && full0) {
@@ -1016,7 +1016,7 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
   const int k = it.first + r;
   const bool valid = r < it.count;
   const int w = it.w, m = w + it.u;
-  const double *W = S.W + it.mat_off;
+  const double *W = S.W + it.mat_off + r;     // the tile's panel: [p - first][r], rows ldw apart
   const int ldw = it.ld;
   const int *piv = S.piv_idx + it.piv_ptr;
   const int *upd = S.upd_idx + it.upd_ptr;
@@ -1026,7 +1026,7 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
   // columns of a tile starting at c0 are zero in the rows above c0 (L11^-1 is lower triangular)
   for (int p0 = it.first + wv * SPD_CH; p0 < m; p0 += NW * SPD_CH) {
     const int pn = min(SPD_CH, m - p0);
-    const double *wp = W + (size_t)p0 * ldw + k;
+    const double *wp = W + (size_t)(p0 - it.first) * ldw;
     double w0[NB];
     const bool full0 = PRE && kq + (NB - 1) * KQ < pn;
     if (valid && full0) {
