@@ -73,11 +73,11 @@ void SpdSolverDev::upload(int dcols) {
   };
   for (const auto &lvl : F.by_height) fwd_level_bytes.push_back(lvl_bytes(lvl));
   for (const auto &lvl : F.by_depth) bwd_level_bytes.push_back(lvl_bytes(lvl));
-  // per level: first the tiles of small fronts (one wave each), then the tiles of wide fronts
-  // (8 waves each, columns / rows split between the waves).
+  // two classes of tiles: small fronts (one wave per tile) and wide fronts (8 waves per tile, the columns /
+  // rows of the reduction split between the waves).
   // The reduction length decides: columns (w) in the forward sweep, rows (w+u) in the backward sweep.
   auto wide = [&](int f, bool fwd) { return (fwd ? F.w[f] : F.w[f] + F.u[f]) > 96; };
-  // a level whose narrow class is small is not worth a launch of its own: its tiles join the wide class
+  // a small narrow class joins the wide class (whole workgroups are cheap when there are few of them)
   auto tiles64 = [&](const std::vector<int> &lvl, bool fwd, bool want_wide) {
     int cnt = 0;
     for (int f : lvl)
@@ -86,12 +86,12 @@ void SpdSolverDev::upload(int dcols) {
   };
   const int MERGE_BELOW = 1024, FINE_BELOW = 512;
   struct Tile { int f, first, count, rows; int64_t len; };   // rows: tile height of its class; len: panel rows
-  auto sweep = [&](bool fwd, std::vector<int> &level_ptr, std::vector<int> &big_ptr, std::vector<int> &rows_of_level,
-                   DevBuf<SpdItem> &items_dev, DevBuf<double> &panels_dev) {
+  auto sweep = [&](bool fwd, std::vector<int> &level_ptr, std::vector<int> &rows_of_level, DevBuf<SpdItem> &items_dev,
+                   DevBuf<int4> &packs_dev, DevBuf<double> &panels_dev) {
     const auto &levels = fwd ? F.by_height : F.by_depth;
     std::vector<Tile> tiles;
+    std::vector<int4> packs;
     level_ptr.assign(1, 0);
-    big_ptr.clear();
     rows_of_level.clear();
     for (const auto &lvl : levels) {
       const bool merge = tiles64(lvl, fwd, true) > 0 && tiles64(lvl, fwd, false) < MERGE_BELOW;
@@ -99,8 +99,8 @@ void SpdSolverDev::upload(int dcols) {
       const int wide_tiles = tiles64(lvl, fwd, true) + (merge ? tiles64(lvl, fwd, false) : 0);
       const int rows = (wide_tiles > 0 && wide_tiles < FINE_BELOW) ? 16 : 64;
       rows_of_level.push_back(rows);
-      for (int pass = 0; pass < 2; pass++) {
-        if (pass == 1) big_ptr.push_back((int)tiles.size());
+      // wide tiles first (one workgroup each), then the narrow ones in packs of 8 (one wave each)
+      for (int pass = 1; pass >= 0; pass--) {
         const size_t begin = tiles.size();
         const int th = pass == 1 ? rows : 64;
         for (int f : lvl) {
@@ -114,8 +114,13 @@ void SpdSolverDev::upload(int dcols) {
           }
         }
         std::stable_sort(tiles.begin() + begin, tiles.end(), [](const Tile &x, const Tile &y) { return x.len * x.count > y.len * y.count; });
+        const int end = (int)tiles.size();
+        if (pass == 1)
+          for (int i = (int)begin; i < end; i++) packs.push_back(make_int4(i, 1, 1, 0));
+        else
+          for (int i = (int)begin; i < end; i += 8) packs.push_back(make_int4(i, std::min(8, end - i), 0, 0));
       }
-      level_ptr.push_back((int)tiles.size());
+      level_ptr.push_back((int)packs.size());
     }
     // panel offsets
     std::vector<SpdItem> items(tiles.size());
@@ -151,10 +156,13 @@ void SpdSolverDev::upload(int dcols) {
       }
     }
     items_dev.upload(items);
+    packs_dev.upload(packs);
     panels_dev.upload(panels);
   };
-  sweep(true, fwd_level_ptr, fwd_big_ptr, fwd_rows, fwd_items, WT);
-  sweep(false, bwd_level_ptr, bwd_big_ptr, bwd_rows, bwd_items, W);
+  sweep(true, fwd_level_ptr, fwd_rows, fwd_items, fwd_packs, WT);
+  sweep(false, bwd_level_ptr, bwd_rows, bwd_items, bwd_packs, W);
+  dev.fwd_packs = fwd_packs.p;
+  dev.bwd_packs = bwd_packs.p;
   dev.piv_idx = piv_idx.p; dev.upd_idx = upd_idx.p; dev.asm_ptr = asm_ptr.p; dev.asm_src = asm_src.p;
   dev.W = W.p; dev.WT = WT.p; dev.fwd_items = fwd_items.p; dev.bwd_items = bwd_items.p; dev.ubuf = ubuf.p;
 }
@@ -539,22 +547,12 @@ void Group::copy_rows(double *dst, const double *src, bool all_rows, int part) {
 }
 
 static void spd_run(int d, hipStream_t st, SpdSolverDev &S, double *vec, double scale) {
-  const int nf = (int)S.fwd_level_ptr.size() - 1;
-  for (int l = 0; l < nf; l++) {
-    const int a = S.fwd_level_ptr[l], mid = S.fwd_big_ptr[l], b = S.fwd_level_ptr[l + 1];
-    const double bytes = S.fwd_level_bytes[l], tot = std::max(b - a, 1);
-    launch_spd_level(d, S.dof, st, S.dev, true, a, mid - a, vec, S.ytmp.p, scale, bytes * (mid - a) / tot, 1);
-    launch_spd_level(d, S.dof, st, S.dev, true, mid, b - mid, vec, S.ytmp.p, scale, bytes * (b - mid) / tot,
-                     S.fwd_rows[l] == 16 ? -8 : 8);
-  }
-  const int nb = (int)S.bwd_level_ptr.size() - 1;
-  for (int l = 0; l < nb; l++) {
-    const int a = S.bwd_level_ptr[l], mid = S.bwd_big_ptr[l], b = S.bwd_level_ptr[l + 1];
-    const double bytes = S.bwd_level_bytes[l], tot = std::max(b - a, 1);
-    launch_spd_level(d, S.dof, st, S.dev, false, a, mid - a, vec, S.ytmp.p, scale, bytes * (mid - a) / tot, 1);
-    launch_spd_level(d, S.dof, st, S.dev, false, mid, b - mid, vec, S.ytmp.p, scale, bytes * (b - mid) / tot,
-                     S.bwd_rows[l] == 16 ? -8 : 8);
-  }
+  for (size_t l = 0; l + 1 < S.fwd_level_ptr.size(); l++)
+    launch_spd_level(d, S.dof, st, S.dev, true, S.fwd_level_ptr[l], S.fwd_level_ptr[l + 1] - S.fwd_level_ptr[l], S.fwd_rows[l], vec,
+                     S.ytmp.p, scale, S.fwd_level_bytes[l]);
+  for (size_t l = 0; l + 1 < S.bwd_level_ptr.size(); l++)
+    launch_spd_level(d, S.dof, st, S.dev, false, S.bwd_level_ptr[l], S.bwd_level_ptr[l + 1] - S.bwd_level_ptr[l], S.bwd_rows[l], vec,
+                     S.ytmp.p, scale, S.bwd_level_bytes[l]);
 }
 
 // DPGO_SPD_DUMP=1: time every launch of one solve on a zero vector (HIP events, best of 5) and print its
@@ -565,27 +563,18 @@ static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec) {
   HIP_CHECK(hipEventCreate(&e0));
   HIP_CHECK(hipEventCreate(&e1));
   double tot_us = 0, tot_mb = 0;
-  auto run = [&](bool fwd, size_t l, int a, int b, int nwaves, const char *cls, const std::vector<int> &fronts) {
+  auto run = [&](bool fwd, size_t l, const std::vector<int> &ptr, int rows, const std::vector<int> &fronts, double bytes) {
+    const int a = ptr[l], b = ptr[l + 1];
     if (b <= a) return;
-    // bytes of the fronts that own the tiles [a, b)
-    std::vector<SpdItem> items((size_t)(b - a));
-    HIP_CHECK(hipMemcpy(items.data(), (fwd ? S.fwd_items.p : S.bwd_items.p) + a, sizeof(SpdItem) * (b - a), hipMemcpyDeviceToHost));
-    double bytes = 0;
-    int wmax = 0, mmax = 0, nfr = 0;
-    std::vector<char> seen(F.nfronts, 0);
-    for (const SpdItem &it : items) {
-      if (seen[it.front]) continue;
-      seen[it.front] = 1;
-      nfr++;
-      const double w = it.w, u = it.u;
-      bytes += 8.0 * (u * w + 0.5 * w * (w + 1)) + 2.0 * 8.0 * d * (w + u);
-      wmax = std::max(wmax, it.w);
-      mmax = std::max(mmax, it.w + it.u);
-    }
+    std::vector<int4> packs((size_t)(b - a));
+    HIP_CHECK(hipMemcpy(packs.data(), (fwd ? S.fwd_packs.p : S.bwd_packs.p) + a, sizeof(int4) * (b - a), hipMemcpyDeviceToHost));
+    int wide = 0, narrow = 0, wmax = 0, mmax = 0;
+    for (const int4 &p : packs) (p.z ? wide : narrow) += p.y;
+    for (int f : fronts) { wmax = std::max(wmax, F.w[f]); mmax = std::max(mmax, F.w[f] + F.u[f]); }
     float best = 1e30f;
     for (int rep = 0; rep < 6; rep++) {
       HIP_CHECK(hipEventRecord(e0, st));
-      launch_spd_level(d, S.dof, st, S.dev, fwd, a, b - a, vec, S.ytmp.p, 1.0, 0.0, nwaves);
+      launch_spd_level(d, S.dof, st, S.dev, fwd, a, b - a, rows, vec, S.ytmp.p, 1.0, 0.0);
       HIP_CHECK(hipEventRecord(e1, st));
       HIP_CHECK(hipEventSynchronize(e1));
       float ms;
@@ -594,17 +583,11 @@ static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec) {
     }
     tot_us += best * 1e3;
     tot_mb += bytes / 1e6;
-    fprintf(stderr, "[spd] dof %d %s level %2zu %-7s fronts %5d tiles %5d max_w %4d max_m %4d  %7.2f MB %6.1f us %6.0f GB/s\n",
-            S.dof, fwd ? "fwd" : "bwd", l, cls, nfr, b - a, wmax, mmax, bytes / 1e6, best * 1e3, bytes / (best * 1e-3) / 1e9);
+    fprintf(stderr, "[spd] dof %d %s level %2zu fronts %5zu wide tiles %5d x %2d rows, narrow tiles %5d, max_w %4d max_m %4d  %7.2f MB %6.1f us %6.0f GB/s\n",
+            S.dof, fwd ? "fwd" : "bwd", l, fronts.size(), wide, rows, narrow, wmax, mmax, bytes / 1e6, best * 1e3, bytes / (best * 1e-3) / 1e9);
   };
-  for (size_t l = 0; l + 1 < S.fwd_level_ptr.size(); l++) {
-    run(true, l, S.fwd_level_ptr[l], S.fwd_big_ptr[l], 1, "narrow", F.by_height[l]);
-    run(true, l, S.fwd_big_ptr[l], S.fwd_level_ptr[l + 1], S.fwd_rows[l] == 16 ? -8 : 8, S.fwd_rows[l] == 16 ? "wide16" : "wide64", F.by_height[l]);
-  }
-  for (size_t l = 0; l + 1 < S.bwd_level_ptr.size(); l++) {
-    run(false, l, S.bwd_level_ptr[l], S.bwd_big_ptr[l], 1, "narrow", F.by_depth[l]);
-    run(false, l, S.bwd_big_ptr[l], S.bwd_level_ptr[l + 1], S.bwd_rows[l] == 16 ? -8 : 8, S.bwd_rows[l] == 16 ? "wide16" : "wide64", F.by_depth[l]);
-  }
+  for (size_t l = 0; l + 1 < S.fwd_level_ptr.size(); l++) run(true, l, S.fwd_level_ptr, S.fwd_rows[l], F.by_height[l], S.fwd_level_bytes[l]);
+  for (size_t l = 0; l + 1 < S.bwd_level_ptr.size(); l++) run(false, l, S.bwd_level_ptr, S.bwd_rows[l], F.by_depth[l], S.bwd_level_bytes[l]);
   fprintf(stderr, "[spd] dof %d total %.1f MB %.1f us %.0f GB/s (launches timed one by one)\n", S.dof, tot_mb, tot_us, tot_mb / tot_us * 1e3);
   HIP_CHECK(hipEventDestroy(e0));
   HIP_CHECK(hipEventDestroy(e1));

@@ -87,8 +87,8 @@ struct SpdSolverDev {
   DevBuf<int> piv_idx, upd_idx, asm_ptr, asm_src;
   DevBuf<double> W, WT, ubuf, ytmp;   // W / WT: backward / forward panels (see upload)
   DevBuf<SpdItem> fwd_items, bwd_items;
-  std::vector<int> fwd_level_ptr, bwd_level_ptr;  // item ranges per level
-  std::vector<int> fwd_big_ptr, bwd_big_ptr;      // first wide-front item of each level
+  DevBuf<int4> fwd_packs, bwd_packs;
+  std::vector<int> fwd_level_ptr, bwd_level_ptr;  // pack ranges per level (one launch each)
   std::vector<int> fwd_rows, bwd_rows;            // tile height of the wide class per level (64 or 16)
   std::vector<double> fwd_level_bytes, bwd_level_bytes;
   SpdDev dev;

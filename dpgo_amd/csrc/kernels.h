@@ -139,14 +139,15 @@ struct SpdDev {
   const int *asm_ptr = nullptr, *asm_src = nullptr;   // per front position: rows of the update buffer to add
   const double *W = nullptr, *WT = nullptr;           // panels of the backward / forward tiles
   const SpdItem *fwd_items = nullptr, *bwd_items = nullptr;
+  const int4 *fwd_packs = nullptr, *bwd_packs = nullptr;   // {first tile, tiles (1..8), wide?, 0}: one workgroup each
   double *ubuf = nullptr;
 };
-// One level of the forward / backward sweep.  dof = 1: unknown i is the translation of pose i;
-// dof = d: unknown i = (pose i / d, rotation row i % d).  vec is a record array, solved in place.
-// forward reads the right-hand side from vec and writes y to ytmp (n x d, matrix order); backward
-// reads ytmp and writes scale * A^-1 b into vec (scale must be +1 or -1).
-void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int item0, int nitems,
-                      double *vec, double *ytmp, double scale, double level_bytes = 0.0, int nwaves = 1);
+// One level of the forward / backward sweep: packs [pack0, pack0 + npacks), wide tiles `rows` (64 or 16) high.
+// dof = 1: unknown i is the translation of pose i; dof = d: unknown i = (pose i / d, rotation row i % d).
+// vec is a record array, solved in place: forward reads the right-hand side from vec and writes y to ytmp
+// (n x d, matrix order); backward reads ytmp and writes scale * A^-1 b into vec (scale must be +1 or -1).
+void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int pack0, int npacks, int rows,
+                      double *vec, double *ytmp, double scale, double level_bytes = 0.0);
 
 // ---- optional per-launch timing (HIP events on the launch stream), off by default ----
 enum ProfKind { PK_BSR = 0, PK_INTER, PK_PROX, PK_AXPBY, PK_DOT, PK_ROTOP, PK_COPYIDX, PK_BDIAG, PK_REDUCE,

@@ -841,7 +841,7 @@ __global__ __launch_bounds__(64) void k_reduce(SegTable T, int all_rows, int nsl
 //     list order (the order of the host solve: results do not depend on the schedule).
 // ---------------------------------------------------------------------------
 #ifndef SPD_WPE
-#define SPD_WPE 8    // waves per SIMD the 64-row solve kernels are compiled for (register budget)
+#define SPD_WPE 6    // waves per SIMD the 64-row solve kernels are compiled for: 85 VGPRs, 3 workgroups per CU (measured best of 5, 6, 8)
 #endif
 template <int D, int DOF>
 __device__ __forceinline__ size_t vaddr(int i) {
@@ -999,15 +999,6 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
 }
 
 template <int D, int DOF, int NW, int SPD_CH, int ROWS>
-__global__ __launch_bounds__(64 * NW, ROWS == 64 ? SPD_WPE : 4) void k_spd_fwd(SpdDev S, int item0, const double *vec, double *ytmp) {
-  __shared__ double f[NW][SPD_CH * D];
-  __shared__ double red[(NW > 1 ? NW : 1) * ROWS * D];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const SpdItem it = load_item(S.fwd_items + item0 + blockIdx.x);
-  spd_fwd_tile<D, DOF, NW, SPD_CH, ROWS>(S, it, vec, ytmp, f[wv], red, wv, lane);
-}
-
-template <int D, int DOF, int NW, int SPD_CH, int ROWS>
 __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it, double scale, const double *ytmp,
                                              double *vec, double *fw, double *red, const int wv, const int lane) {
   constexpr int KQ = 64 / ROWS, NB = 16;
@@ -1103,14 +1094,28 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
   for (int c = 0; c < D; c++) *(dst + c) = (scale * acc[c]);
 }
 
-template <int D, int DOF, int NW, int SPD_CH, int ROWS>
-__global__ __launch_bounds__(64 * NW, ROWS == 64 ? SPD_WPE : 4) void k_spd_bwd(SpdDev S, int item0, double scale, const double *ytmp,
-                                                     double *vec) {
-  __shared__ double f[NW][SPD_CH * D];
-  __shared__ double red[(NW > 1 ? NW : 1) * ROWS * D];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const SpdItem it = load_item(S.bwd_items + item0 + blockIdx.x);
-  spd_bwd_tile<D, DOF, NW, SPD_CH, ROWS>(S, it, scale, ytmp, vec, f[wv], red, wv, lane);
+// One level of a sweep in one launch.  A workgroup (8 waves) draws a PACK: either one tile of a wide front,
+// shared by the 8 waves (ROWS-row tiles), or up to 8 tiles of narrow fronts (reduction length <= 96), one
+// per wave.  Wide packs come first, longest first; the narrow ones fill the tail of the launch.
+template <int D, int DOF, int ROWS, bool FWD>
+__global__ __launch_bounds__(512, ROWS == 64 ? SPD_WPE : 4) void k_spd_level(SpdDev S, int pack0, double scale, double *vec,
+                                                                           double *ytmp) {
+  constexpr int CH = 128;
+  __shared__ double f[8][CH * D];
+  __shared__ double red[8 * ROWS * D];
+  const int4 pk = (FWD ? S.fwd_packs : S.bwd_packs)[pack0 + blockIdx.x];   // {first tile, tiles, wide?, 0}
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const SpdItem *items = FWD ? S.fwd_items : S.bwd_items;
+  if (pk.z == 0) {
+    if (wv >= pk.y) return;
+    const SpdItem it = load_item(items + pk.x + wv);
+    if constexpr (FWD) spd_fwd_tile<D, DOF, 1, CH, 64>(S, it, vec, ytmp, f[wv], red, 0, lane);
+    else spd_bwd_tile<D, DOF, 1, CH, 64>(S, it, scale, ytmp, vec, f[wv], red, 0, lane);
+  } else {
+    const SpdItem it = load_item(items + pk.x);
+    if constexpr (FWD) spd_fwd_tile<D, DOF, 8, CH, ROWS>(S, it, vec, ytmp, f[wv], red, wv, lane);
+    else spd_bwd_tile<D, DOF, 8, CH, ROWS>(S, it, scale, ytmp, vec, f[wv], red, wv, lane);
+  }
 }
 
 }  // namespace
@@ -1357,24 +1362,21 @@ void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows,
   hipLaunchKernelGGL(k_reduce, dim3(nnodes), dim3(64), 0, st, T, all_rows ? 1 : 0, nslots, partials, node_scalars);
 }
 
-void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int item0, int nitems,
-                      double *vec, double *ytmp, double scale, double level_bytes, int nwaves) {
-  // nwaves: 1 = narrow fronts (one wave per 64-row tile), 8 = wide fronts (8 waves per 64-row tile),
-  //         -8 = wide fronts of a sparsely populated level (8 waves per 16-row tile)
-  if (nitems == 0) return;
+void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int pack0, int npacks, int rows,
+                      double *vec, double *ytmp, double scale, double level_bytes) {
+  if (npacks == 0) return;
   ProfScope ps(forward ? PK_SPD_FWD : PK_SPD_BWD, st, level_bytes);
-#define SPD_LAUNCH(DOFV, NWV, ROWSV)                                                                           \
+#define SPD_LAUNCH(DOFV, ROWSV)                                                                                  \
   do {                                                                                                         \
     if (forward)                                                                                               \
-      hipLaunchKernelGGL((k_spd_fwd<D, DOFV, NWV, 128, ROWSV>), dim3(nitems), dim3(64 * NWV), 0, st, S, item0, vec, ytmp); \
+      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, true>), dim3(npacks), dim3(512), 0, st, S, pack0, scale, vec, ytmp);  \
     else                                                                                                       \
-      hipLaunchKernelGGL((k_spd_bwd<D, DOFV, NWV, 128, ROWSV>), dim3(nitems), dim3(64 * NWV), 0, st, S, item0, scale, ytmp, vec); \
+      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, false>), dim3(npacks), dim3(512), 0, st, S, pack0, scale, vec, ytmp); \
   } while (0)
-#define SPD_PICK(DOFV)                            \
-  do {                                            \
-    if (nwaves == 1) SPD_LAUNCH(DOFV, 1, 64);     \
-    else if (nwaves == -8) SPD_LAUNCH(DOFV, 8, 16); \
-    else SPD_LAUNCH(DOFV, 8, 64);                 \
+#define SPD_PICK(DOFV)                  \
+  do {                                  \
+    if (rows == 16) SPD_LAUNCH(DOFV, 16); \
+    else SPD_LAUNCH(DOFV, 64);          \
   } while (0)
   DPGO_DISPATCH_D(d, {
     if (dof == 1) SPD_PICK(1);
