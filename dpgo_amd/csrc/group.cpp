@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <set>
@@ -304,10 +305,12 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   HIP_CHECK(hipHostMalloc((void **)&h_mask_, sizeof(int) * std::max(L, 1) * RING));
   HIP_CHECK(hipHostMalloc((void **)&h_coef_, sizeof(double) * std::max(L, 1) * RING));
   cur_mask_ = mask_ring_.p;
-  HIP_CHECK(hipHostMalloc((void **)&h_scal_, sizeof(double) * std::max(L, 1) * MAX_SLOTS));
+  HIP_CHECK(hipHostMalloc((void **)&h_scal_, sizeof(double) * std::max(L, 1) * MAX_SLOTS + 128, hipHostMallocMapped | hipHostMallocCoherent));
+  h_flag_ = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(h_scal_) + sizeof(double) * std::max(L, 1) * MAX_SLOTS + 64);
+  *h_flag_ = 0;
+  reduce_arrived_.alloc(1);
   HIP_CHECK(hipHostMalloc((void **)&h_gamma_, sizeof(double) * std::max(L, 1)));
   partials_.alloc((size_t)MAX_SLOTS * std::max(T_.nseg_all, 1));
-  node_scal_.alloc((size_t)L * MAX_SLOTS);
 
   // ---- operators
   {
@@ -537,9 +540,18 @@ const double *Group::upload_coef(const std::vector<double> &per_node) {
 void Group::fetch(int nslots, bool all_rows) {
   nslots = std::max(nslots, deferred_slots_);
   deferred_slots_ = 0;
-  launch_reduce(st_, T_, num_local(), all_rows, nslots, partials_.p, node_scal_.p);
-  HIP_CHECK(hipMemcpyAsync(h_scal_, node_scal_.p, sizeof(double) * num_local() * MAX_SLOTS, hipMemcpyDeviceToHost, st_));
-  HIP_CHECK(hipStreamSynchronize(st_));
+  launch_reduce(st_, T_, num_local(), all_rows, nslots, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, ++fetch_seq_);
+  // the flag is written by the last kernel of the (in-order) stream: seeing it means everything before is done
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0; __atomic_load_n(h_flag_, __ATOMIC_ACQUIRE) != fetch_seq_; spins++) {
+    __builtin_ia32_pause();
+    if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+      HIP_CHECK(hipStreamSynchronize(st_));   // surfaces a kernel fault, if that is why the flag never came
+      if (__atomic_load_n(h_flag_, __ATOMIC_ACQUIRE) == fetch_seq_) break;
+      fprintf(stderr, "[dpgo_amd] read-back flag never arrived\n");
+      abort();
+    }
+  }
 }
 
 void Group::copy_rows(double *dst, const double *src, bool all_rows, int part) {

@@ -186,10 +186,12 @@ class Group {
   double *h_coef_ = nullptr;       // pinned, RING x L
   int coef_slot_ = 0;
   const double *upload_coef(const std::vector<double> &per_node);
-  double *h_scal_ = nullptr;       // pinned
+  double *h_scal_ = nullptr;       // pinned, written by k_reduce; the flag (one cache line further) follows the scalars
+  unsigned long long *h_flag_ = nullptr, fetch_seq_ = 0;
+  DevBuf<unsigned> reduce_arrived_;
   double *h_gamma_ = nullptr;      // pinned
   DevBuf<double> gamma_;
-  DevBuf<double> partials_, node_scal_;
+  DevBuf<double> partials_;
   struct BsrBufs { DevBuf<int> ptr, col; DevBuf<double> val; BsrDev dev; };
   BsrBufs G_, S_, P_, P0m_, Q_;
   DevBuf<double> Dd_, Qd_, Tinv_, N_, V_;

@@ -119,9 +119,10 @@ void launch_copy_indexed(int d, hipStream_t st, int count, const int *didx, cons
 void launch_bdiag_dot(int d, hipStream_t st, const SegTable &T, const int *mask, const double *Dd, const double *x,
                       double coef, const double *add, double addcoef, double *partials, int slot);
 
-// node_scalars[node * MAX_SLOTS + s] = sum of the node's partials, s < nslots
-void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows, int nslots,
-                   const double *partials, double *node_scalars);
+// host_scalars[node * MAX_SLOTS + s] = sum of the node's partials, s < nslots, written straight to pinned host
+// memory; *host_flag = seq once all of them are there (arrived: a zeroed device counter)
+void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows, int nslots, const double *partials,
+                   double *host_scalars, unsigned *arrived, unsigned long long *host_flag, unsigned long long seq);
 
 // ---- multifrontal SPD solve (spd.h) ----
 // One tile of the solve with everything it needs to know about its front: 64 bytes, one load.

@@ -813,17 +813,27 @@ __global__ __launch_bounds__(SEG_ROWS) void k_bdiag_dot(const Seg *segs, const i
   block_store<1>(pr, partial + blockIdx.x, 0);
 }
 
+// One wave per (node, slot): sums the node's per-segment partials in a fixed order and writes the scalar
+// straight into pinned host memory; the last wave to finish raises the host-visible flag to `seq`, so the
+// host gets the numbers by polling a cache line instead of a copy + stream synchronisation.
 __global__ __launch_bounds__(64) void k_reduce(SegTable T, int all_rows, int nslots, const double *partials,
-                                               double *node_scalars) {
-  const int a = blockIdx.x, lane = threadIdx.x;
-  for (int s = 0; s < nslots; s++) {
-    const double *p = partials + (size_t)s * T.nseg_all;
-    double v = 0;
-    for (int k = T.own_ptr[a] + lane; k < T.own_ptr[a + 1]; k += 64) v += p[k];
-    if (all_rows)
-      for (int k = T.nbr_ptr[a] + lane; k < T.nbr_ptr[a + 1]; k += 64) v += p[k];
-    v = wave_sum(v);
-    if (lane == 0) node_scalars[a * MAX_SLOTS + s] = v;
+                                               double *host_scalars, unsigned *arrived, unsigned long long *host_flag,
+                                               unsigned long long seq) {
+  const int a = blockIdx.x / nslots, s = blockIdx.x % nslots, lane = threadIdx.x;
+  const double *p = partials + (size_t)s * T.nseg_all;
+  double v = 0;
+  for (int k = T.own_ptr[a] + lane; k < T.own_ptr[a + 1]; k += 64) v += p[k];
+  if (all_rows)
+    for (int k = T.nbr_ptr[a] + lane; k < T.nbr_ptr[a + 1]; k += 64) v += p[k];
+  v = wave_sum(v);
+  if (lane == 0) {
+    __hip_atomic_store(host_scalars + a * MAX_SLOTS + s, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __atomic_thread_fence(__ATOMIC_RELEASE);   // system scope: the scalar is on its way before the count
+    const unsigned done = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (done == gridDim.x - 1) {
+      __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -1356,10 +1366,11 @@ void launch_bdiag_dot(int d, hipStream_t st, const SegTable &T, const int *mask,
                                         coef, add, addcoef, partials + (size_t)slot * T.nseg_all));
 }
 
-void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows, int nslots,
-                   const double *partials, double *node_scalars) {
+void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows, int nslots, const double *partials,
+                   double *host_scalars, unsigned *arrived, unsigned long long *host_flag, unsigned long long seq) {
   ProfScope ps(PK_REDUCE, st, 8.0 * nslots * T.nseg_all);
-  hipLaunchKernelGGL(k_reduce, dim3(nnodes), dim3(64), 0, st, T, all_rows ? 1 : 0, nslots, partials, node_scalars);
+  hipLaunchKernelGGL(k_reduce, dim3(nnodes * nslots), dim3(64), 0, st, T, all_rows ? 1 : 0, nslots, partials, host_scalars,
+                     arrived, host_flag, seq);
 }
 
 void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int pack0, int npacks, int rows,
