@@ -67,6 +67,9 @@ def main():
                     help="diagnostic: host only the nodes rank --emulate-rank would own in an N-GPU run, with frozen "
                          "neighbours and no exchange, to see the per-GPU step time of that run on one GPU")
     ap.add_argument("--emulate-rank", type=int, default=0)
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="diagnostic: run the boundary exchange (pack, all-gather, unpack) even with one rank, to see "
+                         "what it adds to a step")
     args = ap.parse_args()
 
     import torch
@@ -85,9 +88,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     host_staged = args.backend == "gloo"
-    if world > 1:
+    do_exchange = world > 1 or args.force_exchange
+    if do_exchange:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if host_staged:
             dist.init_process_group("gloo")
         else:
@@ -115,8 +122,11 @@ def main():
         raise SystemExit("initialize failed")
 
     RS = (G.d + 1) * G.d
-    send = gathered = None
-    if world > 1:
+    send = gathered = ext = None
+    if do_exchange:
+        # everything the exchange enqueues goes on the group's own stream: the step stays stream-ordered, the
+        # host never waits for the collective
+        ext = torch.cuda.ExternalStream(grp.stream())
         keys = grp.sent_keys()
         allkeys = [None] * world
         dist.all_gather_object(allkeys, (keys[0].tolist(), keys[1].tolist()))
@@ -127,20 +137,20 @@ def main():
         if host_staged:
             send_h = torch.zeros(stride * RS, dtype=torch.float64)
             gathered_h = torch.zeros(world * stride * RS, dtype=torch.float64)
+        torch.cuda.synchronize()
 
     def exchange():
         grp.communicate_local()
-        if world > 1:
-            grp.pack_sent(send.data_ptr())
-            grp.sync()                                   # pack runs on the group's stream
-            if host_staged:
-                send_h.copy_(send)
-                dist.all_gather_into_tensor(gathered_h, send_h)
-                gathered.copy_(gathered_h)
-            else:
-                dist.all_gather_into_tensor(gathered, send)  # RCCL over xGMI
-            torch.cuda.current_stream().synchronize()
-            grp.unpack_recv(gathered.data_ptr())
+        if do_exchange:
+            with torch.cuda.stream(ext):
+                grp.pack_sent(send.data_ptr())
+                if host_staged:
+                    send_h.copy_(send)
+                    dist.all_gather_into_tensor(gathered_h, send_h)
+                    gathered.copy_(gathered_h)
+                else:
+                    dist.all_gather_into_tensor(gathered, send)  # RCCL over xGMI; the stream waits, not the host
+                grp.unpack_recv(gathered.data_ptr())
 
     def step():
         rc = grp.iterate()
@@ -235,7 +245,7 @@ def main():
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if do_exchange:
         dist.destroy_process_group()
 
 

@@ -85,7 +85,9 @@ void SpdSolverDev::upload(int dcols) {
       if (wide(f, fwd) == want_wide) cnt += ((fwd ? F.w[f] + F.u[f] : F.w[f]) + 63) / 64;
     return cnt;
   };
-  const int MERGE_BELOW = 1024, FINE_BELOW = 512;
+  int MERGE_BELOW = 1024, FINE_BELOW = 512;
+  if (const char *e = getenv("DPGO_SPD_FINE")) FINE_BELOW = atoi(e);     // tuning hooks
+  if (const char *e = getenv("DPGO_SPD_MERGE")) MERGE_BELOW = atoi(e);
   struct Tile { int f, first, count, rows; int64_t len; };   // rows: tile height of its class; len: panel rows
   auto sweep = [&](bool fwd, std::vector<int> &level_ptr, std::vector<int> &rows_of_level, DevBuf<SpdItem> &items_dev,
                    DevBuf<int4> &packs_dev, DevBuf<double> &panels_dev) {
