@@ -850,6 +850,13 @@ __global__ __launch_bounds__(64) void k_reduce(SegTable T, int all_rows, int nsl
 //   * the pull lists (children's update rows to add) are read two entries at a time, added in
 //     list order (the order of the host solve: results do not depend on the schedule).
 // ---------------------------------------------------------------------------
+// the panels are read once per solve: non-temporal loads keep them from displacing the operators and
+// vectors that the kernels between two solves re-read (L2 / Infinity Cache)
+#ifdef SPD_PLAIN_LOADS
+#define LDW(p) (*(p))
+#else
+#define LDW(p) __builtin_nontemporal_load(p)
+#endif
 #ifndef SPD_WPE
 #define SPD_WPE 6    // waves per SIMD the 64-row solve kernels are compiled for: 85 VGPRs, 3 workgroups per CU (measured best of 5, 6, 8)
 #endif
@@ -920,7 +927,7 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
     const bool full0 = PRE && kq + (NB - 1) * KQ < kn;
     if (valid && full0) {
 #pragma unroll
-      for (int q = 0; q < NB; q++) w0[q] = wp[(size_t)(kq + q * KQ) * ldm];
+      for (int q = 0; q < NB; q++) w0[q] = LDW(wp + (size_t)(kq + q * KQ) * ldm);
     }
     for (int kk = lane; kk < kn; kk += 64) {
       const int k = k0 + kk;
@@ -947,7 +954,7 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
       for (; kk + (NB - 1) * KQ < kn; kk += NB * KQ) {
         double wb[NB];
 #pragma unroll
-        for (int q = 0; q < NB; q++) wb[q] = wp[(size_t)(kk + q * KQ) * ldm];
+        for (int q = 0; q < NB; q++) wb[q] = LDW(wp + (size_t)(kk + q * KQ) * ldm);
 #pragma unroll
         for (int q = 0; q < NB; q++)
 #pragma unroll
@@ -956,7 +963,7 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
       if (kk < kn) {   // the rest: one predicated batch (the loads are independent, never one at a time)
         double wb[NB];
 #pragma unroll
-        for (int q = 0; q < NB; q++) wb[q] = kk + q * KQ < kn ? wp[(size_t)(kk + q * KQ) * ldm] : 0.0;
+        for (int q = 0; q < NB; q++) wb[q] = kk + q * KQ < kn ? LDW(wp + (size_t)(kk + q * KQ) * ldm) : 0.0;
 #pragma unroll
         for (int q = 0; q < NB; q++)
           if (kk + q * KQ < kn) {
@@ -1032,7 +1039,7 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
     const bool full0 = PRE && kq + (NB - 1) * KQ < pn;
     if (valid && full0) {
 #pragma unroll
-      for (int q = 0; q < NB; q++) w0[q] = wp[(size_t)(kq + q * KQ) * ldw];
+      for (int q = 0; q < NB; q++) w0[q] = LDW(wp + (size_t)(kq + q * KQ) * ldw);
     }
     for (int pp = lane; pp < pn; pp += 64) {
       const int p = p0 + pp;
@@ -1056,7 +1063,7 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
       for (; pp + (NB - 1) * KQ < pn; pp += NB * KQ) {
         double wb[NB];
 #pragma unroll
-        for (int q = 0; q < NB; q++) wb[q] = wp[(size_t)(pp + q * KQ) * ldw];
+        for (int q = 0; q < NB; q++) wb[q] = LDW(wp + (size_t)(pp + q * KQ) * ldw);
 #pragma unroll
         for (int q = 0; q < NB; q++)
 #pragma unroll
@@ -1065,7 +1072,7 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
       if (pp < pn) {
         double wb[NB];
 #pragma unroll
-        for (int q = 0; q < NB; q++) wb[q] = pp + q * KQ < pn ? wp[(size_t)(pp + q * KQ) * ldw] : 0.0;
+        for (int q = 0; q < NB; q++) wb[q] = pp + q * KQ < pn ? LDW(wp + (size_t)(pp + q * KQ) * ldw) : 0.0;
 #pragma unroll
         for (int q = 0; q < NB; q++)
           if (pp + q * KQ < pn) {
