@@ -166,6 +166,10 @@ void SpdSolverDev::upload(int dcols) {
   sweep(false, bwd_level_ptr, bwd_rows, bwd_items, bwd_packs, W);
   dev.fwd_packs = fwd_packs.p;
   dev.bwd_packs = bwd_packs.p;
+  // both panel sets of a factor this small can live in the 256 MiB Infinity Cache from one solve to the next
+  size_t keep = 96u << 20;
+  if (const char *e = getenv("DPGO_SPD_KEEP_MB")) keep = (size_t)atol(e) << 20;
+  stream_once = sizeof(double) * (W.n + WT.n) > keep;
   dev.piv_idx = piv_idx.p; dev.upd_idx = upd_idx.p; dev.asm_ptr = asm_ptr.p; dev.asm_src = asm_src.p;
   dev.W = W.p; dev.WT = WT.p; dev.fwd_items = fwd_items.p; dev.bwd_items = bwd_items.p; dev.ubuf = ubuf.p;
 }
@@ -563,10 +567,10 @@ void Group::copy_rows(double *dst, const double *src, bool all_rows, int part) {
 static void spd_run(int d, hipStream_t st, SpdSolverDev &S, double *vec, double scale) {
   for (size_t l = 0; l + 1 < S.fwd_level_ptr.size(); l++)
     launch_spd_level(d, S.dof, st, S.dev, true, S.fwd_level_ptr[l], S.fwd_level_ptr[l + 1] - S.fwd_level_ptr[l], S.fwd_rows[l], vec,
-                     S.ytmp.p, scale, S.fwd_level_bytes[l]);
+                     S.ytmp.p, scale, S.fwd_level_bytes[l], S.stream_once);
   for (size_t l = 0; l + 1 < S.bwd_level_ptr.size(); l++)
     launch_spd_level(d, S.dof, st, S.dev, false, S.bwd_level_ptr[l], S.bwd_level_ptr[l + 1] - S.bwd_level_ptr[l], S.bwd_rows[l], vec,
-                     S.ytmp.p, scale, S.bwd_level_bytes[l]);
+                     S.ytmp.p, scale, S.bwd_level_bytes[l], S.stream_once);
 }
 
 // DPGO_SPD_DUMP=1: time every launch of one solve on a zero vector (HIP events, best of 5) and print its
@@ -588,7 +592,7 @@ static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec) {
     float best = 1e30f;
     for (int rep = 0; rep < 6; rep++) {
       HIP_CHECK(hipEventRecord(e0, st));
-      launch_spd_level(d, S.dof, st, S.dev, fwd, a, b - a, rows, vec, S.ytmp.p, 1.0, 0.0);
+      launch_spd_level(d, S.dof, st, S.dev, fwd, a, b - a, rows, vec, S.ytmp.p, 1.0, 0.0, S.stream_once);
       HIP_CHECK(hipEventRecord(e1, st));
       HIP_CHECK(hipEventSynchronize(e1));
       float ms;

@@ -93,6 +93,7 @@ struct SpdSolverDev {
   std::vector<double> fwd_level_bytes, bwd_level_bytes;
   SpdDev dev;
   int dof = 1;
+  bool stream_once = true;   // panels read with non-temporal loads (see upload)
   void upload(int dcols);
 };
 

@@ -148,7 +148,7 @@ struct SpdDev {
 // vec is a record array, solved in place: forward reads the right-hand side from vec and writes y to ytmp
 // (n x d, matrix order); backward reads ytmp and writes scale * A^-1 b into vec (scale must be +1 or -1).
 void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int pack0, int npacks, int rows,
-                      double *vec, double *ytmp, double scale, double level_bytes = 0.0);
+                      double *vec, double *ytmp, double scale, double level_bytes = 0.0, bool stream_once = true);
 
 // ---- optional per-launch timing (HIP events on the launch stream), off by default ----
 enum ProfKind { PK_BSR = 0, PK_INTER, PK_PROX, PK_AXPBY, PK_DOT, PK_ROTOP, PK_COPYIDX, PK_BDIAG, PK_REDUCE,

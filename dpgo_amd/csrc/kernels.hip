@@ -850,13 +850,10 @@ __global__ __launch_bounds__(64) void k_reduce(SegTable T, int all_rows, int nsl
 //   * the pull lists (children's update rows to add) are read two entries at a time, added in
 //     list order (the order of the host solve: results do not depend on the schedule).
 // ---------------------------------------------------------------------------
-// the panels are read once per solve: non-temporal loads keep them from displacing the operators and
-// vectors that the kernels between two solves re-read (L2 / Infinity Cache)
-#ifdef SPD_PLAIN_LOADS
-#define LDW(p) (*(p))
-#else
-#define LDW(p) __builtin_nontemporal_load(p)
-#endif
+// NT: the panels are read once per solve; non-temporal loads keep a factor that cannot stay in the Infinity
+// Cache anyway from displacing what the kernels between two solves re-read (operators, vectors, and a
+// smaller factor that does fit)
+#define LDW(p) (NT ? __builtin_nontemporal_load(p) : *(p))
 #ifndef SPD_WPE
 #define SPD_WPE 6    // waves per SIMD the 64-row solve kernels are compiled for: 85 VGPRs, 3 workgroups per CU (measured best of 5, 6, 8)
 #endif
@@ -900,7 +897,7 @@ __device__ __forceinline__ void pull_updates(const SpdDev &S, int pos, double (&
 }
 
 // fw: this wave's staging area (SPD_CH * D doubles); red: NW x (ROWS * D) doubles shared by the tile's waves.
-template <int D, int DOF, int NW, int SPD_CH, int ROWS>
+template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool NT>
 __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it, const double *vec, double *ytmp,
                                              double *fw, double *red, const int wv, const int lane) {
   constexpr int KQ = 64 / ROWS, NB = 16;
@@ -1015,7 +1012,7 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
   }
 }
 
-template <int D, int DOF, int NW, int SPD_CH, int ROWS>
+template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool NT>
 __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it, double scale, const double *ytmp,
                                              double *vec, double *fw, double *red, const int wv, const int lane) {
   constexpr int KQ = 64 / ROWS, NB = 16;
@@ -1114,7 +1111,7 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
 // One level of a sweep in one launch.  A workgroup (8 waves) draws a PACK: either one tile of a wide front,
 // shared by the 8 waves (ROWS-row tiles), or up to 8 tiles of narrow fronts (reduction length <= 96), one
 // per wave.  Wide packs come first, longest first; the narrow ones fill the tail of the launch.
-template <int D, int DOF, int ROWS, bool FWD>
+template <int D, int DOF, int ROWS, bool FWD, bool NT>
 __global__ __launch_bounds__(512, ROWS == 64 ? SPD_WPE : 4) void k_spd_level(SpdDev S, int pack0, double scale, double *vec,
                                                                            double *ytmp) {
   constexpr int CH = 128;
@@ -1126,12 +1123,12 @@ __global__ __launch_bounds__(512, ROWS == 64 ? SPD_WPE : 4) void k_spd_level(Spd
   if (pk.z == 0) {
     if (wv >= pk.y) return;
     const SpdItem it = load_item(items + pk.x + wv);
-    if constexpr (FWD) spd_fwd_tile<D, DOF, 1, CH, 64>(S, it, vec, ytmp, f[wv], red, 0, lane);
-    else spd_bwd_tile<D, DOF, 1, CH, 64>(S, it, scale, ytmp, vec, f[wv], red, 0, lane);
+    if constexpr (FWD) spd_fwd_tile<D, DOF, 1, CH, 64, NT>(S, it, vec, ytmp, f[wv], red, 0, lane);
+    else spd_bwd_tile<D, DOF, 1, CH, 64, NT>(S, it, scale, ytmp, vec, f[wv], red, 0, lane);
   } else {
     const SpdItem it = load_item(items + pk.x);
-    if constexpr (FWD) spd_fwd_tile<D, DOF, 8, CH, ROWS>(S, it, vec, ytmp, f[wv], red, wv, lane);
-    else spd_bwd_tile<D, DOF, 8, CH, ROWS>(S, it, scale, ytmp, vec, f[wv], red, wv, lane);
+    if constexpr (FWD) spd_fwd_tile<D, DOF, 8, CH, ROWS, NT>(S, it, vec, ytmp, f[wv], red, wv, lane);
+    else spd_bwd_tile<D, DOF, 8, CH, ROWS, NT>(S, it, scale, ytmp, vec, f[wv], red, wv, lane);
   }
 }
 
@@ -1381,15 +1378,20 @@ void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows,
 }
 
 void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int pack0, int npacks, int rows,
-                      double *vec, double *ytmp, double scale, double level_bytes) {
+                      double *vec, double *ytmp, double scale, double level_bytes, bool stream_once) {
   if (npacks == 0) return;
   ProfScope ps(forward ? PK_SPD_FWD : PK_SPD_BWD, st, level_bytes);
-#define SPD_LAUNCH(DOFV, ROWSV)                                                                                  \
+#define SPD_LAUNCH2(DOFV, ROWSV, NTV)                                                                            \
   do {                                                                                                         \
     if (forward)                                                                                               \
-      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, true>), dim3(npacks), dim3(512), 0, st, S, pack0, scale, vec, ytmp);  \
+      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, true, NTV>), dim3(npacks), dim3(512), 0, st, S, pack0, scale, vec, ytmp);  \
     else                                                                                                       \
-      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, false>), dim3(npacks), dim3(512), 0, st, S, pack0, scale, vec, ytmp); \
+      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, false, NTV>), dim3(npacks), dim3(512), 0, st, S, pack0, scale, vec, ytmp); \
+  } while (0)
+#define SPD_LAUNCH(DOFV, ROWSV)                \
+  do {                                         \
+    if (stream_once) SPD_LAUNCH2(DOFV, ROWSV, true); \
+    else SPD_LAUNCH2(DOFV, ROWSV, false);      \
   } while (0)
 #define SPD_PICK(DOFV)                  \
   do {                                  \
@@ -1402,6 +1404,7 @@ void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forw
   });
 #undef SPD_PICK
 #undef SPD_LAUNCH
+#undef SPD_LAUNCH2
 }
 
 }  // namespace dpgo
