@@ -430,11 +430,11 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
     }
     Att.n = (int)Att.ptr.size() - 1;
     Arr.n = (int)Arr.ptr.size() - 1;
-    if (spd_factor(Att, Ltt_.F, 32, 0) != 0) return;
+    if (spd_factor(Att, Ltt_.F, 32, getenv("DPGO_SPD_COLLAPSE_TT") ? atoi(getenv("DPGO_SPD_COLLAPSE_TT")) : 0) != 0) return;
     Ltt_.dof = 1;
     Ltt_.upload(d_);
     if (Arr.n > 0) {
-      if (spd_factor(Arr, Lrr_.F, 48, 0) != 0) return;
+      if (spd_factor(Arr, Lrr_.F, 48, getenv("DPGO_SPD_COLLAPSE_RR") ? atoi(getenv("DPGO_SPD_COLLAPSE_RR")) : 0) != 0) return;
       Lrr_.dof = d_;
       Lrr_.upload(d_);
     }
