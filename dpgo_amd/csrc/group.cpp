@@ -85,9 +85,7 @@ void SpdSolverDev::upload(int dcols) {
       if (wide(f, fwd) == want_wide) cnt += ((fwd ? F.w[f] + F.u[f] : F.w[f]) + 63) / 64;
     return cnt;
   };
-  int MERGE_BELOW = 1024, FINE_BELOW = 512;
-  if (const char *e = getenv("DPGO_SPD_FINE")) FINE_BELOW = atoi(e);     // tuning hooks
-  if (const char *e = getenv("DPGO_SPD_MERGE")) MERGE_BELOW = atoi(e);
+  const int MERGE_BELOW = 1024;
   struct Tile { int f, first, count, rows; int64_t len; };   // rows: tile height of its class; len: panel rows
   auto sweep = [&](bool fwd, std::vector<int> &level_ptr, std::vector<int> &rows_of_level, DevBuf<SpdItem> &items_dev,
                    DevBuf<int4> &packs_dev, DevBuf<double> &panels_dev) {
@@ -98,9 +96,17 @@ void SpdSolverDev::upload(int dcols) {
     rows_of_level.clear();
     for (const auto &lvl : levels) {
       const bool merge = tiles64(lvl, fwd, true) > 0 && tiles64(lvl, fwd, false) < MERGE_BELOW;
-      // few wide tiles at this level: 16-row tiles put 4x more workgroups (CUs) on them
+      // Few wide tiles at this level: 16-row tiles put 4x more workgroups (CUs) on them.  A workgroup streams
+      // ~30-45 GB/s, so a level is as slow as its longest tile whenever it has fewer tiles than the chip has
+      // workgroup slots.  Forward tiles re-assemble the front's input vector once per tile, which makes small
+      // tiles expensive: 16 rows only below 192 tiles; backward tiles pay off up to 800 tiles when the
+      // reduction (front height) is long.  Thresholds from the per-launch table (DPGO_SPD_DUMP) of the
+      // headline instance at 8 and at 1 node per GPU.
       const int wide_tiles = tiles64(lvl, fwd, true) + (merge ? tiles64(lvl, fwd, false) : 0);
-      const int rows = (wide_tiles > 0 && wide_tiles < FINE_BELOW) ? 16 : 64;
+      int longest = 0;
+      for (int f : lvl) longest = std::max(longest, F.w[f] + F.u[f]);
+      const bool fine = fwd ? wide_tiles < 192 : (wide_tiles < 256 || (wide_tiles < 800 && longest >= 1000));
+      const int rows = (wide_tiles > 0 && fine) ? 16 : 64;
       rows_of_level.push_back(rows);
       // wide tiles first (one workgroup each), then the narrow ones in packs of 8 (one wave each)
       for (int pass = 1; pass >= 0; pass--) {
