@@ -127,7 +127,7 @@ void SpdSolverDev::upload(int dcols) {
         if (pass == 1)
           for (int i = (int)begin; i < end; i++) packs.push_back(make_int4(i, 1, 1, 0));
         else
-          for (int i = (int)begin; i < end; i += 8) packs.push_back(make_int4(i, std::min(8, end - i), 0, 0));
+          for (int i = (int)begin, nw = spd_pack_waves(rows); i < end; i += nw) packs.push_back(make_int4(i, std::min(nw, end - i), 0, 0));
       }
       level_ptr.push_back((int)packs.size());
     }

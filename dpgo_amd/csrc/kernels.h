@@ -147,6 +147,8 @@ struct SpdDev {
 // dof = 1: unknown i is the translation of pose i; dof = d: unknown i = (pose i / d, rotation row i % d).
 // vec is a record array, solved in place: forward reads the right-hand side from vec and writes y to ytmp
 // (n x d, matrix order); backward reads ytmp and writes scale * A^-1 b into vec (scale must be +1 or -1).
+// waves (= narrow tiles per pack) of the workgroups that run a level whose wide tiles are `rows` high
+int spd_pack_waves(int rows);
 void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int pack0, int npacks, int rows,
                       double *vec, double *ytmp, double scale, double level_bytes = 0.0, bool stream_once = true);
 

@@ -854,6 +854,11 @@ __global__ __launch_bounds__(64) void k_reduce(SegTable T, int all_rows, int nsl
 // Cache anyway from displacing what the kernels between two solves re-read (operators, vectors, and a
 // smaller factor that does fit)
 #define LDW(p) (NT ? __builtin_nontemporal_load(p) : *(p))
+// waves per workgroup of the 16-row class (16 waves per tile measured 5 % slower than 8)
+#ifndef SPD_NW16
+#define SPD_NW16 8
+#endif
+#define SPD_NW(ROWS) ((ROWS) == 16 ? SPD_NW16 : 8)
 #ifndef SPD_WPE
 #define SPD_WPE 6    // waves per SIMD the 64-row solve kernels are compiled for: 85 VGPRs, 3 workgroups per CU (measured best of 5, 6, 8)
 #endif
@@ -1112,11 +1117,11 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
 // shared by the 8 waves (ROWS-row tiles), or up to 8 tiles of narrow fronts (reduction length <= 96), one
 // per wave.  Wide packs come first, longest first; the narrow ones fill the tail of the launch.
 template <int D, int DOF, int ROWS, bool FWD, bool NT>
-__global__ __launch_bounds__(512, ROWS == 64 ? SPD_WPE : 4) void k_spd_level(SpdDev S, int pack0, double scale, double *vec,
-                                                                           double *ytmp) {
-  constexpr int CH = 128;
-  __shared__ double f[8][CH * D];
-  __shared__ double red[8 * ROWS * D];
+__global__ __launch_bounds__(64 * SPD_NW(ROWS), ROWS == 64 ? SPD_WPE : 4) void k_spd_level(SpdDev S, int pack0, double scale,
+                                                                                      double *vec, double *ytmp) {
+  constexpr int CH = 128, NW = SPD_NW(ROWS);
+  __shared__ double f[NW][CH * D];
+  __shared__ double red[NW * ROWS * D];
   const int4 pk = (FWD ? S.fwd_packs : S.bwd_packs)[pack0 + blockIdx.x];   // {first tile, tiles, wide?, 0}
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const SpdItem *items = FWD ? S.fwd_items : S.bwd_items;
@@ -1127,8 +1132,8 @@ __global__ __launch_bounds__(512, ROWS == 64 ? SPD_WPE : 4) void k_spd_level(Spd
     else spd_bwd_tile<D, DOF, 1, CH, 64, NT>(S, it, scale, ytmp, vec, f[wv], red, 0, lane);
   } else {
     const SpdItem it = load_item(items + pk.x);
-    if constexpr (FWD) spd_fwd_tile<D, DOF, 8, CH, ROWS, NT>(S, it, vec, ytmp, f[wv], red, wv, lane);
-    else spd_bwd_tile<D, DOF, 8, CH, ROWS, NT>(S, it, scale, ytmp, vec, f[wv], red, wv, lane);
+    if constexpr (FWD) spd_fwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, vec, ytmp, f[wv], red, wv, lane);
+    else spd_bwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, scale, ytmp, vec, f[wv], red, wv, lane);
   }
 }
 
@@ -1384,9 +1389,9 @@ void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forw
 #define SPD_LAUNCH2(DOFV, ROWSV, NTV)                                                                            \
   do {                                                                                                         \
     if (forward)                                                                                               \
-      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, true, NTV>), dim3(npacks), dim3(512), 0, st, S, pack0, scale, vec, ytmp);  \
+      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, true, NTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, pack0, scale, vec, ytmp);  \
     else                                                                                                       \
-      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, false, NTV>), dim3(npacks), dim3(512), 0, st, S, pack0, scale, vec, ytmp); \
+      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, false, NTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, pack0, scale, vec, ytmp); \
   } while (0)
 #define SPD_LAUNCH(DOFV, ROWSV)                \
   do {                                         \
@@ -1406,5 +1411,7 @@ void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forw
 #undef SPD_LAUNCH
 #undef SPD_LAUNCH2
 }
+
+int spd_pack_waves(int rows) { return SPD_NW(rows); }
 
 }  // namespace dpgo
