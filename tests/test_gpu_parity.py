@@ -398,3 +398,22 @@ def test_receive_messages_equal_communicate(fixtures_dir):
             np.testing.assert_array_equal(a.group[k].Xk(), b.group[k].Xk())
             assert a.group.results(k).fobj == b.group.results(k).fobj
     assert b.group[0].receive({0: np.zeros((4, 3))}) == -1      # not a neighbour -> error, as LOG(ERROR) at :77
+
+
+def test_cpp_facade_runs_the_driver_loop(fixtures_dir, golden_dir):
+    """examples/facade_mm.cpp = the reference driver loop on include/dpgo_amd.hpp (DPGO::DPGOHashGroup): its stdout
+    trace equals the golden oracle trace of BASELINE config 1 (smallGrid3D, MM-PGO, 2 nodes, 200 iterations); the
+    only difference is the chordal initialisation (host PCG vs. sparse direct), hence 1e-6."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "dpgo_amd", "facade_mm")
+    assert os.path.exists(exe), "build with __graft_entry__.build()"
+    out = subprocess.run([exe, os.path.join(fixtures_dir, "smallGrid3D.g2o"), "2", "200", "trivial", "0"], check=True,
+                         capture_output=True, text=True).stdout.strip().split("\n")
+    got = np.array([[float(v) for v in line.split(":")[1].split()] for line in out])
+    with open(os.path.join(golden_dir, "oracle_traces.json")) as fh:
+        ref = np.asarray(json.load(fh)["cases"]["config1_smallGrid3D_mm_2nodes"]["trace_2F_2gradnorm"])
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got[:, 0], ref[:, 0], rtol=1e-6)
+    np.testing.assert_allclose(got[:, 1], ref[:, 1], rtol=1e-3, atol=1e-6 * ref[0, 1])

@@ -123,3 +123,23 @@ def test_chordal_initialization_matches_oracle(fixtures_dir, name):
     np.testing.assert_allclose(X, Xo, atol=2e-8)
     star = GlobalProblem(num_poses, mm, 1, OOptions.driver())
     assert abs(star.evaluate_f(X) - star.evaluate_f(Xo)) <= 1e-8 * abs(star.evaluate_f(Xo))
+
+
+def test_cpp_facade_builds_with_plain_gxx_and_reads_partitions(fixtures_dir, tmp_path):
+    """include/dpgo_amd.hpp (the reference's C++ names over the C ABI) compiles with g++ alone -- no HIP, no
+    torch at the call site -- and its host-only part agrees with the oracle's partition (DPGOProblem n() / m())."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "facade_mm")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "examples", "facade_mm.cpp"), "-o", exe, "-L", os.path.join(root, "dpgo_amd"),
+                    "-ldpgo_amd", "-Wl,-rpath," + os.path.join(root, "dpgo_amd")], check=True)
+    path = os.path.join(fixtures_dir, "smallGrid3D.g2o")
+    out = subprocess.run([exe, "--info", path, "4"], check=True, capture_output=True, text=True).stdout.split("\n")
+    num_poses, mm = og.read_g2o_file(path)
+    _, meas, g_index = og.partition_measurements(num_poses, mm, 4)
+    assert out[0].split() == ["d", "3", "poses", str(num_poses), "edges", str(len(mm)), "nodes", "4"]
+    for a in range(4):
+        info = og.generate_data_info(a, meas[a])
+        assert out[1 + a].split() == ["node", "%d:" % a, "n", str(info.n[0]), str(info.n[1]), "m", str(info.m[0]),
+                                      str(info.m[1]), "offset", str(g_index[a][0])]
