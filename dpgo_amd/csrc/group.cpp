@@ -56,7 +56,7 @@ template struct DevBuf<Seg>;
 // stored, a wave's consecutive loads are consecutive in memory, and every tile is a pure sequential stream.
 // Within a launch the tiles are ordered by decreasing length, so the long ones start first and the short
 // ones fill the tail.
-void SpdSolverDev::upload(int dcols) {
+void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
   piv_idx.upload(F.piv_idx);
   upd_idx.upload(F.upd_idx);
   asm_ptr.upload(F.asm_ptr);
@@ -140,7 +140,9 @@ void SpdSolverDev::upload(int dcols) {
       SpdItem it;
       it.front = f; it.first = t.first; it.count = t.count; it.w = F.w[f];
       it.u = F.u[f]; it.ld = ld; it.piv_ptr = F.piv_ptr[f]; it.upd_ptr = F.upd_ptr[f];
-      it.pos_off = F.pos_off[f]; it.ubuf_off = F.ubuf_off[f]; it.pad0 = it.pad1 = 0;
+      it.pos_off = F.pos_off[f]; it.ubuf_off = F.ubuf_off[f];
+      it.node = node_of_unknown[F.piv_idx[F.piv_ptr[f]]];   // a front never spans two nodes (they are disconnected)
+      it.pad1 = 0;
       it.mat_off = total;
       it.pad2 = 0;
       items[i] = it;
@@ -438,11 +440,16 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
     Arr.n = (int)Arr.ptr.size() - 1;
     if (spd_factor(Att, Ltt_.F, 32, getenv("DPGO_SPD_COLLAPSE_TT") ? atoi(getenv("DPGO_SPD_COLLAPSE_TT")) : 0) != 0) return;
     Ltt_.dof = 1;
-    Ltt_.upload(d_);
+    std::vector<int> node_of_pose(P0_);
+    for (int a = 0; a < L; a++)
+      for (int p = 0; p < info_[a].n[0]; p++) node_of_pose[own_off_[a] + p] = a;
+    Ltt_.upload(d_, node_of_pose);
     if (Arr.n > 0) {
       if (spd_factor(Arr, Lrr_.F, 48, getenv("DPGO_SPD_COLLAPSE_RR") ? atoi(getenv("DPGO_SPD_COLLAPSE_RR")) : 0) != 0) return;
       Lrr_.dof = d_;
-      Lrr_.upload(d_);
+      std::vector<int> node_of_row((size_t)P0_ * d_);
+      for (size_t i = 0; i < node_of_row.size(); i++) node_of_row[i] = node_of_pose[i / d_];
+      Lrr_.upload(d_, node_of_row);
     }
   }
   // ---- halo lists
@@ -517,6 +524,12 @@ void Group::upload_bsr(const std::vector<const BsrMatrix *> &per_node, bool rows
   out.ptr.upload(ptr);
   out.col.upload(col);
   out.val.upload(val);
+  if (&out == &G_) {   // compact copy of the translation column for launch_bsr_tcol
+    std::vector<double> tc((size_t)ptr[nrows] * B_);
+    for (size_t k = 0; k < (size_t)ptr[nrows]; k++)
+      for (int r = 0; r < B_; r++) tc[k * B_ + r] = val[k * B_ * B_ + (size_t)r * B_];
+    out.tcol.upload(tc);
+  }
   out.dev.nrows = nrows;
   out.dev.nnzb = ptr[nrows];
   out.dev.ptr = out.ptr.p;
@@ -570,13 +583,15 @@ void Group::copy_rows(double *dst, const double *src, bool all_rows, int part) {
   launch_axpby(d_, st_, T_, all_rows, cur_mask_, 1.0, src, 0.0, nullptr, dst, part);
 }
 
-static void spd_run(int d, hipStream_t st, SpdSolverDev &S, double *vec, double scale) {
+// out <- scale * A^-1 in (the unknowns' entries of the records; everything else in `out` is left alone).
+// The forward sweep only reads `in`, the backward sweep only touches `out`: in == out solves in place.
+static void spd_run(int d, hipStream_t st, SpdSolverDev &S, const int *mask, double *in, double *out, double scale) {
   for (size_t l = 0; l + 1 < S.fwd_level_ptr.size(); l++)
-    launch_spd_level(d, S.dof, st, S.dev, true, S.fwd_level_ptr[l], S.fwd_level_ptr[l + 1] - S.fwd_level_ptr[l], S.fwd_rows[l], vec,
-                     S.ytmp.p, scale, S.fwd_level_bytes[l], S.stream_once);
+    launch_spd_level(d, S.dof, st, S.dev, true, S.fwd_level_ptr[l], S.fwd_level_ptr[l + 1] - S.fwd_level_ptr[l], S.fwd_rows[l], in,
+                     S.ytmp.p, scale, S.fwd_level_bytes[l], S.stream_once, mask);
   for (size_t l = 0; l + 1 < S.bwd_level_ptr.size(); l++)
-    launch_spd_level(d, S.dof, st, S.dev, false, S.bwd_level_ptr[l], S.bwd_level_ptr[l + 1] - S.bwd_level_ptr[l], S.bwd_rows[l], vec,
-                     S.ytmp.p, scale, S.bwd_level_bytes[l], S.stream_once);
+    launch_spd_level(d, S.dof, st, S.dev, false, S.bwd_level_ptr[l], S.bwd_level_ptr[l + 1] - S.bwd_level_ptr[l], S.bwd_rows[l], out,
+                     S.ytmp.p, scale, S.bwd_level_bytes[l], S.stream_once, mask);
 }
 
 // DPGO_SPD_DUMP=1: time every launch of one solve on a zero vector (HIP events, best of 5) and print its
@@ -598,7 +613,7 @@ static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec) {
     float best = 1e30f;
     for (int rep = 0; rep < 6; rep++) {
       HIP_CHECK(hipEventRecord(e0, st));
-      launch_spd_level(d, S.dof, st, S.dev, fwd, a, b - a, rows, vec, S.ytmp.p, 1.0, 0.0, S.stream_once);
+      launch_spd_level(d, S.dof, st, S.dev, fwd, a, b - a, rows, vec, S.ytmp.p, 1.0, 0.0, S.stream_once, nullptr);
       HIP_CHECK(hipEventRecord(e1, st));
       HIP_CHECK(hipEventSynchronize(e1));
       float ms;
@@ -617,14 +632,23 @@ static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec) {
   HIP_CHECK(hipEventDestroy(e1));
 }
 
-void Group::solve_tt(double *vec, double scale) { spd_run(d_, st_, Ltt_, vec, scale); }
-void Group::solve_rr(double *vec, double scale) { spd_run(d_, st_, Lrr_, vec, scale); }
+// (fronts of nodes outside the current mask are skipped: their entries of `out` stay as they are)
+void Group::solve_tt(double *vec, double scale) { spd_run(d_, st_, Ltt_, cur_mask_, vec, vec, scale); }
+void Group::solve_tt(double *in, double *out, double scale) { spd_run(d_, st_, Ltt_, cur_mask_, in, out, scale); }
+void Group::solve_rr(double *vec, double scale) { spd_run(d_, st_, Lrr_, cur_mask_, vec, vec, scale); }
 
 // X.t = -G_tt^-1 (g_t + G_tR X.R)    (DPGOProblem.h:275-294)
+// Leaves T1_ = G [0 ; X.R] + g on all rows (its translation rows are the right-hand side of the solve):
+// with the new translations, G X + g = T1_ + G_{:,t} X.t, which apply_tcol() adds at a quarter of the
+// cost of another G X.
 void Group::recover_translations(double *X, const double *g) {
   launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, X, true, g, T1_.p, nullptr, 0.0, nullptr, nullptr, 0);
-  solve_tt(T1_.p, -1.0);
-  copy_rows(X, T1_.p, false, 1);
+  solve_tt(T1_.p, X, -1.0);
+}
+
+// y = base + G_{:,t} xt.t
+void Group::apply_tcol(const double *xt, const double *base, double *y) {
+  launch_bsr_tcol(d_, st_, T_, cur_mask_, G_.dev, G_.tcol.p, xt, base, y);
 }
 
 // partial[slot] = tr(X^T (g + 1/2 G X))     (DPGOProblem.cpp:180-205; + f on the host)
@@ -1016,7 +1040,7 @@ int Group::mm(const std::vector<int> &locals) {
     std::vector<int> ref;
     for (int a : locals)
       if (res_[a].refined) ref.push_back(a);
-    if (!ref.empty()) run_tnt(ref, Xak_.p, gc_.p);   // sets Gk
+    if (!ref.empty()) run_tnt(ref, Xak_.p, gc_.p, nullptr, true);   // sets Gk
   }
   if (!plain.empty()) {
     set_mask(plain);
@@ -1072,7 +1096,7 @@ int Group::amm(const std::vector<int> &locals) {
   if (ref.empty()) fetch(DS + 3, false);
   else {
     // TNT minimises G(. | g extrapolated); Gk is G(. | g[k]) at the refined point (:377-383)
-    run_tnt(ref, Xak_.p, gx_.p, gc_.p);
+    run_tnt(ref, Xak_.p, gx_.p, gc_.p, true);
     for (int a : ref) res_[a].Gk = res_[a].Gk_alt;
   }
   std::vector<double> Gkh(num_local(), 0.0), minG(num_local(), 0.0);
@@ -1129,7 +1153,7 @@ int Group::amm(const std::vector<int> &locals) {
       std::vector<int> ref;
       for (int a : restart)
         if (res_[a].refined) ref.push_back(a);
-      if (!ref.empty()) run_tnt(ref, Xak_.p, gc_.p);   // Gk = Results.f (:420-421)
+      if (!ref.empty()) run_tnt(ref, Xak_.p, gc_.p, nullptr, true);   // Gk = Results.f (:420-421)
     }
     if (!plain_r.empty()) {
       set_mask(plain_r);
@@ -1302,7 +1326,7 @@ int Group::star_iterate() {
   launch_proximal(d_, st_, T_, cur_mask_, Y_.p, Dfx_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, nullptr, nullptr, 0);
   copy_rows(Xak_.p, Xakh_.p, false, 2);
   recover_translations(Xak_.p, gx_.p);
-  if (!ref.empty()) run_tnt(ref, Xak_.p, gx_.p);
+  if (!ref.empty()) run_tnt(ref, Xak_.p, gx_.p, nullptr, true);
   // ---- the master's tests (:147-192); Xk = own rows of X[k] (Zc_)
   double fobjh = global_objective(Xakh_.p);
   set_mask(all);
@@ -1320,7 +1344,7 @@ int Group::star_iterate() {
     std::vector<int> plain;
     for (int a : all)
       if (!res_[a].refined) plain.push_back(a);
-    if (!ref.empty()) run_tnt(ref, Xak_.p, gc_.p);   // sets Gk = Results.f
+    if (!ref.empty()) run_tnt(ref, Xak_.p, gc_.p, nullptr, true);   // sets Gk = Results.f
     if (!plain.empty()) {
       set_mask(plain);
       eval_G(Xak_.p, gc_.p, 0);

@@ -94,7 +94,7 @@ struct SpdSolverDev {
   SpdDev dev;
   int dof = 1;
   bool stream_once = true;   // panels read with non-temporal loads (see upload)
-  void upload(int dcols);
+  void upload(int dcols, const std::vector<int> &node_of_unknown);   // node_of_unknown: local node of every row of A
 };
 
 class Group {
@@ -193,7 +193,7 @@ class Group {
   double *h_gamma_ = nullptr;      // pinned
   DevBuf<double> gamma_;
   DevBuf<double> partials_;
-  struct BsrBufs { DevBuf<int> ptr, col; DevBuf<double> val; BsrDev dev; };
+  struct BsrBufs { DevBuf<int> ptr, col; DevBuf<double> val, tcol; BsrDev dev; };   // tcol: first column of every block (G only)
   BsrBufs G_, S_, P_, P0m_, Q_;
   DevBuf<double> Dd_, Qd_, Tinv_, N_, V_;
   DevBuf<int> e_tail_, e_head_, e_inc_ptr_, e_inc_;
@@ -227,7 +227,9 @@ class Group {
   int deferred_slots_ = 0;   // slots written earlier that ride along with the next fetch (saves a host round trip)
   double scal(int local, int s) const { return h_scal_[local * MAX_SLOTS + s]; }
   void copy_rows(double *dst, const double *src, bool all_rows, int part = 0);
-  void solve_tt(double *vec, double scale);               // in place on translation rows
+  void solve_tt(double *vec, double scale);
+  void solve_tt(double *in, double *out, double scale);   // out.t <- scale * G_tt^-1 in.t
+  void apply_tcol(const double *xt, const double *base, double *y);               // in place on translation rows
   void solve_rr(double *vec, double scale);               // in place on rotation rows
   void recover_translations(double *X, const double *g);  // X.t = -Gtt^-1 (g_t + G_tR X.R) for masked nodes
   void eval_G(const double *X, const double *g, int slot);
@@ -235,7 +237,9 @@ class Group {
   int amm(const std::vector<int> &locals);
   int mm(const std::vector<int> &locals);
   // refine X in place (TNT on G(. | g)); sets Gk = G(X | g) and, with g_alt, Gk_alt = G(X | g_alt)
-  void run_tnt(const std::vector<int> &locals, double *X, const double *g, const double *g_alt = nullptr);
+  // base_ready: X.t was just recovered from X.R with this g (recover_translations) and T1_ still holds that product
+  void run_tnt(const std::vector<int> &locals, double *X, const double *g, const double *g_alt = nullptr,
+               bool base_ready = false);
 };
 
 }  // namespace dpgo

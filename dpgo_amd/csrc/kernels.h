@@ -62,6 +62,11 @@ void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, const i
                 const double *x, bool in_rot_only, const double *addv, double *y, const double *dotv,
                 double coef, const double *dotadd, double *partials, int slot);
 
+// y = base + A[:, translation column] t over own rows; tval: the first column of every block of A ((d+1) doubles per
+// block), xt: records whose translation row is t.  A quarter of the traffic of launch_bsr.
+void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, const int *mask, const BsrDev &A, const double *tval,
+                     const double *xt, const double *base, double *y);
+
 // Robust inter-edge pass (B-form, DPGOProblem.cpp:634-725).
 //  mode 0 (update): all rows.  DfE <- B1^T W B1 Z; own rows also g <- DfE - D z.
 //     slot 0: sum of rho_e (tail incidences); if quad: slot 1 = sum tr(dZ^T (DfE_old + 1/2 Q dZ)).
@@ -129,7 +134,7 @@ void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows,
 struct alignas(16) SpdItem {
   int front, first, count, w;            // first row (forward) / pivot column (backward) of the tile, rows in it
   int u, ld, piv_ptr, upd_ptr;           // ld: doubles between consecutive rows of the tile's panel
-  int pos_off, ubuf_off, pad0, pad1;
+  int pos_off, ubuf_off, node, pad1;     // node: local node the front belongs to (launch masks)
   int64_t mat_off;                       // offset of the tile's panel
   int64_t pad2;
 };
@@ -150,7 +155,8 @@ struct SpdDev {
 // waves (= narrow tiles per pack) of the workgroups that run a level whose wide tiles are `rows` high
 int spd_pack_waves(int rows);
 void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int pack0, int npacks, int rows,
-                      double *vec, double *ytmp, double scale, double level_bytes = 0.0, bool stream_once = true);
+                      double *vec, double *ytmp, double scale, double level_bytes = 0.0, bool stream_once = true,
+                      const int *mask = nullptr);   // mask[node] == 0: the node's fronts are skipped
 
 // ---- optional per-launch timing (HIP events on the launch stream), off by default ----
 enum ProfKind { PK_BSR = 0, PK_INTER, PK_PROX, PK_AXPBY, PK_DOT, PK_ROTOP, PK_COPYIDX, PK_BDIAG, PK_REDUCE,

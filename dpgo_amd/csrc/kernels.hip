@@ -302,6 +302,46 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr(const Seg *segs, const int
   if (partial) block_store<1, 4 * SEG_ROWS / 64>(part, partial + blockIdx.x, 0);
 }
 
+// y = base + A[:, translation column] t: what A x adds when only the translation rows of x change.  The
+// first column of every (d+1) x (d+1) block is kept in a compact copy (tval, d+1 doubles per block), so
+// this pass moves a quarter of the operator.  Used after a G_tt solve: G [t ; R] = G [0 ; R] + G_{:,t} t,
+// with the first product already there as the right-hand side of that solve.
+template <int D>
+__global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr_tcol(const Seg *segs, const int *mask, BsrDev A, const double *tval,
+                                                         const double *xt, const double *base, double *y) {
+  constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
+  const Seg s = segs[blockIdx.x];
+  if (mask && !mask[s.node]) return;
+  const int row = s.begin + (threadIdx.x >> 2), j = threadIdx.x & 3;
+  double acc[RS];
+#pragma unroll
+  for (int k = 0; k < RS; k++) acc[k] = 0.0;
+  const bool inrow = row < s.end;
+  const int k1 = inrow ? A.ptr[row + 1] : 0;
+  for (int k = (inrow ? A.ptr[row] : 0) + j; k < k1; k += 4) {
+    const int q = A.col[k];
+    double t[D], c0[B];
+    load_vec<D>(xt + (size_t)q * RS, t);
+    load_vec<B>(tval + (size_t)k * B, c0);
+#pragma unroll
+    for (int r = 0; r < B; r++)
+#pragma unroll
+      for (int c = 0; c < D; c++) acc[r * D + c] = fma(c0[r], t[c], acc[r * D + c]);
+  }
+#pragma unroll
+  for (int k = 0; k < RS; k++) {
+    acc[k] += __shfl_xor(acc[k], 1, 64);
+    acc[k] += __shfl_xor(acc[k], 2, 64);
+  }
+  if (inrow && j == 0) {
+    double bv[RS];
+    load_vec<RS>(base + (size_t)row * RS, bv);
+#pragma unroll
+    for (int k = 0; k < RS; k++) acc[k] += bv[k];
+    store_vec<RS>(y + (size_t)row * RS, acc);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Robust inter-node edge pass (residual form).
 // ---------------------------------------------------------------------------
@@ -1117,8 +1157,8 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
 // shared by the 8 waves (ROWS-row tiles), or up to 8 tiles of narrow fronts (reduction length <= 96), one
 // per wave.  Wide packs come first, longest first; the narrow ones fill the tail of the launch.
 template <int D, int DOF, int ROWS, bool FWD, bool NT>
-__global__ __launch_bounds__(64 * SPD_NW(ROWS), ROWS == 64 ? SPD_WPE : 4) void k_spd_level(SpdDev S, int pack0, double scale,
-                                                                                      double *vec, double *ytmp) {
+__global__ __launch_bounds__(64 * SPD_NW(ROWS), ROWS == 64 ? SPD_WPE : 4) void k_spd_level(SpdDev S, const int *mask, int pack0,
+                                                                                      double scale, double *vec, double *ytmp) {
   constexpr int CH = 128, NW = SPD_NW(ROWS);
   __shared__ double f[NW][CH * D];
   __shared__ double red[NW * ROWS * D];
@@ -1128,10 +1168,12 @@ __global__ __launch_bounds__(64 * SPD_NW(ROWS), ROWS == 64 ? SPD_WPE : 4) void k
   if (pk.z == 0) {
     if (wv >= pk.y) return;
     const SpdItem it = load_item(items + pk.x + wv);
+    if (mask && !mask[it.node]) return;
     if constexpr (FWD) spd_fwd_tile<D, DOF, 1, CH, 64, NT>(S, it, vec, ytmp, f[wv], red, 0, lane);
     else spd_bwd_tile<D, DOF, 1, CH, 64, NT>(S, it, scale, ytmp, vec, f[wv], red, 0, lane);
   } else {
     const SpdItem it = load_item(items + pk.x);
+    if (mask && !mask[it.node]) return;   // (uniform over the workgroup)
     if constexpr (FWD) spd_fwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, vec, ytmp, f[wv], red, wv, lane);
     else spd_bwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, scale, ytmp, vec, f[wv], red, wv, lane);
   }
@@ -1233,6 +1275,14 @@ void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, const i
       hipLaunchKernelGGL((k_bsr<D, false>), dim3(nb), dim3(4 * SEG_ROWS), 0, st, T.segs, mask, A, x, addv, y, dotv, coef,
                          dotadd, part);
   });
+}
+
+void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, const int *mask, const BsrDev &A, const double *tval,
+                     const double *xt, const double *base, double *y) {
+  if (T.nseg_own == 0) return;
+  ProfScope ps(PK_BSR, st, (double)A.nnzb * (8.0 * (d + 1) + 4 + 8.0 * d) + 2.0 * A.nrows * 8.0 * (d + 1) * d);
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_bsr_tcol<D>), dim3(T.nseg_own), dim3(4 * SEG_ROWS), 0, st, T.segs, mask, A, tval,
+                                        xt, base, y));
 }
 
 void launch_inter(int d, hipStream_t st, const SegTable &T, const int *mask, const InterEdgesDev &E, int loss,
@@ -1383,15 +1433,15 @@ void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows,
 }
 
 void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int pack0, int npacks, int rows,
-                      double *vec, double *ytmp, double scale, double level_bytes, bool stream_once) {
+                      double *vec, double *ytmp, double scale, double level_bytes, bool stream_once, const int *mask) {
   if (npacks == 0) return;
   ProfScope ps(forward ? PK_SPD_FWD : PK_SPD_BWD, st, level_bytes);
 #define SPD_LAUNCH2(DOFV, ROWSV, NTV)                                                                            \
   do {                                                                                                         \
     if (forward)                                                                                               \
-      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, true, NTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, pack0, scale, vec, ytmp);  \
+      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, true, NTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, mask, pack0, scale, vec, ytmp);  \
     else                                                                                                       \
-      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, false, NTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, pack0, scale, vec, ytmp); \
+      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, false, NTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, mask, pack0, scale, vec, ytmp); \
   } while (0)
 #define SPD_LAUNCH(DOFV, ROWSV)                \
   do {                                         \

@@ -41,12 +41,13 @@ struct NodeTnt {
 };
 }  // namespace
 
-void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, const double *g_alt) {
+void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, const double *g_alt, bool base_ready) {
   const Options &o = opt_;
   const int L = num_local();
   const bool use_precon = (o.preconditioner == 1) && Lrr_.F.n > 0;
   double *nabla = tmp_[0].p, *grad = tmp_[1].p, *sk = tmp_[2].p, *rk = tmp_[3].p, *vk = tmp_[4].p, *pk = tmp_[5].p,
-         *Hp = tmp_[6].p, *xprop = tmp_[7].p, *w1 = tmp_[8].p, *w2 = tmp_[9].p, *pg = tmp_[10].p, *hh = tmp_[11].p;
+         *Hp = tmp_[6].p, *xprop = tmp_[7].p, *w1 = tmp_[8].p, *w2 = tmp_[9].p, *pg = tmp_[10].p, *hh = tmp_[11].p,
+         *w3 = tmp_[12].p, *nprop = tmp_[13].p;
   // hh accumulates H s_k alongside s_k (every step s_k += c p_k is mirrored by hh += c H p_k), so the
   // predicted decrease needs no extra Hessian-vector product: same value as Hess(x, h) of TNT.h:514-515
   // up to rounding of the CG recurrence.
@@ -62,15 +63,18 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     launch_dots(d_, st_, T_, cur_mask_, s, pa, pb, P2, partials_.p, 0);
     fetch(s, false);
   };
-  auto quad_model = [&](const double *Y) {   // nabla, grad at Y
-    launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Y, false, g, nabla, nullptr, 0, nullptr, nullptr, 0);
+  // nabla = G Y + g and grad = Proj_Y(nabla) (rotation rows).  from_base: Y.t was just recovered from Y.R with
+  // this g (recover_translations), so T1_ = G [0 ; Y.R] + g is there and only the translation column is missing.
+  auto quad_model = [&](const double *Y, bool from_base) {
+    if (from_base) apply_tcol(Y, T1_.p, nabla);
+    else launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Y, false, g, nabla, nullptr, 0, nullptr, nullptr, 0);
     launch_tangent_rot(d_, st_, T_, cur_mask_, Y, nabla, grad);
   };
+  // Hess f(Y)[v] (DPGOProblem.cpp:552-577): tdot = -G_tt^-1 G_tR v.R, then Proj(G [tdot ; v.R] - ...)
   auto hess = [&](const double *Y, const double *v, double *out) {
-    launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, v, true, nullptr, w1, nullptr, 0, nullptr, nullptr, 0);
-    solve_tt(w1, -1.0);                       // w1.t = tdot
-    copy_rows(w1, v, false, 2);               // w1 = [tdot ; Rdot]
-    launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, w1, false, nullptr, w2, nullptr, 0, nullptr, nullptr, 0);
+    launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, v, true, nullptr, w1, nullptr, 0, nullptr, nullptr, 0);   // G [0 ; v.R]
+    solve_tt(w1, w3, -1.0);                   // w3.t = tdot
+    apply_tcol(w3, w1, w2);                   // w2 = G [tdot ; v.R]
     launch_hess_epilogue(d_, st_, T_, cur_mask_, Y, w2, nabla, v, out);
   };
   auto precon = [&](const double *Y, const double *v, double *out) {
@@ -118,7 +122,7 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
   const double sqrt_eps = std::sqrt(std::numeric_limits<double>::epsilon());
   const double eta1 = .05, eta2 = .9, alpha1 = .25, alpha2 = 2.5, Delta_tol = 1e-6;   // TNT.h:83-97,129
   set_mask(nodes);
-  quad_model(X);
+  quad_model(X, base_ready);
   norms(nodes, true);
 
   std::vector<double> c1(L, 0.0), c2(L, 0.0), ones(L, 1.0), mones(L, -1.0), zeros(L, 0.0);
@@ -221,17 +225,17 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     set_mask(A);
     launch_retract_rot(d_, st_, T_, cur_mask_, X, sk, xprop);
     recover_translations(xprop, g);
-    eval_G(xprop, g, MAX_DOTS);
+    apply_tcol(xprop, T1_.p, nprop);          // nprop = G xprop + g: gives f(xprop) and, if accepted, the next model
     {
-      const double *pa[MAX_DOTS] = {sk, grad, sk, xprop, xprop}, *pb[MAX_DOTS] = {sk, sk, hh, g, ga};
+      const double *pa[MAX_DOTS] = {sk, grad, sk, xprop, xprop, xprop}, *pb[MAX_DOTS] = {sk, sk, hh, g, ga, nprop};
       const int parts[MAX_DOTS] = {2, 2, 2, 0, 0, 0};
-      launch_dots(d_, st_, T_, cur_mask_, 5, pa, pb, parts, partials_.p, 0);
+      launch_dots(d_, st_, T_, cur_mask_, 6, pa, pb, parts, partials_.p, 0);
     }
-    fetch(MAX_DOTS + 1, false);
+    fetch(MAX_DOTS, false);
     std::vector<int> acc, requad;
     for (int a : A) {
       NodeTnt &s = S[a];
-      const double fx_prop = scal(a, MAX_DOTS) + res_[a].f;
+      const double fx_prop = 0.5 * (scal(a, 5) + scal(a, 3)) + res_[a].f;
       const double h_norm = std::sqrt(scal(a, 0));
       const double dm = -scal(a, 1) - 0.5 * scal(a, 2);
       const double df = s.fx - fx_prop;
@@ -266,7 +270,8 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     }
     if (!requad.empty()) {
       set_mask(requad);
-      quad_model(X);
+      copy_rows(nabla, nprop, false, 0);   // the model gradient at the accepted point
+      launch_tangent_rot(d_, st_, T_, cur_mask_, X, nabla, grad);
       norms(requad, false);
     }
   }
