@@ -48,6 +48,12 @@ template struct DevBuf<int64_t>;
 template struct DevBuf<int4>;
 template struct DevBuf<Seg>;
 
+// tuning hooks (tools/env_ab.sh): an integer from the environment, or the default
+static int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 // Device layout of a factor.  The solve streams every W_s once per sweep, so the matrices are re-packed
 // into PANELS: the entries one tile reads, contiguous, in the order it reads them.
 //   forward tile (rows p0 .. p0+count of [y ; dupd], all columns k < kend):  panel[k][r] = WT_s[k][p0 + r]
@@ -438,14 +444,14 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
     }
     Att.n = (int)Att.ptr.size() - 1;
     Arr.n = (int)Arr.ptr.size() - 1;
-    if (spd_factor(Att, Ltt_.F, 32, getenv("DPGO_SPD_COLLAPSE_TT") ? atoi(getenv("DPGO_SPD_COLLAPSE_TT")) : 0) != 0) return;
+    if (spd_factor(Att, Ltt_.F, env_int("DPGO_SPD_LEAF_TT", 128), env_int("DPGO_SPD_COLLAPSE_TT", 0)) != 0) return;
     Ltt_.dof = 1;
     std::vector<int> node_of_pose(P0_);
     for (int a = 0; a < L; a++)
       for (int p = 0; p < info_[a].n[0]; p++) node_of_pose[own_off_[a] + p] = a;
     Ltt_.upload(d_, node_of_pose);
     if (Arr.n > 0) {
-      if (spd_factor(Arr, Lrr_.F, 48, getenv("DPGO_SPD_COLLAPSE_RR") ? atoi(getenv("DPGO_SPD_COLLAPSE_RR")) : 0) != 0) return;
+      if (spd_factor(Arr, Lrr_.F, env_int("DPGO_SPD_LEAF_RR", 96), env_int("DPGO_SPD_COLLAPSE_RR", 0)) != 0) return;
       Lrr_.dof = d_;
       std::vector<int> node_of_row((size_t)P0_ * d_);
       for (size_t i = 0; i < node_of_row.size(); i++) node_of_row[i] = node_of_pose[i / d_];
