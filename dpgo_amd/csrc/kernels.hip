@@ -899,6 +899,10 @@ __global__ __launch_bounds__(64) void k_reduce(SegTable T, int all_rows, int nsl
 #define SPD_NW16 8
 #endif
 #define SPD_NW(ROWS) ((ROWS) == 16 ? SPD_NW16 : 8)
+// loads per half-batch of the streaming loop (a lane has HB..2 HB loads in flight)
+#ifndef SPD_HB
+#define SPD_HB 8
+#endif
 #ifndef SPD_WPE
 #define SPD_WPE 6    // waves per SIMD the 64-row solve kernels are compiled for: 85 VGPRs, 3 workgroups per CU (measured best of 5, 6, 8)
 #endif
@@ -941,11 +945,64 @@ __device__ __forceinline__ void pull_updates(const SpdDev &S, int pos, double (&
   }
 }
 
+// The streaming dot products of one chunk: acc[c] += sum_k W[k][lane] f[k][c], k = kq, kq + KQ, ... < kn, the
+// panel rows ld doubles apart.  Two half-batches of HB loads alternate: the loads of the next half are issued
+// before the products of the current one, so a lane always has HB..2 HB loads in flight (a single batch that is
+// waited for as a whole drains to zero between batches).  `pre`: the first half-batch, issued by stream_first()
+// before the chunk's input vector was gathered.
+template <int D, int KQ, bool NT, int HB>
+__device__ __forceinline__ bool stream_first(const double *wp, int ld, int kq, int kn, double (&a)[HB]) {
+  const bool full = kq + (HB - 1) * KQ < kn;
+  if (full) {
+#pragma unroll
+    for (int q = 0; q < HB; q++) a[q] = LDW(wp + (size_t)(kq + q * KQ) * ld);
+  }
+  return full;
+}
+template <int D, int KQ, bool NT, int HB>
+__device__ __forceinline__ void stream_rest(const double *wp, int ld, int kq, int kn, const double *fw, bool have,
+                                            double (&a)[HB], double (&acc)[D]) {
+  double b[HB];
+  int kk = kq;
+#define SPD_FMA(buf, k0)                                                                     \
+  _Pragma("unroll") for (int q = 0; q < HB; q++)                                            \
+      _Pragma("unroll") for (int c = 0; c < D; c++) acc[c] = fma(buf[q], fw[((k0) + q * KQ) * D + c], acc[c]);
+#define SPD_LOAD(buf, k0) \
+  _Pragma("unroll") for (int q = 0; q < HB; q++) buf[q] = LDW(wp + (size_t)((k0) + q * KQ) * ld);
+  while (have) {
+    int k2 = kk + HB * KQ;
+    bool more = k2 + (HB - 1) * KQ < kn;
+    if (more) { SPD_LOAD(b, k2) }
+    SPD_FMA(a, kk)
+    kk = k2;
+    have = more;
+    if (!have) break;
+    k2 = kk + HB * KQ;
+    more = k2 + (HB - 1) * KQ < kn;
+    if (more) { SPD_LOAD(a, k2) }
+    SPD_FMA(b, kk)
+    kk = k2;
+    have = more;
+  }
+#undef SPD_FMA
+#undef SPD_LOAD
+  if (kk < kn) {   // the rest: one predicated half-batch (independent loads, never one at a time)
+#pragma unroll
+    for (int q = 0; q < HB; q++) b[q] = kk + q * KQ < kn ? LDW(wp + (size_t)(kk + q * KQ) * ld) : 0.0;
+#pragma unroll
+    for (int q = 0; q < HB; q++)
+      if (kk + q * KQ < kn) {
+#pragma unroll
+        for (int c = 0; c < D; c++) acc[c] = fma(b[q], fw[(kk + q * KQ) * D + c], acc[c]);
+      }
+  }
+}
+
 // fw: this wave's staging area (SPD_CH * D doubles); red: NW x (ROWS * D) doubles shared by the tile's waves.
 template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool NT>
 __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it, const double *vec, double *ytmp,
                                              double *fw, double *red, const int wv, const int lane) {
-  constexpr int KQ = 64 / ROWS, NB = 16;
+  constexpr int KQ = 64 / ROWS, HB = SPD_HB;
   constexpr bool PRE = ROWS < 64;   // levels with few tiles: latency matters, registers do not
   const int r = lane % ROWS, kq = lane / ROWS;
   const int p = it.first + r;
@@ -965,12 +1022,9 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
     const int kn = min(SPD_CH, kend - k0);
     // first batch of this chunk's matrix entries: in flight while the input vector is gathered
     const double *wp = WT + (size_t)k0 * ldm;
-    double w0[NB];
-    const bool full0 = PRE && kq + (NB - 1) * KQ < kn;
-    if (valid && full0) {
-#pragma unroll
-      for (int q = 0; q < NB; q++) w0[q] = LDW(wp + (size_t)(kq + q * KQ) * ldm);
-    }
+    double w0[HB];
+    bool have0 = false;
+    if (PRE && valid) have0 = stream_first<D, KQ, NT, HB>(wp, ldm, kq, kn, w0);
     for (int kk = lane; kk < kn; kk += 64) {
       const int k = k0 + kk;
       double v[D];
@@ -984,35 +1038,8 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (valid) {
-      int kk = kq;
-      if (full0) {
-#pragma unroll
-        for (int q = 0; q < NB; q++)
-#pragma unroll
-          for (int c = 0; c < D; c++) acc[c] = fma(w0[q], fw[(kk + q * KQ) * D + c], acc[c]);
-        kk += NB * KQ;
-      }
-      // batches of 16 independent loads in flight per lane before the first use
-      for (; kk + (NB - 1) * KQ < kn; kk += NB * KQ) {
-        double wb[NB];
-#pragma unroll
-        for (int q = 0; q < NB; q++) wb[q] = LDW(wp + (size_t)(kk + q * KQ) * ldm);
-#pragma unroll
-        for (int q = 0; q < NB; q++)
-#pragma unroll
-          for (int c = 0; c < D; c++) acc[c] = fma(wb[q], fw[(kk + q * KQ) * D + c], acc[c]);
-      }
-      if (kk < kn) {   // the rest: one predicated batch (the loads are independent, never one at a time)
-        double wb[NB];
-#pragma unroll
-        for (int q = 0; q < NB; q++) wb[q] = kk + q * KQ < kn ? LDW(wp + (size_t)(kk + q * KQ) * ldm) : 0.0;
-#pragma unroll
-        for (int q = 0; q < NB; q++)
-          if (kk + q * KQ < kn) {
-#pragma unroll
-            for (int c = 0; c < D; c++) acc[c] = fma(wb[q], fw[(kk + q * KQ) * D + c], acc[c]);
-          }
-      }
+      if (!PRE) have0 = stream_first<D, KQ, NT, HB>(wp, ldm, kq, kn, w0);
+      stream_rest<D, KQ, NT, HB>(wp, ldm, kq, kn, fw, have0, w0, acc);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -1060,7 +1087,7 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
 template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool NT>
 __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it, double scale, const double *ytmp,
                                              double *vec, double *fw, double *red, const int wv, const int lane) {
-  constexpr int KQ = 64 / ROWS, NB = 16;
+  constexpr int KQ = 64 / ROWS, HB = SPD_HB;
   constexpr bool PRE = ROWS < 64;   // levels with few tiles: latency matters, registers do not
   const int r = lane % ROWS, kq = lane / ROWS;
   const int k = it.first + r;
@@ -1077,12 +1104,9 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
   for (int p0 = it.first + wv * SPD_CH; p0 < m; p0 += NW * SPD_CH) {
     const int pn = min(SPD_CH, m - p0);
     const double *wp = W + (size_t)(p0 - it.first) * ldw;
-    double w0[NB];
-    const bool full0 = PRE && kq + (NB - 1) * KQ < pn;
-    if (valid && full0) {
-#pragma unroll
-      for (int q = 0; q < NB; q++) w0[q] = LDW(wp + (size_t)(kq + q * KQ) * ldw);
-    }
+    double w0[HB];
+    bool have0 = false;
+    if (PRE && valid) have0 = stream_first<D, KQ, NT, HB>(wp, ldw, kq, pn, w0);
     for (int pp = lane; pp < pn; pp += 64) {
       const int p = p0 + pp;
       // ancestors' entries were scaled when they were written: undo by linearity (scale is +-1)
@@ -1094,34 +1118,8 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (valid) {
-      int pp = kq;
-      if (full0) {
-#pragma unroll
-        for (int q = 0; q < NB; q++)
-#pragma unroll
-          for (int c = 0; c < D; c++) acc[c] = fma(w0[q], fw[(pp + q * KQ) * D + c], acc[c]);
-        pp += NB * KQ;
-      }
-      for (; pp + (NB - 1) * KQ < pn; pp += NB * KQ) {
-        double wb[NB];
-#pragma unroll
-        for (int q = 0; q < NB; q++) wb[q] = LDW(wp + (size_t)(pp + q * KQ) * ldw);
-#pragma unroll
-        for (int q = 0; q < NB; q++)
-#pragma unroll
-          for (int c = 0; c < D; c++) acc[c] = fma(wb[q], fw[(pp + q * KQ) * D + c], acc[c]);
-      }
-      if (pp < pn) {
-        double wb[NB];
-#pragma unroll
-        for (int q = 0; q < NB; q++) wb[q] = pp + q * KQ < pn ? LDW(wp + (size_t)(pp + q * KQ) * ldw) : 0.0;
-#pragma unroll
-        for (int q = 0; q < NB; q++)
-          if (pp + q * KQ < pn) {
-#pragma unroll
-            for (int c = 0; c < D; c++) acc[c] = fma(wb[q], fw[(pp + q * KQ) * D + c], acc[c]);
-          }
-      }
+      if (!PRE) have0 = stream_first<D, KQ, NT, HB>(wp, ldw, kq, pn, w0);
+      stream_rest<D, KQ, NT, HB>(wp, ldw, kq, pn, fw, have0, w0, acc);
     }
     __builtin_amdgcn_wave_barrier();
   }
