@@ -21,6 +21,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import sys
+
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -101,6 +103,7 @@ SYMBOLS = {
     "dpgo_group_message_sizes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _IP, _IP]),
     "dpgo_group_send": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _DP, C.c_int]),
     "dpgo_group_receive": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _DP, C.c_int]),
+    "dpgo_group_set_collectives": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dpgo_group_star_initialize": (C.c_int, [C.c_void_p, _DP, C.c_int]),
     "dpgo_group_star_update": (C.c_int, [C.c_void_p]),
     "dpgo_group_star_iterate": (C.c_int, [C.c_void_p]),
@@ -357,6 +360,27 @@ class NodeGroup:
         poses = np.ascontiguousarray(np.concatenate([k[1] for k in keys_per_rank]) if len(counts) else [], np.int32)
         return lib().dpgo_group_set_recv_layout(self._h, len(counts), int(stride), _ip(counts), _ip(nodes), _ip(poses))
 
+    def set_collectives(self, send_ptr, gathered_ptr, allgather, allreduce):
+        """Lend the group an all-gather of its boundary buffer and a sum over the groups (AMM-PGO* with the
+        nodes spread over several processes).  allgather() -> 0; allreduce(numpy array) -> 0, in place."""
+        def _ag(_user):
+            try:
+                return int(allgather() or 0)
+            except Exception as e:      # an exception must not unwind through the C frames
+                sys.stderr.write("allgather callback: %r\n" % (e,))
+                return -1
+
+        def _ar(_user, vals, n):
+            try:
+                a = np.ctypeslib.as_array(vals, shape=(n,))
+                return int(allreduce(a) or 0)
+            except Exception as e:
+                sys.stderr.write("allreduce callback: %r\n" % (e,))
+                return -1
+        self._cb = (C.CFUNCTYPE(C.c_int, C.c_void_p)(_ag), C.CFUNCTYPE(C.c_int, C.c_void_p, _DP, C.c_int)(_ar))
+        return lib().dpgo_group_set_collectives(self._h, C.c_void_p(send_ptr), C.c_void_p(gathered_ptr),
+                                                C.cast(self._cb[0], C.c_void_p), C.cast(self._cb[1], C.c_void_p), None)
+
     def pack_sent(self, dev_ptr):
         return lib().dpgo_group_pack_sent(self._h, C.c_void_p(dev_ptr))
 
@@ -479,12 +503,55 @@ class DistPGO:
 class DPGOStar:
     """AMM-PGO* with the method names of the reference's DPGOStar
     (C++/DPGO/include/DPGO/DPGOStar.h:13-61): initialize / update / iterate / communicate.
-    All nodes are hosted by one GPU; the master's global objective is the sum of per-node
-    device reductions."""
+    The master's global objective is the sum of per-node device reductions.  By default all nodes are hosted
+    by one GPU; with `nodes` (this process's share) and an initialised torch.distributed process group the
+    nodes are spread over one process per GPU: boundary poses travel by all-gather (after every iterate, and
+    for every trial point the master evaluates), the global scalars by all-reduce."""
 
-    def __init__(self, graph, options, device=0):
+    def __init__(self, graph, options, device=0, nodes=None):
         self.graph, self.options = graph, options
-        self.group = NodeGroup(graph, range(graph.num_nodes), options, device)
+        self.group = NodeGroup(graph, range(graph.num_nodes) if nodes is None else nodes, options, device)
+        self._dist = None
+        if nodes is not None and len(list(nodes)) != graph.num_nodes:
+            self._connect()
+
+    def _connect(self):
+        import torch
+        import torch.distributed as dist
+        world, RS = dist.get_world_size(), (self.graph.d + 1) * self.graph.d
+        host = dist.get_backend() == "gloo"          # gloo: staged through pinned host tensors
+        keys = self.group.sent_keys()
+        allkeys = [None] * world
+        dist.all_gather_object(allkeys, (keys[0].tolist(), keys[1].tolist()))
+        stride = max(max(len(k[0]) for k in allkeys), 1)
+        self.group.set_recv_layout(stride, [(np.asarray(k[0], np.int32), np.asarray(k[1], np.int32)) for k in allkeys])
+        send = torch.zeros(stride * RS, dtype=torch.float64, device="cuda")
+        gathered = torch.zeros(world * stride * RS, dtype=torch.float64, device="cuda")
+        send_h = torch.zeros(stride * RS, dtype=torch.float64) if host else None
+        gathered_h = torch.zeros(world * stride * RS, dtype=torch.float64) if host else None
+        ext = torch.cuda.ExternalStream(self.group.stream())
+        torch.cuda.synchronize()
+
+        def allgather():
+            with torch.cuda.stream(ext):
+                if host:
+                    send_h.copy_(send)
+                    dist.all_gather_into_tensor(gathered_h, send_h)
+                    gathered.copy_(gathered_h)
+                else:
+                    dist.all_gather_into_tensor(gathered, send)
+            return 0
+
+        def allreduce(vals):
+            t = torch.from_numpy(vals.copy())
+            if not host:
+                t = t.cuda()
+            dist.all_reduce(t)                       # same reduction order on every rank: identical branches
+            vals[:] = t.cpu().numpy()
+            return 0
+        self._dist = (dist, torch, send, gathered, ext, allgather)
+        if self.group.set_collectives(send.data_ptr(), gathered.data_ptr(), allgather, allreduce) != 0:
+            raise RuntimeError("dpgo_group_set_collectives failed")
 
     def initialize(self, X):
         X, ld = _fcol(X)
@@ -497,7 +564,15 @@ class DPGOStar:
         return lib().dpgo_group_star_iterate(self.group._h)
 
     def communicate(self):
-        return self.group.communicate_local()
+        rc = self.group.communicate_local()
+        if self._dist is not None:                   # DPGOHash::communicate across processes
+            _, torch, send, gathered, ext, allgather = self._dist
+            with torch.cuda.stream(ext):
+                self.group.pack_sent(send.data_ptr())
+            allgather()
+            with torch.cuda.stream(ext):
+                self.group.unpack_recv(gathered.data_ptr())
+        return rc
 
     def state(self):
         F, f, fh, b = C.c_double(), C.c_double(), C.c_double(), C.c_int()

@@ -217,6 +217,11 @@ int dpgo_group_initialize_global(dpgo_group_t *h, const double *X, int ld) { ret
 int dpgo_group_update(dpgo_group_t *h, const int *locals, int n) { return h->grp->update(sel(h, locals, n)); }
 int dpgo_group_iterate(dpgo_group_t *h, const int *locals, int n) { return h->grp->iterate(sel(h, locals, n)); }
 int dpgo_group_communicate_local(dpgo_group_t *h) { return h->grp->communicate_local(); }
+int dpgo_group_set_collectives(dpgo_group_t *h, void *send_dev, void *gathered_dev, dpgo_allgather_fn ag, dpgo_allreduce_fn ar,
+                               void *user) {
+  return h->grp->set_collectives((double *)send_dev, (double *)gathered_dev, ag, ar, user);
+}
+
 int dpgo_group_star_initialize(dpgo_group_t *h, const double *X, int ld) { return h->grp->star_initialize_global(X, ld); }
 int dpgo_group_star_update(dpgo_group_t *h) { return h->grp->star_update(); }
 int dpgo_group_star_iterate(dpgo_group_t *h) { return h->grp->star_iterate(); }

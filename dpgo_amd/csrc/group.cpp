@@ -871,6 +871,16 @@ int Group::unpack_recv(const double *dev_gathered) {
   return 0;
 }
 
+int Group::set_collectives(double *send_dev, double *gathered_dev, AllGatherFn ag, AllReduceFn ar, void *user) {
+  if ((ag && (!send_dev || !gathered_dev)) || (ag && !ar)) return -1;
+  coll_send_ = send_dev;
+  coll_gathered_ = gathered_dev;
+  coll_allgather_ = ag;
+  coll_allreduce_ = ar;
+  coll_user_ = user;
+  return 0;
+}
+
 // ---------------------------------------------------------------------------
 // DPGOHash::update  (DPGOHash.cpp:84-228)
 // ---------------------------------------------------------------------------
@@ -1273,10 +1283,16 @@ double Group::global_objective(const double *X_own) {
   set_mask(all);
   copy_rows(Tall_.p, X_own, false, 0);
   launch_copy_indexed(d_, st_, (int)gather_dst_.n, gather_dst_.p, gather_src_.p, Tall_.p, Tall_.p);
+  if (coll_allgather_) {   // boundary poses of the trial point hosted by other groups
+    launch_copy_indexed(d_, st_, (int)sent_rows_.size(), nullptr, sent_rows_dev_.p, X_own, coll_send_);
+    if (coll_allgather_(coll_user_) != 0) { fprintf(stderr, "[dpgo_amd] ERROR: all-gather callback failed.\n"); return NAN; }
+    launch_copy_indexed(d_, st_, (int)recv_dst_.n, recv_dst_.p, recv_src_.p, coll_gathered_, Tall_.p);
+  }
   launch_cost(d_, st_, T_, cur_mask_, Ei_, E_, opt_.loss == 0, opt_.loss, opt_.loss_reg, Tall_.p, partials_.p, 0);
   fetch(2, true);
   double F = 0;
   for (int a = 0; a < num_local(); a++) F += 0.5 * scal(a, 0) + 0.25 * scal(a, 1);
+  if (coll_allreduce_ && coll_allreduce_(coll_user_, &F, 1) != 0) return NAN;
   return F;
 }
 
@@ -1285,12 +1301,14 @@ double Group::global_sqdist(const double *A_own, const double *B_own) {
   fetch(1, false);
   double s = 0;
   for (int a = 0; a < num_local(); a++) s += scal(a, 0);
+  if (coll_allreduce_ && coll_allreduce_(coll_user_, &s, 1) != 0) return NAN;
   return s;
 }
 
 int Group::star_initialize_global(const double *X, int ld) {
-  if (num_local() != num_nodes_total_) {
-    fprintf(stderr, "[dpgo_amd] ERROR: AMM-PGO* needs every node of the graph in one group.\n");
+  if (num_local() != num_nodes_total_ && !coll_allgather_) {
+    fprintf(stderr, "[dpgo_amd] ERROR: AMM-PGO* needs every node of the graph in one group, or collectives "
+                    "(dpgo_group_set_collectives) that connect the groups.\n");
     return -1;
   }
   if (initialize_global(X, ld) != 0) return -1;

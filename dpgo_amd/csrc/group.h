@@ -139,6 +139,11 @@ class Group {
   // counts[r] keys of rank r (concatenated in nodes/poses); slot of key k of rank r = r*stride + k
   int set_recv_layout(int nranks, int stride, const int *counts, const int *nodes, const int *poses);
   int unpack_recv(const double *dev_gathered);          // gathered buffer of all groups
+  // AMM-PGO* across groups: the master's global objective needs the trial point's boundary poses of the other
+  // groups (all-gather of `send` into `gathered`, stream-ordered on stream()) and sums of scalars over the groups
+  typedef int (*AllGatherFn)(void *user);
+  typedef int (*AllReduceFn)(void *user, double *vals, int n);
+  int set_collectives(double *send_dev, double *gathered_dev, AllGatherFn ag, AllReduceFn ar, void *user);
   // results
   int get_Xk(int local, double *X, int ld) const;       // (d+1)(n0+n1) x d column-major
   int get_X_own(int local, double *X, int ld) const;    // Xak: (d+1) n0 x d
@@ -215,6 +220,10 @@ class Group {
   DevBuf<double> tmp_[14];                                       // P0 rows, TNT work vectors
   std::vector<int> last_mask_;
   bool star_ = false;
+  double *coll_send_ = nullptr, *coll_gathered_ = nullptr;
+  AllGatherFn coll_allgather_ = nullptr;
+  AllReduceFn coll_allreduce_ = nullptr;
+  void *coll_user_ = nullptr;
   double starF_ = 0, star_fobj_ = 0, star_fobjh_ = 0;
   int star_branches_ = 0;
   void prepare_extrapolated();                             // Y, g_x, Df_x for the masked nodes

@@ -127,11 +127,21 @@ int dpgo_group_message_sizes(const dpgo_group_t *grp, int local, int beta, int *
 int dpgo_group_send(const dpgo_group_t *grp, int local, int beta, double *msg, int ld);
 int dpgo_group_receive(dpgo_group_t *grp, int local, int beta, const double *msg, int ld);
 /* AMM-PGO* -- DPGOStar::{initialize, update, iterate} (C++/DPGO/src/DPGOStar.cpp:107-213; per-node
- * helpers :215-711); communicate() is dpgo_group_communicate_local.  Every node of the graph must be in
- * the group (the master's global objective is the sum of the per-node device reductions).  Loop:
+ * helpers :215-711); communicate() is dpgo_group_communicate_local (+ the boundary exchange between groups).
+ * Either every node of the graph is in the group, or the groups are connected by dpgo_group_set_collectives
+ * (the master's global objective is the sum of the per-node device reductions over all groups).  Loop:
  * star_initialize(X); repeat { star_update; star_iterate; communicate_local }.
  * star_state: F (running average, :210), fobj = F(X_k+1), fobjh = F(X_k+1/2), branches bit 0 = plain
  * proximal redo (:149-155), bit 1 = MM redo (:159-169), bit 2 = proximal-rotation fallback (:171-192). */
+/* AMM-PGO* with the nodes spread over several groups (one process per GPU): the caller lends the library two
+ * collectives.  allgather(user): all-gather the registered device buffer `send` (stride * (d+1)*d doubles, the
+ * layout of dpgo_group_pack_sent) into `gathered` (the layout given to dpgo_group_set_recv_layout), ordered on
+ * dpgo_group_stream().  allreduce(user, vals, n): in-place sum of n host doubles over all groups; every group
+ * must get bit-identical results (they steer the same branches: DPGOStar.cpp:147-192).  Both return 0 on success. */
+typedef int (*dpgo_allgather_fn)(void *user);
+typedef int (*dpgo_allreduce_fn)(void *user, double *vals, int n);
+int dpgo_group_set_collectives(dpgo_group_t *grp, void *send, void *gathered, dpgo_allgather_fn allgather,
+                               dpgo_allreduce_fn allreduce, void *user);
 int dpgo_group_star_initialize(dpgo_group_t *grp, const double *X, int ld);
 int dpgo_group_star_update(dpgo_group_t *grp);
 int dpgo_group_star_iterate(dpgo_group_t *grp);
