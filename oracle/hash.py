@@ -21,6 +21,14 @@ from .problem import DPGOProblem, LOSS_NONE
 SCHEME_MM, SCHEME_AMM = 0, 1
 
 
+def _div(a, b):
+    """IEEE division as in C++ (inf / nan instead of ZeroDivisionError): a node whose objective is exactly
+    zero is still handled the way the reference handles it."""
+    if b == 0.0:
+        return float("nan") if a == 0.0 or a != a else math.copysign(float("inf"), a)
+    return a / b
+
+
 class Options:
     """DPGO::Options (DPGO_types.h:78-201) with dist_pgo.cpp:103-120 applied by
     ``Options.driver()``."""
@@ -247,7 +255,7 @@ class DPGOHash:
             else:
                 g, Df = p.evaluate_g_and_Df(Y)
         f = r.f
-        refined = (((r.gradFnorm * r.gradFnorm / r.fobj[0]) > o.accepted_delta)
+        refined = ((_div(r.gradFnorm * r.gradFnorm, r.fobj[0]) > o.accepted_delta)
                    or (r.num_oscillations >= o.max_oscillations)) \
             and o.max_iterations > 0 and o.max_iterations_accepted > 0
         r.refined = refined
@@ -298,7 +306,7 @@ class DPGOHash:
         r, p, o = self.results, self.problem, self.options
         n0 = p.n[0]
         g, Df, f = r.g[0], r.Dfobj[0], r.f
-        refined = ((r.gradFnorm * r.gradFnorm / r.fobj[0]) > o.accepted_delta) \
+        refined = (_div(r.gradFnorm * r.gradFnorm, r.fobj[0]) > o.accepted_delta) \
             and o.max_iterations > 0 and o.max_iterations_accepted > 0
         r.refined = refined
         r.Xakh = p.proximal(r.Xk, Df)

@@ -23,6 +23,14 @@ from .problem import (LOSS_GM, LOSS_HUBER, LOSS_NONE, LOSS_WELSCH,
                       project_to_SOdn, tangent_proj)
 
 
+def _div(a, b):
+    """IEEE division as in C++ (inf / nan instead of ZeroDivisionError): a node whose objective is exactly
+    zero is still handled the way the reference handles it."""
+    if b == 0.0:
+        return float("nan") if a == 0.0 or a != a else math.copysign(float("inf"), a)
+    return a / b
+
+
 class GlobalProblem:
     """The evaluation half of DPGOStar (ctor DPGOStar.cpp:7-40)."""
 
@@ -311,7 +319,7 @@ class DPGOStar:
                 Df = r.Dfobj[0] + r.gamma * (r.Dfobj[0] - r.Dfobj[1])
             else:
                 g, Df = p.evaluate_g_and_Df(Y)
-        r.refined = (r.gradFnorm * r.gradFnorm / r.fobj[0]) > o.accepted_delta       # :515-516
+        r.refined = _div(r.gradFnorm * r.gradFnorm, r.fobj[0]) > o.accepted_delta       # :515-516
         r.Xakh = p.proximal(Y, Df)
         R = r.Xakh[n0:].copy()
         r.Xak = np.vstack([p.recover_translations(R, g), R])
@@ -331,7 +339,7 @@ class DPGOStar:
         r, p, o = nd.results, nd.problem, self.options
         n0 = p.n[0]
         g = r.g[0]
-        refined = (r.gradFnorm * r.gradFnorm / r.fobj[0]) > o.accepted_delta
+        refined = _div(r.gradFnorm * r.gradFnorm, r.fobj[0]) > o.accepted_delta
         R = r.Xakh[n0:].copy()
         r.Xak = np.vstack([p.recover_translations(R, g), R])
         if refined:

@@ -18,6 +18,12 @@ import math
 import numpy as np
 
 
+def _sqrt(x):
+    """std::sqrt semantics: NaN for a negative argument (Python's math.sqrt raises instead), so that a
+    rounding-level negative <r, P r> behaves as it does in the reference (the comparison is false)."""
+    return math.sqrt(x) if x >= 0 else float("nan")
+
+
 class TNTParams:
     def __init__(self):
         # SmoothOptimizerParams / OptimizerParams defaults (Base/Concepts.h:42-63)
@@ -50,24 +56,24 @@ def stpcg(g, H, inner, Delta, max_iterations=1000, kappa_fgr=0.1, theta=0.5,
     sk_M_2 = 0.0
     pk_M_2 = inner(r_k, v_k)
     Delta_2 = Delta * Delta
-    r0_norm = math.sqrt(inner(r_k, v_k))
+    r0_norm = _sqrt(inner(r_k, v_k))
     target = r0_norm * min(kappa_fgr, r0_norm ** theta)
     it = 0
     while it < max_iterations:
-        if math.sqrt(inner(r_k, v_k)) <= target:                    # :290
+        if _sqrt(inner(r_k, v_k)) <= target:                    # :290
             break
         Hp = H(p_k)
         kappa_k = inner(p_k, Hp)
-        if math.sqrt(inner(Hp, Hp)) / math.sqrt(inner(p_k, p_k)) < epsilon:   # :305-338
+        if _sqrt(inner(Hp, Hp)) / _sqrt(inner(p_k, p_k)) < epsilon:   # :305-338
             if inner(p_k, r_k) < 0:
                 p_k = -p_k
                 sk_M_pk = -sk_M_pk
-            sigma = (-sk_M_pk + math.sqrt(sk_M_pk * sk_M_pk + pk_M_2 * (Delta_2 - sk_M_2))) / pk_M_2
+            sigma = (-sk_M_pk + _sqrt(sk_M_pk * sk_M_pk + pk_M_2 * (Delta_2 - sk_M_2))) / pk_M_2
             return s_k + sigma * p_k, Delta, it
         alpha = inner(r_k, v_k) / kappa_k
         skp1_M_2 = sk_M_2 + 2 * alpha * sk_M_pk + alpha * alpha * pk_M_2
         if kappa_k <= 0 or skp1_M_2 > Delta_2:                      # :347-362
-            sigma = (-sk_M_pk + math.sqrt(sk_M_pk * sk_M_pk + pk_M_2 * (Delta_2 - sk_M_2))) / pk_M_2
+            sigma = (-sk_M_pk + _sqrt(sk_M_pk * sk_M_pk + pk_M_2 * (Delta_2 - sk_M_2))) / pk_M_2
             return s_k + sigma * p_k, Delta, it
         s_k = s_k + alpha * p_k
         r_k = r_k + alpha * Hp
@@ -81,7 +87,7 @@ def stpcg(g, H, inner, Delta, max_iterations=1000, kappa_fgr=0.1, theta=0.5,
         if trace is not None:
             trace.append((alpha, beta))
         it += 1
-    return s_k, math.sqrt(sk_M_2), it
+    return s_k, _sqrt(sk_M_2), it
 
 
 def tnt(f, QM, metric, retract, x0, precon=None, params=None, log=None):
@@ -96,10 +102,10 @@ def tnt(f, QM, metric, retract, x0, precon=None, params=None, log=None):
     x = x0
     fx = f(x)
     grad, Hess = QM(x)
-    gnorm = math.sqrt(metric(x, grad, grad))
+    gnorm = _sqrt(metric(x, grad, grad))
     if precon is not None:
         pg = precon(x, grad)
-        pgnorm = math.sqrt(metric(x, pg, pg))
+        pgnorm = _sqrt(metric(x, pg, pg))
     else:
         pgnorm = gnorm
     Delta = p.Delta0
@@ -119,7 +125,7 @@ def tnt(f, QM, metric, retract, x0, precon=None, params=None, log=None):
             p.max_TPCG_iterations, p.kappa_fgr, p.theta,
             (lambda v: precon(xc, v)) if precon is not None else None)
         inner_its.append(nin)
-        h_norm = math.sqrt(metric(x, h, h))
+        h_norm = _sqrt(metric(x, h, h))
         x_prop = retract(x, h)
         fx_prop = f(x_prop)
         dm = -metric(x, grad, h) - 0.5 * metric(x, h, Hess(x, h))
@@ -143,10 +149,10 @@ def tnt(f, QM, metric, retract, x0, precon=None, params=None, log=None):
                 status = "Stepsize"
                 break
             grad, Hess = QM(x)
-            gnorm = math.sqrt(metric(x, grad, grad))
+            gnorm = _sqrt(metric(x, grad, grad))
             if precon is not None:
                 pg = precon(x, grad)
-                pgnorm = math.sqrt(metric(x, pg, pg))
+                pgnorm = _sqrt(metric(x, pg, pg))
             else:
                 pgnorm = gnorm
         if (not math.isnan(rho)) and rho >= p.eta2:
