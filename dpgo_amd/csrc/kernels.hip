@@ -244,6 +244,16 @@ __device__ __forceinline__ void tangent_proj(const double *Y, const double *F, d
     }
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8).  Segment kernels therefore take segment
+// xcd_seg(blockIdx) instead of segment blockIdx: XCD x works on one contiguous eighth of the rows, so the
+// records its gathers touch (lattice neighbours, a few thousand rows away at most) stay in that XCD's own
+// 4 MB L2 instead of being fetched by all eight.  A bijection on [0, n) for any n.
+__device__ __forceinline__ int xcd_seg(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7;
+  return x * q + min(x, r) + (b >> 3);
+}
+#define SEGB xcd_seg((int)blockIdx.x, (int)gridDim.x)
+
 // ---------------------------------------------------------------------------
 // Block-sparse operator apply over pose records.
 // ---------------------------------------------------------------------------
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr(const Seg *segs, const int
                                               const double *addv, double *y, const double *dotv, double coef,
                                               const double *dotadd, double *partial) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
-  const Seg s = segs[blockIdx.x];
+  const Seg s = segs[SEGB];
   const bool active = (mask == nullptr) || (mask[s.node] != 0);
   double part[1] = {0.0};
   const int row = s.begin + (threadIdx.x >> 2), j = threadIdx.x & 3;
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr(const Seg *segs, const int
       }
     }
   }
-  if (partial) block_store<1, 4 * SEG_ROWS / 64>(part, partial + blockIdx.x, 0);
+  if (partial) block_store<1, 4 * SEG_ROWS / 64>(part, partial + SEGB, 0);
 }
 
 // y = base + A[:, translation column] t: what A x adds when only the translation rows of x change.  The
@@ -310,7 +320,7 @@ template <int D>
 __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr_tcol(const Seg *segs, const int *mask, BsrDev A, const double *tval,
                                                          const double *xt, const double *base, double *y) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
-  const Seg s = segs[blockIdx.x];
+  const Seg s = segs[SEGB];
   if (mask && !mask[s.node]) return;
   const int row = s.begin + (threadIdx.x >> 2), j = threadIdx.x & 3;
   double acc[RS];
@@ -369,9 +379,9 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, const int *
                                                const double *Zprev, const double *Qd, const double *Dd,
                                                double *DfE, double *g, double *partial, int pstride) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
-  const Seg s = segs[blockIdx.x];
+  const Seg s = segs[SEGB];
   const bool active = (mask == nullptr) || (mask[s.node] != 0);
-  const bool own = blockIdx.x < nseg_own;
+  const bool own = SEGB < nseg_own;
   double part[2] = {0.0, 0.0};
   const int row = s.begin + threadIdx.x;
   if (active && row < s.end) {
@@ -459,7 +469,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, const int *
       store_vec<RS>(g + (size_t)row * RS, acc);
     }
   }
-  block_store<2>(part, partial + blockIdx.x, pstride);
+  block_store<2>(part, partial + SEGB, pstride);
 }
 
 // ---------------------------------------------------------------------------
@@ -519,7 +529,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_cost(const Seg *segs, const int *m
                                               int eform, int loss, double dl, const double *Z, double *partial,
                                               int pstride) {
   constexpr int RS = Dim<D>::RS;
-  const Seg s = segs[blockIdx.x];
+  const Seg s = segs[SEGB];
   const bool active = (mask == nullptr) || (mask[s.node] != 0);
   double part[2] = {0.0, 0.0};
   const int row = s.begin + threadIdx.x;
@@ -542,7 +552,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_cost(const Seg *segs, const int *m
       part[1] += rho;
     }
   }
-  block_store<2>(part, partial + blockIdx.x, pstride);
+  block_store<2>(part, partial + SEGB, pstride);
 }
 
 // partial = sum |a_p - b_p|^2 over own rows
@@ -550,7 +560,7 @@ template <int D>
 __global__ __launch_bounds__(SEG_ROWS) void k_sqdist(const Seg *segs, const int *mask, const double *a, const double *b,
                                                 double *partial) {
   constexpr int RS = Dim<D>::RS;
-  const Seg s = segs[blockIdx.x];
+  const Seg s = segs[SEGB];
   const bool active = (mask == nullptr) || (mask[s.node] != 0);
   double pr[1] = {0.0};
   const int row = s.begin + threadIdx.x;
@@ -563,7 +573,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_sqdist(const Seg *segs, const int 
     for (int k = 0; k < RS; k++) { const double dd = va[k] - vb[k]; p = fma(dd, dd, p); }
     pr[0] = p;
   }
-  block_store<1>(pr, partial + blockIdx.x, 0);
+  block_store<1>(pr, partial + SEGB, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -575,7 +585,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_proximal(const Seg *segs, const in
                                                   const double *Vb, double *Xout, const double *Xref,
                                                   double *partial) {
   constexpr int RS = Dim<D>::RS;
-  const Seg s = segs[blockIdx.x];
+  const Seg s = segs[SEGB];
   const bool active = (mask == nullptr) || (mask[s.node] != 0);
   double part[1] = {0.0};
   const int row = s.begin + threadIdx.x;
@@ -619,14 +629,14 @@ __global__ __launch_bounds__(SEG_ROWS) void k_proximal(const Seg *segs, const in
       part[0] = p;
     }
   }
-  if (partial) block_store<1>(part, partial + blockIdx.x, 0);
+  if (partial) block_store<1>(part, partial + SEGB, 0);
 }
 
 template <int D>
 __global__ __launch_bounds__(SEG_ROWS) void k_extrapolate(const Seg *segs, const int *mask, const double *gamma,
                                                      const double *a, const double *b, double *out) {
   constexpr int RS = Dim<D>::RS;
-  const Seg s = segs[blockIdx.x];
+  const Seg s = segs[SEGB];
   if (mask && !mask[s.node]) return;
   const int row = s.begin + threadIdx.x;
   if (row >= s.end) return;
@@ -645,7 +655,7 @@ template <int D, int PART>
 __global__ __launch_bounds__(SEG_ROWS) void k_axpby(const Seg *segs, const int *mask, double alpha, const double *a,
                                                     double beta, const double *b, double *out) {
   constexpr int RS = Dim<D>::RS;
-  const Seg s = segs[blockIdx.x];
+  const Seg s = segs[SEGB];
   if (mask && !mask[s.node]) return;
   const int row = s.begin + threadIdx.x;
   if (row >= s.end) return;
@@ -668,7 +678,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_axpby_node(const Seg *segs, const 
                                                     const double *a, const double *beta, const double *b,
                                                     double *out) {
   constexpr int RS = Dim<D>::RS;
-  const Seg s = segs[blockIdx.x];
+  const Seg s = segs[SEGB];
   if (mask && !mask[s.node]) return;
   const int row = s.begin + threadIdx.x;
   if (row >= s.end) return;
@@ -686,7 +696,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_cg_init(const Seg *segs, const int
                                                       const double *pgrad, double *s, double *hs, double *r, double *v,
                                                       double *p) {
   constexpr int RS = Dim<D>::RS;
-  const Seg sg = segs[blockIdx.x];
+  const Seg sg = segs[SEGB];
   if (mask && !mask[sg.node]) return;
   const int row = sg.begin + threadIdx.x;
   if (row >= sg.end) return;
@@ -716,7 +726,7 @@ template <int D>
 __global__ __launch_bounds__(SEG_ROWS) void k_dots(const Seg *segs, const int *mask, DotPairs P, double *partial,
                                                    int pstride) {
   constexpr int RS = Dim<D>::RS;
-  const Seg s = segs[blockIdx.x];
+  const Seg s = segs[SEGB];
   const bool active = (mask == nullptr) || (mask[s.node] != 0);
   double pr[MAX_DOTS];
 #pragma unroll
@@ -736,14 +746,14 @@ __global__ __launch_bounds__(SEG_ROWS) void k_dots(const Seg *segs, const int *m
         pr[q] = p;
       }
   }
-  block_store<MAX_DOTS>(pr, partial + blockIdx.x, pstride);
+  block_store<MAX_DOTS>(pr, partial + SEGB, pstride);
 }
 
 template <int D>
 __global__ __launch_bounds__(SEG_ROWS) void k_tangent_full(const Seg *segs, const int *mask, const double *X,
                                                       const double *V, double *out, double *partial) {
   constexpr int RS = Dim<D>::RS;
-  const Seg s = segs[blockIdx.x];
+  const Seg s = segs[SEGB];
   const bool active = (mask == nullptr) || (mask[s.node] != 0);
   double pr[1] = {0.0};
   const int row = s.begin + threadIdx.x;
@@ -760,7 +770,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_tangent_full(const Seg *segs, cons
     pr[0] = p;
     if (out) store_vec<RS>(out + (size_t)row * RS, o);
   }
-  if (partial) block_store<1>(pr, partial + blockIdx.x, 0);
+  if (partial) block_store<1>(pr, partial + SEGB, 0);
 }
 
 // mode 0: out.Y = Proj_R(in.Y)                         (reduced_tangent_space_projection)
@@ -771,7 +781,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_rot_op(const Seg *segs, const int 
                                                 const double *in, const double *nabla, const double *Rdot,
                                                 double *out) {
   constexpr int RS = Dim<D>::RS;
-  const Seg s = segs[blockIdx.x];
+  const Seg s = segs[SEGB];
   if (mask && !mask[s.node]) return;
   const int row = s.begin + threadIdx.x;
   if (row >= s.end) return;
@@ -834,7 +844,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_bdiag_dot(const Seg *segs, const i
                                                    const double *x, double coef, const double *add,
                                                    double addcoef, double *partial) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
-  const Seg s = segs[blockIdx.x];
+  const Seg s = segs[SEGB];
   const bool active = (mask == nullptr) || (mask[s.node] != 0);
   double pr[1] = {0.0};
   const int row = s.begin + threadIdx.x;
@@ -850,7 +860,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_bdiag_dot(const Seg *segs, const i
     for (int k = 0; k < RS; k++) p = fma(xv[k], fma(coef, dx[k], addcoef * av[k]), p);
     pr[0] = p;
   }
-  block_store<1>(pr, partial + blockIdx.x, 0);
+  block_store<1>(pr, partial + SEGB, 0);
 }
 
 // One wave per (node, slot): sums the node's per-segment partials in a fixed order and writes the scalar
