@@ -1008,6 +1008,14 @@ __device__ __forceinline__ void stream_rest(const double *wp, int ld, int kq, in
   }
 }
 
+// chunk length for a reduction of `len` entries dealt to NW waves: len / NW rounded up to 8, within [8, CH]
+template <int NW, int CH>
+__device__ __forceinline__ int spd_chunk(int len) {
+  if constexpr (NW == 1) return CH;
+  const int c = ((len + NW - 1) / NW + 7) & ~7;
+  return min(max(c, 8), CH);
+}
+
 // fw: this wave's staging area (SPD_CH * D doubles); red: NW x (ROWS * D) doubles shared by the tile's waves.
 template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool NT>
 __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it, const double *vec, double *ytmp,
@@ -1028,8 +1036,11 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
   // the pivot block of W_s is L11^-1, lower triangular: rows of a tile that lies inside it only need
   // the columns up to the tile's last row
   const int kend = (it.first + ROWS <= w) ? it.first + ROWS : w;
-  for (int k0 = wv * SPD_CH; k0 < kend; k0 += NW * SPD_CH) {
-    const int kn = min(SPD_CH, kend - k0);
+  // the reduction is dealt to the tile's NW waves in equal chunks (at most SPD_CH long): a front with few
+  // pivots still keeps every wave busy
+  const int cl = spd_chunk<NW, SPD_CH>(kend);
+  for (int k0 = wv * cl; k0 < kend; k0 += NW * cl) {
+    const int kn = min(cl, kend - k0);
     // first batch of this chunk's matrix entries: in flight while the input vector is gathered
     const double *wp = WT + (size_t)k0 * ldm;
     double w0[HB];
@@ -1111,8 +1122,9 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
 #pragma unroll
   for (int c = 0; c < D; c++) acc[c] = 0.0;
   // columns of a tile starting at c0 are zero in the rows above c0 (L11^-1 is lower triangular)
-  for (int p0 = it.first + wv * SPD_CH; p0 < m; p0 += NW * SPD_CH) {
-    const int pn = min(SPD_CH, m - p0);
+  const int cl = spd_chunk<NW, SPD_CH>(m - it.first);
+  for (int p0 = it.first + wv * cl; p0 < m; p0 += NW * cl) {
+    const int pn = min(cl, m - p0);
     const double *wp = W + (size_t)(p0 - it.first) * ldw;
     double w0[HB];
     bool have0 = false;
