@@ -83,7 +83,8 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
   // two classes of tiles: small fronts (one wave per tile) and wide fronts (8 waves per tile, the columns /
   // rows of the reduction split between the waves).
   // The reduction length decides: columns (w) in the forward sweep, rows (w+u) in the backward sweep.
-  auto wide = [&](int f, bool fwd) { return (fwd ? F.w[f] : F.w[f] + F.u[f]) > 96; };
+  const int wide_above = env_int("DPGO_SPD_WIDE", 96);   // (<= 128: a narrow tile's reduction is one LDS chunk)
+  auto wide = [&](int f, bool fwd) { return (fwd ? F.w[f] : F.w[f] + F.u[f]) > wide_above; };
   // a small narrow class joins the wide class (whole workgroups are cheap when there are few of them)
   auto tiles64 = [&](const std::vector<int> &lvl, bool fwd, bool want_wide) {
     int cnt = 0;
@@ -111,7 +112,8 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
       const int wide_tiles = tiles64(lvl, fwd, true) + (merge ? tiles64(lvl, fwd, false) : 0);
       int longest = 0;
       for (int f : lvl) longest = std::max(longest, F.w[f] + F.u[f]);
-      const bool fine = fwd ? wide_tiles < 192 : (wide_tiles < 256 || (wide_tiles < 800 && longest >= 1000));
+      const bool fine = fwd ? wide_tiles < env_int("DPGO_SPD_FINE_FWD", 192)
+                            : (wide_tiles < env_int("DPGO_SPD_FINE_BWD", 256) || (wide_tiles < env_int("DPGO_SPD_FINE_BWD_TALL", 800) && longest >= 1000));
       const int rows = (wide_tiles > 0 && fine) ? 16 : 64;
       rows_of_level.push_back(rows);
       // wide tiles first (one workgroup each), then the narrow ones in packs of 8 (one wave each)
