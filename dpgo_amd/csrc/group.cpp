@@ -644,6 +644,7 @@ static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec) {
 void Group::solve_tt(double *vec, double scale) { spd_run(d_, st_, Ltt_, cur_mask_, vec, vec, scale); }
 void Group::solve_tt(double *in, double *out, double scale) { spd_run(d_, st_, Ltt_, cur_mask_, in, out, scale); }
 void Group::solve_rr(double *vec, double scale) { spd_run(d_, st_, Lrr_, cur_mask_, vec, vec, scale); }
+void Group::solve_rr(double *in, double *out, double scale) { spd_run(d_, st_, Lrr_, cur_mask_, in, out, scale); }
 
 // X.t = -G_tt^-1 (g_t + G_tR X.R)    (DPGOProblem.h:275-294)
 // Leaves T1_ = G [0 ; X.R] + g on all rows (its translation rows are the right-hand side of the solve):

@@ -82,8 +82,7 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       copy_rows(out, v, false, 0);
       return;
     }
-    copy_rows(w1, v, false, 0);
-    solve_rr(w1, 1.0);
+    solve_rr(const_cast<double *>(v), w1, 1.0);   // w1.R = (G_RR + lambda I)^-1 v.R; the forward sweep only reads v
     launch_tangent_rot(d_, st_, T_, cur_mask_, Y, w1, out);
   };
   // gnorm, pgnorm (and rv0 = <grad, P grad>, the first CG scalar) of the nodes in `set` (mask == set).
