@@ -66,7 +66,13 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
   piv_idx.upload(F.piv_idx);
   upd_idx.upload(F.upd_idx);
   asm_ptr.upload(F.asm_ptr);
-  asm_src.upload(F.asm_src);
+  {
+    // pull-ordered update buffer: the a-th entry of the assembly lists is row a; the child row that feeds it
+    // (F.asm_src[a]) is told where to write.  Every update row has exactly one reader (its parent).
+    std::vector<int> dst(std::max(F.total_upd, 1), 0);
+    for (size_t a = 0; a < F.asm_src.size(); a++) dst[F.asm_src[a]] = (int)a;
+    ubuf_dst.upload(dst);
+  }
   ubuf.alloc((size_t)std::max(F.total_upd, 1) * dcols);
   ytmp.alloc((size_t)std::max(F.n, 1) * dcols);
   fwd_level_bytes.clear();
@@ -186,7 +192,7 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
   size_t keep = 96u << 20;
   if (const char *e = getenv("DPGO_SPD_KEEP_MB")) keep = (size_t)atol(e) << 20;
   stream_once = sizeof(double) * (W.n + WT.n) > keep;
-  dev.piv_idx = piv_idx.p; dev.upd_idx = upd_idx.p; dev.asm_ptr = asm_ptr.p; dev.asm_src = asm_src.p;
+  dev.piv_idx = piv_idx.p; dev.upd_idx = upd_idx.p; dev.asm_ptr = asm_ptr.p; dev.ubuf_dst = ubuf_dst.p;
   dev.W = W.p; dev.WT = WT.p; dev.fwd_items = fwd_items.p; dev.bwd_items = bwd_items.p; dev.ubuf = ubuf.p;
 }
 

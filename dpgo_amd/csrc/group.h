@@ -84,7 +84,7 @@ struct DevBuf {
 
 struct SpdSolverDev {
   SpdFactor F;   // host copy kept for sizes / host solves
-  DevBuf<int> piv_idx, upd_idx, asm_ptr, asm_src;
+  DevBuf<int> piv_idx, upd_idx, asm_ptr, ubuf_dst;
   DevBuf<double> W, WT, ubuf, ytmp;   // W / WT: backward / forward panels (see upload)
   DevBuf<SpdItem> fwd_items, bwd_items;
   DevBuf<int4> fwd_packs, bwd_packs;

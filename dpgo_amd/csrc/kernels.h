@@ -142,7 +142,8 @@ static_assert(sizeof(SpdItem) == 64, "SpdItem is loaded as four int4");
 
 struct SpdDev {
   const int *piv_idx = nullptr, *upd_idx = nullptr;   // matrix indices of the pivots / update rows of every front
-  const int *asm_ptr = nullptr, *asm_src = nullptr;   // per front position: rows of the update buffer to add
+  const int *asm_ptr = nullptr;   // per front position p: it receives update-buffer rows asm_ptr[p] .. asm_ptr[p+1]
+  const int *ubuf_dst = nullptr;  // per update row of a front (ubuf_off + r): its row in the update buffer
   const double *W = nullptr, *WT = nullptr;           // panels of the backward / forward tiles
   const SpdItem *fwd_items = nullptr, *bwd_items = nullptr;
   const int4 *fwd_packs = nullptr, *bwd_packs = nullptr;   // {first tile, tiles (1..8), wide?, 0}: one workgroup each

@@ -897,8 +897,9 @@ __global__ __launch_bounds__(64) void k_reduce(SegTable T, int all_rows, int nsl
 //   * a tile's whole description (front sizes, offsets) travels in its 64-byte SpdItem: one load;
 //   * the first batch of matrix loads of every chunk is issued BEFORE the chunk's input vector is
 //     gathered (the two are independent) where a level has few tiles;
-//   * the pull lists (children's update rows to add) are read two entries at a time, added in
-//     list order (the order of the host solve: results do not depend on the schedule).
+//   * the update buffer is stored in pull order (see pull_updates): a parent reads its children's
+//     contributions as a contiguous run, added in list order (the order of the host solve: results do
+//     not depend on the schedule).
 // ---------------------------------------------------------------------------
 // NT: the panels are read once per solve; non-temporal loads keep a factor that cannot stay in the Infinity
 // Cache anyway from displacing what the kernels between two solves re-read (operators, vectors, and a
@@ -930,25 +931,24 @@ __device__ __forceinline__ SpdItem load_item(const SpdItem *p) {
   return u.it;
 }
 
-// v += sum of the update-buffer rows listed for front position `pos`, in list order
+// v += the children's contributions to front position `pos`.  The update buffer is laid out in PULL order: the
+// rows a position receives are consecutive (rows asm_ptr[pos] .. asm_ptr[pos + 1]), in the fixed order of the
+// host's assembly lists; the children scatter their update rows there (ubuf_dst), which is off the critical path.
 template <int D>
 __device__ __forceinline__ void pull_updates(const SpdDev &S, int pos, double (&v)[D]) {
   const int a0 = S.asm_ptr[pos], a1 = S.asm_ptr[pos + 1];
   constexpr int PB = 2;
   for (int a = a0; a < a1; a += PB) {
-    int idx[PB];
-#pragma unroll
-    for (int q = 0; q < PB; q++) idx[q] = a + q < a1 ? S.asm_src[a + q] : -1;
     double t[PB][D];
 #pragma unroll
     for (int q = 0; q < PB; q++)
-      if (idx[q] >= 0) {
+      if (a + q < a1) {
 #pragma unroll
-        for (int c = 0; c < D; c++) t[q][c] = *(S.ubuf + (size_t)idx[q] * D + c);
+        for (int c = 0; c < D; c++) t[q][c] = S.ubuf[(size_t)(a + q) * D + c];
       }
 #pragma unroll
     for (int q = 0; q < PB; q++)
-      if (idx[q] >= 0) {
+      if (a + q < a1) {
 #pragma unroll
         for (int c = 0; c < D; c++) v[c] += t[q][c];
       }
@@ -1033,6 +1033,9 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
   double acc[D];
 #pragma unroll
   for (int c = 0; c < D; c++) acc[c] = 0.0;
+  // the lane that will write this row: where its update row goes is looked up now, not at the end
+  const bool writer = valid && kq == 0 && wv == 0;
+  const int udst = (writer && p >= w) ? S.ubuf_dst[it.ubuf_off + p - w] : 0;
   // the pivot block of W_s is L11^-1, lower triangular: rows of a tile that lies inside it only need
   // the columns up to the tile's last row
   const int kend = (it.first + ROWS <= w) ? it.first + ROWS : w;
@@ -1072,7 +1075,6 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
   }
   // update rows also receive the children's contributions for that row: fetched while the other
   // waves finish
-  const bool writer = valid && kq == 0 && wv == 0;
   double extra[D];
 #pragma unroll
   for (int c = 0; c < D; c++) extra[c] = 0.0;
@@ -1099,7 +1101,7 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
 #pragma unroll
     for (int c = 0; c < D; c++) *(dst + c) = (acc[c]);
   } else {
-    double *dst = S.ubuf + (size_t)(it.ubuf_off + p - w) * D;
+    double *dst = S.ubuf + (size_t)udst * D;
 #pragma unroll
     for (int c = 0; c < D; c++) *(dst + c) = (acc[c] + extra[c]);
   }
