@@ -100,13 +100,10 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
   };
   const int MERGE_BELOW = 1024;
   struct Tile { int f, first, count, rows; int64_t len; };   // rows: tile height of its class; len: panel rows
-  auto sweep = [&](bool fwd, std::vector<int> &level_ptr, std::vector<int> &rows_of_level, DevBuf<SpdItem> &items_dev,
-                   DevBuf<int4> &packs_dev, DevBuf<double> &panels_dev) {
+  auto sweep = [&](bool fwd, std::vector<Level> &out_levels, DevBuf<SpdItem> &items_dev, DevBuf<double> &panels_dev) {
     const auto &levels = fwd ? F.by_height : F.by_depth;
     std::vector<Tile> tiles;
-    std::vector<int4> packs;
-    level_ptr.assign(1, 0);
-    rows_of_level.clear();
+    out_levels.clear();
     for (const auto &lvl : levels) {
       const bool merge = tiles64(lvl, fwd, true) > 0 && tiles64(lvl, fwd, false) < MERGE_BELOW;
       // Few wide tiles at this level: 16-row tiles put 4x more workgroups (CUs) on them.  A workgroup streams
@@ -121,8 +118,8 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
       const bool fine = fwd ? wide_tiles < env_int("DPGO_SPD_FINE_FWD", 192)
                             : (wide_tiles < env_int("DPGO_SPD_FINE_BWD", 256) || (wide_tiles < env_int("DPGO_SPD_FINE_BWD_TALL", 800) && longest >= 1000));
       const int rows = (wide_tiles > 0 && fine) ? 16 : 64;
-      rows_of_level.push_back(rows);
-      // wide tiles first (one workgroup each), then the narrow ones in packs of 8 (one wave each)
+      // wide tiles first (one workgroup each), then the narrow ones (one wave each)
+      Level lev{(int)tiles.size(), 0, 0, rows};
       for (int pass = 1; pass >= 0; pass--) {
         const size_t begin = tiles.size();
         const int th = pass == 1 ? rows : 64;
@@ -137,13 +134,9 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
           }
         }
         std::stable_sort(tiles.begin() + begin, tiles.end(), [](const Tile &x, const Tile &y) { return x.len * x.count > y.len * y.count; });
-        const int end = (int)tiles.size();
-        if (pass == 1)
-          for (int i = (int)begin; i < end; i++) packs.push_back(make_int4(i, 1, 1, 0));
-        else
-          for (int i = (int)begin, nw = spd_pack_waves(rows); i < end; i += nw) packs.push_back(make_int4(i, std::min(nw, end - i), 0, 0));
+        (pass == 1 ? lev.nwide : lev.nnarrow) = (int)(tiles.size() - begin);
       }
-      level_ptr.push_back((int)packs.size());
+      out_levels.push_back(lev);
     }
     // panel offsets
     std::vector<SpdItem> items(tiles.size());
@@ -181,13 +174,10 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
       }
     }
     items_dev.upload(items);
-    packs_dev.upload(packs);
     panels_dev.upload(panels);
   };
-  sweep(true, fwd_level_ptr, fwd_rows, fwd_items, fwd_packs, WT);
-  sweep(false, bwd_level_ptr, bwd_rows, bwd_items, bwd_packs, W);
-  dev.fwd_packs = fwd_packs.p;
-  dev.bwd_packs = bwd_packs.p;
+  sweep(true, fwd_levels, fwd_items, WT);
+  sweep(false, bwd_levels, bwd_items, W);
   // both panel sets of a factor this small can live in the 256 MiB Infinity Cache from one solve to the next
   size_t keep = 96u << 20;
   if (const char *e = getenv("DPGO_SPD_KEEP_MB")) keep = (size_t)atol(e) << 20;
@@ -600,12 +590,16 @@ void Group::copy_rows(double *dst, const double *src, bool all_rows, int part) {
 // out <- scale * A^-1 in (the unknowns' entries of the records; everything else in `out` is left alone).
 // The forward sweep only reads `in`, the backward sweep only touches `out`: in == out solves in place.
 static void spd_run(int d, hipStream_t st, SpdSolverDev &S, const int *mask, double *in, double *out, double scale) {
-  for (size_t l = 0; l + 1 < S.fwd_level_ptr.size(); l++)
-    launch_spd_level(d, S.dof, st, S.dev, true, S.fwd_level_ptr[l], S.fwd_level_ptr[l + 1] - S.fwd_level_ptr[l], S.fwd_rows[l], in,
-                     S.ytmp.p, scale, S.fwd_level_bytes[l], S.stream_once, mask);
-  for (size_t l = 0; l + 1 < S.bwd_level_ptr.size(); l++)
-    launch_spd_level(d, S.dof, st, S.dev, false, S.bwd_level_ptr[l], S.bwd_level_ptr[l + 1] - S.bwd_level_ptr[l], S.bwd_rows[l], out,
-                     S.ytmp.p, scale, S.bwd_level_bytes[l], S.stream_once, mask);
+  for (size_t l = 0; l < S.fwd_levels.size(); l++) {
+    const SpdSolverDev::Level &v = S.fwd_levels[l];
+    launch_spd_level(d, S.dof, st, S.dev, true, v.tile0, v.nwide, v.nnarrow, v.rows, in, S.ytmp.p, scale, S.fwd_level_bytes[l],
+                     S.stream_once, mask);
+  }
+  for (size_t l = 0; l < S.bwd_levels.size(); l++) {
+    const SpdSolverDev::Level &v = S.bwd_levels[l];
+    launch_spd_level(d, S.dof, st, S.dev, false, v.tile0, v.nwide, v.nnarrow, v.rows, out, S.ytmp.p, scale, S.bwd_level_bytes[l],
+                     S.stream_once, mask);
+  }
 }
 
 // DPGO_SPD_DUMP=1: time every launch of one solve on a zero vector (HIP events, best of 5) and print its
@@ -616,18 +610,14 @@ static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec) {
   HIP_CHECK(hipEventCreate(&e0));
   HIP_CHECK(hipEventCreate(&e1));
   double tot_us = 0, tot_mb = 0;
-  auto run = [&](bool fwd, size_t l, const std::vector<int> &ptr, int rows, const std::vector<int> &fronts, double bytes) {
-    const int a = ptr[l], b = ptr[l + 1];
-    if (b <= a) return;
-    std::vector<int4> packs((size_t)(b - a));
-    HIP_CHECK(hipMemcpy(packs.data(), (fwd ? S.fwd_packs.p : S.bwd_packs.p) + a, sizeof(int4) * (b - a), hipMemcpyDeviceToHost));
-    int wide = 0, narrow = 0, wmax = 0, mmax = 0;
-    for (const int4 &p : packs) (p.z ? wide : narrow) += p.y;
+  auto run = [&](bool fwd, size_t l, const SpdSolverDev::Level &v, const std::vector<int> &fronts, double bytes) {
+    if (v.nwide + v.nnarrow == 0) return;
+    int wmax = 0, mmax = 0;
     for (int f : fronts) { wmax = std::max(wmax, F.w[f]); mmax = std::max(mmax, F.w[f] + F.u[f]); }
     float best = 1e30f;
     for (int rep = 0; rep < 6; rep++) {
       HIP_CHECK(hipEventRecord(e0, st));
-      launch_spd_level(d, S.dof, st, S.dev, fwd, a, b - a, rows, vec, S.ytmp.p, 1.0, 0.0, S.stream_once, nullptr);
+      launch_spd_level(d, S.dof, st, S.dev, fwd, v.tile0, v.nwide, v.nnarrow, v.rows, vec, S.ytmp.p, 1.0, 0.0, S.stream_once, nullptr);
       HIP_CHECK(hipEventRecord(e1, st));
       HIP_CHECK(hipEventSynchronize(e1));
       float ms;
@@ -637,10 +627,10 @@ static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec) {
     tot_us += best * 1e3;
     tot_mb += bytes / 1e6;
     fprintf(stderr, "[spd] dof %d %s level %2zu fronts %5zu wide tiles %5d x %2d rows, narrow tiles %5d, max_w %4d max_m %4d  %7.2f MB %6.1f us %6.0f GB/s\n",
-            S.dof, fwd ? "fwd" : "bwd", l, fronts.size(), wide, rows, narrow, wmax, mmax, bytes / 1e6, best * 1e3, bytes / (best * 1e-3) / 1e9);
+            S.dof, fwd ? "fwd" : "bwd", l, fronts.size(), v.nwide, v.rows, v.nnarrow, wmax, mmax, bytes / 1e6, best * 1e3, bytes / (best * 1e-3) / 1e9);
   };
-  for (size_t l = 0; l + 1 < S.fwd_level_ptr.size(); l++) run(true, l, S.fwd_level_ptr, S.fwd_rows[l], F.by_height[l], S.fwd_level_bytes[l]);
-  for (size_t l = 0; l + 1 < S.bwd_level_ptr.size(); l++) run(false, l, S.bwd_level_ptr, S.bwd_rows[l], F.by_depth[l], S.bwd_level_bytes[l]);
+  for (size_t l = 0; l < S.fwd_levels.size(); l++) run(true, l, S.fwd_levels[l], F.by_height[l], S.fwd_level_bytes[l]);
+  for (size_t l = 0; l < S.bwd_levels.size(); l++) run(false, l, S.bwd_levels[l], F.by_depth[l], S.bwd_level_bytes[l]);
   fprintf(stderr, "[spd] dof %d total %.1f MB %.1f us %.0f GB/s (launches timed one by one)\n", S.dof, tot_mb, tot_us, tot_mb / tot_us * 1e3);
   HIP_CHECK(hipEventDestroy(e0));
   HIP_CHECK(hipEventDestroy(e1));

@@ -87,9 +87,8 @@ struct SpdSolverDev {
   DevBuf<int> piv_idx, upd_idx, asm_ptr, ubuf_dst;
   DevBuf<double> W, WT, ubuf, ytmp;   // W / WT: backward / forward panels (see upload)
   DevBuf<SpdItem> fwd_items, bwd_items;
-  DevBuf<int4> fwd_packs, bwd_packs;
-  std::vector<int> fwd_level_ptr, bwd_level_ptr;  // pack ranges per level (one launch each)
-  std::vector<int> fwd_rows, bwd_rows;            // tile height of the wide class per level (64 or 16)
+  struct Level { int tile0, nwide, nnarrow, rows; };   // one launch: wide tiles (rows high) first, then narrow ones
+  std::vector<Level> fwd_levels, bwd_levels;
   std::vector<double> fwd_level_bytes, bwd_level_bytes;
   SpdDev dev;
   int dof = 1;

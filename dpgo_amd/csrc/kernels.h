@@ -146,17 +146,15 @@ struct SpdDev {
   const int *ubuf_dst = nullptr;  // per update row of a front (ubuf_off + r): its row in the update buffer
   const double *W = nullptr, *WT = nullptr;           // panels of the backward / forward tiles
   const SpdItem *fwd_items = nullptr, *bwd_items = nullptr;
-  const int4 *fwd_packs = nullptr, *bwd_packs = nullptr;   // {first tile, tiles (1..8), wide?, 0}: one workgroup each
   double *ubuf = nullptr;
 };
-// One level of the forward / backward sweep: packs [pack0, pack0 + npacks), wide tiles `rows` (64 or 16) high.
+// One level of the forward / backward sweep: tiles [tile0, tile0 + nwide) are wide (`rows` = 64 or 16 high, one
+// workgroup each), the next nnarrow tiles are narrow (one wave each).
 // dof = 1: unknown i is the translation of pose i; dof = d: unknown i = (pose i / d, rotation row i % d).
-// vec is a record array, solved in place: forward reads the right-hand side from vec and writes y to ytmp
-// (n x d, matrix order); backward reads ytmp and writes scale * A^-1 b into vec (scale must be +1 or -1).
-// waves (= narrow tiles per pack) of the workgroups that run a level whose wide tiles are `rows` high
-int spd_pack_waves(int rows);
-void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int pack0, int npacks, int rows,
-                      double *vec, double *ytmp, double scale, double level_bytes = 0.0, bool stream_once = true,
+// vec is a record array: forward reads the right-hand side from vec and writes y to ytmp (n x d, matrix
+// order); backward reads ytmp and writes scale * A^-1 b into vec (scale must be +1 or -1).
+void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int tile0, int nwide, int nnarrow,
+                      int rows, double *vec, double *ytmp, double scale, double level_bytes = 0.0, bool stream_once = true,
                       const int *mask = nullptr);   // mask[node] == 0: the node's fronts are skipped
 
 // ---- optional per-launch timing (HIP events on the launch stream), off by default ----

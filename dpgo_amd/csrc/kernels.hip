@@ -1175,26 +1175,30 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
   for (int c = 0; c < D; c++) *(dst + c) = (scale * acc[c]);
 }
 
-// One level of a sweep in one launch.  A workgroup (8 waves) draws a PACK: either one tile of a wide front,
+// One level of a sweep in one launch.  A workgroup (8 waves) takes a PACK: either one tile of a wide front,
 // shared by the 8 waves (ROWS-row tiles), or up to 8 tiles of narrow fronts (reduction length <= 96), one
 // per wave.  Wide packs come first, longest first; the narrow ones fill the tail of the launch.
 template <int D, int DOF, int ROWS, bool FWD, bool NT>
-__global__ __launch_bounds__(64 * SPD_NW(ROWS), ROWS == 64 ? SPD_WPE : 4) void k_spd_level(SpdDev S, const int *mask, int pack0,
-                                                                                      double scale, double *vec, double *ytmp) {
+__global__ __launch_bounds__(64 * SPD_NW(ROWS), ROWS == 64 ? SPD_WPE : 4) void k_spd_level(SpdDev S, const int *mask, int tile0,
+                                                                                      int nwide, int nnarrow, double scale,
+                                                                                      double *vec, double *ytmp) {
   constexpr int CH = 128, NW = SPD_NW(ROWS);
   __shared__ double f[NW][CH * D];
   __shared__ double red[NW * ROWS * D];
-  const int4 pk = (FWD ? S.fwd_packs : S.bwd_packs)[pack0 + blockIdx.x];   // {first tile, tiles, wide?, 0}
+  // workgroups [0, nwide) take one wide tile each, the rest NW narrow tiles each (no work list to read: a
+  // tile's index follows from blockIdx)
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const SpdItem *items = FWD ? S.fwd_items : S.bwd_items;
-  if (pk.z == 0) {
-    if (wv >= pk.y) return;
-    const SpdItem it = load_item(items + pk.x + wv);
+  const SpdItem *items = (FWD ? S.fwd_items : S.bwd_items) + tile0;
+  const int b = blockIdx.x;
+  if (b >= nwide) {
+    const int t = (b - nwide) * NW + wv;
+    if (t >= nnarrow) return;
+    const SpdItem it = load_item(items + nwide + t);
     if (mask && !mask[it.node]) return;
     if constexpr (FWD) spd_fwd_tile<D, DOF, 1, CH, 64, NT>(S, it, vec, ytmp, f[wv], red, 0, lane);
     else spd_bwd_tile<D, DOF, 1, CH, 64, NT>(S, it, scale, ytmp, vec, f[wv], red, 0, lane);
   } else {
-    const SpdItem it = load_item(items + pk.x);
+    const SpdItem it = load_item(items + b);
     if (mask && !mask[it.node]) return;   // (uniform over the workgroup)
     if constexpr (FWD) spd_fwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, vec, ytmp, f[wv], red, wv, lane);
     else spd_bwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, scale, ytmp, vec, f[wv], red, wv, lane);
@@ -1454,16 +1458,18 @@ void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows,
                      arrived, host_flag, seq);
 }
 
-void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int pack0, int npacks, int rows,
-                      double *vec, double *ytmp, double scale, double level_bytes, bool stream_once, const int *mask) {
+void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int tile0, int nwide, int nnarrow,
+                      int rows, double *vec, double *ytmp, double scale, double level_bytes, bool stream_once,
+                      const int *mask) {
+  const int nw = SPD_NW(rows), npacks = nwide + (nnarrow + nw - 1) / nw;
   if (npacks == 0) return;
   ProfScope ps(forward ? PK_SPD_FWD : PK_SPD_BWD, st, level_bytes);
 #define SPD_LAUNCH2(DOFV, ROWSV, NTV)                                                                            \
   do {                                                                                                         \
     if (forward)                                                                                               \
-      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, true, NTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, mask, pack0, scale, vec, ytmp);  \
+      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, true, NTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, mask, tile0, nwide, nnarrow, scale, vec, ytmp);  \
     else                                                                                                       \
-      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, false, NTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, mask, pack0, scale, vec, ytmp); \
+      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, false, NTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, mask, tile0, nwide, nnarrow, scale, vec, ytmp); \
   } while (0)
 #define SPD_LAUNCH(DOFV, ROWSV)                \
   do {                                         \
@@ -1483,7 +1489,5 @@ void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forw
 #undef SPD_LAUNCH
 #undef SPD_LAUNCH2
 }
-
-int spd_pack_waves(int rows) { return SPD_NW(rows); }
 
 }  // namespace dpgo
