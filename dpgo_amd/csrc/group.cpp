@@ -651,9 +651,10 @@ void Group::recover_translations(double *X, const double *g) {
   solve_tt(T1_.p, X, -1.0);
 }
 
-// y = base + G_{:,t} xt.t
-void Group::apply_tcol(const double *xt, const double *base, double *y) {
-  launch_bsr_tcol(d_, st_, T_, cur_mask_, G_.dev, G_.tcol.p, xt, base, y);
+// y = base + G_{:,t} xt.t, with the row-local epilogues of launch_bsr_tcol
+void Group::apply_tcol(const double *xt, const double *base, double *y, int mode, const double *X, const double *nabla,
+                       const double *Rdot, double *out2) {
+  launch_bsr_tcol(d_, st_, T_, cur_mask_, G_.dev, G_.tcol.p, xt, base, y, mode, X, nabla, Rdot, out2);
 }
 
 // partial[slot] = tr(X^T (g + 1/2 G X))     (DPGOProblem.cpp:180-205; + f on the host)

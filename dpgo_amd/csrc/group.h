@@ -238,7 +238,8 @@ class Group {
   void solve_tt(double *vec, double scale);
   void solve_tt(double *in, double *out, double scale);   // out.t <- scale * G_tt^-1 in.t
   void solve_rr(double *in, double *out, double scale);   // out.R <- scale * (G_RR + lambda I)^-1 in.R
-  void apply_tcol(const double *xt, const double *base, double *y);               // in place on translation rows
+  void apply_tcol(const double *xt, const double *base, double *y, int mode = 0, const double *X = nullptr,
+                  const double *nabla = nullptr, const double *Rdot = nullptr, double *out2 = nullptr);               // in place on translation rows
   void solve_rr(double *vec, double scale);               // in place on rotation rows
   void recover_translations(double *X, const double *g);  // X.t = -Gtt^-1 (g_t + G_tR X.R) for masked nodes
   void eval_G(const double *X, const double *g, int slot);

@@ -64,8 +64,10 @@ void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, const i
 
 // y = base + A[:, translation column] t over own rows; tval: the first column of every block of A ((d+1) doubles per
 // block), xt: records whose translation row is t.  A quarter of the traffic of launch_bsr.
+// mode 1: also out2 = [0 ; Proj_X(y.R)]; mode 2: y not stored, out2 = [0 ; Proj_X(y.R - sym(nabla.R X.R^T) Rdot.R)], the Hessian-vector product (DPGOProblem.cpp:570-574)
 void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, const int *mask, const BsrDev &A, const double *tval,
-                     const double *xt, const double *base, double *y);
+                     const double *xt, const double *base, double *y, int mode = 0, const double *X = nullptr,
+                     const double *nabla = nullptr, const double *Rdot = nullptr, double *out2 = nullptr);
 
 // Robust inter-edge pass (B-form, DPGOProblem.cpp:634-725).
 //  mode 0 (update): all rows.  DfE <- B1^T W B1 Z; own rows also g <- DfE - D z.
@@ -107,10 +109,6 @@ void launch_cg_init(int d, hipStream_t st, const SegTable &T, const int *mask, c
 // gradF = [V.x ; Proj_R(V.Y)] (DPGOProblem.cpp:145-162); partial ||gradF||^2; out may be null
 void launch_tangent_full(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
                          const double *V, double *out, double *partials, int slot);
-// out.Y = Proj_{X.Y}( in.Y - sym(sbdA.Y ... ) ) helpers for the Riemannian Hessian (DPGOProblem.cpp:552-577):
-//   out.Y = Proj_R( E.Y - sym(nabla.Y R^T) Rdot.Y ) with R = X.Y; translation row of out set to 0
-void launch_hess_epilogue(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
-                          const double *E, const double *nabla, const double *Rdot, double *out);
 // out.Y = Proj_R(in.Y), out.x = 0                                       (DPGOProblem.cpp:164-178)
 void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
                         const double *in, double *out);

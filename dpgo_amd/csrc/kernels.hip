@@ -312,13 +312,45 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr(const Seg *segs, const int
   if (partial) block_store<1, 4 * SEG_ROWS / 64>(part, partial + SEGB, 0);
 }
 
+// out (d x d) = Proj_R(E - sym(nabla R^T) Rdot): the rotation rows of the Riemannian Hessian-vector product
+// (DPGOProblem.cpp:570-574; SymBlockDiagProduct(A = Rdot, B = R, C = nabla), SOdProduct.h:64-89)
+template <int D>
+__device__ __forceinline__ void hess_epilogue_rows(const double *R, const double *E, const double *nb, const double *rd,
+                                                   double *out) {
+  double G[D * D], F[D * D];
+#pragma unroll
+  for (int r = 0; r < D; r++)
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+      double a = 0;
+#pragma unroll
+      for (int k = 0; k < D; k++) a = fma(nb[r * D + k], R[c * D + k], a);
+      G[r * D + c] = a;
+    }
+#pragma unroll
+  for (int r = 0; r < D; r++)
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+      double a = E[r * D + c];
+#pragma unroll
+      for (int k = 0; k < D; k++) a = fma(-0.5 * (G[r * D + k] + G[k * D + r]), rd[k * D + c], a);
+      F[r * D + c] = a;
+    }
+  tangent_proj<D>(R, F, out);
+}
+
 // y = base + A[:, translation column] t: what A x adds when only the translation rows of x change.  The
 // first column of every (d+1) x (d+1) block is kept in a compact copy (tval, d+1 doubles per block), so
 // this pass moves a quarter of the operator.  Used after a G_tt solve: G [t ; R] = G [0 ; R] + G_{:,t} t,
 // with the first product already there as the right-hand side of that solve.
+// Row-local epilogues (mode): 1 = also out2 = [0 ; Proj_X(y.R)] (the reduced Riemannian gradient when y is the
+// model gradient); 2 = y is not stored, out2 = [0 ; Proj_X(y.R - sym(nabla.R X.R^T) Rdot.R)] (the Hessian-vector
+// product when y = G [tdot ; Rdot]).
 template <int D>
 __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr_tcol(const Seg *segs, const int *mask, BsrDev A, const double *tval,
-                                                         const double *xt, const double *base, double *y) {
+                                                         const double *xt, const double *base, double *y, int mode,
+                                                         const double *X, const double *nabla, const double *Rdot,
+                                                         double *out2) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
   if (mask && !mask[s.node]) return;
@@ -348,7 +380,21 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr_tcol(const Seg *segs, cons
     load_vec<RS>(base + (size_t)row * RS, bv);
 #pragma unroll
     for (int k = 0; k < RS; k++) acc[k] += bv[k];
-    store_vec<RS>(y + (size_t)row * RS, acc);
+    if (mode != 2) store_vec<RS>(y + (size_t)row * RS, acc);
+    if (mode != 0) {
+      double x[RS], o[RS];
+      load_vec<RS>(X + (size_t)row * RS, x);
+#pragma unroll
+      for (int k = 0; k < D; k++) o[k] = 0.0;
+      if (mode == 1) tangent_proj<D>(x + D, acc + D, o + D);
+      else {
+        double nb[RS], rd[RS];
+        load_vec<RS>(nabla + (size_t)row * RS, nb);
+        load_vec<RS>(Rdot + (size_t)row * RS, rd);
+        hess_epilogue_rows<D>(x + D, acc + D, nb + D, rd + D, o + D);
+      }
+      store_vec<RS>(out2 + (size_t)row * RS, o);
+    }
   }
 }
 
@@ -774,7 +820,6 @@ __global__ __launch_bounds__(SEG_ROWS) void k_tangent_full(const Seg *segs, cons
 }
 
 // mode 0: out.Y = Proj_R(in.Y)                         (reduced_tangent_space_projection)
-// mode 1: out.Y = Proj_R(E.Y - sym(nabla.Y R^T) Rdot.Y) (Hessian epilogue, DPGOProblem.cpp:570-574)
 // mode 2: out.Y = proj_SO(d)(R + in.Y)                  (SOdProduct::retract)
 template <int D>
 __global__ __launch_bounds__(SEG_ROWS) void k_rot_op(const Seg *segs, const int *mask, int mode, const double *X,
@@ -793,30 +838,6 @@ __global__ __launch_bounds__(SEG_ROWS) void k_rot_op(const Seg *segs, const int 
   const double *R = x + D;
   if (mode == 0) {
     tangent_proj<D>(R, v + D, o + D);
-  } else if (mode == 1) {
-    double nb[RS], rd[RS], G[D * D], F[D * D];
-    load_vec<RS>(nabla + (size_t)row * RS, nb);
-    load_vec<RS>(Rdot + (size_t)row * RS, rd);
-    // sym(nabla R^T) Rdot      (SymBlockDiagProduct(A=Rdot, B=R, C=nabla), SOdProduct.h:64-89)
-#pragma unroll
-    for (int r = 0; r < D; r++)
-#pragma unroll
-      for (int c = 0; c < D; c++) {
-        double a = 0;
-#pragma unroll
-        for (int k = 0; k < D; k++) a = fma(nb[D + r * D + k], R[c * D + k], a);
-        G[r * D + c] = a;
-      }
-#pragma unroll
-    for (int r = 0; r < D; r++)
-#pragma unroll
-      for (int c = 0; c < D; c++) {
-        double a = v[D + r * D + c];
-#pragma unroll
-        for (int k = 0; k < D; k++) a = fma(-0.5 * (G[r * D + k] + G[k * D + r]), rd[D + k * D + c], a);
-        F[r * D + c] = a;
-      }
-    tangent_proj<D>(R, F, o + D);
   } else {
     double M[D * D];
 #pragma unroll
@@ -1304,11 +1325,12 @@ void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, const i
 }
 
 void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, const int *mask, const BsrDev &A, const double *tval,
-                     const double *xt, const double *base, double *y) {
+                     const double *xt, const double *base, double *y, int mode, const double *X, const double *nabla,
+                     const double *Rdot, double *out2) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_BSR, st, (double)A.nnzb * (8.0 * (d + 1) + 4 + 8.0 * d) + 2.0 * A.nrows * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_bsr_tcol<D>), dim3(T.nseg_own), dim3(4 * SEG_ROWS), 0, st, T.segs, mask, A, tval,
-                                        xt, base, y));
+                                        xt, base, y, mode, X, nabla, Rdot, out2));
 }
 
 void launch_inter(int d, hipStream_t st, const SegTable &T, const int *mask, const InterEdgesDev &E, int loss,
@@ -1409,14 +1431,6 @@ void launch_tangent_full(int d, hipStream_t st, const SegTable &T, const int *ma
   ProfScope ps(PK_ROTOP, st, 2.0 * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_tangent_full<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, X,
                                         V, out, part));
-}
-
-void launch_hess_epilogue(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
-                          const double *E, const double *nabla, const double *Rdot, double *out) {
-  if (T.nseg_own == 0) return;
-  ProfScope ps(PK_ROTOP, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, 1, X, E,
-                                        nabla, Rdot, out));
 }
 
 void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,

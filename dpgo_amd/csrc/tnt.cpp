@@ -46,7 +46,7 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
   const int L = num_local();
   const bool use_precon = (o.preconditioner == 1) && Lrr_.F.n > 0;
   double *nabla = tmp_[0].p, *grad = tmp_[1].p, *sk = tmp_[2].p, *rk = tmp_[3].p, *vk = tmp_[4].p, *pk = tmp_[5].p,
-         *Hp = tmp_[6].p, *xprop = tmp_[7].p, *w1 = tmp_[8].p, *w2 = tmp_[9].p, *pg = tmp_[10].p, *hh = tmp_[11].p,
+         *Hp = tmp_[6].p, *xprop = tmp_[7].p, *w1 = tmp_[8].p, *pg = tmp_[10].p, *hh = tmp_[11].p,
          *w3 = tmp_[12].p, *nprop = tmp_[13].p;
   // hh accumulates H s_k alongside s_k (every step s_k += c p_k is mirrored by hh += c H p_k), so the
   // predicted decrease needs no extra Hessian-vector product: same value as Hess(x, h) of TNT.h:514-515
@@ -66,16 +66,18 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
   // nabla = G Y + g and grad = Proj_Y(nabla) (rotation rows).  from_base: Y.t was just recovered from Y.R with
   // this g (recover_translations), so T1_ = G [0 ; Y.R] + g is there and only the translation column is missing.
   auto quad_model = [&](const double *Y, bool from_base) {
-    if (from_base) apply_tcol(Y, T1_.p, nabla);
-    else launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Y, false, g, nabla, nullptr, 0, nullptr, nullptr, 0);
+    if (from_base) {
+      apply_tcol(Y, T1_.p, nabla, 1, Y, nullptr, nullptr, grad);   // nabla and grad in one pass
+      return;
+    }
+    launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Y, false, g, nabla, nullptr, 0, nullptr, nullptr, 0);
     launch_tangent_rot(d_, st_, T_, cur_mask_, Y, nabla, grad);
   };
   // Hess f(Y)[v] (DPGOProblem.cpp:552-577): tdot = -G_tt^-1 G_tR v.R, then Proj(G [tdot ; v.R] - ...)
   auto hess = [&](const double *Y, const double *v, double *out) {
     launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, v, true, nullptr, w1, nullptr, 0, nullptr, nullptr, 0);   // G [0 ; v.R]
     solve_tt(w1, w3, -1.0);                   // w3.t = tdot
-    apply_tcol(w3, w1, w2);                   // w2 = G [tdot ; v.R]
-    launch_hess_epilogue(d_, st_, T_, cur_mask_, Y, w2, nabla, v, out);
+    apply_tcol(w3, w1, nullptr, 2, Y, nabla, v, out);   // out = Proj(G [tdot ; v.R] - sym(nabla R^T) v.R)
   };
   auto precon = [&](const double *Y, const double *v, double *out) {
     if (!use_precon) {
