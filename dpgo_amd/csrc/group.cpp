@@ -1101,8 +1101,7 @@ int Group::amm(const std::vector<int> &locals) {
   constexpr int DS = 2 * MAX_DOTS;
   launch_proximal(d_, st_, T_, cur_mask_, Y_.p, Dfx_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, Xak_.p, partials_.p, DS);
   eval_G(Xakh_.p, gc_.p, DS + 1);
-  // Xak.R = Xakh.R; Xak.t = recover(R, g)   (:369-372)
-  copy_rows(Xak_.p, Xakh_.p, false, 2);
+  // Xak.R = Xakh.R (written by the proximal kernel); Xak.t = recover(R, g)   (:369-372)
   recover_translations(Xak_.p, gx_.p);
   std::vector<int> plain, ref;
   for (int a : locals) (res_[a].refined ? ref : plain).push_back(a);

@@ -85,9 +85,10 @@ void launch_cost(int d, hipStream_t st, const SegTable &T, const int *mask, cons
 // partial[slot] = sum |a_p - b_p|^2 over own rows
 void launch_sqdist(int d, hipStream_t st, const SegTable &T, const int *mask, const double *a, const double *b,
                    double *partials, int slot);
-// Xout = proximal(Z, Df) per own pose (DPGOProblem.cpp:600-632); slot>=0: partial ||Xout - Xref||^2.
+// Xout = proximal(Z, Df) per own pose (DPGOProblem.cpp:600-632).  With Xref: partial ||Xout - Xref||^2, after which
+// Xref takes over Xout's rotation rows (the next step recovers its translations: DPGOHash.cpp:369-372).
 void launch_proximal(int d, hipStream_t st, const SegTable &T, const int *mask, const double *Z, const double *Df,
-                     const double *Tinv, const double *N, const double *V, double *Xout, const double *Xref,
+                     const double *Tinv, const double *N, const double *V, double *Xout, double *Xref,
                      double *partials, int slot);
 
 // out = a + gamma[node] * (a - b) over all rows (own + neighbour)      (DPGOHash.cpp:255-262)

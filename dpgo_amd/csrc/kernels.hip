@@ -628,7 +628,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_sqdist(const Seg *segs, const int 
 template <int D>
 __global__ __launch_bounds__(SEG_ROWS) void k_proximal(const Seg *segs, const int *mask, const double *Z,
                                                   const double *Df, const double *Tinv, const double *Nv,
-                                                  const double *Vb, double *Xout, const double *Xref,
+                                                  const double *Vb, double *Xout, double *Xref,
                                                   double *partial) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
@@ -673,6 +673,10 @@ __global__ __launch_bounds__(SEG_ROWS) void k_proximal(const Seg *segs, const in
 #pragma unroll
       for (int k = 0; k < RS; k++) { const double dd = out[k] - ref[k]; p = fma(dd, dd, p); }
       part[0] = p;
+      // the reference point takes over the new rotations (its translations follow from a solve: DPGOHash.cpp:369-372)
+#pragma unroll
+      for (int k = D; k < RS; k++) ref[k] = out[k];
+      store_vec<RS>(Xref + (size_t)row * RS, ref);
     }
   }
   if (partial) block_store<1>(part, partial + SEGB, 0);
@@ -1363,7 +1367,7 @@ void launch_sqdist(int d, hipStream_t st, const SegTable &T, const int *mask, co
 }
 
 void launch_proximal(int d, hipStream_t st, const SegTable &T, const int *mask, const double *Z, const double *Df,
-                     const double *Tinv, const double *N, const double *V, double *Xout, const double *Xref,
+                     const double *Tinv, const double *N, const double *V, double *Xout, double *Xref,
                      double *partials, int slot) {
   if (T.nseg_own == 0) return;
   double *part = (Xref && partials) ? partials + (size_t)slot * T.nseg_all : nullptr;
