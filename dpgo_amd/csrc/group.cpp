@@ -155,6 +155,12 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
       items[i] = it;
       total += t.len * ld;
     }
+    if (getenv("DPGO_SPD_DUMP")) {
+      int64_t used = 0;
+      for (const Tile &t : tiles) used += t.len * t.count;
+      fprintf(stderr, "[spd] dof %d %s panels: %.1f MB stored, %.1f MB of entries (padding %.1f %%), %zu tiles\n", dof, fwd ? "fwd" : "bwd",
+              total * 8e-6, used * 8e-6, 100.0 * (total - used) / std::max<int64_t>(used, 1), tiles.size());
+    }
     std::vector<double> panels((size_t)std::max<int64_t>(total, 1), 0.0);
 #pragma omp parallel for schedule(dynamic, 16)
     for (size_t i = 0; i < tiles.size(); i++) {

@@ -150,8 +150,8 @@ struct SpdDev {
 // One level of the forward / backward sweep: tiles [tile0, tile0 + nwide) are wide (`rows` = 64 or 16 high, one
 // workgroup each), the next nnarrow tiles are narrow (one wave each).
 // dof = 1: unknown i is the translation of pose i; dof = d: unknown i = (pose i / d, rotation row i % d).
-// vec is a record array: forward reads the right-hand side from vec and writes y to ytmp (n x d, matrix
-// order); backward reads ytmp and writes scale * A^-1 b into vec (scale must be +1 or -1).
+// vec is a record array: forward reads the right-hand side from vec and writes y to ytmp (n x d, the pivots
+// of a front consecutive); backward reads ytmp and writes scale * A^-1 b into vec (scale must be +1 or -1).
 void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int tile0, int nwide, int nnarrow,
                       int rows, double *vec, double *ytmp, double scale, double level_bytes = 0.0, bool stream_once = true,
                       const int *mask = nullptr);   // mask[node] == 0: the node's fronts are skipped

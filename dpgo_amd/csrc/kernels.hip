@@ -999,9 +999,13 @@ __device__ __forceinline__ void stream_rest(const double *wp, int ld, int kq, in
                                             double (&a)[HB], double (&acc)[D]) {
   double b[HB];
   int kk = kq;
+#ifdef SPD_PROBE_NOFMA   /* measurement only (wrong results): what the loop costs without LDS reads and FMAs */
+#define SPD_FMA(buf, k0) _Pragma("unroll") for (int q = 0; q < HB; q++) acc[0] += buf[q];
+#else
 #define SPD_FMA(buf, k0)                                                                     \
   _Pragma("unroll") for (int q = 0; q < HB; q++)                                            \
       _Pragma("unroll") for (int c = 0; c < D; c++) acc[c] = fma(buf[q], fw[((k0) + q * KQ) * D + c], acc[c]);
+#endif
 #define SPD_LOAD(buf, k0) \
   _Pragma("unroll") for (int q = 0; q < HB; q++) buf[q] = LDW(wp + (size_t)((k0) + q * KQ) * ld);
   while (have) {
@@ -1122,7 +1126,7 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
   }
   if (!writer) return;
   if (p < w) {
-    double *dst = ytmp + (size_t)piv[p] * D;
+    double *dst = ytmp + (size_t)(it.piv_ptr + p) * D;   // y in front order: the backward sweep reads it back contiguously
 #pragma unroll
     for (int c = 0; c < D; c++) *(dst + c) = (acc[c]);
   } else {
@@ -1160,7 +1164,7 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
       const int p = p0 + pp;
       // ancestors' entries were scaled when they were written: undo by linearity (scale is +-1)
       const double sc = p < w ? 1.0 : scale;
-      const double *src = p < w ? ytmp + (size_t)piv[p] * D : vec + vaddr<D, DOF>(upd[p - w]);
+      const double *src = p < w ? ytmp + (size_t)(it.piv_ptr + p) * D : vec + vaddr<D, DOF>(upd[p - w]);
 #pragma unroll
       for (int c = 0; c < D; c++) fw[pp * D + c] = sc * *(src + c);
     }
