@@ -104,6 +104,9 @@ void launch_axpby_node(int d, hipStream_t st, const SegTable &T, const int *mask
 // (0 whole record, 1 translation row, 2 rotation rows); always writes MAX_DOTS slots
 void launch_dots(int d, hipStream_t st, const SegTable &T, const int *mask, int n, const double *const *a,
                  const double *const *b, const int *parts, double *partials, int slot0);
+// one CG step (IterativeSolvers.h:340-390): s += c[node] p, hs += c[node] Hp, and r += cr[node] Hp where cr != 0
+void launch_cg_step(int d, hipStream_t st, const SegTable &T, const int *mask, const double *c, const double *cr,
+                    const double *p, const double *Hp, double *s, double *hs, double *r);
 // start of a truncated CG (IterativeSolvers.h:230-260): s = 0, hs = 0, r = grad, v = pgrad, p = -pgrad
 void launch_cg_init(int d, hipStream_t st, const SegTable &T, const int *mask, const double *grad, const double *pgrad,
                     double *s, double *hs, double *r, double *v, double *p);

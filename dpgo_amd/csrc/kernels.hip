@@ -741,6 +741,36 @@ __global__ __launch_bounds__(SEG_ROWS) void k_axpby_node(const Seg *segs, const 
   store_vec<RS>(out + (size_t)row * RS, va);
 }
 
+// one CG step of every node in the mask (IterativeSolvers.h:340-390): s += c p, H s += c H p and, where the node
+// goes on (cr != 0), r += cr H p
+template <int D>
+__global__ __launch_bounds__(SEG_ROWS) void k_cg_step(const Seg *segs, const int *mask, const double *c, const double *cr,
+                                                      const double *p, const double *Hp, double *s, double *hs, double *r) {
+  constexpr int RS = Dim<D>::RS;
+  const Seg sg = segs[SEGB];
+  if (mask && !mask[sg.node]) return;
+  const int row = sg.begin + threadIdx.x;
+  if (row >= sg.end) return;
+  const double cc = c[sg.node], cc_r = cr[sg.node];
+  double vp[RS], vh[RS], v[RS];
+  load_vec<RS>(p + (size_t)row * RS, vp);
+  load_vec<RS>(Hp + (size_t)row * RS, vh);
+  load_vec<RS>(s + (size_t)row * RS, v);
+#pragma unroll
+  for (int k = 0; k < RS; k++) v[k] = fma(cc, vp[k], 1.0 * v[k]);
+  store_vec<RS>(s + (size_t)row * RS, v);
+  load_vec<RS>(hs + (size_t)row * RS, v);
+#pragma unroll
+  for (int k = 0; k < RS; k++) v[k] = fma(cc, vh[k], 1.0 * v[k]);
+  store_vec<RS>(hs + (size_t)row * RS, v);
+  if (cc_r != 0.0) {
+    load_vec<RS>(r + (size_t)row * RS, v);
+#pragma unroll
+    for (int k = 0; k < RS; k++) v[k] = fma(cc_r, vh[k], 1.0 * v[k]);
+    store_vec<RS>(r + (size_t)row * RS, v);
+  }
+}
+
 template <int D>
 __global__ __launch_bounds__(SEG_ROWS) void k_cg_init(const Seg *segs, const int *mask, const double *grad,
                                                       const double *pgrad, double *s, double *hs, double *r, double *v,
@@ -1407,6 +1437,14 @@ void launch_axpby_node(int d, hipStream_t st, const SegTable &T, const int *mask
   ProfScope ps(PK_AXPBY, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_axpby_node<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, alpha,
                                         a, beta, b, out));
+}
+
+void launch_cg_step(int d, hipStream_t st, const SegTable &T, const int *mask, const double *c, const double *cr,
+                    const double *p, const double *Hp, double *s, double *hs, double *r) {
+  if (T.nseg_own == 0) return;
+  ProfScope ps(PK_AXPBY, st, 8.0 * T.rows_own * 8.0 * (d + 1) * d);
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cg_step<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, c, cr, p, Hp,
+                                        s, hs, r));
 }
 
 void launch_dots(int d, hipStream_t st, const SegTable &T, const int *mask, int n, const double *const *a,

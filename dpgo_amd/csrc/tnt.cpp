@@ -197,15 +197,16 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
         s.sk_M_2 = skp1;   // provisional: committed below together with sk_M_pk / pk_M_2
         cont.push_back(a);
       }
-      // s_k += c1 p_k for every node of C (final boundary step or regular step)
+      // s_k += c1 p_k (final boundary step or regular step) and H s_k alongside, for every node of C; nodes that
+      // go on also get r_k += alpha H p_k -- one pass
       {
-        const double *one_d = upload_coef(ones), *c1_d = upload_coef(c1);
-        launch_axpby_node(d_, st_, T_, cur_mask_, one_d, sk, c1_d, pk, sk);
-        launch_axpby_node(d_, st_, T_, cur_mask_, one_d, hh, c1_d, Hp, hh);
+        std::vector<double> cr(L, 0.0);
+        for (int a : cont) cr[a] = c1[a];
+        const double *c1_d = upload_coef(c1), *cr_d = upload_coef(cr);
+        launch_cg_step(d_, st_, T_, cur_mask_, c1_d, cr_d, pk, Hp, sk, hh, rk);
       }
       if (cont.empty()) continue;
       set_mask(cont);
-      launch_axpby_node(d_, st_, T_, cur_mask_, upload_coef(ones), rk, upload_coef(c1), Hp, rk);
       if (use_precon) precon(X, rk, vk); else copy_rows(vk, rk, false, 0);
       dots({{rk, vk}});
       std::vector<double> beta(L, 0.0);
