@@ -324,17 +324,15 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
     T_.own_ptr = own_seg_ptr_.p;
     T_.nbr_ptr = nbr_seg_ptr_.p;
   }
-  mask_ring_.alloc((size_t)RING * L);
-  coef_ring_.alloc((size_t)RING * L);
-  gamma_.alloc(L);
-  HIP_CHECK(hipHostMalloc((void **)&h_mask_, sizeof(int) * std::max(L, 1) * RING));
-  HIP_CHECK(hipHostMalloc((void **)&h_coef_, sizeof(double) * std::max(L, 1) * RING));
-  cur_mask_ = mask_ring_.p;
+  if (L > MAX_LOCAL_NODES) {
+    fprintf(stderr, "[dpgo_amd] ERROR: a group hosts at most %d nodes (%d requested).\n", MAX_LOCAL_NODES, L);
+    return;
+  }
+  cur_mask_ = ALL_NODES;
   HIP_CHECK(hipHostMalloc((void **)&h_scal_, sizeof(double) * std::max(L, 1) * MAX_SLOTS + 128, hipHostMallocMapped | hipHostMallocCoherent));
   h_flag_ = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(h_scal_) + sizeof(double) * std::max(L, 1) * MAX_SLOTS + 64);
   *h_flag_ = 0;
   reduce_arrived_.alloc(1);
-  HIP_CHECK(hipHostMalloc((void **)&h_gamma_, sizeof(double) * std::max(L, 1)));
   partials_.alloc((size_t)MAX_SLOTS * std::max(T_.nseg_all, 1));
 
   // ---- operators
@@ -504,10 +502,7 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
 }
 
 Group::~Group() {
-  if (h_mask_) (void)hipHostFree(h_mask_);
-  if (h_coef_) (void)hipHostFree(h_coef_);
   if (h_scal_) (void)hipHostFree(h_scal_);
-  if (h_gamma_) (void)hipHostFree(h_gamma_);
   if (st_) (void)hipStreamDestroy(st_);
 }
 
@@ -550,27 +545,11 @@ void Group::upload_bsr(const std::vector<const BsrMatrix *> &per_node, bool rows
 
 void Group::sync() const { HIP_CHECK(hipStreamSynchronize(st_)); }
 
+// The nodes the following launches work on: a bit mask passed to every kernel by value (no upload).
 void Group::set_mask(const std::vector<int> &locals) {
-  if (locals == last_mask_) return;
-  last_mask_ = locals;
-  const int L = num_local();
-  mask_slot_ = (mask_slot_ + 1) % RING;
-  int *h = h_mask_ + (size_t)mask_slot_ * L;
-  for (int a = 0; a < L; a++) h[a] = 0;
-  for (int a : locals) h[a] = 1;
-  int *dptr = mask_ring_.p + (size_t)mask_slot_ * L;
-  HIP_CHECK(hipMemcpyAsync(dptr, h, sizeof(int) * L, hipMemcpyHostToDevice, st_));
-  cur_mask_ = dptr;
-}
-
-const double *Group::upload_coef(const std::vector<double> &per_node) {
-  const int L = num_local();
-  coef_slot_ = (coef_slot_ + 1) % RING;
-  double *h = h_coef_ + (size_t)coef_slot_ * L;
-  for (int a = 0; a < L; a++) h[a] = per_node[a];
-  double *dptr = coef_ring_.p + (size_t)coef_slot_ * L;
-  HIP_CHECK(hipMemcpyAsync(dptr, h, sizeof(double) * L, hipMemcpyHostToDevice, st_));
-  return dptr;
+  NodeMask m = 0;
+  for (int a : locals) m |= 1ull << a;
+  cur_mask_ = m;
 }
 
 void Group::fetch(int nslots, bool all_rows) {
@@ -596,7 +575,7 @@ void Group::copy_rows(double *dst, const double *src, bool all_rows, int part) {
 
 // out <- scale * A^-1 in (the unknowns' entries of the records; everything else in `out` is left alone).
 // The forward sweep only reads `in`, the backward sweep only touches `out`: in == out solves in place.
-static void spd_run(int d, hipStream_t st, SpdSolverDev &S, const int *mask, double *in, double *out, double scale) {
+static void spd_run(int d, hipStream_t st, SpdSolverDev &S, NodeMask mask, double *in, double *out, double scale) {
   for (size_t l = 0; l < S.fwd_levels.size(); l++) {
     const SpdSolverDev::Level &v = S.fwd_levels[l];
     launch_spd_level(d, S.dof, st, S.dev, true, v.tile0, v.nwide, v.nnarrow, v.rows, in, S.ytmp.p, scale, S.fwd_level_bytes[l],
@@ -624,7 +603,7 @@ static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec) {
     float best = 1e30f;
     for (int rep = 0; rep < 6; rep++) {
       HIP_CHECK(hipEventRecord(e0, st));
-      launch_spd_level(d, S.dof, st, S.dev, fwd, v.tile0, v.nwide, v.nnarrow, v.rows, vec, S.ytmp.p, 1.0, 0.0, S.stream_once, nullptr);
+      launch_spd_level(d, S.dof, st, S.dev, fwd, v.tile0, v.nwide, v.nnarrow, v.rows, vec, S.ytmp.p, 1.0, 0.0, S.stream_once, ALL_NODES);
       HIP_CHECK(hipEventRecord(e1, st));
       HIP_CHECK(hipEventSynchronize(e1));
       float ms;
@@ -1078,13 +1057,13 @@ int Group::mm(const std::vector<int> &locals) {
 void Group::prepare_extrapolated() {
   const Options &o = opt_;
   const bool trivial = (o.loss == 0);
-  for (int a = 0; a < num_local(); a++) h_gamma_[a] = res_[a].gamma;
-  HIP_CHECK(hipMemcpyAsync(gamma_.p, h_gamma_, sizeof(double) * num_local(), hipMemcpyHostToDevice, st_));
+  NodeCoefs gam;
+  for (int a = 0; a < num_local(); a++) gam.a[a] = gam.b[a] = res_[a].gamma;
   // own AND neighbour rows are extrapolated with the local gamma (DPGOHash.cpp:255-256)
-  launch_extrapolate(d_, st_, T_, true, cur_mask_, gamma_.p, Zc_.p, Zp_.p, Y_.p);
+  launch_extrapolate(d_, st_, T_, true, cur_mask_, gam, Zc_.p, Zp_.p, Y_.p);
   if (trivial) {
-    launch_extrapolate(d_, st_, T_, false, cur_mask_, gamma_.p, gc_.p, gp_.p, gx_.p);      // :259-262
-    launch_extrapolate(d_, st_, T_, false, cur_mask_, gamma_.p, Dfc_.p, Dfp_.p, Dfx_.p);
+    launch_extrapolate(d_, st_, T_, false, cur_mask_, gam, gc_.p, gp_.p, gx_.p);      // :259-262
+    launch_extrapolate(d_, st_, T_, false, cur_mask_, gam, Dfc_.p, Dfp_.p, Dfx_.p);
   } else {
     // evaluate_g_and_Df(Y) (:264 -> DPGOProblem.cpp:683-749)
     launch_inter(d_, st_, T_, cur_mask_, E_, o.loss, o.loss_reg, 1, false, Y_.p, nullptr, nullptr, Dd_.p, nullptr, gx_.p,

@@ -182,20 +182,10 @@ class Group {
   SegTable T_;
   // masks and per-node coefficients live in rings (device + pinned host), so changing them never
   // needs a stream synchronisation
-  static constexpr int RING = 512;
-  DevBuf<int> mask_ring_;
-  int *h_mask_ = nullptr;          // pinned, RING x L
-  int mask_slot_ = 0;
-  const int *cur_mask_ = nullptr;
-  DevBuf<double> coef_ring_;
-  double *h_coef_ = nullptr;       // pinned, RING x L
-  int coef_slot_ = 0;
-  const double *upload_coef(const std::vector<double> &per_node);
+  NodeMask cur_mask_ = ALL_NODES;  // the nodes the launches work on (set_mask), passed to the kernels by value
   double *h_scal_ = nullptr;       // pinned, written by k_reduce; the flag (one cache line further) follows the scalars
   unsigned long long *h_flag_ = nullptr, fetch_seq_ = 0;
   DevBuf<unsigned> reduce_arrived_;
-  double *h_gamma_ = nullptr;      // pinned
-  DevBuf<double> gamma_;
   DevBuf<double> partials_;
   struct BsrBufs { DevBuf<int> ptr, col; DevBuf<double> val, tcol; BsrDev dev; };   // tcol: first column of every block (G only)
   BsrBufs G_, S_, P_, P0m_, Q_;
@@ -217,7 +207,6 @@ class Group {
   DevBuf<double> Xk_, Zc_, Zp_, Y_, DfE_, Tall_;                 // P0+P1 rows
   DevBuf<double> Xak_, Xakh_, gc_, gp_, Dfc_, Dfp_, gx_, Dfx_, T1_;   // P0 rows
   DevBuf<double> tmp_[14];                                       // P0 rows, TNT work vectors
-  std::vector<int> last_mask_;
   bool star_ = false;
   double *coll_send_ = nullptr, *coll_gathered_ = nullptr;
   AllGatherFn coll_allgather_ = nullptr;

@@ -12,8 +12,8 @@
 //    one workgroup per segment.  Kernels that reduce write one partial per
 //    (slot, segment); k_reduce sums a node's partials in fixed order
 //    (deterministic, no atomics).
-//  * mask[node] == 0 makes every workgroup of that node exit early; this is how
-//    per-node branches of the AMM state machine run without splitting launches.
+//  * every launch carries a NodeMask (bit a = local node a): workgroups of nodes outside it exit early; this
+//    is how per-node branches of the AMM state machine run without splitting launches.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -29,6 +29,16 @@ constexpr int MAX_DOTS = 6;     // dot products per k_dots launch (it stores MAX
 
 struct Seg {
   int begin, end, node, pad;
+};
+
+// Two coefficients per local node, passed BY VALUE as a kernel argument (no upload, no memory latency): the step
+// lengths of the batched CG.  A group hosts at most MAX_LOCAL_NODES nodes.
+constexpr int MAX_LOCAL_NODES = 64;
+// which of the group's nodes a launch works on: bit a = local node a, passed by value like the coefficients
+typedef unsigned long long NodeMask;
+constexpr NodeMask ALL_NODES = ~0ull;
+struct NodeCoefs {
+  double a[MAX_LOCAL_NODES], b[MAX_LOCAL_NODES];
 };
 
 struct BsrDev {
@@ -58,14 +68,14 @@ struct SegTable {
 
 // y = A x (+ addv) ; partial[slot] = sum_p < dotv_p , coef * (A x)_p + dotadd_p >
 // in_rot_only: the translation row of x is treated as zero (G_tR R products).
-void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, const int *mask, const BsrDev &A,
+void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask, const BsrDev &A,
                 const double *x, bool in_rot_only, const double *addv, double *y, const double *dotv,
                 double coef, const double *dotadd, double *partials, int slot);
 
 // y = base + A[:, translation column] t over own rows; tval: the first column of every block of A ((d+1) doubles per
 // block), xt: records whose translation row is t.  A quarter of the traffic of launch_bsr.
 // mode 1: also out2 = [0 ; Proj_X(y.R)]; mode 2: y not stored, out2 = [0 ; Proj_X(y.R - sym(nabla.R X.R^T) Rdot.R)], the Hessian-vector product (DPGOProblem.cpp:570-574)
-void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, const int *mask, const BsrDev &A, const double *tval,
+void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, const BsrDev &A, const double *tval,
                      const double *xt, const double *base, double *y, int mode = 0, const double *X = nullptr,
                      const double *nabla = nullptr, const double *Rdot = nullptr, double *out2 = nullptr);
 
@@ -73,57 +83,57 @@ void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, const int *mask, 
 //  mode 0 (update): all rows.  DfE <- B1^T W B1 Z; own rows also g <- DfE - D z.
 //     slot 0: sum of rho_e (tail incidences); if quad: slot 1 = sum tr(dZ^T (DfE_old + 1/2 Q dZ)).
 //  mode 1 (evaluate_g): own rows only, g <- (B1^T W B1 Z)_own - D z.
-void launch_inter(int d, hipStream_t st, const SegTable &T, const int *mask, const InterEdgesDev &E, int loss,
+void launch_inter(int d, hipStream_t st, const SegTable &T, NodeMask mask, const InterEdgesDev &E, int loss,
                   double loss_reg, int mode, bool quad, const double *Z, const double *Zprev,
                   const double *Qdiag, const double *Ddiag, double *DfE, double *g, double *partials);
 
 // Objective of every node at Z (own + neighbour rows): partial[slot0] = sum of intra-edge costs,
 // partial[slot0 + 1] = sum of rho over inter-edge costs; eform selects the data-matrix form (trivial loss).
-void launch_cost(int d, hipStream_t st, const SegTable &T, const int *mask, const InterEdgesDev &Ei,
+void launch_cost(int d, hipStream_t st, const SegTable &T, NodeMask mask, const InterEdgesDev &Ei,
                  const InterEdgesDev &Ee, bool eform, int loss, double loss_reg, const double *Z, double *partials,
                  int slot0);
 // partial[slot] = sum |a_p - b_p|^2 over own rows
-void launch_sqdist(int d, hipStream_t st, const SegTable &T, const int *mask, const double *a, const double *b,
+void launch_sqdist(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *a, const double *b,
                    double *partials, int slot);
 // Xout = proximal(Z, Df) per own pose (DPGOProblem.cpp:600-632).  With Xref: partial ||Xout - Xref||^2, after which
 // Xref takes over Xout's rotation rows (the next step recovers its translations: DPGOHash.cpp:369-372).
-void launch_proximal(int d, hipStream_t st, const SegTable &T, const int *mask, const double *Z, const double *Df,
+void launch_proximal(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *Z, const double *Df,
                      const double *Tinv, const double *N, const double *V, double *Xout, double *Xref,
                      double *partials, int slot);
 
 // out = a + gamma[node] * (a - b) over all rows (own + neighbour)      (DPGOHash.cpp:255-262)
-void launch_extrapolate(int d, hipStream_t st, const SegTable &T, bool all_rows, const int *mask,
-                        const double *gamma, const double *a, const double *b, double *out);
+void launch_extrapolate(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask,
+                        const NodeCoefs &gamma, const double *a, const double *b, double *out);
 // out = alpha * a + beta * b  (b may be null); parts: 0 whole record, 1 translation only, 2 rotation only
-void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, const int *mask, double alpha,
+void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask, double alpha,
                   const double *a, double beta, const double *b, double *out, int part);
-// out = alpha[node] * a + beta[node] * b over own rows (per-node coefficients on the device)
-void launch_axpby_node(int d, hipStream_t st, const SegTable &T, const int *mask, const double *alpha,
-                       const double *a, const double *beta, const double *b, double *out);
+// out = C.a[node] * a + C.b[node] * b over own rows
+void launch_axpby_node(int d, hipStream_t st, const SegTable &T, NodeMask mask, const NodeCoefs &C, const double *a,
+                       const double *b, double *out);
 // n <= MAX_DOTS dot products in one pass over own rows: partial[slot0 + q] = sum <a_q, b_q> over parts[q]
 // (0 whole record, 1 translation row, 2 rotation rows); always writes MAX_DOTS slots
-void launch_dots(int d, hipStream_t st, const SegTable &T, const int *mask, int n, const double *const *a,
+void launch_dots(int d, hipStream_t st, const SegTable &T, NodeMask mask, int n, const double *const *a,
                  const double *const *b, const int *parts, double *partials, int slot0);
-// one CG step (IterativeSolvers.h:340-390): s += c[node] p, hs += c[node] Hp, and r += cr[node] Hp where cr != 0
-void launch_cg_step(int d, hipStream_t st, const SegTable &T, const int *mask, const double *c, const double *cr,
-                    const double *p, const double *Hp, double *s, double *hs, double *r);
+// one CG step (IterativeSolvers.h:340-390): s += C.a[node] p, hs += C.a[node] Hp, and r += C.b[node] Hp where C.b != 0
+void launch_cg_step(int d, hipStream_t st, const SegTable &T, NodeMask mask, const NodeCoefs &C, const double *p,
+                    const double *Hp, double *s, double *hs, double *r);
 // start of a truncated CG (IterativeSolvers.h:230-260): s = 0, hs = 0, r = grad, v = pgrad, p = -pgrad
-void launch_cg_init(int d, hipStream_t st, const SegTable &T, const int *mask, const double *grad, const double *pgrad,
+void launch_cg_init(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *grad, const double *pgrad,
                     double *s, double *hs, double *r, double *v, double *p);
 // gradF = [V.x ; Proj_R(V.Y)] (DPGOProblem.cpp:145-162); partial ||gradF||^2; out may be null
-void launch_tangent_full(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
+void launch_tangent_full(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
                          const double *V, double *out, double *partials, int slot);
 // out.Y = Proj_R(in.Y), out.x = 0                                       (DPGOProblem.cpp:164-178)
-void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
+void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
                         const double *in, double *out);
 // out.Y = proj_SO(d)(X.Y + V.Y); out.x = 0                              (SOdProduct.h:111-116)
-void launch_retract_rot(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
+void launch_retract_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
                         const double *V, double *out);
 // dst[didx[k]] = src[sidx[k]] (didx may be null: dst[k]); halo copy, pack, unpack (DPGOHash.h:28-86)
 void launch_copy_indexed(int d, hipStream_t st, int count, const int *didx, const int *sidx, const double *src,
                          double *dst);
 // partial[slot] = sum_p < x_p , coef * (D_p x_p) + addcoef * add_p > over own rows
-void launch_bdiag_dot(int d, hipStream_t st, const SegTable &T, const int *mask, const double *Dd, const double *x,
+void launch_bdiag_dot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *Dd, const double *x,
                       double coef, const double *add, double addcoef, double *partials, int slot);
 
 // host_scalars[node * MAX_SLOTS + s] = sum of the node's partials, s < nslots, written straight to pinned host
@@ -157,7 +167,7 @@ struct SpdDev {
 // of a front consecutive); backward reads ytmp and writes scale * A^-1 b into vec (scale must be +1 or -1).
 void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int tile0, int nwide, int nnarrow,
                       int rows, double *vec, double *ytmp, double scale, double level_bytes = 0.0, bool stream_once = true,
-                      const int *mask = nullptr);   // mask[node] == 0: the node's fronts are skipped
+                      NodeMask mask = ALL_NODES);   // nodes outside the mask: their fronts are skipped
 
 // ---- optional per-launch timing (HIP events on the launch stream), off by default ----
 enum ProfKind { PK_BSR = 0, PK_INTER, PK_PROX, PK_AXPBY, PK_DOT, PK_ROTOP, PK_COPYIDX, PK_BDIAG, PK_REDUCE,

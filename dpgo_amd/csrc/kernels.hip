@@ -20,6 +20,8 @@ struct Dim {
   static constexpr int RS = (D + 1) * D;
 };
 
+__device__ __forceinline__ bool node_on(NodeMask mask, int node) { return (mask >> node) & 1ull; }
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -262,12 +264,12 @@ __device__ __forceinline__ int xcd_seg(int b, int n) {
 // dependent loads (column index, then record); splitting them over lanes cuts the serial latency of a
 // row by 4x, which is what bounds this kernel when a GPU holds a single node (12.5 k rows).
 template <int D, bool ROT_ONLY>
-__global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr(const Seg *segs, const int *mask, BsrDev A, const double *x,
+__global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr(const Seg *segs, NodeMask mask, BsrDev A, const double *x,
                                               const double *addv, double *y, const double *dotv, double coef,
                                               const double *dotadd, double *partial) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
-  const bool active = (mask == nullptr) || (mask[s.node] != 0);
+  const bool active = node_on(mask, s.node);
   double part[1] = {0.0};
   const int row = s.begin + (threadIdx.x >> 2), j = threadIdx.x & 3;
   if (active) {   // uniform per workgroup; rows past the segment end simply have no blocks
@@ -347,13 +349,13 @@ __device__ __forceinline__ void hess_epilogue_rows(const double *R, const double
 // model gradient); 2 = y is not stored, out2 = [0 ; Proj_X(y.R - sym(nabla.R X.R^T) Rdot.R)] (the Hessian-vector
 // product when y = G [tdot ; Rdot]).
 template <int D>
-__global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr_tcol(const Seg *segs, const int *mask, BsrDev A, const double *tval,
+__global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr_tcol(const Seg *segs, NodeMask mask, BsrDev A, const double *tval,
                                                          const double *xt, const double *base, double *y, int mode,
                                                          const double *X, const double *nabla, const double *Rdot,
                                                          double *out2) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
-  if (mask && !mask[s.node]) return;
+  if (!node_on(mask, s.node)) return;
   const int row = s.begin + (threadIdx.x >> 2), j = threadIdx.x & 3;
   double acc[RS];
 #pragma unroll
@@ -420,13 +422,13 @@ __device__ __forceinline__ void loss_weight(int loss, double dl, double s, doubl
 }
 
 template <int D>
-__global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, const int *mask, InterEdgesDev E, int loss,
+__global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask mask, InterEdgesDev E, int loss,
                                                double dl, int mode, int quad, int nseg_own, const double *Z,
                                                const double *Zprev, const double *Qd, const double *Dd,
                                                double *DfE, double *g, double *partial, int pstride) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
-  const bool active = (mask == nullptr) || (mask[s.node] != 0);
+  const bool active = node_on(mask, s.node);
   const bool own = SEGB < nseg_own;
   double part[2] = {0.0, 0.0};
   const int row = s.begin + threadIdx.x;
@@ -571,12 +573,12 @@ __device__ __forceinline__ double edge_cost(const InterEdgesDev &E, int e, const
 }
 
 template <int D>
-__global__ __launch_bounds__(SEG_ROWS) void k_cost(const Seg *segs, const int *mask, InterEdgesDev Ei, InterEdgesDev Ee,
+__global__ __launch_bounds__(SEG_ROWS) void k_cost(const Seg *segs, NodeMask mask, InterEdgesDev Ei, InterEdgesDev Ee,
                                               int eform, int loss, double dl, const double *Z, double *partial,
                                               int pstride) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
-  const bool active = (mask == nullptr) || (mask[s.node] != 0);
+  const bool active = node_on(mask, s.node);
   double part[2] = {0.0, 0.0};
   const int row = s.begin + threadIdx.x;
   if (active && row < s.end) {
@@ -603,11 +605,11 @@ __global__ __launch_bounds__(SEG_ROWS) void k_cost(const Seg *segs, const int *m
 
 // partial = sum |a_p - b_p|^2 over own rows
 template <int D>
-__global__ __launch_bounds__(SEG_ROWS) void k_sqdist(const Seg *segs, const int *mask, const double *a, const double *b,
+__global__ __launch_bounds__(SEG_ROWS) void k_sqdist(const Seg *segs, NodeMask mask, const double *a, const double *b,
                                                 double *partial) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
-  const bool active = (mask == nullptr) || (mask[s.node] != 0);
+  const bool active = node_on(mask, s.node);
   double pr[1] = {0.0};
   const int row = s.begin + threadIdx.x;
   if (active && row < s.end) {
@@ -626,13 +628,13 @@ __global__ __launch_bounds__(SEG_ROWS) void k_sqdist(const Seg *segs, const int 
 // Per-pose kernels.
 // ---------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(SEG_ROWS) void k_proximal(const Seg *segs, const int *mask, const double *Z,
+__global__ __launch_bounds__(SEG_ROWS) void k_proximal(const Seg *segs, NodeMask mask, const double *Z,
                                                   const double *Df, const double *Tinv, const double *Nv,
                                                   const double *Vb, double *Xout, double *Xref,
                                                   double *partial) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
-  const bool active = (mask == nullptr) || (mask[s.node] != 0);
+  const bool active = node_on(mask, s.node);
   double part[1] = {0.0};
   const int row = s.begin + threadIdx.x;
   if (active && row < s.end) {
@@ -683,14 +685,14 @@ __global__ __launch_bounds__(SEG_ROWS) void k_proximal(const Seg *segs, const in
 }
 
 template <int D>
-__global__ __launch_bounds__(SEG_ROWS) void k_extrapolate(const Seg *segs, const int *mask, const double *gamma,
+__global__ __launch_bounds__(SEG_ROWS) void k_extrapolate(const Seg *segs, NodeMask mask, NodeCoefs gamma,
                                                      const double *a, const double *b, double *out) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
-  if (mask && !mask[s.node]) return;
+  if (!node_on(mask, s.node)) return;
   const int row = s.begin + threadIdx.x;
   if (row >= s.end) return;
-  const double gm = gamma[s.node];
+  const double gm = gamma.a[s.node];
   double va[RS], vb[RS];
   load_vec<RS>(a + (size_t)row * RS, va);
   load_vec<RS>(b + (size_t)row * RS, vb);
@@ -702,11 +704,11 @@ __global__ __launch_bounds__(SEG_ROWS) void k_extrapolate(const Seg *segs, const
 // out = alpha a + beta b on the whole record (PART 0), the translation row (1) or the rotation rows (2);
 // whole 16-byte loads and stores, the untouched part of `out` is carried through registers
 template <int D, int PART>
-__global__ __launch_bounds__(SEG_ROWS) void k_axpby(const Seg *segs, const int *mask, double alpha, const double *a,
+__global__ __launch_bounds__(SEG_ROWS) void k_axpby(const Seg *segs, NodeMask mask, double alpha, const double *a,
                                                     double beta, const double *b, double *out) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
-  if (mask && !mask[s.node]) return;
+  if (!node_on(mask, s.node)) return;
   const int row = s.begin + threadIdx.x;
   if (row >= s.end) return;
   double va[RS], vb[RS], vo[RS];
@@ -724,15 +726,14 @@ __global__ __launch_bounds__(SEG_ROWS) void k_axpby(const Seg *segs, const int *
 
 // out = alpha[node] * a + beta[node] * b  (per-node coefficients: batched CG updates)
 template <int D>
-__global__ __launch_bounds__(SEG_ROWS) void k_axpby_node(const Seg *segs, const int *mask, const double *alpha,
-                                                    const double *a, const double *beta, const double *b,
-                                                    double *out) {
+__global__ __launch_bounds__(SEG_ROWS) void k_axpby_node(const Seg *segs, NodeMask mask, NodeCoefs C,
+                                                    const double *a, const double *b, double *out) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
-  if (mask && !mask[s.node]) return;
+  if (!node_on(mask, s.node)) return;
   const int row = s.begin + threadIdx.x;
   if (row >= s.end) return;
-  const double al = alpha[s.node], be = beta[s.node];
+  const double al = C.a[s.node], be = C.b[s.node];
   double va[RS], vb[RS];
   load_vec<RS>(a + (size_t)row * RS, va);
   load_vec<RS>(b + (size_t)row * RS, vb);
@@ -744,14 +745,14 @@ __global__ __launch_bounds__(SEG_ROWS) void k_axpby_node(const Seg *segs, const 
 // one CG step of every node in the mask (IterativeSolvers.h:340-390): s += c p, H s += c H p and, where the node
 // goes on (cr != 0), r += cr H p
 template <int D>
-__global__ __launch_bounds__(SEG_ROWS) void k_cg_step(const Seg *segs, const int *mask, const double *c, const double *cr,
-                                                      const double *p, const double *Hp, double *s, double *hs, double *r) {
+__global__ __launch_bounds__(SEG_ROWS) void k_cg_step(const Seg *segs, NodeMask mask, NodeCoefs C, const double *p,
+                                                      const double *Hp, double *s, double *hs, double *r) {
   constexpr int RS = Dim<D>::RS;
   const Seg sg = segs[SEGB];
-  if (mask && !mask[sg.node]) return;
+  if (!node_on(mask, sg.node)) return;
   const int row = sg.begin + threadIdx.x;
   if (row >= sg.end) return;
-  const double cc = c[sg.node], cc_r = cr[sg.node];
+  const double cc = C.a[sg.node], cc_r = C.b[sg.node];
   double vp[RS], vh[RS], v[RS];
   load_vec<RS>(p + (size_t)row * RS, vp);
   load_vec<RS>(Hp + (size_t)row * RS, vh);
@@ -772,12 +773,12 @@ __global__ __launch_bounds__(SEG_ROWS) void k_cg_step(const Seg *segs, const int
 }
 
 template <int D>
-__global__ __launch_bounds__(SEG_ROWS) void k_cg_init(const Seg *segs, const int *mask, const double *grad,
+__global__ __launch_bounds__(SEG_ROWS) void k_cg_init(const Seg *segs, NodeMask mask, const double *grad,
                                                       const double *pgrad, double *s, double *hs, double *r, double *v,
                                                       double *p) {
   constexpr int RS = Dim<D>::RS;
   const Seg sg = segs[SEGB];
-  if (mask && !mask[sg.node]) return;
+  if (!node_on(mask, sg.node)) return;
   const int row = sg.begin + threadIdx.x;
   if (row >= sg.end) return;
   double g[RS], pg[RS], z[RS];
@@ -803,11 +804,11 @@ struct DotPairs {
   int n;
 };
 template <int D>
-__global__ __launch_bounds__(SEG_ROWS) void k_dots(const Seg *segs, const int *mask, DotPairs P, double *partial,
+__global__ __launch_bounds__(SEG_ROWS) void k_dots(const Seg *segs, NodeMask mask, DotPairs P, double *partial,
                                                    int pstride) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
-  const bool active = (mask == nullptr) || (mask[s.node] != 0);
+  const bool active = node_on(mask, s.node);
   double pr[MAX_DOTS];
 #pragma unroll
   for (int q = 0; q < MAX_DOTS; q++) pr[q] = 0.0;
@@ -830,11 +831,11 @@ __global__ __launch_bounds__(SEG_ROWS) void k_dots(const Seg *segs, const int *m
 }
 
 template <int D>
-__global__ __launch_bounds__(SEG_ROWS) void k_tangent_full(const Seg *segs, const int *mask, const double *X,
+__global__ __launch_bounds__(SEG_ROWS) void k_tangent_full(const Seg *segs, NodeMask mask, const double *X,
                                                       const double *V, double *out, double *partial) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
-  const bool active = (mask == nullptr) || (mask[s.node] != 0);
+  const bool active = node_on(mask, s.node);
   double pr[1] = {0.0};
   const int row = s.begin + threadIdx.x;
   if (active && row < s.end) {
@@ -856,12 +857,12 @@ __global__ __launch_bounds__(SEG_ROWS) void k_tangent_full(const Seg *segs, cons
 // mode 0: out.Y = Proj_R(in.Y)                         (reduced_tangent_space_projection)
 // mode 2: out.Y = proj_SO(d)(R + in.Y)                  (SOdProduct::retract)
 template <int D>
-__global__ __launch_bounds__(SEG_ROWS) void k_rot_op(const Seg *segs, const int *mask, int mode, const double *X,
+__global__ __launch_bounds__(SEG_ROWS) void k_rot_op(const Seg *segs, NodeMask mask, int mode, const double *X,
                                                 const double *in, const double *nabla, const double *Rdot,
                                                 double *out) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
-  if (mask && !mask[s.node]) return;
+  if (!node_on(mask, s.node)) return;
   const int row = s.begin + threadIdx.x;
   if (row >= s.end) return;
   double x[RS], v[RS], o[RS];
@@ -895,12 +896,12 @@ __global__ __launch_bounds__(256) void k_copy_indexed(int count, const int *didx
 
 // partial = sum_p < x_p , coef * (D_p x_p) + addcoef * add_p >   (own rows, D block diagonal)
 template <int D>
-__global__ __launch_bounds__(SEG_ROWS) void k_bdiag_dot(const Seg *segs, const int *mask, const double *Dd,
+__global__ __launch_bounds__(SEG_ROWS) void k_bdiag_dot(const Seg *segs, NodeMask mask, const double *Dd,
                                                    const double *x, double coef, const double *add,
                                                    double addcoef, double *partial) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
-  const bool active = (mask == nullptr) || (mask[s.node] != 0);
+  const bool active = node_on(mask, s.node);
   double pr[1] = {0.0};
   const int row = s.begin + threadIdx.x;
   if (active && row < s.end) {
@@ -1238,7 +1239,7 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
 // shared by the 8 waves (ROWS-row tiles), or up to 8 tiles of narrow fronts (reduction length <= 96), one
 // per wave.  Wide packs come first, longest first; the narrow ones fill the tail of the launch.
 template <int D, int DOF, int ROWS, bool FWD, bool NT>
-__global__ __launch_bounds__(64 * SPD_NW(ROWS), ROWS == 64 ? SPD_WPE : 4) void k_spd_level(SpdDev S, const int *mask, int tile0,
+__global__ __launch_bounds__(64 * SPD_NW(ROWS), ROWS == 64 ? SPD_WPE : 4) void k_spd_level(SpdDev S, NodeMask mask, int tile0,
                                                                                       int nwide, int nnarrow, double scale,
                                                                                       double *vec, double *ytmp) {
   constexpr int CH = 128, NW = SPD_NW(ROWS);
@@ -1253,12 +1254,12 @@ __global__ __launch_bounds__(64 * SPD_NW(ROWS), ROWS == 64 ? SPD_WPE : 4) void k
     const int t = (b - nwide) * NW + wv;
     if (t >= nnarrow) return;
     const SpdItem it = load_item(items + nwide + t);
-    if (mask && !mask[it.node]) return;
+    if (!node_on(mask, it.node)) return;
     if constexpr (FWD) spd_fwd_tile<D, DOF, 1, CH, 64, NT>(S, it, vec, ytmp, f[wv], red, 0, lane);
     else spd_bwd_tile<D, DOF, 1, CH, 64, NT>(S, it, scale, ytmp, vec, f[wv], red, 0, lane);
   } else {
     const SpdItem it = load_item(items + b);
-    if (mask && !mask[it.node]) return;   // (uniform over the workgroup)
+    if (!node_on(mask, it.node)) return;   // (uniform over the workgroup)
     if constexpr (FWD) spd_fwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, vec, ytmp, f[wv], red, wv, lane);
     else spd_bwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, scale, ytmp, vec, f[wv], red, wv, lane);
   }
@@ -1345,7 +1346,7 @@ void prof_collect(double *ms, double *bytes, long *count) {
 
 static inline int nseg(const SegTable &T, bool all_rows) { return all_rows ? T.nseg_all : T.nseg_own; }
 
-void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, const int *mask, const BsrDev &A,
+void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask, const BsrDev &A,
                 const double *x, bool in_rot_only, const double *addv, double *y, const double *dotv,
                 double coef, const double *dotadd, double *partials, int slot) {
   const int nb = nseg(T, all_rows);
@@ -1362,7 +1363,7 @@ void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, const i
   });
 }
 
-void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, const int *mask, const BsrDev &A, const double *tval,
+void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, const BsrDev &A, const double *tval,
                      const double *xt, const double *base, double *y, int mode, const double *X, const double *nabla,
                      const double *Rdot, double *out2) {
   if (T.nseg_own == 0) return;
@@ -1371,7 +1372,7 @@ void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, const int *mask, 
                                         xt, base, y, mode, X, nabla, Rdot, out2));
 }
 
-void launch_inter(int d, hipStream_t st, const SegTable &T, const int *mask, const InterEdgesDev &E, int loss,
+void launch_inter(int d, hipStream_t st, const SegTable &T, NodeMask mask, const InterEdgesDev &E, int loss,
                   double loss_reg, int mode, bool quad, const double *Z, const double *Zprev,
                   const double *Qdiag, const double *Ddiag, double *DfE, double *g, double *partials) {
   const int nb = mode == 0 ? T.nseg_all : T.nseg_own;
@@ -1382,7 +1383,7 @@ void launch_inter(int d, hipStream_t st, const SegTable &T, const int *mask, con
                                         T.nseg_all));
 }
 
-void launch_cost(int d, hipStream_t st, const SegTable &T, const int *mask, const InterEdgesDev &Ei,
+void launch_cost(int d, hipStream_t st, const SegTable &T, NodeMask mask, const InterEdgesDev &Ei,
                  const InterEdgesDev &Ee, bool eform, int loss, double loss_reg, const double *Z, double *partials,
                  int slot0) {
   if (T.nseg_all == 0) return;
@@ -1392,7 +1393,7 @@ void launch_cost(int d, hipStream_t st, const SegTable &T, const int *mask, cons
                                         T.nseg_all));
 }
 
-void launch_sqdist(int d, hipStream_t st, const SegTable &T, const int *mask, const double *a, const double *b,
+void launch_sqdist(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *a, const double *b,
                    double *partials, int slot) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_DOT, st, 2.0 * T.rows_own * 8.0 * (d + 1) * d);
@@ -1400,7 +1401,7 @@ void launch_sqdist(int d, hipStream_t st, const SegTable &T, const int *mask, co
                                         partials + (size_t)slot * T.nseg_all));
 }
 
-void launch_proximal(int d, hipStream_t st, const SegTable &T, const int *mask, const double *Z, const double *Df,
+void launch_proximal(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *Z, const double *Df,
                      const double *Tinv, const double *N, const double *V, double *Xout, double *Xref,
                      double *partials, int slot) {
   if (T.nseg_own == 0) return;
@@ -1410,8 +1411,8 @@ void launch_proximal(int d, hipStream_t st, const SegTable &T, const int *mask, 
                                         Tinv, N, V, Xout, part ? Xref : nullptr, part));
 }
 
-void launch_extrapolate(int d, hipStream_t st, const SegTable &T, bool all_rows, const int *mask,
-                        const double *gamma, const double *a, const double *b, double *out) {
+void launch_extrapolate(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask,
+                        const NodeCoefs &gamma, const double *a, const double *b, double *out) {
   const int nb = nseg(T, all_rows);
   if (nb == 0) return;
   ProfScope ps(PK_AXPBY, st, 3.0 * (all_rows ? T.rows_all : T.rows_own) * 8.0 * (d + 1) * d);
@@ -1419,7 +1420,7 @@ void launch_extrapolate(int d, hipStream_t st, const SegTable &T, bool all_rows,
                                         out));
 }
 
-void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, const int *mask, double alpha,
+void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask, double alpha,
                   const double *a, double beta, const double *b, double *out, int part) {
   const int nb = nseg(T, all_rows);
   if (nb == 0) return;
@@ -1431,23 +1432,23 @@ void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, const
   });
 }
 
-void launch_axpby_node(int d, hipStream_t st, const SegTable &T, const int *mask, const double *alpha,
-                       const double *a, const double *beta, const double *b, double *out) {
+void launch_axpby_node(int d, hipStream_t st, const SegTable &T, NodeMask mask, const NodeCoefs &C, const double *a,
+                       const double *b, double *out) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_AXPBY, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_axpby_node<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, alpha,
-                                        a, beta, b, out));
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_axpby_node<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, C, a, b,
+                                        out));
 }
 
-void launch_cg_step(int d, hipStream_t st, const SegTable &T, const int *mask, const double *c, const double *cr,
-                    const double *p, const double *Hp, double *s, double *hs, double *r) {
+void launch_cg_step(int d, hipStream_t st, const SegTable &T, NodeMask mask, const NodeCoefs &C, const double *p,
+                    const double *Hp, double *s, double *hs, double *r) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_AXPBY, st, 8.0 * T.rows_own * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cg_step<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, c, cr, p, Hp,
-                                        s, hs, r));
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cg_step<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, C, p, Hp, s, hs,
+                                        r));
 }
 
-void launch_dots(int d, hipStream_t st, const SegTable &T, const int *mask, int n, const double *const *a,
+void launch_dots(int d, hipStream_t st, const SegTable &T, NodeMask mask, int n, const double *const *a,
                  const double *const *b, const int *parts, double *partials, int slot0) {
   if (T.nseg_own == 0 || n <= 0) return;
   DotPairs P;
@@ -1462,7 +1463,7 @@ void launch_dots(int d, hipStream_t st, const SegTable &T, const int *mask, int 
                                         partials + (size_t)slot0 * T.nseg_all, T.nseg_all));
 }
 
-void launch_cg_init(int d, hipStream_t st, const SegTable &T, const int *mask, const double *grad, const double *pgrad,
+void launch_cg_init(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *grad, const double *pgrad,
                     double *s, double *hs, double *r, double *v, double *p) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_AXPBY, st, 7.0 * T.rows_own * 8.0 * (d + 1) * d);
@@ -1470,7 +1471,7 @@ void launch_cg_init(int d, hipStream_t st, const SegTable &T, const int *mask, c
                                         pgrad, s, hs, r, v, p));
 }
 
-void launch_tangent_full(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
+void launch_tangent_full(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
                          const double *V, double *out, double *partials, int slot) {
   if (T.nseg_own == 0) return;
   double *part = partials ? partials + (size_t)slot * T.nseg_all : nullptr;
@@ -1479,7 +1480,7 @@ void launch_tangent_full(int d, hipStream_t st, const SegTable &T, const int *ma
                                         V, out, part));
 }
 
-void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
+void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
                         const double *in, double *out) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_ROTOP, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
@@ -1487,7 +1488,7 @@ void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, const int *mas
                                         nullptr, nullptr, out));
 }
 
-void launch_retract_rot(int d, hipStream_t st, const SegTable &T, const int *mask, const double *X,
+void launch_retract_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
                         const double *V, double *out) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_ROTOP, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
@@ -1503,7 +1504,7 @@ void launch_copy_indexed(int d, hipStream_t st, int count, const int *didx, cons
                                         didx, sidx, src, dst));
 }
 
-void launch_bdiag_dot(int d, hipStream_t st, const SegTable &T, const int *mask, const double *Dd, const double *x,
+void launch_bdiag_dot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *Dd, const double *x,
                       double coef, const double *add, double addcoef, double *partials, int slot) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_BDIAG, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
@@ -1520,7 +1521,7 @@ void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows,
 
 void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int tile0, int nwide, int nnarrow,
                       int rows, double *vec, double *ytmp, double scale, double level_bytes, bool stream_once,
-                      const int *mask) {
+                      NodeMask mask) {
   const int nw = SPD_NW(rows), npacks = nwide + (nnarrow + nw - 1) / nw;
   if (npacks == 0) return;
   ProfScope ps(forward ? PK_SPD_FWD : PK_SPD_BWD, st, level_bytes);

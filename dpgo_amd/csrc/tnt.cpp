@@ -15,9 +15,9 @@
 //
 // Every node runs the reference's control flow with its OWN scalars (step
 // lengths, trust-region radius, stopping tests); the nodes advance in lockstep so
-// that one launch serves all of them.  Per-node step lengths live in a device
-// ring (upload_coef), per-node branches are device masks, and the handful of
-// reductions per CG step come back through one pinned-memory fetch.
+// that one launch serves all of them.  Per-node step lengths and the set of nodes
+// a launch works on travel as kernel arguments (NodeCoefs, NodeMask: no uploads),
+// and the handful of reductions per CG step come back through one polled read-back.
 #include <cmath>
 #include <cstdio>
 #include <limits>
@@ -126,7 +126,7 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
   quad_model(X, base_ready);
   norms(nodes, true);
 
-  std::vector<double> c1(L, 0.0), c2(L, 0.0), ones(L, 1.0), mones(L, -1.0), zeros(L, 0.0);
+  std::vector<double> c1(L, 0.0), c2(L, 0.0);
   for (;;) {
     // ---- nodes that start another trust-region iteration (TNT.h:446-484)
     std::vector<int> A;
@@ -200,10 +200,10 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       // s_k += c1 p_k (final boundary step or regular step) and H s_k alongside, for every node of C; nodes that
       // go on also get r_k += alpha H p_k -- one pass
       {
-        std::vector<double> cr(L, 0.0);
-        for (int a : cont) cr[a] = c1[a];
-        const double *c1_d = upload_coef(c1), *cr_d = upload_coef(cr);
-        launch_cg_step(d_, st_, T_, cur_mask_, c1_d, cr_d, pk, Hp, sk, hh, rk);
+        NodeCoefs C;
+        for (int a = 0; a < L; a++) { C.a[a] = c1[a]; C.b[a] = 0.0; }
+        for (int a : cont) C.b[a] = c1[a];
+        launch_cg_step(d_, st_, T_, cur_mask_, C, pk, Hp, sk, hh, rk);
       }
       if (cont.empty()) continue;
       set_mask(cont);
@@ -220,7 +220,11 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
         s.cg_it++;
         beta[a] = be;
       }
-      launch_axpby_node(d_, st_, T_, cur_mask_, upload_coef(mones), vk, upload_coef(beta), pk, pk);
+      {
+        NodeCoefs C;
+        for (int a = 0; a < L; a++) { C.a[a] = -1.0; C.b[a] = beta[a]; }
+        launch_axpby_node(d_, st_, T_, cur_mask_, C, vk, pk, pk);
+      }
     }
     for (int a : A) S[a].inner_total += S[a].cg_it;
     // ---- trial point (TNT.h:505-536)
