@@ -184,6 +184,9 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
   };
   sweep(true, fwd_levels, fwd_items, WT);
   sweep(false, bwd_levels, bwd_items, W);
+  // the panels are on the device now: the host copy of the factor (gigabytes at the headline size) can go
+  std::vector<double>().swap(F.W);
+  std::vector<double>().swap(F.WT);
   // both panel sets of a factor this small can live in the 256 MiB Infinity Cache from one solve to the next
   // (measured: G_tt with 177 MB of panels at two nodes per GPU still gains 2 % from staying; 288 MB does not)
   size_t keep = 200u << 20;
