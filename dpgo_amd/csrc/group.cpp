@@ -1089,9 +1089,10 @@ int Group::amm(const std::vector<int> &locals) {
   // (these three scalars sit in slots DS.. and are read back together with the first scalars of TNT)
   constexpr int DS = 2 * MAX_DOTS;
   launch_proximal(d_, st_, T_, cur_mask_, Y_.p, Dfx_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, Xak_.p, partials_.p, DS);
-  eval_G(Xakh_.p, gc_.p, DS + 1);
-  // Xak.R = Xakh.R (written by the proximal kernel); Xak.t = recover(R, g)   (:369-372)
-  recover_translations(Xak_.p, gx_.p);
+  // Gkh = G(Xakh | g[k]) needs G Xakh; the translations of Xak = [. ; Xakh.R] need G [0 ; Xakh.R] + g: one pass over
+  // G gives both (T1_ = G [0 ; R] + gx, slot DS + 1 = <Xakh, 1/2 G Xakh + gc>), then the solve   (:363-372)
+  launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xakh_.p, 2, gx_.p, T1_.p, Xakh_.p, 0.5, gc_.p, partials_.p, DS + 1);
+  solve_tt(T1_.p, Xak_.p, -1.0);
   std::vector<int> plain, ref;
   for (int a : locals) (res_[a].refined ? ref : plain).push_back(a);
   // Gk for nodes that are not refined; refined nodes run TNT first (:374-383)

@@ -67,9 +67,10 @@ struct SegTable {
 };
 
 // y = A x (+ addv) ; partial[slot] = sum_p < dotv_p , coef * (A x)_p + dotadd_p >
-// in_rot_only: the translation row of x is treated as zero (G_tR R products).
+// mode 1 (true): the translation row of x is treated as zero (G_tR R products).  mode 2: y as in mode 1, but the
+// dot product sees the full A x -- one pass for "G [0 ; R] + g" and "<x, 1/2 G x + g'>" (DPGOHash.cpp:363-372).
 void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask, const BsrDev &A,
-                const double *x, bool in_rot_only, const double *addv, double *y, const double *dotv,
+                const double *x, int mode, const double *addv, double *y, const double *dotv,
                 double coef, const double *dotadd, double *partials, int slot);
 
 // y = base + A[:, translation column] t over own rows; tval: the first column of every block of A ((d+1) doubles per

@@ -263,7 +263,9 @@ __device__ __forceinline__ int xcd_seg(int b, int n) {
 // (d+1) x d results are combined with two xor-shuffles.  A row has ~10 blocks, each needing two
 // dependent loads (column index, then record); splitting them over lanes cuts the serial latency of a
 // row by 4x, which is what bounds this kernel when a GPU holds a single node (12.5 k rows).
-template <int D, bool ROT_ONLY>
+// MODE 0: y = A x.  MODE 1: the translation row of x counts as zero (y = A [0 ; x.R]).  MODE 2: both at once --
+// y = A [0 ; x.R] (+ add), while the fused dot product sees the full A x (one pass over A instead of two).
+template <int D, int MODE>
 __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr(const Seg *segs, NodeMask mask, BsrDev A, const double *x,
                                               const double *addv, double *y, const double *dotv, double coef,
                                               const double *dotadd, double *partial) {
@@ -273,9 +275,13 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr(const Seg *segs, NodeMask 
   double part[1] = {0.0};
   const int row = s.begin + (threadIdx.x >> 2), j = threadIdx.x & 3;
   if (active) {   // uniform per workgroup; rows past the segment end simply have no blocks
-    double acc[RS];
+    double acc[RS], acct[MODE == 2 ? RS : 1];
 #pragma unroll
     for (int k = 0; k < RS; k++) acc[k] = 0.0;
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int k = 0; k < RS; k++) acct[k] = 0.0;
+    }
     const bool inrow = row < s.end;
     const int k1 = inrow ? A.ptr[row + 1] : 0;
     for (int k = (inrow ? A.ptr[row] : 0) + j; k < k1; k += 4) {
@@ -283,12 +289,25 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr(const Seg *segs, NodeMask 
       double xb[RS], blk[B * B];
       load_vec<RS>(x + (size_t)q * RS, xb);
       load_vec<B * B>(A.val + (size_t)k * B * B, blk);
-      blk_mul_acc<D, ROT_ONLY>(blk, xb, acc);
+      blk_mul_acc<D, MODE != 0>(blk, xb, acc);
+      if constexpr (MODE == 2) {   // what the translation row of x adds: first column of the block
+#pragma unroll
+        for (int r = 0; r < B; r++)
+#pragma unroll
+          for (int c = 0; c < D; c++) acct[r * D + c] = fma(blk[r * B], xb[c], acct[r * D + c]);
+      }
     }
 #pragma unroll
     for (int k = 0; k < RS; k++) {
       acc[k] += __shfl_xor(acc[k], 1, 64);
       acc[k] += __shfl_xor(acc[k], 2, 64);
+    }
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int k = 0; k < RS; k++) {
+        acct[k] += __shfl_xor(acct[k], 1, 64);
+        acct[k] += __shfl_xor(acct[k], 2, 64);
+      }
     }
     if (inrow && j == 0) {
       if (dotv) {
@@ -297,7 +316,10 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr(const Seg *segs, NodeMask 
         if (dotadd) load_vec<RS>(dotadd + (size_t)row * RS, da);
         double p = 0;
 #pragma unroll
-        for (int k = 0; k < RS; k++) p = fma(v[k], fma(coef, acc[k], dotadd ? da[k] : 0.0), p);
+        for (int k = 0; k < RS; k++) {
+          const double full = MODE == 2 ? acc[k] + acct[k] : acc[k];
+          p = fma(v[k], fma(coef, full, dotadd ? da[k] : 0.0), p);
+        }
         part[0] = p;
       }
       if (y) {
@@ -1347,19 +1369,22 @@ void prof_collect(double *ms, double *bytes, long *count) {
 static inline int nseg(const SegTable &T, bool all_rows) { return all_rows ? T.nseg_all : T.nseg_own; }
 
 void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask, const BsrDev &A,
-                const double *x, bool in_rot_only, const double *addv, double *y, const double *dotv,
+                const double *x, int mode, const double *addv, double *y, const double *dotv,
                 double coef, const double *dotadd, double *partials, int slot) {
   const int nb = nseg(T, all_rows);
   if (nb == 0) return;
   double *part = (dotv && partials) ? partials + (size_t)slot * T.nseg_all : nullptr;
   ProfScope ps(PK_BSR, st, (double)A.nnzb * (8.0 * (d + 1) * (d + 1) + 4) + 2.0 * A.nrows * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, {
-    if (in_rot_only)
-      hipLaunchKernelGGL((k_bsr<D, true>), dim3(nb), dim3(4 * SEG_ROWS), 0, st, T.segs, mask, A, x, addv, y, dotv, coef,
-                         dotadd, part);
+    if (mode == 1)
+      hipLaunchKernelGGL((k_bsr<D, 1>), dim3(nb), dim3(4 * SEG_ROWS), 0, st, T.segs, mask, A, x, addv, y, dotv, coef, dotadd,
+                         part);
+    else if (mode == 2)
+      hipLaunchKernelGGL((k_bsr<D, 2>), dim3(nb), dim3(4 * SEG_ROWS), 0, st, T.segs, mask, A, x, addv, y, dotv, coef, dotadd,
+                         part);
     else
-      hipLaunchKernelGGL((k_bsr<D, false>), dim3(nb), dim3(4 * SEG_ROWS), 0, st, T.segs, mask, A, x, addv, y, dotv, coef,
-                         dotadd, part);
+      hipLaunchKernelGGL((k_bsr<D, 0>), dim3(nb), dim3(4 * SEG_ROWS), 0, st, T.segs, mask, A, x, addv, y, dotv, coef, dotadd,
+                         part);
   });
 }
 
