@@ -992,6 +992,9 @@ __global__ __launch_bounds__(64) void k_reduce(SegTable T, int all_rows, int nsl
 #ifndef SPD_HB
 #define SPD_HB 8
 #endif
+#ifndef SPD_PULL16
+#define SPD_PULL16 4   // measured best of 2, 4, 8 (one node per GPU: -2 %)
+#endif
 #ifndef SPD_WPE
 #define SPD_WPE 6    // waves per SIMD the 64-row solve kernels are compiled for: 85 VGPRs, 3 workgroups per CU (measured best of 5, 6, 8)
 #endif
@@ -1012,10 +1015,9 @@ __device__ __forceinline__ SpdItem load_item(const SpdItem *p) {
 // v += the children's contributions to front position `pos`.  The update buffer is laid out in PULL order: the
 // rows a position receives are consecutive (rows asm_ptr[pos] .. asm_ptr[pos + 1]), in the fixed order of the
 // host's assembly lists; the children scatter their update rows there (ubuf_dst), which is off the critical path.
-template <int D>
+template <int D, int PB>
 __device__ __forceinline__ void pull_updates(const SpdDev &S, int pos, double (&v)[D]) {
   const int a0 = S.asm_ptr[pos], a1 = S.asm_ptr[pos + 1];
-  constexpr int PB = 2;
   for (int a = a0; a < a1; a += PB) {
     double t[PB][D];
 #pragma unroll
@@ -1104,6 +1106,7 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
                                              double *fw, double *red, const int wv, const int lane) {
   constexpr int KQ = 64 / ROWS, HB = SPD_HB;
   constexpr bool PRE = ROWS < 64;   // levels with few tiles: latency matters, registers do not
+  constexpr int PULLB = ROWS < 64 ? SPD_PULL16 : 2;   // children's contributions fetched per round (top fronts have many)
   const int r = lane % ROWS, kq = lane / ROWS;
   const int p = it.first + r;
   const bool valid = r < it.count;
@@ -1137,7 +1140,7 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
       const double *src = vec + vaddr<D, DOF>(piv[k]);
 #pragma unroll
       for (int c = 0; c < D; c++) v[c] = *(src + c);
-      pull_updates<D>(S, pos0 + k, v);
+      pull_updates<D, PULLB>(S, pos0 + k, v);
 #pragma unroll
       for (int c = 0; c < D; c++) fw[kk * D + c] = v[c];
     }
@@ -1160,7 +1163,7 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
   double extra[D];
 #pragma unroll
   for (int c = 0; c < D; c++) extra[c] = 0.0;
-  if (writer && p >= w) pull_updates<D>(S, pos0 + p, extra);
+  if (writer && p >= w) pull_updates<D, PULLB>(S, pos0 + p, extra);
   if constexpr (NW > 1) {
     if (kq == 0) {
 #pragma unroll
