@@ -417,3 +417,19 @@ def test_cpp_facade_runs_the_driver_loop(fixtures_dir, golden_dir):
     assert got.shape == ref.shape
     np.testing.assert_allclose(got[:, 0], ref[:, 0], rtol=1e-6)
     np.testing.assert_allclose(got[:, 1], ref[:, 1], rtol=1e-3, atol=1e-6 * ref[0, 1])
+
+
+def test_runs_are_bit_reproducible(fixtures_dir):
+    """No atomics anywhere on the data path: partial sums are combined in a fixed order, the solve pulls its
+    children's contributions in list order.  Two runs of the same problem give bit-identical iterates."""
+    path = os.path.join(fixtures_dir, "torus3D.g2o")
+    num_poses, mm = og.read_g2o_file(path)
+    X0 = chordal_initialization(num_poses, mm)
+    outs = []
+    for _ in range(2):
+        G = dpgo_amd.read_g2o(path, 8)
+        drv = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(LOSS_HUBER, True), X0=X0)
+        for _ in range(15):
+            assert drv.step() == 0
+        outs.append(drv.X().copy())
+    assert np.array_equal(outs[0], outs[1])
