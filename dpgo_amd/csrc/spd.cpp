@@ -66,6 +66,94 @@ struct Dissector {
     return maxlev + 1;
   }
 
+  // Minimum vertex cover of the bipartite graph between X = order[x0, x1) and Y = order[x1, y1) (edges of A among
+  // the current vertex set; X and Y are consecutive BFS levels).  Hopcroft-Karp matching, then Koenig's construction.
+  std::vector<int> lidx_, matchx_, matchy_, dist_;
+  void min_cover(const std::vector<int> &order, int x0, int x1, int y1, std::vector<int> &cover) {
+    const int nx = x1 - x0, ny = y1 - x1;
+    if ((int)lidx_.size() < A.n) lidx_.assign(A.n, -1);
+    for (int i = 0; i < ny; i++) lidx_[order[x1 + i]] = i;
+    const int ylev = level[order[x1]];
+    matchx_.assign(nx, -1);
+    matchy_.assign(ny, -1);
+    dist_.assign(nx, 0);
+    auto ynbr = [&](int xv, int k) {   // local index of neighbour k of X vertex xv if it lies in Y, else -1
+      const int w = A.col[k];
+      return (stamp[w] == cur && level[w] == ylev) ? lidx_[w] : -1;
+    };
+    std::vector<int> q, it(nx);
+    for (;;) {
+      // BFS from the free X vertices: layers of shortest alternating paths
+      q.clear();
+      for (int i = 0; i < nx; i++) {
+        dist_[i] = matchx_[i] < 0 ? 0 : -1;
+        if (matchx_[i] < 0) q.push_back(i);
+      }
+      bool found = false;
+      for (size_t h = 0; h < q.size(); h++) {
+        const int i = q[h], xv = order[x0 + i];
+        for (int k = A.ptr[xv]; k < A.ptr[xv + 1]; k++) {
+          const int j = ynbr(xv, k);
+          if (j < 0) continue;
+          const int i2 = matchy_[j];
+          if (i2 < 0) found = true;
+          else if (dist_[i2] < 0) { dist_[i2] = dist_[i] + 1; q.push_back(i2); }
+        }
+      }
+      if (!found) break;
+      // DFS along the layers (iterative)
+      for (int i = 0; i < nx; i++) it[i] = A.ptr[order[x0 + i]];
+      for (int s = 0; s < nx; s++) {
+        if (matchx_[s] >= 0) continue;
+        std::vector<int> path(1, s);
+        while (!path.empty()) {
+          const int i = path.back(), xv = order[x0 + i];
+          bool advanced = false;
+          while (it[i] < A.ptr[xv + 1]) {
+            const int j = ynbr(xv, it[i]++);
+            if (j < 0) continue;
+            const int i2 = matchy_[j];
+            if (i2 < 0) {   // augment along the path
+              int jj = j;
+              for (int p = (int)path.size() - 1; p >= 0; p--) {
+                const int pi = path[p], prev = matchx_[pi];
+                matchx_[pi] = jj;
+                matchy_[jj] = pi;
+                jj = prev;
+              }
+              path.clear();
+              advanced = true;
+              break;
+            }
+            if (dist_[i2] == dist_[i] + 1) { path.push_back(i2); advanced = true; break; }
+          }
+          if (!advanced) { dist_[i] = -2; path.pop_back(); }   // dead end
+        }
+      }
+    }
+    // Koenig: Z = vertices reachable from the free X vertices by alternating paths; cover = (X \ Z) + (Y & Z)
+    std::vector<char> zx(nx, 0), zy(ny, 0);
+    q.clear();
+    for (int i = 0; i < nx; i++)
+      if (matchx_[i] < 0) { zx[i] = 1; q.push_back(i); }
+    for (size_t h = 0; h < q.size(); h++) {
+      const int i = q[h], xv = order[x0 + i];
+      for (int k = A.ptr[xv]; k < A.ptr[xv + 1]; k++) {
+        const int j = ynbr(xv, k);
+        if (j < 0 || zy[j]) continue;
+        zy[j] = 1;
+        const int i2 = matchy_[j];
+        if (i2 >= 0 && !zx[i2]) { zx[i2] = 1; q.push_back(i2); }
+      }
+    }
+    cover.clear();
+    for (int i = 0; i < nx; i++)
+      if (!zx[i]) cover.push_back(order[x0 + i]);
+    for (int j = 0; j < ny; j++)
+      if (zy[j]) cover.push_back(order[x1 + j]);
+    for (int i = 0; i < ny; i++) lidx_[order[x1 + i]] = -1;
+  }
+
   void dissect(std::vector<int> verts, int parent) {
     // split into connected components
     cur += 2;
@@ -102,26 +190,45 @@ struct Dissector {
       make(std::move(verts), parent);
       return;
     }
-    std::vector<int> cnt(nlev, 0);
-    for (int v : order) cnt[level[v]]++;
+    // BFS order is sorted by level: level l is order[lp[l] .. lp[l + 1])
+    std::vector<int> lp(nlev + 1, 0);
+    for (int v : order) lp[level[v] + 1]++;
+    for (int l = 0; l < nlev; l++) lp[l + 1] += lp[l];
     const double total = (double)order.size();
-    int best = -1;
-    double cum = 0;
-    int half = 1;
-    for (int l = 0; l < nlev; l++) {
-      double lo = cum / total, hi = (cum + cnt[l]) / total;
-      if (lo <= 0.5 && hi >= 0.5) half = l;
-      if (l >= 1 && l <= nlev - 2 && lo >= 0.3 && hi <= 0.7) {
-        if (best < 0 || cnt[l] < cnt[best]) best = l;
-      }
-      cum += cnt[l];
+    // A whole level separates, but usually a smaller set does: the cut between levels l and l+1 is a bipartite
+    // graph, and a minimum vertex cover of it (Koenig: from a maximum matching) separates {levels < l} + (level l
+    // outside the cover) from (level l+1 outside the cover) + {levels > l+1}.  It is never larger than either level.
+    // Try every cut that leaves both sides at least 30 % of the vertices and keep the smallest cover.
+    int best_l = -1;
+    std::vector<int> best_cover;
+    for (int l = 0; l + 1 < nlev; l++) {
+      const double below = lp[l + 1] / total, above = (total - lp[l + 1]) / total;   // if the cover were empty
+      if (below < 0.3 || above < 0.3) continue;
+      if (best_l >= 0 && std::min(lp[l + 1] - lp[l], lp[l + 2] - lp[l + 1]) >= 2 * (int)best_cover.size()) continue;   // cannot win by much
+      std::vector<int> cover;
+      min_cover(order, lp[l], lp[l + 1], lp[l + 2], cover);
+      if (best_l < 0 || cover.size() < best_cover.size()) { best_l = l; best_cover.swap(cover); }
     }
-    if (best < 0) best = std::min(std::max(half, 1), nlev - 2);
     std::vector<int> sep, lo, hi;
-    for (int v : order) {
-      if (level[v] == best) sep.push_back(v);
-      else if (level[v] < best) lo.push_back(v);
-      else hi.push_back(v);
+    if (best_l < 0) {
+      // no balanced cut between two levels (few, fat levels): fall back to the level nearest the middle
+      int half = 1;
+      for (int l = 0; l < nlev; l++)
+        if (lp[l] <= total / 2 && lp[l + 1] >= total / 2) half = l;
+      const int best = std::min(std::max(half, 1), nlev - 2);
+      for (int v : order) {
+        if (level[v] == best) sep.push_back(v);
+        else if (level[v] < best) lo.push_back(v);
+        else hi.push_back(v);
+      }
+    } else {
+      cur += 2;   // (stamps of this vertex set are not needed any more: mark the cover)
+      for (int v : best_cover) stamp[v] = cur;
+      for (int v : order) {
+        if (stamp[v] == cur) sep.push_back(v);
+        else if (level[v] <= best_l) lo.push_back(v);
+        else hi.push_back(v);
+      }
     }
     int id = make(std::move(sep), parent);
     dissect(std::move(lo), id);
