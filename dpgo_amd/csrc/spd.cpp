@@ -190,27 +190,45 @@ struct Dissector {
       make(std::move(verts), parent);
       return;
     }
-    // BFS order is sorted by level: level l is order[lp[l] .. lp[l + 1])
-    std::vector<int> lp(nlev + 1, 0);
-    for (int v : order) lp[level[v] + 1]++;
-    for (int l = 0; l < nlev; l++) lp[l + 1] += lp[l];
-    const double total = (double)order.size();
     // A whole level separates, but usually a smaller set does: the cut between levels l and l+1 is a bipartite
     // graph, and a minimum vertex cover of it (Koenig: from a maximum matching) separates {levels < l} + (level l
     // outside the cover) from (level l+1 outside the cover) + {levels > l+1}.  It is never larger than either level.
-    // Try every cut that leaves both sides at least 30 % of the vertices and keep the smallest cover.
-    int best_l = -1;
-    std::vector<int> best_cover;
-    for (int l = 0; l + 1 < nlev; l++) {
-      const double below = lp[l + 1] / total, above = (total - lp[l + 1]) / total;   // if the cover were empty
-      if (below < 0.3 || above < 0.3) continue;
-      if (best_l >= 0 && std::min(lp[l + 1] - lp[l], lp[l + 2] - lp[l + 1]) >= 2 * (int)best_cover.size()) continue;   // cannot win by much
-      std::vector<int> cover;
-      min_cover(order, lp[l], lp[l + 1], lp[l + 2], cover);
-      if (best_l < 0 || cover.size() < best_cover.size()) { best_l = l; best_cover.swap(cover); }
+    // Every cut that leaves both sides at least `window` of the vertices is tried, in the level structures of both
+    // ends of the pseudo-diameter; the smallest cover wins.  window = 0.4 (measured: 0.3 gives 2 % fewer entries but
+    // 20 % more tree levels, i.e. slower solves; more than two roots change nothing).
+    static const double window = [] { const char *e = getenv("DPGO_ND_WINDOW"); return e ? atof(e) : 0.4; }();
+    static const int nroots = [] { const char *e = getenv("DPGO_ND_ROOTS"); return e ? atoi(e) : 2; }();
+    const double total = (double)order.size();
+    std::vector<int> sep, lo, hi, best_cover, lp;
+    size_t best_size = (size_t)-1;
+    for (int trial = 0; trial < nroots; trial++) {
+      if (trial > 0) nlev = bfs(order.back(), order);   // the level structure seen from the other end
+      // BFS order is sorted by level: level l is order[lp[l] .. lp[l + 1])
+      lp.assign(nlev + 1, 0);
+      for (int v : order) lp[level[v] + 1]++;
+      for (int l = 0; l < nlev; l++) lp[l + 1] += lp[l];
+      int best_l = -1;
+      for (int l = 0; l + 1 < nlev; l++) {
+        const double below = lp[l + 1] / total, above = (total - lp[l + 1]) / total;   // if the cover were empty
+        if (below < window || above < window) continue;
+        if (best_size != (size_t)-1 && (size_t)std::min(lp[l + 1] - lp[l], lp[l + 2] - lp[l + 1]) >= 2 * best_size) continue;
+        std::vector<int> cover;
+        min_cover(order, lp[l], lp[l + 1], lp[l + 2], cover);
+        if (cover.size() < best_size) { best_size = cover.size(); best_l = l; best_cover.swap(cover); }
+      }
+      if (best_l >= 0) {   // this level structure gave the best separator so far: materialise the three sets
+        cur += 2;
+        for (int v : best_cover) stamp[v] = cur;
+        sep.clear(); lo.clear(); hi.clear();
+        for (int v : order) {
+          if (stamp[v] == cur) sep.push_back(v);
+          else if (level[v] <= best_l) lo.push_back(v);
+          else hi.push_back(v);
+        }
+        for (int v : order) stamp[v] = cur;   // the whole vertex set is current again for the next BFS
+      }
     }
-    std::vector<int> sep, lo, hi;
-    if (best_l < 0) {
+    if (best_size == (size_t)-1) {
       // no balanced cut between two levels (few, fat levels): fall back to the level nearest the middle
       int half = 1;
       for (int l = 0; l < nlev; l++)
@@ -219,14 +237,6 @@ struct Dissector {
       for (int v : order) {
         if (level[v] == best) sep.push_back(v);
         else if (level[v] < best) lo.push_back(v);
-        else hi.push_back(v);
-      }
-    } else {
-      cur += 2;   // (stamps of this vertex set are not needed any more: mark the cover)
-      for (int v : best_cover) stamp[v] = cur;
-      for (int v : order) {
-        if (stamp[v] == cur) sep.push_back(v);
-        else if (level[v] <= best_l) lo.push_back(v);
         else hi.push_back(v);
       }
     }
