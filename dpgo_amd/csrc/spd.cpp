@@ -154,6 +154,101 @@ struct Dissector {
     for (int i = 0; i < ny; i++) lidx_[order[x1 + i]] = -1;
   }
 
+  // Approximate Fiedler vector of the subgraph induced by `verts` (all with stamp == cur): Lanczos on its Laplacian in
+  // the complement of the constant vector, full reorthogonalisation, Ritz vector of the smallest Ritz value.
+  void fiedler(const std::vector<int> &verts, std::vector<double> &y) {
+    static const int lanczos_steps = [] { const char *e = getenv("DPGO_ND_LANCZOS"); return e ? atoi(e) : 60; }();
+    const int m = (int)verts.size(), kmax = std::min(m - 1, lanczos_steps);
+    if ((int)lidx_.size() < A.n) lidx_.assign(A.n, -1);
+    for (int i = 0; i < m; i++) lidx_[verts[i]] = i;
+    auto apply = [&](const std::vector<double> &x, std::vector<double> &out) {   // out = L x
+      for (int i = 0; i < m; i++) {
+        const int v = verts[i];
+        double s = 0;
+        int deg = 0;
+        for (int k = A.ptr[v]; k < A.ptr[v + 1]; k++) {
+          const int w = A.col[k];
+          if (stamp[w] != cur) continue;
+          s += x[lidx_[w]];
+          deg++;
+        }
+        out[i] = deg * x[i] - s;
+      }
+    };
+    auto deflate = [&](std::vector<double> &x) {
+      double mean = 0;
+      for (double v : x) mean += v;
+      mean /= m;
+      for (double &v : x) v -= mean;
+    };
+    std::vector<std::vector<double>> Q;
+    std::vector<double> alpha, beta, q(m), w(m);
+    for (int i = 0; i < m; i++) q[i] = std::sin(0.7 * i + 0.3) + 1e-3 * (i % 7);
+    deflate(q);
+    double nrm = 0;
+    for (double v : q) nrm += v * v;
+    nrm = std::sqrt(nrm);
+    for (double &v : q) v /= nrm;
+    for (int k = 0; k < kmax; k++) {
+      Q.push_back(q);
+      apply(q, w);
+      double a = 0;
+      for (int i = 0; i < m; i++) a += w[i] * q[i];
+      alpha.push_back(a);
+      deflate(w);
+      for (int pass = 0; pass < 2; pass++)
+        for (const auto &qq : Q) {
+          double c = 0;
+          for (int i = 0; i < m; i++) c += w[i] * qq[i];
+          for (int i = 0; i < m; i++) w[i] -= c * qq[i];
+        }
+      double b = 0;
+      for (double v : w) b += v * v;
+      b = std::sqrt(b);
+      if (b < 1e-10) break;
+      beta.push_back(b);
+      for (int i = 0; i < m; i++) q[i] = w[i] / b;
+    }
+    const int kk = (int)alpha.size();
+    // smallest eigenvalue of the tridiagonal (alpha, beta) by bisection on the Sturm count
+    double lo = 0, hi = 0;
+    for (int i = 0; i < kk; i++) hi = std::max(hi, alpha[i] + (i > 0 ? beta[i - 1] : 0) + (i < kk - 1 && i < (int)beta.size() ? beta[i] : 0));
+    lo = -1e-9;
+    for (int it = 0; it < 100; it++) {
+      const double mid = 0.5 * (lo + hi);
+      int neg = 0;
+      double dd = 1.0;
+      for (int i = 0; i < kk; i++) {
+        dd = alpha[i] - mid - (i > 0 ? beta[i - 1] * beta[i - 1] / dd : 0.0);
+        if (dd == 0.0) dd = 1e-300;
+        if (dd < 0) neg++;
+      }
+      if (neg >= 1) hi = mid; else lo = mid;
+    }
+    const double theta = 0.5 * (lo + hi);
+    // its eigenvector by inverse iteration on the tridiagonal (Thomas algorithm, slightly shifted)
+    std::vector<double> s(kk, 1.0), c(kk), dprime(kk);
+    for (int rep = 0; rep < 3; rep++) {
+      const double sh = theta - 1e-7 * (std::fabs(theta) + 1e-3);
+      for (int i = 0; i < kk; i++) {
+        const double diag = alpha[i] - sh, sub = i > 0 ? beta[i - 1] : 0.0;
+        const double denom = i > 0 ? diag - sub * c[i - 1] : diag;
+        c[i] = (i < kk - 1 ? beta[i] : 0.0) / denom;
+        dprime[i] = (s[i] - (i > 0 ? sub * dprime[i - 1] : 0.0)) / denom;
+      }
+      s[kk - 1] = dprime[kk - 1];
+      for (int i = kk - 2; i >= 0; i--) s[i] = dprime[i] - c[i] * s[i + 1];
+      double n2 = 0;
+      for (double v : s) n2 += v * v;
+      n2 = std::sqrt(n2);
+      for (double &v : s) v /= n2;
+    }
+    y.assign(m, 0.0);
+    for (int k = 0; k < kk; k++)
+      for (int i = 0; i < m; i++) y[i] += s[k] * Q[k][i];
+    for (int i = 0; i < m; i++) lidx_[verts[i]] = -1;
+  }
+
   void dissect(std::vector<int> verts, int parent) {
     // split into connected components
     cur += 2;
@@ -226,6 +321,49 @@ struct Dissector {
           else hi.push_back(v);
         }
         for (int v : order) stamp[v] = cur;   // the whole vertex set is current again for the next BFS
+      }
+    }
+    // Spectral candidate (Pothen, Simon, Liou 1990): split along the Fiedler vector of the subgraph, again with a
+    // minimum vertex cover of the cut as the separator.  On lattice-like graphs it finds the flat cross-sections
+    // that level sets grown from a corner (diagonal planes) miss.
+    static const int spectral = [] { const char *e = getenv("DPGO_ND_SPECTRAL"); return e ? atoi(e) : 1; }();
+    if (spectral && order.size() >= 64) {
+      std::vector<double> fv;
+      fiedler(order, fv);
+      std::vector<int> perm(order.size());
+      for (size_t i = 0; i < perm.size(); i++) perm[i] = (int)i;
+      std::sort(perm.begin(), perm.end(), [&](int a, int b) { return fv[a] < fv[b] || (fv[a] == fv[b] && a < b); });
+      for (double q : {0.5, 0.45, 0.55, 0.4, 0.6}) {
+        if (q < window || 1.0 - q < window) continue;
+        const size_t cut = (size_t)(q * perm.size());
+        // side 0 / 1 kept in level[] (the BFS levels are not needed any more)
+        for (size_t i = 0; i < perm.size(); i++) level[order[perm[i]]] = i < cut ? 0 : 1;
+        std::vector<int> bd, by;
+        for (int v : order) {
+          bool boundary = false;
+          for (int k = A.ptr[v]; k < A.ptr[v + 1] && !boundary; k++) {
+            const int w = A.col[k];
+            boundary = stamp[w] == cur && level[w] != level[v];
+          }
+          if (boundary) (level[v] == 0 ? bd : by).push_back(v);
+        }
+        if (bd.empty() || by.empty()) continue;
+        const int nx = (int)bd.size();
+        bd.insert(bd.end(), by.begin(), by.end());
+        std::vector<int> cover;
+        min_cover(bd, 0, nx, (int)bd.size(), cover);
+        if (cover.size() < best_size) {
+          best_size = cover.size();
+          cur += 2;
+          for (int v : cover) stamp[v] = cur;
+          sep.clear(); lo.clear(); hi.clear();
+          for (int v : order) {
+            if (stamp[v] == cur) sep.push_back(v);
+            else if (level[v] == 0) lo.push_back(v);
+            else hi.push_back(v);
+          }
+          for (int v : order) stamp[v] = cur;
+        }
       }
     }
     if (best_size == (size_t)-1) {

@@ -367,7 +367,10 @@ def test_amm_pgo_star_matches_oracle(fixtures_dir, name, nn, loss, iters):
         np.testing.assert_allclose(st["fobjh"], orc.fobjh, rtol=1e-7, err_msg="it=%d" % it)
         np.testing.assert_allclose(st["F"], orc.F, rtol=1e-9)
         assert st["branches"] == sum(names[b] for b in orc.branches), (it, orc.branches)
-    np.testing.assert_allclose(gpu.X(), orc.Xk, atol=1e-6)
+    # poses: SURVEY 8d parity bar (translations 1e-5 x scale, rotations 1e-5 rad); the objectives above are the
+    # sharp comparison -- with G_tt regularised by 1e-11 the translations move at the 1e-6 level with the
+    # elimination order of the solver
+    np.testing.assert_allclose(gpu.X(), orc.Xk, atol=1e-5)
     # iterate() without update() is an error
     assert gpu.iterate() == -1
 
