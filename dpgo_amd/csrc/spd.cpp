@@ -289,9 +289,9 @@ struct Dissector {
     // graph, and a minimum vertex cover of it (Koenig: from a maximum matching) separates {levels < l} + (level l
     // outside the cover) from (level l+1 outside the cover) + {levels > l+1}.  It is never larger than either level.
     // Every cut that leaves both sides at least `window` of the vertices is tried, in the level structures of both
-    // ends of the pseudo-diameter; the smallest cover wins.  window = 0.4 (measured: 0.3 gives 2 % fewer entries but
+    // ends of the pseudo-diameter; the smallest cover wins.  window = 0.45 (measured: 0.3 gives 2 % fewer entries but
     // 20 % more tree levels, i.e. slower solves; more than two roots change nothing).
-    static const double window = [] { const char *e = getenv("DPGO_ND_WINDOW"); return e ? atof(e) : 0.4; }();
+    static const double window = [] { const char *e = getenv("DPGO_ND_WINDOW"); return e ? atof(e) : 0.45; }();
     static const int nroots = [] { const char *e = getenv("DPGO_ND_ROOTS"); return e ? atoi(e) : 2; }();
     const double total = (double)order.size();
     std::vector<int> sep, lo, hi, best_cover, lp;
@@ -333,7 +333,7 @@ struct Dissector {
       std::vector<int> perm(order.size());
       for (size_t i = 0; i < perm.size(); i++) perm[i] = (int)i;
       std::sort(perm.begin(), perm.end(), [&](int a, int b) { return fv[a] < fv[b] || (fv[a] == fv[b] && a < b); });
-      for (double q : {0.5, 0.45, 0.55, 0.4, 0.6}) {
+      for (double q : {0.5, 0.475, 0.525, 0.45, 0.55}) {
         if (q < window || 1.0 - q < window) continue;
         const size_t cut = (size_t)(q * perm.size());
         // side 0 / 1 kept in level[] (the BFS levels are not needed any more)
