@@ -154,6 +154,22 @@ struct Dissector {
     for (int i = 0; i < ny; i++) lidx_[order[x1 + i]] = -1;
   }
 
+  // dot product with a summation order that does not depend on the thread count: fixed chunks, then their sums in order
+  static double pdot(const double *a, const double *b, int m) {
+    constexpr int CH = 4096;
+    const int nch = (m + CH - 1) / CH;
+    std::vector<double> part(nch);
+#pragma omp parallel for if (nch > 1)
+    for (int c = 0; c < nch; c++) {
+      double s = 0;
+      for (int i = c * CH, e = std::min(m, (c + 1) * CH); i < e; i++) s += a[i] * b[i];
+      part[c] = s;
+    }
+    double s = 0;
+    for (double v : part) s += v;
+    return s;
+  }
+
   // Approximate Fiedler vector of the subgraph induced by `verts` (all with stamp == cur): Lanczos on its Laplacian in
   // the complement of the constant vector, full reorthogonalisation, Ritz vector of the smallest Ritz value.
   void fiedler(const std::vector<int> &verts, std::vector<double> &y) {
@@ -162,6 +178,7 @@ struct Dissector {
     if ((int)lidx_.size() < A.n) lidx_.assign(A.n, -1);
     for (int i = 0; i < m; i++) lidx_[verts[i]] = i;
     auto apply = [&](const std::vector<double> &x, std::vector<double> &out) {   // out = L x
+#pragma omp parallel for if (m > 4096)
       for (int i = 0; i < m; i++) {
         const int v = verts[i];
         double s = 0;
@@ -181,8 +198,12 @@ struct Dissector {
       mean /= m;
       for (double &v : x) v -= mean;
     };
-    std::vector<std::vector<double>> Q;
-    std::vector<double> alpha, beta, q(m), w(m);
+    // (the long loops run on the host threads: at the top of the tree m is the whole graph; sums are taken over
+    // fixed chunks so that the result does not depend on the number of threads)
+    const bool par = m > 4096;
+    (void)par;
+    std::vector<double> Q((size_t)kmax * m);   // Lanczos vectors, row k = q_k
+    std::vector<double> alpha, beta, q(m), w(m), coef(kmax);
     for (int i = 0; i < m; i++) q[i] = std::sin(0.7 * i + 0.3) + 1e-3 * (i % 7);
     deflate(q);
     double nrm = 0;
@@ -190,21 +211,27 @@ struct Dissector {
     nrm = std::sqrt(nrm);
     for (double &v : q) v /= nrm;
     for (int k = 0; k < kmax; k++) {
-      Q.push_back(q);
+      std::copy(q.begin(), q.end(), Q.begin() + (size_t)k * m);
       apply(q, w);
-      double a = 0;
-      for (int i = 0; i < m; i++) a += w[i] * q[i];
-      alpha.push_back(a);
+      alpha.push_back(pdot(w.data(), q.data(), m));
       deflate(w);
-      for (int pass = 0; pass < 2; pass++)
-        for (const auto &qq : Q) {
+      for (int pass = 0; pass < 2; pass++) {   // classical Gram-Schmidt, twice
+        const int nk = k + 1;
+#pragma omp parallel for if (par)
+        for (int j = 0; j < nk; j++) {
+          const double *qq = &Q[(size_t)j * m];
           double c = 0;
           for (int i = 0; i < m; i++) c += w[i] * qq[i];
-          for (int i = 0; i < m; i++) w[i] -= c * qq[i];
+          coef[j] = c;
         }
-      double b = 0;
-      for (double v : w) b += v * v;
-      b = std::sqrt(b);
+#pragma omp parallel for if (par)
+        for (int i = 0; i < m; i++) {
+          double acc = w[i];
+          for (int j = 0; j < nk; j++) acc -= coef[j] * Q[(size_t)j * m + i];
+          w[i] = acc;
+        }
+      }
+      const double b = std::sqrt(pdot(w.data(), w.data(), m));
       if (b < 1e-10) break;
       beta.push_back(b);
       for (int i = 0; i < m; i++) q[i] = w[i] / b;
@@ -245,7 +272,7 @@ struct Dissector {
     }
     y.assign(m, 0.0);
     for (int k = 0; k < kk; k++)
-      for (int i = 0; i < m; i++) y[i] += s[k] * Q[k][i];
+      for (int i = 0; i < m; i++) y[i] += s[k] * Q[(size_t)k * m + i];
     for (int i = 0; i < m; i++) lidx_[verts[i]] = -1;
   }
 
@@ -386,7 +413,10 @@ struct Dissector {
 
 }  // namespace
 
-static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int collapse, bool symbolic_only) {
+// tree: a nested-dissection tree of A computed earlier (the dissection does not depend on `collapse`); if *tree is
+// empty it is computed here and stored there.
+static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int collapse, bool symbolic_only,
+                           std::vector<TreeNode> *tree) {
   const int n = A.n;
   omp_set_num_threads(host_threads());
   F = SpdFactor();
@@ -407,10 +437,12 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
         if (A.col[k] != i) adj.col[pos[i]++] = A.col[k];
   }
   Dissector D(adj, leaf);
-  {
+  if (tree && !tree->empty()) D.nodes = *tree;
+  else {
     std::vector<int> all(n);
     std::iota(all.begin(), all.end(), 0);
     D.dissect(std::move(all), -1);
+    if (tree) *tree = D.nodes;
   }
   // Level collapsing: absorb every tree node whose depth is not a multiple of `collapse` into its
   // nearest ancestor whose depth is.  The merged front factors the absorbed separators together as one
@@ -740,6 +772,7 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
 }
 
 int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf, int collapse) {
+  std::vector<TreeNode> tree;   // dissected once, reused for every merge depth tried below
   if (const char *e = getenv("DPGO_SPD_COLLAPSE")) collapse = atoi(e);
   if (collapse <= 0) {
     // choose the number of merged levels from a latency + bandwidth model of one sweep on MI355X:
@@ -748,13 +781,13 @@ int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf, int collapse) {
     int best_c = 1;
     for (int c = 1; c <= 3; c++) {
       SpdFactor S;
-      if (spd_factor_impl(A, S, leaf, c, true) != 0) continue;
+      if (spd_factor_impl(A, S, leaf, c, true, &tree) != 0) continue;
       const double t = 12e-6 * (double)S.by_height.size() + 8.0 * (double)S.entries / 3.0e12;
       if (t < best) { best = t; best_c = c; }
     }
     collapse = best_c;
   }
-  return spd_factor_impl(A, F, leaf, collapse, false);
+  return spd_factor_impl(A, F, leaf, collapse, false, &tree);
 }
 
 void spd_solve_host(const SpdFactor &F, double *X, int nc) {
