@@ -360,7 +360,7 @@ struct Dissector {
       std::vector<int> perm(order.size());
       for (size_t i = 0; i < perm.size(); i++) perm[i] = (int)i;
       std::sort(perm.begin(), perm.end(), [&](int a, int b) { return fv[a] < fv[b] || (fv[a] == fv[b] && a < b); });
-      for (double q : {0.5, 0.475, 0.525, 0.45, 0.55}) {
+      for (double q : {0.5, 0.49, 0.51, 0.48, 0.52, 0.47, 0.53, 0.46, 0.54, 0.45, 0.55}) {
         if (q < window || 1.0 - q < window) continue;
         const size_t cut = (size_t)(q * perm.size());
         // side 0 / 1 kept in level[] (the BFS levels are not needed any more)

@@ -1,4 +1,5 @@
-// Sparse SPD direct solver: nested-dissection multifrontal Cholesky.
+// Sparse SPD direct solver: nested-dissection multifrontal Cholesky.  Separators: minimum vertex covers of BFS-level
+// and spectral (Fiedler) cuts, see Dissector in spd.cpp.
 //
 // Replaces the reference's CHOLMOD factorisations `L_` (of G_tt) and
 // `reg_Chol_precon_` (of G_RR + lambda I): C++/DPGO/src/DPGOProblem.cpp:93,119;
