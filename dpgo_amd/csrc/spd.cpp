@@ -172,8 +172,10 @@ struct Dissector {
 
   // Approximate Fiedler vector of the subgraph induced by `verts` (all with stamp == cur): Lanczos on its Laplacian in
   // the complement of the constant vector, full reorthogonalisation, Ritz vector of the smallest Ritz value.
-  void fiedler(const std::vector<int> &verts, std::vector<double> &y) {
-    static const int lanczos_steps = [] { const char *e = getenv("DPGO_ND_LANCZOS"); return e ? atoi(e) : 60; }();
+  // ys: one vector per depth in `depths` (Ritz vectors of the same Lanczos run: different approximations of the
+  // Fiedler vector cut the graph differently, and the smallest separator among them is kept).
+  void fiedler(const std::vector<int> &verts, const std::vector<int> &depths, std::vector<std::vector<double>> &ys) {
+    const int lanczos_steps = *std::max_element(depths.begin(), depths.end());
     const int m = (int)verts.size(), kmax = std::min(m - 1, lanczos_steps);
     if ((int)lidx_.size() < A.n) lidx_.assign(A.n, -1);
     for (int i = 0; i < m; i++) lidx_[verts[i]] = i;
@@ -236,7 +238,10 @@ struct Dissector {
       beta.push_back(b);
       for (int i = 0; i < m; i++) q[i] = w[i] / b;
     }
-    const int kk = (int)alpha.size();
+    ys.clear();
+    for (int depth : depths) {
+    const int kk = std::min((int)alpha.size(), depth);
+    if (!ys.empty() && kk == (int)alpha.size() && depth > (int)alpha.size()) break;   // Lanczos ended early: nothing new
     // smallest eigenvalue of the tridiagonal (alpha, beta) by bisection on the Sturm count
     double lo = 0, hi = 0;
     for (int i = 0; i < kk; i++) hi = std::max(hi, alpha[i] + (i > 0 ? beta[i - 1] : 0) + (i < kk - 1 && i < (int)beta.size() ? beta[i] : 0));
@@ -270,9 +275,11 @@ struct Dissector {
       n2 = std::sqrt(n2);
       for (double &v : s) v /= n2;
     }
-    y.assign(m, 0.0);
+    std::vector<double> y(m, 0.0);
     for (int k = 0; k < kk; k++)
       for (int i = 0; i < m; i++) y[i] += s[k] * Q[(size_t)k * m + i];
+    ys.push_back(std::move(y));
+    }
     for (int i = 0; i < m; i++) lidx_[verts[i]] = -1;
   }
 
@@ -355,12 +362,27 @@ struct Dissector {
     // that level sets grown from a corner (diagonal planes) miss.
     static const int spectral = [] { const char *e = getenv("DPGO_ND_SPECTRAL"); return e ? atoi(e) : 1; }();
     if (spectral && order.size() >= 64) {
-      std::vector<double> fv;
-      fiedler(order, fv);
+      static const std::vector<int> depths = [] {
+        std::vector<int> d;
+        const char *e = getenv("DPGO_ND_LANCZOS");
+        std::string str = e ? e : "40,60,90,120";
+        for (size_t p = 0; p < str.size();) {
+          size_t c = str.find(',', p);
+          if (c == std::string::npos) c = str.size();
+          d.push_back(atoi(str.substr(p, c - p).c_str()));
+          p = c + 1;
+        }
+        return d;
+      }();
+      std::vector<std::vector<double>> fvs;
+      fiedler(order, depths, fvs);
       std::vector<int> perm(order.size());
-      for (size_t i = 0; i < perm.size(); i++) perm[i] = (int)i;
-      std::sort(perm.begin(), perm.end(), [&](int a, int b) { return fv[a] < fv[b] || (fv[a] == fv[b] && a < b); });
+      for (const std::vector<double> &fv : fvs)
       for (double q : {0.5, 0.49, 0.51, 0.48, 0.52, 0.47, 0.53, 0.46, 0.54, 0.45, 0.55}) {
+        if (q == 0.5) {
+          for (size_t i = 0; i < perm.size(); i++) perm[i] = (int)i;
+          std::sort(perm.begin(), perm.end(), [&](int a, int b) { return fv[a] < fv[b] || (fv[a] == fv[b] && a < b); });
+        }
         if (q < window || 1.0 - q < window) continue;
         const size_t cut = (size_t)(q * perm.size());
         // side 0 / 1 kept in level[] (the BFS levels are not needed any more)
