@@ -461,9 +461,60 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
   Dissector D(adj, leaf);
   if (tree && !tree->empty()) D.nodes = *tree;
   else {
-    std::vector<int> all(n);
-    std::iota(all.begin(), all.end(), 0);
-    D.dissect(std::move(all), -1);
+    // connected components (the nodes of a group are disconnected from each other) are dissected independently,
+    // one host thread each; the result does not depend on the number of threads
+    std::vector<std::vector<int>> comps;
+    {
+      std::vector<int> comp(n, -1), stack;
+      for (int r = 0; r < n; r++) {
+        if (comp[r] >= 0) continue;
+        const int c = (int)comps.size();
+        comps.emplace_back();
+        comp[r] = c;
+        stack.assign(1, r);
+        while (!stack.empty()) {
+          const int v = stack.back();
+          stack.pop_back();
+          comps[c].push_back(v);
+          for (int k = adj.ptr[v]; k < adj.ptr[v + 1]; k++)
+            if (comp[adj.col[k]] < 0) { comp[adj.col[k]] = c; stack.push_back(adj.col[k]); }
+        }
+        std::sort(comps[c].begin(), comps[c].end());
+      }
+    }
+    // (components are started largest first; tiny ones share a dissector)
+    std::vector<int> big;
+    std::vector<int> small_verts;
+    for (int c = 0; c < (int)comps.size(); c++) {
+      if ((int)comps[c].size() >= 2048) big.push_back(c);
+      else small_verts.insert(small_verts.end(), comps[c].begin(), comps[c].end());
+    }
+    std::vector<std::vector<TreeNode>> parts(big.size());
+#pragma omp parallel for schedule(dynamic, 1) if (big.size() > 1)
+    for (int b = 0; b < (int)big.size(); b++) {
+      Dissector Dc(adj, leaf);
+      Dc.dissect(comps[big[b]], -1);
+      parts[b] = std::move(Dc.nodes);
+    }
+    for (auto &p : parts) {
+      const int off = (int)D.nodes.size();
+      for (TreeNode &t : p) {
+        if (t.parent >= 0) t.parent += off;
+        for (int &ch : t.children) ch += off;
+        D.nodes.push_back(std::move(t));
+      }
+    }
+    if (!small_verts.empty()) {
+      std::sort(small_verts.begin(), small_verts.end());
+      Dissector Ds(adj, leaf);
+      Ds.dissect(std::move(small_verts), -1);
+      const int off = (int)D.nodes.size();
+      for (TreeNode &t : Ds.nodes) {
+        if (t.parent >= 0) t.parent += off;
+        for (int &ch : t.children) ch += off;
+        D.nodes.push_back(std::move(t));
+      }
+    }
     if (tree) *tree = D.nodes;
   }
   // Level collapsing: absorb every tree node whose depth is not a multiple of `collapse` into its
