@@ -113,6 +113,31 @@ def test_spd_solver_disconnected_and_tiny():
     np.testing.assert_allclose(A @ X, B, atol=1e-12)
 
 
+def test_spd_solver_large_components_and_separator_quality():
+    """Two large disconnected lattice Laplacians (the situation of a group with several nodes): the components are
+    dissected in parallel with minimum-vertex-cover / spectral separators; the solve is exact, and the top separator
+    of a 16 x 16 x 12 lattice is close to its smallest cross-section (16 x 12 = 192), not a diagonal level set."""
+    def lattice(nx, ny, nz):
+        idx = np.arange(nx * ny * nz).reshape(nx, ny, nz)
+        e = [(idx[:-1].ravel(), idx[1:].ravel()), (idx[:, :-1].ravel(), idx[:, 1:].ravel()),
+             (idx[:, :, :-1].ravel(), idx[:, :, 1:].ravel())]
+        i = np.concatenate([a for a, _ in e]); j = np.concatenate([b for _, b in e])
+        W = sp.coo_matrix((np.ones(len(i)), (i, j)), shape=(idx.size, idx.size))
+        W = W + W.T
+        return (sp.diags(np.asarray(W.sum(1)).ravel() + 0.5) - W).tocsr()
+    A = sp.block_diag([lattice(16, 16, 12), lattice(15, 14, 13)]).tocsr()
+    rng = np.random.default_rng(3)
+    B = rng.standard_normal((A.shape[0], 3))
+    X = dpgo_amd.spd_solve_host(A, B, leaf=64)
+    np.testing.assert_allclose(A @ X, B, atol=1e-9)
+    os.environ["DPGO_SPD_COLLAPSE"] = "1"
+    try:
+        _, _, max_front = dpgo_amd.spd_stats(lattice(16, 16, 12), 64)
+    finally:
+        del os.environ["DPGO_SPD_COLLAPSE"]
+    assert max_front <= 1.35 * 192
+
+
 @pytest.mark.parametrize("name", ["smallGrid3D", "M3500"])
 def test_chordal_initialization_matches_oracle(fixtures_dir, name):
     path = os.path.join(fixtures_dir, name + ".g2o")
