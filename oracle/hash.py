@@ -50,6 +50,7 @@ class Options:
         self.stepsize_tol = 1e-4
         self.max_iterations = 10
         self.max_iterations_accepted = 1
+        self.preconditioner = 1                                   # Preconditioner::RegularizedCholesky (DPGO_types.h:155)
         self.reg_Cholesky_precon_max_condition_number = 1e6
         self.preconditioned_grad_norm_tol = 1e-4
         self.max_tCG_iterations = 10000
@@ -101,7 +102,8 @@ class DPGOHash:
         self.options = options
         self.problem = DPGOProblem(
             node, measurements, options.regularizer, options.loss,
-            options.reg_Cholesky_precon_max_condition_number, options.loss_reg)
+            options.reg_Cholesky_precon_max_condition_number, options.loss_reg,
+            preconditioner=bool(getattr(options, "preconditioner", 1)))   # DPGOHash.cpp:16
         self.results = Results()
 
     # DPGOHash.cpp:20-43

@@ -436,3 +436,23 @@ def test_runs_are_bit_reproducible(fixtures_dir):
             assert drv.step() == 0
         outs.append(drv.X().copy())
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("kw", [
+    dict(max_iterations_accepted=3, max_iterations=12),          # several accepted TNT steps: the model is rebuilt
+    dict(preconditioner=0),                                      # Preconditioner::None (identity)
+    dict(max_iterations_accepted=2, max_tCG_iterations=3),       # truncated CG that stops on its iteration cap
+])
+@pytest.mark.parametrize("loss", [LOSS_NONE, LOSS_HUBER])
+def test_tnt_option_variants_match_oracle(fixtures_dir, loss, kw):
+    """TNT / STPCG options other than the driver's (DPGO_types.h:78-201): the refinement paths the default run never
+    takes (a second accepted step re-using the trial point's model gradient, no preconditioner, capped CG)."""
+    orc, gpu = _pair(fixtures_dir, "smallGrid3D", 2, loss, True, **kw)
+    for it in range(12):
+        orc.step(evaluate=False)
+        assert gpu.step() == 0
+        for a in range(2):
+            ro, rg = orc.nodes[a].results, gpu.group.results(a)
+            np.testing.assert_allclose(rg.fobj, ro.fobj[0], rtol=1e-7, err_msg="fobj it=%d node=%d %r" % (it, a, kw))
+            np.testing.assert_allclose(rg.Gk, ro.Gk, rtol=1e-7, err_msg="Gk it=%d node=%d %r" % (it, a, kw))
+    np.testing.assert_allclose(gpu.X(), orc.gather(), atol=1e-6)
