@@ -31,6 +31,8 @@ LIB_PATH = os.path.join(_HERE, "libdpgo_amd.so")
 LOSS_NONE, LOSS_HUBER, LOSS_GM, LOSS_WELSCH = 0, 1, 2, 3
 LOSS_NAMES = {"trivial": 0, "none": 0, "huber": 1, "gm": 2, "welsch": 3}
 SCHEME_MM, SCHEME_AMM = 0, 1
+RESCALE_STATIC, RESCALE_DYNAMIC = 0, 1
+PRECON_NONE, PRECON_JACOBI, PRECON_ICHOL, PRECON_REG_CHOLESKY = 0, 1, 2, 3
 
 
 class Options(C.Structure):
@@ -40,7 +42,7 @@ class Options(C.Structure):
         ("eta", C.c_double * 2), ("psi", C.c_double), ("phi", C.c_double),
         ("max_soft_restart_hits", C.c_int * 2), ("oscillation_cnt_period", C.c_int),
         ("max_oscillations", C.c_int), ("loss", C.c_int), ("loss_reg", C.c_double),
-        ("grad_norm_tol", C.c_double), ("rel_func_decrease_tol", C.c_double), ("stepsize_tol", C.c_double),
+        ("rescale", C.c_int), ("max_rescale_count", C.c_int), ("grad_norm_tol", C.c_double), ("rel_func_decrease_tol", C.c_double), ("stepsize_tol", C.c_double),
         ("max_iterations", C.c_int), ("max_iterations_accepted", C.c_int),
         ("reg_Cholesky_precon_max_condition_number", C.c_double),
         ("preconditioned_grad_norm_tol", C.c_double), ("max_tCG_iterations", C.c_int),
@@ -93,6 +95,11 @@ SYMBOLS = {
     "dpgo_graph_node_offset": (C.c_int, [C.c_void_p, C.c_int]),
     "dpgo_graph_exchange_plan": (C.c_int, [C.c_void_p, _IP, C.c_int, _IP, _IP, _IP, _IP, _IP]),
     "dpgo_chordal_initialization": (C.c_int, [C.c_void_p, _DP, C.c_int]),
+    "dpgo_graph_node_maps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _IP, _IP, _IP, _IP, _IP]),
+    "dpgo_write_g2o": (C.c_int, [C.c_void_p, _DP, C.c_int, C.c_char_p]),
+    "dpgo_group_evaluate": (C.c_int, [C.c_void_p, _DP, C.c_int, _DP, _DP, _DP, C.c_int]),
+    "dpgo_group_set_options": (C.c_int, [C.c_void_p, C.POINTER(Options)]),
+    "dpgo_group_get_options": (C.c_int, [C.c_void_p, C.POINTER(Options)]),
     "dpgo_group_create": (C.c_int, [C.c_void_p, _IP, C.c_int, C.POINTER(Options), C.c_int, C.POINTER(C.c_void_p)]),
     "dpgo_group_free": (None, [C.c_void_p]),
     "dpgo_group_initialize": (C.c_int, [C.c_void_p, C.c_int, _DP, C.c_int]),
@@ -209,6 +216,24 @@ class Graph:
         sn, sp_, rn, rp = (np.empty(c, np.int32) for c in (cnt[0], cnt[0], cnt[1], cnt[1]))
         lib().dpgo_graph_exchange_plan(self._h, _ip(ids), len(ids), _ip(sn), _ip(sp_), _ip(rn), _ip(rp), _ip(cnt))
         return (sn, sp_), (rn, rp)
+
+    def node_maps(self, node, which):
+        """DPGOProblem::index() / sent() / recv() (which = "index" | "sent" | "recv"):
+        list of ((node, pose), (block, k)) in map order."""
+        w = {"index": 0, "sent": 1, "recv": 2}[which]
+        cnt = C.c_int()
+        if lib().dpgo_graph_node_maps(self._h, node, w, None, None, None, None, C.byref(cnt)) != 0:
+            raise ValueError("node_maps")
+        a, b, c, d = (np.empty(cnt.value, np.int32) for _ in range(4))
+        lib().dpgo_graph_node_maps(self._h, node, w, _ip(a), _ip(b), _ip(c), _ip(d), C.byref(cnt))
+        return [((int(a[i]), int(b[i])), (int(c[i]), int(d[i]))) for i in range(cnt.value)]
+
+    def write_g2o(self, filename, X=None):
+        """VERTEX_* lines from X (optional) + EDGE_* lines; returns 0 / -1."""
+        if X is None:
+            return lib().dpgo_write_g2o(self._h, None, 0, os.fsencode(filename))
+        X, ld = _fcol(X)
+        return lib().dpgo_write_g2o(self._h, _dp(X), ld, os.fsencode(filename))
 
     def chordal_initialization(self):
         """Centralised chordal init (dist_pgo.cpp:416-444): X, (d+1)N x d, reference layout."""
@@ -390,6 +415,28 @@ class NodeGroup:
     def scatter_global(self, X):
         assert X.flags.f_contiguous
         return lib().dpgo_group_scatter_global(self._h, _dp(X), X.shape[0])
+
+    def evaluate(self, X, want_grad=False):
+        """DPGOStar::evaluate_f / evaluate_grad at an arbitrary global X: (F, |grad F|^2[, grad]) summed over
+        this group's nodes (over all groups when collectives are attached)."""
+        X, ld = _fcol(X)
+        F, g2 = C.c_double(), C.c_double()
+        G = np.zeros_like(X, order="F") if want_grad else None
+        if lib().dpgo_group_evaluate(self._h, _dp(X), ld, C.byref(F), C.byref(g2), _dp(G) if want_grad else None,
+                                     ld if want_grad else 0) != 0:
+            raise RuntimeError("dpgo_group_evaluate failed")
+        return (F.value, g2.value, G) if want_grad else (F.value, g2.value)
+
+    def set_options(self, options):
+        rc = lib().dpgo_group_set_options(self._h, C.byref(options))
+        if rc == 0:
+            self.options = options
+        return rc
+
+    def get_options(self):
+        o = Options()
+        lib().dpgo_group_get_options(self._h, C.byref(o))
+        return o
 
     def results(self, k):
         r = Results()

@@ -1,7 +1,10 @@
 // C ABI (include/dpgo_amd.h) over the C++ host layer.
 #include "../../include/dpgo_amd.h"
 
+#include <cmath>
+#include <cstdio>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <numeric>
 #include <set>
@@ -10,6 +13,21 @@
 
 namespace dpgo {
 int chordal_initialization(const Graph &g, double *X, int ld);
+}
+
+// No exception leaves the library: a failed HIP call (dpgo::DeviceError) or an allocation failure becomes the
+// reference's `return -1` (+ a line on stderr), never abort() / terminate() in the host process.
+template <class F>
+static int guarded(F &&f) {
+  try {
+    return f();
+  } catch (const std::exception &e) {
+    fprintf(stderr, "[dpgo_amd] ERROR: %s\n", e.what());
+    return -1;
+  } catch (...) {
+    fprintf(stderr, "[dpgo_amd] ERROR: unknown exception\n");
+    return -1;
+  }
 }
 
 struct dpgo_graph {
@@ -26,7 +44,8 @@ static dpgo::Options to_cpp(const dpgo_options_t &o) {
   r.eta[0] = o.eta[0]; r.eta[1] = o.eta[1]; r.psi = o.psi; r.phi = o.phi;
   r.max_soft_restart_hits[0] = o.max_soft_restart_hits[0]; r.max_soft_restart_hits[1] = o.max_soft_restart_hits[1];
   r.oscillation_cnt_period = o.oscillation_cnt_period; r.max_oscillations = o.max_oscillations;
-  r.loss = o.loss; r.loss_reg = o.loss_reg; r.grad_norm_tol = o.grad_norm_tol;
+  r.loss = o.loss; r.loss_reg = o.loss_reg; r.rescale = o.rescale; r.max_rescale_count = o.max_rescale_count;
+  r.grad_norm_tol = o.grad_norm_tol;
   r.rel_func_decrease_tol = o.rel_func_decrease_tol; r.stepsize_tol = o.stepsize_tol;
   r.max_iterations = o.max_iterations; r.max_iterations_accepted = o.max_iterations_accepted;
   r.reg_Cholesky_precon_max_condition_number = o.reg_Cholesky_precon_max_condition_number;
@@ -43,7 +62,8 @@ void dpgo_options_default(dpgo_options_t *o) {
   o->eta[0] = d.eta[0]; o->eta[1] = d.eta[1]; o->psi = d.psi; o->phi = d.phi;
   o->max_soft_restart_hits[0] = d.max_soft_restart_hits[0]; o->max_soft_restart_hits[1] = d.max_soft_restart_hits[1];
   o->oscillation_cnt_period = d.oscillation_cnt_period; o->max_oscillations = d.max_oscillations;
-  o->loss = d.loss; o->loss_reg = d.loss_reg; o->grad_norm_tol = d.grad_norm_tol;
+  o->loss = d.loss; o->loss_reg = d.loss_reg; o->rescale = d.rescale; o->max_rescale_count = d.max_rescale_count;
+  o->grad_norm_tol = d.grad_norm_tol;
   o->rel_func_decrease_tol = d.rel_func_decrease_tol; o->stepsize_tol = d.stepsize_tol;
   o->max_iterations = d.max_iterations; o->max_iterations_accepted = d.max_iterations_accepted;
   o->reg_Cholesky_precon_max_condition_number = d.reg_Cholesky_precon_max_condition_number;
@@ -55,6 +75,7 @@ void dpgo_options_driver(dpgo_options_t *o, int loss, int accelerated) {
   // C++/examples/dist_pgo.cpp:103-120
   dpgo_options_default(o);
   o->loss = loss;
+  o->rescale = 0;   // Rescale::Static (dist_pgo.cpp:105)
   o->loss_reg = 0.25;
   o->scheme = accelerated ? 1 : 0;
   o->STPCG_kappa = 0.05;
@@ -77,7 +98,13 @@ int dpgo_read_g2o(const char *filename, int num_nodes, dpgo_graph_t **out) {
 
 int dpgo_graph_from_edges(int d, int num_poses, int m, const int *I, const int *J, const double *R, const double *t,
                           const double *kappa, const double *tau, int num_nodes, dpgo_graph_t **out) {
-  if ((d != 2 && d != 3) || m <= 0) return -1;
+  *out = nullptr;
+  if ((d != 2 && d != 3) || m <= 0 || num_poses <= 0 || num_nodes < 1 || !I || !J || !R || !t || !kappa || !tau) return -1;
+  for (int e = 0; e < m; e++)
+    if (I[e] < 0 || I[e] >= num_poses || J[e] < 0 || J[e] >= num_poses) {
+      fprintf(stderr, "[dpgo_amd] ERROR: edge %d: pose id out of range (%d, %d), num_poses = %d.\n", e, I[e], J[e], num_poses);
+      return -1;
+    }
   auto *g = new dpgo_graph();
   g->g.d = d;
   g->g.num_poses = num_poses;
@@ -185,20 +212,30 @@ int dpgo_group_create(const dpgo_graph_t *g, const int *node_ids, int num_local,
                       int device, dpgo_group_t **out) {
   *out = nullptr;
   if (!g || num_local <= 0) return -1;
+  if (!node_ids || !opt) return -1;
   std::vector<int> ids(node_ids, node_ids + num_local);
-  for (int id : ids)
-    if (id < 0 || id >= g->g.num_nodes) return -1;
-  auto *h = new dpgo_group();
-  h->grp = new dpgo::Group(g->g, ids, to_cpp(*opt), device);
-  if (!h->grp->ok()) {
-    delete h->grp;
-    delete h;
+  if (std::set<int>(ids.begin(), ids.end()).size() != ids.size()) {
+    fprintf(stderr, "[dpgo_amd] ERROR: dpgo_group_create: a node id appears twice.\n");
     return -1;
   }
-  h->all.resize(num_local);
-  std::iota(h->all.begin(), h->all.end(), 0);
-  *out = h;
-  return 0;
+  for (int id : ids)
+    if (id < 0 || id >= g->g.num_nodes) {
+      fprintf(stderr, "[dpgo_amd] ERROR: dpgo_group_create: node %d is not in [0, %d).\n", id, g->g.num_nodes);
+      return -1;
+    }
+  return guarded([&] {
+    auto *h = new dpgo_group();
+    h->grp = new dpgo::Group(g->g, ids, to_cpp(*opt), device);
+    if (!h->grp->ok()) {
+      delete h->grp;
+      delete h;
+      return -1;
+    }
+    h->all.resize(num_local);
+    std::iota(h->all.begin(), h->all.end(), 0);
+    *out = h;
+    return 0;
+  });
 }
 
 void dpgo_group_free(dpgo_group_t *h) {
@@ -207,24 +244,43 @@ void dpgo_group_free(dpgo_group_t *h) {
   delete h;
 }
 
-static std::vector<int> sel(const dpgo_group_t *h, const int *locals, int n) {
-  if (!locals || n <= 0) return h->all;
-  return std::vector<int>(locals, locals + n);
+// the nodes a batched call works on: every node (locals == NULL), or a list of distinct local indices.
+// false: an index is out of range or appears twice (res_[a] and the 64-bit node mask are indexed by it)
+static bool sel(const dpgo_group_t *h, const int *locals, int n, std::vector<int> &out) {
+  if (!locals || n <= 0) { out = h->all; return true; }
+  out.assign(locals, locals + n);
+  std::vector<char> seen(h->all.size(), 0);
+  for (int a : out) {
+    if (a < 0 || a >= (int)h->all.size() || seen[a]) {
+      fprintf(stderr, "[dpgo_amd] ERROR: local node index %d is out of range [0, %zu) or repeated.\n", a, h->all.size());
+      return false;
+    }
+    seen[a] = 1;
+  }
+  return true;
 }
 
-int dpgo_group_initialize(dpgo_group_t *h, int local, const double *X, int ld) { return h->grp->initialize(local, X, ld); }
-int dpgo_group_initialize_global(dpgo_group_t *h, const double *X, int ld) { return h->grp->initialize_global(X, ld); }
-int dpgo_group_update(dpgo_group_t *h, const int *locals, int n) { return h->grp->update(sel(h, locals, n)); }
-int dpgo_group_iterate(dpgo_group_t *h, const int *locals, int n) { return h->grp->iterate(sel(h, locals, n)); }
-int dpgo_group_communicate_local(dpgo_group_t *h) { return h->grp->communicate_local(); }
+int dpgo_group_initialize(dpgo_group_t *h, int local, const double *X, int ld) { return guarded([&] { return h->grp->initialize(local, X, ld); }); }
+int dpgo_group_initialize_global(dpgo_group_t *h, const double *X, int ld) { return guarded([&] { return h->grp->initialize_global(X, ld); }); }
+int dpgo_group_update(dpgo_group_t *h, const int *locals, int n) {
+  std::vector<int> v;
+  if (!h || !sel(h, locals, n, v)) return -1;
+  return guarded([&] { return h->grp->update(v); });
+}
+int dpgo_group_iterate(dpgo_group_t *h, const int *locals, int n) {
+  std::vector<int> v;
+  if (!h || !sel(h, locals, n, v)) return -1;
+  return guarded([&] { return h->grp->iterate(v); });
+}
+int dpgo_group_communicate_local(dpgo_group_t *h) { return guarded([&] { return h->grp->communicate_local(); }); }
 int dpgo_group_set_collectives(dpgo_group_t *h, void *send_dev, void *gathered_dev, dpgo_allgather_fn ag, dpgo_allreduce_fn ar,
                                void *user) {
-  return h->grp->set_collectives((double *)send_dev, (double *)gathered_dev, ag, ar, user);
+  return guarded([&] { return h->grp->set_collectives((double *)send_dev, (double *)gathered_dev, ag, ar, user); });
 }
 
-int dpgo_group_star_initialize(dpgo_group_t *h, const double *X, int ld) { return h->grp->star_initialize_global(X, ld); }
-int dpgo_group_star_update(dpgo_group_t *h) { return h->grp->star_update(); }
-int dpgo_group_star_iterate(dpgo_group_t *h) { return h->grp->star_iterate(); }
+int dpgo_group_star_initialize(dpgo_group_t *h, const double *X, int ld) { return guarded([&] { return h->grp->star_initialize_global(X, ld); }); }
+int dpgo_group_star_update(dpgo_group_t *h) { return guarded([&] { return h->grp->star_update(); }); }
+int dpgo_group_star_iterate(dpgo_group_t *h) { return guarded([&] { return h->grp->star_iterate(); }); }
 int dpgo_group_star_state(const dpgo_group_t *h, double *F, double *fobj, double *fobjh, int *branches) {
   if (F) *F = h->grp->star_F();
   if (fobj) *fobj = h->grp->star_fobj();
@@ -232,8 +288,8 @@ int dpgo_group_star_state(const dpgo_group_t *h, double *F, double *fobj, double
   if (branches) *branches = h->grp->star_branches();
   return 0;
 }
-int dpgo_group_receive(dpgo_group_t *h, int local, int beta, const double *msg, int ld) { return h->grp->receive(local, beta, msg, ld); }
-int dpgo_group_send(const dpgo_group_t *h, int local, int beta, double *msg, int ld) { return h->grp->send(local, beta, msg, ld); }
+int dpgo_group_receive(dpgo_group_t *h, int local, int beta, const double *msg, int ld) { return guarded([&] { return h->grp->receive(local, beta, msg, ld); }); }
+int dpgo_group_send(const dpgo_group_t *h, int local, int beta, double *msg, int ld) { return guarded([&] { return h->grp->send(local, beta, msg, ld); }); }
 int dpgo_group_message_sizes(const dpgo_group_t *h, int local, int beta, int *num_send, int *num_recv) {
   const int s = h->grp->num_send(local, beta), r = h->grp->num_recv(local, beta);
   if (s < 0 || r < 0) return -1;
@@ -249,15 +305,18 @@ int dpgo_group_sent_keys(const dpgo_group_t *h, int *nodes, int *poses) {
 }
 int dpgo_group_set_recv_layout(dpgo_group_t *h, int nranks, int stride, const int *counts, const int *nodes,
                                const int *poses) {
-  return h->grp->set_recv_layout(nranks, stride, counts, nodes, poses);
+  return guarded([&] { return h->grp->set_recv_layout(nranks, stride, counts, nodes, poses); });
 }
-int dpgo_group_pack_sent(dpgo_group_t *h, void *buf) { return h->grp->pack_sent((double *)buf); }
-int dpgo_group_unpack_recv(dpgo_group_t *h, const void *buf) { return h->grp->unpack_recv((const double *)buf); }
-int dpgo_group_get_Xk(const dpgo_group_t *h, int local, double *X, int ld) { return h->grp->get_Xk(local, X, ld); }
-int dpgo_group_get_Xak(const dpgo_group_t *h, int local, double *X, int ld) { return h->grp->get_X_own(local, X, ld); }
-int dpgo_group_scatter_global(const dpgo_group_t *h, double *X, int ld) { return h->grp->scatter_global(X, ld); }
-int dpgo_group_node_id(const dpgo_group_t *h, int local) { return h->grp->node_id(local); }
-int dpgo_group_sync(const dpgo_group_t *h) { h->grp->sync(); return 0; }
+int dpgo_group_pack_sent(dpgo_group_t *h, void *buf) { return guarded([&] { return h->grp->pack_sent((double *)buf); }); }
+int dpgo_group_unpack_recv(dpgo_group_t *h, const void *buf) { return guarded([&] { return h->grp->unpack_recv((const double *)buf); }); }
+int dpgo_group_get_Xk(const dpgo_group_t *h, int local, double *X, int ld) { return guarded([&] { return h->grp->get_Xk(local, X, ld); }); }
+int dpgo_group_get_Xak(const dpgo_group_t *h, int local, double *X, int ld) { return guarded([&] { return h->grp->get_X_own(local, X, ld); }); }
+int dpgo_group_scatter_global(const dpgo_group_t *h, double *X, int ld) { return guarded([&] { return h->grp->scatter_global(X, ld); }); }
+int dpgo_group_node_id(const dpgo_group_t *h, int local) {
+  if (!h || local < 0 || local >= h->grp->num_local()) return -1;
+  return h->grp->node_id(local);
+}
+int dpgo_group_sync(const dpgo_group_t *h) { return guarded([&] { h->grp->sync(); return 0; }); }
 void *dpgo_group_stream(const dpgo_group_t *h) { return (void *)h->grp->stream(); }
 
 int dpgo_group_results(const dpgo_group_t *h, int local, dpgo_results_t *o) {
@@ -372,7 +431,119 @@ int dpgo_debug_spd_stats(int n, const int *ptr, const int *col, const double *va
 
 int dpgo_group_debug_apply(dpgo_group_t *h, int local, const char *op, const double *in, int ld_in, double *out,
                            int ld_out) {
-  return h->grp->debug_apply(local, op, in, ld_in, out, ld_out);
+  return guarded([&] { return h->grp->debug_apply(local, op, in, ld_in, out, ld_out); });
+}
+
+// ---- boundary: DPGOStar::evaluate_f / evaluate_grad, set_options / options, problem() accessors, g2o export ----
+int dpgo_group_evaluate(dpgo_group_t *h, const double *X, int ld, double *F, double *grad_sqnorm, double *grad, int ldg) {
+  if (!h || !X) return -1;
+  return guarded([&] { return h->grp->evaluate_global(X, ld, F, grad_sqnorm, grad, ldg); });
+}
+
+int dpgo_group_set_options(dpgo_group_t *h, const dpgo_options_t *opt) {
+  if (!h || !opt) return -1;
+  return guarded([&] { return h->grp->set_options(to_cpp(*opt)); });
+}
+
+int dpgo_group_get_options(const dpgo_group_t *h, dpgo_options_t *o) {
+  if (!h || !o) return -1;
+  const dpgo::Options &d = h->grp->options();
+  o->scheme = d.scheme; o->regularizer = d.regularizer; o->accepted_delta = d.accepted_delta;
+  o->eta[0] = d.eta[0]; o->eta[1] = d.eta[1]; o->psi = d.psi; o->phi = d.phi;
+  o->max_soft_restart_hits[0] = d.max_soft_restart_hits[0]; o->max_soft_restart_hits[1] = d.max_soft_restart_hits[1];
+  o->oscillation_cnt_period = d.oscillation_cnt_period; o->max_oscillations = d.max_oscillations;
+  o->loss = d.loss; o->loss_reg = d.loss_reg; o->rescale = d.rescale; o->max_rescale_count = d.max_rescale_count;
+  o->grad_norm_tol = d.grad_norm_tol;
+  o->rel_func_decrease_tol = d.rel_func_decrease_tol; o->stepsize_tol = d.stepsize_tol;
+  o->max_iterations = d.max_iterations; o->max_iterations_accepted = d.max_iterations_accepted;
+  o->reg_Cholesky_precon_max_condition_number = d.reg_Cholesky_precon_max_condition_number;
+  o->preconditioned_grad_norm_tol = d.preconditioned_grad_norm_tol; o->max_tCG_iterations = d.max_tCG_iterations;
+  o->STPCG_kappa = d.STPCG_kappa; o->STPCG_theta = d.STPCG_theta; o->preconditioner = d.preconditioner;
+  return 0;
+}
+
+int dpgo_graph_node_maps(const dpgo_graph_t *g, int node, int which, int *nodes, int *poses, int *block, int *local,
+                         int *count) {
+  dpgo::DataInfo info;
+  if (!count || node_info(g, node, info) != 0 || which < 0 || which > 2) return -1;
+  int k = 0;
+  auto emit = [&](int b, int p, int blk, int loc) {
+    if (nodes) { nodes[k] = b; poses[k] = p; block[k] = blk; local[k] = loc; }
+    k++;
+  };
+  if (which == 0) {          // index_: own poses {0, k}, neighbour poses {1, k}   (DPGO_utils.cpp:400-418)
+    for (int i = 0; i < info.n[0]; i++) emit(node, info.own_pose[i], 0, i);
+    for (int i = 0; i < info.n[1]; i++) emit(info.nbr_key[i].first, info.nbr_key[i].second, 1, i);
+  } else if (which == 1) {   // sent_[beta][own pose] = {0, k}                     (DPGO_utils.cpp:428-431)
+    for (const auto &s : info.sent)
+      for (int i : s.second) emit(s.first, info.own_pose[i], 0, i);
+  } else {                   // recv_[beta][pose of beta] = {1, k}                 (DPGO_utils.cpp:432-435)
+    for (const auto &r : info.recv)
+      for (const auto &pk : r.second) emit(r.first, pk.first, 1, pk.second);
+  }
+  *count = k;
+  return 0;
+}
+
+// g2o export: VERTEX_SE2 / VERTEX_SE3:QUAT lines from X plus the graph's edges.  The information matrices are the
+// isotropic ones the loader's formulas invert (tau = d / tr(I_t^-1), kappa = I33 | 3 / (2 tr(I_R^-1)),
+// DPGO_utils.cpp:63-67, 107-116), so reading the file back gives the same (R, t, kappa, tau).
+int dpgo_write_g2o(const dpgo_graph_t *g, const double *X, int ld, const char *filename) {
+  if (!g || !filename) return -1;
+  const int d = g->g.d, N = g->g.num_poses;
+  if (X && ld < (d + 1) * N) return -1;
+  FILE *fp = fopen(filename, "w");
+  if (!fp) {
+    fprintf(stderr, "[dpgo_amd] ERROR: cannot open %s for writing.\n", filename);
+    return -1;
+  }
+  auto quat = [](const double *R, double *q) {   // R row-major 3x3 -> (qx, qy, qz, qw)
+    const double tr = R[0] + R[4] + R[8];
+    if (tr > 0) {
+      const double s = std::sqrt(tr + 1.0) * 2;
+      q[3] = 0.25 * s; q[0] = (R[7] - R[5]) / s; q[1] = (R[2] - R[6]) / s; q[2] = (R[3] - R[1]) / s;
+    } else if (R[0] > R[4] && R[0] > R[8]) {
+      const double s = std::sqrt(1.0 + R[0] - R[4] - R[8]) * 2;
+      q[3] = (R[7] - R[5]) / s; q[0] = 0.25 * s; q[1] = (R[1] + R[3]) / s; q[2] = (R[2] + R[6]) / s;
+    } else if (R[4] > R[8]) {
+      const double s = std::sqrt(1.0 + R[4] - R[0] - R[8]) * 2;
+      q[3] = (R[2] - R[6]) / s; q[0] = (R[1] + R[3]) / s; q[1] = 0.25 * s; q[2] = (R[5] + R[7]) / s;
+    } else {
+      const double s = std::sqrt(1.0 + R[8] - R[0] - R[4]) * 2;
+      q[3] = (R[3] - R[1]) / s; q[0] = (R[2] + R[6]) / s; q[1] = (R[5] + R[7]) / s; q[2] = 0.25 * s;
+    }
+  };
+  if (X)
+    for (int i = 0; i < N; i++) {
+      // rows N + d i .. of X hold R_i^T: R_i(r, c) = X(N + d i + c, r)
+      double R[9], t[3];
+      for (int c = 0; c < d; c++) {
+        t[c] = X[(size_t)c * ld + i];
+        for (int r = 0; r < d; r++) R[r * d + c] = X[(size_t)r * ld + N + i * d + c];
+      }
+      if (d == 2) fprintf(fp, "VERTEX_SE2 %d %.17g %.17g %.17g\n", i, t[0], t[1], std::atan2(R[2], R[0]));
+      else {
+        double q[4];
+        quat(R, q);
+        fprintf(fp, "VERTEX_SE3:QUAT %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", i, t[0], t[1], t[2], q[0], q[1], q[2], q[3]);
+      }
+    }
+  for (const auto &m : g->g.all) {
+    if (d == 2) {
+      fprintf(fp, "EDGE_SE2 %d %d %.17g %.17g %.17g %.17g 0 0 %.17g 0 %.17g\n", m.ipose, m.jpose, m.t[0], m.t[1],
+              std::atan2(m.R[2], m.R[0]), m.tau, m.tau, m.kappa);
+    } else {
+      double q[4];
+      quat(m.R, q);
+      fprintf(fp, "EDGE_SE3:QUAT %d %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g", m.ipose, m.jpose, m.t[0], m.t[1], m.t[2], q[0], q[1],
+              q[2], q[3]);
+      for (int r = 0; r < 6; r++)
+        for (int c = r; c < 6; c++) fprintf(fp, " %.17g", r == c ? (r < 3 ? m.tau : 2.0 * m.kappa) : 0.0);
+      fprintf(fp, "\n");
+    }
+  }
+  fclose(fp);
+  return 0;
 }
 
 }  // extern "C"

@@ -221,7 +221,13 @@ int chordal_initialization(const Graph &g, double *X, int ld) {
   for (int c = 0; c < d; c++) bt[c] = 0.0;
   dg[0] = 1.0;
   int it2 = pcg(N, d, applyT, dg, bt, xsol, 1e-13, 50000);
-  (void)it1; (void)it2;
+  // the reference solves both least-squares problems directly (SPQR); an iteration that ran into its cap has
+  // not reached the 1e-13 residual target, and the caller must know (disconnected or badly scaled graph)
+  if (it1 >= 50000 || it2 >= 50000) {
+    fprintf(stderr, "[dpgo_amd] ERROR: chordal initialisation: PCG did not converge (rotations %d, translations %d of 50000 "
+                    "iterations); is the graph connected?\n", it1, it2);
+    return -1;
+  }
   for (int i = 0; i < N; i++)
     for (int c = 0; c < d; c++) {
       X[(size_t)c * ld + i] = i == 0 ? 0.0 : xsol[i * d + c];

@@ -133,6 +133,10 @@ int partition(Graph &g, int num_nodes) {
   g.measurements.assign(num_nodes, measurements_t());
   g.g_index.assign(num_nodes, std::map<int, int>());
   for (const auto &mm : g.all) {
+    if (mm.ipose < 0 || mm.ipose >= g.num_poses || mm.jpose < 0 || mm.jpose >= g.num_poses) {
+      fprintf(stderr, "[dpgo_amd] ERROR: pose id out of range in edge (%d, %d): num_poses = %d.\n", mm.ipose, mm.jpose, g.num_poses);
+      return -1;
+    }
     Measurement m = mm;
     index(mm.ipose, m.inode, m.ipose);
     index(mm.jpose, m.jnode, m.jpose);

@@ -9,12 +9,14 @@
 
 namespace dpgo {
 
+// A failed HIP call never aborts the host process (this is a shared library): it is logged and thrown as
+// DeviceError, which every entry point of the C ABI (capi.cpp) turns into the reference's `return -1`.
 #define HIP_CHECK(x)                                                                              \
   do {                                                                                            \
     hipError_t e_ = (x);                                                                          \
     if (e_ != hipSuccess) {                                                                       \
-      fprintf(stderr, "[dpgo_amd] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
-      abort();                                                                                    \
+      fprintf(stderr, "[dpgo_amd] ERROR: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      throw DeviceError(hipGetErrorString(e_));                                                   \
     }                                                                                             \
   } while (0)
 
@@ -271,6 +273,22 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
     fprintf(stderr, "[dpgo_amd] ERROR: d must be 2 or 3.\n");
     return;
   }
+  if (opt.preconditioner != 0 && opt.preconditioner != 3) {
+    fprintf(stderr, "[dpgo_amd] ERROR: preconditioner %d (Jacobi / IncompleteCholesky) is not implemented; use None (0) or "
+                    "RegularizedCholesky (3).\n", opt.preconditioner);
+    return;
+  }
+  if (opt.rescale != 0 && opt.rescale != 1) {
+    fprintf(stderr, "[dpgo_amd] ERROR: rescale must be 0 (Static) or 1 (Dynamic).\n");
+    return;
+  }
+  {
+    std::set<int> uniq(node_ids.begin(), node_ids.end());
+    if (uniq.size() != node_ids.size()) {
+      fprintf(stderr, "[dpgo_amd] ERROR: a node appears twice in the group.\n");
+      return;
+    }
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     fprintf(stderr, "[dpgo_amd] ERROR: no HIP device available; the DPGO hot path has no CPU fallback.\n");
@@ -435,7 +453,7 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
         for (int e = t.ptr[i]; e < t.ptr[i + 1]; e++) { Att.col.push_back(own_off_[a] + t.col[e]); Att.val.push_back(t.val[e]); }
         Att.ptr.push_back((int)Att.col.size());
       }
-      if (opt.preconditioner == 1 && opt.max_iterations > 0 && opt.max_iterations_accepted > 0) {
+      if (opt.preconditioner == 3 && opt.max_iterations > 0 && opt.max_iterations_accepted > 0) {
         const CsrMatrix &r = ops_[a].GRR;
         lambda_max_[a] = lanczos_lambda_max(r);
         const double shift = lambda_max_[a] / opt.reg_Cholesky_precon_max_condition_number;  // DPGOProblem.cpp:119-123
@@ -566,8 +584,8 @@ void Group::fetch(int nslots, bool all_rows) {
     if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
       HIP_CHECK(hipStreamSynchronize(st_));   // surfaces a kernel fault, if that is why the flag never came
       if (__atomic_load_n(h_flag_, __ATOMIC_ACQUIRE) == fetch_seq_) break;
-      fprintf(stderr, "[dpgo_amd] read-back flag never arrived\n");
-      abort();
+      fprintf(stderr, "[dpgo_amd] ERROR: read-back flag never arrived\n");
+      throw DeviceError("read-back flag never arrived");
     }
   }
 }
@@ -695,30 +713,114 @@ int Group::initialize(int a, const double *X, int ld) {
   return 0;
 }
 
+// Rows of a global X ((d+1)N x d, reference layout) that node a works on, as a (d+1)(n0+n1) x d matrix Z in
+// the node's own ordering (dist_pgo.cpp:435-446 + DPGO::communicate)
+void Group::node_rows_of_global(int a, const double *X, int ld, std::vector<double> &Z) const {
+  const int N = num_poses_global_;
+  const int n0 = info_[a].n[0], n1 = info_[a].n[1], rows = (d_ + 1) * (n0 + n1);
+  Z.assign((size_t)rows * d_, 0.0);
+  auto put = [&](int trow, int rrow, int gid) {
+    for (int c = 0; c < d_; c++) {
+      Z[(size_t)c * rows + trow] = X[(size_t)c * ld + gid];
+      for (int r = 0; r < d_; r++) Z[(size_t)c * rows + rrow + r] = X[(size_t)c * ld + N + gid * d_ + r];
+    }
+  };
+  for (int k = 0; k < n0; k++) put(k, n0 + k * d_, g_index_[a].at(info_[a].own_pose[k]));
+  // neighbours: global id from the partition rule (DPGO_utils.cpp:147-158)
+  const int q = N / num_nodes_total_, inc_n = N - num_nodes_total_ * q;
+  for (int k = 0; k < n1; k++) {
+    const int node = info_[a].nbr_key[k].first, pose = info_[a].nbr_key[k].second;
+    const int start = node < inc_n ? node * (q + 1) : inc_n * (q + 1) + (node - inc_n) * q;
+    put((d_ + 1) * n0 + k, (d_ + 1) * n0 + n1 + k * d_, start + pose);
+  }
+}
+
 int Group::initialize_global(const double *X, int ld) {
   const int N = num_poses_global_;
   if (ld < (d_ + 1) * N) return -1;
+  std::vector<double> Z;
   for (int a = 0; a < num_local(); a++) {
-    const int n0 = info_[a].n[0], n1 = info_[a].n[1], rows = (d_ + 1) * (n0 + n1);
-    std::vector<double> Z((size_t)rows * d_, 0.0);
-    auto put = [&](int trow, int rrow, int gid) {
-      for (int c = 0; c < d_; c++) {
-        Z[(size_t)c * rows + trow] = X[(size_t)c * ld + gid];
-        for (int r = 0; r < d_; r++) Z[(size_t)c * rows + rrow + r] = X[(size_t)c * ld + N + gid * d_ + r];
-      }
-    };
-    for (int k = 0; k < n0; k++) put(k, n0 + k * d_, g_index_[a].at(info_[a].own_pose[k]));
-    {
-      // neighbours: global id from the partition rule (DPGO_utils.cpp:147-158)
-      const int q = N / num_nodes_total_, inc_n = N - num_nodes_total_ * q;
-      for (int k = 0; k < n1; k++) {
-        const int node = info_[a].nbr_key[k].first, pose = info_[a].nbr_key[k].second;
-        const int start = node < inc_n ? node * (q + 1) : inc_n * (q + 1) + (node - inc_n) * q;
-        put((d_ + 1) * n0 + k, (d_ + 1) * n0 + n1 + k * d_, start + pose);
-      }
-    }
-    if (initialize(a, Z.data(), rows) != 0) return -1;
+    node_rows_of_global(a, X, ld, Z);
+    if (initialize(a, Z.data(), (d_ + 1) * (info_[a].n[0] + info_[a].n[1])) != 0) return -1;
   }
+  return 0;
+}
+
+// DPGOStar::evaluate_f / evaluate_grad at an arbitrary global X (C++/DPGO/src/DPGOStar.cpp:713-829), without
+// touching the optimizer state.  Every node evaluates its intra edges and its inter edges (objective: charged 1/2
+// per node; gradient: the rows of its own poses, which are DfobjE_top + (G - D) X = g + G X);
+// F and |grad F|^2 are the sums over the nodes of this group, and over all groups when collectives are set.
+// grad (optional): global (d+1)N x d, only the rows of this group's own poses are written.
+int Group::evaluate_global(const double *X, int ld, double *F, double *grad_sqnorm, double *grad, int ldg) {
+  const int N = num_poses_global_;
+  if (ld < (d_ + 1) * N || (grad && ldg < (d_ + 1) * N)) {
+    fprintf(stderr, "[dpgo_amd] ERROR: evaluate: inconsistent size of X.\n");
+    return -1;
+  }
+  sync();
+  {
+    std::vector<double> rec((size_t)(P0_ + P1_) * RS_), Z;
+    for (int a = 0; a < num_local(); a++) {
+      node_rows_of_global(a, X, ld, Z);
+      const int n0 = info_[a].n[0], n1 = info_[a].n[1], rows = (d_ + 1) * (n0 + n1);
+      to_records(d_, n0, Z.data(), rows, 0, n0, rec.data() + (size_t)own_off_[a] * RS_);
+      to_records(d_, n1, Z.data(), rows, (d_ + 1) * n0, (d_ + 1) * n0 + n1, rec.data() + (size_t)(P0_ + nbr_off_[a]) * RS_);
+    }
+    HIP_CHECK(hipMemcpy(Tall_.p, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice));
+  }
+  std::vector<int> all(num_local());
+  for (int a = 0; a < num_local(); a++) all[a] = a;
+  set_mask(all);
+  double *g = tmp_[0].p, *Df = tmp_[1].p, *gr = tmp_[2].p;
+  if (opt_.loss == 0)   // g = S Z
+    launch_bsr(d_, st_, T_, false, cur_mask_, S_.dev, Tall_.p, false, nullptr, g, nullptr, 0, nullptr, nullptr, 0);
+  else                  // g = (B1^T W B1 Z)_own - D X   (weights at X)
+    launch_inter(d_, st_, T_, cur_mask_, E_, opt_.loss, opt_.loss_reg, 1, false, Tall_.p, nullptr, nullptr, Dd_.p, nullptr, g,
+                 partials_.p);
+  launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Tall_.p, false, g, Df, nullptr, 0, nullptr, nullptr, 0);
+  launch_cost(d_, st_, T_, cur_mask_, Ei_, E_, opt_.loss == 0, opt_.loss, opt_.loss_reg, Tall_.p, partials_.p, 0);
+  launch_tangent_full(d_, st_, T_, cur_mask_, Tall_.p, Df, gr, partials_.p, 2);
+  fetch(3, true);
+  double v[2] = {0, 0};
+  for (int a = 0; a < num_local(); a++) {
+    v[0] += 0.5 * scal(a, 0) + 0.25 * scal(a, 1);
+    v[1] += scal(a, 2);
+  }
+  if (coll_allreduce_ && coll_allreduce_(coll_user_, v, 2) != 0) return -1;
+  if (F) *F = v[0];
+  if (grad_sqnorm) *grad_sqnorm = v[1];
+  if (grad) {
+    std::vector<double> own((size_t)P0_ * RS_);
+    HIP_CHECK(hipMemcpy(own.data(), gr, sizeof(double) * own.size(), hipMemcpyDeviceToHost));
+    for (int a = 0; a < num_local(); a++)
+      for (int k = 0; k < info_[a].n[0]; k++) {
+        const int gid = g_index_[a].at(info_[a].own_pose[k]);
+        const double *rec = &own[(size_t)(own_off_[a] + k) * RS_];
+        for (int c = 0; c < d_; c++) {
+          grad[(size_t)c * ldg + gid] = rec[c];
+          for (int r = 0; r < d_; r++) grad[(size_t)c * ldg + N + gid * d_ + r] = rec[d_ + r * d_ + c];
+        }
+      }
+  }
+  return 0;
+}
+
+// DPGOHash::set_options (DPGOHash.h:93-96).  The reference swaps the optimizer's options and keeps the problem it
+// built at construction; here the fields baked into the problem (operators, factorizations) must not change.
+int Group::set_options(const Options &o) {
+  if (o.loss != opt_.loss || o.loss_reg != opt_.loss_reg || o.regularizer != opt_.regularizer || o.rescale != opt_.rescale ||
+      o.preconditioner != opt_.preconditioner ||
+      o.reg_Cholesky_precon_max_condition_number != opt_.reg_Cholesky_precon_max_condition_number) {
+    fprintf(stderr, "[dpgo_amd] ERROR: set_options: loss, loss_reg, regularizer, rescale and the preconditioner are part of "
+                    "the problem built at construction; create a new group to change them.\n");
+    return -1;
+  }
+  if (o.preconditioner == 3 && Lrr_.F.n == 0 && o.max_iterations > 0 && o.max_iterations_accepted > 0) {
+    fprintf(stderr, "[dpgo_amd] ERROR: set_options: the group was created without refinement (max_iterations = 0), so "
+                    "the preconditioner was never factorised.\n");
+    return -1;
+  }
+  opt_ = o;
   return 0;
 }
 
@@ -877,14 +979,18 @@ void Group::host_update_logic(int a, double fobj, double f, double gradFnorm) {
   NodeResults &r = res_[a];
   const Options &o = opt_;
   const int it = r.iters;
-  r.fobj_prev = r.fobj;
+  // update() may run again at the same iteration (update -> receive() -> update): X[iter-1], fobj[iter-1] and
+  // s[iter] are those of the first call, everything else is re-done as the reference does (DPGOHash.cpp:99-225)
+  const bool repeat = (r.hist_iter == it);
+  r.hist_iter = it;
+  if (!repeat) r.fobj_prev = r.fobj;
   r.fobj = fobj;
   r.f = f;
   r.gradFnorm = gradFnorm;
   if (star_) {   // update_n (DPGOStar.cpp:339-385): no restart counters, Gk = Fk = fobj every iteration
     r.Gk = fobj;
     if (o.scheme == 1) {
-      r.s0 = it == 0 ? 1.0 : r.s1;
+      if (!repeat) r.s0 = it == 0 ? 1.0 : r.s1;
       r.s1 = 0.5 + 0.5 * std::sqrt(4.0 * r.s0 * r.s0 + 1.0);
       r.gamma = (r.s0 - 1) / r.s1;
     }
@@ -899,8 +1005,9 @@ void Group::host_update_logic(int a, double fobj, double f, double gradFnorm) {
   if (o.scheme == 1) {
     if (it == 0) {
       r.s0 = 1.0;
-      r.oscillations.assign(1, 1);
-    } else {
+      if (!repeat) r.oscillations.assign(1, 1);
+      else r.oscillations.push_back(1);   // the reference pushes again (DPGOHash.cpp:168-171)
+    } else if (!repeat) {
       r.s0 = r.s1;
     }
     r.s1 = 0.5 + 0.5 * std::sqrt(4.0 * r.s0 * r.s0 + 1.0);
@@ -932,19 +1039,25 @@ int Group::update(const std::vector<int> &locals_in) {
   if (locals.empty()) return 0;
   const bool trivial = (opt_.loss == 0);
   set_mask(locals);
-  // history: X[iter-1] <- X[iter], X[iter] <- Xk ; same for g and Dfobj (masked nodes only)
-  if ((int)locals.size() == num_local()) {
+  // history: X[iter-1] <- X[iter], X[iter] <- Xk ; same for g and Dfobj (masked nodes only).  A node whose
+  // history already stands at this iteration (update() ran, then receive() cleared `updated`) only refreshes
+  // X[iter]: the reference overwrites X[iter] / g[iter] in place and leaves X[iter-1] alone (DPGOHash.cpp:99-106).
+  std::vector<int> adv;
+  for (int a : locals)
+    if (res_[a].hist_iter != res_[a].iters) adv.push_back(a);
+  if ((int)adv.size() == num_local()) {
     // every node advances: rotate the buffers instead of copying them
     Zp_.swap(Zc_);
     gp_.swap(gc_);
     Dfp_.swap(Dfc_);
-    copy_rows(Zc_.p, Xk_.p, true);
-  } else {
+  } else if (!adv.empty()) {
+    set_mask(adv);
     copy_rows(Zp_.p, Zc_.p, true);
-    copy_rows(Zc_.p, Xk_.p, true);
     copy_rows(gp_.p, gc_.p, false);
     copy_rows(Dfp_.p, Dfc_.p, false);
+    set_mask(locals);
   }
+  copy_rows(Zc_.p, Xk_.p, true);
   std::vector<int> first, later;
   for (int a : locals) ((res_[a].iters == 0 || star_) ? first : later).push_back(a);
   if (trivial) {

@@ -14,6 +14,7 @@
 
 #include <cstdint>
 #include <map>
+#include <stdexcept>
 #include <utility>
 #include <string>
 #include <vector>
@@ -24,6 +25,11 @@
 #include "spd.h"
 
 namespace dpgo {
+
+// thrown by the host layer when a HIP call fails; the C ABI catches it and returns -1
+struct DeviceError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
 
 // DPGO::Options (C++/DPGO/include/DPGO/DPGO_types.h:78-201), plain data.
 struct Options {
@@ -38,6 +44,8 @@ struct Options {
   int max_oscillations = 12;
   int loss = 0;  // 0 None, 1 Huber, 2 GemanMcClure, 3 Welsch
   double loss_reg = 1.0;
+  int rescale = 1;            // 0 Static, 1 Dynamic (DPGO_types.h:128)
+  int max_rescale_count = 5;  // DPGO_types.h:131
   double grad_norm_tol = 5e-3;
   double rel_func_decrease_tol = 1e-6;
   double stepsize_tol = 1e-4;
@@ -48,13 +56,14 @@ struct Options {
   int max_tCG_iterations = 10000;
   double STPCG_kappa = 0.05;
   double STPCG_theta = 0.9;
-  int preconditioner = 1;  // 0 None, 1 RegularizedCholesky
+  int preconditioner = 3;  // Preconditioner (DPGO_types.h:35-40): 0 None, 1 Jacobi, 2 IncompleteCholesky, 3 RegularizedCholesky
 };
 
 // The scalar fields of DPGOResult (DPGO_types.h:204-322) the state machine uses.
 struct NodeResults {
   int updated = 1;
   int iters = 0;
+  int hist_iter = -1;   // iteration whose X[iter-1], g[iter-1], fobj[iter-1], s[iter] are in place (update() may run twice per iteration)
   double gradFnorm = 0, fobjE = 0, Fk[2] = {0, 0}, Gk = 0, Gkh = 0;
   double Gk_alt = 0;   // run_tnt: the refined point's surrogate value under the caller's second linear term
   double fobj = 0, fobj_prev = 0, f = 0, gamma = 0, s0 = 1, s1 = 1;
@@ -113,6 +122,9 @@ class Group {
   // X: global (d+1)N x d column-major; fills own and neighbour rows of every local node
   // (dist_pgo.cpp:435-446) and initialises them.
   int initialize_global(const double *X, int ld);
+  // DPGOStar::evaluate_f / evaluate_grad at an arbitrary global X (DPGOStar.cpp:713-829); state untouched
+  int evaluate_global(const double *X, int ld, double *F, double *grad_sqnorm, double *grad, int ldg);
+  int set_options(const Options &o);                     // DPGOHash::set_options (DPGOHash.h:93-96)
   int update(const std::vector<int> &locals);
   int iterate(const std::vector<int> &locals);
   int communicate_local();
@@ -214,6 +226,7 @@ class Group {
   void *coll_user_ = nullptr;
   double starF_ = 0, star_fobj_ = 0, star_fobjh_ = 0;
   int star_branches_ = 0;
+  void node_rows_of_global(int a, const double *X, int ld, std::vector<double> &Z) const;
   void prepare_extrapolated();                             // Y, g_x, Df_x for the masked nodes
   double global_objective(const double *X_own);           // F at the point whose own rows are X_own
   double global_sqdist(const double *A_own, const double *B_own);

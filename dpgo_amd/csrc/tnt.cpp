@@ -44,7 +44,7 @@ struct NodeTnt {
 void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, const double *g_alt, bool base_ready) {
   const Options &o = opt_;
   const int L = num_local();
-  const bool use_precon = (o.preconditioner == 1) && Lrr_.F.n > 0;
+  const bool use_precon = (o.preconditioner == 3) && Lrr_.F.n > 0;   // Preconditioner::RegularizedCholesky
   double *nabla = tmp_[0].p, *grad = tmp_[1].p, *sk = tmp_[2].p, *rk = tmp_[3].p, *vk = tmp_[4].p, *pk = tmp_[5].p,
          *Hp = tmp_[6].p, *xprop = tmp_[7].p, *w1 = tmp_[8].p, *pg = tmp_[10].p, *hh = tmp_[11].p,
          *w3 = tmp_[12].p, *nprop = tmp_[13].p;

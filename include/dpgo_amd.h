@@ -24,7 +24,9 @@
 extern "C" {
 #endif
 
-/* DPGO::Options -- C++/DPGO/include/DPGO/DPGO_types.h:78-201 (same names, same defaults). */
+/* DPGO::Options -- C++/DPGO/include/DPGO/DPGO_types.h:78-201: same names, same defaults, enums as their integer
+ * values.  Not carried: verbose, max_computation_time, user_function, log_iterates (no effect on the iterates).
+ * dpgo_group_create fails (-1) for what is not implemented: preconditioner Jacobi / IncompleteCholesky. */
 typedef struct dpgo_options {
   int scheme;                 /* 0 = Scheme::MM, 1 = Scheme::AMM */
   double regularizer;
@@ -37,6 +39,8 @@ typedef struct dpgo_options {
   int max_oscillations;
   int loss;                   /* 0 None, 1 Huber, 2 GemanMcClure, 3 Welsch */
   double loss_reg;
+  int rescale;                /* Rescale (DPGO_types.h:43-46): 0 Static, 1 Dynamic (the reference default, :128) */
+  int max_rescale_count;      /* DPGO_types.h:131 */
   double grad_norm_tol;
   double rel_func_decrease_tol;
   double stepsize_tol;
@@ -47,7 +51,8 @@ typedef struct dpgo_options {
   int max_tCG_iterations;
   double STPCG_kappa;
   double STPCG_theta;
-  int preconditioner;         /* 0 None, 1 RegularizedCholesky */
+  int preconditioner;         /* Preconditioner (DPGO_types.h:35-40): 0 None, 1 Jacobi, 2 IncompleteCholesky,
+                                 3 RegularizedCholesky (default) */
 } dpgo_options_t;
 
 /* The scalar part of DPGOResult -- C++/DPGO/include/DPGO/DPGO_types.h:204-322. */
@@ -100,6 +105,14 @@ int dpgo_graph_node_offset(const dpgo_graph_t *g, int node);
  * key arrays may be NULL to query the counts.  (sent_ / recv_ of C++/DPGO/src/DPGO_utils.cpp:428-435.) */
 int dpgo_graph_exchange_plan(const dpgo_graph_t *g, const int *node_ids, int num_local, int *sent_nodes,
                              int *sent_poses, int *recv_nodes, int *recv_poses, int *counts);
+/* DPGOProblem::index() / sent() / recv() -- C++/DPGO/include/DPGO/DPGOProblem.h:212-225 (host only): the entries
+ * {(node, pose) -> (block, k)} of the map `which` (0 index, 1 sent, 2 recv), in map order.  Arrays may be NULL
+ * to query *count. */
+int dpgo_graph_node_maps(const dpgo_graph_t *g, int node, int which, int *nodes, int *poses, int *block, int *local,
+                         int *count);
+/* Result format: VERTEX_SE2 / VERTEX_SE3:QUAT lines from X ((d+1)N x d; NULL: edges only) followed
+ * by the graph's EDGE_* lines with the isotropic information the loader's formulas invert. */
+int dpgo_write_g2o(const dpgo_graph_t *g, const double *X, int ld, const char *filename);
 /* Centralised chordal initialisation -- C++/examples/dist_pgo.cpp:416-444
  * (C++/SESync/src/SESync_utils.cpp:573-652).  Host, set-up only.  X: (d+1)N x d. */
 int dpgo_chordal_initialization(const dpgo_graph_t *g, double *X, int ld);
@@ -155,6 +168,18 @@ int dpgo_group_set_recv_layout(dpgo_group_t *grp, int nranks, int stride, const 
                                const int *poses);
 int dpgo_group_pack_sent(dpgo_group_t *grp, void *device_buffer);
 int dpgo_group_unpack_recv(dpgo_group_t *grp, const void *device_gathered);
+
+/* DPGOStar::evaluate_f / evaluate_grad -- C++/DPGO/src/DPGOStar.cpp:713-829 -- at an ARBITRARY global X
+ * ((d+1)N x d); the optimizer state is not touched.  *F and *grad_sqnorm (= |grad F|^2, Riemannian) are sums over
+ * the nodes of this group -- over all groups when collectives are set (dpgo_group_set_collectives / dpgo_comm_attach);
+ * the driver prints 2 F and 2 sqrt(grad_sqnorm) (dist_pgo.cpp:477-481).  grad (optional, (d+1)N x d, leading
+ * dimension ldg): the rows of this group's own poses are written.  Any output pointer may be NULL. */
+int dpgo_group_evaluate(dpgo_group_t *grp, const double *X, int ld, double *F, double *grad_sqnorm, double *grad,
+                        int ldg);
+/* DPGOHash::set_options / options -- C++/DPGO/include/DPGO/DPGOHash.h:91-96.  Fields that are part of the problem
+ * built at construction (loss, loss_reg, regularizer, rescale, preconditioner) must keep their values (-1). */
+int dpgo_group_set_options(dpgo_group_t *grp, const dpgo_options_t *opt);
+int dpgo_group_get_options(const dpgo_group_t *grp, dpgo_options_t *opt);
 
 /* results().Xk / results().Xak -- DPGO_types.h:207-214 */
 int dpgo_group_get_Xk(const dpgo_group_t *grp, int local, double *X, int ld);

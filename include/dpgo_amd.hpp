@@ -50,7 +50,13 @@ class Matrix {
 
 enum class Scheme { MM = 0, AMM = 1 };                                       // DPGO_types.h:52
 enum class Loss { None = 0, Huber = 1, GemanMcClure = 2, Welsch = 3 };       // DPGO_types.h:54
-enum class Preconditioner { None = 0, RegularizedCholesky = 1 };             // DPGO_types.h:41
+enum class Preconditioner { None = 0, Jacobi = 1, IncompleteCholesky = 2, RegularizedCholesky = 3 };   // DPGO_types.h:35-40
+enum class Rescale { Static = 0, Dynamic = 1 };                              // DPGO_types.h:43-46
+
+// entry of DPGOProblem::index() / sent() / recv() (DPGOProblem.h:212-225): (node, pose) -> {block, k}
+struct IndexEntry {
+  int node, pose, block, k;
+};
 
 // DPGO::Options (DPGO_types.h:78-201): the C struct with the reference's field names
 struct Options : dpgo_options_t {
@@ -81,6 +87,14 @@ class Graph {
   // DPGOProblem::n() / m() (DPGOProblem.h:241-248): {own, neighbour} poses, {intra, inter} edges
   void sizes(int node, int n[2], int m[2]) const { dpgo_graph_node_sizes(h_, node, &n[0], &n[1], &m[0], &m[1]); }
   int offset(int node) const { return dpgo_graph_node_offset(h_, node); }   // first global pose id of the node
+  // DPGOProblem::index() / sent() / recv() of a node (DPGOProblem.h:212-225), entries in map order
+  std::vector<IndexEntry> index(int node) const { return maps(node, 0); }
+  std::vector<IndexEntry> sent(int node) const { return maps(node, 1); }
+  std::vector<IndexEntry> recv(int node) const { return maps(node, 2); }
+  // g2o export: VERTEX_* lines from X ((d+1) N x d) + the EDGE_* lines
+  int write_g2o(const std::string &filename, const Matrix &X) const {
+    return dpgo_write_g2o(h_, X.data(), X.rows(), filename.c_str());
+  }
   // centralised chordal initialisation (dist_pgo.cpp:416-444): X is (d+1) N x d
   Matrix chordal_initialization() const {
     Matrix X((d_ + 1) * num_poses_, d_);
@@ -91,6 +105,15 @@ class Graph {
 
  private:
   explicit Graph(dpgo_graph_t *h) : h_(h) { dpgo_graph_info(h_, &d_, &num_poses_, &num_nodes_, &num_edges_); }
+  std::vector<IndexEntry> maps(int node, int which) const {
+    int cnt = 0;
+    if (dpgo_graph_node_maps(h_, node, which, nullptr, nullptr, nullptr, nullptr, &cnt) != 0) return {};
+    std::vector<int> a(cnt), b(cnt), c(cnt), d(cnt);
+    dpgo_graph_node_maps(h_, node, which, a.data(), b.data(), c.data(), d.data(), &cnt);
+    std::vector<IndexEntry> out(cnt);
+    for (int i = 0; i < cnt; i++) out[i] = {a[i], b[i], c[i], d[i]};
+    return out;
+  }
   dpgo_graph_t *h_;
   int d_ = 0, num_poses_ = 0, num_nodes_ = 0, num_edges_ = 0;
 };
@@ -146,6 +169,18 @@ class DPGOHashGroup {
   // gather X^alpha into the global X (dist_pgo.cpp:502-511)
   int gather(Matrix &X) const { return dpgo_group_scatter_global(h_, X.data(), X.rows()); }
   const Options &options() const { return options_; }
+  // DPGOHash::set_options (DPGOHash.h:93-96) for every node of the group
+  int set_options(const Options &o) {
+    if (dpgo_group_set_options(h_, &o) != 0) return -1;
+    options_ = o;
+    return 0;
+  }
+  // DPGOStar::evaluate_f / evaluate_grad at an arbitrary global X (DPGOStar.cpp:713-829), summed over this group
+  int evaluate_f(const Matrix &X, Scalar &fobj) const { return dpgo_group_evaluate(h_, X.data(), X.rows(), &fobj, nullptr, nullptr, 0); }
+  int evaluate_grad(const Matrix &X, Matrix &grad) const {
+    grad.resize(X.rows(), X.cols());
+    return dpgo_group_evaluate(h_, X.data(), X.rows(), nullptr, nullptr, grad.data(), grad.rows());
+  }
   const Graph &graph() const { return *graph_; }
   dpgo_group_t *handle() const { return h_; }
 
@@ -206,6 +241,12 @@ class DPGOStar {
   int state(double &F, double &fobj, double &fobjh, int &branches) const {
     return dpgo_group_star_state(group_->handle(), &F, &fobj, &fobjh, &branches);
   }
+  // DPGOStar::evaluate_f / evaluate_grad (DPGOStar.h:49-51, DPGOStar.cpp:713-829): any X of size (d+1) N x d
+  int evaluate_f(const Matrix &X, Scalar &fobj) const { return group_->evaluate_f(X, fobj); }
+  int evaluate_grad(const Matrix &X, Matrix &grad) const { return group_->evaluate_grad(X, grad); }
+  const Options &options() const { return group_->options(); }
+  int set_options(const Options &o) { return group_->set_options(o); }
+  int num_nodes() const { return graph_->num_nodes(); }
   const DPGOHashGroup &nodes() const { return *group_; }
   const Graph &graph() const { return *graph_; }
 

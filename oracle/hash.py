@@ -50,7 +50,7 @@ class Options:
         self.stepsize_tol = 1e-4
         self.max_iterations = 10
         self.max_iterations_accepted = 1
-        self.preconditioner = 1                                   # Preconditioner::RegularizedCholesky (DPGO_types.h:155)
+        self.preconditioner = 3                                   # Preconditioner::RegularizedCholesky (DPGO_types.h:155)
         self.reg_Cholesky_precon_max_condition_number = 1e6
         self.preconditioned_grad_norm_tol = 1e-4
         self.max_tCG_iterations = 10000
@@ -103,7 +103,7 @@ class DPGOHash:
         self.problem = DPGOProblem(
             node, measurements, options.regularizer, options.loss,
             options.reg_Cholesky_precon_max_condition_number, options.loss_reg,
-            preconditioner=bool(getattr(options, "preconditioner", 1)))   # DPGOHash.cpp:16
+            preconditioner=(getattr(options, "preconditioner", 3) == 3))   # DPGOHash.cpp:16
         self.results = Results()
 
     # DPGOHash.cpp:20-43
@@ -134,15 +134,38 @@ class DPGOHash:
                 Xk[r0:r0 + d] = src[nb0 + j * d: nb0 + j * d + d]
         return 0
 
+    # DPGOHash.cpp:45-82
+    def receive(self, msg):
+        """msg: {beta: ((d+1) |recv[beta]|) x d matrix [t rows ; R rows]}; clears `updated`."""
+        p, r = self.problem, self.results
+        d, n, s = p.d, p.n, p.s
+        for b, M in msg.items():
+            if b not in p.info.recv:
+                return -1
+            r.updated = False
+            poses = p.info.recv[b]
+            k = len(poses)
+            assert M.shape == ((d + 1) * k, d)
+            i = next(iter(poses.values()))[1]
+            r.Xk[s[1] * (d + 1) + i: s[1] * (d + 1) + i + k] = M[:k]
+            r0 = s[1] * (d + 1) + n[1] + i * d
+            r.Xk[r0:r0 + k * d] = M[k:]
+        return 0
+
     # DPGOHash.cpp:84-228
     def update(self):
         r, p, o = self.results, self.problem, self.options
         if r.updated:
             return 0
         it = r.iters
-        # shift history: index 0 = current iteration, 1 = previous
-        r.X = [r.Xk.copy(), r.X[0]]
-        prev_fobj = r.fobj[0]
+        # history: index 0 = current iteration, 1 = previous.  The reference writes X[iter], g[iter], ... in place
+        # (DPGOHash.cpp:99-106), so a second update() at the same iteration (after receive()) keeps X[iter-1],
+        # g[iter-1], fobj[iter-1] and s[iter]; the counters below are simply run again, as in the reference.
+        repeat = getattr(r, "hist_iter", -1) == it
+        r.hist_iter = it
+        h = 1 if repeat else 0
+        r.X = [r.Xk.copy(), r.X[h]]
+        prev_fobj = r.fobj[h]
         if p.trivial:
             if it == 0:
                 g, f = p.evaluate_none_g_and_f0(r.X[0])
@@ -156,7 +179,7 @@ class DPGOHash:
             else:
                 g, f, Dfobj, fobj, r.DfobjE, r.fobjE = p.evaluate_g_and_f(
                     r.X[0], r.X[1], r.Gk, r.DfobjE, r.fobjE)
-        r.g = [g, r.g[0]]
+        r.g = [g, r.g[h]]
         r.f = f
         r.fobj = [fobj, prev_fobj]
         if it == 0:
@@ -166,13 +189,13 @@ class DPGOHash:
             Dfobj, gradF = p.full_Riemannian_gradient_G(r.Xak, g)
         else:
             gradF = p.full_tangent_space_projection(r.Xak, Dfobj)
-        r.Dfobj = [Dfobj, r.Dfobj[0]]
+        r.Dfobj = [Dfobj, r.Dfobj[h]]
         r.gradFnorm = float(np.linalg.norm(gradF))
         if o.scheme == SCHEME_AMM:
             if it == 0:
                 r.s = [1.0, 1.0]
-                r.oscillations = [1]
-            else:
+                r.oscillations = [1] if not repeat else r.oscillations + [1]   # push_back (DPGOHash.cpp:168-171)
+            elif not repeat:
                 r.s = [r.s[1], 0.0]
             s0 = r.s[0]
             s1 = 0.5 + 0.5 * math.sqrt(4.0 * s0 * s0 + 1.0)

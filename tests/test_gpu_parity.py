@@ -456,3 +456,140 @@ def test_tnt_option_variants_match_oracle(fixtures_dir, loss, kw):
             np.testing.assert_allclose(rg.fobj, ro.fobj[0], rtol=1e-7, err_msg="fobj it=%d node=%d %r" % (it, a, kw))
             np.testing.assert_allclose(rg.Gk, ro.Gk, rtol=1e-7, err_msg="Gk it=%d node=%d %r" % (it, a, kw))
     np.testing.assert_allclose(gpu.X(), orc.gather(), atol=1e-6)
+
+
+def _random_global_X(rng, N, d, scale=3.0):
+    X = np.zeros(((d + 1) * N, d))
+    X[:N] = scale * rng.standard_normal((N, d))
+    q, _ = np.linalg.qr(rng.standard_normal((N, d, d)))
+    q[:, :, 0] *= np.sign(np.linalg.det(q))[:, None]
+    X[N:] = q.transpose(0, 2, 1).reshape(N * d, d)
+    return X
+
+
+@pytest.mark.parametrize("name,nn", [("smallGrid3D", 2), ("M3500", 4), ("torus3D", 3)])
+@pytest.mark.parametrize("loss", [LOSS_NONE, LOSS_HUBER, LOSS_GM, LOSS_WELSCH])
+def test_evaluate_f_and_grad_at_arbitrary_X(fixtures_dir, name, nn, loss):
+    """dpgo_group_evaluate == DPGOStar::evaluate_f / evaluate_grad (DPGOStar.cpp:713-829) at RANDOM points (not
+    linearisation points), through the C ABI; the optimizer state is not touched.  1e-11 relative."""
+    path = os.path.join(fixtures_dir, name + ".g2o")
+    num_poses, mm = og.read_g2o_file(path)
+    from oracle.star import GlobalProblem
+    star = GlobalProblem(num_poses, mm, nn, _oracle_opts(loss, True))
+    G = dpgo_amd.read_g2o(path, nn)
+    X0 = chordal_initialization(num_poses, mm)
+    gpu = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(loss, True), X0=X0)
+    ref = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(loss, True), X0=X0)
+    rng = np.random.default_rng(7)
+    for X in (_random_global_X(rng, num_poses, G.d), X0, _random_global_X(rng, num_poses, G.d, 0.1)):
+        F, g2, grad = gpu.group.evaluate(X, want_grad=True)
+        Fo, go = star.evaluate_f(X), star.evaluate_grad(X)
+        assert abs(F - Fo) <= 1e-11 * abs(Fo)
+        np.testing.assert_allclose(grad, go, rtol=0, atol=1e-11 * np.abs(go).max())
+        assert abs(g2 - np.sum(go * go)) <= 1e-11 * np.sum(go * go)
+        assert gpu.step() == 0 and ref.step() == 0                     # evaluating leaves the trajectory alone
+        assert np.array_equal(gpu.X(), ref.X())
+
+
+def test_set_options_and_accessors(fixtures_dir):
+    """DPGOHash::set_options (DPGOHash.h:93-96): optimizer-level fields change the run exactly as a group created
+    with them; problem-level fields are refused."""
+    path = os.path.join(fixtures_dir, "smallGrid3D.g2o")
+    G = dpgo_amd.read_g2o(path, 2)
+    X0 = G.chordal_initialization()
+    a = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(LOSS_HUBER, True), X0=X0)
+    b = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(LOSS_HUBER, True, max_iterations_accepted=3, max_iterations=12), X0=X0)
+    o = dpgo_amd.Options.driver(LOSS_HUBER, True, max_iterations_accepted=3, max_iterations=12)
+    assert a.group.set_options(o) == 0
+    got = a.group.get_options()
+    assert (got.max_iterations_accepted, got.max_iterations, got.rescale) == (3, 12, dpgo_amd.RESCALE_STATIC)
+    for _ in range(6):
+        assert a.step() == 0 and b.step() == 0
+    assert np.array_equal(a.X(), b.X())
+    assert a.group.set_options(dpgo_amd.Options.driver(LOSS_NONE, True)) == -1      # the loss is part of the problem
+    assert a.group.set_options(dpgo_amd.Options.driver(LOSS_HUBER, True, regularizer=1e-3)) == -1
+    assert a.group.update([0, 0]) == -1 and a.group.iterate([5]) == -1             # ADVICE r1: locals are validated
+    with pytest.raises(RuntimeError):
+        dpgo_amd.NodeGroup(G, [0, 1], dpgo_amd.Options.driver(LOSS_HUBER, True, preconditioner=dpgo_amd.PRECON_JACOBI))
+
+
+@pytest.mark.parametrize("loss", [LOSS_NONE, LOSS_HUBER])
+def test_update_twice_in_one_iteration_keeps_history(fixtures_dir, loss):
+    """update -> receive() (clears `updated`) -> update at the same iteration: X[iter-1], g[iter-1], fobj[iter-1],
+    s[iter] stay those of the first call (the reference overwrites X[iter] in place, DPGOHash.cpp:99-106), the
+    restart counters run again.  Oracle = the same call sequence on the restatement."""
+    path = os.path.join(fixtures_dir, "smallGrid3D.g2o")
+    orc, gpu = _pair(fixtures_dir, "smallGrid3D", 2, loss, True)
+    for it in range(8):
+        for nd in orc.nodes:
+            nd.iterate()
+        for nd in orc.nodes:
+            nd.communicate(orc.nodes)
+        for nd in orc.nodes:
+            nd.update()
+        assert gpu.group.iterate() == 0 and gpu.group.communicate_local() == 0 and gpu.group.update() == 0
+        if it in (0, 3, 4):
+            # every node re-receives what its neighbour owes it (same numbers), then updates again
+            for k in range(2):
+                other = 1 - k
+                n_o = orc.nodes[other]
+                sent = n_o.problem.info.sent[k]
+                rows = [v[1] for v in sent.values()]
+                n0o, d = n_o.problem.n[0], n_o.problem.d
+                M = np.vstack([n_o.results.Xk[rows]] + [n_o.results.Xk[n0o + r * d: n0o + r * d + d] for r in rows])
+                assert orc.nodes[k].receive({other: M}) == 0
+                assert gpu.group[k].receive({other: gpu.group[other].message_for(k)}) == 0
+            for nd in orc.nodes:
+                nd.update()
+            assert gpu.group.update() == 0
+        for a in range(2):
+            ro, rg = orc.nodes[a].results, gpu.group.results(a)
+            np.testing.assert_allclose(rg.fobj, ro.fobj[0], rtol=1e-7, err_msg="it=%d" % it)
+            np.testing.assert_allclose(rg.gamma, ro.gamma, rtol=1e-12)
+            np.testing.assert_allclose([rg.Fk[0], rg.Fk[1]], ro.Fk, rtol=1e-7)
+            assert list(rg.soft_restart_hits) == list(ro.soft_restart_hits)
+    np.testing.assert_allclose(gpu.X(), orc.gather(), atol=1e-6)
+
+
+def test_headline_size_properties():
+    """The full 100 000-pose / 400 000-edge headline graph (BASELINE config 4), a few iterations: properties that do
+    not need the oracle: sum_a fobj^a = F(X) from the independent k_cost pass at 1e-8, rotations
+    in SO(3), the translation system G_tt t + G_tR R + g_t = 0 solved to 1e-9 of its scale, objective decreasing over
+    the window, and two runs bit-identical."""
+    from dpgo_amd import synthetic
+    g = synthetic.grid(50, 50, 40, 400000, seed=synthetic.HEADLINE["seed"])
+    N = g["num_poses"]
+    G = dpgo_amd.graph_from_edges(3, N, g["I"], g["J"], g["R"], g["t"], g["kappa"], g["tau"], 8)
+    X0 = G.chordal_initialization()
+    opt = dpgo_amd.Options.driver(LOSS_HUBER, True)
+    grp = dpgo_amd.NodeGroup(G, range(8), opt)
+    outs = []
+    for run in range(2):
+        assert grp.initialize_global(X0) == 0 and grp.update() == 0
+        F0 = sum(grp.results(k).fobj for k in range(8))
+        for it in range(4):
+            assert grp.iterate() == 0 and grp.communicate_local() == 0 and grp.update() == 0
+        X = np.zeros((4 * N, 3), order="F")
+        grp.scatter_global(X)
+        outs.append(X.copy())
+        if run:
+            break
+        Fsum = sum(grp.results(k).fobj for k in range(8))
+        F, g2 = grp.evaluate(X)
+        assert abs(Fsum - F) <= 1e-8 * F, (Fsum, F)
+        assert abs(sum(grp.results(k).gradFnorm ** 2 for k in range(8)) - g2) <= 1e-8 * g2
+        assert F < F0
+        R = X[N:].reshape(N, 3, 3)
+        np.testing.assert_allclose(np.einsum("nij,nkj->nik", R, R), np.broadcast_to(np.eye(3), R.shape), atol=1e-12)
+        np.testing.assert_allclose(np.linalg.det(R), 1.0, atol=1e-12)
+        # exactness of the multifrontal solve at this size: residual of G_tt t = b against the device operator
+        n0 = G.node_sizes(3)[0]
+        rng = np.random.default_rng(3)
+        B = np.zeros((4 * n0, 3))
+        B[:n0] = rng.standard_normal((n0, 3))
+        T = grp.debug_apply(3, "solve_tt", B, 4 * n0)
+        Z = np.zeros((4 * n0, 3))
+        Z[:n0] = T[:n0]
+        GT = grp.debug_apply(3, "G", Z, 4 * n0)
+        assert np.abs(GT[:n0] - B[:n0]).max() <= 1e-9 * np.abs(B[:n0]).max()
+    assert np.array_equal(outs[0], outs[1])
