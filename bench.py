@@ -258,7 +258,7 @@ def main():
             step()
             grp.sync()
             trace.append((time.perf_counter() - t0, 2.0 * sum(grp.results(k).fobj for k in range(len(grp))),
-                          sum(int(grp.results(k).tnt_inner_iterations) for k in range(len(grp))) / len(grp),
+                          sum(int(grp.results(k).tnt_inner_iterations) for k in range(len(grp)) if grp.results(k).refined) / len(grp),
                           sum(int(grp.results(k).refined) for k in range(len(grp)))))
         best = min(f for _, f, _, _ in trace)
         hit = next(i for i, (_, f, _, _) in enumerate(trace) if f <= best * (1 + 1e-6))

@@ -49,6 +49,8 @@ template struct DevBuf<double>;
 template struct DevBuf<int64_t>;
 template struct DevBuf<int4>;
 template struct DevBuf<Seg>;
+template struct DevBuf<CgNode>;
+template struct DevBuf<NodeBits>;
 
 // tuning hooks (tools/env_ab.sh): an integer from the environment, or the default
 static int env_int(const char *name, int dflt) {
@@ -355,6 +357,8 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   *h_flag_ = 0;
   reduce_arrived_.alloc(1);
   partials_.alloc((size_t)MAX_SLOTS * std::max(T_.nseg_all, 1));
+  cg_.alloc(MAX_LOCAL_NODES);
+  dmask_.alloc(2);
 
   // ---- operators
   {
@@ -568,22 +572,27 @@ void Group::sync() const { HIP_CHECK(hipStreamSynchronize(st_)); }
 
 // The nodes the following launches work on: a bit mask passed to every kernel by value (no upload).
 void Group::set_mask(const std::vector<int> &locals) {
-  NodeMask m = 0;
+  NodeBits m = 0;
   for (int a : locals) m |= 1ull << a;
-  cur_mask_ = m;
+  cur_mask_ = NodeMask{m, nullptr};
 }
 
 void Group::fetch(int nslots, bool all_rows) {
   nslots = std::max(nslots, deferred_slots_);
   deferred_slots_ = 0;
   launch_reduce(st_, T_, num_local(), all_rows, nslots, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, ++fetch_seq_);
-  // the flag is written by the last kernel of the (in-order) stream: seeing it means everything before is done
+  wait_flag(fetch_seq_);
+}
+
+// Poll the pinned flag until the kernel that raises it to `seq` (or a later one of the in-order stream) has run:
+// seeing it means everything enqueued before that kernel is done.
+void Group::wait_flag(unsigned long long seq) {
   const auto t0 = std::chrono::steady_clock::now();
-  for (unsigned spins = 0; __atomic_load_n(h_flag_, __ATOMIC_ACQUIRE) != fetch_seq_; spins++) {
+  for (unsigned spins = 0; __atomic_load_n(h_flag_, __ATOMIC_ACQUIRE) < seq; spins++) {
     __builtin_ia32_pause();
     if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
       HIP_CHECK(hipStreamSynchronize(st_));   // surfaces a kernel fault, if that is why the flag never came
-      if (__atomic_load_n(h_flag_, __ATOMIC_ACQUIRE) == fetch_seq_) break;
+      if (__atomic_load_n(h_flag_, __ATOMIC_ACQUIRE) >= seq) break;
       fprintf(stderr, "[dpgo_amd] ERROR: read-back flag never arrived\n");
       throw DeviceError("read-back flag never arrived");
     }
@@ -660,8 +669,8 @@ void Group::recover_translations(double *X, const double *g) {
 
 // y = base + G_{:,t} xt.t, with the row-local epilogues of launch_bsr_tcol
 void Group::apply_tcol(const double *xt, const double *base, double *y, int mode, const double *X, const double *nabla,
-                       const double *Rdot, double *out2) {
-  launch_bsr_tcol(d_, st_, T_, cur_mask_, G_.dev, G_.tcol.p, xt, base, y, mode, X, nabla, Rdot, out2);
+                       const double *Rdot, double *out2, const double *rres, double *partials) {
+  launch_bsr_tcol(d_, st_, T_, cur_mask_, G_.dev, G_.tcol.p, xt, base, y, mode, X, nabla, Rdot, out2, rres, partials);
 }
 
 // partial[slot] = tr(X^T (g + 1/2 G X))     (DPGOProblem.cpp:180-205; + f on the host)

@@ -199,6 +199,8 @@ class Group {
   unsigned long long *h_flag_ = nullptr, fetch_seq_ = 0;
   DevBuf<unsigned> reduce_arrived_;
   DevBuf<double> partials_;
+  DevBuf<CgNode> cg_;       // device-resident state of the truncated CG (tnt.cpp, k_cg_scal)
+  DevBuf<NodeBits> dmask_;  // [0] nodes taking the next Hessian product, [1] nodes going on to the preconditioner
   struct BsrBufs { DevBuf<int> ptr, col; DevBuf<double> val, tcol; BsrDev dev; };   // tcol: first column of every block (G only)
   BsrBufs G_, S_, P_, P0m_, Q_;
   DevBuf<double> Dd_, Qd_, Tinv_, N_, V_;
@@ -234,6 +236,7 @@ class Group {
   void upload_bsr(const std::vector<const BsrMatrix *> &per_node, bool rows_all, BsrBufs &out);
   void set_mask(const std::vector<int> &locals);
   void fetch(int nslots, bool all_rows);                  // -> h_scal_[local * MAX_SLOTS + s]
+  void wait_flag(unsigned long long seq);
   int deferred_slots_ = 0;   // slots written earlier that ride along with the next fetch (saves a host round trip)
   double scal(int local, int s) const { return h_scal_[local * MAX_SLOTS + s]; }
   void copy_rows(double *dst, const double *src, bool all_rows, int part = 0);
@@ -241,7 +244,8 @@ class Group {
   void solve_tt(double *in, double *out, double scale);   // out.t <- scale * G_tt^-1 in.t
   void solve_rr(double *in, double *out, double scale);   // out.R <- scale * (G_RR + lambda I)^-1 in.R
   void apply_tcol(const double *xt, const double *base, double *y, int mode = 0, const double *X = nullptr,
-                  const double *nabla = nullptr, const double *Rdot = nullptr, double *out2 = nullptr);               // in place on translation rows
+                  const double *nabla = nullptr, const double *Rdot = nullptr, double *out2 = nullptr,
+                  const double *rres = nullptr, double *partials = nullptr);
   void solve_rr(double *vec, double scale);               // in place on rotation rows
   void recover_translations(double *X, const double *g);  // X.t = -Gtt^-1 (g_t + G_tR X.R) for masked nodes
   void eval_G(const double *X, const double *g, int slot);

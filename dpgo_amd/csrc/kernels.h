@@ -34,11 +34,30 @@ struct Seg {
 // Two coefficients per local node, passed BY VALUE as a kernel argument (no upload, no memory latency): the step
 // lengths of the batched CG.  A group hosts at most MAX_LOCAL_NODES nodes.
 constexpr int MAX_LOCAL_NODES = 64;
-// which of the group's nodes a launch works on: bit a = local node a, passed by value like the coefficients
-typedef unsigned long long NodeMask;
-constexpr NodeMask ALL_NODES = ~0ull;
+// which of the group's nodes a launch works on: bit a = local node a.  `v` travels by value like the coefficients;
+// `p` (optional) points at a device-resident mask that the kernel ands in -- the truncated CG keeps its set of
+// still-iterating nodes on the device (k_cg_scal), so the host need not read it back before the next launch
+typedef unsigned long long NodeBits;
+struct NodeMask {
+  NodeBits v;
+  const NodeBits *p;
+};
+constexpr NodeMask ALL_NODES = {~0ull, nullptr};
 struct NodeCoefs {
   double a[MAX_LOCAL_NODES], b[MAX_LOCAL_NODES];
+};
+
+// Per-node state of the Steihaug-Toint CG (IterativeSolvers.h:207-390), device resident: the scalar recurrences
+// run in k_cg_scal, the vector kernels read their step lengths from here.
+struct alignas(16) CgNode {
+  double sk_M_pk, sk_M_2, pk_M_2, rv, Delta, Delta_2, target, h_M_norm;
+  double c1, cr;        // s += c1 p, H s += c1 H p, r += cr H p   (cr = 0: the node stops after this step)
+  double al, kap, be;   // alpha_k, kappa_k (kept for beta), beta_k
+  int cg_it, max_it, live, pad;
+};
+// start values of a CG run, by value (the host knows them from the read-back of the gradient norms)
+struct CgStart {
+  double rv[MAX_LOCAL_NODES], Delta[MAX_LOCAL_NODES], target[MAX_LOCAL_NODES];
 };
 
 struct BsrDev {
@@ -76,9 +95,12 @@ void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMas
 // y = base + A[:, translation column] t over own rows; tval: the first column of every block of A ((d+1) doubles per
 // block), xt: records whose translation row is t.  A quarter of the traffic of launch_bsr.
 // mode 1: also out2 = [0 ; Proj_X(y.R)]; mode 2: y not stored, out2 = [0 ; Proj_X(y.R - sym(nabla.R X.R^T) Rdot.R)], the Hessian-vector product (DPGOProblem.cpp:570-574)
+// mode 2 with partials: slots 0..3 = <Rdot, out2>, <out2, out2>, <Rdot, Rdot>, <Rdot, rres> (the four scalars of a
+// CG step, IterativeSolvers.h:296-347) in the same pass
 void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, const BsrDev &A, const double *tval,
                      const double *xt, const double *base, double *y, int mode = 0, const double *X = nullptr,
-                     const double *nabla = nullptr, const double *Rdot = nullptr, double *out2 = nullptr);
+                     const double *nabla = nullptr, const double *Rdot = nullptr, double *out2 = nullptr,
+                     const double *rres = nullptr, double *partials = nullptr);
 
 // Robust inter-edge pass (B-form, DPGOProblem.cpp:634-725).
 //  mode 0 (update): all rows.  DfE <- B1^T W B1 Z; own rows also g <- DfE - D z.
@@ -111,13 +133,15 @@ void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeM
 // out = C.a[node] * a + C.b[node] * b over own rows
 void launch_axpby_node(int d, hipStream_t st, const SegTable &T, NodeMask mask, const NodeCoefs &C, const double *a,
                        const double *b, double *out);
+// p = -v + cg[node].be * p (the CG direction update with the device-resident beta)
+void launch_cg_dir(int d, hipStream_t st, const SegTable &T, NodeMask mask, const CgNode *cg, const double *v, double *p);
 // n <= MAX_DOTS dot products in one pass over own rows: partial[slot0 + q] = sum <a_q, b_q> over parts[q]
 // (0 whole record, 1 translation row, 2 rotation rows); always writes MAX_DOTS slots
 void launch_dots(int d, hipStream_t st, const SegTable &T, NodeMask mask, int n, const double *const *a,
                  const double *const *b, const int *parts, double *partials, int slot0);
 // one CG step (IterativeSolvers.h:340-390): s += C.a[node] p, hs += C.a[node] Hp, and r += C.b[node] Hp where C.b != 0
 void launch_cg_step(int d, hipStream_t st, const SegTable &T, NodeMask mask, const NodeCoefs &C, const double *p,
-                    const double *Hp, double *s, double *hs, double *r);
+                    const double *Hp, double *s, double *hs, double *r, const CgNode *cg = nullptr);   // cg: coefficients from the device state
 // start of a truncated CG (IterativeSolvers.h:230-260): s = 0, hs = 0, r = grad, v = pgrad, p = -pgrad
 void launch_cg_init(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *grad, const double *pgrad,
                     double *s, double *hs, double *r, double *v, double *p);
@@ -125,8 +149,10 @@ void launch_cg_init(int d, hipStream_t st, const SegTable &T, NodeMask mask, con
 void launch_tangent_full(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
                          const double *V, double *out, double *partials, int slot);
 // out.Y = Proj_R(in.Y), out.x = 0                                       (DPGOProblem.cpp:164-178)
+// with dotv: partial[slot] = <dotv.Y, out.Y> in the same pass
 void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
-                        const double *in, double *out);
+                        const double *in, double *out, const double *dotv = nullptr, double *partials = nullptr,
+                        int slot = 0);
 // out.Y = proj_SO(d)(X.Y + V.Y); out.x = 0                              (SOdProduct.h:111-116)
 void launch_retract_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
                         const double *V, double *out);
@@ -141,6 +167,20 @@ void launch_bdiag_dot(int d, hipStream_t st, const SegTable &T, NodeMask mask, c
 // memory; *host_flag = seq once all of them are there (arrived: a zeroed device counter)
 void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows, int nslots, const double *partials,
                    double *host_scalars, unsigned *arrived, unsigned long long *host_flag, unsigned long long seq);
+
+// ---- device-side control of the truncated CG (tnt.cpp) ----
+// cg_begin: state of the nodes in `bits` from the start values; dmask[0] = dmask[1] = bits.
+void launch_cg_begin(hipStream_t st, int nnodes, NodeBits bits, const CgStart &S, int max_it, CgNode *cg, NodeBits *dmask);
+// dmask[0]: the nodes of the step under way; dmask[1]: the nodes that go on after it.
+// phase 0 (after H p and its four dot products, partial slots 0..3): step length / boundary / negative-curvature
+// logic of IterativeSolvers.h:296-362; nodes that stop are cleared from dmask[1].
+// phase 1 (after the preconditioner and <r, v>, partial slot 0): beta and the recurrences (:364-390), then the
+// stopping test of the next step (:285-291); nodes that stop are cleared from dmask[1], then dmask[0] = dmask[1].
+// Either phase ends by writing, per node, (live, h_M_norm, cg_it) to host_scalars[node * MAX_SLOTS + 0..2] and
+// raising *host_flag to seq (same protocol as launch_reduce).
+void launch_cg_scal(hipStream_t st, const SegTable &T, int nnodes, int phase, const double *partials, CgNode *cg,
+                    NodeBits *dmask, double *host_scalars, unsigned *arrived, unsigned long long *host_flag,
+                    unsigned long long seq);
 
 // ---- multifrontal SPD solve (spd.h) ----
 // One tile of the solve with everything it needs to know about its front: 64 bytes, one load.

@@ -20,7 +20,9 @@ struct Dim {
   static constexpr int RS = (D + 1) * D;
 };
 
-__device__ __forceinline__ bool node_on(NodeMask mask, int node) { return (mask >> node) & 1ull; }
+// the nodes a launch works on: the by-value bits, and-ed with the device-resident mask when there is one
+__device__ __forceinline__ NodeBits mask_bits(const NodeMask &m) { return m.p ? (m.v & *m.p) : m.v; }
+__device__ __forceinline__ bool node_on(const NodeMask &m, int node) { return (mask_bits(m) >> node) & 1ull; }
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -374,11 +376,13 @@ template <int D>
 __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr_tcol(const Seg *segs, NodeMask mask, BsrDev A, const double *tval,
                                                          const double *xt, const double *base, double *y, int mode,
                                                          const double *X, const double *nabla, const double *Rdot,
-                                                         double *out2) {
+                                                         double *out2, const double *rres, double *partial,
+                                                         int pstride) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
-  if (!node_on(mask, s.node)) return;
+  if (!node_on(mask, s.node)) return;   // (partials of a node outside the mask are never read)
   const int row = s.begin + (threadIdx.x >> 2), j = threadIdx.x & 3;
+  double pr[4] = {0.0, 0.0, 0.0, 0.0};
   double acc[RS];
 #pragma unroll
   for (int k = 0; k < RS; k++) acc[k] = 0.0;
@@ -416,10 +420,22 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr_tcol(const Seg *segs, Node
         load_vec<RS>(nabla + (size_t)row * RS, nb);
         load_vec<RS>(Rdot + (size_t)row * RS, rd);
         hess_epilogue_rows<D>(x + D, acc + D, nb + D, rd + D, o + D);
+        if (partial) {   // <p, Hp>, <Hp, Hp>, <p, p>, <p, r> over the rotation rows
+          double rr[RS];
+          load_vec<RS>(rres + (size_t)row * RS, rr);
+#pragma unroll
+          for (int k = D; k < RS; k++) {
+            pr[0] = fma(rd[k], o[k], pr[0]);
+            pr[1] = fma(o[k], o[k], pr[1]);
+            pr[2] = fma(rd[k], rd[k], pr[2]);
+            pr[3] = fma(rd[k], rr[k], pr[3]);
+          }
+        }
       }
       store_vec<RS>(out2 + (size_t)row * RS, o);
     }
   }
+  if (partial) block_store<4, 4 * SEG_ROWS / 64>(pr, partial + SEGB, pstride);
 }
 
 // ---------------------------------------------------------------------------
@@ -768,13 +784,14 @@ __global__ __launch_bounds__(SEG_ROWS) void k_axpby_node(const Seg *segs, NodeMa
 // goes on (cr != 0), r += cr H p
 template <int D>
 __global__ __launch_bounds__(SEG_ROWS) void k_cg_step(const Seg *segs, NodeMask mask, NodeCoefs C, const double *p,
-                                                      const double *Hp, double *s, double *hs, double *r) {
+                                                      const double *Hp, double *s, double *hs, double *r,
+                                                      const CgNode *cg) {
   constexpr int RS = Dim<D>::RS;
   const Seg sg = segs[SEGB];
   if (!node_on(mask, sg.node)) return;
   const int row = sg.begin + threadIdx.x;
   if (row >= sg.end) return;
-  const double cc = C.a[sg.node], cc_r = C.b[sg.node];
+  const double cc = cg ? cg[sg.node].c1 : C.a[sg.node], cc_r = cg ? cg[sg.node].cr : C.b[sg.node];
   double vp[RS], vh[RS], v[RS];
   load_vec<RS>(p + (size_t)row * RS, vp);
   load_vec<RS>(Hp + (size_t)row * RS, vh);
@@ -792,6 +809,24 @@ __global__ __launch_bounds__(SEG_ROWS) void k_cg_step(const Seg *segs, NodeMask 
     for (int k = 0; k < RS; k++) v[k] = fma(cc_r, vh[k], 1.0 * v[k]);
     store_vec<RS>(r + (size_t)row * RS, v);
   }
+}
+
+// p = -v + beta[node] p with the device-resident beta of k_cg_scal (IterativeSolvers.h:386-388)
+template <int D>
+__global__ __launch_bounds__(SEG_ROWS) void k_cg_dir(const Seg *segs, NodeMask mask, const CgNode *cg, const double *v,
+                                                     double *p) {
+  constexpr int RS = Dim<D>::RS;
+  const Seg sg = segs[SEGB];
+  if (!node_on(mask, sg.node)) return;
+  const int row = sg.begin + threadIdx.x;
+  if (row >= sg.end) return;
+  const double be = cg[sg.node].be;
+  double vv[RS], vp[RS];
+  load_vec<RS>(v + (size_t)row * RS, vv);
+  load_vec<RS>(p + (size_t)row * RS, vp);
+#pragma unroll
+  for (int k = 0; k < RS; k++) vp[k] = fma(be, vp[k], -1.0 * vv[k]);
+  store_vec<RS>(p + (size_t)row * RS, vp);
 }
 
 template <int D>
@@ -880,28 +915,39 @@ __global__ __launch_bounds__(SEG_ROWS) void k_tangent_full(const Seg *segs, Node
 // mode 2: out.Y = proj_SO(d)(R + in.Y)                  (SOdProduct::retract)
 template <int D>
 __global__ __launch_bounds__(SEG_ROWS) void k_rot_op(const Seg *segs, NodeMask mask, int mode, const double *X,
-                                                const double *in, const double *nabla, const double *Rdot,
+                                                const double *in, const double *dotv, double *partial,
                                                 double *out) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
   if (!node_on(mask, s.node)) return;
   const int row = s.begin + threadIdx.x;
-  if (row >= s.end) return;
-  double x[RS], v[RS], o[RS];
-  load_vec<RS>(X + (size_t)row * RS, x);
-  load_vec<RS>(in + (size_t)row * RS, v);
+  double pr[1] = {0.0};
+  if (row < s.end) {
+    double x[RS], v[RS], o[RS];
+    load_vec<RS>(X + (size_t)row * RS, x);
+    load_vec<RS>(in + (size_t)row * RS, v);
 #pragma unroll
-  for (int k = 0; k < D; k++) o[k] = 0.0;
-  const double *R = x + D;
-  if (mode == 0) {
-    tangent_proj<D>(R, v + D, o + D);
-  } else {
-    double M[D * D];
+    for (int k = 0; k < D; k++) o[k] = 0.0;
+    const double *R = x + D;
+    if (mode == 0) {
+      tangent_proj<D>(R, v + D, o + D);
+    } else {
+      double M[D * D];
 #pragma unroll
-    for (int k = 0; k < D * D; k++) M[k] = R[k] + v[D + k];
-    project_sod<D>(M, o + D);
+      for (int k = 0; k < D * D; k++) M[k] = R[k] + v[D + k];
+      project_sod<D>(M, o + D);
+    }
+    store_vec<RS>(out + (size_t)row * RS, o);
+    if (partial) {   // <dotv, out> over the rotation rows
+      double dv[RS];
+      load_vec<RS>(dotv + (size_t)row * RS, dv);
+      double p = 0;
+#pragma unroll
+      for (int k = D; k < RS; k++) p = fma(dv[k], o[k], p);
+      pr[0] = p;
+    }
   }
-  store_vec<RS>(out + (size_t)row * RS, o);
+  if (partial) block_store<1>(pr, partial + SEGB, 0);
 }
 
 // dst[didx[k]] = src[sidx[k]]  (didx == nullptr: dst[k]); halo copies, pack and unpack
@@ -959,6 +1005,103 @@ __global__ __launch_bounds__(64) void k_reduce(SegTable T, int all_rows, int nsl
     __atomic_thread_fence(__ATOMIC_RELEASE);   // system scope: the scalar is on its way before the count
     const unsigned done = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
     if (done == gridDim.x - 1) {
+      __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Device-side control of the Steihaug-Toint CG (IterativeSolvers.h:207-390): the scalar recurrences of every
+// node live in CgNode records, the set of still-iterating nodes in two device masks (dmask[0]: the nodes of the
+// step under way -- Hessian product and s / H s update; dmask[1]: the nodes that go on to the preconditioner and
+// to the next step).  The host enqueues
+// whole CG steps and only polls the summary these kernels write to pinned memory.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_cg_begin(int nnodes, NodeBits bits, CgStart S, int max_it, CgNode *cg,
+                                                 NodeBits *dmask) {
+  const int a = threadIdx.x;
+  if (a < nnodes && ((bits >> a) & 1ull)) {
+    CgNode c;
+    c.sk_M_pk = 0.0; c.sk_M_2 = 0.0; c.pk_M_2 = S.rv[a]; c.rv = S.rv[a];
+    c.Delta = S.Delta[a]; c.Delta_2 = S.Delta[a] * S.Delta[a]; c.target = S.target[a]; c.h_M_norm = 0.0;
+    c.c1 = 0.0; c.cr = 0.0; c.al = 0.0; c.kap = 0.0; c.be = 0.0;
+    c.cg_it = 0; c.max_it = max_it; c.pad = 0;
+    // the stopping test of the first step (:285-291)
+    c.live = !(c.cg_it >= max_it || sqrt(c.rv) <= c.target);
+    if (!c.live) c.h_M_norm = sqrt(c.sk_M_2);
+    cg[a] = c;
+  }
+  const bool live = a < nnodes && ((bits >> a) & 1ull) && cg[a].live;
+  const NodeBits m = __ballot(live);
+  if (a == 0) { dmask[0] = m; dmask[1] = m; }
+}
+
+// one wave per node; the partial sums are combined in the order of k_reduce
+__global__ __launch_bounds__(64) void k_cg_scal(SegTable T, int phase, const double *partials, CgNode *cg,
+                                                NodeBits *dmask, double *host_scalars, unsigned *arrived,
+                                                unsigned long long *host_flag, unsigned long long seq) {
+  const int a = blockIdx.x, lane = threadIdx.x;
+  const NodeBits on = dmask[phase];      // (read before anyone clears a bit of it: bits are only ever cleared)
+  const bool mine = (on >> a) & 1ull;
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  if (mine) {
+    const int ns = phase == 0 ? 4 : 1;
+    for (int q = 0; q < ns; q++) {
+      const double *p = partials + (size_t)q * T.nseg_all;
+      double t = 0;
+      for (int k = T.own_ptr[a] + lane; k < T.own_ptr[a + 1]; k += 64) t += p[k];
+      v[q] = wave_sum(t);
+    }
+  }
+  if (lane == 0) {
+    CgNode c = cg[a];
+    if (mine && phase == 0) {
+      const double kappa_k = v[0];
+      bool stop = false;
+      if (sqrt(v[1]) / sqrt(v[2]) < 1e-8) {   // p is (numerically) in the kernel of H (:305-338)
+        double sgn = 1.0;
+        if (v[3] < 0) { sgn = -1.0; c.sk_M_pk = -c.sk_M_pk; }
+        const double sigma = (-c.sk_M_pk + sqrt(c.sk_M_pk * c.sk_M_pk + c.pk_M_2 * (c.Delta_2 - c.sk_M_2))) / c.pk_M_2;
+        c.c1 = sgn * sigma;
+        stop = true;
+      } else {
+        const double alpha = c.rv / kappa_k;
+        const double skp1 = c.sk_M_2 + 2 * alpha * c.sk_M_pk + alpha * alpha * c.pk_M_2;
+        if (kappa_k <= 0 || skp1 > c.Delta_2) {   // negative curvature or the step leaves the region (:347-362)
+          c.c1 = (-c.sk_M_pk + sqrt(c.sk_M_pk * c.sk_M_pk + c.pk_M_2 * (c.Delta_2 - c.sk_M_2))) / c.pk_M_2;
+          stop = true;
+        } else {
+          c.c1 = alpha; c.cr = alpha; c.al = alpha; c.kap = kappa_k; c.sk_M_2 = skp1;
+        }
+      }
+      if (stop) { c.cr = 0.0; c.h_M_norm = c.Delta; c.live = 0; }
+    } else if (mine) {
+      const double rk_vk = v[0];
+      const double be = rk_vk / (c.al * c.kap);   // (:364-390)
+      c.sk_M_pk = be * (c.sk_M_pk + c.al * c.pk_M_2);
+      c.pk_M_2 = rk_vk + be * be * c.pk_M_2;
+      c.rv = rk_vk;
+      c.be = be;
+      c.cg_it++;
+      if (c.cg_it >= c.max_it || sqrt(c.rv) <= c.target) {   // the stopping test of the next step (:285-291)
+        c.h_M_norm = sqrt(c.sk_M_2);
+        c.live = 0;
+      }
+    }
+    if (mine) {
+      cg[a] = c;
+      // a node that stops leaves dmask[1] now; dmask[0] (the nodes of the step under way, which still take the
+      // s / H s update of this step) follows at the end of phase 1
+      if (!c.live) atomicAnd(dmask + 1, ~(1ull << a));
+    }
+    __hip_atomic_store(host_scalars + a * MAX_SLOTS + 0, (double)c.live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(host_scalars + a * MAX_SLOTS + 1, c.h_M_norm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(host_scalars + a * MAX_SLOTS + 2, (double)c.cg_it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    const unsigned done = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (done == gridDim.x - 1) {
+      if (phase == 1) dmask[0] = __hip_atomic_load(dmask + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next step's nodes
       __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -1275,16 +1418,18 @@ __global__ __launch_bounds__(64 * SPD_NW(ROWS), ROWS == 64 ? SPD_WPE : 4) void k
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const SpdItem *items = (FWD ? S.fwd_items : S.bwd_items) + tile0;
   const int b = blockIdx.x;
+  const NodeBits bits = mask_bits(mask);
+  if (bits == 0) return;   // every node has left the device-side mask: nothing to read at all
   if (b >= nwide) {
     const int t = (b - nwide) * NW + wv;
     if (t >= nnarrow) return;
     const SpdItem it = load_item(items + nwide + t);
-    if (!node_on(mask, it.node)) return;
+    if (!((bits >> it.node) & 1ull)) return;
     if constexpr (FWD) spd_fwd_tile<D, DOF, 1, CH, 64, NT>(S, it, vec, ytmp, f[wv], red, 0, lane);
     else spd_bwd_tile<D, DOF, 1, CH, 64, NT>(S, it, scale, ytmp, vec, f[wv], red, 0, lane);
   } else {
     const SpdItem it = load_item(items + b);
-    if (!node_on(mask, it.node)) return;   // (uniform over the workgroup)
+    if (!((bits >> it.node) & 1ull)) return;   // (uniform over the workgroup)
     if constexpr (FWD) spd_fwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, vec, ytmp, f[wv], red, wv, lane);
     else spd_bwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, scale, ytmp, vec, f[wv], red, wv, lane);
   }
@@ -1393,11 +1538,12 @@ void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMas
 
 void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, const BsrDev &A, const double *tval,
                      const double *xt, const double *base, double *y, int mode, const double *X, const double *nabla,
-                     const double *Rdot, double *out2) {
+                     const double *Rdot, double *out2, const double *rres, double *partials) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_BSR, st, (double)A.nnzb * (8.0 * (d + 1) + 4 + 8.0 * d) + 2.0 * A.nrows * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_bsr_tcol<D>), dim3(T.nseg_own), dim3(4 * SEG_ROWS), 0, st, T.segs, mask, A, tval,
-                                        xt, base, y, mode, X, nabla, Rdot, out2));
+                                        xt, base, y, mode, X, nabla, Rdot, out2, rres, (mode == 2 && rres) ? partials : nullptr,
+                                        T.nseg_all));
 }
 
 void launch_inter(int d, hipStream_t st, const SegTable &T, NodeMask mask, const InterEdgesDev &E, int loss,
@@ -1469,11 +1615,29 @@ void launch_axpby_node(int d, hipStream_t st, const SegTable &T, NodeMask mask, 
 }
 
 void launch_cg_step(int d, hipStream_t st, const SegTable &T, NodeMask mask, const NodeCoefs &C, const double *p,
-                    const double *Hp, double *s, double *hs, double *r) {
+                    const double *Hp, double *s, double *hs, double *r, const CgNode *cg) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_AXPBY, st, 8.0 * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cg_step<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, C, p, Hp, s, hs,
-                                        r));
+                                        r, cg));
+}
+
+void launch_cg_dir(int d, hipStream_t st, const SegTable &T, NodeMask mask, const CgNode *cg, const double *v, double *p) {
+  if (T.nseg_own == 0) return;
+  ProfScope ps(PK_AXPBY, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cg_dir<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, cg, v, p));
+}
+
+void launch_cg_begin(hipStream_t st, int nnodes, NodeBits bits, const CgStart &S, int max_it, CgNode *cg, NodeBits *dmask) {
+  hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(64), 0, st, nnodes, bits, S, max_it, cg, dmask);
+}
+
+void launch_cg_scal(hipStream_t st, const SegTable &T, int nnodes, int phase, const double *partials, CgNode *cg,
+                    NodeBits *dmask, double *host_scalars, unsigned *arrived, unsigned long long *host_flag,
+                    unsigned long long seq) {
+  ProfScope ps(PK_REDUCE, st, 8.0 * (phase == 0 ? 4 : 1) * T.nseg_own);
+  hipLaunchKernelGGL(k_cg_scal, dim3(nnodes), dim3(64), 0, st, T, phase, partials, cg, dmask, host_scalars, arrived,
+                     host_flag, seq);
 }
 
 void launch_dots(int d, hipStream_t st, const SegTable &T, NodeMask mask, int n, const double *const *a,
@@ -1509,11 +1673,12 @@ void launch_tangent_full(int d, hipStream_t st, const SegTable &T, NodeMask mask
 }
 
 void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
-                        const double *in, double *out) {
+                        const double *in, double *out, const double *dotv, double *partials, int slot) {
   if (T.nseg_own == 0) return;
-  ProfScope ps(PK_ROTOP, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
+  ProfScope ps(PK_ROTOP, st, (dotv ? 4.0 : 3.0) * T.rows_own * 8.0 * (d + 1) * d);
+  double *part = (dotv && partials) ? partials + (size_t)slot * T.nseg_all : nullptr;
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, 0, X, in,
-                                        nullptr, nullptr, out));
+                                        dotv, part, out));
 }
 
 void launch_retract_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,

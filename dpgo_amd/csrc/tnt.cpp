@@ -20,6 +20,7 @@
 // and the handful of reductions per CG step come back through one polled read-back.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <limits>
 
 #include "group.h"
@@ -27,6 +28,11 @@
 namespace dpgo {
 
 namespace {
+// DPGO_CG_LAG=0: wait for every CG step's outcome before enqueueing the next (measurement hook)
+int env_lag() {
+  const char *e = getenv("DPGO_CG_LAG");
+  return e ? atoi(e) : 1;
+}
 enum { ST_GRADIENT = 0, ST_PRECON_GRADIENT, ST_REL_DECREASE, ST_STEPSIZE, ST_TRUST_REGION, ST_ITER_LIMIT };
 
 struct NodeTnt {
@@ -56,13 +62,6 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
   for (int a : nodes) S[a] = NodeTnt();
 
   const int P2[MAX_DOTS] = {2, 2, 2, 2, 2, 2};
-  auto dots = [&](std::initializer_list<std::pair<const double *, const double *>> prs) {
-    const double *pa[MAX_DOTS], *pb[MAX_DOTS];
-    int s = 0;
-    for (const auto &pr : prs) { pa[s] = pr.first; pb[s] = pr.second; s++; }
-    launch_dots(d_, st_, T_, cur_mask_, s, pa, pb, P2, partials_.p, 0);
-    fetch(s, false);
-  };
   // nabla = G Y + g and grad = Proj_Y(nabla) (rotation rows).  from_base: Y.t was just recovered from Y.R with
   // this g (recover_translations), so T1_ = G [0 ; Y.R] + g is there and only the translation column is missing.
   auto quad_model = [&](const double *Y, bool from_base) {
@@ -72,12 +71,6 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     }
     launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Y, false, g, nabla, nullptr, 0, nullptr, nullptr, 0);
     launch_tangent_rot(d_, st_, T_, cur_mask_, Y, nabla, grad);
-  };
-  // Hess f(Y)[v] (DPGOProblem.cpp:552-577): tdot = -G_tt^-1 G_tR v.R, then Proj(G [tdot ; v.R] - ...)
-  auto hess = [&](const double *Y, const double *v, double *out) {
-    launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, v, true, nullptr, w1, nullptr, 0, nullptr, nullptr, 0);   // G [0 ; v.R]
-    solve_tt(w1, w3, -1.0);                   // w3.t = tdot
-    apply_tcol(w3, w1, nullptr, 2, Y, nabla, v, out);   // out = Proj(G [tdot ; v.R] - sym(nabla R^T) v.R)
   };
   auto precon = [&](const double *Y, const double *v, double *out) {
     if (!use_precon) {
@@ -126,7 +119,6 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
   quad_model(X, base_ready);
   norms(nodes, true);
 
-  std::vector<double> c1(L, 0.0), c2(L, 0.0);
   for (;;) {
     // ---- nodes that start another trust-region iteration (TNT.h:446-484)
     std::vector<int> A;
@@ -139,92 +131,83 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       A.push_back(a);
     }
     if (A.empty()) break;
-    // ---- STPCG (IterativeSolvers.h:207-426)
+    // ---- STPCG (IterativeSolvers.h:207-426).  The scalar recurrences (alpha, beta, the boundary / negative
+    // curvature / kernel tests, the stopping test) run on the device (k_cg_scal); the vector kernels take their
+    // step lengths and the set of still-iterating nodes from device memory, so a whole CG step is enqueued
+    // without a host round trip.  The host only polls the summary (live, |h|_M, iterations) of a step it enqueued
+    // earlier: step i+1 is already queued when the outcome of step i arrives; once every node has stopped, the
+    // kernels of the surplus step find an empty device mask and return at once.
     set_mask(A);
+    const NodeBits bitsA = cur_mask_.v;
     // s_0 = 0, H s_0 = 0, r_0 = grad, v_0 = P(grad) (already there from the preconditioned gradient norm), p_0 = -v_0
     launch_cg_init(d_, st_, T_, cur_mask_, grad, use_precon ? pg : grad, sk, hh, rk, vk, pk);
-    for (int a : A) {
-      NodeTnt &s = S[a];
-      s.cg = true;
-      s.cg_it = 0;
-      s.sk_M_pk = s.sk_M_2 = 0;
-      s.rv = s.pk_M_2 = rv0[a];   // <r_0, v_0> = <grad, P grad>, read back together with the norms
-      s.Delta_2 = s.Delta * s.Delta;
-      const double r0 = std::sqrt(s.rv);
-      s.target = r0 * std::min(o.STPCG_kappa, std::pow(r0, o.STPCG_theta));
-      s.h_M_norm = 0;
-    }
-    for (;;) {
-      std::vector<int> C;
+    {
+      CgStart cs;
+      for (int a = 0; a < L; a++) cs.rv[a] = cs.Delta[a] = cs.target[a] = 0.0;
       for (int a : A) {
-        NodeTnt &s = S[a];
-        if (!s.cg) continue;
-        if (s.cg_it >= o.max_tCG_iterations || std::sqrt(s.rv) <= s.target) {   // :285-291
-          s.h_M_norm = std::sqrt(s.sk_M_2);
-          s.cg = false;
-          continue;
+        cs.rv[a] = rv0[a];   // <r_0, v_0> = <grad, P grad>, read back together with the norms
+        cs.Delta[a] = S[a].Delta;
+        const double r0 = std::sqrt(rv0[a]);
+        cs.target[a] = r0 * std::min(o.STPCG_kappa, std::pow(r0, o.STPCG_theta));
+      }
+      launch_cg_begin(st_, L, bitsA, cs, o.max_tCG_iterations, cg_.p, dmask_.p);
+    }
+    const NodeMask mA{bitsA, dmask_.p}, mB{bitsA, dmask_.p + 1};
+    // first half of a step: H p and its four scalars, then the step-length logic (:296-362)
+    auto stepA = [&]() {
+      cur_mask_ = mA;
+      launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, pk, true, nullptr, w1, nullptr, 0, nullptr, nullptr, 0);   // G [0 ; p.R]
+      solve_tt(w1, w3, -1.0);
+      apply_tcol(w3, w1, nullptr, 2, X, nabla, pk, Hp, rk, partials_.p);   // Hp and <p,Hp>, <Hp,Hp>, <p,p>, <p,r>
+      launch_cg_scal(st_, T_, L, 0, partials_.p, cg_.p, dmask_.p, h_scal_, reduce_arrived_.p, h_flag_, ++fetch_seq_);
+      // s += c1 p, H s += c1 H p for every node of the step (a node that stops here takes its boundary step), r += alpha H p
+      // for those that go on
+      launch_cg_step(d_, st_, T_, mA, NodeCoefs(), pk, Hp, sk, hh, rk, cg_.p);
+      return fetch_seq_;
+    };
+    // second half: preconditioner; beta and the recurrences, next stopping test (:364-390, :285-291)
+    auto stepB = [&]() {
+      cur_mask_ = mB;
+      if (use_precon) {
+        solve_rr(rk, w1, 1.0);
+        launch_tangent_rot(d_, st_, T_, cur_mask_, X, w1, vk, rk, partials_.p, 0);   // v = Proj(M^-1 r) and <r, v>
+      } else {
+        copy_rows(vk, rk, false, 0);
+        const double *pa[MAX_DOTS] = {rk}, *pb[MAX_DOTS] = {vk};
+        launch_dots(d_, st_, T_, cur_mask_, 1, pa, pb, P2, partials_.p, 0);
+      }
+      launch_cg_scal(st_, T_, L, 1, partials_.p, cg_.p, dmask_.p, h_scal_, reduce_arrived_.p, h_flag_, ++fetch_seq_);
+      launch_cg_dir(d_, st_, T_, cur_mask_, cg_.p, vk, pk);
+      return fetch_seq_;
+    };
+    auto any_live = [&]() {
+      for (int a : A)
+        if (scal(a, 0) != 0.0) return true;
+      return false;
+    };
+    static const int lag = env_lag();
+    // the first step is awaited at once: in the early regime every node ends it on the trust-region boundary
+    wait_flag(stepA());
+    if (any_live()) {
+      unsigned long long seqB = stepB();
+      for (;;) {
+        if (!lag) {
+          wait_flag(seqB);
+          if (!any_live()) break;
         }
-        C.push_back(a);
-      }
-      if (C.empty()) break;
-      set_mask(C);
-      hess(X, pk, Hp);
-      dots({{pk, Hp}, {Hp, Hp}, {pk, pk}, {pk, rk}});
-      std::vector<int> cont;
-      for (int a : C) {
-        NodeTnt &s = S[a];
-        const double kappa_k = scal(a, 0);
-        c1[a] = 0.0;   // coefficient of p_k in s_k += c1 p_k
-        if (std::sqrt(scal(a, 1)) / std::sqrt(scal(a, 2)) < 1e-8) {   // :305-338
-          double sgn = 1.0;
-          if (scal(a, 3) < 0) { sgn = -1.0; s.sk_M_pk = -s.sk_M_pk; }
-          const double sigma = (-s.sk_M_pk + std::sqrt(s.sk_M_pk * s.sk_M_pk + s.pk_M_2 * (s.Delta_2 - s.sk_M_2))) / s.pk_M_2;
-          c1[a] = sgn * sigma;
-          s.h_M_norm = s.Delta;
-          s.cg = false;
-          continue;
+        stepA();
+        const unsigned long long next = stepB();
+        if (lag) {
+          wait_flag(seqB);   // the outcome of the step before the one just enqueued
+          if (!any_live()) break;
         }
-        const double alpha = s.rv / kappa_k;
-        const double skp1 = s.sk_M_2 + 2 * alpha * s.sk_M_pk + alpha * alpha * s.pk_M_2;
-        if (kappa_k <= 0 || skp1 > s.Delta_2) {   // :347-362
-          c1[a] = (-s.sk_M_pk + std::sqrt(s.sk_M_pk * s.sk_M_pk + s.pk_M_2 * (s.Delta_2 - s.sk_M_2))) / s.pk_M_2;
-          s.h_M_norm = s.Delta;
-          s.cg = false;
-          continue;
-        }
-        c1[a] = alpha;
-        c2[a] = kappa_k;   // kept for beta
-        s.sk_M_2 = skp1;   // provisional: committed below together with sk_M_pk / pk_M_2
-        cont.push_back(a);
+        seqB = next;
       }
-      // s_k += c1 p_k (final boundary step or regular step) and H s_k alongside, for every node of C; nodes that
-      // go on also get r_k += alpha H p_k -- one pass
-      {
-        NodeCoefs C;
-        for (int a = 0; a < L; a++) { C.a[a] = c1[a]; C.b[a] = 0.0; }
-        for (int a : cont) C.b[a] = c1[a];
-        launch_cg_step(d_, st_, T_, cur_mask_, C, pk, Hp, sk, hh, rk);
-      }
-      if (cont.empty()) continue;
-      set_mask(cont);
-      if (use_precon) precon(X, rk, vk); else copy_rows(vk, rk, false, 0);
-      dots({{rk, vk}});
-      std::vector<double> beta(L, 0.0);
-      for (int a : cont) {
-        NodeTnt &s = S[a];
-        const double alpha = c1[a], kappa_k = c2[a], rk_vk = scal(a, 0);
-        const double be = rk_vk / (alpha * kappa_k);
-        s.sk_M_pk = be * (s.sk_M_pk + alpha * s.pk_M_2);
-        s.pk_M_2 = rk_vk + be * be * s.pk_M_2;
-        s.rv = rk_vk;
-        s.cg_it++;
-        beta[a] = be;
-      }
-      {
-        NodeCoefs C;
-        for (int a = 0; a < L; a++) { C.a[a] = -1.0; C.b[a] = beta[a]; }
-        launch_axpby_node(d_, st_, T_, cur_mask_, C, vk, pk, pk);
-      }
+    }
+    for (int a : A) {
+      S[a].h_M_norm = scal(a, 1);
+      S[a].cg_it = (int)scal(a, 2);
+      S[a].cg = false;
     }
     for (int a : A) S[a].inner_total += S[a].cg_it;
     // ---- trial point (TNT.h:505-536)

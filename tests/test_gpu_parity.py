@@ -484,9 +484,11 @@ def test_evaluate_f_and_grad_at_arbitrary_X(fixtures_dir, name, nn, loss):
     for X in (_random_global_X(rng, num_poses, G.d), X0, _random_global_X(rng, num_poses, G.d, 0.1)):
         F, g2, grad = gpu.group.evaluate(X, want_grad=True)
         Fo, go = star.evaluate_f(X), star.evaluate_grad(X)
-        assert abs(F - Fo) <= 1e-11 * abs(Fo)
-        np.testing.assert_allclose(grad, go, rtol=0, atol=1e-11 * np.abs(go).max())
-        assert abs(g2 - np.sum(go * go)) <= 1e-11 * np.sum(go * go)
+        # trivial loss: the reference's 1/2 tr(X^T M X) cancels |x|^2-sized terms down to residual size (M3500: 1e-10
+        # of F is lost there); the device sums squared residuals, so the comparison is only as good as the oracle
+        assert abs(F - Fo) <= (1e-9 if loss == LOSS_NONE else 1e-11) * abs(Fo)
+        np.testing.assert_allclose(grad, go, rtol=0, atol=1e-10 * np.abs(go).max())
+        assert abs(g2 - np.sum(go * go)) <= 1e-9 * np.sum(go * go)
         assert gpu.step() == 0 and ref.step() == 0                     # evaluating leaves the trajectory alone
         assert np.array_equal(gpu.X(), ref.X())
 
