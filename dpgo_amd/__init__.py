@@ -65,6 +65,17 @@ class Options(C.Structure):
         return o
 
 
+class DChordalOptions(C.Structure):
+    """DChordal::Options::reg_G + the driver's stage schedule (dist_pgo.cpp:205,274,344,383) + stage-0 length."""
+    _fields_ = [("iters", C.c_int * 4), ("local_iters", C.c_int), ("reg_G", C.c_double)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        lib().dpgo_dchordal_options_default(C.byref(self))
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
 class Results(C.Structure):
     """Scalar part of DPGOResult (C++/DPGO/include/DPGO/DPGO_types.h:204-322)."""
     _fields_ = [
@@ -100,6 +111,8 @@ SYMBOLS = {
     "dpgo_group_evaluate": (C.c_int, [C.c_void_p, _DP, C.c_int, _DP, _DP, _DP, C.c_int]),
     "dpgo_group_set_options": (C.c_int, [C.c_void_p, C.POINTER(Options)]),
     "dpgo_group_get_options": (C.c_int, [C.c_void_p, C.POINTER(Options)]),
+    "dpgo_dchordal_options_default": (None, [C.c_void_p]),
+    "dpgo_group_dist_chordal_initialization": (C.c_int, [C.c_void_p, C.c_void_p, _DP, C.c_int, _DP, C.c_int, _DP, _IP]),
     "dpgo_group_create": (C.c_int, [C.c_void_p, _IP, C.c_int, C.POINTER(Options), C.c_int, C.POINTER(C.c_void_p)]),
     "dpgo_group_free": (None, [C.c_void_p]),
     "dpgo_group_initialize": (C.c_int, [C.c_void_p, C.c_int, _DP, C.c_int]),
@@ -415,6 +428,23 @@ class NodeGroup:
     def scatter_global(self, X):
         assert X.flags.f_contiguous
         return lib().dpgo_group_scatter_global(self._h, _dp(X), X.shape[0])
+
+    def dist_chordal_initialization(self, options=None, X_local=None):
+        """The --dist_init true branch of dist_pgo (dist_pgo.cpp:144-416): returns (X, objectives) -- the initial
+        guess ((d+1)N x d) and the stage objectives sampled every 20 iterations."""
+        o = options or DChordalOptions()
+        N, d = self.graph.num_poses, self.d
+        X = np.zeros(((d + 1) * N, d), order="F")
+        cap = sum((o.iters[k] + 19) // 20 for k in range(4))
+        obj, cnt = np.zeros(max(cap, 1)), C.c_int(cap)
+        xl, ldl = (None, 0)
+        if X_local is not None:
+            Xl, ldl = _fcol(X_local)
+            xl = _dp(Xl)
+        if lib().dpgo_group_dist_chordal_initialization(self._h, C.byref(o), xl, ldl, _dp(X), X.shape[0], _dp(obj),
+                                                        C.byref(cnt)) != 0:
+            raise RuntimeError("distributed chordal initialisation failed")
+        return X, obj[:cnt.value]
 
     def evaluate(self, X, want_grad=False):
         """DPGOStar::evaluate_f / evaluate_grad at an arbitrary global X: (F, |grad F|^2[, grad]) summed over

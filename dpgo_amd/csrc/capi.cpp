@@ -1,6 +1,7 @@
 // C ABI (include/dpgo_amd.h) over the C++ host layer.
 #include "../../include/dpgo_amd.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -544,6 +545,35 @@ int dpgo_write_g2o(const dpgo_graph_t *g, const double *X, int ld, const char *f
   }
   fclose(fp);
   return 0;
+}
+
+void dpgo_dchordal_options_default(dpgo_dchordal_options_t *o) {
+  const dpgo::DChordalOptions d;
+  for (int k = 0; k < 4; k++) o->iters[k] = d.iters[k];
+  o->local_iters = d.local_iters;
+  o->reg_G = d.reg_G;
+}
+
+int dpgo_group_dist_chordal_initialization(dpgo_group_t *h, const dpgo_dchordal_options_t *opt, const double *X_local,
+                                           int ld_local, double *X, int ld, double *objectives, int *num_objectives) {
+  if (!h || !X) return -1;
+  dpgo::DChordalOptions o;
+  if (opt) {
+    for (int k = 0; k < 4; k++) o.iters[k] = opt->iters[k];
+    o.local_iters = opt->local_iters;
+    o.reg_G = opt->reg_G;
+    if (o.reg_G < 0 || o.local_iters < 0 || o.iters[0] < 0 || o.iters[1] < 0 || o.iters[2] < 0 || o.iters[3] < 0) return -1;
+  }
+  return guarded([&] {
+    std::vector<double> obj;
+    const int rc = h->grp->dist_chordal_initialization(o, X_local, ld_local, X, ld, objectives ? &obj : nullptr);
+    if (rc == 0 && objectives && num_objectives) {
+      const int n = std::min<int>(*num_objectives, (int)obj.size());
+      std::copy(obj.begin(), obj.begin() + n, objectives);
+      *num_objectives = (int)obj.size();
+    }
+    return rc;
+  });
 }
 
 }  // extern "C"

@@ -133,6 +133,8 @@ int pcg(int n, int nc, const Apply &A, const std::vector<double> &diag, const st
 
 }  // namespace
 
+void project_to_SOd_host(int d, double *M) { project_block(d, M); }
+
 int chordal_initialization(const Graph &g, double *X, int ld) {
   const int d = g.d, N = g.num_poses;
   const auto &E = g.all;

@@ -10,8 +10,10 @@
 //              estimates_<loss>.txt  (X with t <- t - t_0, X <- X R_0)                (:554-567)
 // All nodes are hosted by one GPU (--gpu).  fobj = 2 F and grad = 2 |grad F| come from the per-node
 // device reductions (sum_a fobj^a = F, sum_a |Proj(Dfobj^a)|^2 = |grad F|^2; DPGOStar.cpp:713-829).
-// --dist_init true (the distributed chordal initialisation, C++/DChordal) is not part of this
-// library yet: the centralised chordal initialisation (:416-444) is used and a note is printed.
+// --dist_init true runs the distributed chordal initialisation (:144-416, C++/DChordal) through
+// dpgo_group_dist_chordal_initialization and prints the stage objectives the reference prints every 20
+// iterations (:206-210); its stage 0 (a per-node SE-Sync solve in the reference) is the library's stand-in.
+// --dist_init false is the centralised chordal initialisation (:416-444).
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -63,17 +65,30 @@ int main(int argc, char **argv) {
   dpgo_graph_info(g, &d, &N, &nn, &m);
   dpgo_options_t opt;
   dpgo_options_driver(&opt, loss, accelerated);
-  if (dist_init)
-    printf("note: --dist_init true (distributed chordal initialisation) is not available; using the centralised "
-           "chordal initialisation of --dist_init false.\n");
-  printf("===============================================\nInitialization\n-----------------------------------------------\n");
   const int ld = (d + 1) * N;
   std::vector<double> X((size_t)ld * d, 0.0);
-  if (dpgo_chordal_initialization(g, X.data(), ld) != 0) return -1;
   std::vector<int> ids(num_nodes);
   for (int a = 0; a < num_nodes; a++) ids[a] = a;
   dpgo_group_t *grp = nullptr;
   if (dpgo_group_create(g, ids.data(), num_nodes, &opt, gpu, &grp) != 0) return -1;
+  if (dist_init) {
+    dpgo_dchordal_options_t co;
+    dpgo_dchordal_options_default(&co);
+    int cap = 0;
+    for (int k = 0; k < 4; k++) cap += (co.iters[k] + 19) / 20;
+    std::vector<double> obj(cap);
+    if (dpgo_group_dist_chordal_initialization(grp, &co, nullptr, 0, X.data(), ld, obj.data(), &cap) != 0) return -1;
+    const char *names[4] = {"Initialize the reduced rotation", "Initialize the rotation", "Initialize the reduced translation",
+                            "Initialize the translation"};
+    int at = 0;
+    for (int k = 0; k < 4; k++) {
+      printf("===============================================\n%s\n-----------------------------------------------\n", names[k]);
+      for (int it = 0; it < co.iters[k]; it += 20) printf("%d: %.16g\n", it, obj[at++]);
+    }
+  } else {
+    printf("===============================================\nInitialization\n-----------------------------------------------\n");
+    if (dpgo_chordal_initialization(g, X.data(), ld) != 0) return -1;
+  }
   if (dpgo_group_initialize_global(grp, X.data(), ld) != 0) return -1;
   if (dpgo_group_update(grp, nullptr, 0) != 0) return -1;
 

@@ -49,6 +49,8 @@ template struct DevBuf<double>;
 template struct DevBuf<int64_t>;
 template struct DevBuf<int4>;
 template struct DevBuf<Seg>;
+template struct DevBuf<SpdItem>;
+template struct DevBuf<unsigned>;
 template struct DevBuf<CgNode>;
 template struct DevBuf<NodeBits>;
 
@@ -527,6 +529,7 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
 }
 
 Group::~Group() {
+  chordal_release();
   if (h_scal_) (void)hipHostFree(h_scal_);
   if (st_) (void)hipStreamDestroy(st_);
 }
@@ -605,7 +608,7 @@ void Group::copy_rows(double *dst, const double *src, bool all_rows, int part) {
 
 // out <- scale * A^-1 in (the unknowns' entries of the records; everything else in `out` is left alone).
 // The forward sweep only reads `in`, the backward sweep only touches `out`: in == out solves in place.
-static void spd_run(int d, hipStream_t st, SpdSolverDev &S, NodeMask mask, double *in, double *out, double scale) {
+void spd_run(int d, hipStream_t st, SpdSolverDev &S, NodeMask mask, double *in, double *out, double scale) {
   for (size_t l = 0; l < S.fwd_levels.size(); l++) {
     const SpdSolverDev::Level &v = S.fwd_levels[l];
     launch_spd_level(d, S.dof, st, S.dev, true, v.tile0, v.nwide, v.nnarrow, v.rows, in, S.ytmp.p, scale, S.fwd_level_bytes[l],

@@ -76,6 +76,14 @@ struct NodeResults {
   std::vector<int> oscillations;
 };
 
+// DChordal::Options (C++/DChordal/include/DChordal/DChordal_types.h:44-70) + the driver's stage schedule
+// (C++/examples/dist_pgo.cpp:205,274,344,383) + the length of the stage-0 stand-in (dchordal.cpp)
+struct DChordalOptions {
+  int iters[4] = {100, 400, 150, 250};   // reduced R, R, reduced t, t
+  int local_iters = 30;
+  double reg_G = 1e-12;
+};
+
 template <class T>
 struct DevBuf {
   T *p = nullptr;
@@ -104,6 +112,9 @@ struct SpdSolverDev {
   bool stream_once = true;   // panels read with non-temporal loads (see upload)
   void upload(int dcols, const std::vector<int> &node_of_unknown);   // node_of_unknown: local node of every row of A
 };
+
+// out <- scale * A^-1 in on the unknowns' entries of the records (everything else in `out` is left alone)
+void spd_run(int d, hipStream_t st, SpdSolverDev &S, NodeMask mask, double *in, double *out, double scale);
 
 class Group {
  public:
@@ -135,6 +146,19 @@ class Group {
   int send(int local, int beta, double *msg, int ld) const;
   int num_recv(int local, int beta) const;
   int num_send(int local, int beta) const;
+
+  // ---- distributed chordal initialisation (dchordal.cpp; C++/DChordal, C++/examples/dist_pgo.cpp:144-416).
+  // Xlocal (optional): per-node local solutions in the global layout (stage 0); X: the initial guess, global
+  // (d+1)N x d; objectives (optional): 0.5 sum |B X + b|^2 of the running stage every 20 iterations, stages in order.
+  int dist_chordal_initialization(const DChordalOptions &o, const double *Xlocal, int ldl, double *X, int ld,
+                                  std::vector<double> *objectives);
+  // the sparse stages: setup -> initialize -> step ... -> get (DChordal_R / DChordal_t for all nodes in lockstep)
+  int chordal_setup(int kind, double xi, const std::vector<std::vector<double>> &R);
+  int chordal_initialize(const std::vector<std::vector<double>> &X);
+  int chordal_step();
+  double chordal_objective();
+  int chordal_get(std::vector<std::vector<double>> &Xak);
+  void chordal_release();
 
   // ---- AMM-PGO* (DPGOStar, C++/DPGO/src/DPGOStar.cpp:107-711); every node of the graph must be local
   int star_initialize_global(const double *X, int ld);   // DPGOStar::initialize (:107-124)
@@ -221,6 +245,8 @@ class Group {
   DevBuf<double> Xk_, Zc_, Zp_, Y_, DfE_, Tall_;                 // P0+P1 rows
   DevBuf<double> Xak_, Xakh_, gc_, gp_, Dfc_, Dfp_, gx_, Dfx_, T1_;   // P0 rows
   DevBuf<double> tmp_[14];                                       // P0 rows, TNT work vectors
+  struct ChordalState;
+  ChordalState *ch_ = nullptr;
   bool star_ = false;
   double *coll_send_ = nullptr, *coll_gathered_ = nullptr;
   AllGatherFn coll_allgather_ = nullptr;

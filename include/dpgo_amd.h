@@ -76,6 +76,7 @@ typedef struct dpgo_results {
   int restarts;
 } dpgo_results_t;
 
+
 typedef struct dpgo_graph dpgo_graph_t;
 typedef struct dpgo_group dpgo_group_t;
 
@@ -116,6 +117,24 @@ int dpgo_write_g2o(const dpgo_graph_t *g, const double *X, int ld, const char *f
 /* Centralised chordal initialisation -- C++/examples/dist_pgo.cpp:416-444
  * (C++/SESync/src/SESync_utils.cpp:573-652).  Host, set-up only.  X: (d+1)N x d. */
 int dpgo_chordal_initialization(const dpgo_graph_t *g, double *X, int ld);
+
+/* Distributed chordal initialisation -- the `--dist_init true` branch of C++/examples/dist_pgo.cpp:144-416 on
+ * C++/DChordal (DChordalReduced_R, DChordal_R, DChordalReduced_t, DChordal_t; DChordal.cpp:79-152,
+ * DChordalProblem.h:128-246, DChordal_utils.cpp:67-1204).  The two sparse stages run on the group's GPU, the two
+ * reduced ones (one d x d block / one translation per node) on the host.  Every node of the graph must be in the
+ * group, in order.  opts: DChordal::Options::reg_G, the driver's stage schedule, and the length of the stage-0
+ * stand-in (the reference's stage 0 is a per-node SE-Sync solve, out of scope: here chordal initialisation of the
+ * node's own subgraph + local_iters refined MM-PGO iterations).  X_local (optional): stage-0 poses of every node in
+ * the global layout.  X: (d+1)N x d result.  objectives (optional, capacity *num_objectives on entry): 0.5 sum |B X +
+ * b|^2 sampled every 20 iterations through the four stages (what the driver prints, :206-210). */
+typedef struct dpgo_dchordal_options {
+  int iters[4];      /* 100, 400, 150, 250 */
+  int local_iters;   /* 30 */
+  double reg_G;      /* 1e-12 (DChordal_types.h:50) */
+} dpgo_dchordal_options_t;
+void dpgo_dchordal_options_default(dpgo_dchordal_options_t *opt);
+int dpgo_group_dist_chordal_initialization(dpgo_group_t *grp, const dpgo_dchordal_options_t *opt, const double *X_local,
+                                           int ld_local, double *X, int ld, double *objectives, int *num_objectives);
 
 /* DPGOHash(node, measurements, options) for every node in node_ids -- C++/DPGO/src/DPGOHash.cpp:11-18,
  * C++/DPGO/src/DPGOProblem.cpp:11-125.  Fails (-1) when no HIP device is present: there is no CPU path. */

@@ -1,0 +1,93 @@
+"""GPU parity of the distributed chordal initialisation (C++/DChordal, dist_pgo.cpp:144-416): the HIP
+path through the C ABI against oracle/dchordal.py, stage by stage (the objectives the reference driver prints every
+20 iterations) and on the final initial guess."""
+import os
+
+import numpy as np
+import pytest
+
+import dpgo_amd
+from oracle import g2o as og
+from oracle.dchordal import dist_chordal_initialization, local_solve
+from oracle.hash import Options as OOptions
+from oracle.problem import LOSS_NONE
+from oracle.star import GlobalProblem, chordal_initialization, DPGOStar as ODPGOStar
+
+pytestmark = pytest.mark.gpu
+
+
+def _global(Xs, g_index, num_poses, d):
+    X = np.zeros(((d + 1) * num_poses, d))
+    for a, Xa in enumerate(Xs):
+        n0, o = len(g_index[a]), g_index[a][0]
+        X[o:o + n0] = Xa[:n0]
+        X[num_poses + d * o: num_poses + d * (o + n0)] = Xa[n0:(d + 1) * n0]
+    return X
+
+
+@pytest.mark.parametrize("name,nn", [("M3500", 4), ("smallGrid3D", 2), ("torus3D", 3)])
+def test_stages_match_oracle_from_the_same_local_solutions(fixtures_dir, name, nn):
+    """Same stage-0 poses in, then every stage must agree: the sampled objectives 0.5 sum |B X + b|^2 of the four
+    stages to 1e-7 relative, the resulting initial guess to 1e-7 absolute."""
+    path = os.path.join(fixtures_dir, name + ".g2o")
+    num_poses, mm = og.read_g2o_file(path)
+    _, meas, g_index = og.partition_measurements(num_poses, mm, nn)
+    loc = [local_solve(a, meas[a], iters=5) for a in range(nn)]
+    tr = {}
+    Xo = _global(dist_chordal_initialization(meas, local_solutions=loc, trace=tr), g_index, num_poses, mm.d)
+    G = dpgo_amd.read_g2o(path, nn)
+    grp = dpgo_amd.NodeGroup(G, range(nn), dpgo_amd.Options.driver(LOSS_NONE, True))
+    X, obj = grp.dist_chordal_initialization(X_local=_global(loc, g_index, num_poses, mm.d))
+    ref = np.concatenate([tr[k] for k in ("objective_reduced_R", "objective_R", "objective_reduced_t", "objective_t")])
+    assert obj.shape == ref.shape == (5 + 20 + 8 + 13,)
+    np.testing.assert_allclose(obj, ref, rtol=1e-7, atol=1e-9 * ref.max())
+    np.testing.assert_allclose(X, Xo, atol=1e-7 * max(1.0, np.abs(Xo).max()))
+    R = X[num_poses:].reshape(num_poses, mm.d, mm.d)
+    np.testing.assert_allclose(np.einsum("nij,nkj->nik", R, R), np.broadcast_to(np.eye(mm.d), R.shape), atol=1e-12)
+
+
+@pytest.mark.parametrize("name,nn", [("M3500", 4), ("smallGrid3D", 2)])
+def test_whole_pipeline_with_its_own_stage0(fixtures_dir, name, nn):
+    """Stage 0 on the device (chordal initialisation of each node's subgraph + refined MM-PGO iterations) against
+    the oracle's stage 0, through all four stages: initial guess within 1e-6, objective no worse than the centralised
+    chordal initialisation's by more than 5 %."""
+    path = os.path.join(fixtures_dir, name + ".g2o")
+    num_poses, mm = og.read_g2o_file(path)
+    _, meas, g_index = og.partition_measurements(num_poses, mm, nn)
+    Xo = _global(dist_chordal_initialization(meas), g_index, num_poses, mm.d)
+    G = dpgo_amd.read_g2o(path, nn)
+    grp = dpgo_amd.NodeGroup(G, range(nn), dpgo_amd.Options.driver(LOSS_NONE, True))
+    X, _ = grp.dist_chordal_initialization()
+    np.testing.assert_allclose(X, Xo, atol=1e-6 * max(1.0, np.abs(Xo).max()))
+    star = GlobalProblem(num_poses, mm, nn, OOptions.driver(LOSS_NONE, True))
+    assert star.evaluate_f(X) <= 1.05 * star.evaluate_f(chordal_initialization(num_poses, mm))
+
+
+def test_baseline_config5_as_written(fixtures_dir):
+    """BASELINE config 5: M3500 (SE(2)), distributed chordal warm start, AMM-PGO*, 4 nodes: the device run from the
+    device's own warm start follows the oracle's AMM-PGO* run from the oracle's warm start."""
+    path = os.path.join(fixtures_dir, "M3500.g2o")
+    num_poses, mm = og.read_g2o_file(path)
+    _, meas, g_index = og.partition_measurements(num_poses, mm, 4)
+    Xo = _global(dist_chordal_initialization(meas), g_index, num_poses, mm.d)
+    orc = ODPGOStar(path, 4, OOptions.driver(LOSS_NONE, True), mm=mm, num_poses=num_poses)
+    orc.initialize(Xo)
+    G = dpgo_amd.read_g2o(path, 4)
+    star = dpgo_amd.DPGOStar(G, dpgo_amd.Options.driver(LOSS_NONE, True))
+    X0, _ = star.group.dist_chordal_initialization()
+    assert star.initialize(X0) == 0
+    for it in range(20):
+        orc.step()
+        assert star.step() == 0
+        np.testing.assert_allclose(star.state()["fobj"], orc.fobj, rtol=1e-6, err_msg="it=%d" % it)
+
+
+def test_error_conventions(fixtures_dir):
+    G = dpgo_amd.read_g2o(os.path.join(fixtures_dir, "smallGrid3D.g2o"), 2)
+    grp = dpgo_amd.NodeGroup(G, [0], dpgo_amd.Options.driver(LOSS_NONE, True))
+    with pytest.raises(RuntimeError):
+        grp.dist_chordal_initialization()          # not every node in the group
+    G1 = dpgo_amd.read_g2o(os.path.join(fixtures_dir, "smallGrid3D.g2o"), 1)
+    grp1 = dpgo_amd.NodeGroup(G1, [0], dpgo_amd.Options.driver(LOSS_NONE, True))
+    with pytest.raises(RuntimeError):
+        grp1.dist_chordal_initialization()         # num_nodes = 1: the reference's own trap
