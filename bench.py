@@ -103,25 +103,16 @@ def main():
     host_staged = args.backend == "gloo"
     do_exchange = world > 1 or args.force_exchange
     if do_exchange:
+        # control plane (rendezvous, the RCCL unique id, barriers, the max over ranks of the timing): gloo over TCP.
+        # data plane: the library's own RCCL communicator (dpgo_comm_*), or -- with --backend gloo -- host-staged
+        # gloo collectives, which let several ranks share one GPU (tests on a 1-GPU box)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if not host_staged:
-            try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-                probe = torch.ones(1, device="cuda")
-                dist.all_reduce(probe)              # first collective: surfaces a broken RCCL set-up now, not mid-run
-                torch.cuda.synchronize()
-            except Exception as e:                  # keep the run alive: stage the (small) exchange through the host
-                sys.stderr.write("[bench] RCCL unavailable (%r): falling back to the gloo host-staged exchange\n" % (e,))
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                host_staged = True
-        if host_staged:
-            dist.init_process_group("gloo")
-    cdev = "cpu" if host_staged else "cuda"
+        dist.init_process_group("gloo")
+    cdev = "cpu"
 
     # ---- set-up (untimed): graph, partition, chordal initialisation, operators, factorizations
     t0 = time.time()
@@ -144,10 +135,26 @@ def main():
         raise SystemExit("initialize failed")
 
     RS = (G.d + 1) * G.d
-    send = gathered = ext = None
-    if do_exchange:
-        # everything the exchange enqueues goes on the group's own stream: the step stays stream-ordered, the
-        # host never waits for the collective
+    send = gathered = ext = comm = None
+    if do_exchange and not host_staged:
+        # RCCL behind the C ABI; the ranks agree on the outcome, so that nobody is left waiting in a collective
+        def bcast(raw):
+            box = [raw]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        try:
+            comm = dpgo_amd.Comm(grp, rank, world, bcast if world > 1 else None)
+            ok = 1
+        except Exception as e:
+            sys.stderr.write("[bench] rank %d: RCCL communicator failed (%r)\n" % (rank, e))
+            ok = 0
+        vote = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+        if int(vote.item()) == 0:
+            sys.stderr.write("[bench] RCCL unavailable on some rank: falling back to the gloo host-staged exchange\n")
+            comm = None
+            host_staged = True
+    if do_exchange and host_staged:
         ext = torch.cuda.ExternalStream(grp.stream())
         keys = grp.sent_keys()
         allkeys = [None] * world
@@ -156,22 +163,20 @@ def main():
         grp.set_recv_layout(stride, [(np.asarray(k[0], np.int32), np.asarray(k[1], np.int32)) for k in allkeys])
         send = torch.zeros(stride * RS, dtype=torch.float64, device="cuda")
         gathered = torch.zeros(world * stride * RS, dtype=torch.float64, device="cuda")
-        if host_staged:
-            send_h = torch.zeros(stride * RS, dtype=torch.float64)
-            gathered_h = torch.zeros(world * stride * RS, dtype=torch.float64)
+        send_h = torch.zeros(stride * RS, dtype=torch.float64)
+        gathered_h = torch.zeros(world * stride * RS, dtype=torch.float64)
         torch.cuda.synchronize()
 
     def exchange():
+        if comm is not None:
+            comm.exchange()            # pack -> ncclAllGather -> unpack on the communicator's stream; update() joins it
         grp.communicate_local()
-        if do_exchange:
+        if do_exchange and host_staged:
             with torch.cuda.stream(ext):
                 grp.pack_sent(send.data_ptr())
-                if host_staged:
-                    send_h.copy_(send)
-                    dist.all_gather_into_tensor(gathered_h, send_h)
-                    gathered.copy_(gathered_h)
-                else:
-                    dist.all_gather_into_tensor(gathered, send)  # RCCL over xGMI; the stream waits, not the host
+                send_h.copy_(send)
+                dist.all_gather_into_tensor(gathered_h, send_h)
+                gathered.copy_(gathered_h)
                 grp.unpack_recv(gathered.data_ptr())
 
     def step():
@@ -285,7 +290,8 @@ def main():
                        "iterations_before_timed_region": args.warmup,
                        "refined_nodes_last_step": refined, "tnt_inner_iterations_last_step": inner},
             "objective_2F": 2 * fsum,
-            "exchange": None if not do_exchange else ("gloo, staged through the host" if host_staged else "RCCL all-gather on the group's stream"),
+            "exchange": None if not do_exchange else ("gloo, staged through the host" if host_staged else
+                                                     "RCCL all-gather behind the C ABI (dpgo_comm_exchange) on the communicator's stream, joined in update()"),
             "setup_s": {"graph+chordal_init": t_init, "operators+factorizations": t_group},
             "solver": grp.solver_stats(),
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
@@ -293,6 +299,8 @@ def main():
         if convergence is not None:
             out["convergence"] = convergence
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if comm is not None:
+        comm.close()
     if do_exchange:
         dist.destroy_process_group()
 

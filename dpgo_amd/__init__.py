@@ -111,6 +111,15 @@ SYMBOLS = {
     "dpgo_group_evaluate": (C.c_int, [C.c_void_p, _DP, C.c_int, _DP, _DP, _DP, C.c_int]),
     "dpgo_group_set_options": (C.c_int, [C.c_void_p, C.POINTER(Options)]),
     "dpgo_group_get_options": (C.c_int, [C.c_void_p, C.POINTER(Options)]),
+    "dpgo_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "dpgo_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "dpgo_comm_free": (None, [C.c_void_p]),
+    "dpgo_comm_exchange": (C.c_int, [C.c_void_p]),
+    "dpgo_comm_allreduce_sum": (C.c_int, [C.c_void_p, _DP, C.c_long]),
+    "dpgo_comm_barrier": (C.c_int, [C.c_void_p]),
+    "dpgo_host_pack_sent": (C.c_int, [C.c_void_p, _IP, C.c_int, _DP, C.c_int, _DP]),
+    "dpgo_host_unpack_recv": (C.c_int, [C.c_void_p, _IP, C.c_int, C.c_int, C.c_int, C.c_int, _IP, _IP, _IP, _DP, _DP,
+                                        C.c_int]),
     "dpgo_dchordal_options_default": (None, [C.c_void_p]),
     "dpgo_group_dist_chordal_initialization": (C.c_int, [C.c_void_p, C.c_void_p, _DP, C.c_int, _DP, C.c_int, _DP, _IP]),
     "dpgo_group_create": (C.c_int, [C.c_void_p, _IP, C.c_int, C.POINTER(Options), C.c_int, C.POINTER(C.c_void_p)]),
@@ -247,6 +256,33 @@ class Graph:
             return lib().dpgo_write_g2o(self._h, None, 0, os.fsencode(filename))
         X, ld = _fcol(X)
         return lib().dpgo_write_g2o(self._h, _dp(X), ld, os.fsencode(filename))
+
+    def host_pack_sent(self, node_ids, X):
+        """Records of the poses a group hosting node_ids exports (key order), from a global X: what
+        dpgo_group_pack_sent puts into the device buffer (host version, no GPU)."""
+        ids = np.asarray(list(node_ids), np.int32)
+        (sn, _), _ = self.exchange_plan(ids)
+        X, ld = _fcol(X)
+        buf = np.zeros(max(len(sn), 1) * (self.d + 1) * self.d)
+        n = lib().dpgo_host_pack_sent(self._h, _ip(ids), len(ids), _dp(X), ld, _dp(buf))
+        if n < 0:
+            raise RuntimeError("dpgo_host_pack_sent failed")
+        return buf[:n * (self.d + 1) * self.d]
+
+    def host_unpack_recv(self, node_ids, node, stride, keys_per_rank, gathered, Z):
+        """Fill the neighbour rows of node's Z ((d+1)(n0+n1) x d, F order) from the gathered buffers (host version
+        of dpgo_group_unpack_recv); returns the number of poses written."""
+        ids = np.asarray(list(node_ids), np.int32)
+        counts = np.asarray([len(k[0]) for k in keys_per_rank], np.int32)
+        nodes = np.ascontiguousarray(np.concatenate([np.asarray(k[0], np.int32) for k in keys_per_rank]), np.int32)
+        poses = np.ascontiguousarray(np.concatenate([np.asarray(k[1], np.int32) for k in keys_per_rank]), np.int32)
+        gathered = np.ascontiguousarray(gathered, np.float64)
+        assert Z.flags.f_contiguous
+        n = lib().dpgo_host_unpack_recv(self._h, _ip(ids), len(ids), int(node), len(counts), int(stride), _ip(counts),
+                                        _ip(nodes), _ip(poses), _dp(gathered), _dp(Z), Z.shape[0])
+        if n < 0:
+            raise RuntimeError("dpgo_host_unpack_recv failed")
+        return n
 
     def chordal_initialization(self):
         """Centralised chordal init (dist_pgo.cpp:416-444): X, (d+1)N x d, reference layout."""
@@ -484,6 +520,48 @@ class NodeGroup:
         if lib().dpgo_group_debug_apply(self._h, k, op.encode(), _dp(X), ld, _dp(out), out.shape[0]) != 0:
             raise RuntimeError("debug_apply(%s) failed" % op)
         return out
+
+
+class Comm:
+    """The RCCL communicator of one group (one process per GPU): dpgo_comm_* of include/dpgo_amd.h.  `bcast`
+    carries the 128-byte unique id from rank 0 to the others: a function bytes -> bytes (e.g. through
+    torch.distributed's gloo store, MPI, a file); with one rank it is not needed."""
+
+    def __init__(self, group, rank, nranks, bcast=None):
+        self.group, self.rank, self.nranks = group, rank, nranks
+        idb = C.create_string_buffer(128)
+        if rank == 0 and lib().dpgo_comm_unique_id(idb) != 0:
+            raise RuntimeError("dpgo_comm_unique_id failed (RCCL not available)")
+        raw = bytes(idb.raw)
+        if nranks > 1:
+            if bcast is None:
+                raise ValueError("nranks > 1 needs a broadcast function for the unique id")
+            raw = bcast(raw)
+        idb = C.create_string_buffer(raw, 128)
+        h = C.c_void_p()
+        if lib().dpgo_comm_create(group._h, rank, nranks, idb, C.byref(h)) != 0:
+            raise RuntimeError("dpgo_comm_create failed")
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().dpgo_comm_free(self._h)
+            self._h = None
+
+    def close(self):
+        self.__del__()
+
+    def exchange(self):
+        return lib().dpgo_comm_exchange(self._h)
+
+    def allreduce_sum(self, vals):
+        a = np.ascontiguousarray(vals, np.float64).ravel().copy()
+        if lib().dpgo_comm_allreduce_sum(self._h, _dp(a), len(a)) != 0:
+            raise RuntimeError("dpgo_comm_allreduce_sum failed")
+        return a
+
+    def barrier(self):
+        return lib().dpgo_comm_barrier(self._h)
 
 
 class DPGOHash:

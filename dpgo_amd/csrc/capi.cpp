@@ -10,6 +10,7 @@
 #include <numeric>
 #include <set>
 
+#include "comm.h"
 #include "group.h"
 
 namespace dpgo {
@@ -37,6 +38,9 @@ struct dpgo_graph {
 struct dpgo_group {
   dpgo::Group *grp = nullptr;
   std::vector<int> all;
+};
+struct dpgo_comm {
+  dpgo::Comm *c = nullptr;
 };
 
 static dpgo::Options to_cpp(const dpgo_options_t &o) {
@@ -545,6 +549,101 @@ int dpgo_write_g2o(const dpgo_graph_t *g, const double *X, int ld, const char *f
   }
   fclose(fp);
   return 0;
+}
+
+// ---- RCCL exchange (comm.cpp) ----
+int dpgo_comm_unique_id(void *id128) {
+  if (!id128) return -1;
+  return guarded([&] { return dpgo::Comm::unique_id(id128); });
+}
+
+int dpgo_comm_create(dpgo_group_t *h, int rank, int nranks, const void *id128, dpgo_comm_t **out) {
+  if (!out) return -1;
+  *out = nullptr;
+  if (!h || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return -1;
+  return guarded([&] {
+    auto *c = new dpgo_comm();
+    c->c = new dpgo::Comm(h->grp, rank, nranks, id128);
+    if (!c->c->ok()) {
+      delete c->c;
+      delete c;
+      return -1;
+    }
+    *out = c;
+    return 0;
+  });
+}
+
+void dpgo_comm_free(dpgo_comm_t *c) {
+  if (!c) return;
+  (void)guarded([&] { delete c->c; return 0; });
+  delete c;
+}
+
+int dpgo_comm_exchange(dpgo_comm_t *c) {
+  if (!c) return -1;
+  return guarded([&] { return c->c->exchange(); });
+}
+
+int dpgo_comm_allreduce_sum(dpgo_comm_t *c, double *vals, long n) {
+  if (!c || !vals || n < 0) return -1;
+  return guarded([&] { return n <= 4096 ? c->c->allreduce(vals, (int)n) : c->c->allreduce_large(vals, (size_t)n); });
+}
+
+int dpgo_comm_barrier(dpgo_comm_t *c) {
+  if (!c) return -1;
+  return guarded([&] { return c->c->barrier(); });
+}
+
+int dpgo_host_pack_sent(const dpgo_graph_t *g, const int *node_ids, int num_local, const double *X, int ld, double *buf) {
+  if (!g || !node_ids || num_local <= 0 || !X || !buf) return -1;
+  const int d = g->g.d, N = g->g.num_poses, RS = (d + 1) * d;
+  if (ld < (d + 1) * N) return -1;
+  int cnt[2];
+  if (dpgo_graph_exchange_plan(g, node_ids, num_local, nullptr, nullptr, nullptr, nullptr, cnt) != 0) return -1;
+  std::vector<int> sn(cnt[0]), sp(cnt[0]), rn(cnt[1]), rp(cnt[1]);
+  if (dpgo_graph_exchange_plan(g, node_ids, num_local, sn.data(), sp.data(), rn.data(), rp.data(), cnt) != 0) return -1;
+  for (int k = 0; k < cnt[0]; k++) {
+    const int gid = g->g.g_index[sn[k]].at(sp[k]);
+    for (int c = 0; c < d; c++) {
+      buf[(size_t)k * RS + c] = X[(size_t)c * ld + gid];
+      for (int r = 0; r < d; r++) buf[(size_t)k * RS + d + r * d + c] = X[(size_t)c * ld + N + gid * d + r];
+    }
+  }
+  return cnt[0];
+}
+
+int dpgo_host_unpack_recv(const dpgo_graph_t *g, const int *node_ids, int num_local, int node, int nranks, int stride,
+                          const int *counts, const int *nodes, const int *poses, const double *gathered, double *Z, int ldz) {
+  if (!g || !node_ids || !counts || !nodes || !poses || !gathered || !Z || nranks < 1 || stride < 1) return -1;
+  dpgo::DataInfo info;
+  if (node_info(g, node, info) != 0) return -1;
+  const int d = g->g.d, RS = (d + 1) * d, n0 = info.n[0], n1 = info.n[1];
+  if (ldz < (d + 1) * (n0 + n1)) return -1;
+  std::set<int> local(node_ids, node_ids + num_local);
+  std::map<std::pair<int, int>, int> slot;
+  int off = 0;
+  for (int r = 0; r < nranks; r++) {
+    for (int k = 0; k < counts[r]; k++) slot[{nodes[off + k], poses[off + k]}] = r * stride + k;
+    off += counts[r];
+  }
+  int written = 0;
+  for (int k = 0; k < n1; k++) {
+    const auto key = info.nbr_key[k];
+    if (local.count(key.first)) continue;
+    auto it = slot.find(key);
+    if (it == slot.end()) {
+      fprintf(stderr, "[dpgo_amd] ERROR: No information for pose [%d, %d].\n", key.first, key.second);
+      return -1;
+    }
+    const double *rec = gathered + (size_t)it->second * RS;
+    for (int c = 0; c < d; c++) {
+      Z[(size_t)c * ldz + (d + 1) * n0 + k] = rec[c];
+      for (int r = 0; r < d; r++) Z[(size_t)c * ldz + (d + 1) * n0 + n1 + k * d + r] = rec[d + r * d + c];
+    }
+    written++;
+  }
+  return written;
 }
 
 void dpgo_dchordal_options_default(dpgo_dchordal_options_t *o) {

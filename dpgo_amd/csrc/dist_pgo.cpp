@@ -8,8 +8,12 @@
 //   stdout     "<iter>: <fobj> <grad>" with 20 digits, then the final summary         (:493-494, 533-536)
 //   files      results_chordal_<N>_<amm|mm>.txt  (iter time fobj grad, 16 digits)     (:538-552)
 //              estimates_<loss>.txt  (X with t <- t - t_0, X <- X R_0)                (:554-567)
-// All nodes are hosted by one GPU (--gpu).  fobj = 2 F and grad = 2 |grad F| come from the per-node
-// device reductions (sum_a fobj^a = F, sum_a |Proj(Dfobj^a)|^2 = |grad F|^2; DPGOStar.cpp:713-829).
+// One process hosts all nodes on one GPU (--gpu), or -- one process per GPU -- rank r of n (--rank / --world, or
+// RANK / WORLD_SIZE / LOCAL_RANK from a launcher) hosts nodes [r num_nodes / n, (r + 1) num_nodes / n) and the
+// boundary poses travel by RCCL (dpgo_comm_exchange); the 128-byte RCCL id goes from rank 0 to the others through
+// the file --rdv (a path all ranks of the box can see).  fobj = 2 F and grad = 2 |grad F| come from the per-node
+// device reductions (sum_a fobj^a = F, sum_a |Proj(Dfobj^a)|^2 = |grad F|^2; DPGOStar.cpp:713-829), summed over
+// the ranks.
 // --dist_init true runs the distributed chordal initialisation (:144-416, C++/DChordal) through
 // dpgo_group_dist_chordal_initialization and prints the stage objectives the reference prints every 20
 // iterations (:206-210); its stage 0 (a per-node SE-Sync solve in the reference) is the library's stand-in.
@@ -20,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dpgo_amd.h"
@@ -28,8 +33,10 @@ static bool parse_bool(const char *s) { return !(strcmp(s, "false") == 0 || strc
 
 int main(int argc, char **argv) {
   std::string dataset, loss_type = "trivial";
-  int num_nodes = -1, iters = 1000, gpu = 0;
+  int num_nodes = -1, iters = 1000, gpu = -1;
   bool dist_init = true, accelerated = true, save = true;
+  int rank = getenv("RANK") ? atoi(getenv("RANK")) : 0, world = getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1;
+  std::string rdv = std::string("/tmp/dpgo_rdv_") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0");
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
     auto val = [&](const char *name) -> const char * {
@@ -50,7 +57,12 @@ int main(int argc, char **argv) {
     else if (const char *v = val("--accelerated")) accelerated = parse_bool(v);
     else if (const char *v = val("--save")) save = parse_bool(v);
     else if (const char *v = val("--gpu")) gpu = atoi(v);
+    else if (const char *v = val("--rank")) rank = atoi(v);
+    else if (const char *v = val("--world")) world = atoi(v);
+    else if (const char *v = val("--rdv")) rdv = v;
   }
+  if (gpu < 0) gpu = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : (world > 1 ? rank : 0);
+  if (world < 1 || rank < 0 || rank >= world) { fprintf(stderr, "Inconsistent --rank / --world.\n"); return -1; }
   if (dataset.empty()) { fprintf(stderr, "No dataset has been specfied.\n"); return -1; }
   if (num_nodes < 1) { fprintf(stderr, "No number of nodes has been specfied.\n"); return -1; }
   int loss;
@@ -67,56 +79,87 @@ int main(int argc, char **argv) {
   dpgo_options_driver(&opt, loss, accelerated);
   const int ld = (d + 1) * N;
   std::vector<double> X((size_t)ld * d, 0.0);
-  std::vector<int> ids(num_nodes);
-  for (int a = 0; a < num_nodes; a++) ids[a] = a;
+  if (num_nodes % world != 0) { fprintf(stderr, "The number of nodes must be a multiple of the number of ranks.\n"); return -1; }
+  const int per = num_nodes / world;
+  std::vector<int> ids(per), all_ids(num_nodes);
+  for (int a = 0; a < per; a++) ids[a] = rank * per + a;
+  for (int a = 0; a < num_nodes; a++) all_ids[a] = a;
+  const bool root = rank == 0;
   dpgo_group_t *grp = nullptr;
-  if (dpgo_group_create(g, ids.data(), num_nodes, &opt, gpu, &grp) != 0) return -1;
+  if (dpgo_group_create(g, ids.data(), per, &opt, gpu, &grp) != 0) return -1;
+  dpgo_comm_t *comm = nullptr;
+  if (world > 1 || getenv("DPGO_FORCE_COMM")) {   // (DPGO_FORCE_COMM: a world of one rank still runs the whole protocol)
+    // the RCCL id: rank 0 writes it, the others wait for the file
+    unsigned char id[128];
+    if (root) {
+      if (dpgo_comm_unique_id(id) != 0) return -1;
+      FILE *f = fopen((rdv + ".tmp").c_str(), "wb");
+      if (!f || fwrite(id, 1, 128, f) != 128) return -1;
+      fclose(f);
+      if (rename((rdv + ".tmp").c_str(), rdv.c_str()) != 0) return -1;
+    } else {
+      FILE *f = nullptr;
+      for (int tries = 0; tries < 6000 && !(f = fopen(rdv.c_str(), "rb")); tries++)
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+      if (!f || fread(id, 1, 128, f) != 128) { fprintf(stderr, "No rendezvous file %s.\n", rdv.c_str()); return -1; }
+      fclose(f);
+    }
+    if (dpgo_comm_create(grp, rank, world, id, &comm) != 0) return -1;
+    dpgo_comm_barrier(comm);
+    if (root) remove(rdv.c_str());
+  }
   if (dist_init) {
+    // every node of the graph takes part in the distributed initialisation; with several ranks each computes it on
+    // its own GPU with a temporary group over all nodes (set-up, deterministic: the ranks agree to the last bit)
+    dpgo_group_t *ig = grp;
+    if (world > 1 && dpgo_group_create(g, all_ids.data(), num_nodes, &opt, gpu, &ig) != 0) return -1;
     dpgo_dchordal_options_t co;
     dpgo_dchordal_options_default(&co);
     int cap = 0;
     for (int k = 0; k < 4; k++) cap += (co.iters[k] + 19) / 20;
     std::vector<double> obj(cap);
-    if (dpgo_group_dist_chordal_initialization(grp, &co, nullptr, 0, X.data(), ld, obj.data(), &cap) != 0) return -1;
+    if (dpgo_group_dist_chordal_initialization(ig, &co, nullptr, 0, X.data(), ld, obj.data(), &cap) != 0) return -1;
+    if (ig != grp) dpgo_group_free(ig);
     const char *names[4] = {"Initialize the reduced rotation", "Initialize the rotation", "Initialize the reduced translation",
                             "Initialize the translation"};
     int at = 0;
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < 4 && root; k++) {
       printf("===============================================\n%s\n-----------------------------------------------\n", names[k]);
       for (int it = 0; it < co.iters[k]; it += 20) printf("%d: %.16g\n", it, obj[at++]);
     }
   } else {
-    printf("===============================================\nInitialization\n-----------------------------------------------\n");
+    if (root) printf("===============================================\nInitialization\n-----------------------------------------------\n");
     if (dpgo_chordal_initialization(g, X.data(), ld) != 0) return -1;
   }
   if (dpgo_group_initialize_global(grp, X.data(), ld) != 0) return -1;
   if (dpgo_group_update(grp, nullptr, 0) != 0) return -1;
 
   auto evaluate = [&](double &fobj, double &grad) {
-    double f = 0, g2 = 0;
-    for (int a = 0; a < num_nodes; a++) {
+    double v[2] = {0, 0};
+    for (int a = 0; a < per; a++) {
       dpgo_results_t r;
       dpgo_group_results(grp, a, &r);
-      f += r.fobj;
-      g2 += r.gradFnorm * r.gradFnorm;
+      v[0] += r.fobj;
+      v[1] += r.gradFnorm * r.gradFnorm;
     }
-    fobj = 2 * f;
-    grad = 2 * std::sqrt(g2);
+    if (comm) dpgo_comm_allreduce_sum(comm, v, 2);
+    fobj = 2 * v[0];
+    grad = 2 * std::sqrt(v[1]);
   };
   double fobj, grad, time = 0;
   evaluate(fobj, grad);
   std::vector<std::vector<double>> results;
   results.push_back({0, 0, fobj, grad});
-  printf("===============================================\nDistributed PGO\n-----------------------------------------------\n");
+  if (root) printf("===============================================\nDistributed PGO\n-----------------------------------------------\n");
   using clk = std::chrono::steady_clock;
   for (int iter = 0; iter < iters; iter++) {
-    printf("%d: %.20g %.20g\n", iter, fobj, grad);
+    if (root) printf("%d: %.20g %.20g\n", iter, fobj, grad);
     auto t0 = clk::now();
     if (dpgo_group_iterate(grp, nullptr, 0) != 0) return -1;
     dpgo_group_sync(grp);
     time += std::chrono::duration<double>(clk::now() - t0).count();
+    if (comm && dpgo_comm_exchange(comm) != 0) return -1;   // neighbours on other GPUs: RCCL, joined by update()
     dpgo_group_communicate_local(grp);
-    dpgo_group_sync(grp);
     t0 = clk::now();
     if (dpgo_group_update(grp, nullptr, 0) != 0) return -1;
     dpgo_group_sync(grp);
@@ -124,15 +167,20 @@ int main(int argc, char **argv) {
     evaluate(fobj, grad);
     results.push_back({double(iter) + 1, time, fobj, grad});
   }
-  printf("---------------------------------------\nfinal objective: %.20g\nfinal gradient: %.20g\ntime: %.20g s/node.\n", fobj,
-         grad, time / num_nodes);
+  if (root)
+    printf("---------------------------------------\nfinal objective: %.20g\nfinal gradient: %.20g\ntime: %.20g s/node.\n", fobj,
+           grad, time / per);
   if (save) {
+    std::fill(X.begin(), X.end(), 0.0);
+    dpgo_group_scatter_global(grp, X.data(), ld);
+    if (comm) dpgo_comm_allreduce_sum(comm, X.data(), (long)X.size());   // every rank contributes its own poses
+  }
+  if (save && root) {
     const std::string resfile = "results_chordal_" + std::to_string(num_nodes) + "_" + (accelerated ? "amm" : "mm") + ".txt";
     FILE *f = fopen(resfile.c_str(), "w");
     if (!f) return -1;
     for (const auto &r : results) fprintf(f, "%d %.16g %.16g %.16g\n", (int)r[0], r[1], r[2], r[3]);
     fclose(f);
-    dpgo_group_scatter_global(grp, X.data(), ld);
     // gauge fix (:554-558): t <- t - t_0 ; X <- X * R with R = X.middleRows(num_poses, d)^T
     std::vector<double> R(d * d), t0v(d);
     for (int c = 0; c < d; c++) {
@@ -155,6 +203,7 @@ int main(int argc, char **argv) {
     }
     fclose(f);
   }
+  if (comm) dpgo_comm_free(comm);
   dpgo_group_free(grp);
   dpgo_graph_free(g);
   return 0;

@@ -571,7 +571,10 @@ void Group::upload_bsr(const std::vector<const BsrMatrix *> &per_node, bool rows
   out.dev.val = out.val.p;
 }
 
-void Group::sync() const { HIP_CHECK(hipStreamSynchronize(st_)); }
+void Group::sync() const {
+  if (xchg_done_) HIP_CHECK(hipEventSynchronize(xchg_done_));   // an exchange on the communicator's stream
+  HIP_CHECK(hipStreamSynchronize(st_));
+}
 
 // The nodes the following launches work on: a bit mask passed to every kernel by value (no upload).
 void Group::set_mask(const std::vector<int> &locals) {
@@ -939,9 +942,15 @@ int Group::send(int a, int beta, double *msg, int ld) const {
   return 0;
 }
 
-int Group::pack_sent(double *dev_buf) {
-  launch_copy_indexed(d_, st_, (int)sent_rows_.size(), nullptr, sent_rows_dev_.p, Xk_.p, dev_buf);
+int Group::pack_sent(double *dev_buf, hipStream_t st) {
+  launch_copy_indexed(d_, st ? st : st_, (int)sent_rows_.size(), nullptr, sent_rows_dev_.p, Xk_.p, dev_buf);
   return 0;
+}
+
+void Group::join_exchange() {
+  if (!xchg_done_) return;
+  HIP_CHECK(hipStreamWaitEvent(st_, xchg_done_, 0));
+  xchg_done_ = nullptr;
 }
 
 int Group::set_recv_layout(int nranks, int stride, const int *counts, const int *nodes, const int *poses) {
@@ -969,8 +978,8 @@ int Group::set_recv_layout(int nranks, int stride, const int *counts, const int 
   return 0;
 }
 
-int Group::unpack_recv(const double *dev_gathered) {
-  launch_copy_indexed(d_, st_, (int)recv_dst_.n, recv_dst_.p, recv_src_.p, dev_gathered, Xk_.p);
+int Group::unpack_recv(const double *dev_gathered, hipStream_t st) {
+  launch_copy_indexed(d_, st ? st : st_, (int)recv_dst_.n, recv_dst_.p, recv_src_.p, dev_gathered, Xk_.p);
   return 0;
 }
 
@@ -1069,35 +1078,42 @@ int Group::update(const std::vector<int> &locals_in) {
     copy_rows(Dfp_.p, Dfc_.p, false);
     set_mask(locals);
   }
-  copy_rows(Zc_.p, Xk_.p, true);
+  // The new linearisation point needs the neighbours' poses, which may still be on their way (an exchange on the
+  // communicator's stream, comm.cpp).  What needs no neighbour row goes first -- X[iter] own rows and the product
+  // with G, a third of the surrogate build -- then the stream waits for the exchange and takes the neighbour rows.
   std::vector<int> first, later;
   for (int a : locals) ((res_[a].iters == 0 || star_) ? first : later).push_back(a);
+  copy_rows(Zc_.p, Xk_.p, false);
+  if (trivial)   // T1 = G Xak and <Xak, 1/2 G Xak>   (half of evaluate_G, DPGOProblem.cpp:180-205)
+    launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xak_.p, false, nullptr, T1_.p, Xak_.p, 0.5, nullptr, partials_.p, 5);
+  else           // T1 = G X and <X, 1/2 G X>
+    launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Zc_.p, false, nullptr, T1_.p, Zc_.p, 0.5, nullptr, partials_.p, 5);
+  join_exchange();
+  launch_copy_nbr_rows(d_, st_, T_, cur_mask_, Xk_.p, Zc_.p);
   if (trivial) {
-    // g = S Z  (evaluate_none_g_and_f0 / _f, DPGOProblem.cpp:269-287, 516-542)
-    launch_bsr(d_, st_, T_, false, cur_mask_, S_.dev, Zc_.p, false, nullptr, gc_.p, nullptr, 0, nullptr, nullptr, 0);
+    // g = S Z  (evaluate_none_g_and_f0 / _f, DPGOProblem.cpp:269-287, 516-542), with <Xak, g> alongside
+    launch_bsr(d_, st_, T_, false, cur_mask_, S_.dev, Zc_.p, false, nullptr, gc_.p, Xak_.p, 1.0, nullptr, partials_.p, 1);
     if (!first.empty()) {
       set_mask(first);
       launch_bsr(d_, st_, T_, true, cur_mask_, P0m_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 0);
-      // fobj = G(Xak | g, f0): slot 1; also Dfobj = g + G Xak
-      launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xak_.p, false, gc_.p, Dfc_.p, Xak_.p, 0.5, gc_.p, partials_.p, 1);
-      launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, Dfc_.p, nullptr, partials_.p, 2);
-      fetch(3, true);
+      // fobj = G(Xak | g, f0) = f0 + <Xak, g> + <Xak, 1/2 G Xak>: slots 1 and 5; Dfobj = g + G Xak
+      launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, partials_.p, 2, gc_.p, Dfc_.p);
+      fetch(6, true);
       for (int a : first) {
         const double f0 = scal(a, 0);
-        host_update_logic(a, f0 + scal(a, 1), f0, std::sqrt(scal(a, 2)));
+        host_update_logic(a, f0 + (scal(a, 1) + scal(a, 5)), f0, std::sqrt(scal(a, 2)));
       }
     }
     if (!later.empty()) {
       set_mask(later);
       launch_axpby(d_, st_, T_, true, cur_mask_, 1.0, Zc_.p, -1.0, Zp_.p, Tall_.p, 0);
       launch_bsr(d_, st_, T_, true, cur_mask_, Q_.dev, Tall_.p, false, nullptr, nullptr, Tall_.p, 0.5, nullptr, partials_.p, 0);
-      launch_bsr(d_, st_, T_, true, cur_mask_, P_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 1);
-      launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xak_.p, false, gc_.p, Dfc_.p, nullptr, 0, nullptr, nullptr, 0);
-      launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, Dfc_.p, nullptr, partials_.p, 2);
-      fetch(3, true);
+      launch_bsr(d_, st_, T_, true, cur_mask_, P_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 3);
+      launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, partials_.p, 2, gc_.p, Dfc_.p);
+      fetch(4, true);
       for (int a : later) {
         const double fobj = res_[a].Gk + scal(a, 0);
-        host_update_logic(a, fobj, fobj + scal(a, 1), std::sqrt(scal(a, 2)));
+        host_update_logic(a, fobj, fobj + scal(a, 3), std::sqrt(scal(a, 2)));
       }
     }
   } else {
@@ -1107,21 +1123,21 @@ int Group::update(const std::vector<int> &locals_in) {
       if (set.empty()) continue;
       set_mask(set);
       launch_inter(d_, st_, T_, cur_mask_, E_, opt_.loss, opt_.loss_reg, 0, pass == 1, Zc_.p, Zp_.p, Qd_.p, Dd_.p, DfE_.p,
-                   gc_.p, partials_.p);
-      launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Zc_.p, false, gc_.p, Dfc_.p, Zc_.p, 0.5, gc_.p, partials_.p, 2);
+                   gc_.p, partials_.p);   // slots 0, 1 and 2 = <X, g>
       if (pass == 0) launch_bdiag_dot(d_, st_, T_, cur_mask_, Dd_.p, Zc_.p, 0.5, DfE_.p, -1.0, partials_.p, 3);
-      launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, Dfc_.p, nullptr, partials_.p, 4);
-      fetch(5, true);
+      launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, partials_.p, 4, gc_.p, Dfc_.p);   // Dfobj = G X + g
+      fetch(6, true);
       for (int a : set) {
         NodeResults &r = res_[a];
         const double fobjE = 0.5 * scal(a, 0);
+        const double quad = scal(a, 2) + scal(a, 5);   // tr(X^T (g + 1/2 G X))
         double fobj, f;
         if (pass == 0) {
           f = 0.5 * fobjE + scal(a, 3);
-          fobj = f + scal(a, 2);
+          fobj = f + quad;
         } else {
           fobj = r.Gk - 0.5 * r.fobjE - 0.5 * scal(a, 1) + 0.5 * fobjE;
-          f = fobj - scal(a, 2);
+          f = fobj - quad;
         }
         r.fobjE = fobjE;
         host_update_logic(a, fobj, f, std::sqrt(scal(a, 4)));

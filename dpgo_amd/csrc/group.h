@@ -170,10 +170,15 @@ class Group {
   int star_branches() const { return star_branches_; }   // bit 0 pm, bit 1 mm, bit 2 phi fallback
   // boundary exchange across groups: records of the poses other groups need
   int num_sent() const { return (int)sent_rows_.size(); }
-  int pack_sent(double *dev_buf);                       // device buffer, num_sent()*RS doubles
+  // device buffer, num_sent()*RS doubles; st: the stream to enqueue on (default: the group's)
+  int pack_sent(double *dev_buf, hipStream_t st = nullptr);
   // counts[r] keys of rank r (concatenated in nodes/poses); slot of key k of rank r = r*stride + k
   int set_recv_layout(int nranks, int stride, const int *counts, const int *nodes, const int *poses);
-  int unpack_recv(const double *dev_gathered);          // gathered buffer of all groups
+  int unpack_recv(const double *dev_gathered, hipStream_t st = nullptr);   // gathered buffer of all groups
+  // an exchange running on another stream (comm.cpp): `done` is recorded behind its unpack.  update() queues the
+  // part of the surrogate build that needs no neighbour row, then makes the group's stream wait for it.
+  void set_pending_exchange(hipEvent_t done) { xchg_done_ = done; }
+  int device() const { return device_; }
   // AMM-PGO* across groups: the master's global objective needs the trial point's boundary poses of the other
   // groups (all-gather of `send` into `gathered`, stream-ordered on stream()) and sums of scalars over the groups
   typedef int (*AllGatherFn)(void *user);
@@ -245,6 +250,8 @@ class Group {
   DevBuf<double> Xk_, Zc_, Zp_, Y_, DfE_, Tall_;                 // P0+P1 rows
   DevBuf<double> Xak_, Xakh_, gc_, gp_, Dfc_, Dfp_, gx_, Dfx_, T1_;   // P0 rows
   DevBuf<double> tmp_[14];                                       // P0 rows, TNT work vectors
+  hipEvent_t xchg_done_ = nullptr;   // pending boundary exchange (not owned)
+  void join_exchange();              // the group's stream waits for it
   struct ChordalState;
   ChordalState *ch_ = nullptr;
   bool star_ = false;

@@ -104,7 +104,8 @@ void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, co
 
 // Robust inter-edge pass (B-form, DPGOProblem.cpp:634-725).
 //  mode 0 (update): all rows.  DfE <- B1^T W B1 Z; own rows also g <- DfE - D z.
-//     slot 0: sum of rho_e (tail incidences); if quad: slot 1 = sum tr(dZ^T (DfE_old + 1/2 Q dZ)).
+//     slot 0: sum of rho_e (tail incidences); if quad: slot 1 = sum tr(dZ^T (DfE_old + 1/2 Q dZ)); slot 2: <z, g> over
+//     own rows (always written: three consecutive slots).
 //  mode 1 (evaluate_g): own rows only, g <- (B1^T W B1 Z)_own - D z.
 void launch_inter(int d, hipStream_t st, const SegTable &T, NodeMask mask, const InterEdgesDev &E, int loss,
                   double loss_reg, int mode, bool quad, const double *Z, const double *Zprev,
@@ -146,8 +147,12 @@ void launch_cg_step(int d, hipStream_t st, const SegTable &T, NodeMask mask, con
 void launch_cg_init(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *grad, const double *pgrad,
                     double *s, double *hs, double *r, double *v, double *p);
 // gradF = [V.x ; Proj_R(V.Y)] (DPGOProblem.cpp:145-162); partial ||gradF||^2; out may be null
+// with add: the vector is V + add, stored to sum_out if given (Dfobj = G X + g from its two halves)
 void launch_tangent_full(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
-                         const double *V, double *out, double *partials, int slot);
+                         const double *V, double *out, double *partials, int slot, const double *add = nullptr,
+                         double *sum_out = nullptr);
+// dst = src on the neighbour rows only
+void launch_copy_nbr_rows(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *src, double *dst);
 // out.Y = Proj_R(in.Y), out.x = 0                                       (DPGOProblem.cpp:164-178)
 // with dotv: partial[slot] = <dotv.Y, out.Y> in the same pass
 void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,

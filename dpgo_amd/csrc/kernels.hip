@@ -468,7 +468,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask ma
   const Seg s = segs[SEGB];
   const bool active = node_on(mask, s.node);
   const bool own = SEGB < nseg_own;
-  double part[2] = {0.0, 0.0};
+  double part[3] = {0.0, 0.0, 0.0};   // sum rho ; the quadratic term ; <z, g> over own rows
   const int row = s.begin + threadIdx.x;
   if (active && row < s.end) {
     double zp[RS], acc[RS];
@@ -550,12 +550,17 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask ma
 #pragma unroll
       for (int k = 0; k < RS; k++) dz[k] = 0.0;
       blk_mul_acc<D, false>(Dd + (size_t)row * B * B, zp, dz);
+      double zg = 0;
 #pragma unroll
-      for (int k = 0; k < RS; k++) acc[k] -= dz[k];
+      for (int k = 0; k < RS; k++) {
+        acc[k] -= dz[k];
+        zg = fma(zp[k], acc[k], zg);
+      }
+      part[2] = zg;
       store_vec<RS>(g + (size_t)row * RS, acc);
     }
   }
-  block_store<2>(part, partial + SEGB, pstride);
+  block_store<3>(part, partial + SEGB, pstride);
 }
 
 // ---------------------------------------------------------------------------
@@ -889,7 +894,8 @@ __global__ __launch_bounds__(SEG_ROWS) void k_dots(const Seg *segs, NodeMask mas
 
 template <int D>
 __global__ __launch_bounds__(SEG_ROWS) void k_tangent_full(const Seg *segs, NodeMask mask, const double *X,
-                                                      const double *V, double *out, double *partial) {
+                                                      const double *V, const double *add, double *sum_out,
+                                                      double *out, double *partial) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
   const bool active = node_on(mask, s.node);
@@ -899,6 +905,13 @@ __global__ __launch_bounds__(SEG_ROWS) void k_tangent_full(const Seg *segs, Node
     double x[RS], v[RS], o[RS];
     load_vec<RS>(X + (size_t)row * RS, x);
     load_vec<RS>(V + (size_t)row * RS, v);
+    if (add) {   // the vector is V + add (and is wanted: Dfobj = G X + g)
+      double w[RS];
+      load_vec<RS>(add + (size_t)row * RS, w);
+#pragma unroll
+      for (int k = 0; k < RS; k++) v[k] += w[k];
+      if (sum_out) store_vec<RS>(sum_out + (size_t)row * RS, v);
+    }
 #pragma unroll
     for (int k = 0; k < D; k++) o[k] = v[k];
     tangent_proj<D>(x + D, v + D, o + D);
@@ -1664,12 +1677,20 @@ void launch_cg_init(int d, hipStream_t st, const SegTable &T, NodeMask mask, con
 }
 
 void launch_tangent_full(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
-                         const double *V, double *out, double *partials, int slot) {
+                         const double *V, double *out, double *partials, int slot, const double *add, double *sum_out) {
   if (T.nseg_own == 0) return;
   double *part = partials ? partials + (size_t)slot * T.nseg_all : nullptr;
-  ProfScope ps(PK_ROTOP, st, 2.0 * T.rows_own * 8.0 * (d + 1) * d);
+  ProfScope ps(PK_ROTOP, st, (add ? 4.0 : 2.0) * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_tangent_full<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, X,
-                                        V, out, part));
+                                        V, add, sum_out, out, part));
+}
+
+void launch_copy_nbr_rows(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *src, double *dst) {
+  const int nb = T.nseg_all - T.nseg_own;
+  if (nb <= 0) return;
+  ProfScope ps(PK_AXPBY, st, 2.0 * (T.rows_all - T.rows_own) * 8.0 * (d + 1) * d);
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_axpby<D, 0>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs + T.nseg_own, mask, 1.0, src,
+                                        0.0, nullptr, dst));
 }
 
 void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,

@@ -200,6 +200,34 @@ int dpgo_group_evaluate(dpgo_group_t *grp, const double *X, int ld, double *F, d
 int dpgo_group_set_options(dpgo_group_t *grp, const dpgo_options_t *opt);
 int dpgo_group_get_options(const dpgo_group_t *grp, dpgo_options_t *opt);
 
+/* ---- the exchange between GPUs: RCCL behind the C ABI (one process per GPU; replaces the in-process copies of
+ * DPGOHash::communicate, C++/DPGO/include/DPGO/DPGOHash.h:28-86, and the master's sums of DPGOStar.cpp:147-192).
+ * dpgo_comm_unique_id: ncclGetUniqueId on one rank; the caller carries the 128 bytes to the others (file, socket,
+ *   MPI, torch.distributed -- any channel).
+ * dpgo_comm_create: ncclCommInitRank + the exchange lay-out (the ranks all-gather their exported (node, pose) keys);
+ *   also connects the group's AMM-PGO* / global-evaluation collectives (dpgo_group_set_collectives) to RCCL.
+ * dpgo_comm_exchange: communicate() for neighbours hosted by other ranks -- pack, ncclAllGather, unpack on the
+ *   communicator's own stream; returns at once, the group's next update() joins it after queueing the part of the
+ *   surrogate build that needs no neighbour data.  Call after dpgo_group_iterate, every rank, every iteration.
+ * dpgo_comm_allreduce_sum: in-place sum of n host doubles over the ranks (bit-identical on every rank).
+ * The library binds RCCL at run time (librccl.so.1); these calls return -1 when it cannot be loaded. */
+typedef struct dpgo_comm dpgo_comm_t;
+int dpgo_comm_unique_id(void *id128);
+int dpgo_comm_create(dpgo_group_t *grp, int rank, int nranks, const void *id128, dpgo_comm_t **out);
+void dpgo_comm_free(dpgo_comm_t *comm);
+int dpgo_comm_exchange(dpgo_comm_t *comm);
+int dpgo_comm_allreduce_sum(dpgo_comm_t *comm, double *vals, long n);
+int dpgo_comm_barrier(dpgo_comm_t *comm);
+/* The same pack / unpack on host matrices (no GPU needed; what a host-staged transport or a test uses): records
+ * of the poses a group exports, in key order, from a global X ((d+1)N x d) into buf (count x (d+1)d doubles,
+ * [t | rows of R^T] per pose); and the neighbour rows of node `node` ((d+1)(n0+n1) x d matrix Z, DPGOHash::initialize
+ * lay-out) from the gathered buffers of all ranks (slot of key k of rank r = r * stride + k, as in
+ * dpgo_group_set_recv_layout).  Return the number of poses written, -1 on error. */
+int dpgo_host_pack_sent(const dpgo_graph_t *g, const int *node_ids, int num_local, const double *X, int ld, double *buf);
+int dpgo_host_unpack_recv(const dpgo_graph_t *g, const int *node_ids, int num_local, int node, int nranks, int stride,
+                          const int *counts, const int *nodes, const int *poses, const double *gathered, double *Z,
+                          int ldz);
+
 /* results().Xk / results().Xak -- DPGO_types.h:207-214 */
 int dpgo_group_get_Xk(const dpgo_group_t *grp, int local, double *X, int ld);
 int dpgo_group_get_Xak(const dpgo_group_t *grp, int local, double *X, int ld);

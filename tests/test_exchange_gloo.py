@@ -1,6 +1,7 @@
 """The N > 1 boundary exchange on CPU: two gloo processes, each hosting half of the nodes, run the
-same plan -> pack -> all_gather -> unpack protocol bench.py uses with RCCL, and must reproduce the
-neighbour rows the oracle's in-process communicate() (DPGOHash.h:28-86) produces."""
+plan -> pack -> all_gather -> unpack protocol of dpgo_comm_exchange with the library's own host packing
+(dpgo_host_pack_sent / dpgo_host_unpack_recv: same key order and slot lay-out as the device kernels), and must
+reproduce the neighbour rows the oracle's in-process communicate() (DPGOHash.h:28-86) produces."""
 import os
 import socket
 import sys
@@ -28,7 +29,7 @@ def _worker(rank, world, port, path, nn, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import dpgo_amd
     from oracle import g2o as og
-    from oracle.star import chordal_initialization
+    from oracle.star import chordal_initialization, DistPGO as ODistPGO
     G = dpgo_amd.read_g2o(path, nn)
     d, N = G.d, G.num_poses
     RS = (d + 1) * d
@@ -36,33 +37,37 @@ def _worker(rank, world, port, path, nn, out):
     mine = list(range(rank * per, (rank + 1) * per))
     (sn, sp_), (rn, rp) = G.exchange_plan(mine)
     num_poses, mm = og.read_g2o_file(path)
-    X = chordal_initialization(num_poses, mm) + 0.01 * rank * 0     # same X on both ranks
-    # pack: records of the exported poses, in key order (what dpgo_group_pack_sent does on the device)
-    def record(node, pose):
-        gid = G.node_offset(node) + pose
-        return np.concatenate([X[gid], X[N + gid * d: N + gid * d + d].ravel()])
+    X = chordal_initialization(num_poses, mm)                       # same X on both ranks
+    # pack with the LIBRARY's host packing (dpgo_host_pack_sent: the lay-out dpgo_group_pack_sent produces on the
+    # device), all-gather with gloo, unpack with the library (dpgo_host_unpack_recv)
     allkeys = [None] * world
     dist.all_gather_object(allkeys, (sn.tolist(), sp_.tolist()))
     stride = max(max(len(k[0]) for k in allkeys), 1)
     send = torch.zeros(stride * RS, dtype=torch.float64)
-    for i, (a, p) in enumerate(zip(sn, sp_)):
-        send[i * RS:(i + 1) * RS] = torch.from_numpy(record(a, p))
+    packed = G.host_pack_sent(mine, X)
+    send[:len(packed)] = torch.from_numpy(packed)
     gathered = torch.zeros(world * stride * RS, dtype=torch.float64)
     dist.all_gather_into_tensor(gathered, send)
-    # unpack: slot of key k of rank r = r * stride + k (dpgo_group_set_recv_layout)
-    slot = {}
-    for r, (ns, ps) in enumerate(allkeys):
-        for k, key in enumerate(zip(ns, ps)):
-            slot[key] = r * stride + k
-    ok = True
-    for a, p in zip(rn.tolist(), rp.tolist()):
-        got = gathered[slot[(a, p)] * RS:(slot[(a, p)] + 1) * RS].numpy()
-        ok = ok and np.array_equal(got, record(a, p))
+    # the oracle's in-process communicate() gives the neighbour rows every node must end up with
+    orc = ODistPGO(path, nn, X0=X, mm=mm, num_poses=num_poses)
+    ok, imported = True, 0
+    for a in mine:
+        n0, n1, _, _ = G.node_sizes(a)
+        Z = np.zeros(((d + 1) * (n0 + n1), d), order="F")
+        imported += G.host_unpack_recv(mine, a, stride, allkeys, gathered.numpy(), Z)
+        want = orc.nodes[a].results.Xk
+        nb_node, _ = G.node_neighbours(a)
+        for k in range(n1):
+            if nb_node[k] in mine:
+                continue                                            # hosted by this rank: dpgo_group_communicate_local
+            ok = ok and np.array_equal(Z[(d + 1) * n0 + k], want[(d + 1) * n0 + k])
+            r0 = (d + 1) * n0 + n1 + k * d
+            ok = ok and np.array_equal(Z[r0:r0 + d], want[r0:r0 + d])
     # every imported key must be exported by exactly the rank that hosts its node
     for a, p in zip(rn.tolist(), rp.tolist()):
         owner = a // per
         ok = ok and ((a, p) in set(zip(*allkeys[owner])))
-    out[rank] = (bool(ok), len(rn), len(sn))
+    out[rank] = (bool(ok), len(rn), len(sn), imported)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -78,6 +83,7 @@ def test_exchange_protocol_world2(fixtures_dir, name, nn):
     assert out[0][1] > 0 and out[1][1] > 0      # both ranks import something
     # symmetric-free sanity: what rank 0 imports, rank 1 exports (2 ranks only)
     assert out[0][1] == out[1][2] and out[1][1] == out[0][2]
+    assert out[0][3] >= out[0][1] and out[1][3] >= out[1][1]     # every imported key fills at least one neighbour row
 
 
 def test_plan_matches_oracle_recv_sets(fixtures_dir):

@@ -1,0 +1,76 @@
+"""The RCCL exchange behind the C ABI (dpgo_comm_*, comm.cpp) on the one GPU of the test box: a communicator of
+one rank runs the full protocol -- key exchange, pack -> ncclAllGather -> unpack on the communicator's stream, the
+join in update(), the scalar all-reduce, the collectives AMM-PGO* borrows -- and must not change a bit of the
+trajectory.  (RCCL refuses two ranks on one device, so N > 1 is covered by the world-2 gloo CPU test of the same
+packing code, tests/test_exchange_gloo.py, and by bench.py --gpus N on a multi-GPU box.)"""
+import os
+
+import numpy as np
+import pytest
+
+import dpgo_amd
+from oracle.problem import LOSS_HUBER, LOSS_NONE
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("loss", [LOSS_NONE, LOSS_HUBER])
+def test_comm_world1_keeps_the_trajectory(fixtures_dir, loss):
+    path = os.path.join(fixtures_dir, "torus3D.g2o")
+    G = dpgo_amd.read_g2o(path, 4)
+    X0 = G.chordal_initialization()
+    opt = dpgo_amd.Options.driver(loss, True)
+    a = dpgo_amd.DistPGO(G, opt, X0=X0)
+    b = dpgo_amd.DistPGO(G, opt, X0=X0)
+    comm = dpgo_amd.Comm(b.group, 0, 1)
+    for _ in range(12):
+        assert a.step() == 0
+        assert b.group.iterate() == 0
+        assert comm.exchange() == 0                 # nothing to import with one rank, but every stage runs
+        assert b.group.communicate_local() == 0
+        assert b.group.update() == 0
+    assert np.array_equal(a.X(), b.X())
+    v = comm.allreduce_sum([1.5, -2.0, 3.25])
+    np.testing.assert_array_equal(v, [1.5, -2.0, 3.25])
+    big = np.arange(10000, dtype=np.float64)
+    np.testing.assert_array_equal(comm.allreduce_sum(big), big)
+    assert comm.barrier() == 0
+    # the global evaluation goes through the communicator's all-reduce now
+    F, g2 = b.group.evaluate(b.X())
+    Fa, g2a = a.group.evaluate(a.X())
+    assert F == Fa and g2 == g2a
+    comm.close()
+
+
+def test_star_with_native_collectives(fixtures_dir):
+    """AMM-PGO* with the master's sums and the trial-point all-gather routed through RCCL (one rank)."""
+    path = os.path.join(fixtures_dir, "M3500.g2o")
+    G = dpgo_amd.read_g2o(path, 4)
+    X0 = G.chordal_initialization()
+    opt = dpgo_amd.Options.driver(LOSS_NONE, True)
+    a, b = dpgo_amd.DPGOStar(G, opt), dpgo_amd.DPGOStar(G, opt)
+    comm = dpgo_amd.Comm(b.group, 0, 1)
+    assert a.initialize(X0) == 0 and b.initialize(X0) == 0
+    for _ in range(8):
+        assert a.step() == 0 and b.step() == 0
+        assert a.state() == b.state()
+    assert np.array_equal(a.X(), b.X())
+    comm.close()
+
+
+def test_dist_pgo_one_rank_with_comm(fixtures_dir, tmp_path):
+    """The C++ driver in its one-process-per-GPU form with a world of one rank: rendezvous file, dpgo_comm_create,
+    exchange every iteration -- same output as the plain run."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "dpgo_amd", "dist_pgo")
+    path = os.path.join(fixtures_dir, "smallGrid3D.g2o")
+    base = [exe, "--dataset", path, "--num_nodes", "2", "--iters", "15", "--loss", "huber", "--dist_init", "false",
+            "--save", "false"]
+    one = subprocess.run(base, capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    env = dict(os.environ, DPGO_FORCE_COMM="1")
+    two = subprocess.run(base + ["--world", "1", "--rank", "0", "--rdv", str(tmp_path / "rdv")], capture_output=True, text=True,
+                         cwd=tmp_path, timeout=300, env=env)
+    assert one.returncode == 0 and two.returncode == 0, (one.stderr[-1000:], two.stderr[-1000:])
+    pick = lambda s: [l for l in s.splitlines() if l[:1].isdigit() or l.startswith("final")]
+    assert pick(one.stdout) == pick(two.stdout)

@@ -91,3 +91,31 @@ def test_error_conventions(fixtures_dir):
     grp1 = dpgo_amd.NodeGroup(G1, [0], dpgo_amd.Options.driver(LOSS_NONE, True))
     with pytest.raises(RuntimeError):
         grp1.dist_chordal_initialization()         # num_nodes = 1: the reference's own trap
+
+
+def test_dist_pgo_cli_with_dist_init(fixtures_dir, tmp_path):
+    """dist_pgo --dist_init true (the reference's default, dist_pgo.cpp:32-34): the driver prints the four stages with
+    their objectives every 20 iterations (:206-210) and then runs the MM loop from that warm start; stage objectives
+    and the final objective against the oracle's pipeline."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "dpgo_amd", "dist_pgo")
+    path = os.path.join(fixtures_dir, "M3500.g2o")
+    out = subprocess.run([exe, "--dataset", path, "--num_nodes", "4", "--iters", "10", "--save", "false"],
+                         capture_output=True, text=True, cwd=tmp_path, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    txt = out.stdout
+    for title in ("Initialize the reduced rotation", "Initialize the rotation", "Initialize the reduced translation",
+                  "Initialize the translation", "Distributed PGO"):
+        assert title in txt
+    assert "not available" not in txt
+    stage = txt.split("Initialize the rotation")[1].split("=====")[0]
+    got = [float(l.split(":")[1]) for l in stage.splitlines() if l[:1].isdigit()]
+    num_poses, mm = og.read_g2o_file(path)
+    _, meas, g_index = og.partition_measurements(num_poses, mm, 4)
+    tr = {}
+    Xo = _global(dist_chordal_initialization(meas, trace=tr), g_index, num_poses, mm.d)
+    np.testing.assert_allclose(got, tr["objective_R"], rtol=1e-5)
+    f0 = float([l for l in txt.split("Distributed PGO")[1].splitlines() if l.startswith("0: ")][0].split()[1])
+    star = GlobalProblem(num_poses, mm, 4, OOptions.driver(LOSS_NONE, True))
+    assert abs(f0 - 2 * star.evaluate_f(Xo)) <= 1e-5 * f0
