@@ -98,7 +98,12 @@ void scalar_csr(const BsrMatrix &G, int n0, int d, bool rot, CsrMatrix &out) {
 
 }  // namespace
 
-int assemble_node(const DataInfo &info, double xi, bool trivial, NodeOperators &ops) {
+int assemble_node(const DataInfo &info, double xi, bool trivial, NodeOperators &ops, const double *scale) {
+  // scale != nullptr: Rescale::Dynamic (DPGO_utils.cpp:2969-3903 + DPGOProblem::update_quadratic_mat,
+  // DPGOProblem.cpp:751-840): the contribution of inter-node edge e to G, D, Q and to the proximal majoriser H
+  // (the columns of the reference's E_ / F_, :3518-3585) is multiplied by scale[e], and the majoriser is
+  // regularised by 0.5 xi instead of 1.5 xi (:3621, :3634 against :2222-2241).
+  const bool dynamic = scale != nullptr && !trivial;
   const int d = info.d, B = d + 1, n0 = info.n[0], n1 = info.n[1], nz = n0 + n1;
   ops = NodeOperators();
   ops.d = d; ops.n0 = n0; ops.n1 = n1; ops.trivial = trivial;
@@ -115,13 +120,16 @@ int assemble_node(const DataInfo &info, double xi, bool trivial, NodeOperators &
       P.add(p, p, E.AA, -1); P.add(p, q, E.AI, -1); P.add(q, p, E.IA, -1); P.add(q, q, E.II, -1);
     }
   }
+  int e_inter = 0;
   for (const auto &m : info.inter) {
     const int p = info.tail(m), q = info.head(m);
     const bool tail_own = (m.inode == info.node);
     edge_blocks(m, d, E);
+    const double w2 = 2.0 * (dynamic ? scale[e_inter] : 1.0);
+    e_inter++;
     // own endpoint gets 2 bd(E) in G, D, H (:1964-2028, :2097-2127 / :2748-2865)
-    if (tail_own) { G.add(p, p, E.AA, 2); Dd.add(p, p, E.AA, 2); H.add(p, p, E.AA, 2); }
-    else          { G.add(q, q, E.II, 2); Dd.add(q, q, E.II, 2); H.add(q, q, E.II, 2); }
+    if (tail_own) { G.add(p, p, E.AA, w2); Dd.add(p, p, E.AA, w2); H.add(p, p, E.AA, w2); }
+    else          { G.add(q, q, E.II, w2); Dd.add(q, q, E.II, w2); H.add(q, q, E.II, w2); }
     if (trivial) {
       // Q = -1/2 E+ (:1864-1962), P0 = +1/2 E+ (:1872-1961), E+ = bd(E) - od(E)
       Q.add(p, p, E.AA, -0.5); Q.add(q, q, E.II, -0.5); Q.add(p, q, E.AI, 0.5); Q.add(q, p, E.IA, 0.5);
@@ -133,11 +141,11 @@ int assemble_node(const DataInfo &info, double xi, bool trivial, NodeOperators &
       else          { S.add(q, q, E.II, -1); S.add(q, p, E.IA, 1); }
     } else {
       // robust Q = 2 bd(E) on both endpoints (:2711-2746)
-      Q.add(p, p, E.AA, 2); Q.add(q, q, E.II, 2);
+      Q.add(p, p, E.AA, w2); Q.add(q, q, E.II, w2);
     }
   }
   for (int i = 0; i < n0; i++) {   // xi terms (:2212-2243 / :2906-2927)
-    G.add_diag(i, xi); Dd.add_diag(i, xi); H.add_diag(i, 1.5 * xi);
+    G.add_diag(i, xi); Dd.add_diag(i, xi); H.add_diag(i, (dynamic ? 0.5 : 1.5) * xi);
     if (trivial) { S.add_diag(i, -xi); Q.add_diag(i, -xi); P.add_diag(i, xi); P0.add_diag(i, xi); }
     else Q.add_diag(i, 2.0 * xi);
   }

@@ -42,6 +42,7 @@ struct NodeOperators {
 
 // xi = options.regularizer.  trivial selects simplify_quadratic_data_matrix,
 // otherwise simplify_regular_data_matrix (Static rescale).
-int assemble_node(const DataInfo &info, double xi, bool trivial, NodeOperators &ops);
+// scale (optional, one number per inter-node edge in the order of info.inter): Rescale::Dynamic.
+int assemble_node(const DataInfo &info, double xi, bool trivial, NodeOperators &ops, const double *scale = nullptr);
 
 }  // namespace dpgo

@@ -304,6 +304,8 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   const bool trivial = (opt.loss == 0);
   info_.resize(L);
   ops_.resize(L);
+  scale_.assign(L, {});
+  rescale_count_.assign(L, 0);
   res_.assign(L, NodeResults());
   lambda_max_.assign(L, 0.0);
   g_index_.resize(L);
@@ -312,7 +314,9 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   for (int a = 0; a < L; a++) {
     local_of_node_[nodes_[a]] = a;
     if (generate_data_info(nodes_[a], d_, g.measurements[nodes_[a]], info_[a]) != 0) return;
-    if (assemble_node(info_[a], opt.regularizer, trivial, ops_[a]) != 0) return;
+    // Rescale::Dynamic (robust losses): one scale per inter-node edge, all ones at construction (DPGOProblem.cpp:34)
+    if (!trivial && opt.rescale == 1) scale_[a].assign(info_[a].inter.size(), 1.0);
+    if (assemble_node(info_[a], opt.regularizer, trivial, ops_[a], scale_[a].empty() ? nullptr : scale_[a].data()) != 0) return;
     g_index_[a] = g.g_index[nodes_[a]];
     own_off_[a + 1] = own_off_[a] + info_[a].n[0];
     nbr_off_[a + 1] = nbr_off_[a] + info_[a].n[1];
@@ -362,46 +366,14 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   cg_.alloc(MAX_LOCAL_NODES);
   dmask_.alloc(2);
 
-  // ---- operators
-  {
-    std::vector<const BsrMatrix *> v(L);
-    for (int a = 0; a < L; a++) v[a] = &ops_[a].G;
-    upload_bsr(v, false, G_);
-    if (trivial) {
-      for (int a = 0; a < L; a++) v[a] = &ops_[a].S;
-      upload_bsr(v, false, S_);
-      for (int a = 0; a < L; a++) v[a] = &ops_[a].P;
-      upload_bsr(v, true, P_);
-      for (int a = 0; a < L; a++) v[a] = &ops_[a].P0;
-      upload_bsr(v, true, P0m_);
-      for (int a = 0; a < L; a++) v[a] = &ops_[a].Q;
-      upload_bsr(v, true, Q_);
-    }
-    std::vector<double> Dd((size_t)P0_ * B_ * B_), Ti(P0_), Nn((size_t)P0_ * d_), Vv((size_t)P0_ * d_ * d_);
-    std::vector<double> Qd((size_t)(P0_ + P1_) * B_ * B_, 0.0);
-    for (int a = 0; a < L; a++) {
-      const int n0 = info_[a].n[0];
-      std::copy(ops_[a].D.begin(), ops_[a].D.end(), Dd.begin() + (size_t)own_off_[a] * B_ * B_);
-      std::copy(ops_[a].Tinv.begin(), ops_[a].Tinv.end(), Ti.begin() + own_off_[a]);
-      std::copy(ops_[a].N.begin(), ops_[a].N.end(), Nn.begin() + (size_t)own_off_[a] * d_);
-      std::copy(ops_[a].V.begin(), ops_[a].V.end(), Vv.begin() + (size_t)own_off_[a] * d_ * d_);
-      if (!trivial) {   // robust Q is block diagonal
-        const BsrMatrix &Q = ops_[a].Q;
-        for (int r = 0; r < Q.nrows; r++)
-          for (int k = Q.ptr[r]; k < Q.ptr[r + 1]; k++)
-            if (Q.col[k] == r)
-              std::copy(&Q.val[(size_t)k * B_ * B_], &Q.val[(size_t)(k + 1) * B_ * B_],
-                        Qd.begin() + (size_t)uni(a, r) * B_ * B_);
-      }
-      (void)n0;
-    }
-    Dd_.upload(Dd); Tinv_.upload(Ti); N_.upload(Nn); V_.upload(Vv); Qd_.upload(Qd);
-  }
+  upload_operators();
   // ---- inter-node edges (residual form) and their incidence lists
   {
     std::vector<int> tail, head;
     std::vector<double> R, t, kap, tau;
     std::vector<std::vector<int>> inc(P0_ + P1_);
+    e_off_.assign(L + 1, 0);
+    for (int a = 0; a < L; a++) e_off_[a + 1] = e_off_[a] + (int)info_[a].inter.size();
     for (int a = 0; a < L; a++)
       for (const auto &m : info_[a].inter) {
         const int e = (int)tail.size();
@@ -422,6 +394,7 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
     E_.nrows_own = P0_; E_.nrows_all = P0_ + P1_;
     E_.m = (int)tail.size(); E_.tail = e_tail_.p; E_.head = e_head_.p; E_.R = e_R_.p; E_.t = e_t_.p;
     E_.kappa = e_kappa_.p; E_.tau = e_tau_.p; E_.inc_ptr = e_inc_ptr_.p; E_.inc = e_inc_.p;
+    if (dynamic()) e_w_.alloc(std::max<size_t>(tail.size(), 1));
   }
   {
     std::vector<int> tail, head;
@@ -449,16 +422,11 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
     Ei_.kappa = i_kappa_.p; Ei_.tau = i_tau_.p; Ei_.inc_ptr = i_inc_ptr_.p; Ei_.inc = i_inc_.p;
   }
   // ---- SPD solvers: one block-diagonal system over all local nodes
+  if (refactor_tt() != 0) return;
   {
-    CsrMatrix Att, Arr;
-    Att.ptr.push_back(0);
+    CsrMatrix Arr;
     Arr.ptr.push_back(0);
     for (int a = 0; a < L; a++) {
-      const CsrMatrix &t = ops_[a].Gtt;
-      for (int i = 0; i < t.n; i++) {
-        for (int e = t.ptr[i]; e < t.ptr[i + 1]; e++) { Att.col.push_back(own_off_[a] + t.col[e]); Att.val.push_back(t.val[e]); }
-        Att.ptr.push_back((int)Att.col.size());
-      }
       if (opt.preconditioner == 3 && opt.max_iterations > 0 && opt.max_iterations_accepted > 0) {
         const CsrMatrix &r = ops_[a].GRR;
         lambda_max_[a] = lanczos_lambda_max(r);
@@ -472,19 +440,13 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
         }
       }
     }
-    Att.n = (int)Att.ptr.size() - 1;
     Arr.n = (int)Arr.ptr.size() - 1;
-    if (spd_factor(Att, Ltt_.F, env_int("DPGO_SPD_LEAF_TT", 128), env_int("DPGO_SPD_COLLAPSE_TT", 0)) != 0) return;
-    Ltt_.dof = 1;
-    std::vector<int> node_of_pose(P0_);
-    for (int a = 0; a < L; a++)
-      for (int p = 0; p < info_[a].n[0]; p++) node_of_pose[own_off_[a] + p] = a;
-    Ltt_.upload(d_, node_of_pose);
     if (Arr.n > 0) {
       if (spd_factor(Arr, Lrr_.F, env_int("DPGO_SPD_LEAF_RR", 96), env_int("DPGO_SPD_COLLAPSE_RR", 0)) != 0) return;
       Lrr_.dof = d_;
       std::vector<int> node_of_row((size_t)P0_ * d_);
-      for (size_t i = 0; i < node_of_row.size(); i++) node_of_row[i] = node_of_pose[i / d_];
+      for (int a = 0; a < L; a++)
+        for (int p = 0; p < info_[a].n[0] * d_; p++) node_of_row[(size_t)own_off_[a] * d_ + p] = a;
       Lrr_.upload(d_, node_of_row);
     }
   }
@@ -526,6 +488,68 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   }
   HIP_CHECK(hipDeviceSynchronize());
   ok_ = true;
+}
+
+// The operators of every local node on the device (block-CSR G, S, P, P0, Q; the per-pose arrays D, T, N, V, robust Q).
+// Called at construction and after a Dynamic rescale.
+void Group::upload_operators() {
+  const int L = num_local();
+  const bool trivial = (opt_.loss == 0);
+  auto uni = [&](int a, int p) { return p < info_[a].n[0] ? own_off_[a] + p : P0_ + nbr_off_[a] + (p - info_[a].n[0]); };
+    std::vector<const BsrMatrix *> v(L);
+    for (int a = 0; a < L; a++) v[a] = &ops_[a].G;
+    upload_bsr(v, false, G_);
+    if (trivial) {
+      for (int a = 0; a < L; a++) v[a] = &ops_[a].S;
+      upload_bsr(v, false, S_);
+      for (int a = 0; a < L; a++) v[a] = &ops_[a].P;
+      upload_bsr(v, true, P_);
+      for (int a = 0; a < L; a++) v[a] = &ops_[a].P0;
+      upload_bsr(v, true, P0m_);
+      for (int a = 0; a < L; a++) v[a] = &ops_[a].Q;
+      upload_bsr(v, true, Q_);
+    }
+    std::vector<double> Dd((size_t)P0_ * B_ * B_), Ti(P0_), Nn((size_t)P0_ * d_), Vv((size_t)P0_ * d_ * d_);
+    std::vector<double> Qd((size_t)(P0_ + P1_) * B_ * B_, 0.0);
+    for (int a = 0; a < L; a++) {
+      const int n0 = info_[a].n[0];
+      std::copy(ops_[a].D.begin(), ops_[a].D.end(), Dd.begin() + (size_t)own_off_[a] * B_ * B_);
+      std::copy(ops_[a].Tinv.begin(), ops_[a].Tinv.end(), Ti.begin() + own_off_[a]);
+      std::copy(ops_[a].N.begin(), ops_[a].N.end(), Nn.begin() + (size_t)own_off_[a] * d_);
+      std::copy(ops_[a].V.begin(), ops_[a].V.end(), Vv.begin() + (size_t)own_off_[a] * d_ * d_);
+      if (!trivial) {   // robust Q is block diagonal
+        const BsrMatrix &Q = ops_[a].Q;
+        for (int r = 0; r < Q.nrows; r++)
+          for (int k = Q.ptr[r]; k < Q.ptr[r + 1]; k++)
+            if (Q.col[k] == r)
+              std::copy(&Q.val[(size_t)k * B_ * B_], &Q.val[(size_t)(k + 1) * B_ * B_],
+                        Qd.begin() + (size_t)uni(a, r) * B_ * B_);
+      }
+      (void)n0;
+    }
+    Dd_.upload(Dd); Tinv_.upload(Ti); N_.upload(Nn); V_.upload(Vv); Qd_.upload(Qd);
+}
+
+// Factor G_tt of all local nodes (block diagonal): L_.compute / L_.factorize (DPGOProblem.cpp:93, 315, 479)
+int Group::refactor_tt() {
+  const int L = num_local();
+  CsrMatrix Att;
+  Att.ptr.push_back(0);
+  for (int a = 0; a < L; a++) {
+    const CsrMatrix &t = ops_[a].Gtt;
+    for (int i = 0; i < t.n; i++) {
+      for (int e = t.ptr[i]; e < t.ptr[i + 1]; e++) { Att.col.push_back(own_off_[a] + t.col[e]); Att.val.push_back(t.val[e]); }
+      Att.ptr.push_back((int)Att.col.size());
+    }
+  }
+  Att.n = (int)Att.ptr.size() - 1;
+  if (spd_factor(Att, Ltt_.F, env_int("DPGO_SPD_LEAF_TT", 128), env_int("DPGO_SPD_COLLAPSE_TT", 0)) != 0) return -1;
+  Ltt_.dof = 1;
+  std::vector<int> node_of_pose(P0_);
+  for (int a = 0; a < L; a++)
+    for (int p = 0; p < info_[a].n[0]; p++) node_of_pose[own_off_[a] + p] = a;
+  Ltt_.upload(d_, node_of_pose);
+  return 0;
 }
 
 Group::~Group() {
@@ -725,6 +749,7 @@ int Group::initialize(int a, const double *X, int ld) {
     HIP_CHECK(hipMemset(dst + (size_t)own_off_[a] * RS_, 0, sizeof(double) * n0 * RS_));
   res_[a] = NodeResults();
   res_[a].updated = 0;
+  rescale_count_[a] = 0;   // DPGOResult::clear (DPGO_types.h:301); the scales belong to the problem and stay
   return 0;
 }
 
@@ -1053,6 +1078,35 @@ void Group::host_update_logic(int a, double fobj, double f, double gradFnorm) {
   r.updated = 1;
 }
 
+// The rescale test of evaluate_g_and_f*_rescale (DPGOProblem.cpp:300-321, 464-485) for the nodes of `set`: a node
+// is rescaled when its counter has reached max_rescale_count or some edge weight exceeds the edge's scale; its new
+// scales are clamp(1.25 w, min_rescale_, max_rescale_) (DPGOProblem.h:17-18), update_quadratic_mat (:751-840) and
+// L_.factorize follow.  The preconditioner keeps the factor of the constructor, as in the reference.
+std::vector<int> Group::maybe_rescale(const std::vector<int> &set) {
+  std::vector<int> changed;
+  std::vector<double> w(std::max<size_t>(e_w_.n, 1));
+  sync();
+  if (E_.m > 0) HIP_CHECK(hipMemcpy(w.data(), e_w_.p, sizeof(double) * E_.m, hipMemcpyDeviceToHost));
+  for (int a : set) {
+    const int m1 = e_off_[a + 1] - e_off_[a];
+    bool rescaled = rescale_count_[a] >= opt_.max_rescale_count;
+    for (int e = 0; e < m1 && !rescaled; e++) rescaled = w[e_off_[a] + e] > scale_[a][e];
+    if (!rescaled) {
+      rescale_count_[a]++;
+      continue;
+    }
+    for (int e = 0; e < m1; e++) scale_[a][e] = std::min(1.0, std::max(0.01, 1.25 * w[e_off_[a] + e]));
+    rescale_count_[a] = 0;
+    if (assemble_node(info_[a], opt_.regularizer, false, ops_[a], scale_[a].data()) != 0) throw DeviceError("assemble_node");
+    changed.push_back(a);
+  }
+  if (!changed.empty()) {
+    upload_operators();
+    if (refactor_tt() != 0) throw DeviceError("G_tt is not positive definite after a rescale");
+  }
+  return changed;
+}
+
 int Group::update(const std::vector<int> &locals_in) {
   std::vector<int> locals;
   for (int a : locals_in)
@@ -1117,26 +1171,42 @@ int Group::update(const std::vector<int> &locals_in) {
       }
     }
   } else {
-    // evaluate_g_and_f0 / evaluate_g_and_f (DPGOProblem.cpp:222-267, 360-424)
+    // evaluate_g_and_f0 / evaluate_g_and_f (DPGOProblem.cpp:222-267, 360-424); _rescale variants (:289-358, :426-514)
     for (int pass = 0; pass < 2; pass++) {
       const std::vector<int> &set = pass == 0 ? first : later;
       if (set.empty()) continue;
       set_mask(set);
       launch_inter(d_, st_, T_, cur_mask_, E_, opt_.loss, opt_.loss_reg, 0, pass == 1, Zc_.p, Zp_.p, Qd_.p, Dd_.p, DfE_.p,
-                   gc_.p, partials_.p);   // slots 0, 1 and 2 = <X, g>
+                   gc_.p, partials_.p, dynamic() ? e_w_.p : nullptr);   // slots 0, 1 and 2 = <X, g>
+      std::vector<double> rho(num_local(), 0.0), gap(num_local(), 0.0);
+      if (dynamic()) {
+        // Rescale::Dynamic: the sum of rho and the majorisation gap (under the OLD Q) are final; whether the
+        // surrogate is rescaled depends on the edge weights just computed (:300-321, :464-485).  Rescaled nodes get
+        // their D, G, T, N, V, Q and the factor of G_tt rebuilt, and g, G X are taken again with the new operators.
+        fetch(3, true);
+        for (int a : set) { rho[a] = scal(a, 0); gap[a] = scal(a, 1); }
+        const std::vector<int> changed = maybe_rescale(set);
+        if (!changed.empty()) {
+          set_mask(changed);
+          launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Zc_.p, false, nullptr, T1_.p, Zc_.p, 0.5, nullptr, partials_.p, 5);
+          launch_inter(d_, st_, T_, cur_mask_, E_, opt_.loss, opt_.loss_reg, 1, false, Zc_.p, nullptr, nullptr, Dd_.p, nullptr,
+                       gc_.p, partials_.p);   // g = DfobjE_own - D X with the new D (slot 2 = <X, g> again)
+          set_mask(set);
+        }
+      }
       if (pass == 0) launch_bdiag_dot(d_, st_, T_, cur_mask_, Dd_.p, Zc_.p, 0.5, DfE_.p, -1.0, partials_.p, 3);
       launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, partials_.p, 4, gc_.p, Dfc_.p);   // Dfobj = G X + g
       fetch(6, true);
       for (int a : set) {
         NodeResults &r = res_[a];
-        const double fobjE = 0.5 * scal(a, 0);
+        const double fobjE = 0.5 * (dynamic() ? rho[a] : scal(a, 0));
         const double quad = scal(a, 2) + scal(a, 5);   // tr(X^T (g + 1/2 G X))
         double fobj, f;
         if (pass == 0) {
           f = 0.5 * fobjE + scal(a, 3);
           fobj = f + quad;
         } else {
-          fobj = r.Gk - 0.5 * r.fobjE - 0.5 * scal(a, 1) + 0.5 * fobjE;
+          fobj = r.Gk - 0.5 * r.fobjE - 0.5 * (dynamic() ? gap[a] : scal(a, 1)) + 0.5 * fobjE;
           f = fobj - quad;
         }
         r.fobjE = fobjE;

@@ -267,6 +267,18 @@ class Group {
   double global_sqdist(const double *A_own, const double *B_own);
 
   void upload_bsr(const std::vector<const BsrMatrix *> &per_node, bool rows_all, BsrBufs &out);
+  void upload_operators();
+  int refactor_tt();
+  // Rescale::Dynamic (DPGOProblem.cpp:289-358, 426-514, 751-840): scale of every inter-node edge per node, the
+  // counter of DPGOResult::rescale_count, the edge weights of the last evaluate_E
+  std::vector<std::vector<double>> scale_;
+  std::vector<int> rescale_count_;
+  std::vector<int> e_off_;          // first inter edge of every node in E_
+  DevBuf<double> e_w_;
+  bool dynamic() const { return opt_.loss != 0 && opt_.rescale == 1; }
+  // decide per node whether its surrogate is rescaled (weights in e_w_), rebuild what changed; returns the nodes
+  // that were rescaled
+  std::vector<int> maybe_rescale(const std::vector<int> &set);
   void set_mask(const std::vector<int> &locals);
   void fetch(int nslots, bool all_rows);                  // -> h_scal_[local * MAX_SLOTS + s]
   void wait_flag(unsigned long long seq);

@@ -109,7 +109,8 @@ void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, co
 //  mode 1 (evaluate_g): own rows only, g <- (B1^T W B1 Z)_own - D z.
 void launch_inter(int d, hipStream_t st, const SegTable &T, NodeMask mask, const InterEdgesDev &E, int loss,
                   double loss_reg, int mode, bool quad, const double *Z, const double *Zprev,
-                  const double *Qdiag, const double *Ddiag, double *DfE, double *g, double *partials);
+                  const double *Qdiag, const double *Ddiag, double *DfE, double *g, double *partials,
+                  double *wout = nullptr);   // wout (mode 0): the loss weight of every edge
 
 // Objective of every node at Z (own + neighbour rows): partial[slot0] = sum of intra-edge costs,
 // partial[slot0 + 1] = sum of rho over inter-edge costs; eform selects the data-matrix form (trivial loss).

@@ -463,7 +463,7 @@ template <int D>
 __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask mask, InterEdgesDev E, int loss,
                                                double dl, int mode, int quad, int nseg_own, const double *Z,
                                                const double *Zprev, const double *Qd, const double *Dd,
-                                               double *DfE, double *g, double *partial, int pstride) {
+                                               double *DfE, double *g, double *partial, int pstride, double *wout) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
   const bool active = node_on(mask, s.node);
@@ -512,6 +512,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask ma
       loss_weight(loss, dl, sn, w, rho);
       if (role == 0) {
         part[0] += rho;
+        if (wout) wout[e] = w;   // the weight of every edge, once (Rescale::Dynamic reads them, DPGOProblem.cpp:300-306)
 #pragma unroll
         for (int c = 0; c < D; c++) acc[c] = fma(w * tau, u[c], acc[c]);
 #pragma unroll
@@ -1561,13 +1562,13 @@ void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, co
 
 void launch_inter(int d, hipStream_t st, const SegTable &T, NodeMask mask, const InterEdgesDev &E, int loss,
                   double loss_reg, int mode, bool quad, const double *Z, const double *Zprev,
-                  const double *Qdiag, const double *Ddiag, double *DfE, double *g, double *partials) {
+                  const double *Qdiag, const double *Ddiag, double *DfE, double *g, double *partials, double *wout) {
   const int nb = mode == 0 ? T.nseg_all : T.nseg_own;
   if (nb == 0) return;
   ProfScope ps(PK_INTER, st, (double)E.m * (8.0 * (d * d + d + 2) + 8) + 2.0 * (mode == 0 ? E.nrows_all : E.nrows_own) * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_inter<D>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, E, loss, loss_reg,
                                         mode, quad ? 1 : 0, T.nseg_own, Z, Zprev, Qdiag, Ddiag, DfE, g, partials,
-                                        T.nseg_all));
+                                        T.nseg_all, mode == 0 ? wout : nullptr));
 }
 
 void launch_cost(int d, hipStream_t st, const SegTable &T, NodeMask mask, const InterEdgesDev &Ei,

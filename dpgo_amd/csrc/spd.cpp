@@ -12,7 +12,11 @@
 #include <numeric>
 #include <queue>
 
+#include <hip/hip_runtime.h>
+
 namespace dpgo {
+int spd_factor_numeric_device(const CsrMatrix &A, SpdFactor &F, const std::vector<std::vector<int>> &children,
+                              double *flops_out, double *mfma_ms_out);
 namespace {
 
 struct TreeNode {
@@ -654,6 +658,7 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
   }
   F.W.assign(F.w_off[nt], 0.0);
   F.WT.assign(F.wt_off[nt], 0.0);
+  (void)hipGetLastError();
 
   // numeric multifrontal factorisation, level by level: fronts of one tree height are independent.
   // Small fronts are spread over threads; big fronts are factored one at a time with threads inside.
@@ -694,7 +699,6 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
       const std::vector<double> &Uc = Umat[c];
       for (int a = 0; a < uc; a++) {
         int la = loc[upc[a]];
-        asm_lists[F.pos_off[f] + la].push_back(F.ubuf_off[c] + a);
         for (int b = 0; b <= a; b++) {
           int lb = loc[upc[b]];
           int r = std::max(la, lb), cc = std::min(la, lb);
@@ -803,7 +807,40 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
     for (int k = 0; k < u; k++) loc[up[k]] = -1;
   };
 
-  for (int h = 0; h <= maxh_n && !fail; h++) {
+  // assembly lists of the solve (which update-buffer rows feed every front position): symbolic
+  {
+    std::vector<int> loc(n, -1);
+    for (int f = 0; f < nt; f++) {
+      const int w = F.w[f], u = F.u[f];
+      const int *piv = &F.piv_idx[F.piv_ptr[f]];
+      const int *up = u ? &F.upd_idx[F.upd_ptr[f]] : nullptr;
+      for (int k = 0; k < w; k++) loc[piv[k]] = k;
+      for (int k = 0; k < u; k++) loc[up[k]] = w + k;
+      for (int c : children[f]) {
+        const int uc = F.u[c];
+        const int *upc = uc ? &F.upd_idx[F.upd_ptr[c]] : nullptr;
+        for (int a = 0; a < uc; a++) asm_lists[F.pos_off[f] + loc[upc[a]]].push_back(F.ubuf_off[c] + a);
+      }
+      for (int k = 0; k < w; k++) loc[piv[k]] = -1;
+      for (int k = 0; k < u; k++) loc[up[k]] = -1;
+    }
+  }
+  // numeric phase: on the GPU when there is one (spd_dev.hip: front elimination with v_mfma_f64_16x16x4_f64), else --
+  // or with DPGO_SPD_HOST_FACTOR=1 -- the host loop below
+  bool on_device = false;
+  {
+    int ndev = 0;
+    if (!getenv("DPGO_SPD_HOST_FACTOR") && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
+      double flops = 0, ms = 0;
+      const bool report = getenv("DPGO_SPD_DUMP") != nullptr;
+      if (spd_factor_numeric_device(A, F, children, report ? &flops : nullptr, report ? &ms : nullptr) != 0) return -1;
+      if (report)
+        fprintf(stderr, "[spd] device factorisation: %.2f GFLOP in the MFMA tile kernel, %.2f ms there = %.1f TFLOP/s fp64\n",
+                flops * 1e-9, ms, flops / (ms * 1e-3) * 1e-12);
+      on_device = true;
+    }
+  }
+  for (int h = 0; h <= maxh_n && !fail && !on_device; h++) {
     std::vector<int> small, big;
     for (int f : lvl_fronts[h]) (F.w[f] + F.u[f] >= BIG ? big : small).push_back(f);
 #pragma omp parallel

@@ -117,10 +117,14 @@ class NodeMatrices:
     pass
 
 
-def assemble_node(info, d, xi, trivial):
+def assemble_node(info, d, xi, trivial, scale=None):
     """All matrices of one node.  trivial=True follows
     simplify_quadratic_data_matrix, trivial=False simplify_regular_data_matrix
-    (Static rescale)."""
+    (Static rescale).  scale (one number per inter-node edge) selects the Dynamic
+    variant (DPGO_utils.cpp:2969-3903 + DPGOProblem::update_quadratic_mat,
+    DPGOProblem.cpp:751-840): every inter-edge contribution to G, D, Q and the proximal
+    majoriser H (columns of E_ / F_, :3518-3585) is multiplied by its edge's scale, and the
+    majoriser carries 0.5 xi instead of 1.5 xi (:3621, :3634 against :2222-2241)."""
     n0, n1 = info.n
     D1 = d + 1
     N0, NZ = D1 * n0, D1 * (n0 + n1)
@@ -130,6 +134,9 @@ def assemble_node(info, d, xi, trivial):
     Ei = edge_hessians(info.intra)
     ii, _ = _edge_index(info, info.intra)
     Ee = edge_hessians(info.inter)
+    dynamic = scale is not None
+    if dynamic:
+        Ee = Ee * np.asarray(scale, np.float64)[:, None, None]
     ie, own = _edge_index(info, info.inter)
     tail_own, head_own = own[:, 0], own[:, 1]
 
@@ -157,7 +164,7 @@ def assemble_node(info, d, xi, trivial):
     own_diag = np.arange(N0)
     G.add(own_diag, own_diag, np.full(N0, xi))            # :2212-2233
     D.add(own_diag, own_diag, np.full(N0, xi))
-    H.add(own_diag, own_diag, np.full(N0, 1.5 * xi))
+    H.add(own_diag, own_diag, np.full(N0, (0.5 if dynamic else 1.5) * xi))
 
     out = NodeMatrices()
     out.trivial = trivial

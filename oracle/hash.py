@@ -45,6 +45,8 @@ class Options:
         self.max_oscillations = 12
         self.loss = LOSS_NONE
         self.loss_reg = 1.0
+        self.rescale = 1                                          # Rescale::Dynamic (DPGO_types.h:128)
+        self.max_rescale_count = 5                                # DPGO_types.h:131
         self.grad_norm_tol = 5e-3
         self.rel_func_decrease_tol = 1e-6
         self.stepsize_tol = 1e-4
@@ -61,6 +63,7 @@ class Options:
     def driver(loss=LOSS_NONE, accelerated=True):
         o = Options()
         o.loss = loss
+        o.rescale = 0                                             # Rescale::Static (dist_pgo.cpp:105)
         o.loss_reg = 0.25
         o.scheme = SCHEME_AMM if accelerated else SCHEME_MM
         o.grad_norm_tol = 1e-3
@@ -103,7 +106,8 @@ class DPGOHash:
         self.problem = DPGOProblem(
             node, measurements, options.regularizer, options.loss,
             options.reg_Cholesky_precon_max_condition_number, options.loss_reg,
-            preconditioner=(getattr(options, "preconditioner", 3) == 3))   # DPGOHash.cpp:16
+            preconditioner=(getattr(options, "preconditioner", 3) == 3),
+            dynamic=(getattr(options, "rescale", 0) == 1))                   # DPGOHash.cpp:16
         self.results = Results()
 
     # DPGOHash.cpp:20-43
@@ -174,7 +178,15 @@ class DPGOHash:
                 g, f, fobj = p.evaluate_none_g_and_f(r.X[0], r.X[1], r.Gk)
             Dfobj = None
         else:
-            if it == 0:
+            if p.dynamic:        # Rescale::Dynamic (DPGOHash.cpp:131-144)
+                rc = getattr(r, "rescale_count", 0)
+                if it == 0:
+                    g, f, Dfobj, fobj, r.DfobjE, r.fobjE, rc = p.evaluate_g_and_f0_rescale(r.X[0], rc, o.max_rescale_count)
+                else:
+                    g, f, Dfobj, fobj, r.DfobjE, r.fobjE, rc = p.evaluate_g_and_f_rescale(
+                        r.X[0], r.X[1], r.Gk, r.DfobjE, r.fobjE, rc, o.max_rescale_count)
+                r.rescale_count = rc
+            elif it == 0:
                 g, f, Dfobj, fobj, r.DfobjE, r.fobjE = p.evaluate_g_and_f0(r.X[0])
             else:
                 g, f, Dfobj, fobj, r.DfobjE, r.fobjE = p.evaluate_g_and_f(

@@ -80,8 +80,10 @@ class SpdSolver:
 class DPGOProblem:
     """DPGOProblem.cpp:11-125 (constructor) and the evaluate_* family."""
 
+    MAX_RESCALE, MIN_RESCALE = 1.0, 0.01          # DPGOProblem.h:17-18
+
     def __init__(self, node, measurements, reg=1e-5, loss=LOSS_NONE,
-                 reg_chol_precon_max_cond=1e6, loss_reg=1.0, preconditioner=True):
+                 reg_chol_precon_max_cond=1e6, loss_reg=1.0, preconditioner=True, dynamic=False):
         self.node = node
         self.info = generate_data_info(node, measurements)
         self.d = measurements.d
@@ -91,7 +93,12 @@ class DPGOProblem:
         self.loss = loss
         self.loss_reg = loss_reg
         self.trivial = (loss == LOSS_NONE)          # "loss_ == None && SIMPLE"
-        self.mat = assemble_node(self.info, self.d, reg, self.trivial)
+        self.reg = reg
+        # Rescale::Dynamic (DPGOProblem.cpp:46-84): the robust surrogate with one scale per inter-node edge,
+        # all ones at construction
+        self.dynamic = dynamic and not self.trivial
+        self.scale = np.ones(self.m[1]) if self.dynamic else None
+        self.mat = assemble_node(self.info, self.d, reg, self.trivial, self.scale)
         self.size0 = (self.d + 1) * self.n[0]
         self.L = SpdSolver(self.mat.Gtt)            # :93
         self.precon = None
@@ -210,6 +217,53 @@ class DPGOProblem:
         Dfobj = g + temp
         fobj = f0 + float(np.sum(X * (0.5 * temp + g)))
         return g, f0, Dfobj, fobj, DfobjE, fobjE
+
+    def update_quadratic_mat(self, scale):
+        """DPGOProblem.cpp:751-840 + L_.factorize (:315, :479).  The preconditioner and lambda_max keep the
+        values of the constructor (the reference never recomputes them)."""
+        self.scale = np.asarray(scale, np.float64).copy()
+        self.mat = assemble_node(self.info, self.d, self.reg, self.trivial, self.scale)
+        self.L = SpdSolver(self.mat.Gtt)
+
+    def _maybe_rescale(self, w, rescale_count, max_rescale_count):
+        """The test of DPGOProblem.cpp:300-321 / :464-485 -> new rescale_count."""
+        if (rescale_count >= max_rescale_count) or bool(np.any(w > self.scale)):
+            self.update_quadratic_mat(np.clip(1.25 * w, self.MIN_RESCALE, self.MAX_RESCALE))
+            return 0
+        return rescale_count + 1
+
+    def evaluate_g_and_f0_rescale(self, Z, rescale_count, max_rescale_count):
+        """DPGOProblem.cpp:289-358 -> g, f0, Dfobj, fobj, DfobjE, fobjE, rescale_count."""
+        X = Z[:self.size0]
+        DfobjE, fobjE, w = self.evaluate_E(Z)
+        if self.dynamic:
+            rescale_count = self._maybe_rescale(w, rescale_count, max_rescale_count)
+        g = DfobjE[:self.size0].copy()
+        temp = self.mat.D @ X
+        g -= temp
+        temp = 0.5 * temp - DfobjE[:self.size0]
+        f0 = 0.5 * fobjE + float(np.sum(X * temp))
+        temp = self.mat.G @ X
+        Dfobj = g + temp
+        fobj = f0 + float(np.sum(X * (0.5 * temp + g)))
+        return g, f0, Dfobj, fobj, DfobjE, fobjE, rescale_count
+
+    def evaluate_g_and_f_rescale(self, Z, Z0, G, DfobjE0, fobjE0, rescale_count, max_rescale_count):
+        """DPGOProblem.cpp:426-514 (robust branch): the majorisation gap uses the OLD Q, then the surrogate may
+        be rescaled, then g, Dfobj, f use the new D and G."""
+        X = Z[:self.size0]
+        Y = Z - Z0
+        temp = DfobjE0 + 0.5 * (self.mat.Q @ Y)
+        fobj = G - 0.5 * fobjE0 - 0.5 * float(np.sum(Y * temp))
+        DfobjE, fobjE, w = self.evaluate_E(Z)
+        fobj += 0.5 * fobjE
+        if self.dynamic:
+            rescale_count = self._maybe_rescale(w, rescale_count, max_rescale_count)
+        g = DfobjE[:self.size0] - self.mat.D @ X
+        temp = self.mat.G @ X
+        Dfobj = g + temp
+        f = fobj - float(np.sum(X * (0.5 * temp + g)))
+        return g, f, Dfobj, fobj, DfobjE, fobjE, rescale_count
 
     def evaluate_g_and_f(self, Z, Z0, G, DfobjE0, fobjE0):
         """DPGOProblem.cpp:360-424 (robust branch) -> g, f, Dfobj, fobj, DfobjE, fobjE."""

@@ -290,7 +290,11 @@ class DPGOStar:
                 fobj = p.evaluate_G(r.Xak, g, f)
                 Dfobj, gradF = p.full_Riemannian_gradient_G(r.Xak, g)
             else:
-                g, f, Dfobj, fobj, r.DfobjE, r.fobjE = p.evaluate_g_and_f0(r.X[0])
+                if p.dynamic:      # Rescale::Dynamic (DPGOStar.cpp:350-355)
+                    g, f, Dfobj, fobj, r.DfobjE, r.fobjE, r.rescale_count = p.evaluate_g_and_f0_rescale(
+                        r.X[0], getattr(r, "rescale_count", 0), o.max_rescale_count)
+                else:
+                    g, f, Dfobj, fobj, r.DfobjE, r.fobjE = p.evaluate_g_and_f0(r.X[0])
                 gradF = p.full_tangent_space_projection(r.Xak, Dfobj)
             r.Gk = fobj
             r.g = [g, r.g[0]]

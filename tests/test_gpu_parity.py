@@ -595,3 +595,45 @@ def test_headline_size_properties():
         GT = grp.debug_apply(3, "G", Z, 4 * n0)
         assert np.abs(GT[:n0] - B[:n0]).max() <= 1e-9 * np.abs(B[:n0]).max()
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("name,nn,loss,acc,iters", [
+    ("smallGrid3D", 2, LOSS_HUBER, True, 40), ("smallGrid3D", 2, LOSS_GM, True, 25), ("smallGrid3D", 2, LOSS_WELSCH, False, 25),
+    ("tinyGrid3D", 2, LOSS_HUBER, True, 30), ("M3500", 4, LOSS_HUBER, True, 25), ("torus3D", 3, LOSS_WELSCH, True, 15)])
+def test_dynamic_rescale_matches_oracle(fixtures_dir, name, nn, loss, acc, iters):
+    """Rescale::Dynamic, the default of DPGO::Options (DPGO_types.h:128; evaluate_g_and_f*_rescale +
+    update_quadratic_mat, DPGOProblem.cpp:289-358, 426-514, 751-840): every inter-node edge carries a scale that follows
+    its loss weight; per-iteration traces against the oracle."""
+    orc, gpu = _pair(fixtures_dir, name, nn, loss, acc, rescale=1)
+    assert gpu.group.get_options().rescale == dpgo_amd.RESCALE_DYNAMIC
+    rescaled = 0
+    for it in range(iters):
+        orc.step(evaluate=False)
+        assert gpu.step() == 0
+        for a in range(nn):
+            ro, rg = orc.nodes[a].results, gpu.group.results(a)
+            np.testing.assert_allclose(rg.fobj, ro.fobj[0], rtol=1e-7, err_msg="fobj it=%d node=%d" % (it, a))
+            np.testing.assert_allclose(rg.Gk, ro.Gk, rtol=1e-7, err_msg="Gk it=%d node=%d" % (it, a))
+            rescaled += int(ro.rescale_count == 0)
+    assert rescaled > 0                                   # the surrogate was rescaled along the way
+    if name != "M3500":                                  # (M3500 has no outliers: every weight stays 1)
+        assert min(nd.problem.scale.min() for nd in orc.nodes) < 1.0
+    np.testing.assert_allclose(gpu.X(), orc.gather(), atol=1e-6)
+    Fo = orc.star.evaluate_f(orc.gather())
+    assert abs(gpu.sum_fobj() - Fo) <= 1e-6 * abs(Fo)
+
+
+def test_dynamic_rescale_with_amm_pgo_star(fixtures_dir):
+    """AMM-PGO* re-linearises with evaluate_g_and_f0_rescale every iteration (DPGOStar.cpp:350-355)."""
+    from oracle.star import DPGOStar as ODPGOStar
+    path = os.path.join(fixtures_dir, "smallGrid3D.g2o")
+    num_poses, mm = og.read_g2o_file(path)
+    X0 = chordal_initialization(num_poses, mm)
+    orc = ODPGOStar(path, 2, _oracle_opts(LOSS_HUBER, True, rescale=1), mm=mm, num_poses=num_poses)
+    orc.initialize(X0)
+    star = dpgo_amd.DPGOStar(dpgo_amd.read_g2o(path, 2), dpgo_amd.Options.driver(LOSS_HUBER, True, rescale=1))
+    assert star.initialize(X0) == 0
+    for it in range(20):
+        orc.step()
+        assert star.step() == 0
+        np.testing.assert_allclose(star.state()["fobj"], orc.fobj, rtol=1e-7, err_msg="it=%d" % it)
