@@ -543,7 +543,10 @@ int Group::refactor_tt() {
     }
   }
   Att.n = (int)Att.ptr.size() - 1;
-  if (spd_factor(Att, Ltt_.F, env_int("DPGO_SPD_LEAF_TT", 128), env_int("DPGO_SPD_COLLAPSE_TT", 0)) != 0) return -1;
+  if (Ltt_.F.n == Att.n && Ltt_.F.nfronts > 0 && !Ltt_.F.children.empty()) {
+    // same pattern, new values (a Dynamic rescale): numeric phase only, on the GPU
+    if (spd_refactor(Att, Ltt_.F) != 0) return -1;
+  } else if (spd_factor(Att, Ltt_.F, env_int("DPGO_SPD_LEAF_TT", 128), env_int("DPGO_SPD_COLLAPSE_TT", 0)) != 0) return -1;
   Ltt_.dof = 1;
   std::vector<int> node_of_pose(P0_);
   for (int a = 0; a < L; a++)

@@ -857,6 +857,7 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
     }
   }
   if (fail) return -1;
+  F.children = children;
   F.asm_ptr.assign(F.total_pos + 1, 0);
   for (int p = 0; p < F.total_pos; p++) F.asm_ptr[p + 1] = F.asm_ptr[p] + (int)asm_lists[p].size();
   F.asm_src.resize(F.asm_ptr[F.total_pos]);
@@ -879,6 +880,14 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
     F.by_depth[F.depth[f]].push_back(f);
   }
   return 0;
+}
+
+int spd_refactor(const CsrMatrix &A, SpdFactor &F) {
+  int ndev = 0;
+  if (F.n != A.n || (int)F.children.size() != F.nfronts || getenv("DPGO_SPD_HOST_FACTOR") ||
+      hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return spd_factor(A, F, 64, 0);
+  return spd_factor_numeric_device(A, F, F.children, nullptr, nullptr);
 }
 
 int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf, int collapse) {

@@ -45,6 +45,7 @@ struct SpdFactor {
   std::vector<int> ubuf_off;             // first row of each front's update vector in the update buffer
   std::vector<int> asm_ptr, asm_src;     // per front position: rows of the update buffer to add
   std::vector<std::vector<int>> by_height, by_depth;
+  std::vector<std::vector<int>> children;   // elimination tree, kept for spd_refactor
   int total_pos = 0, total_upd = 0, max_front = 0;
   int64_t nnz() const { return entries; }
 };
@@ -54,6 +55,10 @@ struct SpdFactor {
 // collapse = number of nested-dissection levels merged into one front (1 = plain binary tree,
 // 0 = choose 1..3 from a latency + bandwidth model of the device solve).
 int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf = 32, int collapse = 0);
+
+// New values, same pattern (a Dynamic rescale changes the diagonal of G_tt): the numeric phase only, on the GPU
+// (spd_dev.hip); without a GPU the whole factorisation is redone.  F must come from spd_factor of the same pattern.
+int spd_refactor(const CsrMatrix &A, SpdFactor &F);
 
 // Host solve (setup paths and tests): X (n x ncols, row-major) <- A^-1 X.
 void spd_solve_host(const SpdFactor &F, double *X, int ncols);

@@ -30,6 +30,7 @@ namespace dpgo {
 namespace {
 typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int NB = 32;    // block column
+constexpr int SB = 128;   // super-block: the update of its block columns reaches the rest of the front in one pass
 constexpr int TS = 64;    // MFMA tile: 64 x 64 per workgroup, 4 waves of 32 x 32 (2 x 2 instructions of 16 x 16 x 4)
 constexpr int LDT = NB + 1;
 
@@ -159,17 +160,27 @@ __global__ __launch_bounds__(256) void k_fa_panel(const FrontDesc *fd, const int
 //         over [ke, m); an element (i, j) is touched iff (i < m and j <= i) or (i >= m and j < w).
 //  MODE 1 (W_bottom): out[a, j] = -sum_k F[w + a, k] F[m + j, k], k over [0, w); a over [0, u), j over [0, w);
 //         written to W[(w + a) ldw + j] and WT[j ldm + w + a].
+//  MODE 0, narrow pass (wide = 0): K = the block column [k_lo, k_hi) (clipped to the front's w); columns from its end to
+//  the end of the 128-wide super-block sb_end -- or to the end of the front when the super-block holds the front's
+//  last pivots.  Wide pass (wide = 1): K = the whole super-block [k_lo, k_hi = sb_end), columns right of it; only
+//  for fronts with pivots beyond the super-block.  The wide pass is what keeps the read-modify-write of the
+//  trailing matrix from bounding the kernel (K = 128 instead of 32).
 template <int MODE>
-__global__ __launch_bounds__(256) void k_fa_abt(const FrontDesc *fd, const int *lvl, int kb, double *Fm, double *Wout, double *WTout) {
+__global__ __launch_bounds__(256) void k_fa_abt(const FrontDesc *fd, const int *lvl, int k_lo, int k_hi, int sb_end, int wide,
+                                                double *Fm, double *Wout, double *WTout) {
   const FrontDesc f = fd[lvl[blockIdx.y]];
-  int r0, c0, nrt, nct, kbeg, kend;
+  int r0, c0, nrt, nct, kbeg, kend, cend = 0;
   if (MODE == 0) {
-    if (f.w <= kb) return;
-    const int ke = kb + min(NB, f.w - kb);
-    r0 = ke; c0 = ke;
-    nrt = (f.m + ke - ke + TS - 1) / TS;          // rows [ke, m + ke)
-    nct = (f.m - ke + TS - 1) / TS;               // columns [ke, m)
-    kbeg = kb; kend = ke;
+    if (f.w <= k_lo) return;
+    if (wide && f.w <= sb_end) return;
+    const int ke = min(k_hi, f.w);
+    c0 = ke;
+    cend = (wide || sb_end >= f.w) ? f.m : sb_end;
+    if (c0 >= cend) return;
+    r0 = c0;                                       // lower triangle: rows from the first touched column on
+    nrt = (f.m + ke - r0 + TS - 1) / TS;           // rows [r0, m + ke): regular rows and the identity rows < ke
+    nct = (cend - c0 + TS - 1) / TS;
+    kbeg = k_lo; kend = ke;
   } else {
     if (f.u == 0) return;
     r0 = f.w; c0 = f.m;                           // A rows: L21 (w .. m); B rows: the identity rows (m .. m + w)
@@ -183,8 +194,8 @@ __global__ __launch_bounds__(256) void k_fa_abt(const FrontDesc *fd, const int *
   const int i0 = r0 + ti * TS, j0 = c0 + tj * TS;          // first row of the A tile / of the B tile (rows of F)
   int ilim, jlim;
   if (MODE == 0) {
-    ilim = f.m + r0;                                       // rows < m + ke
-    jlim = f.m;
+    ilim = f.m + kend;                                     // rows < m + ke
+    jlim = cend;
     // tiles strictly above the diagonal carry nothing (for the identity rows every column < w counts)
     if (i0 < f.m && j0 > min(i0 + TS - 1, f.m - 1)) return;
     if (i0 >= f.m && j0 >= f.w) return;
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(256) void k_fa_abt(const FrontDesc *fd, const int *
         const double v = acc[a][b][r];
         if (MODE == 0) {
           const bool on = (ii < f.m) ? (jj <= ii) : (ii < ilim && jj < f.w);
-          if (on && jj < f.m) Fm[f.fm_off + (long long)ii * f.m + jj] -= v;
+          if (on && jj < cend) Fm[f.fm_off + (long long)ii * f.m + jj] -= v;
         } else {
           const int arow = ii - f.w, jcol = jj - f.m;
           if (ii < f.m && jcol < f.w) {
@@ -396,24 +407,30 @@ int spd_factor_numeric_device(const CsrMatrix &A, SpdFactor &F, const std::vecto
         if (pair_rng[h][s].second > 0)
           hipLaunchKernelGGL(k_fa_extend, dim3(pair_maxu[h][s], pair_rng[h][s].second), dim3(256), 0, st, d_fd,
                              d_pairs + pair_rng[h][s].first, d_cmap, d_Fm);
-      for (int kb = 0; kb < max_w; kb += NB) {
-        const int ke = std::min(kb + NB, max_w);
-        hipLaunchKernelGGL(k_fa_potrf, dim3(nf), dim3(64), 0, st, d_fd, L, kb, d_Fm, d_dinv, d_fail);
-        hipLaunchKernelGGL(k_fa_panel, dim3((max_m + 255) / 256, nf), dim3(256), 0, st, d_fd, L, kb, d_Fm, d_dinv);
-        const int nrt = (max_m + TS - 1) / TS, nct = (max_m - kb + TS - 1) / TS;
-        if (nct > 0) {
-          if (mfma_ms_out) {
-            hipEvent_t a, b;
-            FA_OK(hipEventCreate(&a)); FA_OK(hipEventCreate(&b));
-            FA_OK(hipEventRecord(a, st));
-            hipLaunchKernelGGL((k_fa_abt<0>), dim3(nrt * nct, nf), dim3(256), 0, st, d_fd, L, kb, d_Fm, d_W, d_WT);
-            FA_OK(hipEventRecord(b, st));
-            evs.push_back({a, b});
-          } else {
-            hipLaunchKernelGGL((k_fa_abt<0>), dim3(nrt * nct, nf), dim3(256), 0, st, d_fd, L, kb, d_Fm, d_W, d_WT);
-          }
+      auto abt0 = [&](int k_lo, int k_hi, int sb_end, int wide) -> int {
+        // upper bounds over the fronts of the level (a front's block column may end before k_hi: columns from k_lo + 1 on)
+        const int nrt = (max_m + TS - 1) / TS, nct = (max_m - k_lo + TS - 1) / TS;
+        if (nct <= 0) return 0;
+        hipEvent_t a = nullptr, b = nullptr;
+        if (mfma_ms_out) {
+          FA_OK(hipEventCreate(&a)); FA_OK(hipEventCreate(&b));
+          FA_OK(hipEventRecord(a, st));
         }
-        (void)ke;
+        hipLaunchKernelGGL((k_fa_abt<0>), dim3(nrt * nct, nf), dim3(256), 0, st, d_fd, L, k_lo, k_hi, sb_end, wide, d_Fm, d_W, d_WT);
+        if (mfma_ms_out) {
+          FA_OK(hipEventRecord(b, st));
+          evs.push_back({a, b});
+        }
+        return 0;
+      };
+      for (int sb = 0; sb < max_w; sb += SB) {
+        const int se = sb + SB;
+        for (int kb = sb; kb < std::min(se, max_w); kb += NB) {
+          hipLaunchKernelGGL(k_fa_potrf, dim3(nf), dim3(64), 0, st, d_fd, L, kb, d_Fm, d_dinv, d_fail);
+          hipLaunchKernelGGL(k_fa_panel, dim3((max_m + 255) / 256, nf), dim3(256), 0, st, d_fd, L, kb, d_Fm, d_dinv);
+          if (abt0(kb, kb + NB, se, 0) != 0) return -1;      // the rest of the super-block (of the front, if it ends here), K = 32
+        }
+        if (se < max_w && abt0(sb, se, se, 1) != 0) return -1;   // everything right of the super-block, K = 128
       }
       // the products the MFMA kernel carries for this level (useful flops: lower triangle of the trailing update)
       for (int f : lvl[h]) {
@@ -429,11 +446,11 @@ int spd_factor_numeric_device(const CsrMatrix &A, SpdFactor &F, const std::vecto
           hipEvent_t a, b;
           FA_OK(hipEventCreate(&a)); FA_OK(hipEventCreate(&b));
           FA_OK(hipEventRecord(a, st));
-          hipLaunchKernelGGL((k_fa_abt<1>), dim3(nrt * nct, nf), dim3(256), 0, st, d_fd, L, 0, d_Fm, d_W, d_WT);
+          hipLaunchKernelGGL((k_fa_abt<1>), dim3(nrt * nct, nf), dim3(256), 0, st, d_fd, L, 0, 0, 0, 0, d_Fm, d_W, d_WT);
           FA_OK(hipEventRecord(b, st));
           evs.push_back({a, b});
         } else {
-          hipLaunchKernelGGL((k_fa_abt<1>), dim3(nrt * nct, nf), dim3(256), 0, st, d_fd, L, 0, d_Fm, d_W, d_WT);
+          hipLaunchKernelGGL((k_fa_abt<1>), dim3(nrt * nct, nf), dim3(256), 0, st, d_fd, L, 0, 0, 0, 0, d_Fm, d_W, d_WT);
         }
       }
     }
