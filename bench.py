@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--grid", type=str, default="50,50,40,400000")
     ap.add_argument("--loss", type=str, default="huber")
     ap.add_argument("--prof-steps", type=int, default=5)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--backend", type=str, default="nccl",
@@ -306,46 +306,56 @@ def main():
 
 
 def cpu_baseline(g, num_nodes, loss, X0, steps):
-    """The oracle timed on the host cores, bounded sample: ONE node (an interior slab) of the 8,
-    `steps` x (iterate + update), neighbour poses frozen.  Timing scope as in the reference driver
-    (sum of iterate()+update(), dist_pgo.cpp:496-521); whole-job rate = 1 / (num_nodes * t_node)."""
-    from oracle.g2o import Measurements, partition_measurements
-    from oracle.hash import DPGOHash, Options as OOptions
-    z = np.zeros(len(g["I"]), np.int64)
-    mm = Measurements(z, g["I"], z, g["J"], g["R"], g["t"], g["kappa"], g["tau"])
-    N, d = g["num_poses"], 3
-    _, meas, g_index = partition_measurements(N, mm, num_nodes)
-    a = num_nodes // 2
-    o = OOptions.driver(loss, True)
-    t0 = time.time()
-    nd = DPGOHash(a, meas[a], o)
-    t_setup = time.time() - t0
-    p = nd.problem
-    n0, n1 = p.n
-    Z = np.zeros(((d + 1) * (n0 + n1), d))
-    q, inc_n = N // num_nodes, N - num_nodes * (N // num_nodes)
-    start = lambda b: b * (q + 1) if b < inc_n else inc_n * (q + 1) + (b - inc_n) * q
-    for b, poses in p.info.index.items():
-        for pose, (blk, k) in poses.items():
-            gid = start(b) + pose
-            if blk == 0:
-                Z[k] = X0[gid]
-                Z[n0 + k * d: n0 + k * d + d] = X0[N + gid * d: N + gid * d + d]
-            else:
-                Z[(d + 1) * n0 + k] = X0[gid]
-                r0 = (d + 1) * n0 + n1 + k * d
-                Z[r0:r0 + d] = X0[N + gid * d: N + gid * d + d]
-    nd.initialize(Z)
-    nd.update()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        nd.iterate()
-        nd.update()
-    t_node = (time.perf_counter() - t0) / steps
-    return {"value": 1.0 / (num_nodes * t_node), "unit": "iters/s", "cores": 1, "kind": "port",
-            "sample": "oracle (numpy/scipy restatement), node %d of %d (n0=%d, n1=%d), %d x (iterate+update), "
-                      "neighbours frozen; whole-job rate = 1/(%d * %.3f s); oracle set-up %.1f s untimed"
-                      % (a, num_nodes, n0, n1, steps, num_nodes, t_node, t_setup)}
+    """The C++ CPU restatement of the path (tools/cpu_baseline/cpu_dpgo: -O3 -march=native -fopenmp on the library's
+    host data structures, see its header) timed on this box's host cores on a bounded sample: all `num_nodes` nodes,
+    `steps` outer iterations from the same initial guess, once with one thread and once with the cores the cgroup
+    grants.  Timing scope as in the reference driver: sum of iterate() + update() over the nodes, communication
+    excluded (dist_pgo.cpp:496-521).  `value` is the all-core rate."""
+    import struct
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "tools", "cpu_baseline", "cpu_dpgo")
+    if not os.path.exists(exe):
+        return {"value": None, "unit": "iters/s", "cores": 0, "kind": "port",
+                "sample": "tools/cpu_baseline/cpu_dpgo is not built (make -C tools/cpu_baseline)"}
+    d, N, m = 3, g["num_poses"], len(g["I"])
+    tmp = tempfile.mkdtemp(prefix="dpgo_cpu_")
+    fe, fx = os.path.join(tmp, "edges.bin"), os.path.join(tmp, "X0.bin")
+    rec = np.dtype([("i", "<i4"), ("j", "<i4"), ("R", "<f8", (d * d,)), ("t", "<f8", (d,)), ("kappa", "<f8"), ("tau", "<f8")])
+    E = np.zeros(m, rec)
+    E["i"], E["j"] = g["I"], g["J"]
+    E["R"], E["t"] = np.asarray(g["R"]).reshape(m, d * d), g["t"]
+    E["kappa"], E["tau"] = g["kappa"], g["tau"]
+    with open(fe, "wb") as fh:
+        fh.write(struct.pack("<iii", d, N, m))
+        fh.write(E.tobytes())
+    np.asfortranarray(X0, dtype=np.float64).T.copy().tofile(fx)        # column-major
+    cores = _host_cores()
+    runs = {}
+    try:
+        out = subprocess.run([exe, fe, fx, str(num_nodes), str(loss), str(steps), "1,%d" % cores], capture_output=True, text=True,
+                             timeout=900)
+        res = json.loads(out.stdout.strip().splitlines()[-1])
+        for r in res["runs"]:
+            runs[r["threads"]] = dict(r, setup_s=res["setup_s"])
+    except Exception as e:
+        runs = {1: {"error": repr(e)}, cores: {"error": repr(e)}}
+    for f in (fe, fx):
+        os.remove(f)
+    os.rmdir(tmp)
+    cpu_model = "unknown"
+    try:
+        cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
+    rate = lambda r: (1.0 / r["seconds_per_iteration"]) if "seconds_per_iteration" in r else None
+    return {"value": rate(runs[cores]), "unit": "iters/s", "cores": min(cores, num_nodes), "kind": "port",
+            "value_1_thread": rate(runs[1]), "cpu_model": cpu_model, "host_cores_granted": cores,
+            "objective_2F_after_sample": runs[cores].get("objective_2F"),
+            "sample": "C++ restatement (tools/cpu_baseline/cpu_dpgo, g++ -O3 -march=native -fopenmp), all %d nodes, %d outer "
+                      "iterations (iterate + update, communication excluded) from the chordal initialisation; the nodes "
+                      "are dealt to the threads (at most %d run at once); set-up %.1f s untimed"
+                      % (num_nodes, steps, num_nodes, runs[cores].get("setup_s", float("nan")))}
 
 
 if __name__ == "__main__":

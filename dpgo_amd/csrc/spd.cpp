@@ -12,7 +12,9 @@
 #include <numeric>
 #include <queue>
 
+#ifndef DPGO_NO_DEVICE   /* (tools/cpu_baseline builds this file for the host alone) */
 #include <hip/hip_runtime.h>
+#endif
 
 namespace dpgo {
 int spd_factor_numeric_device(const CsrMatrix &A, SpdFactor &F, const std::vector<std::vector<int>> &children,
@@ -658,7 +660,6 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
   }
   F.W.assign(F.w_off[nt], 0.0);
   F.WT.assign(F.wt_off[nt], 0.0);
-  (void)hipGetLastError();
 
   // numeric multifrontal factorisation, level by level: fronts of one tree height are independent.
   // Small fronts are spread over threads; big fronts are factored one at a time with threads inside.
@@ -828,6 +829,7 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
   // numeric phase: on the GPU when there is one (spd_dev.hip: front elimination with v_mfma_f64_16x16x4_f64), else --
   // or with DPGO_SPD_HOST_FACTOR=1 -- the host loop below
   bool on_device = false;
+#ifndef DPGO_NO_DEVICE
   {
     int ndev = 0;
     if (!getenv("DPGO_SPD_HOST_FACTOR") && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
@@ -840,6 +842,7 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
       on_device = true;
     }
   }
+#endif
   for (int h = 0; h <= maxh_n && !fail && !on_device; h++) {
     std::vector<int> small, big;
     for (int f : lvl_fronts[h]) (F.w[f] + F.u[f] >= BIG ? big : small).push_back(f);
@@ -883,11 +886,13 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
 }
 
 int spd_refactor(const CsrMatrix &A, SpdFactor &F) {
+#ifndef DPGO_NO_DEVICE
   int ndev = 0;
-  if (F.n != A.n || (int)F.children.size() != F.nfronts || getenv("DPGO_SPD_HOST_FACTOR") ||
-      hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-    return spd_factor(A, F, 64, 0);
-  return spd_factor_numeric_device(A, F, F.children, nullptr, nullptr);
+  if (F.n == A.n && (int)F.children.size() == F.nfronts && !getenv("DPGO_SPD_HOST_FACTOR") &&
+      hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0)
+    return spd_factor_numeric_device(A, F, F.children, nullptr, nullptr);
+#endif
+  return spd_factor(A, F, 64, 0);
 }
 
 int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf, int collapse) {
