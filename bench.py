@@ -237,15 +237,18 @@ def main():
         # HBM bytes per launch from the PMC counters: measured by separate rocprofv3 --pmc passes of this
         # same command (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process); the committed
         # summary (tools/pmc_summary.py) is quoted when it covers this workload and kernel
-        traffic = None
+        traffic = traffic_source = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
+            import glob
+            cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+            pm = json.load(open(cand[-1]))
             if pm.get("workload") == args.grid and pm.get("n_gpus") == world and not args.emulate_world:
                 traffic = pm["kernels"][dom[0]]["hbm_bytes_per_launch"]
+                traffic_source = "committed rocprofv3 --pmc passes of this command (%s), not measured in this run" % os.path.basename(cand[-1])
         except Exception:
             traffic = None
         roofline = dict(kernel=dom[0], bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=ach / HBM_PEAK_GBS, traffic=traffic, avg_launch_us=1e3 * ms / cnt,
+                        frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_source, avg_launch_us=1e3 * ms / cnt,
                         algorithmic_bytes_per_launch=by / cnt, launches_per_step=cnt / args.prof_steps)
 
     # ---- CPU baseline: the oracle (numpy/scipy restatement) on a bounded sample, rank 0, N = 1 only

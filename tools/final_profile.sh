@@ -3,7 +3,7 @@
 tag=${1:-r02}
 out=gpurun_out/final
 mkdir -p $out
-timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $out/gpu_tests.txt
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $out/gpu_tests.txt
 timeout 600 python bench.py > $out/${tag}_bench_n1.json 2> $out/bench_n1.err
 timeout 600 python bench.py --emulate-world 8 --emulate-rank 3 --no-cpu > $out/${tag}_bench_emulated_rank3of8.json 2> $out/bench_emu.err
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

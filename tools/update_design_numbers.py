@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
 """Rewrite the measured-numbers table of DESIGN.md section 6a from the committed artefacts
-(profiles/rNN_bench_n1.json, rNN_bench_emulated_rank3of8.json, pmc_hbm_traffic.json).  Usage: update_design_numbers.py r01"""
+(profiles/rNN_bench_n1.json, rNN_bench_emulated_rank3of8.json, rNN_pmc_hbm_traffic.json, rNN_mfma_utilisation.json).
+Usage: update_design_numbers.py r02"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 j = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench_n1.json")))
 e = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench_emulated_rank3of8.json")))
-pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
+pm = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_hbm_traffic.json")))
+mf = json.load(open(os.path.join(ROOT, "profiles", tag + "_mfma_utilisation.json")))
+cv, cb = j["convergence"], j["cpu_baseline"]
 K, r = j["kernels"], j["roofline"]
 
 
@@ -37,7 +40,10 @@ other = sum(v["ms_per_step"] for k, v in K.items() if not k.startswith("k_spd") 
 rows = [
     "| quantity | value | source |", "|---|---|---|",
     "| throughput | **%.1f outer iterations / s**, %.2f ms / iteration | `profiles/%s_bench_n1.json` |" % (j["value"], j["ms_per_step"], tag),
-    "| CPU baseline (oracle, 1 core, bounded sample: 1 of 8 nodes) | %.2f iterations / s | same file, `cpu_baseline` |" % j["cpu_baseline"]["value"],
+    "| to the reference objective (within 1e-6 of the value the run converges to) | **%d iterations, %.2f s** (mean %.1f ms / iteration); whole 400-iteration run %.1f ms / iteration; last 20 iterations (no node refines any more) %.2f ms / iteration | same file, `convergence` |" % (
+        cv["iterations_to_1e-6"], cv["seconds_to_1e-6"], cv["mean_ms_per_iter_to_1e-6"], cv["mean_ms_per_iter_whole_run"], cv["last20_ms_per_iter"]),
+    "| CPU baseline (C++ restatement, all 8 nodes, 3 iterations; %s) | %.2f iterations / s on %d cores, %.2f on 1 thread | same file, `cpu_baseline` |" % (
+        cb.get("cpu_model", "?"), cb["value"], cb["cores"], cb["value_1_thread"]),
     "| set-up (untimed) | %.1f s graph + chordal init, %.1f s operators + both factorizations | same file |" % (
         j["setup_s"]["graph+chordal_init"], j["setup_s"]["operators+factorizations"]),
     "| one rank of an 8-GPU run emulated on one GPU (1 node, frozen neighbours, no exchange) | %.2f ms / iteration | `profiles/%s_bench_emulated_rank3of8.json` (diagnostic, not a metric) |" % (e["ms_per_step"], tag),
@@ -45,10 +51,14 @@ rows = [
         r["kernel"], r["launches_per_step"], r["avg_launch_us"], rocprof_avg_us(r["kernel"]), tag, tag),
     "| its algorithmic bytes | %.1f MB / launch ⇒ %.2f TB/s = **%.2f of the 8 TB/s HBM roofline** | §3 table |" % (
         r["algorithmic_bytes_per_launch"] / 1e6, r["achieved"] / 1e3, r["frac"]),
-    "| its measured HBM traffic | %.1f MB / launch (2×FETCH_SIZE + WRITE_SIZE) = %.2f × algorithmic | `profiles/pmc_hbm_traffic.json` |" % (
-        tr / 1e6, tr / r["algorithmic_bytes_per_launch"]),
+    "| its measured HBM traffic | %.1f MB / launch (2×FETCH_SIZE + WRITE_SIZE) = %.2f × algorithmic | `profiles/%s_pmc_hbm_traffic.json` |" % (
+        tr / 1e6, tr / r["algorithmic_bytes_per_launch"], tag),
     "| time split per iteration | SPD solves %.2f ms (1 `G_RR+λI` solve + 3 `G_tt` solves), operator applies %.2f ms, everything else %.2f ms | `%s_bench_n1.json` `kernels` |" % (
         spd, K["k_bsr"]["ms_per_step"], other, tag),
+    "| factorisation on the GPU (MFMA tile kernel `k_fa_abt`) | %s | `profiles/%s_mfma_utilisation.json` |" % (
+        "; ".join("%.1f GFLOP in %.1f ms = %.1f TFLOP/s (%.2f of the 78.6 TFLOP/s FP64 matrix peak)" % (r_["GFLOP"], r_["ms"], r_["TFLOPs"], r_["fraction_of_peak"])
+                  for r_ in mf["hip_event_rates_G_tt_then_G_RR"]) +
+        "; matrix pipe busy %.2f of the CU-busy cycles" % mf["kernels"]["k_fa_abt"].get("mfma_busy_over_cu_busy", float("nan")), tag),
     "| solver | %.1f M / %.1f M factor entries, %d / %d tree levels (`G_tt` / `G_RR+λI`); one node per GPU: %d / %d levels | `solver` in both files |" % (
         j["solver"]["nnz_tt"] / 1e6, j["solver"]["nnz_rr"] / 1e6, j["solver"]["levels_tt"], j["solver"]["levels_rr"],
         e["solver"]["levels_tt"], e["solver"]["levels_rr"]),
