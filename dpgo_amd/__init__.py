@@ -529,14 +529,16 @@ class Comm:
 
     def __init__(self, group, rank, nranks, bcast=None):
         self.group, self.rank, self.nranks = group, rank, nranks
+        if nranks > 1 and bcast is None:
+            raise ValueError("nranks > 1 needs a broadcast function for the unique id")
         idb = C.create_string_buffer(128)
-        if rank == 0 and lib().dpgo_comm_unique_id(idb) != 0:
-            raise RuntimeError("dpgo_comm_unique_id failed (RCCL not available)")
-        raw = bytes(idb.raw)
+        raw = b""
+        if rank == 0 and lib().dpgo_comm_unique_id(idb) == 0:
+            raw = bytes(idb.raw)
         if nranks > 1:
-            if bcast is None:
-                raise ValueError("nranks > 1 needs a broadcast function for the unique id")
-            raw = bcast(raw)
+            raw = bcast(raw)          # (an empty id tells every rank that rank 0 could not get one: nobody is left waiting)
+        if len(raw) != 128:
+            raise RuntimeError("dpgo_comm_unique_id failed (RCCL not available)")
         idb = C.create_string_buffer(raw, 128)
         h = C.c_void_p()
         if lib().dpgo_comm_create(group._h, rank, nranks, idb, C.byref(h)) != 0:
