@@ -13,10 +13,14 @@ Pinning status ("Oracle"):
     and against the known-answer vectors of the reference's unit tests
     (C++/Optimization/tests/IterativeSolvers_unit_test.cpp:79-247,
     TNT_unit_test.cpp:63-187) committed under tests/golden/.
-  * Everything that needs Eigen / CHOLMOD / glog / Boost (DPGOHash,
-    DPGOProblem, DPGOStar, the SIMD SO(d) projection) is PARITY UNPINNED: the
+  * ``oracle.problem.project_to_SOdn`` (nearest rotation) is PINNED: checked
+    against the reference's own AVX2 kernels (project_to_SOd.cpp:7-33,
+    97-196) built by oracle/ref_so3/Makefile from the sources where they lie;
+    outputs committed as tests/golden/so_ref.npz.
+  * Everything else that needs Eigen / CHOLMOD / glog / Boost to run
+    (DPGOHash, DPGOProblem, DPGOStar, DChordal) is PARITY UNPINNED: the
     reference cannot be built in this image and ships no tests or golden
     vectors for this path.  It is pinned only by algebraic invariants
      and by the mathematical definition of each
-    operator (nearest rotation = polar factor, exact SPD solves).
+    operator (exact SPD solves, explicit sparse products).
 """

@@ -637,3 +637,26 @@ def test_dynamic_rescale_with_amm_pgo_star(fixtures_dir):
         orc.step()
         assert star.step() == 0
         np.testing.assert_allclose(star.state()["fobj"], orc.fobj, rtol=1e-7, err_msg="it=%d" % it)
+
+
+def test_projection_kernel_matches_reference_avx_vectors(fixtures_dir, golden_dir):
+    """The device projection (project_so3 / project_so2 in kernels.hip) against the outputs of the REFERENCE's own AVX2
+    kernels (tests/golden/so_ref.npz, see tests/test_oracle_so.py): reference-pinned parity for row a9."""
+    z = np.load(os.path.join(golden_dir, "so_ref.npz"))
+    from tests.test_oracle_so import well_conditioned
+    G = dpgo_amd.read_g2o(os.path.join(fixtures_dir, "sphere2500.g2o"), 1)
+    grp = dpgo_amd.NodeGroup(G, [0], dpgo_amd.Options.driver())
+    n0, A, U = 2500, z["A3"], z["U3"]
+    pad = np.tile(np.eye(3), (n0 - len(A), 1, 1))
+    out = grp.debug_apply(0, "project", np.concatenate([A, pad]).reshape(3 * n0, 3), 3 * n0).reshape(n0, 3, 3)[:len(A)]
+    well = well_conditioned(A)
+    np.testing.assert_allclose(out[well], U[well], rtol=0, atol=1e-9)
+    d_out = np.linalg.norm((out - A).reshape(len(A), -1), axis=1)
+    d_ref = np.linalg.norm((U - A).reshape(len(A), -1), axis=1)
+    np.testing.assert_allclose(d_out, d_ref, rtol=1e-8, atol=1e-12)
+    G2 = dpgo_amd.read_g2o(os.path.join(fixtures_dir, "M3500.g2o"), 1)
+    grp2 = dpgo_amd.NodeGroup(G2, [0], dpgo_amd.Options.driver())
+    n2, A2, U2 = 3500, z["A2"], z["U2"]
+    pad = np.tile(np.eye(2), (n2 - len(A2), 1, 1))
+    out2 = grp2.debug_apply(0, "project", np.concatenate([A2, pad]).reshape(2 * n2, 2), 2 * n2).reshape(n2, 2, 2)[:len(A2)]
+    np.testing.assert_allclose(out2, U2, rtol=0, atol=1e-15)
