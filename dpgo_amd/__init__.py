@@ -26,7 +26,8 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdpgo_amd.so")
+# (DPGO_AMD_LIB: A/B builds of the same library from tools/build_variant.sh; never a different implementation)
+LIB_PATH = os.environ.get("DPGO_AMD_LIB") or os.path.join(_HERE, "libdpgo_amd.so")
 
 LOSS_NONE, LOSS_HUBER, LOSS_GM, LOSS_WELSCH = 0, 1, 2, 3
 LOSS_NAMES = {"trivial": 0, "none": 0, "huber": 1, "gm": 2, "welsch": 3}

@@ -662,6 +662,15 @@ static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec) {
   HIP_CHECK(hipEventCreate(&e0));
   HIP_CHECK(hipEventCreate(&e1));
   double tot_us = 0, tot_mb = 0;
+  unsigned long long *trace = nullptr;
+  if (getenv("DPGO_SPD_TRACE")) {
+    size_t most = 1;
+    for (const auto &v : S.fwd_levels) most = std::max(most, (size_t)(v.nwide + v.nnarrow));
+    for (const auto &v : S.bwd_levels) most = std::max(most, (size_t)(v.nwide + v.nnarrow));
+    HIP_CHECK(hipMalloc(&trace, most * 6 * 8));
+    HIP_CHECK(hipMemset(trace, 0, most * 6 * 8));
+    spd_trace_set(trace);
+  }
   auto run = [&](bool fwd, size_t l, const SpdSolverDev::Level &v, const std::vector<int> &fronts, double bytes) {
     if (v.nwide + v.nnarrow == 0) return;
     int wmax = 0, mmax = 0;
@@ -678,12 +687,41 @@ static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec) {
     }
     tot_us += best * 1e3;
     tot_mb += bytes / 1e6;
+    if (trace) {   // (-DSPD_TRACE builds) phase timestamps of the last repetition, 100 MHz ticks -> us
+      const int nt = v.nwide + v.nnarrow;
+      std::vector<unsigned long long> h((size_t)nt * 6);
+      HIP_CHECK(hipMemcpy(h.data(), trace, h.size() * 8, hipMemcpyDeviceToHost));
+      unsigned long long tmin = ~0ull;
+      for (int t = 0; t < nt; t++) if (h[(size_t)t * 6]) tmin = std::min(tmin, h[(size_t)t * 6]);
+      auto pct = [](std::vector<double> &x, double q) { if (x.empty()) return 0.0; std::sort(x.begin(), x.end()); return x[std::min(x.size() - 1, (size_t)(q * x.size()))]; };
+      for (int cls = 0; cls < 2; cls++) {
+        const int a = cls == 0 ? 0 : v.nwide, b = cls == 0 ? v.nwide : nt;
+        if (a == b) continue;
+        std::vector<double> ph[5], start, end;
+        for (int t = a; t < b; t++) {
+          const unsigned long long *q = &h[(size_t)t * 6];
+          if (!q[0] || !q[5]) continue;
+          for (int i = 0; i < 5; i++) ph[i].push_back((double)(q[i + 1] - q[i]) * 0.01);
+          start.push_back((double)(q[0] - tmin) * 0.01);
+          end.push_back((double)(q[5] - tmin) * 0.01);
+        }
+        fprintf(stderr, "[trace]   %s tiles %5zu: item %.2f/%.2f  gather %.2f/%.2f  stream %.2f/%.2f  reduce %.2f/%.2f  write %.2f/%.2f us (median/p90);"
+                " start p10 %.1f p50 %.1f p90 %.1f max %.1f, end p10 %.1f p50 %.1f p90 %.1f max %.1f us\n", cls == 0 ? "wide  " : "narrow", start.size(),
+                pct(ph[0], .5), pct(ph[0], .9), pct(ph[1], .5), pct(ph[1], .9), pct(ph[2], .5), pct(ph[2], .9), pct(ph[3], .5), pct(ph[3], .9),
+                pct(ph[4], .5), pct(ph[4], .9), pct(start, .1), pct(start, .5), pct(start, .9), pct(start, 1.0), pct(end, .1), pct(end, .5),
+                pct(end, .9), pct(end, 1.0));
+      }
+    }
     fprintf(stderr, "[spd] dof %d %s level %2zu fronts %5zu wide tiles %5d x %2d rows, narrow tiles %5d, max_w %4d max_m %4d  %7.2f MB %6.1f us %6.0f GB/s\n",
             S.dof, fwd ? "fwd" : "bwd", l, fronts.size(), v.nwide, v.rows, v.nnarrow, wmax, mmax, bytes / 1e6, best * 1e3, bytes / (best * 1e-3) / 1e9);
   };
   for (size_t l = 0; l < S.fwd_levels.size(); l++) run(true, l, S.fwd_levels[l], F.by_height[l], S.fwd_level_bytes[l]);
   for (size_t l = 0; l < S.bwd_levels.size(); l++) run(false, l, S.bwd_levels[l], F.by_depth[l], S.bwd_level_bytes[l]);
   fprintf(stderr, "[spd] dof %d total %.1f MB %.1f us %.0f GB/s (launches timed one by one)\n", S.dof, tot_mb, tot_us, tot_mb / tot_us * 1e3);
+  if (trace) {
+    spd_trace_set(nullptr);
+    HIP_CHECK(hipFree(trace));
+  }
   HIP_CHECK(hipEventDestroy(e0));
   HIP_CHECK(hipEventDestroy(e1));
 }

@@ -212,6 +212,8 @@ struct SpdDev {
 // dof = 1: unknown i is the translation of pose i; dof = d: unknown i = (pose i / d, rotation row i % d).
 // vec is a record array: forward reads the right-hand side from vec and writes y to ytmp (n x d, the pivots
 // of a front consecutive); backward reads ytmp and writes scale * A^-1 b into vec (scale must be +1 or -1).
+// measurement builds (-DSPD_TRACE) only: where the solve tiles write their phase timestamps (6 per tile); no-op otherwise
+void spd_trace_set(unsigned long long *p);
 void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int tile0, int nwide, int nnarrow,
                       int rows, double *vec, double *ytmp, double scale, double level_bytes = 0.0, bool stream_once = true,
                       NodeMask mask = ALL_NODES);   // nodes outside the mask: their fronts are skipped

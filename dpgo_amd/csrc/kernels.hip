@@ -1122,6 +1122,16 @@ __global__ __launch_bounds__(64) void k_cg_scal(SegTable T, int phase, const dou
   }
 }
 
+#ifdef SPD_TRACE   /* measurement build only: per-tile phase timestamps (100 MHz wall clock), see spd_profile() */
+__device__ unsigned long long *g_spd_trace = nullptr;
+#define SPD_T(i) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tr[i] = wall_clock64(); }
+#define SPD_TRACE_DECL unsigned long long tr[6] = {trace_t0, 0, 0, 0, 0, 0};
+#define SPD_TRACE_FLUSH(cond) if (g_spd_trace && (cond)) { _Pragma("unroll") for (int q = 0; q < 6; q++) g_spd_trace[(size_t)trace_slot * 6 + q] = tr[q]; }
+#else
+#define SPD_T(i)
+#define SPD_TRACE_DECL
+#define SPD_TRACE_FLUSH(cond)
+#endif
 // ---------------------------------------------------------------------------
 // Multifrontal SPD solve.  A tile = ROWS rows (forward: rows of W_s^T's transpose, i.e. outputs
 // [y_s ; dupd]; backward: pivots x_s) of one front; NW waves share a tile and split the reduction
@@ -1151,6 +1161,12 @@ __global__ __launch_bounds__(64) void k_cg_scal(SegTable T, int phase, const dou
 #endif
 #ifndef SPD_PULL16
 #define SPD_PULL16 4   // measured best of 2, 4, 8 (one node per GPU: -2 %)
+#endif
+#ifndef SPD_PULL64
+#define SPD_PULL64 2
+#endif
+#ifndef SPD_PRE64
+#define SPD_PRE64 0
 #endif
 #ifndef SPD_WPE
 #define SPD_WPE 6    // waves per SIMD the 64-row solve kernels are compiled for: 85 VGPRs, 3 workgroups per CU (measured best of 5, 6, 8)
@@ -1260,10 +1276,13 @@ __device__ __forceinline__ int spd_chunk(int len) {
 // fw: this wave's staging area (SPD_CH * D doubles); red: NW x (ROWS * D) doubles shared by the tile's waves.
 template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool NT>
 __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it, const double *vec, double *ytmp,
-                                             double *fw, double *red, const int wv, const int lane) {
+                                             double *fw, double *red, const int wv, const int lane,
+                                             int trace_slot = 0, unsigned long long trace_t0 = 0) {
+  SPD_TRACE_DECL
+  SPD_T(1)
   constexpr int KQ = 64 / ROWS, HB = SPD_HB;
-  constexpr bool PRE = ROWS < 64;   // levels with few tiles: latency matters, registers do not
-  constexpr int PULLB = ROWS < 64 ? SPD_PULL16 : 2;   // children's contributions fetched per round (top fronts have many)
+  constexpr bool PRE = ROWS < 64 || SPD_PRE64;   // levels with few tiles: latency matters, registers do not
+  constexpr int PULLB = ROWS < 64 ? SPD_PULL16 : SPD_PULL64;   // children's contributions fetched per round (top fronts have many)
   const int r = lane % ROWS, kq = lane / ROWS;
   const int p = it.first + r;
   const bool valid = r < it.count;
@@ -1294,7 +1313,11 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
     for (int kk = lane; kk < kn; kk += 64) {
       const int k = k0 + kk;
       double v[D];
+#ifdef SPD_PROBE_DENSE   /* measurement only (wrong results): the front's input already in front order */
+      const double *src = S.ubuf + (size_t)(it.piv_ptr + k) * D;
+#else
       const double *src = vec + vaddr<D, DOF>(piv[k]);
+#endif
 #pragma unroll
       for (int c = 0; c < D; c++) v[c] = *(src + c);
       pull_updates<D, PULLB>(S, pos0 + k, v);
@@ -1303,12 +1326,16 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#ifdef SPD_TRACE
+    if (tr[2] == 0) SPD_T(2)
+#endif
     if (valid) {
       if (!PRE) have0 = stream_first<D, KQ, NT, HB>(wp, ldm, kq, kn, w0);
       stream_rest<D, KQ, NT, HB>(wp, ldm, kq, kn, fw, have0, w0, acc);
     }
     __builtin_amdgcn_wave_barrier();
   }
+  SPD_T(3)
   if constexpr (KQ > 1) {
 #pragma unroll
     for (int c = 0; c < D; c++)
@@ -1337,23 +1364,30 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
       }
     }
   }
-  if (!writer) return;
-  if (p < w) {
-    double *dst = ytmp + (size_t)(it.piv_ptr + p) * D;   // y in front order: the backward sweep reads it back contiguously
+  SPD_T(4)
+  if (writer) {
+    if (p < w) {
+      double *dst = ytmp + (size_t)(it.piv_ptr + p) * D;   // y in front order: the backward sweep reads it back contiguously
 #pragma unroll
-    for (int c = 0; c < D; c++) *(dst + c) = (acc[c]);
-  } else {
-    double *dst = S.ubuf + (size_t)udst * D;
+      for (int c = 0; c < D; c++) *(dst + c) = (acc[c]);
+    } else {
+      double *dst = S.ubuf + (size_t)udst * D;
 #pragma unroll
-    for (int c = 0; c < D; c++) *(dst + c) = (acc[c] + extra[c]);
+      for (int c = 0; c < D; c++) *(dst + c) = (acc[c] + extra[c]);
+    }
   }
+  SPD_T(5)
+  SPD_TRACE_FLUSH(wv == 0 && lane == 0)
 }
 
 template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool NT>
 __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it, double scale, const double *ytmp,
-                                             double *vec, double *fw, double *red, const int wv, const int lane) {
+                                             double *vec, double *fw, double *red, const int wv, const int lane,
+                                             int trace_slot = 0, unsigned long long trace_t0 = 0) {
+  SPD_TRACE_DECL
+  SPD_T(1)
   constexpr int KQ = 64 / ROWS, HB = SPD_HB;
-  constexpr bool PRE = ROWS < 64;   // levels with few tiles: latency matters, registers do not
+  constexpr bool PRE = ROWS < 64 || SPD_PRE64;   // levels with few tiles: latency matters, registers do not
   const int r = lane % ROWS, kq = lane / ROWS;
   const int k = it.first + r;
   const bool valid = r < it.count;
@@ -1377,18 +1411,26 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
       const int p = p0 + pp;
       // ancestors' entries were scaled when they were written: undo by linearity (scale is +-1)
       const double sc = p < w ? 1.0 : scale;
+#ifdef SPD_PROBE_DENSE   /* measurement only (wrong results) */
+      const double *src = p < w ? ytmp + (size_t)(it.piv_ptr + p) * D : S.ubuf + (size_t)(it.ubuf_off + p - w) * D;
+#else
       const double *src = p < w ? ytmp + (size_t)(it.piv_ptr + p) * D : vec + vaddr<D, DOF>(upd[p - w]);
+#endif
 #pragma unroll
       for (int c = 0; c < D; c++) fw[pp * D + c] = sc * *(src + c);
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#ifdef SPD_TRACE
+    if (tr[2] == 0) SPD_T(2)
+#endif
     if (valid) {
       if (!PRE) have0 = stream_first<D, KQ, NT, HB>(wp, ldw, kq, pn, w0);
       stream_rest<D, KQ, NT, HB>(wp, ldw, kq, pn, fw, have0, w0, acc);
     }
     __builtin_amdgcn_wave_barrier();
   }
+  SPD_T(3)
   if constexpr (KQ > 1) {
 #pragma unroll
     for (int c = 0; c < D; c++)
@@ -1411,10 +1453,14 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
       }
     }
   }
-  if (!valid || kq != 0) return;
-  double *dst = vec + vaddr<D, DOF>(piv[k]);
+  SPD_T(4)
+  if (valid && kq == 0) {
+    double *dst = vec + vaddr<D, DOF>(piv[k]);
 #pragma unroll
-  for (int c = 0; c < D; c++) *(dst + c) = (scale * acc[c]);
+    for (int c = 0; c < D; c++) *(dst + c) = (scale * acc[c]);
+  }
+  SPD_T(5)
+  SPD_TRACE_FLUSH(wv == 0 && lane == 0)
 }
 
 // ---- 128-row tiles: two rows per lane, 16-byte panel loads (1 KB per wave instruction) -------------------------
@@ -1611,6 +1657,12 @@ __global__ __launch_bounds__(64 * SPD_NW(ROWS), ROWS == 64 ? SPD_WPE : 4) void k
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const SpdItem *items = (FWD ? S.fwd_items : S.bwd_items) + tile0;
   const int b = blockIdx.x;
+#ifdef SPD_TRACE
+  const unsigned long long tt0 = wall_clock64();
+#define SPD_TRACE_ARGS(slot) , (slot), tt0
+#else
+#define SPD_TRACE_ARGS(slot)
+#endif
   const NodeBits bits = mask_bits(mask);
   if (bits == 0) return;   // every node has left the device-side mask: nothing to read at all
   if (b >= nwide) {
@@ -1618,8 +1670,8 @@ __global__ __launch_bounds__(64 * SPD_NW(ROWS), ROWS == 64 ? SPD_WPE : 4) void k
     if (t >= nnarrow) return;
     const SpdItem it = load_item(items + nwide + t);
     if (!((bits >> it.node) & 1ull)) return;
-    if constexpr (FWD) spd_fwd_tile<D, DOF, 1, CH, 64, NT>(S, it, vec, ytmp, f[wv], red, 0, lane);
-    else spd_bwd_tile<D, DOF, 1, CH, 64, NT>(S, it, scale, ytmp, vec, f[wv], red, 0, lane);
+    if constexpr (FWD) spd_fwd_tile<D, DOF, 1, CH, 64, NT>(S, it, vec, ytmp, f[wv], red, 0, lane SPD_TRACE_ARGS(nwide + t));
+    else spd_bwd_tile<D, DOF, 1, CH, 64, NT>(S, it, scale, ytmp, vec, f[wv], red, 0, lane SPD_TRACE_ARGS(nwide + t));
   } else {
     const SpdItem it = load_item(items + b);
     if (!((bits >> it.node) & 1ull)) return;   // (uniform over the workgroup)
@@ -1627,10 +1679,11 @@ __global__ __launch_bounds__(64 * SPD_NW(ROWS), ROWS == 64 ? SPD_WPE : 4) void k
       if constexpr (FWD) spd_fwd_tile2<D, DOF, NW, CH, NT>(S, it, vec, ytmp, f[wv], red, wv, lane);
       else spd_bwd_tile2<D, DOF, NW, CH, NT>(S, it, scale, ytmp, vec, f[wv], red, wv, lane);
     } else {
-      if constexpr (FWD) spd_fwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, vec, ytmp, f[wv], red, wv, lane);
-      else spd_bwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, scale, ytmp, vec, f[wv], red, wv, lane);
+      if constexpr (FWD) spd_fwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, vec, ytmp, f[wv], red, wv, lane SPD_TRACE_ARGS(b));
+      else spd_bwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, scale, ytmp, vec, f[wv], red, wv, lane SPD_TRACE_ARGS(b));
     }
   }
+#undef SPD_TRACE_ARGS
 }
 
 }  // namespace
@@ -1918,6 +1971,11 @@ void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows,
                      arrived, host_flag, seq);
 }
 
+#ifdef SPD_TRACE
+void spd_trace_set(unsigned long long *p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_spd_trace), &p, sizeof(p)); }
+#else
+void spd_trace_set(unsigned long long *) {}
+#endif
 void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int tile0, int nwide, int nnarrow,
                       int rows, double *vec, double *ytmp, double scale, double level_bytes, bool stream_once,
                       NodeMask mask) {

@@ -24,6 +24,6 @@ for v in vals:
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stderr
     print("== %s=%s" % (var, v))
     for line in out.splitlines():
-        if line.startswith("[spd]") and ("total" in line or (levels and "level" in line)):
+        if (line.startswith("[spd]") and ("total" in line or (levels and "level" in line))) or (levels and line.startswith("[trace]")):
             print(line)
     sys.stdout.flush()
