@@ -60,6 +60,18 @@ static int env_int(const char *name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
+// DPGO_SETUP_TIMING=1: wall time of the set-up phases on stderr
+struct SetupClock {
+  const bool on = getenv("DPGO_SETUP_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char *what) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[setup] %-44s %8.3f s\n", what, std::chrono::duration<double>(n - t).count());
+    t = n;
+  }
+};
+
 // Device layout of a factor.  The solve streams every W_s once per sweep, so the matrices are re-packed
 // into PANELS: the entries one tile reads, contiguous, in the order it reads them.
 //   forward tile (rows p0 .. p0+count of [y ; dupd], all columns k < kend):  panel[k][r] = WT_s[k][p0 + r]
@@ -427,6 +439,7 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   // ---- SPD solvers: one block-diagonal system over all local nodes
   if (refactor_tt() != 0) return;
   {
+    SetupClock clk;
     CsrMatrix Arr;
     Arr.ptr.push_back(0);
     for (int a = 0; a < L; a++) {
@@ -444,13 +457,16 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
       }
     }
     Arr.n = (int)Arr.ptr.size() - 1;
+    clk.lap("G_RR: lambda_max (Lanczos) + shifted matrix");
     if (Arr.n > 0) {
-      if (spd_factor(Arr, Lrr_.F, env_int("DPGO_SPD_LEAF_RR", 96), env_int("DPGO_SPD_COLLAPSE_RR", 0)) != 0) return;
+      if (spd_factor(Arr, Lrr_.F, env_int("DPGO_SPD_LEAF_RR", 96), env_int("DPGO_SPD_COLLAPSE_RR", 0), env_int("DPGO_SPD_QUOTIENT", 1) ? d_ : 1) != 0) return;
+      clk.lap("G_RR: ordering + symbolic + numeric factor");
       Lrr_.dof = d_;
       std::vector<int> node_of_row((size_t)P0_ * d_);
       for (int a = 0; a < L; a++)
         for (int p = 0; p < info_[a].n[0] * d_; p++) node_of_row[(size_t)own_off_[a] * d_ + p] = a;
       Lrr_.upload(d_, node_of_row);
+      clk.lap("G_RR: panels (pack + upload)");
     }
   }
   // ---- halo lists
@@ -546,15 +562,18 @@ int Group::refactor_tt() {
     }
   }
   Att.n = (int)Att.ptr.size() - 1;
+  SetupClock clk;
   if (Ltt_.F.n == Att.n && Ltt_.F.nfronts > 0 && !Ltt_.F.children.empty()) {
     // same pattern, new values (a Dynamic rescale): numeric phase only, on the GPU
     if (spd_refactor(Att, Ltt_.F) != 0) return -1;
   } else if (spd_factor(Att, Ltt_.F, env_int("DPGO_SPD_LEAF_TT", 128), env_int("DPGO_SPD_COLLAPSE_TT", 0)) != 0) return -1;
+  clk.lap("G_tt: ordering + symbolic + numeric factor");
   Ltt_.dof = 1;
   std::vector<int> node_of_pose(P0_);
   for (int a = 0; a < L; a++)
     for (int p = 0; p < info_[a].n[0]; p++) node_of_pose[own_off_[a] + p] = a;
   Ltt_.upload(d_, node_of_pose);
+  clk.lap("G_tt: panels (pack + upload)");
   return 0;
 }
 

@@ -443,9 +443,17 @@ struct Dissector {
 
 // tree: a nested-dissection tree of A computed earlier (the dissection does not depend on `collapse`); if *tree is
 // empty it is computed here and stored there.
+static double setup_lap(double &t0, const char *what) {   // DPGO_SETUP_TIMING=1: phase times on stderr
+  const double t = omp_get_wtime();
+  if (getenv("DPGO_SETUP_TIMING")) fprintf(stderr, "[setup]   spd: %-37s %8.3f s\n", what, t - t0);
+  t0 = t;
+  return t;
+}
+
 static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int collapse, bool symbolic_only,
-                           std::vector<TreeNode> *tree) {
+                           std::vector<TreeNode> *tree, int block) {
   const int n = A.n;
+  double t_lap = omp_get_wtime();
   omp_set_num_threads(host_threads());
   F = SpdFactor();
   F.n = n;
@@ -467,61 +475,97 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
   Dissector D(adj, leaf);
   if (tree && !tree->empty()) D.nodes = *tree;
   else {
-    // connected components (the nodes of a group are disconnected from each other) are dissected independently,
-    // one host thread each; the result does not depend on the number of threads
-    std::vector<std::vector<int>> comps;
+    // block > 1 (G_RR: the d rows of a pose have the same neighbours): the quotient graph -- one vertex per block of
+    // `block` consecutive unknowns -- is dissected instead and every tree node expanded afterwards.  Same separators
+    // as on the scalar graph with indistinguishable vertices kept together, at 1 / block^2 of the work.
+    CsrMatrix quot;
+    const bool use_q = block > 1 && n % block == 0;
+    if (use_q) {
+      const int nq = n / block;
+      quot.n = nq;
+      quot.ptr.assign(nq + 1, 0);
+      std::vector<int> mark(nq, -1);
+      for (int q = 0; q < nq; q++) {
+        for (int i = q * block; i < (q + 1) * block; i++)
+          for (int k = adj.ptr[i]; k < adj.ptr[i + 1]; k++) {
+            const int w = adj.col[k] / block;
+            if (w != q && mark[w] != q) { mark[w] = q; quot.col.push_back(w); }
+          }
+        std::sort(quot.col.begin() + quot.ptr[q], quot.col.end());
+        quot.ptr[q + 1] = (int)quot.col.size();
+      }
+    }
+    const CsrMatrix &gq = use_q ? quot : adj;
+    const int gn = gq.n, gleaf = use_q ? std::max(1, leaf / block) : leaf;
+    Dissector Dq(gq, gleaf);
     {
-      std::vector<int> comp(n, -1), stack;
-      for (int r = 0; r < n; r++) {
-        if (comp[r] >= 0) continue;
-        const int c = (int)comps.size();
-        comps.emplace_back();
-        comp[r] = c;
-        stack.assign(1, r);
-        while (!stack.empty()) {
-          const int v = stack.back();
-          stack.pop_back();
-          comps[c].push_back(v);
-          for (int k = adj.ptr[v]; k < adj.ptr[v + 1]; k++)
-            if (comp[adj.col[k]] < 0) { comp[adj.col[k]] = c; stack.push_back(adj.col[k]); }
+      Dissector &D = Dq;   // (the code below fills D.nodes)
+      // connected components (the nodes of a group are disconnected from each other) are dissected independently,
+      // one host thread each; the result does not depend on the number of threads
+      std::vector<std::vector<int>> comps;
+      {
+        std::vector<int> comp(gn, -1), stack;
+        for (int r = 0; r < gn; r++) {
+          if (comp[r] >= 0) continue;
+          const int c = (int)comps.size();
+          comps.emplace_back();
+          comp[r] = c;
+          stack.assign(1, r);
+          while (!stack.empty()) {
+            const int v = stack.back();
+            stack.pop_back();
+            comps[c].push_back(v);
+            for (int k = gq.ptr[v]; k < gq.ptr[v + 1]; k++)
+              if (comp[gq.col[k]] < 0) { comp[gq.col[k]] = c; stack.push_back(gq.col[k]); }
+          }
+          std::sort(comps[c].begin(), comps[c].end());
         }
-        std::sort(comps[c].begin(), comps[c].end());
       }
-    }
-    // (components are started largest first; tiny ones share a dissector)
-    std::vector<int> big;
-    std::vector<int> small_verts;
-    for (int c = 0; c < (int)comps.size(); c++) {
-      if ((int)comps[c].size() >= 2048) big.push_back(c);
-      else small_verts.insert(small_verts.end(), comps[c].begin(), comps[c].end());
-    }
-    std::vector<std::vector<TreeNode>> parts(big.size());
+      // (components are started largest first; tiny ones share a dissector)
+      std::vector<int> big;
+      std::vector<int> small_verts;
+      for (int c = 0; c < (int)comps.size(); c++) {
+        if ((int)comps[c].size() >= 2048) big.push_back(c);
+        else small_verts.insert(small_verts.end(), comps[c].begin(), comps[c].end());
+      }
+      std::vector<std::vector<TreeNode>> parts(big.size());
 #pragma omp parallel for schedule(dynamic, 1) if (big.size() > 1)
-    for (int b = 0; b < (int)big.size(); b++) {
-      Dissector Dc(adj, leaf);
-      Dc.dissect(comps[big[b]], -1);
-      parts[b] = std::move(Dc.nodes);
-    }
-    for (auto &p : parts) {
-      const int off = (int)D.nodes.size();
-      for (TreeNode &t : p) {
-        if (t.parent >= 0) t.parent += off;
-        for (int &ch : t.children) ch += off;
-        D.nodes.push_back(std::move(t));
+      for (int b = 0; b < (int)big.size(); b++) {
+        Dissector Dc(gq, gleaf);
+        Dc.dissect(comps[big[b]], -1);
+        parts[b] = std::move(Dc.nodes);
+      }
+      for (auto &p : parts) {
+        const int off = (int)D.nodes.size();
+        for (TreeNode &t : p) {
+          if (t.parent >= 0) t.parent += off;
+          for (int &ch : t.children) ch += off;
+          D.nodes.push_back(std::move(t));
+        }
+      }
+      if (!small_verts.empty()) {
+        std::sort(small_verts.begin(), small_verts.end());
+        Dissector Ds(gq, gleaf);
+        Ds.dissect(std::move(small_verts), -1);
+        const int off = (int)D.nodes.size();
+        for (TreeNode &t : Ds.nodes) {
+          if (t.parent >= 0) t.parent += off;
+          for (int &ch : t.children) ch += off;
+          D.nodes.push_back(std::move(t));
+        }
       }
     }
-    if (!small_verts.empty()) {
-      std::sort(small_verts.begin(), small_verts.end());
-      Dissector Ds(adj, leaf);
-      Ds.dissect(std::move(small_verts), -1);
-      const int off = (int)D.nodes.size();
-      for (TreeNode &t : Ds.nodes) {
-        if (t.parent >= 0) t.parent += off;
-        for (int &ch : t.children) ch += off;
-        D.nodes.push_back(std::move(t));
+    D.nodes = std::move(Dq.nodes);
+    if (use_q)
+      for (TreeNode &t : D.nodes) {
+        std::vector<int> vs;
+        vs.reserve(t.verts.size() * block);
+        for (int q : t.verts)
+          for (int b = 0; b < block; b++) vs.push_back(q * block + b);
+        t.verts.swap(vs);
       }
-    }
     if (tree) *tree = D.nodes;
+    setup_lap(t_lap, "nested dissection");
   }
   // Level collapsing: absorb every tree node whose depth is not a multiple of `collapse` into its
   // nearest ancestor whose depth is.  The merged front factors the absorbed separators together as one
@@ -658,8 +702,10 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
     F.by_height.assign(mh + 1, {});
     return 0;
   }
+  setup_lap(t_lap, "symbolic");
   F.W.assign(F.w_off[nt], 0.0);
   F.WT.assign(F.wt_off[nt], 0.0);
+  setup_lap(t_lap, "host W / WT allocation");
 
   // numeric multifrontal factorisation, level by level: fronts of one tree height are independent.
   // Small fronts are spread over threads; big fronts are factored one at a time with threads inside.
@@ -826,6 +872,7 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
       for (int k = 0; k < u; k++) loc[up[k]] = -1;
     }
   }
+  setup_lap(t_lap, "assembly lists");
   // numeric phase: on the GPU when there is one (spd_dev.hip: front elimination with v_mfma_f64_16x16x4_f64), else --
   // or with DPGO_SPD_HOST_FACTOR=1 -- the host loop below
   bool on_device = false;
@@ -843,6 +890,7 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
     }
   }
 #endif
+  if (on_device) setup_lap(t_lap, "numeric (device, incl. copies)");
   for (int h = 0; h <= maxh_n && !fail && !on_device; h++) {
     std::vector<int> small, big;
     for (int f : lvl_fronts[h]) (F.w[f] + F.u[f] >= BIG ? big : small).push_back(f);
@@ -892,10 +940,10 @@ int spd_refactor(const CsrMatrix &A, SpdFactor &F) {
       hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0)
     return spd_factor_numeric_device(A, F, F.children, nullptr, nullptr);
 #endif
-  return spd_factor(A, F, 64, 0);
+  return spd_factor(A, F, 64, 0, 1);
 }
 
-int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf, int collapse) {
+int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf, int collapse, int block) {
   std::vector<TreeNode> tree;   // dissected once, reused for every merge depth tried below
   if (const char *e = getenv("DPGO_SPD_COLLAPSE")) collapse = atoi(e);
   if (collapse <= 0) {
@@ -905,13 +953,13 @@ int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf, int collapse) {
     int best_c = 1;
     for (int c = 1; c <= 3; c++) {
       SpdFactor S;
-      if (spd_factor_impl(A, S, leaf, c, true, &tree) != 0) continue;
+      if (spd_factor_impl(A, S, leaf, c, true, &tree, block) != 0) continue;
       const double t = 12e-6 * (double)S.by_height.size() + 8.0 * (double)S.entries / 3.0e12;
       if (t < best) { best = t; best_c = c; }
     }
     collapse = best_c;
   }
-  return spd_factor_impl(A, F, leaf, collapse, false, &tree);
+  return spd_factor_impl(A, F, leaf, collapse, false, &tree, block);
 }
 
 void spd_solve_host(const SpdFactor &F, double *X, int nc) {

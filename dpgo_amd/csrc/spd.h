@@ -54,7 +54,9 @@ struct SpdFactor {
 // vertices of a nested-dissection leaf.  Returns 0, or -1 if a pivot is not positive.
 // collapse = number of nested-dissection levels merged into one front (1 = plain binary tree,
 // 0 = choose 1..3 from a latency + bandwidth model of the device solve).
-int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf = 32, int collapse = 0);
+// block > 1: consecutive groups of `block` unknowns share their neighbours (the d rotation rows of a pose); the ordering
+// is computed on the quotient graph
+int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf = 32, int collapse = 0, int block = 1);
 
 // New values, same pattern (a Dynamic rescale changes the diagonal of G_tt): the numeric phase only, on the GPU
 // (spd_dev.hip); without a GPU the whole factorisation is redone.  F must come from spd_factor of the same pattern.
