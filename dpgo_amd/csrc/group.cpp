@@ -606,12 +606,26 @@ void Group::upload_bsr(const std::vector<const BsrMatrix *> &per_node, bool rows
   }
   out.ptr.upload(ptr);
   out.col.upload(col);
-  out.val.upload(val);
   if (&out == &G_) {   // compact copy of the translation column for launch_bsr_tcol
     std::vector<double> tc((size_t)ptr[nrows] * B_);
     for (size_t k = 0; k < (size_t)ptr[nrows]; k++)
       for (int r = 0; r < B_; r++) tc[k * B_ + r] = val[k * B_ * B_ + (size_t)r * B_];
     out.tcol.upload(tc);
+  }
+  {
+    // k_bsr gives a block row to BSR_LPR lanes, lane j taking blocks j, j + BSR_LPR, ... of the row.  The values of the (up
+    // to) BSR_LPR blocks one round reads are stored interleaved in 16-byte pieces (8-byte for the 3 x 3 blocks of SE(2)):
+    // piece p of lane j at ((p * cnt + j) * PS), so that the quad's loads of one instruction are contiguous
+    const int BB = B_ * B_, PS = BB % 2 == 0 ? 2 : 1;
+    std::vector<double> il(val.size());
+    for (int r = 0; r < nrows; r++)
+      for (int k0 = ptr[r]; k0 < ptr[r + 1]; k0 += BSR_LPR) {
+        const int cnt = std::min(BSR_LPR, ptr[r + 1] - k0);
+        for (int j = 0; j < cnt; j++)
+          for (int e = 0; e < BB; e++)
+            il[(size_t)k0 * BB + (size_t)((e / PS) * cnt + j) * PS + e % PS] = val[(size_t)(k0 + j) * BB + e];
+      }
+    out.val.upload(il);
   }
   out.dev.nrows = nrows;
   out.dev.nnzb = ptr[nrows];

@@ -24,6 +24,12 @@ namespace dpgo {
 // 64 rows per segment = one wavefront per workgroup for the row kernels: a node of 12.5 k poses still
 // yields ~200 workgroups, enough to spread over the 256 CUs when a GPU holds a single node.
 constexpr int SEG_ROWS = 64;
+// lanes that share one block row in k_bsr (lane j takes blocks j, j + BSR_LPR, ...); the block values are stored
+// interleaved per round of BSR_LPR blocks (Group::upload_bsr)
+#ifndef DPGO_BSR_LPR
+#define DPGO_BSR_LPR 4   // (8 lanes per row measured 5 % slower at the headline size, equal at one node per GPU)
+#endif
+constexpr int BSR_LPR = DPGO_BSR_LPR;
 constexpr int MAX_SLOTS = 16;   // per-node scalars one read-back can carry
 constexpr int MAX_DOTS = 6;     // dot products per k_dots launch (it stores MAX_DOTS consecutive slots)
 

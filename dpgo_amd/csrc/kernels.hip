@@ -75,6 +75,23 @@ __device__ __forceinline__ void load_vec(const double *p, double (&r)[N]) {
     for (int k = 0; k < N; k++) r[k] = p[k];
   }
 }
+// One block of a round of k_bsr: the values of the round's cnt blocks are interleaved in pieces of 16 bytes (8 bytes
+// when the block has an odd number of entries), piece p of lane j at (p * cnt + j) -- see Group::upload_bsr
+template <int N>
+__device__ __forceinline__ void load_block(const double *base, int cnt, int j, double (&r)[N]) {
+  if constexpr (N % 2 == 0) {
+    const double2 *q = reinterpret_cast<const double2 *>(base) + j;
+#pragma unroll
+    for (int p = 0; p < N / 2; p++) {
+      double2 v = q[p * cnt];
+      r[2 * p] = v.x;
+      r[2 * p + 1] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < N; p++) r[p] = base[p * cnt + j];
+  }
+}
 template <int N>
 __device__ __forceinline__ void store_vec(double *p, const double (&r)[N]) {
   static_assert(N % 2 == 0, "records are multiples of 16 bytes");
@@ -268,14 +285,15 @@ __device__ __forceinline__ int xcd_seg(int b, int n) {
 // MODE 0: y = A x.  MODE 1: the translation row of x counts as zero (y = A [0 ; x.R]).  MODE 2: both at once --
 // y = A [0 ; x.R] (+ add), while the fused dot product sees the full A x (one pass over A instead of two).
 template <int D, int MODE>
-__global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr(const Seg *segs, NodeMask mask, BsrDev A, const double *x,
+__global__ __launch_bounds__(BSR_LPR * SEG_ROWS) void k_bsr(const Seg *segs, NodeMask mask, BsrDev A, const double *x,
                                               const double *addv, double *y, const double *dotv, double coef,
                                               const double *dotadd, double *partial) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
   const bool active = node_on(mask, s.node);
   double part[1] = {0.0};
-  const int row = s.begin + (threadIdx.x >> 2), j = threadIdx.x & 3;
+  constexpr int LPR = BSR_LPR;
+  const int row = s.begin + (int)threadIdx.x / LPR, j = threadIdx.x % LPR;
   if (active) {   // uniform per workgroup; rows past the segment end simply have no blocks
     double acc[RS], acct[MODE == 2 ? RS : 1];
 #pragma unroll
@@ -286,11 +304,11 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr(const Seg *segs, NodeMask 
     }
     const bool inrow = row < s.end;
     const int k1 = inrow ? A.ptr[row + 1] : 0;
-    for (int k = (inrow ? A.ptr[row] : 0) + j; k < k1; k += 4) {
+    for (int k = (inrow ? A.ptr[row] : 0) + j; k < k1; k += LPR) {
       const int q = A.col[k];
       double xb[RS], blk[B * B];
       load_vec<RS>(x + (size_t)q * RS, xb);
-      load_vec<B * B>(A.val + (size_t)k * B * B, blk);
+      load_block<B * B>(A.val + (size_t)(k - j) * B * B, min(LPR, k1 - (k - j)), j, blk);
       blk_mul_acc<D, MODE != 0>(blk, xb, acc);
       if constexpr (MODE == 2) {   // what the translation row of x adds: first column of the block
 #pragma unroll
@@ -300,16 +318,14 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr(const Seg *segs, NodeMask 
       }
     }
 #pragma unroll
-    for (int k = 0; k < RS; k++) {
-      acc[k] += __shfl_xor(acc[k], 1, 64);
-      acc[k] += __shfl_xor(acc[k], 2, 64);
-    }
+    for (int k = 0; k < RS; k++)
+#pragma unroll
+      for (int o = 1; o < LPR; o <<= 1) acc[k] += __shfl_xor(acc[k], o, 64);
     if constexpr (MODE == 2) {
 #pragma unroll
-      for (int k = 0; k < RS; k++) {
-        acct[k] += __shfl_xor(acct[k], 1, 64);
-        acct[k] += __shfl_xor(acct[k], 2, 64);
-      }
+      for (int k = 0; k < RS; k++)
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) acct[k] += __shfl_xor(acct[k], o, 64);
     }
     if (inrow && j == 0) {
       if (dotv) {
@@ -335,7 +351,7 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr(const Seg *segs, NodeMask 
       }
     }
   }
-  if (partial) block_store<1, 4 * SEG_ROWS / 64>(part, partial + SEGB, 0);
+  if (partial) block_store<1, LPR * SEG_ROWS / 64>(part, partial + SEGB, 0);
 }
 
 // out (d x d) = Proj_R(E - sym(nabla R^T) Rdot): the rotation rows of the Riemannian Hessian-vector product
@@ -1776,13 +1792,13 @@ void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMas
   ProfScope ps(PK_BSR, st, (double)A.nnzb * (8.0 * (d + 1) * (d + 1) + 4) + 2.0 * A.nrows * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, {
     if (mode == 1)
-      hipLaunchKernelGGL((k_bsr<D, 1>), dim3(nb), dim3(4 * SEG_ROWS), 0, st, T.segs, mask, A, x, addv, y, dotv, coef, dotadd,
+      hipLaunchKernelGGL((k_bsr<D, 1>), dim3(nb), dim3(BSR_LPR * SEG_ROWS), 0, st, T.segs, mask, A, x, addv, y, dotv, coef, dotadd,
                          part);
     else if (mode == 2)
-      hipLaunchKernelGGL((k_bsr<D, 2>), dim3(nb), dim3(4 * SEG_ROWS), 0, st, T.segs, mask, A, x, addv, y, dotv, coef, dotadd,
+      hipLaunchKernelGGL((k_bsr<D, 2>), dim3(nb), dim3(BSR_LPR * SEG_ROWS), 0, st, T.segs, mask, A, x, addv, y, dotv, coef, dotadd,
                          part);
     else
-      hipLaunchKernelGGL((k_bsr<D, 0>), dim3(nb), dim3(4 * SEG_ROWS), 0, st, T.segs, mask, A, x, addv, y, dotv, coef, dotadd,
+      hipLaunchKernelGGL((k_bsr<D, 0>), dim3(nb), dim3(BSR_LPR * SEG_ROWS), 0, st, T.segs, mask, A, x, addv, y, dotv, coef, dotadd,
                          part);
   });
 }
