@@ -53,6 +53,7 @@ template struct DevBuf<SpdItem>;
 template struct DevBuf<unsigned>;
 template struct DevBuf<CgNode>;
 template struct DevBuf<NodeBits>;
+template struct DevBuf<PanelSrc>;
 
 // tuning hooks (tools/env_ab.sh): an integer from the environment, or the default
 static int env_int(const char *name, int dflt) {
@@ -182,6 +183,22 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
       fprintf(stderr, "[spd] dof %d %s panels: %.1f MB stored, %.1f MB of entries (padding %.1f %%), %zu tiles\n", dof, fwd ? "fwd" : "bwd",
               total * 8e-6, used * 8e-6, 100.0 * (total - used) / std::max<int64_t>(used, 1), tiles.size());
     }
+    items_dev.upload(items);
+    if (F.dev_W && F.dev_WT) {
+      // the factor is still on the device: the panels are cut out of it there (no trip through the host)
+      std::vector<PanelSrc> srcs(tiles.size());
+      for (size_t i = 0; i < tiles.size(); i++) {
+        const Tile &t = tiles[i];
+        if (fwd) srcs[i] = PanelSrc{(long long)(F.wt_off[t.f] + t.first), F.ldm[t.f], (int)t.len};
+        else srcs[i] = PanelSrc{(long long)(F.w_off[t.f] + (int64_t)t.first * F.ldw[t.f] + t.first), F.ldw[t.f], (int)t.len};
+      }
+      DevBuf<PanelSrc> srcs_dev;
+      srcs_dev.upload(srcs);
+      panels_dev.alloc((size_t)std::max<int64_t>(total, 1));   // (zero-filled: the padding of a panel row stays zero)
+      launch_pack_panels(nullptr, items_dev.p, srcs_dev.p, (int)tiles.size(), fwd ? F.dev_WT : F.dev_W, panels_dev.p);
+      HIP_CHECK(hipDeviceSynchronize());
+      return;
+    }
     std::vector<double> panels((size_t)std::max<int64_t>(total, 1), 0.0);
 #pragma omp parallel for schedule(dynamic, 16)
     for (size_t i = 0; i < tiles.size(); i++) {
@@ -200,11 +217,11 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
           for (int r = 0; r < t.count; r++) dst[p * it.ld + r] = src[(size_t)p * ldw + r];
       }
     }
-    items_dev.upload(items);
     panels_dev.upload(panels);
   };
   sweep(true, fwd_levels, fwd_items, WT);
   sweep(false, bwd_levels, bwd_items, W);
+  spd_release_device(F);
   // the panels are on the device now: the host copy of the factor (gigabytes at the headline size) can go
   std::vector<double>().swap(F.W);
   std::vector<double>().swap(F.WT);
@@ -459,7 +476,8 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
     Arr.n = (int)Arr.ptr.size() - 1;
     clk.lap("G_RR: lambda_max (Lanczos) + shifted matrix");
     if (Arr.n > 0) {
-      if (spd_factor(Arr, Lrr_.F, env_int("DPGO_SPD_LEAF_RR", 96), env_int("DPGO_SPD_COLLAPSE_RR", 0), env_int("DPGO_SPD_QUOTIENT", 1) ? d_ : 1) != 0) return;
+      if (spd_factor(Arr, Lrr_.F, env_int("DPGO_SPD_LEAF_RR", 96), env_int("DPGO_SPD_COLLAPSE_RR", 0), env_int("DPGO_SPD_QUOTIENT", 1) ? d_ : 1,
+                     env_int("DPGO_SPD_DEVICE_PANELS", 1) != 0) != 0) return;
       clk.lap("G_RR: ordering + symbolic + numeric factor");
       Lrr_.dof = d_;
       std::vector<int> node_of_row((size_t)P0_ * d_);
@@ -566,7 +584,8 @@ int Group::refactor_tt() {
   if (Ltt_.F.n == Att.n && Ltt_.F.nfronts > 0 && !Ltt_.F.children.empty()) {
     // same pattern, new values (a Dynamic rescale): numeric phase only, on the GPU
     if (spd_refactor(Att, Ltt_.F) != 0) return -1;
-  } else if (spd_factor(Att, Ltt_.F, env_int("DPGO_SPD_LEAF_TT", 128), env_int("DPGO_SPD_COLLAPSE_TT", 0)) != 0) return -1;
+  } else if (spd_factor(Att, Ltt_.F, env_int("DPGO_SPD_LEAF_TT", 128), env_int("DPGO_SPD_COLLAPSE_TT", 0), 1,
+                        env_int("DPGO_SPD_DEVICE_PANELS", 1) != 0) != 0) return -1;
   clk.lap("G_tt: ordering + symbolic + numeric factor");
   Ltt_.dof = 1;
   std::vector<int> node_of_pose(P0_);

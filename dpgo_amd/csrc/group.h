@@ -101,6 +101,7 @@ struct DevBuf {
 
 struct SpdSolverDev {
   SpdFactor F;   // host copy kept for sizes / host solves
+  ~SpdSolverDev() { spd_release_device(F); }
   DevBuf<int> piv_idx, upd_idx, asm_ptr, ubuf_dst;
   DevBuf<double> W, WT, ubuf, ytmp;   // W / WT: backward / forward panels (see upload)
   DevBuf<SpdItem> fwd_items, bwd_items;

@@ -218,6 +218,10 @@ struct SpdDev {
 // dof = 1: unknown i is the translation of pose i; dof = d: unknown i = (pose i / d, rotation row i % d).
 // vec is a record array: forward reads the right-hand side from vec and writes y to ytmp (n x d, the pivots
 // of a front consecutive); backward reads ytmp and writes scale * A^-1 b into vec (scale must be +1 or -1).
+// Panels of the solve tiles from a factor that is still on the device (front-major W / WT, spd_dev.hip): tile i copies
+// len rows of `count` entries, src_ld apart, starting at src + src_off, to panels + items[i].mat_off (rows items[i].ld apart).
+struct PanelSrc { long long src_off; int src_ld; int len; };
+void launch_pack_panels(hipStream_t st, const SpdItem *items, const PanelSrc *srcs, int ntiles, const double *src, double *panels);
 // measurement builds (-DSPD_TRACE) only: where the solve tiles write their phase timestamps (6 per tile); no-op otherwise
 void spd_trace_set(unsigned long long *p);
 void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int tile0, int nwide, int nnarrow,

@@ -1987,6 +1987,21 @@ void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows,
                      arrived, host_flag, seq);
 }
 
+__global__ __launch_bounds__(256) void k_pack_panels(const SpdItem *items, const PanelSrc *srcs, const double *src, double *panels) {
+  const SpdItem it = load_item(items + blockIdx.x);
+  const PanelSrc ps = srcs[blockIdx.x];
+  const double *in = src + ps.src_off;
+  double *out = panels + it.mat_off;
+  const int cnt = it.count, total = ps.len * cnt;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int k = i / cnt, r = i - k * cnt;
+    out[(size_t)k * it.ld + r] = in[(size_t)k * ps.src_ld + r];
+  }
+}
+void launch_pack_panels(hipStream_t st, const SpdItem *items, const PanelSrc *srcs, int ntiles, const double *src, double *panels) {
+  if (ntiles > 0) hipLaunchKernelGGL(k_pack_panels, dim3(ntiles), dim3(256), 0, st, items, srcs, src, panels);
+}
+
 #ifdef SPD_TRACE
 void spd_trace_set(unsigned long long *p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_spd_trace), &p, sizeof(p)); }
 #else

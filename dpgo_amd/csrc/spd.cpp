@@ -19,6 +19,9 @@
 namespace dpgo {
 int spd_factor_numeric_device(const CsrMatrix &A, SpdFactor &F, const std::vector<std::vector<int>> &children,
                               double *flops_out, double *mfma_ms_out);
+#ifdef DPGO_NO_DEVICE
+void spd_release_device(SpdFactor &) {}
+#endif
 namespace {
 
 struct TreeNode {
@@ -451,12 +454,14 @@ static double setup_lap(double &t0, const char *what) {   // DPGO_SETUP_TIMING=1
 }
 
 static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int collapse, bool symbolic_only,
-                           std::vector<TreeNode> *tree, int block) {
+                           std::vector<TreeNode> *tree, int block, bool keep_device) {
   const int n = A.n;
   double t_lap = omp_get_wtime();
   omp_set_num_threads(host_threads());
+  spd_release_device(F);
   F = SpdFactor();
   F.n = n;
+  F.keep_device = keep_device;
   // adjacency without the diagonal
   CsrMatrix adj;
   adj.n = n;
@@ -703,8 +708,17 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
     return 0;
   }
   setup_lap(t_lap, "symbolic");
-  F.W.assign(F.w_off[nt], 0.0);
-  F.WT.assign(F.wt_off[nt], 0.0);
+  bool device_numeric = false;
+#ifndef DPGO_NO_DEVICE
+  {
+    int ndev = 0;
+    device_numeric = !getenv("DPGO_SPD_HOST_FACTOR") && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0;
+  }
+#endif
+  if (!(device_numeric && F.keep_device)) {   // (the device numeric phase allocates the host copies it needs itself)
+    F.W.assign(F.w_off[nt], 0.0);
+    F.WT.assign(F.wt_off[nt], 0.0);
+  }
   setup_lap(t_lap, "host W / WT allocation");
 
   // numeric multifrontal factorisation, level by level: fronts of one tree height are independent.
@@ -940,10 +954,10 @@ int spd_refactor(const CsrMatrix &A, SpdFactor &F) {
       hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0)
     return spd_factor_numeric_device(A, F, F.children, nullptr, nullptr);
 #endif
-  return spd_factor(A, F, 64, 0, 1);
+  return spd_factor(A, F, 64, 0, 1, F.keep_device);
 }
 
-int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf, int collapse, int block) {
+int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf, int collapse, int block, bool keep_device) {
   std::vector<TreeNode> tree;   // dissected once, reused for every merge depth tried below
   if (const char *e = getenv("DPGO_SPD_COLLAPSE")) collapse = atoi(e);
   if (collapse <= 0) {
@@ -953,13 +967,13 @@ int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf, int collapse, int blo
     int best_c = 1;
     for (int c = 1; c <= 3; c++) {
       SpdFactor S;
-      if (spd_factor_impl(A, S, leaf, c, true, &tree, block) != 0) continue;
+      if (spd_factor_impl(A, S, leaf, c, true, &tree, block, false) != 0) continue;
       const double t = 12e-6 * (double)S.by_height.size() + 8.0 * (double)S.entries / 3.0e12;
       if (t < best) { best = t; best_c = c; }
     }
     collapse = best_c;
   }
-  return spd_factor_impl(A, F, leaf, collapse, false, &tree, block);
+  return spd_factor_impl(A, F, leaf, collapse, false, &tree, block, keep_device);
 }
 
 void spd_solve_host(const SpdFactor &F, double *X, int nc) {

@@ -47,6 +47,10 @@ struct SpdFactor {
   std::vector<std::vector<int>> by_height, by_depth;
   std::vector<std::vector<int>> children;   // elimination tree, kept for spd_refactor
   int total_pos = 0, total_upd = 0, max_front = 0;
+  // keep_device: the numeric phase leaves W / WT on the GPU (dev_W / dev_WT, same per-front layout as W / WT, owned by
+  // the factor until spd_release_device) and does not fill the host copies -- for callers that only solve on the device
+  bool keep_device = false;
+  double *dev_W = nullptr, *dev_WT = nullptr;
   int64_t nnz() const { return entries; }
 };
 
@@ -56,7 +60,9 @@ struct SpdFactor {
 // 0 = choose 1..3 from a latency + bandwidth model of the device solve).
 // block > 1: consecutive groups of `block` unknowns share their neighbours (the d rotation rows of a pose); the ordering
 // is computed on the quotient graph
-int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf = 32, int collapse = 0, int block = 1);
+int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf = 32, int collapse = 0, int block = 1, bool keep_device = false);
+// frees dev_W / dev_WT (no-op when there are none)
+void spd_release_device(SpdFactor &F);
 
 // New values, same pattern (a Dynamic rescale changes the diagonal of G_tt): the numeric phase only, on the GPU
 // (spd_dev.hip); without a GPU the whole factorisation is redone.  F must come from spd_factor of the same pattern.

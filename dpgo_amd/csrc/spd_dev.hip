@@ -470,10 +470,19 @@ int spd_factor_numeric_device(const CsrMatrix &A, SpdFactor &F, const std::vecto
       (void)hipEventDestroy(ev.second);
     }
     if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
-    F.W.assign(F.w_off[nt], 0.0);
-    F.WT.assign(F.wt_off[nt], 0.0);
-    if (F.w_off[nt] > 0) FA_OK(hipMemcpy(F.W.data(), d_W, sizeof(double) * F.w_off[nt], hipMemcpyDeviceToHost));
-    if (F.wt_off[nt] > 0) FA_OK(hipMemcpy(F.WT.data(), d_WT, sizeof(double) * F.wt_off[nt], hipMemcpyDeviceToHost));
+    if (F.keep_device) {   // the caller packs its solve panels from the device copies (Group: SpdSolverDev::upload)
+      spd_release_device(F);
+      F.dev_W = d_W;
+      F.dev_WT = d_WT;
+      d_W = d_WT = nullptr;
+      std::vector<double>().swap(F.W);
+      std::vector<double>().swap(F.WT);
+    } else {
+      F.W.assign(F.w_off[nt], 0.0);
+      F.WT.assign(F.wt_off[nt], 0.0);
+      if (F.w_off[nt] > 0) FA_OK(hipMemcpy(F.W.data(), d_W, sizeof(double) * F.w_off[nt], hipMemcpyDeviceToHost));
+      if (F.wt_off[nt] > 0) FA_OK(hipMemcpy(F.WT.data(), d_WT, sizeof(double) * F.wt_off[nt], hipMemcpyDeviceToHost));
+    }
     if (flops_out) *flops_out = flops;
     if (mfma_ms_out) *mfma_ms_out = mfma_ms;
     return 0;
@@ -484,6 +493,12 @@ int spd_factor_numeric_device(const CsrMatrix &A, SpdFactor &F, const std::vecto
     if (p) (void)hipFree(p);
   if (st) (void)hipStreamDestroy(st);
   return rc;
+}
+
+void spd_release_device(SpdFactor &F) {
+  if (F.dev_W) (void)hipFree(F.dev_W);
+  if (F.dev_WT) (void)hipFree(F.dev_WT);
+  F.dev_W = F.dev_WT = nullptr;
 }
 
 }  // namespace dpgo
