@@ -309,8 +309,8 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
     fprintf(stderr, "[dpgo_amd] ERROR: d must be 2 or 3.\n");
     return;
   }
-  if (opt.preconditioner != 0 && opt.preconditioner != 3) {
-    fprintf(stderr, "[dpgo_amd] ERROR: preconditioner %d (Jacobi / IncompleteCholesky) is not implemented; use None (0) or "
+  if (opt.preconditioner != 0 && opt.preconditioner != 1 && opt.preconditioner != 3) {
+    fprintf(stderr, "[dpgo_amd] ERROR: preconditioner %d (IncompleteCholesky) is not implemented; use None (0), Jacobi (1) or "
                     "RegularizedCholesky (3).\n", opt.preconditioner);
     return;
   }
@@ -486,6 +486,16 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
       Lrr_.upload(d_, node_of_row);
       clk.lap("G_RR: panels (pack + upload)");
     }
+  }
+  if (opt.preconditioner == 1) {   // Preconditioner::Jacobi: diag(G_RR)^-1, fixed at construction (DPGOProblem.cpp:96-98)
+    std::vector<double> dinv((size_t)P0_ * d_, 1.0);
+    for (int a = 0; a < L; a++) {
+      const CsrMatrix &r = ops_[a].GRR;
+      for (int i = 0; i < r.n; i++)
+        for (int e = r.ptr[i]; e < r.ptr[i + 1]; e++)
+          if (r.col[e] == i) dinv[(size_t)own_off_[a] * d_ + i] = 1.0 / r.val[e];
+    }
+    jacobi_.upload(dinv);
   }
   // ---- halo lists
   {

@@ -230,6 +230,7 @@ class Group {
   DevBuf<unsigned> reduce_arrived_;
   DevBuf<double> partials_;
   DevBuf<CgNode> cg_;       // device-resident state of the truncated CG (tnt.cpp, k_cg_scal)
+  DevBuf<double> jacobi_;   // Preconditioner::Jacobi: 1 / diag(G_RR), one entry per rotation row
   DevBuf<NodeBits> dmask_;  // [0] nodes taking the next Hessian product, [1] nodes going on to the preconditioner
   struct BsrBufs { DevBuf<int> ptr, col; DevBuf<double> val, tcol; BsrDev dev; };   // tcol: first column of every block (G only)
   BsrBufs G_, S_, P_, P0m_, Q_;

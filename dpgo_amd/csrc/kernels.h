@@ -165,6 +165,8 @@ void launch_copy_nbr_rows(int d, hipStream_t st, const SegTable &T, NodeMask mas
 void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
                         const double *in, double *out, const double *dotv = nullptr, double *partials = nullptr,
                         int slot = 0);
+// out.Y rows = dinv (one entry per rotation row) * in.Y rows: Preconditioner::Jacobi   (DPGOProblem.cpp:96-98, 583-585)
+void launch_rot_rowscale(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *dinv, const double *in, double *out);
 // out.Y = proj_SO(d)(X.Y + V.Y); out.x = 0                              (SOdProduct.h:111-116)
 void launch_retract_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
                         const double *V, double *out);

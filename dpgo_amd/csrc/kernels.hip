@@ -802,6 +802,23 @@ __global__ __launch_bounds__(SEG_ROWS) void k_axpby_node(const Seg *segs, NodeMa
   store_vec<RS>(out + (size_t)row * RS, va);
 }
 
+// out.Y row (pose, r) = dinv[pose * D + r] * in.Y row: the Jacobi preconditioner diag(G_RR)^-1 (DPGOProblem.cpp:96-98, 583-585)
+template <int D>
+__global__ __launch_bounds__(SEG_ROWS) void k_rot_rowscale(const Seg *segs, NodeMask mask, const double *dinv, const double *in,
+                                                      double *out) {
+  constexpr int RS = Dim<D>::RS;
+  const Seg s = segs[SEGB];
+  if (!node_on(mask, s.node)) return;
+  const int row = s.begin + threadIdx.x;
+  if (row >= s.end) return;
+#pragma unroll
+  for (int r = 0; r < D; r++) {
+    const double a = dinv[(size_t)row * D + r];
+#pragma unroll
+    for (int c = 0; c < D; c++) out[(size_t)row * RS + D + r * D + c] = a * in[(size_t)row * RS + D + r * D + c];
+  }
+}
+
 // one CG step of every node in the mask (IterativeSolvers.h:340-390): s += c p, H s += c H p and, where the node
 // goes on (cr != 0), r += cr H p
 template <int D>
@@ -1879,6 +1896,12 @@ void launch_axpby_node(int d, hipStream_t st, const SegTable &T, NodeMask mask, 
   ProfScope ps(PK_AXPBY, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_axpby_node<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, C, a, b,
                                         out));
+}
+
+void launch_rot_rowscale(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *dinv, const double *in, double *out) {
+  if (T.nseg_own == 0) return;
+  ProfScope ps(PK_AXPBY, st, 2.0 * T.rows_own * 8.0 * d * d);
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_rowscale<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, dinv, in, out));
 }
 
 void launch_cg_step(int d, hipStream_t st, const SegTable &T, NodeMask mask, const NodeCoefs &C, const double *p,

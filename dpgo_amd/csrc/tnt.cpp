@@ -50,7 +50,8 @@ struct NodeTnt {
 void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, const double *g_alt, bool base_ready) {
   const Options &o = opt_;
   const int L = num_local();
-  const bool use_precon = (o.preconditioner == 3) && Lrr_.F.n > 0;   // Preconditioner::RegularizedCholesky
+  const bool jacobi = (o.preconditioner == 1) && jacobi_.n > 0;       // Preconditioner::Jacobi
+  const bool use_precon = jacobi || ((o.preconditioner == 3) && Lrr_.F.n > 0);   // ... or RegularizedCholesky
   double *nabla = tmp_[0].p, *grad = tmp_[1].p, *sk = tmp_[2].p, *rk = tmp_[3].p, *vk = tmp_[4].p, *pk = tmp_[5].p,
          *Hp = tmp_[6].p, *xprop = tmp_[7].p, *w1 = tmp_[8].p, *pg = tmp_[10].p, *hh = tmp_[11].p,
          *w3 = tmp_[12].p, *nprop = tmp_[13].p;
@@ -77,7 +78,8 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       copy_rows(out, v, false, 0);
       return;
     }
-    solve_rr(const_cast<double *>(v), w1, 1.0);   // w1.R = (G_RR + lambda I)^-1 v.R; the forward sweep only reads v
+    if (jacobi) launch_rot_rowscale(d_, st_, T_, cur_mask_, jacobi_.p, v, w1);
+    else solve_rr(const_cast<double *>(v), w1, 1.0);   // w1.R = (G_RR + lambda I)^-1 v.R; the forward sweep only reads v
     launch_tangent_rot(d_, st_, T_, cur_mask_, Y, w1, out);
   };
   // gnorm, pgnorm (and rv0 = <grad, P grad>, the first CG scalar) of the nodes in `set` (mask == set).
@@ -169,7 +171,8 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     auto stepB = [&]() {
       cur_mask_ = mB;
       if (use_precon) {
-        solve_rr(rk, w1, 1.0);
+        if (jacobi) launch_rot_rowscale(d_, st_, T_, cur_mask_, jacobi_.p, rk, w1);
+        else solve_rr(rk, w1, 1.0);
         launch_tangent_rot(d_, st_, T_, cur_mask_, X, w1, vk, rk, partials_.p, 0);   // v = Proj(M^-1 r) and <r, v>
       } else {
         copy_rows(vk, rk, false, 0);

@@ -26,7 +26,7 @@ extern "C" {
 
 /* DPGO::Options -- C++/DPGO/include/DPGO/DPGO_types.h:78-201: same names, same defaults, enums as their integer
  * values.  Not carried: verbose, max_computation_time, user_function, log_iterates (no effect on the iterates).
- * dpgo_group_create fails (-1) for what is not implemented: preconditioner Jacobi / IncompleteCholesky. */
+ * dpgo_group_create fails (-1) for what is not implemented: preconditioner IncompleteCholesky. */
 typedef struct dpgo_options {
   int scheme;                 /* 0 = Scheme::MM, 1 = Scheme::AMM */
   double regularizer;

@@ -106,7 +106,7 @@ class DPGOHash:
         self.problem = DPGOProblem(
             node, measurements, options.regularizer, options.loss,
             options.reg_Cholesky_precon_max_condition_number, options.loss_reg,
-            preconditioner=(getattr(options, "preconditioner", 3) == 3),
+            preconditioner=getattr(options, "preconditioner", 3),
             dynamic=(getattr(options, "rescale", 0) == 1))                   # DPGOHash.cpp:16
         self.results = Results()
 
@@ -260,7 +260,7 @@ class DPGOHash:
         def retract(Y, Ydot):
             return p.retract(Y, Ydot, g)
 
-        precon = (lambda Y, V: p.precondition(Y, V)) if p.precon is not None else None
+        precon = (lambda Y, V: p.precondition(Y, V)) if (p.precon is not None or p.jacobi is not None) else None
         prm = tnt_mod.TNTParams()
         prm.gradient_tolerance = o.grad_norm_tol
         prm.preconditioned_gradient_tolerance = o.preconditioned_grad_norm_tol

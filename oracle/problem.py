@@ -102,7 +102,10 @@ class DPGOProblem:
         self.size0 = (self.d + 1) * self.n[0]
         self.L = SpdSolver(self.mat.Gtt)            # :93
         self.precon = None
-        if preconditioner:
+        self.jacobi = None
+        if preconditioner == 1:
+            self.jacobi = 1.0 / self.mat.GRR.diagonal()      # Preconditioner::Jacobi, :96-98
+        elif preconditioner is True or preconditioner == 3:
             # RegularizedCholesky, :101-124 (Spectra, tol 1e-4, ncv 3)
             GRR = self.mat.GRR
             if GRR.shape[0] > 3:
@@ -300,6 +303,8 @@ class DPGOProblem:
 
     def precondition(self, Y, Ydot):
         """DPGOProblem.cpp:579-598 (RegularizedCholesky)."""
+        if self.jacobi is not None:                       # :583-585
+            return self.reduced_tangent_space_projection(Y, self.jacobi[:, None] * Ydot)
         if self.precon is None:
             return Ydot
         return self.reduced_tangent_space_projection(Y, self.precon.solve(Ydot))

@@ -441,6 +441,8 @@ def test_runs_are_bit_reproducible(fixtures_dir):
 @pytest.mark.parametrize("kw", [
     dict(max_iterations_accepted=3, max_iterations=12),          # several accepted TNT steps: the model is rebuilt
     dict(preconditioner=0),                                      # Preconditioner::None (identity)
+    dict(preconditioner=1),                                      # Preconditioner::Jacobi (diag(G_RR)^-1)
+    dict(preconditioner=1, max_iterations_accepted=2, max_iterations=8),
     dict(max_iterations_accepted=2, max_tCG_iterations=3),       # truncated CG that stops on its iteration cap
 ])
 @pytest.mark.parametrize("loss", [LOSS_NONE, LOSS_HUBER])
@@ -512,7 +514,7 @@ def test_set_options_and_accessors(fixtures_dir):
     assert a.group.set_options(dpgo_amd.Options.driver(LOSS_HUBER, True, regularizer=1e-3)) == -1
     assert a.group.update([0, 0]) == -1 and a.group.iterate([5]) == -1             # locals are validated
     with pytest.raises(RuntimeError):
-        dpgo_amd.NodeGroup(G, [0, 1], dpgo_amd.Options.driver(LOSS_HUBER, True, preconditioner=dpgo_amd.PRECON_JACOBI))
+        dpgo_amd.NodeGroup(G, [0, 1], dpgo_amd.Options.driver(LOSS_HUBER, True, preconditioner=dpgo_amd.PRECON_ICHOL))
 
 
 @pytest.mark.parametrize("loss", [LOSS_NONE, LOSS_HUBER])
