@@ -103,7 +103,8 @@ class DPGOProblem:
         self.L = SpdSolver(self.mat.Gtt)            # :93
         self.precon = None
         self.jacobi = None
-        if preconditioner == 1:
+        # (True: RegularizedCholesky, the value older callers pass; note True == 1 in Python)
+        if preconditioner is not True and preconditioner == 1:
             self.jacobi = 1.0 / self.mat.GRR.diagonal()      # Preconditioner::Jacobi, :96-98
         elif preconditioner is True or preconditioner == 3:
             # RegularizedCholesky, :101-124 (Spectra, tol 1e-4, ncv 3)
