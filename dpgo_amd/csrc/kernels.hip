@@ -30,7 +30,10 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// Sum NS per-thread values over a 256-thread workgroup and store to dst[s * stride].
+// Sum NS per-thread values over a 256-thread workgroup and store to dst[s * stride].  Callers store only for segments of
+// nodes inside the launch mask: a masked launch must leave the partials of the other nodes alone (a second, narrower
+// pass over the same slots -- the nodes a Dynamic rescale changed -- would otherwise zero what the first pass left
+// for the nodes it skips).
 template <int NS, int NWAVES = SEG_ROWS / 64>
 __device__ __forceinline__ void block_store(const double (&v)[NS], double *dst, int stride) {
   if constexpr (NWAVES == 1) {
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(BSR_LPR * SEG_ROWS) void k_bsr(const Seg *segs, Nod
       }
     }
   }
-  if (partial) block_store<1, LPR * SEG_ROWS / 64>(part, partial + SEGB, 0);
+  if (partial && active) block_store<1, LPR * SEG_ROWS / 64>(part, partial + SEGB, 0);
 }
 
 // out (d x d) = Proj_R(E - sym(nabla R^T) Rdot): the rotation rows of the Riemannian Hessian-vector product
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask ma
       store_vec<RS>(g + (size_t)row * RS, acc);
     }
   }
-  block_store<3>(part, partial + SEGB, pstride);
+  if (active) block_store<3>(part, partial + SEGB, pstride);
 }
 
 // ---------------------------------------------------------------------------
@@ -660,7 +663,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_cost(const Seg *segs, NodeMask mas
       part[1] += rho;
     }
   }
-  block_store<2>(part, partial + SEGB, pstride);
+  if (active) block_store<2>(part, partial + SEGB, pstride);
 }
 
 // partial = sum |a_p - b_p|^2 over own rows
@@ -681,7 +684,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_sqdist(const Seg *segs, NodeMask m
     for (int k = 0; k < RS; k++) { const double dd = va[k] - vb[k]; p = fma(dd, dd, p); }
     pr[0] = p;
   }
-  block_store<1>(pr, partial + SEGB, 0);
+  if (active) block_store<1>(pr, partial + SEGB, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_proximal(const Seg *segs, NodeMask
       store_vec<RS>(Xref + (size_t)row * RS, ref);
     }
   }
-  if (partial) block_store<1>(part, partial + SEGB, 0);
+  if (partial && active) block_store<1>(part, partial + SEGB, 0);
 }
 
 template <int D>
@@ -923,7 +926,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_dots(const Seg *segs, NodeMask mas
         pr[q] = p;
       }
   }
-  block_store<MAX_DOTS>(pr, partial + SEGB, pstride);
+  if (active) block_store<MAX_DOTS>(pr, partial + SEGB, pstride);
 }
 
 template <int D>
@@ -955,7 +958,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_tangent_full(const Seg *segs, Node
     pr[0] = p;
     if (out) store_vec<RS>(out + (size_t)row * RS, o);
   }
-  if (partial) block_store<1>(pr, partial + SEGB, 0);
+  if (partial && active) block_store<1>(pr, partial + SEGB, 0);
 }
 
 // mode 0: out.Y = Proj_R(in.Y)                         (reduced_tangent_space_projection)
@@ -1031,7 +1034,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_bdiag_dot(const Seg *segs, NodeMas
     for (int k = 0; k < RS; k++) p = fma(xv[k], fma(coef, dx[k], addcoef * av[k]), p);
     pr[0] = p;
   }
-  block_store<1>(pr, partial + SEGB, 0);
+  if (active) block_store<1>(pr, partial + SEGB, 0);
 }
 
 // One wave per (node, slot): sums the node's per-segment partials in a fixed order and writes the scalar

@@ -662,3 +662,30 @@ def test_projection_kernel_matches_reference_avx_vectors(fixtures_dir, golden_di
     pad = np.tile(np.eye(2), (n2 - len(A2), 1, 1))
     out2 = grp2.debug_apply(0, "project", np.concatenate([A2, pad]).reshape(2 * n2, 2), 2 * n2).reshape(n2, 2, 2)[:len(A2)]
     np.testing.assert_allclose(out2, U2, rtol=0, atol=1e-15)
+
+
+def test_dynamic_rescale_on_synthetic_lattice():
+    """Rescale::Dynamic on the scaled-down headline workload (outlier closures: weights well below 1, a rescale of some
+    nodes -- not all -- in most iterations: the narrower second pass over the partial sums must leave the other nodes' alone)."""
+    from dpgo_amd import synthetic
+    from oracle.g2o import Measurements
+    g = synthetic.grid(12, 12, 8, 4000)
+    z = np.zeros(len(g["I"]), np.int64)
+    mm = Measurements(z, g["I"], z, g["J"], g["R"], g["t"], g["kappa"], g["tau"])
+    G = dpgo_amd.graph_from_edges(3, g["num_poses"], g["I"], g["J"], g["R"], g["t"], g["kappa"], g["tau"], 8)
+    X0 = G.chordal_initialization()
+    orc = ODistPGO(None, 8, _oracle_opts(LOSS_HUBER, True, rescale=1), X0=X0, mm=mm, num_poses=g["num_poses"])
+    gpu = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(LOSS_HUBER, True, rescale=1), X0=X0)
+    for it in range(30):
+        orc.step(evaluate=False)
+        assert gpu.step() == 0
+        for a in range(8):
+            np.testing.assert_allclose(gpu.group.results(a).fobj, orc.nodes[a].results.fobj[0], rtol=1e-7,
+                                       err_msg="it=%d node=%d" % (it, a))
+    Fo = orc.star.evaluate_f(orc.gather())
+    assert abs(orc.star.evaluate_f(gpu.X()) - Fo) <= 1e-6 * abs(Fo)
+    # (with Dynamic rescale fobj follows the reference's recursion fobj = Gk - ... (DPGOProblem.cpp:426-514), which
+    # tracks F to 1e-5 here, not to rounding: the sum is compared with the oracle's own sum)
+    So = sum(nd.results.fobj[0] for nd in orc.nodes)
+    assert abs(gpu.sum_fobj() - So) <= 1e-7 * abs(So)
+    assert abs(So - Fo) <= 1e-4 * abs(Fo)
