@@ -1,4 +1,5 @@
 #include "group.h"
+#include "graph.h"
 
 #include <algorithm>
 #include <cmath>
@@ -348,13 +349,19 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
     if (generate_data_info(nodes_[a], d_, g.measurements[nodes_[a]], info_[a]) != 0) return;
     // Rescale::Dynamic (robust losses): one scale per inter-node edge, all ones at construction (DPGOProblem.cpp:34)
     if (!trivial && opt.rescale == 1) scale_[a].assign(info_[a].inter.size(), 1.0);
-    if (assemble_node(info_[a], opt.regularizer, trivial, ops_[a], scale_[a].empty() ? nullptr : scale_[a].data()) != 0) return;
     g_index_[a] = g.g_index[nodes_[a]];
     own_off_[a + 1] = own_off_[a] + info_[a].n[0];
     nbr_off_[a + 1] = nbr_off_[a] + info_[a].n[1];
   }
   P0_ = own_off_[L];
   P1_ = nbr_off_[L];
+  {   // the operators of the nodes, one host thread per node
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(std::max(1, std::min(L, host_threads()))) reduction(+ : bad)
+    for (int a = 0; a < L; a++)
+      bad += assemble_node(info_[a], opt.regularizer, trivial, ops_[a], scale_[a].empty() ? nullptr : scale_[a].data()) != 0;
+    if (bad) return;
+  }
   auto uni = [&](int a, int p) { return p < info_[a].n[0] ? own_off_[a] + p : P0_ + nbr_off_[a] + (p - info_[a].n[0]); };
 
   // ---- segments
@@ -1189,6 +1196,7 @@ void Group::host_update_logic(int a, double fobj, double f, double gradFnorm) {
 // scales are clamp(1.25 w, min_rescale_, max_rescale_) (DPGOProblem.h:17-18), update_quadratic_mat (:751-840) and
 // L_.factorize follow.  The preconditioner keeps the factor of the constructor, as in the reference.
 std::vector<int> Group::maybe_rescale(const std::vector<int> &set) {
+  SetupClock clk;   // (DPGO_SETUP_TIMING=1)
   std::vector<int> changed;
   std::vector<double> w(std::max<size_t>(e_w_.n, 1));
   sync();
@@ -1203,11 +1211,20 @@ std::vector<int> Group::maybe_rescale(const std::vector<int> &set) {
     }
     for (int e = 0; e < m1; e++) scale_[a][e] = std::min(1.0, std::max(0.01, 1.25 * w[e_off_[a] + e]));
     rescale_count_[a] = 0;
-    if (assemble_node(info_[a], opt_.regularizer, false, ops_[a], scale_[a].data()) != 0) throw DeviceError("assemble_node");
     changed.push_back(a);
   }
   if (!changed.empty()) {
+    int bad = 0;
+    const int nc = (int)changed.size();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(std::max(1, std::min(nc, host_threads()))) reduction(+ : bad)
+    for (int i = 0; i < nc; i++) {
+      const int a = changed[i];
+      bad += assemble_node(info_[a], opt_.regularizer, false, ops_[a], scale_[a].data()) != 0;
+    }
+    if (bad) throw DeviceError("assemble_node");
+    clk.lap("rescale: weights + host assembly");
     upload_operators();
+    clk.lap("rescale: operators to the device");
     if (refactor_tt() != 0) throw DeviceError("G_tt is not positive definite after a rescale");
   }
   return changed;
