@@ -110,3 +110,32 @@ def test_random_graph_star(tmp_path, seed):
         s = gpu.state()
         np.testing.assert_allclose(s["F"], orc.F, rtol=1e-7, atol=1e-9, err_msg="%s it=%d F" % (tag, it))
         np.testing.assert_allclose(s["fobj"], orc.fobj, rtol=1e-7, atol=1e-9, err_msg="%s it=%d fobj" % (tag, it))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_graph_dynamic_rescale(tmp_path, seed):
+    """The random graphs with Rescale::Dynamic (DPGO::Options' default) and a robust loss: nodes are rescaled at
+    different iterations, so most updates re-linearise a subset of the group; per-node fobj / Gk after every iteration."""
+    path = str(tmp_path / ("fuzzdyn%d.g2o" % seed))
+    d, n, nn, loss, acc = _write_case(path, 9000 + seed)
+    loss = 1 + loss % 3                       # Huber, GM, Welsch
+    num_poses, mm = og.read_g2o_file(path)
+    X0 = chordal_initialization(num_poses, mm)
+    oo = OOptions.driver(loss, acc)
+    oo.rescale = 1
+    orc = ODistPGO(path, nn, oo, X0=X0, mm=mm, num_poses=num_poses)
+    G = dpgo_amd.read_g2o(path, nn)
+    gpu = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(loss, acc, rescale=1), X0=X0)
+    tag = "seed=%d d=%d n=%d nodes=%d loss=%d acc=%s" % (seed, d, n, nn, loss, acc)
+    for it in range(20):
+        orc.step(evaluate=False)
+        assert gpu.step() == 0, tag
+        for a in range(nn):
+            ro, rg = orc.nodes[a].results, gpu.group.results(a)
+            np.testing.assert_allclose(rg.fobj, ro.fobj[0], rtol=1e-7, atol=1e-9, err_msg="%s it=%d node=%d fobj" % (tag, it, a))
+            np.testing.assert_allclose(rg.Gk, ro.Gk, rtol=1e-7, atol=1e-9, err_msg="%s it=%d node=%d Gk" % (tag, it, a))
+    Xg, Xo = gpu.X(), orc.gather()
+    if nn == 1:
+        Xg[:num_poses] -= Xg[:num_poses].mean(axis=0)
+        Xo[:num_poses] -= Xo[:num_poses].mean(axis=0)
+    np.testing.assert_allclose(Xg, Xo, atol=1e-6, err_msg=tag)

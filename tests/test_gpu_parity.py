@@ -689,3 +689,41 @@ def test_dynamic_rescale_on_synthetic_lattice():
     So = sum(nd.results.fobj[0] for nd in orc.nodes)
     assert abs(gpu.sum_fobj() - So) <= 1e-7 * abs(So)
     assert abs(So - Fo) <= 1e-4 * abs(Fo)
+
+
+@pytest.mark.parametrize("loss,acc,kw", [
+    (LOSS_NONE, False, {}),                         # MM-PGO, trivial loss
+    (LOSS_NONE, True, {}),
+    (LOSS_GM, True, {}),
+    (LOSS_WELSCH, False, {}),
+    (LOSS_HUBER, True, dict(preconditioner=0)),
+    (LOSS_HUBER, True, dict(preconditioner=1)),
+    (LOSS_HUBER, True, dict(max_iterations_accepted=3, max_iterations=12)),
+])
+def test_option_matrix_at_scale(loss, acc, kw):
+    """Every scheme / loss / TNT variant on a 32 x 32 x 24 lattice (24 576 poses, 6 nodes of unequal boundary sizes, the
+    tile classes of the big factor) without the oracle: sum_a fobj^a = F from the independent cost pass, |grad| from the
+    per-node norms, rotations in SO(3), MM monotone, the objective below its start."""
+    from dpgo_amd import synthetic
+    g = synthetic.grid(32, 32, 24, 98304)
+    N = g["num_poses"]
+    G = dpgo_amd.graph_from_edges(3, N, g["I"], g["J"], g["R"], g["t"], g["kappa"], g["tau"], 6)
+    X0 = G.chordal_initialization()
+    grp = dpgo_amd.NodeGroup(G, range(6), dpgo_amd.Options.driver(loss, acc, **kw))
+    assert grp.initialize_global(X0) == 0 and grp.update() == 0
+    F0 = prev = sum(grp.results(k).fobj for k in range(6))
+    for it in range(8):
+        assert grp.iterate() == 0 and grp.communicate_local() == 0 and grp.update() == 0
+        Fsum = sum(grp.results(k).fobj for k in range(6))
+        assert np.isfinite(Fsum)
+        if not acc:
+            assert Fsum <= prev * (1 + 1e-12), (it, Fsum, prev)      # MM-PGO is monotone (SURVEY Appendix B)
+        prev = Fsum
+    X = np.zeros((4 * N, 3), order="F")
+    grp.scatter_global(X)
+    F, g2 = grp.evaluate(X)
+    assert abs(Fsum - F) <= 1e-8 * F, (Fsum, F)
+    assert abs(sum(grp.results(k).gradFnorm ** 2 for k in range(6)) - g2) <= 1e-8 * g2
+    assert F < F0
+    R = X[N:].reshape(N, 3, 3)
+    np.testing.assert_allclose(np.einsum("nij,nkj->nik", R, R), np.broadcast_to(np.eye(3), R.shape), atol=1e-12)
