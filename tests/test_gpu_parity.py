@@ -727,3 +727,29 @@ def test_option_matrix_at_scale(loss, acc, kw):
     assert F < F0
     R = X[N:].reshape(N, 3, 3)
     np.testing.assert_allclose(np.einsum("nij,nkj->nik", R, R), np.broadcast_to(np.eye(3), R.shape), atol=1e-12)
+
+
+@pytest.mark.parametrize("loss", [LOSS_NONE, LOSS_HUBER])
+def test_amm_pgo_star_at_scale(loss):
+    """AMM-PGO* (BASELINE config 5's scheme) on the 24 576-pose lattice, 4 nodes, no oracle: the master's fobj
+    is the global objective at the iterate (independent cost pass, 1e-8) and its reference value F never increases
+    (DPGOStar.cpp:126-213: a step that does not decrease it is taken again without extrapolation)."""
+    from dpgo_amd import synthetic
+    g = synthetic.grid(32, 32, 24, 98304)
+    N = g["num_poses"]
+    G = dpgo_amd.graph_from_edges(3, N, g["I"], g["J"], g["R"], g["t"], g["kappa"], g["tau"], 4)
+    star = dpgo_amd.DPGOStar(G, dpgo_amd.Options.driver(loss, True))
+    assert star.initialize(G.chordal_initialization()) == 0
+    prev = None
+    for it in range(8):
+        assert star.step() == 0
+        F = star.state()["F"]
+        assert np.isfinite(F)
+        if prev is not None:
+            assert F <= prev * (1 + 1e-12), (it, F, prev)
+        prev = F
+    Fx, _ = star.group.evaluate(star.X())
+    assert star.update() == 0                      # fobj of the state refers to the last linearisation point
+    s = star.state()
+    assert abs(s["fobj"] - Fx) <= 1e-8 * Fx, (s, Fx)
+    assert s["fobj"] <= s["F"]                     # F: the master's running reference value (DPGOStar.cpp:200-205)
