@@ -12,8 +12,9 @@ iterate() -> boundary-pose exchange -> update()  (dist_pgo.cpp:496-521).
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line (rank 0) with the throughput, a `roofline` object for the dominant kernel family
-(per-launch durations measured with HIP events on the launch stream in an instrumented pass that
-repeats the timed region) and, at N = 1, a `cpu_baseline` object (the oracle timed on a bounded sample).
+(launch durations measured with HIP events on the launch stream in an instrumented pass that repeats the
+timed region; a solve sweep's back-to-back launches share one event pair) and, at N = 1, a `cpu_baseline`
+object (the C++ CPU restatement timed on a bounded sample).
 """
 import argparse
 import json

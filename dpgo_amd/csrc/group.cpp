@@ -711,11 +711,24 @@ void Group::copy_rows(double *dst, const double *src, bool all_rows, int part) {
 // out <- scale * A^-1 in (the unknowns' entries of the records; everything else in `out` is left alone).
 // The forward sweep only reads `in`, the backward sweep only touches `out`: in == out solves in place.
 void spd_run(int d, hipStream_t st, SpdSolverDev &S, NodeMask mask, double *in, double *out, double scale) {
+  auto total = [](const std::vector<SpdSolverDev::Level> &lv, const std::vector<double> &bytes, int &n) {
+    double b = 0;
+    n = 0;
+    for (size_t l = 0; l < lv.size(); l++)
+      if (lv[l].nwide + lv[l].nnarrow > 0) { b += bytes[l]; n++; }
+    return b;
+  };
+  int nf = 0, nb = 0;
+  const double bf = total(S.fwd_levels, S.fwd_level_bytes, nf), bb = total(S.bwd_levels, S.bwd_level_bytes, nb);
+  {
+  ProfSweep sweep(true, st, bf, nf);
   for (size_t l = 0; l < S.fwd_levels.size(); l++) {
     const SpdSolverDev::Level &v = S.fwd_levels[l];
     launch_spd_level(d, S.dof, st, S.dev, true, v.tile0, v.nwide, v.nnarrow, v.rows, in, S.ytmp.p, scale, S.fwd_level_bytes[l],
                      S.stream_once, mask);
   }
+  }
+  ProfSweep sweep(false, st, bb, nb);
   for (size_t l = 0; l < S.bwd_levels.size(); l++) {
     const SpdSolverDev::Level &v = S.bwd_levels[l];
     launch_spd_level(d, S.dof, st, S.dev, false, v.tile0, v.nwide, v.nnarrow, v.rows, out, S.ytmp.p, scale, S.bwd_level_bytes[l],

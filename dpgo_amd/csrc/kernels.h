@@ -234,6 +234,15 @@ void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forw
 enum ProfKind { PK_BSR = 0, PK_INTER, PK_PROX, PK_AXPBY, PK_DOT, PK_ROTOP, PK_COPYIDX, PK_BDIAG, PK_REDUCE,
                 PK_SPD_FWD, PK_SPD_BWD, PK_COUNT };
 void prof_enable(bool on);
+// One timing scope around the back-to-back launches of a solve sweep (profiling pass only; nothing otherwise)
+struct ProfSweep {
+  struct Impl;
+  Impl *p;
+  ProfSweep(bool forward, hipStream_t st, double bytes, int launches);
+  ~ProfSweep();
+  ProfSweep(const ProfSweep &) = delete;
+  ProfSweep &operator=(const ProfSweep &) = delete;
+};
 void prof_reset();
 void prof_collect(double *ms, double *bytes, long *count);
 

@@ -1738,6 +1738,7 @@ struct Prof {
   double ms[PK_COUNT] = {0};
   double bytes[PK_COUNT] = {0};
   long count[PK_COUNT] = {0};
+  int nested = 0;
   void flush() {
     if (!used) return;
     (void)hipEventSynchronize(ev[2 * used - 1]);
@@ -1753,7 +1754,10 @@ Prof g_prof;
 struct ProfScope {
   hipStream_t st;
   bool on;
-  ProfScope(int kind, hipStream_t s, double bytes) : st(s), on(g_prof.on) {
+  // n launches share the scope (a sweep of the solve: one event pair around its back-to-back launches, so that the
+  // events do not sit between the kernels they time); scopes opened inside such a scope do nothing
+  ProfScope(int kind, hipStream_t s, double bytes, int n = 1) : st(s), on(g_prof.on && g_prof.nested == 0) {
+    if (g_prof.on && n > 1) { g_prof.nested++; outer = true; }
     if (!on) return;
     if (g_prof.used == g_prof.kind.size()) {
       if (g_prof.kind.size() >= 32768) g_prof.flush();
@@ -1767,17 +1771,24 @@ struct ProfScope {
       }
     }
     g_prof.kind[g_prof.used] = kind;
-    g_prof.count[kind]++;
+    g_prof.count[kind] += n;
     g_prof.bytes[kind] += bytes;
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
   }
+  bool outer = false;
   ~ProfScope() {
+    if (outer) g_prof.nested--;
     if (!on) return;
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
     g_prof.used++;
   }
 };
 }  // namespace
+
+struct ProfSweep::Impl { ProfScope ps; Impl(int k, hipStream_t st, double b, int n) : ps(k, st, b, n) {} };
+ProfSweep::ProfSweep(bool forward, hipStream_t st, double bytes, int launches)
+    : p(g_prof.on && launches > 1 ? new Impl(forward ? PK_SPD_FWD : PK_SPD_BWD, st, bytes, launches) : nullptr) {}
+ProfSweep::~ProfSweep() { delete p; }
 
 void prof_enable(bool on) {
   g_prof.flush();

@@ -47,7 +47,7 @@ rows = [
     "| set-up (untimed) | %.1f s graph + chordal init, %.1f s operators + both factorizations | same file |" % (
         j["setup_s"]["graph+chordal_init"], j["setup_s"]["operators+factorizations"]),
     "| one rank of an 8-GPU run emulated on one GPU (1 node, frozen neighbours, no exchange) | %.2f ms / iteration | `profiles/%s_bench_emulated_rank3of8.json` (diagnostic, not a metric) |" % (e["ms_per_step"], tag),
-    "| dominant kernel family | `%s`: %.0f launches / iteration, %.1f µs average (HIP events, events included) vs %.1f µs (rocprofv3 --stats) | `%s_bench_n1.json`, `%s_kernel_stats_bench_default.csv` |" % (
+    "| dominant kernel family | `%s`: %.0f launches / iteration, %.1f µs average (HIP events around each sweep, launch gaps included) vs %.1f µs (rocprofv3 --stats, kernel time only) | `%s_bench_n1.json`, `%s_kernel_stats_bench_default.csv` |" % (
         r["kernel"], r["launches_per_step"], r["avg_launch_us"], rocprof_avg_us(r["kernel"]), tag, tag),
     "| its algorithmic bytes | %.1f MB / launch ⇒ %.2f TB/s = **%.2f of the 8 TB/s HBM roofline** | §3 table |" % (
         r["algorithmic_bytes_per_launch"] / 1e6, r["achieved"] / 1e3, r["frac"]),
