@@ -74,6 +74,15 @@ struct SetupClock {
   }
 };
 
+// The factor stores explicit inverses of the pivot blocks: a pivot range beyond 1e13 (a badly scaled dataset: information
+// matrices that differ by many orders of magnitude, or a regulariser far below the weights) leaves few correct digits.
+static void warn_conditioning(const char *what, const SpdFactor &F) {
+  if (F.pivot_min > 0.0 && F.pivot_max / F.pivot_min > 1e13)
+    fprintf(stderr, "[dpgo_amd] WARNING: %s is badly conditioned (pivots %.3e .. %.3e, ratio %.1e): expect about %d correct "
+                    "digits from its solves.\n", what, F.pivot_min, F.pivot_max, F.pivot_max / F.pivot_min,
+            std::max(0, 16 - (int)std::ceil(std::log10(F.pivot_max / F.pivot_min))));
+}
+
 // Device layout of a factor.  The solve streams every W_s once per sweep, so the matrices are re-packed
 // into PANELS: the entries one tile reads, contiguous, in the order it reads them.
 //   forward tile (rows p0 .. p0+count of [y ; dupd], all columns k < kend):  panel[k][r] = WT_s[k][p0 + r]
@@ -486,6 +495,7 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
       if (spd_factor(Arr, Lrr_.F, env_int("DPGO_SPD_LEAF_RR", 96), env_int("DPGO_SPD_COLLAPSE_RR", 0), env_int("DPGO_SPD_QUOTIENT", 1) ? d_ : 1,
                      env_int("DPGO_SPD_DEVICE_PANELS", 1) != 0) != 0) return;
       clk.lap("G_RR: ordering + symbolic + numeric factor");
+      warn_conditioning("G_RR + lambda I", Lrr_.F);
       Lrr_.dof = d_;
       std::vector<int> node_of_row((size_t)P0_ * d_);
       for (int a = 0; a < L; a++)
@@ -604,6 +614,7 @@ int Group::refactor_tt() {
   } else if (spd_factor(Att, Ltt_.F, env_int("DPGO_SPD_LEAF_TT", 128), env_int("DPGO_SPD_COLLAPSE_TT", 0), 1,
                         env_int("DPGO_SPD_DEVICE_PANELS", 1) != 0) != 0) return -1;
   clk.lap("G_tt: ordering + symbolic + numeric factor");
+  warn_conditioning("G_tt", Ltt_.F);
   Ltt_.dof = 1;
   std::vector<int> node_of_pose(P0_);
   for (int a = 0; a < L; a++)

@@ -49,6 +49,9 @@ struct SpdFactor {
   int total_pos = 0, total_upd = 0, max_front = 0;
   // keep_device: the numeric phase leaves W / WT on the GPU (dev_W / dev_WT, same per-front layout as W / WT, owned by
   // the factor until spd_release_device) and does not fill the host copies -- for callers that only solve on the device
+  // smallest / largest pivot d_kk of the factorisation (device numeric phase; 0 / 0 when not recorded): their ratio is a
+  // lower bound of the condition number -- W_s holds the explicit L11^-1, so a huge ratio costs digits in every solve
+  double pivot_min = 0.0, pivot_max = 0.0;
   bool keep_device = false;
   double *dev_W = nullptr, *dev_WT = nullptr;
   int64_t nnz() const { return entries; }

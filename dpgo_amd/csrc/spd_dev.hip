@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "spd.h"
@@ -81,7 +82,10 @@ __global__ __launch_bounds__(256) void k_fa_extend(const FrontDesc *fd, const Ex
 }
 
 // Cholesky of the diagonal block [kb, kb + nb) and its inverse (one wave per front)
-__global__ __launch_bounds__(64) void k_fa_potrf(const FrontDesc *fd, const int *lvl, int kb, double *Fm, double *dinv, int *fail) {
+// fail[0]: 1 + front of a non-positive pivot; pivr[0] / pivr[1]: smallest / largest pivot d_kk seen (bit patterns of positive
+// doubles order like integers)
+__global__ __launch_bounds__(64) void k_fa_potrf(const FrontDesc *fd, const int *lvl, int kb, double *Fm, double *dinv, int *fail,
+                                                 unsigned long long *pivr) {
   const FrontDesc f = fd[lvl[blockIdx.x]];
   if (f.w <= kb) return;
   const int nb = min(NB, f.w - kb), t = threadIdx.x;
@@ -93,12 +97,15 @@ __global__ __launch_bounds__(64) void k_fa_potrf(const FrontDesc *fd, const int 
     X[i][j] = 0.0;
   }
   __syncthreads();
+  double dmin = 1e300, dmax = 0.0;
   for (int k = 0; k < nb; k++) {
     const double dkk = L[k][k];
     if (!(dkk > 0.0)) {
       if (t == 0) atomicExch(fail, 1 + lvl[blockIdx.x]);
       return;
     }
+    dmin = fmin(dmin, dkk);
+    dmax = fmax(dmax, dkk);
     const double lkk = sqrt(dkk), inv = 1.0 / lkk;
     __syncthreads();
     if (t == 0) L[k][k] = lkk;
@@ -110,6 +117,10 @@ __global__ __launch_bounds__(64) void k_fa_potrf(const FrontDesc *fd, const int 
       for (int j = k + 1; j <= t; j++) L[t][j] -= lik * L[j][k];
     }
     __syncthreads();
+  }
+  if (t == 0) {
+    atomicMin(pivr, (unsigned long long)__double_as_longlong(dmin));
+    atomicMax(pivr + 1, (unsigned long long)__double_as_longlong(dmax));
   }
   // X = L^-1: lane j owns column j (forward substitution on e_j)
   if (t < nb) {
@@ -368,7 +379,7 @@ int spd_factor_numeric_device(const CsrMatrix &A, SpdFactor &F, const std::vecto
     FA_OK(hipMalloc((void **)&d_src, sizeof(int) * std::max<size_t>(src.size(), 1)));
     FA_OK(hipMalloc((void **)&d_cmap, sizeof(int) * cmap.size()));
     FA_OK(hipMalloc((void **)&d_lvl, sizeof(int) * std::max<size_t>(lvl_flat.size(), 1)));
-    FA_OK(hipMalloc((void **)&d_fail, sizeof(int)));
+    FA_OK(hipMalloc((void **)&d_fail, 24));   // int fail; then two 64-bit words: smallest / largest pivot
     FA_OK(hipMalloc((void **)&d_aval, sizeof(double) * std::max<size_t>(A.val.size(), 1)));
     FA_OK(hipMalloc((void **)&d_Fm, sizeof(double) * std::max<long long>(fm_total, 1)));
     FA_OK(hipMalloc((void **)&d_dinv, sizeof(double) * max_lvl * NB * NB));
@@ -383,7 +394,11 @@ int spd_factor_numeric_device(const CsrMatrix &A, SpdFactor &F, const std::vecto
     FA_OK(hipMemcpyAsync(d_lvl, lvl_flat.data(), sizeof(int) * lvl_flat.size(), hipMemcpyHostToDevice, st));
     FA_OK(hipMemcpyAsync(d_aval, A.val.data(), sizeof(double) * A.val.size(), hipMemcpyHostToDevice, st));
     if (!pairs.empty()) FA_OK(hipMemcpyAsync(d_pairs, pairs.data(), sizeof(ExtendPair) * pairs.size(), hipMemcpyHostToDevice, st));
-    FA_OK(hipMemsetAsync(d_fail, 0, sizeof(int), st));
+    {
+      unsigned long long init[3] = {0ull, 0x7ff0000000000000ull, 0ull};
+      FA_OK(hipMemcpyAsync(d_fail, init, 24, hipMemcpyHostToDevice, st));
+      FA_OK(hipStreamSynchronize(st));
+    }
     FA_OK(hipMemsetAsync(d_Fm, 0, sizeof(double) * std::max<long long>(fm_total, 1), st));
     FA_OK(hipMemsetAsync(d_W, 0, sizeof(double) * std::max<int64_t>(F.w_off[nt], 1), st));
     FA_OK(hipMemsetAsync(d_WT, 0, sizeof(double) * std::max<int64_t>(F.wt_off[nt], 1), st));
@@ -426,7 +441,8 @@ int spd_factor_numeric_device(const CsrMatrix &A, SpdFactor &F, const std::vecto
       for (int sb = 0; sb < max_w; sb += SB) {
         const int se = sb + SB;
         for (int kb = sb; kb < std::min(se, max_w); kb += NB) {
-          hipLaunchKernelGGL(k_fa_potrf, dim3(nf), dim3(64), 0, st, d_fd, L, kb, d_Fm, d_dinv, d_fail);
+          hipLaunchKernelGGL(k_fa_potrf, dim3(nf), dim3(64), 0, st, d_fd, L, kb, d_Fm, d_dinv, d_fail,
+                             reinterpret_cast<unsigned long long *>(d_fail) + 1);
           hipLaunchKernelGGL(k_fa_panel, dim3((max_m + 255) / 256, nf), dim3(256), 0, st, d_fd, L, kb, d_Fm, d_dinv);
           if (abt0(kb, kb + NB, se, 0) != 0) return -1;      // the rest of the super-block (of the front, if it ends here), K = 32
         }
@@ -455,8 +471,17 @@ int spd_factor_numeric_device(const CsrMatrix &A, SpdFactor &F, const std::vecto
       }
     }
     int fail = 0;
-    FA_OK(hipMemcpyAsync(&fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
+    unsigned long long back[3] = {0, 0, 0};
+    FA_OK(hipMemcpyAsync(back, d_fail, 24, hipMemcpyDeviceToHost, st));
     FA_OK(hipStreamSynchronize(st));
+    fail = (int)(back[0] & 0xffffffffull);
+    {
+      double lo, hi;
+      memcpy(&lo, &back[1], 8);
+      memcpy(&hi, &back[2], 8);
+      F.pivot_min = lo;
+      F.pivot_max = hi;
+    }
     FA_OK(hipGetLastError());
     if (fail) {
       fprintf(stderr, "[dpgo_amd] ERROR: spd_factor (device): non-positive pivot in front %d\n", fail - 1);

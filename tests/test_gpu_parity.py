@@ -753,3 +753,22 @@ def test_amm_pgo_star_at_scale(loss):
     s = star.state()
     assert abs(s["fobj"] - Fx) <= 1e-8 * Fx, (s, Fx)
     assert s["fobj"] <= s["F"]                     # F: the master's running reference value (DPGOStar.cpp:200-205)
+
+
+def test_conditioning_warning(fixtures_dir, capfd):
+    """The factor holds explicit inverses of its pivot blocks: a pivot range beyond 1e13 is reported at
+    construction; the BASELINE datasets stay silent."""
+    n = 12
+    I, J = np.arange(n - 1), np.arange(1, n)
+    R = np.tile(np.eye(3), (n - 1, 1, 1))
+    t = np.tile(np.array([1.0, 0.0, 0.0]), (n - 1, 1))
+    kappa = np.full(n - 1, 100.0)
+    tau = np.full(n - 1, 1e3)
+    tau[2] = 3e-12                                # poses 0..2 hang on the rest by a measurement 15 orders weaker
+    G = dpgo_amd.graph_from_edges(3, n, I, J, R, t, kappa, tau, 2)
+    capfd.readouterr()
+    dpgo_amd.NodeGroup(G, [0, 1], dpgo_amd.Options.driver(LOSS_NONE, True))
+    assert "badly conditioned" in capfd.readouterr().err
+    G2 = dpgo_amd.read_g2o(os.path.join(fixtures_dir, "sphere2500.g2o"), 1)   # one node: G_tt = Laplacian + 1e-11 I
+    dpgo_amd.NodeGroup(G2, [0], dpgo_amd.Options.driver(LOSS_NONE, True))
+    assert "WARNING" not in capfd.readouterr().err
