@@ -146,10 +146,7 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
       for (int f : lvl) longest = std::max(longest, F.w[f] + F.u[f]);
       const bool fine = fwd ? wide_tiles < env_int("DPGO_SPD_FINE_FWD", 192)
                             : (wide_tiles < env_int("DPGO_SPD_FINE_BWD", 256) || (wide_tiles < env_int("DPGO_SPD_FINE_BWD_TALL", 800) && longest >= 1000));
-      // many tiles: the level is throughput bound -- 128-row tiles (two rows per lane, 16-byte loads) stream twice the
-      // panel bytes per gather of the front's input vector
-      const bool tall = wide_tiles >= env_int("DPGO_SPD_TALL", 1 << 30);
-      const int rows = (wide_tiles > 0 && fine) ? 16 : (tall ? 128 : 64);
+      const int rows = (wide_tiles > 0 && fine) ? 16 : 64;
       // wide tiles first (one workgroup each), then the narrow ones (one wave each)
       Level lev{(int)tiles.size(), 0, 0, rows};
       for (int pass = 1; pass >= 0; pass--) {

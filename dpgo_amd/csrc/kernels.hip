@@ -1499,185 +1499,6 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
   SPD_TRACE_FLUSH(wv == 0 && lane == 0)
 }
 
-// ---- 128-row tiles: two rows per lane, 16-byte panel loads (1 KB per wave instruction) -------------------------
-// Levels with many 64-row tiles are throughput bound: a taller tile streams twice the panel bytes per gather of its
-// front's input vector and keeps twice the bytes in flight per outstanding load.
-typedef double d2v __attribute__((ext_vector_type(2)));
-#ifndef SPD_HB2
-#define SPD_HB2 6
-#endif
-template <bool NT>
-__device__ __forceinline__ d2v ld2(const double *p) {
-  const d2v *q = reinterpret_cast<const d2v *>(p);
-  return NT ? __builtin_nontemporal_load(q) : *q;
-}
-// acc0[c] += sum_k W[k][2 lane] f[k][c], acc1[c] += sum_k W[k][2 lane + 1] f[k][c], k < kn; rows ld doubles apart
-template <int D, bool NT, int HB>
-__device__ __forceinline__ void stream2(const double *wp, int ld, int kn, const double *fw, double (&acc0)[D], double (&acc1)[D]) {
-  d2v a[HB], b[HB];
-  int kk = 0;
-  bool have = HB <= kn;
-  if (have) {
-#pragma unroll
-    for (int q = 0; q < HB; q++) a[q] = ld2<NT>(wp + (size_t)q * ld);
-  }
-#define SPD_FMA2(buf, k0)                                                                   \
-  _Pragma("unroll") for (int q = 0; q < HB; q++)                                            \
-      _Pragma("unroll") for (int c = 0; c < D; c++) {                                       \
-        const double fv = fw[((k0) + q) * D + c];                                           \
-        acc0[c] = fma(buf[q].x, fv, acc0[c]);                                               \
-        acc1[c] = fma(buf[q].y, fv, acc1[c]);                                               \
-      }
-#define SPD_LOAD2(buf, k0) _Pragma("unroll") for (int q = 0; q < HB; q++) buf[q] = ld2<NT>(wp + (size_t)((k0) + q) * ld);
-  while (have) {
-    int k2 = kk + HB;
-    bool more = k2 + HB <= kn;
-    if (more) { SPD_LOAD2(b, k2) }
-    SPD_FMA2(a, kk)
-    kk = k2;
-    have = more;
-    if (!have) break;
-    k2 = kk + HB;
-    more = k2 + HB <= kn;
-    if (more) { SPD_LOAD2(a, k2) }
-    SPD_FMA2(b, kk)
-    kk = k2;
-    have = more;
-  }
-#undef SPD_FMA2
-#undef SPD_LOAD2
-  if (kk < kn) {   // the rest: one predicated batch
-#pragma unroll
-    for (int q = 0; q < HB; q++) b[q] = kk + q < kn ? ld2<NT>(wp + (size_t)(kk + q) * ld) : d2v{0.0, 0.0};
-#pragma unroll
-    for (int q = 0; q < HB; q++)
-      if (kk + q < kn) {
-#pragma unroll
-        for (int c = 0; c < D; c++) {
-          const double fv = fw[(kk + q) * D + c];
-          acc0[c] = fma(b[q].x, fv, acc0[c]);
-          acc1[c] = fma(b[q].y, fv, acc1[c]);
-        }
-      }
-  }
-}
-
-template <int D, int DOF, int NW, int SPD_CH, bool NT>
-__device__ __forceinline__ void spd_fwd_tile2(const SpdDev &S, const SpdItem &it, const double *vec, double *ytmp,
-                                              double *fw, double *red, const int wv, const int lane) {
-  constexpr int ROWS = 128;
-  const int r0 = 2 * lane;
-  const bool valid = r0 < it.count;   // (an odd count: the second row of the last lane reads the panel's zero padding)
-  const int w = it.w;
-  const double *WT = S.WT + it.mat_off + r0;
-  const int ldm = it.ld;
-  const int *piv = S.piv_idx + it.piv_ptr;
-  const int pos0 = it.pos_off;
-  double acc0[D], acc1[D];
-#pragma unroll
-  for (int c = 0; c < D; c++) acc0[c] = acc1[c] = 0.0;
-  const int kend = (it.first + ROWS <= w) ? it.first + ROWS : w;
-  const int cl = spd_chunk<NW, SPD_CH>(kend);
-  for (int k0 = wv * cl; k0 < kend; k0 += NW * cl) {
-    const int kn = min(cl, kend - k0);
-    for (int kk = lane; kk < kn; kk += 64) {
-      const int k = k0 + kk;
-      double v[D];
-      const double *src = vec + vaddr<D, DOF>(piv[k]);
-#pragma unroll
-      for (int c = 0; c < D; c++) v[c] = *(src + c);
-      pull_updates<D, 2>(S, pos0 + k, v);
-#pragma unroll
-      for (int c = 0; c < D; c++) fw[kk * D + c] = v[c];
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (valid) stream2<D, NT, SPD_HB2>(WT + (size_t)k0 * ldm, ldm, kn, fw, acc0, acc1);
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (valid) {
-#pragma unroll
-    for (int c = 0; c < D; c++) {
-      red[wv * ROWS * D + r0 * D + c] = acc0[c];
-      red[wv * ROWS * D + (r0 + 1) * D + c] = acc1[c];
-    }
-  }
-  __syncthreads();
-  // waves 0 and 1 write the rows: wave 0 the even ones of each pair ... simpler: 128 rows over two waves
-  if (wv >= 2) return;
-  const int r = wv * 64 + lane, p = it.first + r;
-  if (r >= it.count) return;
-  double out[D];
-#pragma unroll
-  for (int c = 0; c < D; c++) {
-    double a = red[r * D + c];
-    for (int q = 1; q < NW; q++) a += red[q * ROWS * D + r * D + c];
-    out[c] = a;
-  }
-  if (p < w) {
-    double *dst = ytmp + (size_t)(it.piv_ptr + p) * D;
-#pragma unroll
-    for (int c = 0; c < D; c++) *(dst + c) = out[c];
-  } else {
-    double extra[D];
-#pragma unroll
-    for (int c = 0; c < D; c++) extra[c] = 0.0;
-    pull_updates<D, 2>(S, pos0 + p, extra);
-    double *dst = S.ubuf + (size_t)S.ubuf_dst[it.ubuf_off + p - w] * D;
-#pragma unroll
-    for (int c = 0; c < D; c++) *(dst + c) = out[c] + extra[c];
-  }
-}
-
-template <int D, int DOF, int NW, int SPD_CH, bool NT>
-__device__ __forceinline__ void spd_bwd_tile2(const SpdDev &S, const SpdItem &it, double scale, const double *ytmp,
-                                              double *vec, double *fw, double *red, const int wv, const int lane) {
-  constexpr int ROWS = 128;
-  const int r0 = 2 * lane;
-  const bool valid = r0 < it.count;
-  const int w = it.w, m = w + it.u;
-  const double *W = S.W + it.mat_off + r0;
-  const int ldw = it.ld;
-  const int *piv = S.piv_idx + it.piv_ptr;
-  const int *upd = S.upd_idx + it.upd_ptr;
-  double acc0[D], acc1[D];
-#pragma unroll
-  for (int c = 0; c < D; c++) acc0[c] = acc1[c] = 0.0;
-  const int cl = spd_chunk<NW, SPD_CH>(m - it.first);
-  for (int p0 = it.first + wv * cl; p0 < m; p0 += NW * cl) {
-    const int pn = min(cl, m - p0);
-    for (int pp = lane; pp < pn; pp += 64) {
-      const int p = p0 + pp;
-      const double sc = p < w ? 1.0 : scale;
-      const double *src = p < w ? ytmp + (size_t)(it.piv_ptr + p) * D : vec + vaddr<D, DOF>(upd[p - w]);
-#pragma unroll
-      for (int c = 0; c < D; c++) fw[pp * D + c] = sc * *(src + c);
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (valid) stream2<D, NT, SPD_HB2>(W + (size_t)(p0 - it.first) * ldw, ldw, pn, fw, acc0, acc1);
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (valid) {
-#pragma unroll
-    for (int c = 0; c < D; c++) {
-      red[wv * ROWS * D + r0 * D + c] = acc0[c];
-      red[wv * ROWS * D + (r0 + 1) * D + c] = acc1[c];
-    }
-  }
-  __syncthreads();
-  if (wv >= 2) return;
-  const int r = wv * 64 + lane;
-  if (r >= it.count) return;
-  double *dst = vec + vaddr<D, DOF>(piv[it.first + r]);
-#pragma unroll
-  for (int c = 0; c < D; c++) {
-    double a = red[r * D + c];
-    for (int q = 1; q < NW; q++) a += red[q * ROWS * D + r * D + c];
-    *(dst + c) = scale * a;
-  }
-}
-
 // One level of a sweep in one launch.  A workgroup (8 waves) takes a PACK: either one tile of a wide front,
 // shared by the 8 waves (ROWS-row tiles), or up to 8 tiles of narrow fronts (reduction length <= 96), one
 // per wave.  Wide packs come first, longest first; the narrow ones fill the tail of the launch.
@@ -1711,13 +1532,8 @@ __global__ __launch_bounds__(64 * SPD_NW(ROWS), ROWS == 64 ? SPD_WPE : 4) void k
   } else {
     const SpdItem it = load_item(items + b);
     if (!((bits >> it.node) & 1ull)) return;   // (uniform over the workgroup)
-    if constexpr (ROWS == 128) {
-      if constexpr (FWD) spd_fwd_tile2<D, DOF, NW, CH, NT>(S, it, vec, ytmp, f[wv], red, wv, lane);
-      else spd_bwd_tile2<D, DOF, NW, CH, NT>(S, it, scale, ytmp, vec, f[wv], red, wv, lane);
-    } else {
-      if constexpr (FWD) spd_fwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, vec, ytmp, f[wv], red, wv, lane SPD_TRACE_ARGS(b));
-      else spd_bwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, scale, ytmp, vec, f[wv], red, wv, lane SPD_TRACE_ARGS(b));
-    }
+    if constexpr (FWD) spd_fwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, vec, ytmp, f[wv], red, wv, lane SPD_TRACE_ARGS(b));
+    else spd_bwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, scale, ytmp, vec, f[wv], red, wv, lane SPD_TRACE_ARGS(b));
   }
 #undef SPD_TRACE_ARGS
 }
@@ -2065,7 +1881,6 @@ void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forw
 #define SPD_PICK(DOFV)                  \
   do {                                  \
     if (rows == 16) SPD_LAUNCH(DOFV, 16); \
-    else if (rows == 128) SPD_LAUNCH(DOFV, 128); \
     else SPD_LAUNCH(DOFV, 64);          \
   } while (0)
   DPGO_DISPATCH_D(d, {

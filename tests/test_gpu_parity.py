@@ -620,7 +620,10 @@ def test_dynamic_rescale_matches_oracle(fixtures_dir, name, nn, loss, acc, iters
     assert rescaled > 0                                   # the surrogate was rescaled along the way
     if name != "M3500":                                  # (M3500 has no outliers: every weight stays 1)
         assert min(nd.problem.scale.min() for nd in orc.nodes) < 1.0
-    np.testing.assert_allclose(gpu.X(), orc.gather(), atol=1e-6)
+    # poses: SURVEY 8d states 1e-5 (rad / scale).  The two sides estimate lambda_max of G_RR independently to 1e-4 (ARPACK
+    # with its process-wide random start on the oracle's side, Lanczos on the library's), so the preconditioner and with
+    # it the truncated CG differ in the last digits: 1.1e-6 on two rotation entries of M3500 after 25 iterations
+    np.testing.assert_allclose(gpu.X(), orc.gather(), atol=5e-6)
     Fo = orc.star.evaluate_f(orc.gather())
     assert abs(gpu.sum_fobj() - Fo) <= 1e-6 * abs(Fo)
 
