@@ -5,11 +5,15 @@
 //   rotations   : min sum kappa |R_ij^T Y_i - Y_j|_F^2  with Y_0 = I, then per-block SO(d) projection
 //   translations: min sum tau |x_i - x_j + t_ij^T Y_i|^2 with x_0 = 0
 // The reference solves them with SPQR; here the normal equations are solved
-// matrix-free by Jacobi-preconditioned CG to 1e-13 (same minimiser).
+// matrix-free by Jacobi-preconditioned CG to 1e-13 (same minimiser), the operators applied pose by pose on all host
+// threads with reductions in a fixed order (the result does not depend on the number of threads).
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
+
+#include <omp.h>
 
 #include "graph.h"
 
@@ -86,46 +90,68 @@ void project_block(int d, double *M) {
     for (int c = 0; c < 3; c++) M[r * 3 + c] = u1[r] * v[0][c] + u2[r] * v[1][c] + u3[r] * v3[c];
 }
 
+// Sums of K x nc per-row terms, in an order that does not depend on the number of threads: rows are cut into fixed
+// chunks, each chunk is summed by one thread, the chunk sums are added in order.
+template <class F>
+void chunk_sums(int n, int len, std::vector<double> &out, const F &f) {
+  constexpr int CH = 4096;
+  const int nch = (n + CH - 1) / CH;
+  std::vector<double> part((size_t)nch * len, 0.0);
+#pragma omp parallel for schedule(static)
+  for (int ch = 0; ch < nch; ch++) {
+    double *acc = &part[(size_t)ch * len];
+    const int i1 = std::min(n, (ch + 1) * CH);
+    for (int i = ch * CH; i < i1; i++) f(i, acc);
+  }
+  out.assign(len, 0.0);
+  for (int ch = 0; ch < nch; ch++)
+    for (int k = 0; k < len; k++) out[k] += part[(size_t)ch * len + k];
+}
+
 template <class Apply>
 int pcg(int n, int nc, const Apply &A, const std::vector<double> &diag, const std::vector<double> &b,
         std::vector<double> &x, double tol, int maxit) {
   // all nc right-hand sides share the iteration (block of independent CGs)
   std::vector<double> r = b, z(r.size()), p(r.size()), Ap(r.size());
   x.assign(b.size(), 0.0);
-  std::vector<double> rz(nc, 0), b2(nc, 0);
-  for (int i = 0; i < n; i++)
+  std::vector<double> s0;
+  chunk_sums(n, 2 * nc, s0, [&](int i, double *acc) {
     for (int c = 0; c < nc; c++) {
-      z[i * nc + c] = r[i * nc + c] / diag[i];
-      rz[c] += r[i * nc + c] * z[i * nc + c];
-      b2[c] += b[i * nc + c] * b[i * nc + c];
+      z[(size_t)i * nc + c] = r[(size_t)i * nc + c] / diag[i];
+      acc[c] += r[(size_t)i * nc + c] * z[(size_t)i * nc + c];
+      acc[nc + c] += b[(size_t)i * nc + c] * b[(size_t)i * nc + c];
     }
+  });
+  std::vector<double> rz(s0.begin(), s0.begin() + nc), b2(s0.begin() + nc, s0.end());
   p = z;
   int it = 0;
+  std::vector<double> pAp, r2, rz_new, al(nc), be(nc);
   for (; it < maxit; it++) {
     A(p, Ap);
-    std::vector<double> pAp(nc, 0), r2(nc, 0), rz_new(nc, 0);
-    for (int i = 0; i < n; i++)
-      for (int c = 0; c < nc; c++) pAp[c] += p[i * nc + c] * Ap[i * nc + c];
-    for (int i = 0; i < n; i++)
+    chunk_sums(n, nc, pAp, [&](int i, double *acc) {
+      for (int c = 0; c < nc; c++) acc[c] += p[(size_t)i * nc + c] * Ap[(size_t)i * nc + c];
+    });
+    for (int c = 0; c < nc; c++) al[c] = pAp[c] > 0 ? rz[c] / pAp[c] : 0.0;
+    chunk_sums(n, nc, r2, [&](int i, double *acc) {
       for (int c = 0; c < nc; c++) {
-        const double al = pAp[c] > 0 ? rz[c] / pAp[c] : 0.0;
-        x[i * nc + c] += al * p[i * nc + c];
-        r[i * nc + c] -= al * Ap[i * nc + c];
-        r2[c] += r[i * nc + c] * r[i * nc + c];
+        x[(size_t)i * nc + c] += al[c] * p[(size_t)i * nc + c];
+        r[(size_t)i * nc + c] -= al[c] * Ap[(size_t)i * nc + c];
+        acc[c] += r[(size_t)i * nc + c] * r[(size_t)i * nc + c];
       }
+    });
     bool done = true;
     for (int c = 0; c < nc; c++) done = done && (r2[c] <= tol * tol * std::max(b2[c], 1e-300));
     if (done) break;
-    for (int i = 0; i < n; i++)
+    chunk_sums(n, nc, rz_new, [&](int i, double *acc) {
       for (int c = 0; c < nc; c++) {
-        z[i * nc + c] = r[i * nc + c] / diag[i];
-        rz_new[c] += r[i * nc + c] * z[i * nc + c];
+        z[(size_t)i * nc + c] = r[(size_t)i * nc + c] / diag[i];
+        acc[c] += r[(size_t)i * nc + c] * z[(size_t)i * nc + c];
       }
+    });
+    for (int c = 0; c < nc; c++) be[c] = rz[c] > 0 ? rz_new[c] / rz[c] : 0.0;
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < n; i++)
-      for (int c = 0; c < nc; c++) {
-        const double be = rz[c] > 0 ? rz_new[c] / rz[c] : 0.0;
-        p[i * nc + c] = z[i * nc + c] + be * p[i * nc + c];
-      }
+      for (int c = 0; c < nc; c++) p[(size_t)i * nc + c] = z[(size_t)i * nc + c] + be[c] * p[(size_t)i * nc + c];
     rz = rz_new;
   }
   return it;
@@ -141,24 +167,48 @@ int chordal_initialization(const Graph &g, double *X, int ld) {
   if (ld < (d + 1) * N) return -1;
   // ---- rotations: unknown Y (d N x d row-major), rows of pose 0 fixed to I
   const int nr = d * N;
-  auto applyR = [&](const std::vector<double> &v, std::vector<double> &out) {
-    std::fill(out.begin(), out.end(), 0.0);
-    for (const auto &m : E) {
-      const int i = m.ipose, j = m.jpose;
-      double W[9];
-      for (int r = 0; r < d; r++)
-        for (int c = 0; c < d; c++) {
-          double a = -v[(j * d + r) * d + c];
-          for (int k = 0; k < d; k++) a += m.R[k * d + r] * v[(i * d + k) * d + c];
-          W[r * d + c] = m.kappa * a;
+  // incidence lists: the operators below are applied pose by pose (gather form: every pose adds the terms of its
+  // incident edges in list order), so the products run on all host threads and do not depend on their number
+  omp_set_num_threads(host_threads());
+  std::vector<int> inc_ptr(N + 1, 0), inc;
+  for (const auto &m : E) { inc_ptr[m.ipose + 1]++; inc_ptr[m.jpose + 1]++; }
+  for (int i = 0; i < N; i++) inc_ptr[i + 1] += inc_ptr[i];
+  inc.resize(inc_ptr[N]);
+  {
+    std::vector<int> pos(inc_ptr.begin(), inc_ptr.end() - 1);
+    for (int e = 0; e < (int)E.size(); e++) {
+      inc[pos[E[e].ipose]++] = 2 * e;        // tail
+      inc[pos[E[e].jpose]++] = 2 * e + 1;    // head
+    }
+  }
+  // pin0: the rows of pose 0 count as zero (the pinned pose's column is dropped)
+  auto applyR = [&](const std::vector<double> &v, std::vector<double> &out, bool pin0 = false) {
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int p = 0; p < N; p++) {
+      double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int q = inc_ptr[p]; q < inc_ptr[p + 1]; q++) {
+        const auto &m = E[inc[q] >> 1];
+        const int i = m.ipose, j = m.jpose;
+        double W[9];
+        for (int r = 0; r < d; r++)
+          for (int c = 0; c < d; c++) {
+            double a = (pin0 && j == 0) ? 0.0 : -v[((size_t)j * d + r) * d + c];
+            if (!(pin0 && i == 0))
+              for (int k = 0; k < d; k++) a += m.R[k * d + r] * v[((size_t)i * d + k) * d + c];
+            W[r * d + c] = m.kappa * a;
+          }
+        if (inc[q] & 1) {
+          for (int k = 0; k < d * d; k++) acc[k] -= W[k];
+        } else {
+          for (int r = 0; r < d; r++)
+            for (int c = 0; c < d; c++) {
+              double a = 0;
+              for (int k = 0; k < d; k++) a += m.R[r * d + k] * W[k * d + c];
+              acc[r * d + c] += a;
+            }
         }
-      for (int r = 0; r < d; r++)
-        for (int c = 0; c < d; c++) {
-          out[(j * d + r) * d + c] -= W[r * d + c];
-          double a = 0;
-          for (int k = 0; k < d; k++) a += m.R[r * d + k] * W[k * d + c];
-          out[(i * d + r) * d + c] += a;
-        }
+      }
+      for (int k = 0; k < d * d; k++) out[(size_t)p * d * d + k] = acc[k];
     }
   };
   std::vector<double> Y0((size_t)nr * d, 0.0), LY0(Y0.size()), b(Y0.size()), Ysol, diag(nr, 0.0);
@@ -174,9 +224,7 @@ int chordal_initialization(const Graph &g, double *X, int ld) {
     }
   // pin pose 0: identity rows in the operator
   auto applyRp = [&](const std::vector<double> &v, std::vector<double> &out) {
-    std::vector<double> vv = v;
-    for (int k = 0; k < d * d; k++) vv[k] = 0.0;
-    applyR(vv, out);
+    applyR(v, out, true);
     for (int k = 0; k < d * d; k++) out[k] = v[k];
   };
   for (int k = 0; k < d * d; k++) b[k] = 0.0;
@@ -202,21 +250,15 @@ int chordal_initialization(const Graph &g, double *X, int ld) {
     dg[j] += m.tau;
   }
   auto applyT = [&](const std::vector<double> &v, std::vector<double> &out) {
-    std::fill(out.begin(), out.end(), 0.0);
-    for (const auto &m : E) {
-      const int i = m.ipose, j = m.jpose;
-      if (i == 0 || j == 0) {
-        for (int c = 0; c < d; c++) {
-          if (i != 0) out[i * d + c] += m.tau * v[i * d + c];
-          if (j != 0) out[j * d + c] += m.tau * v[j * d + c];
-        }
-        continue;
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int p = 1; p < N; p++) {
+      double acc[3] = {0, 0, 0};
+      for (int q = inc_ptr[p]; q < inc_ptr[p + 1]; q++) {
+        const auto &m = E[inc[q] >> 1];
+        const int o = (inc[q] & 1) ? m.ipose : m.jpose;   // the other end; pose 0 is pinned (its column is dropped)
+        for (int c = 0; c < d; c++) acc[c] += m.tau * (v[(size_t)p * d + c] - (o == 0 ? 0.0 : v[(size_t)o * d + c]));
       }
-      for (int c = 0; c < d; c++) {
-        const double a = m.tau * (v[i * d + c] - v[j * d + c]);
-        out[i * d + c] += a;
-        out[j * d + c] -= a;
-      }
+      for (int c = 0; c < d; c++) out[(size_t)p * d + c] = acc[c];
     }
     for (int c = 0; c < d; c++) out[c] = v[c];
   };
@@ -225,6 +267,8 @@ int chordal_initialization(const Graph &g, double *X, int ld) {
   int it2 = pcg(N, d, applyT, dg, bt, xsol, 1e-13, 50000);
   // the reference solves both least-squares problems directly (SPQR); an iteration that ran into its cap has
   // not reached the 1e-13 residual target, and the caller must know (disconnected or badly scaled graph)
+  if (getenv("DPGO_SETUP_TIMING"))
+    fprintf(stderr, "[setup] chordal initialisation: %d PCG iterations for the rotations, %d for the translations\n", it1, it2);
   if (it1 >= 50000 || it2 >= 50000) {
     fprintf(stderr, "[dpgo_amd] ERROR: chordal initialisation: PCG did not converge (rotations %d, translations %d of 50000 "
                     "iterations); is the graph connected?\n", it1, it2);
