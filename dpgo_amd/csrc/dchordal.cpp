@@ -296,7 +296,7 @@ int Group::chordal_setup(int kind, double xi, const std::vector<std::vector<doub
     }
   }
   A.n = (int)A.ptr.size() - 1;
-  if (spd_factor(A, ch_->L.F, 64, 0) != 0) {
+  if (spd_factor(A, ch_->L.F, 64, 0, dof, true) != 0) {   // (ordering on the pose graph, factor kept on the device)
     fprintf(stderr, "[dpgo_amd] ERROR: distributed chordal initialisation: the stage matrix is not positive definite "
                     "(a node without inter-node edges, or a node whose poses are not connected?).\n");
     return -1;
@@ -405,6 +405,7 @@ int Group::chordal_get(std::vector<std::vector<double>> &Xak) {
 int Group::dist_chordal_initialization(const DChordalOptions &o, const double *Xlocal, int ldl, double *X, int ld,
                                        std::vector<double> *objectives) {
   const int N = num_local(), d = d_, NP = num_poses_global_;
+  SetupClock clk;   // (DPGO_SETUP_TIMING=1)
   if (N != num_nodes_total_) {
     fprintf(stderr, "[dpgo_amd] ERROR: the distributed chordal initialisation needs every node of the graph in the group.\n");
     return -1;
@@ -472,6 +473,7 @@ int Group::dist_chordal_initialization(const DChordalOptions &o, const double *X
     Xlocal = Xl.data();
     ldl = ldx;
   }
+  clk.lap("dist-init: stage 0 (local solutions)");
   // xs[a]: (n0 + n1) poses, each [t (d) | Y (d x d)] -- own poses in the node's gauge, neighbours filled by communicate
   std::vector<std::vector<double>> xt(N), xY(N);
   auto fill_neighbours = [&]() {   // DPGO::communicate (DPGO_utils.h:397-453)
@@ -561,6 +563,7 @@ int Group::dist_chordal_initialization(const DChordalOptions &o, const double *X
     rots_n[a].assign(rr[a].Xk.begin(), rr[a].Xk.begin() + d * d);
     project_to_SOd_host(d, rots_n[a].data());
   }
+  clk.lap("dist-init: stage 1 (reduced rotations, host)");
   // ---- stage 2: rotations on the device (:230-304)
   std::vector<std::vector<double>> rots(N);
   auto halo = [&](std::vector<std::vector<double>> &v, int bs) {   // DChordal::communicate (DChordal_utils.h:196-240)
@@ -592,36 +595,44 @@ int Group::dist_chordal_initialization(const DChordalOptions &o, const double *X
     rots_n[a].assign(rots[a].begin(), rots[a].begin() + d * d);
     for (int k = 0; k < n0; k++) mul_nt(d, &rots[a][(size_t)k * d * d], rots_n[a].data(), &xY[a][(size_t)k * d * d]);   // back to the node's gauge
   }
+  clk.lap("dist-init: stage 2 (rotations, device)");
   // ---- stage 3: reduced translations (:311-359)
-  for (int a = 0; a < N; a++) {
-    // recover_translations (DChordalReducedProblem.h:251-261): t = -L^-1 (P R), L = intra tau-Laplacian + 100 at (0,0)
-    const DataInfo &info = info_[a];
-    const int n0 = info.n[0];
-    std::vector<std::map<int, double>> rows(n0);
-    std::vector<double> rhs((size_t)n0 * d, 0.0);
-    for (const auto &m : info.intra) {
-      const int i = info.tail(m), j = info.head(m);
-      rows[i][i] += m.tau; rows[j][j] += m.tau; rows[i][j] -= m.tau; rows[j][i] -= m.tau;
-      for (int c = 0; c < d; c++) {
-        double acc = 0;
-        for (int k = 0; k < d; k++) acc += m.t[k] * xY[a][(size_t)i * d * d + k * d + c];
-        rhs[(size_t)i * d + c] += m.tau * acc;
-        rhs[(size_t)j * d + c] -= m.tau * acc;
+  {
+    // recover_translations (DChordalReducedProblem.h:251-261) of every node: t = -L^-1 (P R), L = intra tau-Laplacian + 100
+    // at (0,0).  The nodes' systems are the diagonal blocks of one matrix: one ordering (components in parallel), one
+    // numeric factorisation, one solve.
+    CsrMatrix Lm;
+    Lm.ptr.push_back(0);
+    std::vector<double> rhs((size_t)P0_ * d, 0.0);
+    for (int a = 0; a < N; a++) {
+      const DataInfo &info = info_[a];
+      const int n0 = info.n[0], off = own_off_[a];
+      std::vector<std::map<int, double>> rows(n0);
+      for (const auto &m : info.intra) {
+        const int i = info.tail(m), j = info.head(m);
+        rows[i][i] += m.tau; rows[j][j] += m.tau; rows[i][j] -= m.tau; rows[j][i] -= m.tau;
+        for (int c = 0; c < d; c++) {
+          double acc = 0;
+          for (int k = 0; k < d; k++) acc += m.t[k] * xY[a][(size_t)i * d * d + k * d + c];
+          rhs[(size_t)(off + i) * d + c] += m.tau * acc;
+          rhs[(size_t)(off + j) * d + c] -= m.tau * acc;
+        }
+      }
+      rows[0][0] += 100.0;
+      for (int r = 0; r < n0; r++) {
+        for (const auto &cv : rows[r]) { Lm.col.push_back(off + cv.first); Lm.val.push_back(cv.second); }
+        Lm.ptr.push_back((int)Lm.col.size());
       }
     }
-    rows[0][0] += 100.0;
-    CsrMatrix Lm;
-    Lm.n = n0;
-    Lm.ptr.push_back(0);
-    for (int r = 0; r < n0; r++) {
-      for (const auto &cv : rows[r]) { Lm.col.push_back(cv.first); Lm.val.push_back(cv.second); }
-      Lm.ptr.push_back((int)Lm.col.size());
-    }
+    Lm.n = (int)Lm.ptr.size() - 1;
     SpdFactor F;
     if (spd_factor(Lm, F, 64, 1) != 0) return -1;
     spd_solve_host(F, rhs.data(), d);
-    for (int k = 0; k < n0; k++)
-      for (int c = 0; c < d; c++) xt[a][(size_t)k * d + c] = -(rhs[(size_t)k * d + c] - rhs[c]);
+    for (int a = 0; a < N; a++) {
+      const int n0 = info_[a].n[0], off = own_off_[a];
+      for (int k = 0; k < n0; k++)
+        for (int c = 0; c < d; c++) xt[a][(size_t)k * d + c] = -(rhs[(size_t)(off + k) * d + c] - rhs[(size_t)off * d + c]);
+    }
   }
   fill_neighbours();
   std::vector<std::vector<double>> nRs(N);
@@ -680,6 +691,7 @@ int Group::dist_chordal_initialization(const DChordalOptions &o, const double *X
     for (int a = 1; a < N; a++) { rt[a].update(); rt[a].iterate(); }
     n_communicate(rt);
   }
+  clk.lap("dist-init: stage 3 (reduced translations, host)");
   // ---- stage 4: translations on the device (:365-407)
   std::vector<std::vector<double>> ts(N);
   for (int a = 0; a < N; a++) {

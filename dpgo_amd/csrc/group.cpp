@@ -62,18 +62,6 @@ static int env_int(const char *name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-// DPGO_SETUP_TIMING=1: wall time of the set-up phases on stderr
-struct SetupClock {
-  const bool on = getenv("DPGO_SETUP_TIMING") != nullptr;
-  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-  void lap(const char *what) {
-    if (!on) return;
-    const auto n = std::chrono::steady_clock::now();
-    fprintf(stderr, "[setup] %-44s %8.3f s\n", what, std::chrono::duration<double>(n - t).count());
-    t = n;
-  }
-};
-
 // The factor stores explicit inverses of the pivot blocks: a pivot range beyond 1e13 (a badly scaled dataset: information
 // matrices that differ by many orders of magnitude, or a regulariser far below the weights) leaves few correct digits.
 static void warn_conditioning(const char *what, const SpdFactor &F) {

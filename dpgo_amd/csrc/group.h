@@ -10,6 +10,9 @@
 // adaptive-restart counters) stays on the host exactly as in the reference; a
 // per-node device mask lets nodes that take different branches share launches.
 #pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -97,6 +100,18 @@ struct DevBuf {
   void alloc(size_t count, bool zero = true);
   void upload(const std::vector<T> &h);
   void download(std::vector<T> &h) const;
+};
+
+// DPGO_SETUP_TIMING=1: wall time of the set-up phases on stderr
+struct SetupClock {
+  const bool on = getenv("DPGO_SETUP_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char *what) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[setup] %-44s %8.3f s\n", what, std::chrono::duration<double>(n - t).count());
+    t = n;
+  }
 };
 
 struct SpdSolverDev {
