@@ -252,7 +252,7 @@ def main():
                         frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_source, avg_launch_us=1e3 * ms / cnt,
                         algorithmic_bytes_per_launch=by / cnt, launches_per_step=cnt / args.prof_steps)
 
-    # ---- CPU baseline: the oracle (numpy/scipy restatement) on a bounded sample, rank 0, N = 1 only
+    # ---- CPU baseline: the C++ restatement of the path (tools/cpu_baseline) on a bounded sample, rank 0, N = 1 only
     cpu = None
     if world == 1 and not args.no_cpu and args.cpu_steps > 0:
         cpu = cpu_baseline(g, args.nodes, loss, X0, args.cpu_steps)

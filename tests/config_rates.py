@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Outer iterations per second of the BASELINE.json parity configurations: the HIP path on one GPU and the oracle on
 one host core of the same box (same initial point, same number of iterations).  Small graphs are launch-latency
-bound on a GPU; the table says by how much.  Usage (GPU box): python tools/config_rates.py > gpurun_out/config_rates.json"""
+bound on a GPU; the table says by how much.  Usage (GPU box): python tests/config_rates.py > gpurun_out/config_rates.json"""
 import json
 import os
 import sys

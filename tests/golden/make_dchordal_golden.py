@@ -9,7 +9,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import g2o as og                      # noqa: E402
 from oracle.dchordal import dist_chordal_initialization   # noqa: E402

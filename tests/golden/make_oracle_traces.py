@@ -5,13 +5,13 @@ driver loop (oracle/star.py DistPGO, chordal initialisation) on the BASELINE.jso
 The reference itself cannot be built here, so these traces do NOT pin the oracle
 against the reference; they freeze the oracle's behaviour (a change in oracle/ that moves a trace is
 caught on CPU) and give the GPU tests fixed numbers to hit at the full iteration counts.
-Usage: python tools/make_oracle_traces.py   (a few minutes of CPU)."""
+Usage: python tests/golden/make_oracle_traces.py   (a few minutes of CPU)."""
 import json
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 from oracle import g2o as og                                   # noqa: E402
@@ -32,7 +32,7 @@ CASES = [
 
 
 def main():
-    out = {"generator": "tools/make_oracle_traces.py", "cases": {}}
+    out = {"generator": "tests/golden/make_oracle_traces.py", "cases": {}}
     for name, ds, nn, loss, acc, iters in CASES:
         path = os.path.join(ROOT, "fixtures", "g2o", ds + ".g2o")
         t0 = time.time()

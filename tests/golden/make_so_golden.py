@@ -8,7 +8,7 @@ import subprocess
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 EXE = os.path.join(ROOT, "oracle", "_ref", "so_ref")
 subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle", "ref_so3")])
 

@@ -1,4 +1,4 @@
-"""Committed oracle traces (tests/golden/oracle_traces.json, made by tools/make_oracle_traces.py): per-iteration
+"""Committed oracle traces (tests/golden/oracle_traces.json, made by tests/golden/make_oracle_traces.py): per-iteration
 (2F, 2|grad F|) of the dist_pgo driver loop on the BASELINE.json parity configurations.
 
 CPU: the oracle still reproduces the cheap traces (freezes oracle/ -- the traces are the oracle's own output,

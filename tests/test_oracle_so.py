@@ -3,7 +3,7 @@
 tests/golden/so_ref.npz holds seeded inputs and the outputs of DPGO::internal::project_to_SO3 / project_to_SO2
 (C++/DPGO/src/internal/project_to_SOd.cpp:7-33, 97-196: McAdams-style Jacobi SVD, 8 sweeps), produced by
 oracle/_ref/so_ref (oracle/ref_so3/Makefile builds it from the reference's sources where they lie;
-tools/make_so_golden.py wrote the file).  This pins row a9 of the path: the oracle's nearest-rotation map
+tests/golden/make_so_golden.py wrote the file).  This pins row a9 of the path: the oracle's nearest-rotation map
 IS the reference's, to the accuracy the reference's fixed sweep count reaches."""
 import os
 

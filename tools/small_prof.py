@@ -1,13 +1,10 @@
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import dpgo_amd
-from oracle import g2o as og
-from oracle.star import chordal_initialization
 for ds, nn in (("city10000", 8), ("torus3D", 8), ("sphere2500", 1)):
     path = os.path.join("fixtures", "g2o", ds + ".g2o")
-    num_poses, mm = og.read_g2o_file(path)
-    X0 = chordal_initialization(num_poses, mm)
     G = dpgo_amd.read_g2o(path, nn)
+    X0 = G.chordal_initialization()
     gpu = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(0, True), X0=X0)
     for _ in range(5): gpu.step()
     dpgo_amd.prof_enable(True)
