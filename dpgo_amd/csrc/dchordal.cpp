@@ -404,6 +404,7 @@ int Group::chordal_get(std::vector<std::vector<double>> &Xak) {
 // ---------------------------------------------------------------------------------------------------------
 int Group::dist_chordal_initialization(const DChordalOptions &o, const double *Xlocal, int ldl, double *X, int ld,
                                        std::vector<double> *objectives) {
+  finish_update();
   const int N = num_local(), d = d_, NP = num_poses_global_;
   SetupClock clk;   // (DPGO_SETUP_TIMING=1)
   if (N != num_nodes_total_) {

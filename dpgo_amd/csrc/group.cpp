@@ -678,7 +678,25 @@ void Group::set_mask(const std::vector<int> &locals) {
   cur_mask_ = NodeMask{m, nullptr};
 }
 
+unsigned long long Group::fetch_async(int nslots, bool all_rows) {
+  finish_update();
+  nslots = std::max(nslots, deferred_slots_);
+  deferred_slots_ = 0;
+  launch_reduce(st_, T_, num_local(), all_rows, nslots, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, ++fetch_seq_);
+  return fetch_seq_;
+}
+
+// The deferred end of update(): wait for its reduction, then the scalar logic that needs the numbers.
+void Group::finish_update() {
+  if (!pending_update_) return;
+  std::function<void()> f;
+  f.swap(pending_update_);
+  wait_flag(pending_seq_);
+  f();
+}
+
 void Group::fetch(int nslots, bool all_rows) {
+  finish_update();   // (its scalars sit in the pinned slots the next reduction overwrites)
   nslots = std::max(nslots, deferred_slots_);
   deferred_slots_ = 0;
   launch_reduce(st_, T_, num_local(), all_rows, nslots, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, ++fetch_seq_);
@@ -852,6 +870,7 @@ static void from_records(int d, int n, const double *rec, double *X, int ld, int
 }
 
 int Group::initialize(int a, const double *X, int ld) {
+  finish_update();
   if (a < 0 || a >= num_local()) return -1;
   const int n0 = info_[a].n[0], n1 = info_[a].n[1];
   if (ld < (d_ + 1) * (n0 + n1)) {
@@ -898,6 +917,7 @@ void Group::node_rows_of_global(int a, const double *X, int ld, std::vector<doub
 }
 
 int Group::initialize_global(const double *X, int ld) {
+  finish_update();
   const int N = num_poses_global_;
   if (ld < (d_ + 1) * N) return -1;
   std::vector<double> Z;
@@ -914,6 +934,7 @@ int Group::initialize_global(const double *X, int ld) {
 // F and |grad F|^2 are the sums over the nodes of this group, and over all groups when collectives are set.
 // grad (optional): global (d+1)N x d, only the rows of this group's own poses are written.
 int Group::evaluate_global(const double *X, int ld, double *F, double *grad_sqnorm, double *grad, int ldg) {
+  finish_update();
   const int N = num_poses_global_;
   if (ld < (d_ + 1) * N || (grad && ldg < (d_ + 1) * N)) {
     fprintf(stderr, "[dpgo_amd] ERROR: evaluate: inconsistent size of X.\n");
@@ -970,6 +991,7 @@ int Group::evaluate_global(const double *X, int ld, double *F, double *grad_sqno
 // DPGOHash::set_options (DPGOHash.h:93-96).  The reference swaps the optimizer's options and keeps the problem it
 // built at construction; here the fields baked into the problem (operators, factorizations) must not change.
 int Group::set_options(const Options &o) {
+  finish_update();
   if (o.loss != opt_.loss || o.loss_reg != opt_.loss_reg || o.regularizer != opt_.regularizer || o.rescale != opt_.rescale ||
       o.preconditioner != opt_.preconditioner ||
       o.reg_Cholesky_precon_max_condition_number != opt_.reg_Cholesky_precon_max_condition_number) {
@@ -1047,6 +1069,7 @@ int Group::num_send(int a, int beta) const {
 }
 
 int Group::receive(int a, int beta, const double *msg, int ld) {
+  finish_update();
   if (a < 0 || a >= num_local()) return -1;
   auto it = info_[a].recv.find(beta);
   if (it == info_[a].recv.end()) {
@@ -1143,13 +1166,32 @@ int Group::set_collectives(double *send_dev, double *gathered_dev, AllGatherFn a
 // ---------------------------------------------------------------------------
 // DPGOHash::update  (DPGOHash.cpp:84-228)
 // ---------------------------------------------------------------------------
+// The part of the scalar logic that does not need the numbers update() reads back: the Nesterov sequence s[iter],
+// s[iter+1] and gamma (DPGOHash.cpp:150-160, 206-216).  The next iterate() may start with it.
+void Group::host_update_pre(int a) {
+  NodeResults &r = res_[a];
+  const int it = r.iters;
+  r.pre_repeat = (r.hist_iter == it);
+  r.pre_done = true;
+  if (opt_.scheme == 1) {
+    if (it == 0) r.s0 = 1.0;
+    else if (!r.pre_repeat) r.s0 = r.s1;
+    r.s1 = 0.5 + 0.5 * std::sqrt(4.0 * r.s0 * r.s0 + 1.0);
+    r.gamma = (r.s0 - 1) / r.s1;
+  } else {
+    r.gamma = 0;
+  }
+}
+
 void Group::host_update_logic(int a, double fobj, double f, double gradFnorm) {
   NodeResults &r = res_[a];
   const Options &o = opt_;
   const int it = r.iters;
   // update() may run again at the same iteration (update -> receive() -> update): X[iter-1], fobj[iter-1] and
   // s[iter] are those of the first call, everything else is re-done as the reference does (DPGOHash.cpp:99-225)
-  const bool repeat = (r.hist_iter == it);
+  const bool pre = r.pre_done;   // the Nesterov sequence was already advanced by host_update_pre
+  const bool repeat = pre ? r.pre_repeat : (r.hist_iter == it);
+  r.pre_done = false;
   r.hist_iter = it;
   if (!repeat) r.fobj_prev = r.fobj;
   r.fobj = fobj;
@@ -1172,14 +1214,16 @@ void Group::host_update_logic(int a, double fobj, double f, double gradFnorm) {
   }
   if (o.scheme == 1) {
     if (it == 0) {
-      r.s0 = 1.0;
+      if (!pre) r.s0 = 1.0;
       if (!repeat) r.oscillations.assign(1, 1);
       else r.oscillations.push_back(1);   // the reference pushes again (DPGOHash.cpp:168-171)
-    } else if (!repeat) {
+    } else if (!repeat && !pre) {
       r.s0 = r.s1;
     }
-    r.s1 = 0.5 + 0.5 * std::sqrt(4.0 * r.s0 * r.s0 + 1.0);
-    r.gamma = (r.s0 - 1) / r.s1;
+    if (!pre) {
+      r.s1 = 0.5 + 0.5 * std::sqrt(4.0 * r.s0 * r.s0 + 1.0);
+      r.gamma = (r.s0 - 1) / r.s1;
+    }
     if (fobj <= r.Fk[1]) r.soft_restart_hits[0] = r.soft_restart_hits[0] > 2 ? r.soft_restart_hits[0] - 2 : 0;
     else r.soft_restart_hits[0]++;
     if (it > 0) {
@@ -1195,7 +1239,7 @@ void Group::host_update_logic(int a, double fobj, double f, double gradFnorm) {
     r.Fk[1] = std::max(fobj, r.Fk[1] * (1 - o.eta[1]) + fobj * o.eta[1]);
   } else {
     r.Fk[0] = r.Fk[1] = fobj;
-    r.gamma = 0;
+    if (!pre) r.gamma = 0;
   }
   r.updated = 1;
 }
@@ -1240,6 +1284,7 @@ std::vector<int> Group::maybe_rescale(const std::vector<int> &set) {
 }
 
 int Group::update(const std::vector<int> &locals_in) {
+  finish_update();
   std::vector<int> locals;
   for (int a : locals_in)
     if (!res_[a].updated) locals.push_back(a);
@@ -1269,6 +1314,23 @@ int Group::update(const std::vector<int> &locals_in) {
   // with G, a third of the surrogate build -- then the stream waits for the exchange and takes the neighbour rows.
   std::vector<int> first, later;
   for (int a : locals) ((res_[a].iters == 0 || star_) ? first : later).push_back(a);
+  // the closing read-back is deferred to the next reader (finish_update) where there is exactly one of them and nothing
+  // depends on it at once: not for AMM-PGO* (the master decides on the sums right away) nor with Dynamic rescale
+  static const bool defer_enabled = env_int("DPGO_DEFER_UPDATE", 1) != 0;
+  const bool can_defer = defer_enabled && !star_ && !dynamic() && (first.empty() != later.empty());
+  auto end_with = [&](int nslots, const std::vector<int> &set, std::function<void()> logic) {
+    if (can_defer) {
+      pending_seq_ = fetch_async(nslots, true);
+      for (int a : set) {
+        host_update_pre(a);
+        res_[a].updated = 1;
+      }
+      pending_update_ = std::move(logic);
+    } else {
+      fetch(nslots, true);
+      logic();
+    }
+  };
   copy_rows(Zc_.p, Xk_.p, false);
   if (trivial)   // T1 = G Xak and <Xak, 1/2 G Xak>   (half of evaluate_G, DPGOProblem.cpp:180-205)
     launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xak_.p, false, nullptr, T1_.p, Xak_.p, 0.5, nullptr, partials_.p, 5);
@@ -1284,11 +1346,12 @@ int Group::update(const std::vector<int> &locals_in) {
       launch_bsr(d_, st_, T_, true, cur_mask_, P0m_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 0);
       // fobj = G(Xak | g, f0) = f0 + <Xak, g> + <Xak, 1/2 G Xak>: slots 1 and 5; Dfobj = g + G Xak
       launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, partials_.p, 2, gc_.p, Dfc_.p);
-      fetch(6, true);
-      for (int a : first) {
-        const double f0 = scal(a, 0);
-        host_update_logic(a, f0 + (scal(a, 1) + scal(a, 5)), f0, std::sqrt(scal(a, 2)));
-      }
+      end_with(6, first, [this, first] {
+        for (int a : first) {
+          const double f0 = scal(a, 0);
+          host_update_logic(a, f0 + (scal(a, 1) + scal(a, 5)), f0, std::sqrt(scal(a, 2)));
+        }
+      });
     }
     if (!later.empty()) {
       set_mask(later);
@@ -1296,11 +1359,12 @@ int Group::update(const std::vector<int> &locals_in) {
       launch_bsr(d_, st_, T_, true, cur_mask_, Q_.dev, Tall_.p, false, nullptr, nullptr, Tall_.p, 0.5, nullptr, partials_.p, 0);
       launch_bsr(d_, st_, T_, true, cur_mask_, P_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 3);
       launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, partials_.p, 2, gc_.p, Dfc_.p);
-      fetch(4, true);
-      for (int a : later) {
-        const double fobj = res_[a].Gk + scal(a, 0);
-        host_update_logic(a, fobj, fobj + scal(a, 3), std::sqrt(scal(a, 2)));
-      }
+      end_with(4, later, [this, later] {
+        for (int a : later) {
+          const double fobj = res_[a].Gk + scal(a, 0);
+          host_update_logic(a, fobj, fobj + scal(a, 3), std::sqrt(scal(a, 2)));
+        }
+      });
     }
   } else {
     // evaluate_g_and_f0 / evaluate_g_and_f (DPGOProblem.cpp:222-267, 360-424); _rescale variants (:289-358, :426-514)
@@ -1328,22 +1392,24 @@ int Group::update(const std::vector<int> &locals_in) {
       }
       if (pass == 0) launch_bdiag_dot(d_, st_, T_, cur_mask_, Dd_.p, Zc_.p, 0.5, DfE_.p, -1.0, partials_.p, 3);
       launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, partials_.p, 4, gc_.p, Dfc_.p);   // Dfobj = G X + g
-      fetch(6, true);
-      for (int a : set) {
-        NodeResults &r = res_[a];
-        const double fobjE = 0.5 * (dynamic() ? rho[a] : scal(a, 0));
-        const double quad = scal(a, 2) + scal(a, 5);   // tr(X^T (g + 1/2 G X))
-        double fobj, f;
-        if (pass == 0) {
-          f = 0.5 * fobjE + scal(a, 3);
-          fobj = f + quad;
-        } else {
-          fobj = r.Gk - 0.5 * r.fobjE - 0.5 * (dynamic() ? gap[a] : scal(a, 1)) + 0.5 * fobjE;
-          f = fobj - quad;
+      const bool dyn = dynamic();
+      end_with(6, set, [this, set, pass, dyn, rho, gap] {
+        for (int a : set) {
+          NodeResults &r = res_[a];
+          const double fobjE = 0.5 * (dyn ? rho[a] : scal(a, 0));
+          const double quad = scal(a, 2) + scal(a, 5);   // tr(X^T (g + 1/2 G X))
+          double fobj, f;
+          if (pass == 0) {
+            f = 0.5 * fobjE + scal(a, 3);
+            fobj = f + quad;
+          } else {
+            fobj = r.Gk - 0.5 * r.fobjE - 0.5 * (dyn ? gap[a] : scal(a, 1)) + 0.5 * fobjE;
+            f = fobj - quad;
+          }
+          r.fobjE = fobjE;
+          host_update_logic(a, fobj, f, std::sqrt(scal(a, 4)));
         }
-        r.fobjE = fobjE;
-        host_update_logic(a, fobj, f, std::sqrt(scal(a, 4)));
-      }
+      });
     }
   }
   return 0;
@@ -1377,6 +1443,7 @@ int Group::mm(const std::vector<int> &locals) {
   launch_proximal(d_, st_, T_, cur_mask_, Zc_.p, Dfc_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, nullptr, nullptr, 0);
   recover_translations(Xakh_.p, gc_.p);
   copy_rows(Xak_.p, Xakh_.p, false);
+  finish_update();   // the scalars of the last update(): needed from here on (the GPU has the launches above to chew on)
   std::vector<int> plain;
   for (int a : locals) {
     NodeResults &r = res_[a];
@@ -1423,11 +1490,6 @@ int Group::amm(const std::vector<int> &locals) {
   const Options &o = opt_;
   set_mask(locals);
   prepare_extrapolated();
-  for (int a : locals) {
-    NodeResults &r = res_[a];
-    r.refined = (((r.gradFnorm * r.gradFnorm / r.fobj) > o.accepted_delta) || (r.num_oscillations >= o.max_oscillations)) &&
-                o.max_iterations > 0 && o.max_iterations_accepted > 0;   // :351-355
-  }
   // Xakh = proximal(Y, Df); Gkh = G(Xakh | g[k], f); |Xakh - Xak|^2    (:363-367)
   // (these three scalars sit in slots DS.. and are read back together with the first scalars of TNT)
   constexpr int DS = 2 * MAX_DOTS;
@@ -1436,6 +1498,12 @@ int Group::amm(const std::vector<int> &locals) {
   // G gives both (T1_ = G [0 ; R] + gx, slot DS + 1 = <Xakh, 1/2 G Xakh + gc>), then the solve   (:363-372)
   launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xakh_.p, 2, gx_.p, T1_.p, Xakh_.p, 0.5, gc_.p, partials_.p, DS + 1);
   solve_tt(T1_.p, Xak_.p, -1.0);
+  finish_update();   // the scalars of the last update(): needed from here on (the GPU has the launches above to chew on)
+  for (int a : locals) {
+    NodeResults &r = res_[a];
+    r.refined = (((r.gradFnorm * r.gradFnorm / r.fobj) > o.accepted_delta) || (r.num_oscillations >= o.max_oscillations)) &&
+                o.max_iterations > 0 && o.max_iterations_accepted > 0;   // :351-355
+  }
   std::vector<int> plain, ref;
   for (int a : locals) (res_[a].refined ? ref : plain).push_back(a);
   // Gk for nodes that are not refined; refined nodes run TNT first (:374-383)
@@ -1542,6 +1610,7 @@ namespace dpgo {
 
 // Single operators on reference-layout inputs, for the parity tests.
 int Group::debug_apply(int a, const char *op_c, const double *in, int ld_in, double *out, int ld_out) {
+  finish_update();
   if (a < 0 || a >= num_local()) return -1;
   const std::string op(op_c);
   const int n0 = info_[a].n[0], n1 = info_[a].n[1];
@@ -1638,6 +1707,7 @@ double Group::global_sqdist(const double *A_own, const double *B_own) {
 }
 
 int Group::star_initialize_global(const double *X, int ld) {
+  finish_update();
   if (num_local() != num_nodes_total_ && !coll_allgather_) {
     fprintf(stderr, "[dpgo_amd] ERROR: AMM-PGO* needs every node of the graph in one group, or collectives "
                     "(dpgo_group_set_collectives) that connect the groups.\n");
@@ -1652,6 +1722,7 @@ int Group::star_initialize_global(const double *X, int ld) {
 }
 
 int Group::star_update() {
+  finish_update();
   if (!star_) return -1;
   std::vector<int> all(num_local());
   for (int a = 0; a < num_local(); a++) all[a] = a;
@@ -1659,6 +1730,7 @@ int Group::star_update() {
 }
 
 int Group::star_iterate() {
+  finish_update();
   if (!star_) return -1;
   const Options &o = opt_;
   const int L = num_local();

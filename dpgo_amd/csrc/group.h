@@ -11,6 +11,7 @@
 // per-node device mask lets nodes that take different branches share launches.
 #pragma once
 #include <chrono>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <hip/hip_runtime.h>
@@ -66,6 +67,7 @@ struct Options {
 struct NodeResults {
   int updated = 1;
   int iters = 0;
+  bool pre_done = false, pre_repeat = false;   // host_update_pre ran for the update under way (and what `repeat` was)
   int hist_iter = -1;   // iteration whose X[iter-1], g[iter-1], fobj[iter-1], s[iter] are in place (update() may run twice per iteration)
   double gradFnorm = 0, fobjE = 0, Fk[2] = {0, 0}, Gk = 0, Gkh = 0;
   double Gk_alt = 0;   // run_tnt: the refined point's surrogate value under the caller's second linear term
@@ -140,7 +142,7 @@ class Group {
   int d() const { return d_; }
   int num_local() const { return (int)nodes_.size(); }
   const DataInfo &info(int local) const { return info_[local]; }
-  const NodeResults &results(int local) const { return res_[local]; }
+  const NodeResults &results(int local) { finish_update(); return res_[local]; }
   const Options &options() const { return opt_; }
   int node_id(int local) const { return nodes_[local]; }
 
@@ -312,6 +314,16 @@ class Group {
   void recover_translations(double *X, const double *g);  // X.t = -Gtt^-1 (g_t + G_tR X.R) for masked nodes
   void eval_G(const double *X, const double *g, int slot);
   void host_update_logic(int local, double fobj, double f, double gradFnorm);
+  // The read-back that ends update() is deferred where nothing has to be decided yet: update() enqueues the reduction,
+  // advances the Nesterov sequence (host_update_pre: s, gamma -- they do not depend on the numbers read back) and
+  // returns; the next iterate() queues its extrapolation, proximal step and translation solve and only then waits
+  // (finish_update), so the GPU does not idle while the host takes the scalars.  Every other reader of the node state
+  // or of the pinned scalars calls finish_update() first.
+  void host_update_pre(int local);
+  void finish_update();
+  unsigned long long fetch_async(int nslots, bool all_rows);
+  std::function<void()> pending_update_;
+  unsigned long long pending_seq_ = 0;
   int amm(const std::vector<int> &locals);
   int mm(const std::vector<int> &locals);
   // refine X in place (TNT on G(. | g)); sets Gk = G(X | g) and, with g_alt, Gk_alt = G(X | g_alt)

@@ -48,6 +48,7 @@ struct NodeTnt {
 }  // namespace
 
 void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, const double *g_alt, bool base_ready) {
+  finish_update();
   const Options &o = opt_;
   const int L = num_local();
   const bool jacobi = (o.preconditioner == 1) && jacobi_.n > 0;       // Preconditioner::Jacobi
