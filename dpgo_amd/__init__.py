@@ -48,6 +48,7 @@ class Options(C.Structure):
         ("reg_Cholesky_precon_max_condition_number", C.c_double),
         ("preconditioned_grad_norm_tol", C.c_double), ("max_tCG_iterations", C.c_int),
         ("STPCG_kappa", C.c_double), ("STPCG_theta", C.c_double), ("preconditioner", C.c_int),
+        ("verbose", C.c_int),
     ]
 
     def __init__(self, **kw):

@@ -56,6 +56,7 @@ static dpgo::Options to_cpp(const dpgo_options_t &o) {
   r.reg_Cholesky_precon_max_condition_number = o.reg_Cholesky_precon_max_condition_number;
   r.preconditioned_grad_norm_tol = o.preconditioned_grad_norm_tol; r.max_tCG_iterations = o.max_tCG_iterations;
   r.STPCG_kappa = o.STPCG_kappa; r.STPCG_theta = o.STPCG_theta; r.preconditioner = o.preconditioner;
+  r.verbose = o.verbose;
   return r;
 }
 
@@ -74,6 +75,7 @@ void dpgo_options_default(dpgo_options_t *o) {
   o->reg_Cholesky_precon_max_condition_number = d.reg_Cholesky_precon_max_condition_number;
   o->preconditioned_grad_norm_tol = d.preconditioned_grad_norm_tol; o->max_tCG_iterations = d.max_tCG_iterations;
   o->STPCG_kappa = d.STPCG_kappa; o->STPCG_theta = d.STPCG_theta; o->preconditioner = d.preconditioner;
+  o->verbose = d.verbose;
 }
 
 void dpgo_options_driver(dpgo_options_t *o, int loss, int accelerated) {
@@ -464,6 +466,7 @@ int dpgo_group_get_options(const dpgo_group_t *h, dpgo_options_t *o) {
   o->reg_Cholesky_precon_max_condition_number = d.reg_Cholesky_precon_max_condition_number;
   o->preconditioned_grad_norm_tol = d.preconditioned_grad_norm_tol; o->max_tCG_iterations = d.max_tCG_iterations;
   o->STPCG_kappa = d.STPCG_kappa; o->STPCG_theta = d.STPCG_theta; o->preconditioner = d.preconditioner;
+  o->verbose = d.verbose;
   return 0;
 }
 

@@ -60,6 +60,7 @@ struct Options {
   int max_tCG_iterations = 10000;
   double STPCG_kappa = 0.05;
   double STPCG_theta = 0.9;
+  int verbose = 0;         // DPGO_types.h:87: a summary line per node and TNT refinement on stdout
   int preconditioner = 3;  // Preconditioner (DPGO_types.h:35-40): 0 None, 1 Jacobi, 2 IncompleteCholesky, 3 RegularizedCholesky
 };
 

@@ -268,6 +268,13 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       norms(requad, false);
     }
   }
+  if (o.verbose) {
+    static const char *names[] = {"gradient", "preconditioned gradient", "relative decrease", "step size", "trust region", "iteration limit"};
+    for (int a : nodes)
+      printf("[dpgo_amd] node %d TNT: f = %.12e, |grad| = %.3e, %d iteration(s), %d accepted, %d CG step(s), Delta = %.3e, stop: %s\n",
+             nodes_[a], S[a].fx + 0.0, S[a].gnorm, S[a].iteration, S[a].accepted, S[a].inner_total, S[a].Delta, names[S[a].status]);
+    fflush(stdout);
+  }
   for (int a : nodes) {
     res_[a].Gk = S[a].fx;
     res_[a].Gk_alt = S[a].fx - lin[a] + lin_alt[a];   // f(X | g_alt): only the linear term depends on g

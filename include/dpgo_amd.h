@@ -25,7 +25,8 @@ extern "C" {
 #endif
 
 /* DPGO::Options -- C++/DPGO/include/DPGO/DPGO_types.h:78-201: same names, same defaults, enums as their integer
- * values.  Not carried: verbose, max_computation_time, user_function, log_iterates (no effect on the iterates).
+ * values.  verbose prints one summary line per truncated-Newton refinement.  Not carried: user_function, log_iterates
+ * (no effect on the iterates).
  * dpgo_group_create fails (-1) for what is not implemented: preconditioner IncompleteCholesky. */
 typedef struct dpgo_options {
   int scheme;                 /* 0 = Scheme::MM, 1 = Scheme::AMM */
@@ -53,6 +54,7 @@ typedef struct dpgo_options {
   double STPCG_theta;
   int preconditioner;         /* Preconditioner (DPGO_types.h:35-40): 0 None, 1 Jacobi, 2 IncompleteCholesky,
                                  3 RegularizedCholesky (default) */
+  int verbose;                /* DPGO_types.h:87: 0 (default) quiet; 1: a line per node and refinement on stdout */
 } dpgo_options_t;
 
 /* The scalar part of DPGOResult -- C++/DPGO/include/DPGO/DPGO_types.h:204-322. */

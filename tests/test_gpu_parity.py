@@ -775,3 +775,18 @@ def test_conditioning_warning(fixtures_dir, capfd):
     G2 = dpgo_amd.read_g2o(os.path.join(fixtures_dir, "sphere2500.g2o"), 1)   # one node: G_tt = Laplacian + 1e-11 I
     dpgo_amd.NodeGroup(G2, [0], dpgo_amd.Options.driver(LOSS_NONE, True))
     assert "WARNING" not in capfd.readouterr().err
+
+
+def test_verbose_option_prints_and_changes_nothing(fixtures_dir, capfd):
+    """Options::verbose (DPGO_types.h:87): one line per node and refinement, same iterates."""
+    G = dpgo_amd.read_g2o(os.path.join(fixtures_dir, "smallGrid3D.g2o"), 2)
+    outs = []
+    for verbose in (0, 1):
+        drv = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(LOSS_HUBER, True, verbose=verbose))
+        capfd.readouterr()
+        for _ in range(5):
+            assert drv.step() == 0
+        text = capfd.readouterr().out
+        assert ("TNT:" in text) == bool(verbose)
+        outs.append(drv.X().copy())
+    assert np.array_equal(outs[0], outs[1])
