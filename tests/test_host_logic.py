@@ -238,3 +238,19 @@ def test_c_abi_rejects_bad_input(fixtures_dir):
     assert o.rescale == dpgo_amd.RESCALE_DYNAMIC and o.max_rescale_count == 5      # DPGO_types.h:128-131
     assert o.preconditioner == dpgo_amd.PRECON_REG_CHOLESKY                        # DPGO_types.h:155
     assert dpgo_amd.Options.driver(LOSS_HUBER).rescale == dpgo_amd.RESCALE_STATIC  # dist_pgo.cpp:105
+
+
+def test_chordal_initialization_does_not_depend_on_the_thread_count(fixtures_dir, tmp_path):
+    """The host PCG applies its operators pose by pose and sums in fixed chunks (chordal.cpp): 1 thread and 4 threads
+    give bit-identical initial guesses (the thread count is read once per process: two subprocesses)."""
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import dpgo_amd; "
+            "G = dpgo_amd.read_g2o(%r, 2); np.save(sys.argv[1], G.chordal_initialization())"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(fixtures_dir, "torus3D.g2o")))
+    outs = []
+    for nt in ("1", "4"):
+        path = str(tmp_path / ("x%s.npy" % nt))
+        subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, DPGO_HOST_THREADS=nt))
+        outs.append(np.load(path))
+    assert np.array_equal(outs[0], outs[1])
