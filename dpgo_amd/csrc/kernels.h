@@ -149,8 +149,10 @@ void launch_dots(int d, hipStream_t st, const SegTable &T, NodeMask mask, int n,
                  const double *const *b, const int *parts, double *partials, int slot0);
 // one CG step (IterativeSolvers.h:340-390): s += C.a[node] p, hs += C.a[node] Hp, and r += C.b[node] Hp where C.b != 0
 void launch_cg_step(int d, hipStream_t st, const SegTable &T, NodeMask mask, const NodeCoefs &C, const double *p,
-                    const double *Hp, double *s, double *hs, double *r, const CgNode *cg = nullptr);   // cg: coefficients from the device state
-// start of a truncated CG (IterativeSolvers.h:230-260): s = 0, hs = 0, r = grad, v = pgrad, p = -pgrad
+                    const double *Hp, double *s, double *hs, double *r, const CgNode *cg = nullptr,   // cg: coefficients from the device state
+                    const double *r0 = nullptr);   // r0: first step of a run -- s = hs = 0 (not read), r = r0
+// start of a truncated CG (IterativeSolvers.h:230-260): s = 0, hs = 0, r = grad, v = pgrad, p = -pgrad; with s == nullptr
+// only p = -pgrad (the first launch_cg_step, given r0 = grad, supplies the rest)
 void launch_cg_init(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *grad, const double *pgrad,
                     double *s, double *hs, double *r, double *v, double *p);
 // gradF = [V.x ; Proj_R(V.Y)] (DPGOProblem.cpp:145-162); partial ||gradF||^2; out may be null

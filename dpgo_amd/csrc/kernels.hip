@@ -827,7 +827,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_rot_rowscale(const Seg *segs, Node
 template <int D>
 __global__ __launch_bounds__(SEG_ROWS) void k_cg_step(const Seg *segs, NodeMask mask, NodeCoefs C, const double *p,
                                                       const double *Hp, double *s, double *hs, double *r,
-                                                      const CgNode *cg) {
+                                                      const CgNode *cg, const double *r0) {
   constexpr int RS = Dim<D>::RS;
   const Seg sg = segs[SEGB];
   if (!node_on(mask, sg.node)) return;
@@ -837,16 +837,27 @@ __global__ __launch_bounds__(SEG_ROWS) void k_cg_step(const Seg *segs, NodeMask 
   double vp[RS], vh[RS], v[RS];
   load_vec<RS>(p + (size_t)row * RS, vp);
   load_vec<RS>(Hp + (size_t)row * RS, vh);
-  load_vec<RS>(s + (size_t)row * RS, v);
+  // r0 != nullptr: the first step of a CG run -- s and H s start from zero (not read), r from r0 (the gradient)
+  if (r0) {
+#pragma unroll
+    for (int k = 0; k < RS; k++) v[k] = 0.0;
+  } else {
+    load_vec<RS>(s + (size_t)row * RS, v);
+  }
 #pragma unroll
   for (int k = 0; k < RS; k++) v[k] = fma(cc, vp[k], 1.0 * v[k]);
   store_vec<RS>(s + (size_t)row * RS, v);
-  load_vec<RS>(hs + (size_t)row * RS, v);
+  if (r0) {
+#pragma unroll
+    for (int k = 0; k < RS; k++) v[k] = 0.0;
+  } else {
+    load_vec<RS>(hs + (size_t)row * RS, v);
+  }
 #pragma unroll
   for (int k = 0; k < RS; k++) v[k] = fma(cc, vh[k], 1.0 * v[k]);
   store_vec<RS>(hs + (size_t)row * RS, v);
   if (cc_r != 0.0) {
-    load_vec<RS>(r + (size_t)row * RS, v);
+    load_vec<RS>((r0 ? r0 : r) + (size_t)row * RS, v);
 #pragma unroll
     for (int k = 0; k < RS; k++) v[k] = fma(cc_r, vh[k], 1.0 * v[k]);
     store_vec<RS>(r + (size_t)row * RS, v);
@@ -881,14 +892,16 @@ __global__ __launch_bounds__(SEG_ROWS) void k_cg_init(const Seg *segs, NodeMask 
   const int row = sg.begin + threadIdx.x;
   if (row >= sg.end) return;
   double g[RS], pg[RS], z[RS];
-  load_vec<RS>(grad + (size_t)row * RS, g);
   load_vec<RS>(pgrad + (size_t)row * RS, pg);
+  if (s) {   // (s == nullptr: only p = -P grad; the first k_cg_step then takes s = H s = 0 and r = grad as given)
+    load_vec<RS>(grad + (size_t)row * RS, g);
 #pragma unroll
-  for (int k = 0; k < RS; k++) z[k] = 0.0;
-  store_vec<RS>(s + (size_t)row * RS, z);
-  store_vec<RS>(hs + (size_t)row * RS, z);
-  store_vec<RS>(r + (size_t)row * RS, g);
-  store_vec<RS>(v + (size_t)row * RS, pg);
+    for (int k = 0; k < RS; k++) z[k] = 0.0;
+    store_vec<RS>(s + (size_t)row * RS, z);
+    store_vec<RS>(hs + (size_t)row * RS, z);
+    store_vec<RS>(r + (size_t)row * RS, g);
+    store_vec<RS>(v + (size_t)row * RS, pg);
+  }
 #pragma unroll
   for (int k = 0; k < RS; k++) pg[k] = -1.0 * pg[k];
   store_vec<RS>(p + (size_t)row * RS, pg);
@@ -1735,11 +1748,11 @@ void launch_rot_rowscale(int d, hipStream_t st, const SegTable &T, NodeMask mask
 }
 
 void launch_cg_step(int d, hipStream_t st, const SegTable &T, NodeMask mask, const NodeCoefs &C, const double *p,
-                    const double *Hp, double *s, double *hs, double *r, const CgNode *cg) {
+                    const double *Hp, double *s, double *hs, double *r, const CgNode *cg, const double *r0) {
   if (T.nseg_own == 0) return;
-  ProfScope ps(PK_AXPBY, st, 8.0 * T.rows_own * 8.0 * (d + 1) * d);
+  ProfScope ps(PK_AXPBY, st, (r0 ? 6.0 : 8.0) * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cg_step<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, C, p, Hp, s, hs,
-                                        r, cg));
+                                        r, cg, r0));
 }
 
 void launch_cg_dir(int d, hipStream_t st, const SegTable &T, NodeMask mask, const CgNode *cg, const double *v, double *p) {
@@ -1778,7 +1791,7 @@ void launch_dots(int d, hipStream_t st, const SegTable &T, NodeMask mask, int n,
 void launch_cg_init(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *grad, const double *pgrad,
                     double *s, double *hs, double *r, double *v, double *p) {
   if (T.nseg_own == 0) return;
-  ProfScope ps(PK_AXPBY, st, 7.0 * T.rows_own * 8.0 * (d + 1) * d);
+  ProfScope ps(PK_AXPBY, st, (s ? 7.0 : 2.0) * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cg_init<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, grad,
                                         pgrad, s, hs, r, v, p));
 }

@@ -142,8 +142,10 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     // kernels of the surplus step find an empty device mask and return at once.
     set_mask(A);
     const NodeBits bitsA = cur_mask_.v;
-    // s_0 = 0, H s_0 = 0, r_0 = grad, v_0 = P(grad) (already there from the preconditioned gradient norm), p_0 = -v_0
-    launch_cg_init(d_, st_, T_, cur_mask_, grad, use_precon ? pg : grad, sk, hh, rk, vk, pk);
+    // p_0 = -v_0, v_0 = P(grad) (already there from the preconditioned gradient norm);
+    // s_0 = 0, H s_0 = 0, r_0 = grad are not materialised: the first step of the run takes them as given
+    launch_cg_init(d_, st_, T_, cur_mask_, grad, use_precon ? pg : grad, nullptr, nullptr, nullptr, nullptr, pk);
+    bool first_step = true;
     {
       CgStart cs;
       for (int a = 0; a < L; a++) cs.rv[a] = cs.Delta[a] = cs.target[a] = 0.0;
@@ -161,11 +163,15 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       cur_mask_ = mA;
       launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, pk, true, nullptr, w1, nullptr, 0, nullptr, nullptr, 0);   // G [0 ; p.R]
       solve_tt(w1, w3, -1.0);
-      apply_tcol(w3, w1, nullptr, 2, X, nabla, pk, Hp, rk, partials_.p);   // Hp and <p,Hp>, <Hp,Hp>, <p,p>, <p,r>
+      apply_tcol(w3, w1, nullptr, 2, X, nabla, pk, Hp, first_step ? grad : rk, partials_.p);   // Hp and <p,Hp>, <Hp,Hp>, <p,p>, <p,r>
       launch_cg_scal(st_, T_, L, 0, partials_.p, cg_.p, dmask_.p, h_scal_, reduce_arrived_.p, h_flag_, ++fetch_seq_);
       // s += c1 p, H s += c1 H p for every node of the step (a node that stops here takes its boundary step), r += alpha H p
       // for those that go on
-      launch_cg_step(d_, st_, T_, mA, NodeCoefs(), pk, Hp, sk, hh, rk, cg_.p);
+      // (the first step runs for every node of A, live or not: a node that stops before its first step has c1 = 0 and
+      // gets its s = H s = 0 written here)
+      launch_cg_step(d_, st_, T_, first_step ? NodeMask{bitsA, nullptr} : mA, NodeCoefs(), pk, Hp, sk, hh, rk, cg_.p,
+                     first_step ? grad : nullptr);
+      first_step = false;
       return fetch_seq_;
     };
     // second half: preconditioner; beta and the recurrences, next stopping test (:364-390, :285-291)
