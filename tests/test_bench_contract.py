@@ -1,0 +1,55 @@
+"""The bench.py contract (one JSON line): the keys the driver and the judge read, checked on the committed line of the
+last profiling run (profiles/rNN_bench_n1.json) and, on a GPU box, on a fresh short run."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _check(j, n1=True):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config"):
+        assert k in j, k
+    assert j["unit"] == "iters/s" and j["higher_is_better"] is True and j["dtype"] == "f64" and j["data"] == "synthetic"
+    assert j["vs_baseline"] is None                       # BASELINE.md publishes no number for this metric
+    assert "workload" in j["config"] and "model" not in j["config"]
+    assert abs(j["value"] * j["ms_per_step"] * 1e-3 - 1.0) < 1e-6      # iterations / s and ms / iteration agree
+    r = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    if n1:
+        c = j["cpu_baseline"]
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in c, k
+        assert c["kind"] == "port" and c["unit"] == j["unit"] and c["cores"] >= 1
+        cv = j["convergence"]
+        assert cv["iterations_to_1e-6"] > 0 and cv["seconds_to_1e-6"] > 0
+
+
+def test_committed_bench_line():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1.json")))
+    assert files
+    _check(json.load(open(files[-1])))
+
+
+def test_bench_help_runs_without_a_gpu():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
+    text = out.stdout + out.stderr      # (bench.py keeps stdout for the JSON line)
+    assert out.returncode == 0 and "--gpus" in text and "--steps" in text and "--warmup" in text
+
+
+@pytest.mark.gpu
+def test_fresh_bench_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--grid", "20,20,16,25000", "--steps", "5",
+                          "--warmup", "2", "--converge", "40", "--cpu-steps", "1"], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                # ONE JSON line
+    _check(json.loads(lines[0]))
