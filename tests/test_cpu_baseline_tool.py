@@ -43,3 +43,41 @@ def test_cpu_tool_follows_the_oracle(fixtures_dir, tmp_path, name, nn, loss, ite
     ref = np.array(ref)
     assert got.shape == ref.shape
     np.testing.assert_allclose(got, ref, rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_headline_size_trace_against_the_cpu_restatement(tmp_path):
+    """BASELINE config 4 at FULL size (100 000 poses / 400 000 edges, Huber, AMM-PGO#, 8 nodes): the objective trace of
+    the HIP path against the independent C++ CPU restatement (host multifrontal solves, host TNT; pinned to the oracle
+    by the test above), iteration by iteration to 1e-8 relative -- the sizes the numpy oracle cannot afford."""
+    import struct
+    import dpgo_amd
+    from dpgo_amd import synthetic
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(EXE)])
+    g = synthetic.grid(50, 50, 40, 400000, seed=synthetic.HEADLINE["seed"])
+    d, N, m, iters = 3, g["num_poses"], len(g["I"]), 8
+    G = dpgo_amd.graph_from_edges(3, N, g["I"], g["J"], g["R"], g["t"], g["kappa"], g["tau"], 8)
+    X0 = G.chordal_initialization()
+    fe, fx = str(tmp_path / "edges.bin"), str(tmp_path / "X0.bin")
+    rec = np.dtype([("i", "<i4"), ("j", "<i4"), ("R", "<f8", (d * d,)), ("t", "<f8", (d,)), ("kappa", "<f8"), ("tau", "<f8")])
+    E = np.zeros(m, rec)
+    E["i"], E["j"] = g["I"], g["J"]
+    E["R"], E["t"] = np.asarray(g["R"]).reshape(m, d * d), g["t"]
+    E["kappa"], E["tau"] = g["kappa"], g["tau"]
+    with open(fe, "wb") as fh:
+        fh.write(struct.pack("<iii", d, N, m))
+        fh.write(E.tobytes())
+    np.asfortranarray(X0, dtype=np.float64).T.copy().tofile(fx)
+    out = subprocess.run([EXE, fe, fx, "8", "1", str(iters), "8", "trace"], capture_output=True, text=True, check=True,
+                         timeout=900).stderr
+    cpu = np.array([float(l.split()[1]) for l in out.splitlines() if l[:1].isdigit()])
+    grp = dpgo_amd.NodeGroup(G, range(8), dpgo_amd.Options.driver(1, True))
+    assert grp.initialize_global(X0) == 0 and grp.update() == 0
+    gpu = [2 * sum(grp.results(k).fobj for k in range(8))]
+    for _ in range(iters):
+        assert grp.iterate() == 0 and grp.communicate_local() == 0 and grp.update() == 0
+        gpu.append(2 * sum(grp.results(k).fobj for k in range(8)))
+    gpu = np.array(gpu)
+    assert cpu.shape == gpu.shape
+    np.testing.assert_allclose(gpu, cpu, rtol=1e-8)
+    assert gpu[-1] < gpu[0]
