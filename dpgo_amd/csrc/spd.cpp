@@ -961,14 +961,17 @@ int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf, int collapse, int blo
   std::vector<TreeNode> tree;   // dissected once, reused for every merge depth tried below
   if (const char *e = getenv("DPGO_SPD_COLLAPSE")) collapse = atoi(e);
   if (collapse <= 0) {
-    // choose the number of merged levels from a latency + bandwidth model of one sweep on MI355X:
-    // every tree level is one dependent launch (~12 us, measured), every factor entry is read once
+    // choose the number of merged levels from the measured cost of one sweep on MI355X: a level costs
+    // ~12 us whatever it holds (launch, gather chain, drain) plus its bytes at ~7 TB/s.  (With the 3 TB/s of a whole
+    // solve in place of the streaming rate the model undervalues a level: the deeper merge it now picks for G_RR + lambda I
+    // is equal in the early regime and 4 % faster to the reference objective, where CG steps run on the few nodes that
+    // still iterate and the per-level cost is all that is left.)
     double best = 1e300;
     int best_c = 1;
     for (int c = 1; c <= 3; c++) {
       SpdFactor S;
       if (spd_factor_impl(A, S, leaf, c, true, &tree, block, false) != 0) continue;
-      const double t = 12e-6 * (double)S.by_height.size() + 8.0 * (double)S.entries / 3.0e12;
+      const double t = 12e-6 * (double)S.by_height.size() + 8.0 * (double)S.entries / 7.0e12;
       if (t < best) { best = t; best_c = c; }
     }
     collapse = best_c;
