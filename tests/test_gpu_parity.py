@@ -790,3 +790,37 @@ def test_verbose_option_prints_and_changes_nothing(fixtures_dir, capfd):
         assert ("TNT:" in text) == bool(verbose)
         outs.append(drv.X().copy())
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_deferred_update_readback_changes_nothing(fixtures_dir, tmp_path):
+    """update() returns before its scalars are read back (Group::finish_update) unless DPGO_DEFER_UPDATE=0; both ways give
+    the same bits, through refinements, restarts and a per-node calling pattern (two processes: the switch is read once)."""
+    import subprocess
+    import sys
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import dpgo_amd
+G = dpgo_amd.read_g2o(%r, 3)
+drv = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(1, True))
+trace = []
+for it in range(30):
+    assert drv.step() == 0
+    trace.append([drv.group.results(a).fobj for a in range(3)] + [drv.group.results(a).gamma for a in range(3)])
+grp = drv.group
+for it in range(6):                       # nodes one by one, results read in between
+    for a in range(3):
+        assert grp.iterate([a]) == 0
+    assert grp.communicate_local() == 0
+    for a in (2, 0, 1):
+        assert grp.update([a]) == 0
+        trace.append([grp.results(a).fobj, grp.results(a).Gk, 0, 0, 0, 0])
+np.savez(sys.argv[1], X=drv.X(), trace=np.array(trace))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(fixtures_dir, "torus3D.g2o"))
+    outs = []
+    for v in ("0", "1"):
+        path = str(tmp_path / ("defer%s.npz" % v))
+        subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, DPGO_DEFER_UPDATE=v))
+        outs.append(np.load(path))
+    assert np.array_equal(outs[0]["X"], outs[1]["X"])
+    assert np.array_equal(outs[0]["trace"], outs[1]["trace"])
