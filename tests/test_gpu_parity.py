@@ -824,3 +824,33 @@ np.savez(sys.argv[1], X=drv.X(), trace=np.array(trace))
         outs.append(np.load(path))
     assert np.array_equal(outs[0]["X"], outs[1]["X"])
     assert np.array_equal(outs[0]["trace"], outs[1]["trace"])
+
+
+def test_engineering_switches_do_not_change_the_results(fixtures_dir, tmp_path):
+    """The switches of DESIGN 6b select HOW something is computed, never WHAT: lagged CG polling (DPGO_CG_LAG=0) is bit
+    for bit the same run; the host numeric factorisation (DPGO_SPD_HOST_FACTOR=1), panels packed on the host
+    (DPGO_SPD_DEVICE_PANELS=0) and the scalar-graph ordering (DPGO_SPD_QUOTIENT=0) are other exact factorisations of the
+    same matrices, so the iterates agree to rounding (1e-9 after 25 iterations with refinements)."""
+    import subprocess
+    import sys
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import dpgo_amd
+G = dpgo_amd.read_g2o(%r, 4)
+drv = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(1, True))
+for it in range(25):
+    assert drv.step() == 0
+np.save(sys.argv[1], drv.X())
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(fixtures_dir, "sphere2500.g2o"))
+
+    def run(tag, **env):
+        path = str(tmp_path / (tag + ".npy"))
+        subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, **env))
+        return np.load(path)
+
+    base = run("base")
+    assert np.array_equal(run("lag0", DPGO_CG_LAG="0"), base)
+    for tag, env in (("hostfactor", dict(DPGO_SPD_HOST_FACTOR="1")), ("hostpanels", dict(DPGO_SPD_DEVICE_PANELS="0")),
+                     ("scalarorder", dict(DPGO_SPD_QUOTIENT="0"))):
+        np.testing.assert_allclose(run(tag, **env), base, rtol=0, atol=1e-9, err_msg=tag)
