@@ -48,7 +48,78 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` started directly (no torch.distributed.run around it): this parent -- which has not
+    imported torch nor touched HIP, and never does -- starts N fresh children of this same script, one per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (a free port) set, relays rank 0's single JSON line,
+    and returns non-zero when any rank fails.  The reference analogue is one `dist_pgo` process that runs all nodes
+    (C++/examples/dist_pgo.cpp:96-126, 492-531)."""
+    import signal
+    import subprocess
+    port = _free_port()
+    share = max(1, min(_host_cores(), 32) // n)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "DPGO_HOST_THREADS"):
+            env[v] = os.environ.get(v + "_PER_RANK", str(share))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, start_new_session=True))
+    rc = 0
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    try:
+        # a rank that dies leaves the others waiting in a collective: poll, and stop everybody when one has failed
+        pending = set(range(n))
+        while pending:
+            for r in list(pending):
+                c = procs[r].poll()
+                if c is not None:
+                    pending.discard(r)
+                    if c != 0:
+                        rc = rc or c
+            if rc:
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                if rc == 0:
+                    p.wait()
+                else:
+                    try:
+                        os.killpg(p.pid, signal.SIGTERM)    # the exact process groups started above
+                    except ProcessLookupError:
+                        pass
+    reader.join(timeout=10)
+    lines = [l for l in b"".join(chunks).decode(errors="replace").splitlines() if l.startswith("{")]
+    if rc == 0 and lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    elif rc == 0:
+        rc = 1
+    return rc
+
+
 def main():
+    # started by hand with --gpus N > 1 and no launcher around it: become the launcher (before any torch / HIP import)
+    if "WORLD_SIZE" not in os.environ:
+        pre = argparse.ArgumentParser(add_help=False)
+        pre.add_argument("--gpus", type=int, default=1)
+        n = pre.parse_known_args()[0].gpus
+        if n > 1:
+            sys.exit(launch_ranks(n, sys.argv[1:]))
+
     # The contract is ONE JSON line on stdout.  RCCL prints its banner and warnings to the C-level stdout (the GPU
     # boxes export NCCL_DEBUG=VERSION), so everything this process writes to fd 1 goes to stderr from here on and
     # the JSON line is written to the saved descriptor at the end.
@@ -81,6 +152,8 @@ def main():
                          "(relative) of the lowest one reached (SURVEY 8d: iterations and wall time to the reference "
                          "objective), the whole-run mean ms/iter and the ms/iter + CG steps/iter of the last 20 "
                          "iterations (the interior-step regime); 0 skips it")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="stop after the ranks have met (no GPU needed): checks the launcher")
     ap.add_argument("--force-exchange", action="store_true",
                     help="diagnostic: run the boundary exchange (pack, all-gather, unpack) even with one rank, to see "
                          "what it adds to a step")
@@ -99,7 +172,6 @@ def main():
         raise SystemExit("num_nodes must be divisible by the number of GPUs")
     if args.share_gpu:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
     dist = None
     host_staged = args.backend == "gloo"
     do_exchange = world > 1 or args.force_exchange
@@ -113,10 +185,24 @@ def main():
             # one node: rendezvous and bootstrap over the loopback interface (the container's hostname may not resolve)
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-        os.environ.setdefault("MASTER_PORT", "29517")
+        if "MASTER_PORT" not in os.environ:
+            if world > 1:
+                raise SystemExit("WORLD_SIZE > 1 without MASTER_PORT")
+            os.environ["MASTER_PORT"] = str(_free_port())
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("gloo")
+    if args.rendezvous_only:
+        # launcher check (runs without a GPU): every rank arrived with a consistent environment
+        seen = [None] * world
+        if world > 1:
+            dist.all_gather_object(seen, (rank, local_rank, os.environ.get("MASTER_PORT")))
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            os.write(real_stdout, (json.dumps({"rendezvous": "ok", "n_gpus": world, "ranks": seen}) + "\n").encode())
+        return
+    torch.cuda.set_device(local_rank)
     cdev = "cpu"
 
     # ---- set-up (untimed): graph, partition, chordal initialisation, operators, factorizations

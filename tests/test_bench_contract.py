@@ -45,6 +45,24 @@ def test_bench_help_runs_without_a_gpu():
     assert out.returncode == 0 and "--gpus" in text and "--steps" in text and "--warmup" in text
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the way the driver may start it) must spawn its two
+    ranks itself and reach the rendezvous -- not exit with "WORLD_SIZE=1"; a failing rank makes it return non-zero."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+                          "--rendezvous-only"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["rendezvous"] == "ok" and j["n_gpus"] == 2
+    assert sorted(r[0] for r in j["ranks"]) == [0, 1] and len({r[2] for r in j["ranks"]}) == 1
+    # num_nodes = 8 is not divisible by 3 ranks: every rank exits with an error, and so does the launcher
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--backend", "gloo", "--share-gpu",
+                          "--rendezvous-only"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
+
+
 @pytest.mark.gpu
 def test_fresh_bench_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--grid", "20,20,16,25000", "--steps", "5",

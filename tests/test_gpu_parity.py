@@ -261,14 +261,23 @@ def test_multiprocess_path_matches_single_process(tmp_path):
                          timeout=600, cwd=root)
     assert one.returncode == 0, one.stderr[-2000:]
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--backend", "gloo", "--share-gpu"] + common,
-                         capture_output=True, text=True, timeout=900, cwd=root)
-    assert two.returncode == 0, two.stderr[-3000:]
-    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
-    assert j2["n_gpus"] == 2 and j2["config"]["nodes_per_gpu"] == 4
-    assert abs(j1["objective_2F"] - j2["objective_2F"]) <= 1e-10 * abs(j1["objective_2F"])
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    # (a) under the launcher the driver uses, (b) started directly: bench.py spawns its own two ranks
+    for cmd in ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                 "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py")],
+                [sys.executable, os.path.join(root, "bench.py")]):
+        two = subprocess.run(cmd + ["--gpus", "2", "--backend", "gloo", "--share-gpu"] + common,
+                             capture_output=True, text=True, timeout=900, cwd=root, env=env)
+        assert two.returncode == 0, two.stderr[-3000:]
+        lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        j2 = json.loads(lines[0])
+        assert j2["n_gpus"] == 2 and j2["config"]["nodes_per_gpu"] == 4
+        assert abs(j1["objective_2F"] - j2["objective_2F"]) <= 1e-10 * abs(j1["objective_2F"])
 
 
 @pytest.mark.parametrize("loss", [LOSS_NONE, LOSS_HUBER])
