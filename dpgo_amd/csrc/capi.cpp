@@ -1,6 +1,7 @@
 // C ABI (include/dpgo_amd.h) over the C++ host layer.
 #include "../../include/dpgo_amd.h"
 
+#include <memory>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -289,20 +290,26 @@ int dpgo_group_star_initialize(dpgo_group_t *h, const double *X, int ld) { retur
 int dpgo_group_star_update(dpgo_group_t *h) { return guarded([&] { return h->grp->star_update(); }); }
 int dpgo_group_star_iterate(dpgo_group_t *h) { return guarded([&] { return h->grp->star_iterate(); }); }
 int dpgo_group_star_state(const dpgo_group_t *h, double *F, double *fobj, double *fobjh, int *branches) {
-  if (F) *F = h->grp->star_F();
-  if (fobj) *fobj = h->grp->star_fobj();
-  if (fobjh) *fobjh = h->grp->star_fobjh();
-  if (branches) *branches = h->grp->star_branches();
-  return 0;
+  if (!h) return -1;
+  return guarded([&] {
+    if (F) *F = h->grp->star_F();
+    if (fobj) *fobj = h->grp->star_fobj();
+    if (fobjh) *fobjh = h->grp->star_fobjh();
+    if (branches) *branches = h->grp->star_branches();
+    return 0;
+  });
 }
 int dpgo_group_receive(dpgo_group_t *h, int local, int beta, const double *msg, int ld) { return guarded([&] { return h->grp->receive(local, beta, msg, ld); }); }
 int dpgo_group_send(const dpgo_group_t *h, int local, int beta, double *msg, int ld) { return guarded([&] { return h->grp->send(local, beta, msg, ld); }); }
 int dpgo_group_message_sizes(const dpgo_group_t *h, int local, int beta, int *num_send, int *num_recv) {
-  const int s = h->grp->num_send(local, beta), r = h->grp->num_recv(local, beta);
-  if (s < 0 || r < 0) return -1;
-  if (num_send) *num_send = s;
-  if (num_recv) *num_recv = r;
-  return 0;
+  if (!h) return -1;
+  return guarded([&] {
+    const int s = h->grp->num_send(local, beta), r = h->grp->num_recv(local, beta);
+    if (s < 0 || r < 0) return -1;
+    if (num_send) *num_send = s;
+    if (num_recv) *num_recv = r;
+    return 0;
+  });
 }
 int dpgo_group_num_sent(const dpgo_group_t *h) { return h->grp->num_sent(); }
 int dpgo_group_sent_keys(const dpgo_group_t *h, int *nodes, int *poses) {
@@ -327,7 +334,9 @@ int dpgo_group_sync(const dpgo_group_t *h) { return guarded([&] { h->grp->sync()
 void *dpgo_group_stream(const dpgo_group_t *h) { return (void *)h->grp->stream(); }
 
 int dpgo_group_results(const dpgo_group_t *h, int local, dpgo_results_t *o) {
-  if (local < 0 || local >= h->grp->num_local()) return -1;
+  if (!h || !o || local < 0 || local >= h->grp->num_local()) return -1;
+  // results() may have to take the deferred read-back of the last update(): a device error there becomes -1
+  return guarded([&] {
   const dpgo::NodeResults &r = h->grp->results(local);
   o->updated = r.updated; o->iters = r.iters; o->gradFnorm = r.gradFnorm; o->fobjE = r.fobjE;
   o->Fk[0] = r.Fk[0]; o->Fk[1] = r.Fk[1]; o->Gk = r.Gk; o->Gkh = r.Gkh; o->fobj = r.fobj; o->f = r.f;
@@ -336,6 +345,7 @@ int dpgo_group_results(const dpgo_group_t *h, int local, dpgo_results_t *o) {
   o->num_oscillations = r.num_oscillations; o->refined = r.refined; o->tnt_status = r.tnt_status;
   o->tnt_inner_iterations = r.tnt_inner; o->restarts = r.restarts;
   return 0;
+  });
 }
 
 // ---- test hooks ----
@@ -565,14 +575,12 @@ int dpgo_comm_create(dpgo_group_t *h, int rank, int nranks, const void *id128, d
   *out = nullptr;
   if (!h || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return -1;
   return guarded([&] {
-    auto *c = new dpgo_comm();
-    c->c = new dpgo::Comm(h->grp, rank, nranks, id128);
-    if (!c->c->ok()) {
-      delete c->c;
-      delete c;
-      return -1;
-    }
-    *out = c;
+    std::unique_ptr<dpgo_comm> c(new dpgo_comm());
+    c->c = nullptr;
+    std::unique_ptr<dpgo::Comm> cc(new dpgo::Comm(h->grp, rank, nranks, id128));   // (cleans up after itself when it throws)
+    if (!cc->ok()) return -1;
+    c->c = cc.release();
+    *out = c.release();
     return 0;
   });
 }

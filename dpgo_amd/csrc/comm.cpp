@@ -86,6 +86,18 @@ int Comm::unique_id(void *id128) {
 
 Comm::Comm(Group *grp, int rank, int nranks, const void *id128) : grp_(grp), rank_(rank), nranks_(nranks) {
   if (!rccl().ok || !grp || rank < 0 || rank >= nranks) return;
+  // a constructor that throws never runs its destructor: release what was created, then pass the error on
+  try {
+    init(id128);
+  } catch (...) {
+    release();
+    throw;
+  }
+}
+
+void Comm::init(const void *id128) {
+  Group *grp = grp_;
+  const int rank = rank_, nranks = nranks_;
   ncclUniqueId id;
   std::memcpy(&id, id128, sizeof(id));
   HIP_OK(hipSetDevice(grp->device()));
@@ -130,13 +142,24 @@ Comm::Comm(Group *grp, int rank, int nranks, const void *id128) : grp_(grp), ran
   ok_ = true;
 }
 
-Comm::~Comm() {
-  if (grp_) grp_->set_collectives(nullptr, nullptr, nullptr, nullptr, nullptr);
+Comm::~Comm() { release(); }
+
+void Comm::release() {
+  if (grp_) {
+    // an exchange that no update() has joined yet: let it finish, and take its event away from the group before the
+    // event is destroyed
+    if (ev_done_) (void)hipEventSynchronize(ev_done_);
+    grp_->set_pending_exchange(nullptr);
+    grp_->set_collectives(nullptr, nullptr, nullptr, nullptr, nullptr);
+  }
+  if (cs_) (void)hipStreamSynchronize(cs_);
   if (comm_ && rccl().ok) (void)rccl().CommDestroy((ncclComm_t)comm_);
   if (ev_ready_) (void)hipEventDestroy(ev_ready_);
   if (ev_done_) (void)hipEventDestroy(ev_done_);
   if (cs_) (void)hipStreamDestroy(cs_);
   if (h_red_) (void)hipHostFree(h_red_);
+  comm_ = nullptr; ev_ready_ = ev_done_ = nullptr; cs_ = nullptr; h_red_ = nullptr;
+  ok_ = false;
 }
 
 // DPGOHash::communicate for the neighbours hosted by other ranks (DPGOHash.h:64-82), asynchronous: the group's

@@ -22,6 +22,8 @@ class Comm {
   int barrier();
 
  private:
+  void init(const void *id128);
+  void release();
   static int cb_allgather(void *user);
   static int cb_allreduce(void *user, double *vals, int n);
   Group *grp_ = nullptr;

@@ -11,7 +11,7 @@
 // One process hosts all nodes on one GPU (--gpu), or -- one process per GPU -- rank r of n (--rank / --world, or
 // RANK / WORLD_SIZE / LOCAL_RANK from a launcher) hosts nodes [r num_nodes / n, (r + 1) num_nodes / n) and the
 // boundary poses travel by RCCL (dpgo_comm_exchange); the 128-byte RCCL id goes from rank 0 to the others through
-// the file --rdv (a path all ranks of the box can see).  fobj = 2 F and grad = 2 |grad F| come from the per-node
+// the private directory --rdv (default: named after the launcher's run id / MASTER_PORT) with a nonce handshake.  fobj = 2 F and grad = 2 |grad F| come from the per-node
 // device reductions (sum_a fobj^a = F, sum_a |Proj(Dfobj^a)|^2 = |grad F|^2; DPGOStar.cpp:713-829), summed over
 // the ranks.
 // --dist_init true runs the distributed chordal initialisation (:144-416, C++/DChordal) through
@@ -27,7 +27,11 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 #include "../../include/dpgo_amd.h"
+#include "rdv.h"
+
 
 static bool parse_bool(const char *s) { return !(strcmp(s, "false") == 0 || strcmp(s, "0") == 0); }
 
@@ -36,7 +40,7 @@ int main(int argc, char **argv) {
   int num_nodes = -1, iters = 1000, gpu = -1;
   bool dist_init = true, accelerated = true, save = true;
   int rank = getenv("RANK") ? atoi(getenv("RANK")) : 0, world = getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1;
-  std::string rdv = std::string("/tmp/dpgo_rdv_") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0");
+  std::string rdv;
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
     auto val = [&](const char *name) -> const char * {
@@ -63,6 +67,12 @@ int main(int argc, char **argv) {
   }
   if (gpu < 0) gpu = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : (world > 1 ? rank : 0);
   if (world < 1 || rank < 0 || rank >= world) { fprintf(stderr, "Inconsistent --rank / --world.\n"); return -1; }
+  if (world > 1 && rdv.empty()) {
+    // a name all ranks of this launch -- and no other launch -- agree on: the launcher's run id / port
+    const char *run = getenv("TORCHELASTIC_RUN_ID"), *port = getenv("MASTER_PORT");
+    if (!run && !port) { fprintf(stderr, "Several ranks need --rdv <directory> (or a launcher that sets MASTER_PORT).\n"); return -1; }
+    rdv = std::string("/tmp/dpgo_rdv_") + std::to_string((long)geteuid()) + "_" + (run ? run : "none") + "_" + (port ? port : "0");
+  }
   if (dataset.empty()) { fprintf(stderr, "No dataset has been specfied.\n"); return -1; }
   if (num_nodes < 1) { fprintf(stderr, "No number of nodes has been specfied.\n"); return -1; }
   int loss;
@@ -89,24 +99,11 @@ int main(int argc, char **argv) {
   if (dpgo_group_create(g, ids.data(), per, &opt, gpu, &grp) != 0) return -1;
   dpgo_comm_t *comm = nullptr;
   if (world > 1 || getenv("DPGO_FORCE_COMM")) {   // (DPGO_FORCE_COMM: a world of one rank still runs the whole protocol)
-    // the RCCL id: rank 0 writes it, the others wait for the file
     unsigned char id[128];
-    if (root) {
-      if (dpgo_comm_unique_id(id) != 0) return -1;
-      FILE *f = fopen((rdv + ".tmp").c_str(), "wb");
-      if (!f || fwrite(id, 1, 128, f) != 128) return -1;
-      fclose(f);
-      if (rename((rdv + ".tmp").c_str(), rdv.c_str()) != 0) return -1;
-    } else {
-      FILE *f = nullptr;
-      for (int tries = 0; tries < 6000 && !(f = fopen(rdv.c_str(), "rb")); tries++)
-        std::this_thread::sleep_for(std::chrono::milliseconds(20));
-      if (!f || fread(id, 1, 128, f) != 128) { fprintf(stderr, "No rendezvous file %s.\n", rdv.c_str()); return -1; }
-      fclose(f);
-    }
+    if (root && dpgo_comm_unique_id(id) != 0) return -1;
+    if (world > 1 && dpgo_rdv::rendezvous(rdv, rank, world, id) != 0) return -1;
     if (dpgo_comm_create(grp, rank, world, id, &comm) != 0) return -1;
     dpgo_comm_barrier(comm);
-    if (root) remove(rdv.c_str());
   }
   if (dist_init) {
     // every node of the graph takes part in the distributed initialisation; with several ranks each computes it on

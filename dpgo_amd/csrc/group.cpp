@@ -940,6 +940,7 @@ int Group::evaluate_global(const double *X, int ld, double *F, double *grad_sqno
     fprintf(stderr, "[dpgo_amd] ERROR: evaluate: inconsistent size of X.\n");
     return -1;
   }
+  join_exchange();
   sync();
   {
     std::vector<double> rec((size_t)(P0_ + P1_) * RS_), Z;
@@ -1288,7 +1289,10 @@ int Group::update(const std::vector<int> &locals_in) {
   std::vector<int> locals;
   for (int a : locals_in)
     if (!res_[a].updated) locals.push_back(a);
-  if (locals.empty()) return 0;
+  if (locals.empty()) {
+    join_exchange();   // a pending exchange must still be ordered before whatever the caller does next on this stream
+    return 0;
+  }
   const bool trivial = (opt_.loss == 0);
   set_mask(locals);
   // history: X[iter-1] <- X[iter], X[iter] <- Xk ; same for g and Dfobj (masked nodes only).  A node whose
@@ -1425,6 +1429,7 @@ int Group::iterate(const std::vector<int> &locals) {
       return -1;
     }
   if (locals.empty()) return 0;
+  join_exchange();   // (iterate -> exchange -> iterate without an update(): the pack must not race with the new Xk)
   const int rc = opt_.scheme == 1 ? amm(locals) : mm(locals);
   if (rc != 0) return rc;
   set_mask(locals);

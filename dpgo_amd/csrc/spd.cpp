@@ -954,7 +954,9 @@ int spd_refactor(const CsrMatrix &A, SpdFactor &F) {
       hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0)
     return spd_factor_numeric_device(A, F, F.children, nullptr, nullptr);
 #endif
-  return spd_factor(A, F, 64, 0, 1, F.keep_device);
+  // host path: the same ordering parameters as the first factorisation, so that the switch does not change the bits
+  const int leaf = F.leaf, collapse = F.collapse, block = F.block;
+  return spd_factor(A, F, leaf, collapse, block, F.keep_device);
 }
 
 int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf, int collapse, int block, bool keep_device) {
@@ -976,7 +978,11 @@ int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf, int collapse, int blo
     }
     collapse = best_c;
   }
-  return spd_factor_impl(A, F, leaf, collapse, false, &tree, block, keep_device);
+  const int rc = spd_factor_impl(A, F, leaf, collapse, false, &tree, block, keep_device);
+  F.leaf = leaf;
+  F.collapse = collapse;   // (the merge depth actually used)
+  F.block = block;
+  return rc;
 }
 
 void spd_solve_host(const SpdFactor &F, double *X, int nc) {

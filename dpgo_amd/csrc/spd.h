@@ -53,6 +53,7 @@ struct SpdFactor {
   // lower bound of the condition number -- W_s holds the explicit L11^-1, so a huge ratio costs digits in every solve
   double pivot_min = 0.0, pivot_max = 0.0;
   bool keep_device = false;
+  int leaf = 32, collapse = 0, block = 1;   // the parameters this factor was built with (spd_refactor's host path repeats them)
   double *dev_W = nullptr, *dev_WT = nullptr;
   int64_t nnz() const { return entries; }
 };

@@ -192,7 +192,7 @@ int dpgo_group_unpack_recv(dpgo_group_t *grp, const void *device_gathered);
 
 /* DPGOStar::evaluate_f / evaluate_grad -- C++/DPGO/src/DPGOStar.cpp:713-829 -- at an ARBITRARY global X
  * ((d+1)N x d); the optimizer state is not touched.  *F and *grad_sqnorm (= |grad F|^2, Riemannian) are sums over
- * the nodes of this group -- over all groups when collectives are set (dpgo_group_set_collectives / dpgo_comm_attach);
+ * the nodes of this group -- over all groups when collectives are set (dpgo_group_set_collectives / dpgo_comm_create);
  * the driver prints 2 F and 2 sqrt(grad_sqnorm) (dist_pgo.cpp:477-481).  grad (optional, (d+1)N x d, leading
  * dimension ldg): the rows of this group's own poses are written.  Any output pointer may be NULL. */
 int dpgo_group_evaluate(dpgo_group_t *grp, const double *X, int ld, double *F, double *grad_sqnorm, double *grad,
