@@ -55,6 +55,7 @@ template struct DevBuf<unsigned>;
 template struct DevBuf<CgNode>;
 template struct DevBuf<NodeBits>;
 template struct DevBuf<PanelSrc>;
+template struct DevBuf<InterInc>;
 
 // tuning hooks (tools/env_ab.sh): an integer from the environment, or the default
 static int env_int(const char *name, int dflt) {
@@ -116,12 +117,44 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
     return cnt;
   };
   const int MERGE_BELOW = 1024;
+  // The roots are applied through the EXPLICIT inverse of their Schur complement (one launch instead of two, below),
+  // which is only as good as that complement is conditioned: cancellation costs kappa * eps in every component, where
+  // the two triangular sweeps confine the damage to the near-null direction.  So the pivots of every root are looked
+  // at first (d_kk = 1 / Linv_kk^2, within the spectrum of the complement), and a factor with a root whose pivots span
+  // more than 1e9 -- G_tt of a graph hosted by ONE node is the Laplacian + 1e-11 I, singular along the gauge -- keeps
+  // the two sweeps.
+  fused_root = env_int("DPGO_SPD_FUSE_ROOT", 1) != 0;
+  if (fused_root) {
+    double worst = 1.0;
+    std::vector<double> diag;
+    for (int f = 0; f < F.nfronts && fused_root; f++) {
+      if (!(F.parent[f] < 0 && F.u[f] == 0 && F.w[f] > 0)) continue;
+      const int w = F.w[f], ld = F.ldw[f];
+      diag.assign(w, 0.0);
+      if (F.dev_W) HIP_CHECK(hipMemcpy2D(diag.data(), sizeof(double), F.dev_W + F.w_off[f], sizeof(double) * (ld + 1), sizeof(double), w, hipMemcpyDeviceToHost));
+      else if (!F.W.empty()) for (int k = 0; k < w; k++) diag[k] = F.W[F.w_off[f] + (size_t)k * ld + k];
+      else { fused_root = false; break; }
+      double lo = 1e300, hi = 0.0;
+      for (int k = 0; k < w; k++) { lo = std::min(lo, std::fabs(diag[k])); hi = std::max(hi, std::fabs(diag[k])); }
+      if (!(lo > 0.0) || !std::isfinite(hi)) { fused_root = false; break; }
+      worst = std::max(worst, (hi / lo) * (hi / lo));
+    }
+    if (worst > std::pow(10.0, env_int("DPGO_SPD_FUSE_ROOT_MAXLOG", 9))) fused_root = false;
+    if (getenv("DPGO_SPD_DUMP")) fprintf(stderr, "[spd] dof %d roots: pivot range %.2e -> %s\n", dof, worst, fused_root ? "fused" : "two sweeps");
+  }
+  auto is_root = [&](int f) { return fused_root && F.parent[f] < 0 && F.u[f] == 0 && F.w[f] > 0; };
+  int nnodes = 1;
+  for (int a : node_of_unknown) nnodes = std::max(nnodes, a + 1);
+  auto node_of_front = [&](int f) { return node_of_unknown[F.piv_idx[F.piv_ptr[f]]]; };   // a front never spans two nodes (they are disconnected)
   struct Tile { int f, first, count, rows; int64_t len; };   // rows: tile height of its class; len: panel rows
   auto sweep = [&](bool fwd, std::vector<Level> &out_levels, DevBuf<SpdItem> &items_dev, DevBuf<double> &panels_dev) {
     const auto &levels = fwd ? F.by_height : F.by_depth;
     std::vector<Tile> tiles;
     out_levels.clear();
-    for (const auto &lvl : levels) {
+    for (const auto &lvl_all : levels) {
+      std::vector<int> lvl;   // (the roots have a launch of their own)
+      for (int f : lvl_all)
+        if (!is_root(f)) lvl.push_back(f);
       const bool merge = tiles64(lvl, fwd, true) > 0 && tiles64(lvl, fwd, false) < MERGE_BELOW;
       // Few wide tiles at this level: 16-row tiles put 4x more workgroups (CUs) on them.  A workgroup streams
       // ~30-45 GB/s, so a level is as slow as its longest tile whenever it has fewer tiles than the chip has
@@ -135,24 +168,30 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
       const bool fine = fwd ? wide_tiles < env_int("DPGO_SPD_FINE_FWD", 192)
                             : (wide_tiles < env_int("DPGO_SPD_FINE_BWD", 256) || (wide_tiles < env_int("DPGO_SPD_FINE_BWD_TALL", 800) && longest >= 1000));
       const int rows = (wide_tiles > 0 && fine) ? 16 : 64;
-      // wide tiles first (one workgroup each), then the narrow ones (one wave each)
-      Level lev{(int)tiles.size(), 0, 0, rows};
-      for (int pass = 1; pass >= 0; pass--) {
-        const size_t begin = tiles.size();
-        const int th = pass == 1 ? rows : 64;
-        for (int f : lvl) {
-          if ((int)(wide(f, fwd) || merge) != pass) continue;
-          const int w = F.w[f], m = w + F.u[f], ext = fwd ? m : w;
-          for (int r = 0; r < ext; r += th) {
-            const int cnt = std::min(th, ext - r);
-            // forward: columns k < kend of rows r..; backward: rows p >= r of columns r..
-            const int64_t len = fwd ? ((r + th <= w) ? r + th : w) : (m - r);
-            tiles.push_back({f, r, cnt, th, len});
+      // node by node; within a node the wide tiles first (one workgroup each, longest first), then the narrow ones
+      // (one wave each): a launch picks the ranges of the nodes that are still live (Level::map)
+      Level lev{(int)tiles.size(), 0, 0, rows, std::vector<int>(nnodes, 0), std::vector<int>(nnodes, 0), std::vector<int>(nnodes, 0),
+                std::vector<int>(nnodes, 0), std::vector<double>(nnodes, 0.0)};
+      for (int f : lvl) lev.node_bytes[node_of_front(f)] += lvl_bytes(std::vector<int>{f});
+      for (int a = 0; a < nnodes; a++)
+        for (int pass = 1; pass >= 0; pass--) {
+          const size_t begin = tiles.size();
+          const int th = pass == 1 ? rows : 64;
+          for (int f : lvl) {
+            if (node_of_front(f) != a || (int)(wide(f, fwd) || merge) != pass) continue;
+            const int w = F.w[f], m = w + F.u[f], ext = fwd ? m : w;
+            for (int r = 0; r < ext; r += th) {
+              const int cnt = std::min(th, ext - r);
+              // forward: columns k < kend of rows r..; backward: rows p >= r of columns r..
+              const int64_t len = fwd ? ((r + th <= w) ? r + th : w) : (m - r);
+              tiles.push_back({f, r, cnt, th, len});
+            }
           }
+          std::stable_sort(tiles.begin() + begin, tiles.end(), [](const Tile &x, const Tile &y) { return x.len * x.count > y.len * y.count; });
+          (pass == 1 ? lev.wstart : lev.nstart)[a] = (int)begin;
+          (pass == 1 ? lev.wcount : lev.ncount)[a] = (int)(tiles.size() - begin);
+          (pass == 1 ? lev.nwide : lev.nnarrow) += (int)(tiles.size() - begin);
         }
-        std::stable_sort(tiles.begin() + begin, tiles.end(), [](const Tile &x, const Tile &y) { return x.len * x.count > y.len * y.count; });
-        (pass == 1 ? lev.nwide : lev.nnarrow) = (int)(tiles.size() - begin);
-      }
       out_levels.push_back(lev);
     }
     // panel offsets
@@ -165,7 +204,7 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
       it.front = f; it.first = t.first; it.count = t.count; it.w = F.w[f];
       it.u = F.u[f]; it.ld = ld; it.piv_ptr = F.piv_ptr[f]; it.upd_ptr = F.upd_ptr[f];
       it.pos_off = F.pos_off[f]; it.ubuf_off = F.ubuf_off[f];
-      it.node = node_of_unknown[F.piv_idx[F.piv_ptr[f]]];   // a front never spans two nodes (they are disconnected)
+      it.node = node_of_front(f);
       it.pad1 = 0;
       it.mat_off = total;
       it.pad2 = 0;
@@ -216,6 +255,70 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
   };
   sweep(true, fwd_levels, fwd_items, WT);
   sweep(false, bwd_levels, bwd_items, W);
+  // ---- the roots: tiles of the full w x w product L11^-T L11^-1, forward-style (rows of the front, all columns)
+  root_level = Level{0, 0, 0, 64, std::vector<int>(nnodes, 0), std::vector<int>(nnodes, 0), std::vector<int>(nnodes, 0),
+                     std::vector<int>(nnodes, 0), std::vector<double>(nnodes, 0.0)};
+  root_items.release();
+  Wroot.release();
+  if (fused_root) {
+    std::vector<int> roots;
+    for (int f = 0; f < F.nfronts; f++)
+      if (is_root(f)) roots.push_back(f);
+    int t64 = 0;
+    for (int f : roots) t64 += (F.w[f] + 63) / 64;
+    const int rows = t64 < env_int("DPGO_SPD_FINE_FWD", 192) ? 16 : 64;   // few tiles: 16-row tiles reach 4x more CUs
+    root_level.rows = rows;
+    std::vector<Tile> tiles;
+    for (int a = 0; a < nnodes; a++) {
+      const size_t begin = tiles.size();
+      for (int f : roots) {
+        if (node_of_front(f) != a) continue;
+        for (int r = 0; r < F.w[f]; r += rows) tiles.push_back({f, r, std::min(rows, F.w[f] - r), rows, (int64_t)F.w[f]});
+        root_level.node_bytes[a] += 8.0 * (double)F.w[f] * F.w[f] + 2.0 * 8.0 * dcols * F.w[f];
+      }
+      root_level.wstart[a] = (int)begin;
+      root_level.wcount[a] = (int)(tiles.size() - begin);
+      root_level.nwide += (int)(tiles.size() - begin);
+    }
+    std::vector<SpdItem> items(tiles.size());
+    std::vector<PanelSrc> srcs(tiles.size());
+    // where the roots' W_s = L11^-1 are: still on the device after a device factorisation, else uploaded here
+    std::vector<double> host_src;
+    std::vector<int64_t> src_off(F.nfronts, 0);
+    if (!F.dev_W)
+      for (int f : roots) {
+        src_off[f] = (int64_t)host_src.size();
+        host_src.insert(host_src.end(), F.W.begin() + F.w_off[f], F.W.begin() + F.w_off[f] + (size_t)F.w[f] * F.ldw[f]);
+      }
+    int64_t total = 0;
+    for (size_t i = 0; i < tiles.size(); i++) {
+      const Tile &t = tiles[i];
+      const int f = t.f, ld = (t.count + 15) / 16 * 16;
+      SpdItem it;
+      it.front = f; it.first = t.first; it.count = t.count; it.w = F.w[f];
+      it.u = 0; it.ld = ld; it.piv_ptr = F.piv_ptr[f]; it.upd_ptr = F.upd_ptr[f];
+      it.pos_off = F.pos_off[f]; it.ubuf_off = F.ubuf_off[f];
+      it.node = node_of_front(f);
+      it.pad1 = 1;
+      it.mat_off = total;
+      it.pad2 = 0;
+      items[i] = it;
+      srcs[i] = PanelSrc{(long long)(F.dev_W ? F.w_off[f] : src_off[f]), F.ldw[f], F.w[f]};
+      total += (int64_t)F.w[f] * ld;
+    }
+    if (!tiles.empty()) {
+      root_items.upload(items);
+      DevBuf<PanelSrc> srcs_dev;
+      srcs_dev.upload(srcs);
+      DevBuf<double> src_dev;
+      if (!F.dev_W) src_dev.upload(host_src);
+      Wroot.alloc((size_t)total);   // (zero-filled: the padding of a panel row stays zero)
+      launch_root_product(nullptr, root_items.p, srcs_dev.p, (int)tiles.size(), F.dev_W ? F.dev_W : src_dev.p, Wroot.p);
+      HIP_CHECK(hipDeviceSynchronize());
+    }
+    if (getenv("DPGO_SPD_DUMP"))
+      fprintf(stderr, "[spd] dof %d fused roots: %zu fronts, %zu tiles x %d rows, %.1f MB of panels\n", dof, roots.size(), tiles.size(), rows, total * 8e-6);
+  }
   spd_release_device(F);
   // the panels are on the device now: the host copy of the factor (gigabytes at the headline size) can go
   std::vector<double>().swap(F.W);
@@ -224,9 +327,10 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
   // (measured: G_tt with 177 MB of panels at two nodes per GPU still gains 2 % from staying; 288 MB does not)
   size_t keep = 200u << 20;
   if (const char *e = getenv("DPGO_SPD_KEEP_MB")) keep = (size_t)atol(e) << 20;
-  stream_once = sizeof(double) * (W.n + WT.n) > keep;
+  stream_once = sizeof(double) * (W.n + WT.n + Wroot.n) > keep;
   dev.piv_idx = piv_idx.p; dev.upd_idx = upd_idx.p; dev.asm_ptr = asm_ptr.p; dev.ubuf_dst = ubuf_dst.p;
   dev.W = W.p; dev.WT = WT.p; dev.fwd_items = fwd_items.p; dev.bwd_items = bwd_items.p; dev.ubuf = ubuf.p;
+  dev.root_items = root_items.p; dev.Wroot = Wroot.p;
 }
 
 static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec);
@@ -391,13 +495,19 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
     return;
   }
   cur_mask_ = ALL_NODES;
-  HIP_CHECK(hipHostMalloc((void **)&h_scal_, sizeof(double) * std::max(L, 1) * MAX_SLOTS + 128, hipHostMallocMapped | hipHostMallocCoherent));
-  h_flag_ = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(h_scal_) + sizeof(double) * std::max(L, 1) * MAX_SLOTS + 64);
+  // pinned: [scalars of k_reduce | a cache line | the flag's cache line | CG summaries | TNT summaries]
+  const size_t nsc = (size_t)std::max(L, 1) * MAX_SLOTS;
+  HIP_CHECK(hipHostMalloc((void **)&h_scal_, sizeof(double) * (nsc + 16 + (size_t)std::max(L, 1) * (CG_SUMMARY + TNT_SUMMARY)),
+                          hipHostMallocMapped | hipHostMallocCoherent));
+  h_flag_ = reinterpret_cast<unsigned long long *>(h_scal_ + nsc + 8);
   *h_flag_ = 0;
+  h_cg_ = h_scal_ + nsc + 16;
+  h_tnt_ = h_cg_ + (size_t)std::max(L, 1) * CG_SUMMARY;
+  for (int i = 0; i < std::max(L, 1) * (CG_SUMMARY + TNT_SUMMARY); i++) h_cg_[i] = 0.0;
   reduce_arrived_.alloc(1);
   partials_.alloc((size_t)MAX_SLOTS * std::max(T_.nseg_all, 1));
   cg_.alloc(MAX_LOCAL_NODES);
-  dmask_.alloc(2);
+  dmask_.alloc(4);
 
   upload_operators();
   // ---- inter-node edges (residual form) and their incidence lists
@@ -424,6 +534,22 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
     }
     e_tail_.upload(tail); e_head_.upload(head); e_R_.upload(R); e_t_.upload(t); e_kappa_.upload(kap);
     e_tau_.upload(tau); e_inc_ptr_.upload(iptr); e_inc_.upload(iv);
+    {
+      // one 128-byte record per incidence, in the order of the incidence lists (kernels.h: InterInc)
+      std::vector<InterInc> rec(std::max<size_t>(iv.size(), 1));
+      std::memset(rec.data(), 0, sizeof(InterInc) * rec.size());
+      for (size_t k = 0; k < iv.size(); k++) {
+        const int e = iv[k] >> 1, role = iv[k] & 1;
+        InterInc &r = rec[k];
+        r.other = role ? tail[e] : head[e];
+        r.code = iv[k];
+        r.tau = tau[e]; r.kappa = kap[e];
+        for (int i = 0; i < d_; i++) r.t[i] = t[(size_t)e * d_ + i];
+        for (int i = 0; i < d_ * d_; i++) r.R[i] = R[(size_t)e * d_ * d_ + i];
+      }
+      e_rec_.upload(rec);
+      E_.rec = e_rec_.p;
+    }
     E_.nrows_own = P0_; E_.nrows_all = P0_ + P1_;
     E_.m = (int)tail.size(); E_.tail = e_tail_.p; E_.head = e_head_.p; E_.R = e_R_.p; E_.t = e_t_.p;
     E_.kappa = e_kappa_.p; E_.tau = e_tau_.p; E_.inc_ptr = e_inc_ptr_.p; E_.inc = e_inc_.p;
@@ -724,30 +850,53 @@ void Group::copy_rows(double *dst, const double *src, bool all_rows, int part) {
 
 // out <- scale * A^-1 in (the unknowns' entries of the records; everything else in `out` is left alone).
 // The forward sweep only reads `in`, the backward sweep only touches `out`: in == out solves in place.
-void spd_run(int d, hipStream_t st, SpdSolverDev &S, NodeMask mask, double *in, double *out, double scale) {
-  auto total = [](const std::vector<SpdSolverDev::Level> &lv, const std::vector<double> &bytes, int &n) {
-    double b = 0;
-    n = 0;
-    for (size_t l = 0; l < lv.size(); l++)
-      if (lv[l].nwide + lv[l].nnarrow > 0) { b += bytes[l]; n++; }
-    return b;
-  };
-  int nf = 0, nb = 0;
-  const double bf = total(S.fwd_levels, S.fwd_level_bytes, nf), bb = total(S.bwd_levels, S.bwd_level_bytes, nb);
-  {
-  ProfSweep sweep(true, st, bf, nf);
-  for (size_t l = 0; l < S.fwd_levels.size(); l++) {
-    const SpdSolverDev::Level &v = S.fwd_levels[l];
-    launch_spd_level(d, S.dof, st, S.dev, true, v.tile0, v.nwide, v.nnarrow, v.rows, in, S.ytmp.p, scale, S.fwd_level_bytes[l],
-                     S.stream_once, mask);
+bool SpdSolverDev::Level::map(NodeBits bits, SpdLevelMap &M, double *bytes) const {
+  const int nw = spd_waves(rows);
+  M.nlive = 0;
+  M.pad = tile0;
+  int maxw = 0, maxn = 0;
+  double b = 0;
+  for (int a = 0; a < (int)wcount.size() && a < MAX_LOCAL_NODES; a++) {
+    if (!((bits >> a) & 1ull) || wcount[a] + ncount[a] == 0) continue;
+    const int j = M.nlive++;
+    M.node[j] = (unsigned char)a;
+    M.wstart[j] = wstart[a]; M.wcount[j] = wcount[a];
+    M.nstart[j] = nstart[a]; M.ncount[j] = ncount[a];
+    maxw = std::max(maxw, wcount[a]);
+    maxn = std::max(maxn, ncount[a]);
+    b += node_bytes[a];
   }
+  M.wide_wgs = M.nlive * maxw;
+  M.narrow_wgs = M.nlive * ((maxn + nw - 1) / nw);
+  if (bytes) *bytes = b;
+  return M.nlive > 0;
+}
+
+void spd_run(int d, hipStream_t st, SpdSolverDev &S, NodeMask mask, double *in, double *out, double scale) {
+  // the launches of the nodes in mask.v (what the host knows); mask.p, if any, is the device's more recent word
+  std::vector<SpdLevelMap> fm(S.fwd_levels.size()), bm(S.bwd_levels.size());
+  std::vector<double> fby(fm.size(), 0.0), bby(bm.size(), 0.0);
+  std::vector<char> fon(fm.size(), 0), bon(bm.size(), 0);
+  double bf = 0, bb = 0;
+  int nf = 0, nb = 0;
+  for (size_t l = 0; l < fm.size(); l++)
+    if ((fon[l] = S.fwd_levels[l].map(mask.v, fm[l], &fby[l]))) { bf += fby[l]; nf++; }
+  for (size_t l = 0; l < bm.size(); l++)
+    if ((bon[l] = S.bwd_levels[l].map(mask.v, bm[l], &bby[l]))) { bb += bby[l]; nb++; }
+  SpdLevelMap rm;
+  double rby = 0;
+  const bool ron = S.root_level.map(mask.v, rm, &rby);
+  if (ron && in == out) throw DeviceError("spd_run: the fused root step cannot solve in place");
+  {
+  ProfSweep sweep(true, st, bf + rby, nf + (ron ? 1 : 0));
+  for (size_t l = 0; l < fm.size(); l++)
+    if (fon[l]) launch_spd_level(d, S.dof, st, S.dev, 0, fm[l], S.fwd_levels[l].rows, in, S.ytmp.p, scale, fby[l], S.stream_once, mask);
+  // the roots: right-hand side from `in` (+ the children's updates), solution straight into `out`
+  if (ron) launch_spd_level(d, S.dof, st, S.dev, 2, rm, S.root_level.rows, in, out, scale, rby, S.stream_once, mask);
   }
   ProfSweep sweep(false, st, bb, nb);
-  for (size_t l = 0; l < S.bwd_levels.size(); l++) {
-    const SpdSolverDev::Level &v = S.bwd_levels[l];
-    launch_spd_level(d, S.dof, st, S.dev, false, v.tile0, v.nwide, v.nnarrow, v.rows, out, S.ytmp.p, scale, S.bwd_level_bytes[l],
-                     S.stream_once, mask);
-  }
+  for (size_t l = 0; l < bm.size(); l++)
+    if (bon[l]) launch_spd_level(d, S.dof, st, S.dev, 1, bm[l], S.bwd_levels[l].rows, out, S.ytmp.p, scale, bby[l], S.stream_once, mask);
 }
 
 // DPGO_SPD_DUMP=1: time every launch of one solve on a zero vector (HIP events, best of 5) and print its
@@ -763,18 +912,29 @@ static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec) {
     size_t most = 1;
     for (const auto &v : S.fwd_levels) most = std::max(most, (size_t)(v.nwide + v.nnarrow));
     for (const auto &v : S.bwd_levels) most = std::max(most, (size_t)(v.nwide + v.nnarrow));
+    most = std::max(most, (size_t)S.root_level.nwide);
     HIP_CHECK(hipMalloc(&trace, most * 6 * 8));
     HIP_CHECK(hipMemset(trace, 0, most * 6 * 8));
     spd_trace_set(trace);
   }
-  auto run = [&](bool fwd, size_t l, const SpdSolverDev::Level &v, const std::vector<int> &fronts, double bytes) {
+  auto is_root = [&](int f) { return S.fused_root && F.parent[f] < 0 && F.u[f] == 0 && F.w[f] > 0; };
+  auto run = [&](int mode, size_t l, const SpdSolverDev::Level &v, const std::vector<int> &fronts_all) {
     if (v.nwide + v.nnarrow == 0) return;
+    const bool fwd = mode != 1;
     int wmax = 0, mmax = 0;
+    std::vector<int> fronts;
+    for (int f : fronts_all)
+      if (is_root(f) == (mode == 2)) fronts.push_back(f);
     for (int f : fronts) { wmax = std::max(wmax, F.w[f]); mmax = std::max(mmax, F.w[f] + F.u[f]); }
+    double bytes = 0;
+    for (double b : v.node_bytes) bytes += b;
     float best = 1e30f;
     for (int rep = 0; rep < 6; rep++) {
       HIP_CHECK(hipEventRecord(e0, st));
-      launch_spd_level(d, S.dof, st, S.dev, fwd, v.tile0, v.nwide, v.nnarrow, v.rows, vec, S.ytmp.p, 1.0, 0.0, S.stream_once, ALL_NODES);
+      SpdLevelMap M;
+      v.map(~0ull, M);
+      // (mode 2 on a zero vector: in and out may be the same array here, nothing is compared)
+      launch_spd_level(d, S.dof, st, S.dev, mode, M, v.rows, vec, mode == 2 ? vec : S.ytmp.p, 1.0, 0.0, S.stream_once, ALL_NODES);
       HIP_CHECK(hipEventRecord(e1, st));
       HIP_CHECK(hipEventSynchronize(e1));
       float ms;
@@ -809,10 +969,13 @@ static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec) {
       }
     }
     fprintf(stderr, "[spd] dof %d %s level %2zu fronts %5zu wide tiles %5d x %2d rows, narrow tiles %5d, max_w %4d max_m %4d  %7.2f MB %6.1f us %6.0f GB/s\n",
-            S.dof, fwd ? "fwd" : "bwd", l, fronts.size(), v.nwide, v.rows, v.nnarrow, wmax, mmax, bytes / 1e6, best * 1e3, bytes / (best * 1e-3) / 1e9);
+            S.dof, mode == 2 ? "root" : (fwd ? "fwd" : "bwd"), l, fronts.size(), v.nwide, v.rows, v.nnarrow, wmax, mmax, bytes / 1e6, best * 1e3, bytes / (best * 1e-3) / 1e9);
   };
-  for (size_t l = 0; l < S.fwd_levels.size(); l++) run(true, l, S.fwd_levels[l], F.by_height[l], S.fwd_level_bytes[l]);
-  for (size_t l = 0; l < S.bwd_levels.size(); l++) run(false, l, S.bwd_levels[l], F.by_depth[l], S.bwd_level_bytes[l]);
+  std::vector<int> every(F.nfronts);
+  for (int f = 0; f < F.nfronts; f++) every[f] = f;
+  for (size_t l = 0; l < S.fwd_levels.size(); l++) run(0, l, S.fwd_levels[l], F.by_height[l]);
+  run(2, 0, S.root_level, every);
+  for (size_t l = 0; l < S.bwd_levels.size(); l++) run(1, l, S.bwd_levels[l], F.by_depth[l]);
   fprintf(stderr, "[spd] dof %d total %.1f MB %.1f us %.0f GB/s (launches timed one by one)\n", S.dof, tot_mb, tot_us, tot_mb / tot_us * 1e3);
   if (trace) {
     spd_trace_set(nullptr);
@@ -823,9 +986,7 @@ static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec) {
 }
 
 // (fronts of nodes outside the current mask are skipped: their entries of `out` stay as they are)
-void Group::solve_tt(double *vec, double scale) { spd_run(d_, st_, Ltt_, cur_mask_, vec, vec, scale); }
 void Group::solve_tt(double *in, double *out, double scale) { spd_run(d_, st_, Ltt_, cur_mask_, in, out, scale); }
-void Group::solve_rr(double *vec, double scale) { spd_run(d_, st_, Lrr_, cur_mask_, vec, vec, scale); }
 void Group::solve_rr(double *in, double *out, double scale) { spd_run(d_, st_, Lrr_, cur_mask_, in, out, scale); }
 
 // X.t = -G_tt^-1 (g_t + G_tR X.R)    (DPGOProblem.h:275-294)
@@ -839,8 +1000,10 @@ void Group::recover_translations(double *X, const double *g) {
 
 // y = base + G_{:,t} xt.t, with the row-local epilogues of launch_bsr_tcol
 void Group::apply_tcol(const double *xt, const double *base, double *y, int mode, const double *X, const double *nabla,
-                       const double *Rdot, double *out2, const double *rres, double *partials) {
-  launch_bsr_tcol(d_, st_, T_, cur_mask_, G_.dev, G_.tcol.p, xt, base, y, mode, X, nabla, Rdot, out2, rres, partials);
+                       const double *Rdot, double *out2, const double *rres, double *partials, const double *dg,
+                       const double *dga, const double *ds, const double *dgrad, const double *dhs) {
+  launch_bsr_tcol(d_, st_, T_, cur_mask_, G_.dev, G_.tcol.p, xt, base, y, mode, X, nabla, Rdot, out2, rres, partials, dg, dga,
+                  ds, dgrad, dhs);
 }
 
 // partial[slot] = tr(X^T (g + 1/2 G X))     (DPGOProblem.cpp:180-205; + f on the host)
@@ -1301,11 +1464,13 @@ int Group::update(const std::vector<int> &locals_in) {
   std::vector<int> adv;
   for (int a : locals)
     if (res_[a].hist_iter != res_[a].iters) adv.push_back(a);
+  bool zc_done = false;
   if ((int)adv.size() == num_local()) {
     // every node advances: rotate the buffers instead of copying them
     Zp_.swap(Zc_);
     gp_.swap(gc_);
     Dfp_.swap(Dfc_);
+    zc_done = zc_ready_;   // iterate() already left Xk's own rows in what is X[iter] now
   } else if (!adv.empty()) {
     set_mask(adv);
     copy_rows(Zp_.p, Zc_.p, true);
@@ -1335,7 +1500,8 @@ int Group::update(const std::vector<int> &locals_in) {
       logic();
     }
   };
-  copy_rows(Zc_.p, Xk_.p, false);
+  zc_ready_ = false;
+  if (!zc_done) copy_rows(Zc_.p, Xk_.p, false);
   if (trivial)   // T1 = G Xak and <Xak, 1/2 G Xak>   (half of evaluate_G, DPGOProblem.cpp:180-205)
     launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xak_.p, false, nullptr, T1_.p, Xak_.p, 0.5, nullptr, partials_.p, 5);
   else           // T1 = G X and <X, 1/2 G X>
@@ -1433,7 +1599,11 @@ int Group::iterate(const std::vector<int> &locals) {
   const int rc = opt_.scheme == 1 ? amm(locals) : mm(locals);
   if (rc != 0) return rc;
   set_mask(locals);
-  copy_rows(Xk_.p, Xak_.p, false);   // Xk.top = Xak   (:614)
+  // Xk.top = Xak (:614).  When every node of the group iterated, the same pass also writes the buffer that the next
+  // update() turns into X[iter] (it rotates the history buffers when every node advances; X[iter-1], which that buffer
+  // holds now, has had its last reader), so update() need not copy Xk's own rows again.
+  zc_ready_ = (int)locals.size() == num_local() && !star_;
+  launch_axpby(d_, st_, T_, false, cur_mask_, 1.0, Xak_.p, 0.0, nullptr, Xk_.p, 0, zc_ready_ ? Zp_.p : nullptr);
   for (int a : locals) {
     res_[a].iters++;
     res_[a].updated = 0;
@@ -1648,12 +1818,13 @@ int Group::debug_apply(int a, const char *op_c, const double *in, int ld_in, dou
     get_own(C, out, ld_out, 0, 0, false);
   } else if (op == "solve_tt" || op == "solve_rr") {
     put_own(A, in, ld_in, 0, n0, true);
-    if (op == "solve_tt") solve_tt(A, 1.0);
+    put_own(Bv, in, ld_in, 0, n0, true);   // (the solve writes the unknowns' entries only: the rest of the answer is the input's)
+    if (op == "solve_tt") solve_tt(A, Bv, 1.0);
     else {
       if (Lrr_.F.n == 0) return -1;
-      solve_rr(A, 1.0);
+      solve_rr(A, Bv, 1.0);
     }
-    get_own(A, out, ld_out, 0, n0, true);
+    get_own(Bv, out, ld_out, 0, n0, true);
   } else if (op == "G") {
     put_own(A, in, ld_in, 0, n0, true);
     launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, A, false, nullptr, Bv, nullptr, 0, nullptr, nullptr, 0);

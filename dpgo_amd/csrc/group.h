@@ -123,8 +123,22 @@ struct SpdSolverDev {
   DevBuf<int> piv_idx, upd_idx, asm_ptr, ubuf_dst;
   DevBuf<double> W, WT, ubuf, ytmp;   // W / WT: backward / forward panels (see upload)
   DevBuf<SpdItem> fwd_items, bwd_items;
-  struct Level { int tile0, nwide, nnarrow, rows; };   // one launch: wide tiles (rows high) first, then narrow ones
-  std::vector<Level> fwd_levels, bwd_levels;
+  // one launch.  Tiles [tile0, tile0 + nwide + nnarrow) of the sweep's item list, stored node by node: node a's wide
+  // tiles (rows high) are [wstart[a], wstart[a] + wcount[a]), its narrow ones [nstart[a], nstart[a] + ncount[a])
+  struct Level {
+    int tile0, nwide, nnarrow, rows;
+    std::vector<int> wstart, wcount, nstart, ncount;
+    std::vector<double> node_bytes;   // algorithmic bytes of the level per node
+    // the launch for the nodes of `bits` (false: none of them has a tile here); bytes: their share of the level
+    bool map(NodeBits bits, SpdLevelMap &M, double *bytes = nullptr) const;
+  };
+  std::vector<Level> fwd_levels, bwd_levels;   // (without the roots of the trees)
+  // the roots: forward and backward step fused into one launch over the explicit inverse of the root's Schur
+  // complement (k_spd_level MODE 2); DPGO_SPD_FUSE_ROOT=0 keeps them in the two sweeps
+  Level root_level{0, 0, 0, 64, {}, {}, {}, {}, {}};
+  bool fused_root = false;
+  DevBuf<SpdItem> root_items;
+  DevBuf<double> Wroot;
   std::vector<double> fwd_level_bytes, bwd_level_bytes;
   SpdDev dev;
   int dof = 1;
@@ -132,7 +146,7 @@ struct SpdSolverDev {
   void upload(int dcols, const std::vector<int> &node_of_unknown);   // node_of_unknown: local node of every row of A
 };
 
-// out <- scale * A^-1 in on the unknowns' entries of the records (everything else in `out` is left alone)
+// out <- scale * A^-1 in on the unknowns' entries of the records (everything else in `out` is left alone); in != out
 void spd_run(int d, hipStream_t st, SpdSolverDev &S, NodeMask mask, double *in, double *out, double scale);
 
 class Group {
@@ -245,16 +259,20 @@ class Group {
   NodeMask cur_mask_ = ALL_NODES;  // the nodes the launches work on (set_mask), passed to the kernels by value
   double *h_scal_ = nullptr;       // pinned, written by k_reduce; the flag (one cache line further) follows the scalars
   unsigned long long *h_flag_ = nullptr, fetch_seq_ = 0;
+  double *h_cg_ = nullptr, *h_tnt_ = nullptr;   // pinned summaries of k_cg_scal / k_tnt_begin (same allocation as h_scal_)
+  bool zc_ready_ = false;       // iterate() wrote Xk's own rows into the buffer the next update() rotates into X[iter]
+  bool tnt_speculate_ = true;   // run_tnt: take the trial point behind the first CG step without waiting for its outcome
   DevBuf<unsigned> reduce_arrived_;
   DevBuf<double> partials_;
   DevBuf<CgNode> cg_;       // device-resident state of the truncated CG (tnt.cpp, k_cg_scal)
   DevBuf<double> jacobi_;   // Preconditioner::Jacobi: 1 / diag(G_RR), one entry per rotation row
-  DevBuf<NodeBits> dmask_;  // [0] nodes taking the next Hessian product, [1] nodes going on to the preconditioner
+  DevBuf<NodeBits> dmask_;  // [0] nodes taking the next Hessian product, [1] nodes going on to the preconditioner, [2] nodes whose CG is over
   struct BsrBufs { DevBuf<int> ptr, col; DevBuf<double> val, tcol; BsrDev dev; };   // tcol: first column of every block (G only)
   BsrBufs G_, S_, P_, P0m_, Q_;
   DevBuf<double> Dd_, Qd_, Tinv_, N_, V_;
   DevBuf<int> e_tail_, e_head_, e_inc_ptr_, e_inc_;
   DevBuf<double> e_R_, e_t_, e_kappa_, e_tau_;
+  DevBuf<InterInc> e_rec_;        // the same data once more, one record per incidence (k_inter)
   InterEdgesDev E_;
   DevBuf<int> i_tail_, i_head_, i_inc_ptr_, i_inc_;
   DevBuf<double> i_R_, i_t_, i_kappa_, i_tau_;
@@ -305,13 +323,13 @@ class Group {
   int deferred_slots_ = 0;   // slots written earlier that ride along with the next fetch (saves a host round trip)
   double scal(int local, int s) const { return h_scal_[local * MAX_SLOTS + s]; }
   void copy_rows(double *dst, const double *src, bool all_rows, int part = 0);
-  void solve_tt(double *vec, double scale);
   void solve_tt(double *in, double *out, double scale);   // out.t <- scale * G_tt^-1 in.t
   void solve_rr(double *in, double *out, double scale);   // out.R <- scale * (G_RR + lambda I)^-1 in.R
   void apply_tcol(const double *xt, const double *base, double *y, int mode = 0, const double *X = nullptr,
                   const double *nabla = nullptr, const double *Rdot = nullptr, double *out2 = nullptr,
-                  const double *rres = nullptr, double *partials = nullptr);
-  void solve_rr(double *vec, double scale);               // in place on rotation rows
+                  const double *rres = nullptr, double *partials = nullptr, const double *dg = nullptr,
+                  const double *dga = nullptr, const double *ds = nullptr, const double *dgrad = nullptr,
+                  const double *dhs = nullptr);
   void recover_translations(double *X, const double *g);  // X.t = -Gtt^-1 (g_t + G_tR X.R) for masked nodes
   void eval_G(const double *X, const double *g, int slot);
   void host_update_logic(int local, double fobj, double f, double gradFnorm);

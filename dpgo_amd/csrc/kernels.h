@@ -73,7 +73,17 @@ struct BsrDev {
 };
 
 // Inter-node edges of the local nodes, B-form (residual) data.
+// One incidence of an inter-node edge (edge e seen from one of its poses), everything k_inter needs in ONE 128-byte
+// record: the other endpoint, the edge and the role (code = 2 e + (0 tail | 1 head)), the measurement.  The records
+// of a row are consecutive (the order of inc): a row's chain is inc_ptr -> record -> the other pose, and an incidence
+// costs one cache line instead of the six that tail/head, R, t, kappa, tau in separate arrays touch.
+struct alignas(16) InterInc {
+  int other, code;
+  double tau, kappa, t[3], R[9], pad;
+};
+static_assert(sizeof(InterInc) == 128, "InterInc is loaded as eight 16-byte quads");
 struct InterEdgesDev {
+  const InterInc *rec = nullptr;                // per incidence (optional: k_inter; the arrays below serve k_cost)
   int m = 0, nrows_own = 0, nrows_all = 0;
   const int *tail = nullptr, *head = nullptr;   // unified pose ids
   const double *R = nullptr;                    // d*d row-major
@@ -103,10 +113,17 @@ void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMas
 // mode 1: also out2 = [0 ; Proj_X(y.R)]; mode 2: y not stored, out2 = [0 ; Proj_X(y.R - sym(nabla.R X.R^T) Rdot.R)], the Hessian-vector product (DPGOProblem.cpp:570-574)
 // mode 2 with partials: slots 0..3 = <Rdot, out2>, <out2, out2>, <Rdot, Rdot>, <Rdot, rres> (the four scalars of a
 // CG step, IterativeSolvers.h:296-347) in the same pass
+// mode 1 with partials and dg / dga: slots 0..3 = |out2|^2, <X, y>, <X, dg>, <X, dga> (the start of a refinement: gradient
+// norm and f from the model gradient y)
+// mode 0 with partials and ds / dgrad / dhs / dg / dga: slots 0..5 = <ds,ds>, <dgrad,ds>, <ds,dhs> (rotation rows),
+// <xt,dg>, <xt,dga>, <xt,y> (the sums of a trial point xt, TNT.h:505-536)
+// (the epilogue sums always occupy 6 consecutive slots)
 void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, const BsrDev &A, const double *tval,
                      const double *xt, const double *base, double *y, int mode = 0, const double *X = nullptr,
                      const double *nabla = nullptr, const double *Rdot = nullptr, double *out2 = nullptr,
-                     const double *rres = nullptr, double *partials = nullptr);
+                     const double *rres = nullptr, double *partials = nullptr, const double *dg = nullptr,
+                     const double *dga = nullptr, const double *ds = nullptr, const double *dgrad = nullptr,
+                     const double *dhs = nullptr);
 
 // Robust inter-edge pass (B-form, DPGOProblem.cpp:634-725).
 //  mode 0 (update): all rows.  DfE <- B1^T W B1 Z; own rows also g <- DfE - D z.
@@ -136,8 +153,9 @@ void launch_proximal(int d, hipStream_t st, const SegTable &T, NodeMask mask, co
 void launch_extrapolate(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask,
                         const NodeCoefs &gamma, const double *a, const double *b, double *out);
 // out = alpha * a + beta * b  (b may be null); parts: 0 whole record, 1 translation only, 2 rotation only
+// out2 (part 0 only): a second copy of the result
 void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask, double alpha,
-                  const double *a, double beta, const double *b, double *out, int part);
+                  const double *a, double beta, const double *b, double *out, int part, double *out2 = nullptr);
 // out = C.a[node] * a + C.b[node] * b over own rows
 void launch_axpby_node(int d, hipStream_t st, const SegTable &T, NodeMask mask, const NodeCoefs &C, const double *a,
                        const double *b, double *out);
@@ -163,10 +181,11 @@ void launch_tangent_full(int d, hipStream_t st, const SegTable &T, NodeMask mask
 // dst = src on the neighbour rows only
 void launch_copy_nbr_rows(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *src, double *dst);
 // out.Y = Proj_R(in.Y), out.x = 0                                       (DPGOProblem.cpp:164-178)
-// with dotv: partial[slot] = <dotv.Y, out.Y> in the same pass
+// with dotv: partial[slot] = <dotv.Y, out.Y> in the same pass; two: partial[slot] = |out.Y|^2, partial[slot + 1] = <dotv.Y, out.Y>
+// neg: also neg = -out (the first CG direction)
 void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
                         const double *in, double *out, const double *dotv = nullptr, double *partials = nullptr,
-                        int slot = 0);
+                        int slot = 0, bool two = false, double *neg = nullptr);
 // out.Y rows = dinv (one entry per rotation row) * in.Y rows: Preconditioner::Jacobi   (DPGOProblem.cpp:96-98, 583-585)
 void launch_rot_rowscale(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *dinv, const double *in, double *out);
 // out.Y = proj_SO(d)(X.Y + V.Y); out.x = 0                              (SOdProduct.h:111-116)
@@ -185,14 +204,21 @@ void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows,
                    double *host_scalars, unsigned *arrived, unsigned long long *host_flag, unsigned long long seq);
 
 // ---- device-side control of the truncated CG (tnt.cpp) ----
-// cg_begin: state of the nodes in `bits` from the start values; dmask[0] = dmask[1] = bits.
+constexpr int CG_SUMMARY = 4;    // doubles per node k_cg_scal writes to pinned memory: live, |h|_M, iterations
+constexpr int TNT_SUMMARY = 8;   // doubles per node k_tnt_begin writes: the six sums it reduced, then `active`
+// tnt_begin: the first trust-region iteration's norms, gradient tests and CG start values, all on the device (see k_tnt_begin)
+void launch_tnt_begin(hipStream_t st, const SegTable &T, int nnodes, NodeBits bits, bool use_precon, int max_it, double grad_tol,
+                      double pgrad_tol, double kappa, double theta, const double *Delta, const double *partials, CgNode *cg,
+                      NodeBits *dmask, double *host_tnt);
+// cg_begin: state of the nodes in `bits` from the start values; dmask[0] = dmask[1] = the live ones, dmask[2] = the others.
 void launch_cg_begin(hipStream_t st, int nnodes, NodeBits bits, const CgStart &S, int max_it, CgNode *cg, NodeBits *dmask);
 // dmask[0]: the nodes of the step under way; dmask[1]: the nodes that go on after it.
 // phase 0 (after H p and its four dot products, partial slots 0..3): step length / boundary / negative-curvature
 // logic of IterativeSolvers.h:296-362; nodes that stop are cleared from dmask[1].
 // phase 1 (after the preconditioner and <r, v>, partial slot 0): beta and the recurrences (:364-390), then the
 // stopping test of the next step (:285-291); nodes that stop are cleared from dmask[1], then dmask[0] = dmask[1].
-// Either phase ends by writing, per node, (live, h_M_norm, cg_it) to host_scalars[node * MAX_SLOTS + 0..2] and
+// dmask[2] collects the nodes whose CG has ended (their trial point may be taken).
+// Either phase ends by writing, per node, (live, h_M_norm, cg_it) to host_scalars[node * CG_SUMMARY + 0..2] and
 // raising *host_flag to seq (same protocol as launch_reduce).
 void launch_cg_scal(hipStream_t st, const SegTable &T, int nnodes, int phase, const double *partials, CgNode *cg,
                     NodeBits *dmask, double *host_scalars, unsigned *arrived, unsigned long long *host_flag,
@@ -215,10 +241,23 @@ struct SpdDev {
   const int *ubuf_dst = nullptr;  // per update row of a front (ubuf_off + r): its row in the update buffer
   const double *W = nullptr, *WT = nullptr;           // panels of the backward / forward tiles
   const SpdItem *fwd_items = nullptr, *bwd_items = nullptr;
+  const SpdItem *root_items = nullptr;   // the fused root tiles (k_spd_level MODE 2) and their panels
+  const double *Wroot = nullptr;
   double *ubuf = nullptr;
 };
-// One level of the forward / backward sweep: tiles [tile0, tile0 + nwide) are wide (`rows` = 64 or 16 high, one
-// workgroup each), the next nnarrow tiles are narrow (one wave each).
+// One level of the forward / backward sweep.  The tiles of a level are stored node by node -- a node's wide tiles
+// (`rows` = 64 or 16 high, one workgroup each, longest first), then its narrow ones (one wave each) -- and a launch
+// covers the nodes the host still counts as live: workgroup b works for live slot b % nlive on that node's
+// (b / nlive)-th tile, so the grid shrinks with the set of nodes (a masked-out node costs no workgroup at all), a
+// node's longest tiles still start first, and with 8 live nodes a node's tiles all run on one XCD (round-robin
+// dispatch), next to its vectors in that XCD's L2.  All of it is decided from kernel arguments: no load before the
+// tile's own descriptor.
+struct SpdLevelMap {
+  int nlive = 0, wide_wgs = 0, narrow_wgs = 0, pad = 0;   // wide_wgs = nlive * max wcount, narrow_wgs = nlive * ceil(max ncount / waves); pad: first tile of the level (trace builds)
+  int wstart[MAX_LOCAL_NODES], wcount[MAX_LOCAL_NODES];   // per live slot: first wide tile (index into the sweep's items), how many
+  int nstart[MAX_LOCAL_NODES], ncount[MAX_LOCAL_NODES];   // the same for the narrow tiles
+  unsigned char node[MAX_LOCAL_NODES];                    // local node of the slot
+};
 // dof = 1: unknown i is the translation of pose i; dof = d: unknown i = (pose i / d, rotation row i % d).
 // vec is a record array: forward reads the right-hand side from vec and writes y to ytmp (n x d, the pivots
 // of a front consecutive); backward reads ytmp and writes scale * A^-1 b into vec (scale must be +1 or -1).
@@ -228,9 +267,14 @@ struct PanelSrc { long long src_off; int src_ld; int len; };
 void launch_pack_panels(hipStream_t st, const SpdItem *items, const PanelSrc *srcs, int ntiles, const double *src, double *panels);
 // measurement builds (-DSPD_TRACE) only: where the solve tiles write their phase timestamps (6 per tile); no-op otherwise
 void spd_trace_set(unsigned long long *p);
-void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int tile0, int nwide, int nnarrow,
-                      int rows, double *vec, double *ytmp, double scale, double level_bytes = 0.0, bool stream_once = true,
-                      NodeMask mask = ALL_NODES);   // nodes outside the mask: their fronts are skipped
+int spd_waves(int rows);   // waves (= narrow tiles) per workgroup of the class with `rows`-high wide tiles
+// mode 0: a forward level; 1: a backward level; 2: the roots of the trees, forward and backward step in one pass (vec: the
+// right-hand side records, ytmp: the records that receive scale * A^-1 b on the roots' unknowns; must not be the same array)
+void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, int mode, const SpdLevelMap &M, int rows,
+                      double *vec, double *ytmp, double scale, double level_bytes = 0.0, bool stream_once = true,
+                      NodeMask mask = ALL_NODES);   // mask.p: the device-side mask (nodes that stopped since the host last looked)
+// panels of the fused root tiles from the roots' L11^-1 (see k_root_product); srcs[i].src_off / src_ld locate the front's W_s
+void launch_root_product(hipStream_t st, const SpdItem *items, const PanelSrc *srcs, int ntiles, const double *src, double *panels);
 
 // ---- optional per-launch timing (HIP events on the launch stream), off by default ----
 enum ProfKind { PK_BSR = 0, PK_INTER, PK_PROX, PK_AXPBY, PK_DOT, PK_ROTOP, PK_COPYIDX, PK_BDIAG, PK_REDUCE,

@@ -384,6 +384,10 @@ __device__ __forceinline__ void hess_epilogue_rows(const double *R, const double
   tangent_proj<D>(R, F, out);
 }
 
+// more vectors for the dot-product epilogues of k_bsr_tcol
+struct TcolDots {
+  const double *s = nullptr, *grad = nullptr, *hs = nullptr, *g = nullptr, *ga = nullptr;
+};
 // y = base + A[:, translation column] t: what A x adds when only the translation rows of x change.  The
 // first column of every (d+1) x (d+1) block is kept in a compact copy (tval, d+1 doubles per block), so
 // this pass moves a quarter of the operator.  Used after a G_tt solve: G [t ; R] = G [0 ; R] + G_{:,t} t,
@@ -396,12 +400,12 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr_tcol(const Seg *segs, Node
                                                          const double *xt, const double *base, double *y, int mode,
                                                          const double *X, const double *nabla, const double *Rdot,
                                                          double *out2, const double *rres, double *partial,
-                                                         int pstride) {
+                                                         int pstride, TcolDots E) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
   if (!node_on(mask, s.node)) return;   // (partials of a node outside the mask are never read)
   const int row = s.begin + (threadIdx.x >> 2), j = threadIdx.x & 3;
-  double pr[4] = {0.0, 0.0, 0.0, 0.0};
+  double pr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   double acc[RS];
 #pragma unroll
   for (int k = 0; k < RS; k++) acc[k] = 0.0;
@@ -428,13 +432,48 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr_tcol(const Seg *segs, Node
 #pragma unroll
     for (int k = 0; k < RS; k++) acc[k] += bv[k];
     if (mode != 2) store_vec<RS>(y + (size_t)row * RS, acc);
+    if (mode == 0 && partial) {
+      // the six sums of a trial point x+ (= xt), TNT.h:505-536: <s,s>, <grad,s>, <s,Hs> over the rotation rows,
+      // <x+, g>, <x+, g_alt>, <x+, G x+ + g> over the whole record
+      double xp[RS], sv[RS], gv[RS], hv[RS], g1[RS], g2[RS];
+      load_vec<RS>(xt + (size_t)row * RS, xp);
+      load_vec<RS>(E.s + (size_t)row * RS, sv);
+      load_vec<RS>(E.grad + (size_t)row * RS, gv);
+      load_vec<RS>(E.hs + (size_t)row * RS, hv);
+      load_vec<RS>(E.g + (size_t)row * RS, g1);
+      load_vec<RS>(E.ga + (size_t)row * RS, g2);
+#pragma unroll
+      for (int k = 0; k < RS; k++) {
+        if (k >= D) {
+          pr[0] = fma(sv[k], sv[k], pr[0]);
+          pr[1] = fma(gv[k], sv[k], pr[1]);
+          pr[2] = fma(sv[k], hv[k], pr[2]);
+        }
+        pr[3] = fma(xp[k], g1[k], pr[3]);
+        pr[4] = fma(xp[k], g2[k], pr[4]);
+        pr[5] = fma(xp[k], acc[k], pr[5]);
+      }
+    }
     if (mode != 0) {
       double x[RS], o[RS];
       load_vec<RS>(X + (size_t)row * RS, x);
 #pragma unroll
       for (int k = 0; k < D; k++) o[k] = 0.0;
-      if (mode == 1) tangent_proj<D>(x + D, acc + D, o + D);
-      else {
+      if (mode == 1) {
+        tangent_proj<D>(x + D, acc + D, o + D);
+        if (partial) {   // |grad|^2 (rotation rows), <X, nabla>, <X, g>, <X, g_alt>: the start of a refinement (tnt.cpp)
+          double g1[RS], g2[RS];
+          load_vec<RS>(E.g + (size_t)row * RS, g1);
+          load_vec<RS>(E.ga + (size_t)row * RS, g2);
+#pragma unroll
+          for (int k = 0; k < RS; k++) {
+            if (k >= D) pr[0] = fma(o[k], o[k], pr[0]);
+            pr[1] = fma(x[k], acc[k], pr[1]);
+            pr[2] = fma(x[k], g1[k], pr[2]);
+            pr[3] = fma(x[k], g2[k], pr[3]);
+          }
+        }
+      } else {
         double nb[RS], rd[RS];
         load_vec<RS>(nabla + (size_t)row * RS, nb);
         load_vec<RS>(Rdot + (size_t)row * RS, rd);
@@ -454,7 +493,7 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr_tcol(const Seg *segs, Node
       store_vec<RS>(out2 + (size_t)row * RS, o);
     }
   }
-  if (partial) block_store<4, 4 * SEG_ROWS / 64>(pr, partial + SEGB, pstride);
+  if (partial) block_store<6, 4 * SEG_ROWS / 64>(pr, partial + SEGB, pstride);
 }
 
 // ---------------------------------------------------------------------------
@@ -496,15 +535,20 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask ma
     for (int k = 0; k < RS; k++) acc[k] = 0.0;
     const int k1 = E.inc_ptr[row + 1];
     for (int k = E.inc_ptr[row]; k < k1; k++) {
-      const int code = E.inc[k], e = code >> 1, role = code & 1;
-      const int other = role ? E.tail[e] : E.head[e];
+      // the incidence's record: eight 16-byte loads of one line, then the other pose
+      union { double2 q[8]; InterInc r; } u8;
+      const double2 *rq = reinterpret_cast<const double2 *>(E.rec + k);
+#pragma unroll
+      for (int i = 0; i < 8; i++) u8.q[i] = rq[i];
+      const int code = u8.r.code, e = code >> 1, role = code & 1;
+      const int other = u8.r.other;
       double zo[RS], Re[D * D], te[D];
       load_vec<RS>(Z + (size_t)other * RS, zo);
 #pragma unroll
-      for (int i = 0; i < D * D; i++) Re[i] = E.R[(size_t)e * D * D + i];
+      for (int i = 0; i < D * D; i++) Re[i] = u8.r.R[i];
 #pragma unroll
-      for (int i = 0; i < D; i++) te[i] = E.t[(size_t)e * D + i];
-      const double tau = E.tau[e], kap = E.kappa[e];
+      for (int i = 0; i < D; i++) te[i] = u8.r.t[i];
+      const double tau = u8.r.tau, kap = u8.r.kappa;
       const double *zi = role ? zo : zp;   // tail record
       const double *zj = role ? zp : zo;   // head record
       double u[D], W[D * D];
@@ -768,7 +812,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_extrapolate(const Seg *segs, NodeM
 // whole 16-byte loads and stores, the untouched part of `out` is carried through registers
 template <int D, int PART>
 __global__ __launch_bounds__(SEG_ROWS) void k_axpby(const Seg *segs, NodeMask mask, double alpha, const double *a,
-                                                    double beta, const double *b, double *out) {
+                                                    double beta, const double *b, double *out, double *out2) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
   if (!node_on(mask, s.node)) return;
@@ -785,6 +829,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_axpby(const Seg *segs, NodeMask ma
     va[k] = in ? v : vo[k];
   }
   store_vec<RS>(out + (size_t)row * RS, va);
+  if (PART == 0 && out2) store_vec<RS>(out2 + (size_t)row * RS, va);   // a second copy of the result
 }
 
 // out = alpha[node] * a + beta[node] * b  (per-node coefficients: batched CG updates)
@@ -979,12 +1024,12 @@ __global__ __launch_bounds__(SEG_ROWS) void k_tangent_full(const Seg *segs, Node
 template <int D>
 __global__ __launch_bounds__(SEG_ROWS) void k_rot_op(const Seg *segs, NodeMask mask, int mode, const double *X,
                                                 const double *in, const double *dotv, double *partial,
-                                                double *out) {
+                                                double *out, int pstride, int two, double *neg) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
   if (!node_on(mask, s.node)) return;
   const int row = s.begin + threadIdx.x;
-  double pr[1] = {0.0};
+  double pr[2] = {0.0, 0.0};
   if (row < s.end) {
     double x[RS], v[RS], o[RS];
     load_vec<RS>(X + (size_t)row * RS, x);
@@ -1001,16 +1046,28 @@ __global__ __launch_bounds__(SEG_ROWS) void k_rot_op(const Seg *segs, NodeMask m
       project_sod<D>(M, o + D);
     }
     store_vec<RS>(out + (size_t)row * RS, o);
-    if (partial) {   // <dotv, out> over the rotation rows
+    if (partial) {   // <dotv, out> over the rotation rows; two: <out, out> first, then <dotv, out>
       double dv[RS];
       load_vec<RS>(dotv + (size_t)row * RS, dv);
-      double p = 0;
+      double p = 0, q = 0;
 #pragma unroll
-      for (int k = D; k < RS; k++) p = fma(dv[k], o[k], p);
-      pr[0] = p;
+      for (int k = D; k < RS; k++) {
+        p = fma(dv[k], o[k], p);
+        q = fma(o[k], o[k], q);
+      }
+      pr[0] = two ? q : p;
+      pr[1] = p;
+    }
+    if (neg) {   // the first CG direction p_0 = -P grad (IterativeSolvers.h:258)
+#pragma unroll
+      for (int k = 0; k < RS; k++) o[k] = -1.0 * o[k];
+      store_vec<RS>(neg + (size_t)row * RS, o);
     }
   }
-  if (partial) block_store<1>(pr, partial + SEGB, 0);
+  if (partial) {
+    if (two) block_store<2>(pr, partial + SEGB, pstride);
+    else block_store<1>(reinterpret_cast<const double(&)[1]>(pr), partial + SEGB, 0);
+  }
 }
 
 // dst[didx[k]] = src[sidx[k]]  (didx == nullptr: dst[k]); halo copies, pack and unpack
@@ -1097,27 +1154,96 @@ __global__ __launch_bounds__(64) void k_cg_begin(int nnodes, NodeBits bits, CgSt
   }
   const bool live = a < nnodes && ((bits >> a) & 1ull) && cg[a].live;
   const NodeBits m = __ballot(live);
-  if (a == 0) { dmask[0] = m; dmask[1] = m; }
+  if (a == 0) { dmask[0] = m; dmask[1] = m; dmask[2] = bits & ~m; }
+}
+
+// The start of a trust-region iteration without a host round trip (TNT.h:446-484, IterativeSolvers.h:230-291): per node the
+// sums |grad|^2, <X, nabla>, <X, g>, <X, g_alt> (partial slots 0..3) and |P grad|^2, <grad, P grad> (slots MAX_DOTS,
+// MAX_DOTS + 1) are reduced in the order of k_reduce and written to pinned host memory (the host reads them whenever it
+// next waits, and forms the same norms from the same bits); the gradient-norm tests decide which nodes iterate at all;
+// those get the start values of their CG (k_cg_begin's job, with <r_0, v_0> taken from the sums).
+// dmask[0] = dmask[1] = the nodes whose CG runs, dmask[2] = active nodes whose CG is over.
+struct TntBegin {
+  NodeBits bits;          // the candidates (iteration limits are the host's business)
+  int use_precon, max_it;
+  double grad_tol, pgrad_tol, kappa, theta;
+  double Delta[MAX_LOCAL_NODES];
+};
+__global__ __launch_bounds__(384) void k_tnt_begin(SegTable T, int nnodes, TntBegin B, const double *partials, CgNode *cg,
+                                                   NodeBits *dmask, double *host_tnt) {
+  // one workgroup per node, one wave per sum (six independent reductions side by side; each in the order of k_reduce)
+  __shared__ double sums[6];
+  const int a = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool mine = (B.bits >> a) & 1ull;
+  if (mine && (wv < 4 || B.use_precon)) {
+    const int slot = wv < 4 ? wv : MAX_DOTS + (wv - 4);
+    const double *p = partials + (size_t)slot * T.nseg_all;
+    double t = 0;
+    for (int k = T.own_ptr[a] + lane; k < T.own_ptr[a + 1]; k += 64) t += p[k];
+    t = wave_sum(t);
+    if (lane == 0) sums[wv] = t;
+  } else if (lane == 0) {
+    sums[wv] = 0.0;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  bool active = false, live = false;
+  if (mine) {
+    double v[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) v[q] = sums[q];
+    const double gnorm = sqrt(v[0]), pgnorm = B.use_precon ? sqrt(v[4]) : gnorm, rv0 = B.use_precon ? v[5] : v[0];
+    active = !(gnorm < B.grad_tol) && !(pgnorm < B.pgrad_tol);
+    CgNode c;
+    c.sk_M_pk = 0.0; c.sk_M_2 = 0.0; c.pk_M_2 = rv0; c.rv = rv0;
+    c.Delta = B.Delta[a]; c.Delta_2 = B.Delta[a] * B.Delta[a];
+    const double r0 = sqrt(rv0);
+    c.target = r0 * fmin(B.kappa, pow(r0, B.theta));
+    c.h_M_norm = 0.0;
+    c.c1 = 0.0; c.cr = 0.0; c.al = 0.0; c.kap = 0.0; c.be = 0.0;
+    c.cg_it = 0; c.max_it = B.max_it; c.pad = 0;
+    c.live = active && !(c.cg_it >= B.max_it || sqrt(c.rv) <= c.target);
+    if (!c.live) c.h_M_norm = sqrt(c.sk_M_2);
+    cg[a] = c;
+    live = c.live;
+#pragma unroll
+    for (int q = 0; q < 6; q++) __hip_atomic_store(host_tnt + a * TNT_SUMMARY + q, v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(host_tnt + a * TNT_SUMMARY + 6, active ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // every node owns its bit of the three masks (a node outside `bits` clears it): no word is written as a whole, so the
+  // workgroups need not meet
+  const NodeBits bit = 1ull << a;
+  if (live) { atomicOr(dmask + 0, bit); atomicOr(dmask + 1, bit); atomicAnd(dmask + 2, ~bit); }
+  else {
+    atomicAnd(dmask + 0, ~bit); atomicAnd(dmask + 1, ~bit);
+    if (active) atomicOr(dmask + 2, bit);
+    else atomicAnd(dmask + 2, ~bit);
+  }
 }
 
 // one wave per node; the partial sums are combined in the order of k_reduce
-__global__ __launch_bounds__(64) void k_cg_scal(SegTable T, int phase, const double *partials, CgNode *cg,
-                                                NodeBits *dmask, double *host_scalars, unsigned *arrived,
-                                                unsigned long long *host_flag, unsigned long long seq) {
-  const int a = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void k_cg_scal(SegTable T, int phase, const double *partials, CgNode *cg,
+                                                 NodeBits *dmask, double *host_scalars, unsigned *arrived,
+                                                 unsigned long long *host_flag, unsigned long long seq) {
+  // one workgroup per node; the (up to) four sums of a phase are reduced side by side, one wave each
+  __shared__ double sums[4];
+  const int a = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const NodeBits on = dmask[phase];      // (read before anyone clears a bit of it: bits are only ever cleared)
   const bool mine = (on >> a) & 1ull;
-  double v[4] = {0.0, 0.0, 0.0, 0.0};
-  if (mine) {
-    const int ns = phase == 0 ? 4 : 1;
-    for (int q = 0; q < ns; q++) {
-      const double *p = partials + (size_t)q * T.nseg_all;
-      double t = 0;
-      for (int k = T.own_ptr[a] + lane; k < T.own_ptr[a + 1]; k += 64) t += p[k];
-      v[q] = wave_sum(t);
-    }
+  const int ns = phase == 0 ? 4 : 1;
+  if (mine && wv < ns) {
+    const double *p = partials + (size_t)wv * T.nseg_all;
+    double t = 0;
+    for (int k = T.own_ptr[a] + lane; k < T.own_ptr[a + 1]; k += 64) t += p[k];
+    t = wave_sum(t);
+    if (lane == 0) sums[wv] = t;
   }
-  if (lane == 0) {
+  __syncthreads();
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  if (mine && threadIdx.x == 0) {
+    for (int q = 0; q < ns; q++) v[q] = sums[q];
+  }
+  if (threadIdx.x == 0) {
     CgNode c = cg[a];
     if (mine && phase == 0) {
       const double kappa_k = v[0];
@@ -1156,11 +1282,16 @@ __global__ __launch_bounds__(64) void k_cg_scal(SegTable T, int phase, const dou
       cg[a] = c;
       // a node that stops leaves dmask[1] now; dmask[0] (the nodes of the step under way, which still take the
       // s / H s update of this step) follows at the end of phase 1
-      if (!c.live) atomicAnd(dmask + 1, ~(1ull << a));
+      if (!c.live) {
+        atomicAnd(dmask + 1, ~(1ull << a));
+        atomicOr(dmask + 2, 1ull << a);    // ... and joins the nodes whose trial point can be taken
+      }
     }
-    __hip_atomic_store(host_scalars + a * MAX_SLOTS + 0, (double)c.live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(host_scalars + a * MAX_SLOTS + 1, c.h_M_norm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(host_scalars + a * MAX_SLOTS + 2, (double)c.cg_it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (the summary has its own pinned area, CG_SUMMARY doubles per node: it must survive the read-back of a trial point
+    // that was enqueued behind this step)
+    __hip_atomic_store(host_scalars + a * CG_SUMMARY + 0, (double)c.live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(host_scalars + a * CG_SUMMARY + 1, c.h_M_norm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(host_scalars + a * CG_SUMMARY + 2, (double)c.cg_it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __atomic_thread_fence(__ATOMIC_RELEASE);
     const unsigned done = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
     if (done == gridDim.x - 1) {
@@ -1323,10 +1454,15 @@ __device__ __forceinline__ int spd_chunk(int len) {
 }
 
 // fw: this wave's staging area (SPD_CH * D doubles); red: NW x (ROWS * D) doubles shared by the tile's waves.
-template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool NT>
+// ROOT: the tile belongs to the root of a node's elimination tree.  A root has no update rows and nobody above it, so
+// its forward step y = L11^-1 f is followed at once by its backward step x = L11^-T y: the tile streams rows of the
+// explicit product L11^-T L11^-1 (= the inverse of the root's Schur complement, S.Wroot) and writes scale * x straight
+// into `out` -- one launch instead of two, the same bytes (w^2 entries against two triangles).
+template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool NT, bool ROOT = false>
 __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it, const double *vec, double *ytmp,
                                              double *fw, double *red, const int wv, const int lane,
-                                             int trace_slot = 0, unsigned long long trace_t0 = 0) {
+                                             int trace_slot = 0, unsigned long long trace_t0 = 0, double *out = nullptr,
+                                             double scale = 1.0) {
   SPD_TRACE_DECL
   SPD_T(1)
   constexpr int KQ = 64 / ROWS, HB = SPD_HB;
@@ -1336,7 +1472,7 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
   const int p = it.first + r;
   const bool valid = r < it.count;
   const int w = it.w;
-  const double *WT = S.WT + it.mat_off + r;   // the tile's panel: [k][r], rows ldm apart
+  const double *WT = (ROOT ? S.Wroot : S.WT) + it.mat_off + r;   // the tile's panel: [k][r], rows ldm apart
   const int ldm = it.ld;
   const int *piv = S.piv_idx + it.piv_ptr;
   const int pos0 = it.pos_off;
@@ -1348,7 +1484,7 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
   const int udst = (writer && p >= w) ? S.ubuf_dst[it.ubuf_off + p - w] : 0;
   // the pivot block of W_s is L11^-1, lower triangular: rows of a tile that lies inside it only need
   // the columns up to the tile's last row
-  const int kend = (it.first + ROWS <= w) ? it.first + ROWS : w;
+  const int kend = (!ROOT && it.first + ROWS <= w) ? it.first + ROWS : w;   // (the root's product matrix is full)
   // the reduction is dealt to the tile's NW waves in equal chunks (at most SPD_CH long): a front with few
   // pivots still keeps every wave busy
   const int cl = spd_chunk<NW, SPD_CH>(kend);
@@ -1414,7 +1550,13 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
     }
   }
   SPD_T(4)
-  if (writer) {
+  if (ROOT) {
+    if (writer) {
+      double *dst = out + vaddr<D, DOF>(piv[p]);
+#pragma unroll
+      for (int c = 0; c < D; c++) *(dst + c) = (scale * acc[c]);
+    }
+  } else if (writer) {
     if (p < w) {
       double *dst = ytmp + (size_t)(it.piv_ptr + p) * D;   // y in front order: the backward sweep reads it back contiguously
 #pragma unroll
@@ -1515,38 +1657,42 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
 // One level of a sweep in one launch.  A workgroup (8 waves) takes a PACK: either one tile of a wide front,
 // shared by the 8 waves (ROWS-row tiles), or up to 8 tiles of narrow fronts (reduction length <= 96), one
 // per wave.  Wide packs come first, longest first; the narrow ones fill the tail of the launch.
-template <int D, int DOF, int ROWS, bool FWD, bool NT>
-__global__ __launch_bounds__(64 * SPD_NW(ROWS), ROWS == 64 ? SPD_WPE : 4) void k_spd_level(SpdDev S, NodeMask mask, int tile0,
-                                                                                      int nwide, int nnarrow, double scale,
-                                                                                      double *vec, double *ytmp) {
+template <int D, int DOF, int ROWS, int MODE, bool NT>   // MODE 0: forward level, 1: backward level, 2: the roots (fused)
+__global__ __launch_bounds__(64 * SPD_NW(ROWS), ROWS == 64 ? SPD_WPE : 4) void k_spd_level(SpdDev S, NodeMask mask, SpdLevelMap M,
+                                                                                      double scale, double *vec, double *ytmp) {
   constexpr int CH = 128, NW = SPD_NW(ROWS);
   __shared__ double f[NW][CH * D];
   __shared__ double red[NW * ROWS * D];
-  // workgroups [0, nwide) take one wide tile each, the rest NW narrow tiles each (no work list to read: a
-  // tile's index follows from blockIdx)
+  // workgroups [0, wide_wgs) take one wide tile each, the rest NW narrow tiles each; slot = b % nlive picks the node,
+  // b / nlive the tile within the node (no work list to read: a tile's index follows from blockIdx and the arguments)
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const SpdItem *items = (FWD ? S.fwd_items : S.bwd_items) + tile0;
-  const int b = blockIdx.x;
+  const SpdItem *items = MODE == 0 ? S.fwd_items : (MODE == 1 ? S.bwd_items : S.root_items);
+  int b = blockIdx.x;
 #ifdef SPD_TRACE
   const unsigned long long tt0 = wall_clock64();
-#define SPD_TRACE_ARGS(slot) , (slot), tt0
+#define SPD_TRACE_ARGS(slot) , (slot) - M.pad, tt0
 #else
-#define SPD_TRACE_ARGS(slot)
+#define SPD_TRACE_ARGS(slot) , 0, 0ull
 #endif
-  const NodeBits bits = mask_bits(mask);
-  if (bits == 0) return;   // every node has left the device-side mask: nothing to read at all
-  if (b >= nwide) {
-    const int t = (b - nwide) * NW + wv;
-    if (t >= nnarrow) return;
-    const SpdItem it = load_item(items + nwide + t);
-    if (!((bits >> it.node) & 1ull)) return;
-    if constexpr (FWD) spd_fwd_tile<D, DOF, 1, CH, 64, NT>(S, it, vec, ytmp, f[wv], red, 0, lane SPD_TRACE_ARGS(nwide + t));
-    else spd_bwd_tile<D, DOF, 1, CH, 64, NT>(S, it, scale, ytmp, vec, f[wv], red, 0, lane SPD_TRACE_ARGS(nwide + t));
+  const bool is_wide = b < M.wide_wgs;
+  if (!is_wide) b -= M.wide_wgs;
+  const int j = b % M.nlive, r = b / M.nlive;
+  if (is_wide ? r >= M.wcount[j] : r * NW + wv >= M.ncount[j]) return;
+  // a node that left the device-side mask after the host sized this launch: nothing of it is read
+  if (mask.p && !((*mask.p >> M.node[j]) & 1ull)) return;
+  // (MODE 2: `vec` is the right-hand side, `ytmp` the record array that receives the solution)
+  if (!is_wide) {
+    const int t = M.nstart[j] + r * NW + wv;
+    const SpdItem it = load_item(items + t);
+    if constexpr (MODE == 0) spd_fwd_tile<D, DOF, 1, CH, 64, NT>(S, it, vec, ytmp, f[wv], red, 0, lane SPD_TRACE_ARGS(t));
+    else if constexpr (MODE == 1) spd_bwd_tile<D, DOF, 1, CH, 64, NT>(S, it, scale, ytmp, vec, f[wv], red, 0, lane SPD_TRACE_ARGS(t));
+    else spd_fwd_tile<D, DOF, 1, CH, 64, NT, true>(S, it, vec, nullptr, f[wv], red, 0, lane SPD_TRACE_ARGS(t), ytmp, scale);
   } else {
-    const SpdItem it = load_item(items + b);
-    if (!((bits >> it.node) & 1ull)) return;   // (uniform over the workgroup)
-    if constexpr (FWD) spd_fwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, vec, ytmp, f[wv], red, wv, lane SPD_TRACE_ARGS(b));
-    else spd_bwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, scale, ytmp, vec, f[wv], red, wv, lane SPD_TRACE_ARGS(b));
+    const int t = M.wstart[j] + r;
+    const SpdItem it = load_item(items + t);
+    if constexpr (MODE == 0) spd_fwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, vec, ytmp, f[wv], red, wv, lane SPD_TRACE_ARGS(t));
+    else if constexpr (MODE == 1) spd_bwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, scale, ytmp, vec, f[wv], red, wv, lane SPD_TRACE_ARGS(t));
+    else spd_fwd_tile<D, DOF, NW, CH, ROWS, NT, true>(S, it, vec, nullptr, f[wv], red, wv, lane SPD_TRACE_ARGS(t), ytmp, scale);
   }
 #undef SPD_TRACE_ARGS
 }
@@ -1665,12 +1811,16 @@ void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMas
 
 void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, const BsrDev &A, const double *tval,
                      const double *xt, const double *base, double *y, int mode, const double *X, const double *nabla,
-                     const double *Rdot, double *out2, const double *rres, double *partials) {
+                     const double *Rdot, double *out2, const double *rres, double *partials, const double *dg,
+                     const double *dga, const double *ds, const double *dgrad, const double *dhs) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_BSR, st, (double)A.nnzb * (8.0 * (d + 1) + 4 + 8.0 * d) + 2.0 * A.nrows * 8.0 * (d + 1) * d);
+  TcolDots E;
+  E.g = dg; E.ga = dga; E.s = ds; E.grad = dgrad; E.hs = dhs;
+  // which epilogue sums are produced: mode 2 with rres (a CG step's four), mode 1 with dg (a refinement's start), mode 0 with ds (a trial point's six)
+  const bool sums = partials && ((mode == 2 && rres) || (mode == 1 && dg) || (mode == 0 && ds));
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_bsr_tcol<D>), dim3(T.nseg_own), dim3(4 * SEG_ROWS), 0, st, T.segs, mask, A, tval,
-                                        xt, base, y, mode, X, nabla, Rdot, out2, rres, (mode == 2 && rres) ? partials : nullptr,
-                                        T.nseg_all));
+                                        xt, base, y, mode, X, nabla, Rdot, out2, rres, sums ? partials : nullptr, T.nseg_all, E));
 }
 
 void launch_inter(int d, hipStream_t st, const SegTable &T, NodeMask mask, const InterEdgesDev &E, int loss,
@@ -1722,14 +1872,14 @@ void launch_extrapolate(int d, hipStream_t st, const SegTable &T, bool all_rows,
 }
 
 void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask, double alpha,
-                  const double *a, double beta, const double *b, double *out, int part) {
+                  const double *a, double beta, const double *b, double *out, int part, double *out2) {
   const int nb = nseg(T, all_rows);
   if (nb == 0) return;
   ProfScope ps(PK_AXPBY, st, (b ? 3.0 : 2.0) * (all_rows ? T.rows_all : T.rows_own) * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, {
-    if (part == 0) hipLaunchKernelGGL((k_axpby<D, 0>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, alpha, a, beta, b, out);
-    else if (part == 1) hipLaunchKernelGGL((k_axpby<D, 1>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, alpha, a, beta, b, out);
-    else hipLaunchKernelGGL((k_axpby<D, 2>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, alpha, a, beta, b, out);
+    if (part == 0) hipLaunchKernelGGL((k_axpby<D, 0>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, alpha, a, beta, b, out, out2);
+    else if (part == 1) hipLaunchKernelGGL((k_axpby<D, 1>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, alpha, a, beta, b, out, nullptr);
+    else hipLaunchKernelGGL((k_axpby<D, 2>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, alpha, a, beta, b, out, nullptr);
   });
 }
 
@@ -1765,11 +1915,22 @@ void launch_cg_begin(hipStream_t st, int nnodes, NodeBits bits, const CgStart &S
   hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(64), 0, st, nnodes, bits, S, max_it, cg, dmask);
 }
 
+void launch_tnt_begin(hipStream_t st, const SegTable &T, int nnodes, NodeBits bits, bool use_precon, int max_it, double grad_tol,
+                      double pgrad_tol, double kappa, double theta, const double *Delta, const double *partials, CgNode *cg,
+                      NodeBits *dmask, double *host_tnt) {
+  TntBegin B;
+  B.bits = bits; B.use_precon = use_precon; B.max_it = max_it;
+  B.grad_tol = grad_tol; B.pgrad_tol = pgrad_tol; B.kappa = kappa; B.theta = theta;
+  for (int a = 0; a < MAX_LOCAL_NODES; a++) B.Delta[a] = a < nnodes ? Delta[a] : 0.0;
+  ProfScope ps(PK_REDUCE, st, 8.0 * 6 * T.nseg_own);
+  hipLaunchKernelGGL(k_tnt_begin, dim3(nnodes), dim3(384), 0, st, T, nnodes, B, partials, cg, dmask, host_tnt);
+}
+
 void launch_cg_scal(hipStream_t st, const SegTable &T, int nnodes, int phase, const double *partials, CgNode *cg,
                     NodeBits *dmask, double *host_scalars, unsigned *arrived, unsigned long long *host_flag,
                     unsigned long long seq) {
   ProfScope ps(PK_REDUCE, st, 8.0 * (phase == 0 ? 4 : 1) * T.nseg_own);
-  hipLaunchKernelGGL(k_cg_scal, dim3(nnodes), dim3(64), 0, st, T, phase, partials, cg, dmask, host_scalars, arrived,
+  hipLaunchKernelGGL(k_cg_scal, dim3(nnodes), dim3(256), 0, st, T, phase, partials, cg, dmask, host_scalars, arrived,
                      host_flag, seq);
 }
 
@@ -1810,16 +1971,16 @@ void launch_copy_nbr_rows(int d, hipStream_t st, const SegTable &T, NodeMask mas
   if (nb <= 0) return;
   ProfScope ps(PK_AXPBY, st, 2.0 * (T.rows_all - T.rows_own) * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_axpby<D, 0>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs + T.nseg_own, mask, 1.0, src,
-                                        0.0, nullptr, dst));
+                                        0.0, nullptr, dst, nullptr));
 }
 
 void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
-                        const double *in, double *out, const double *dotv, double *partials, int slot) {
+                        const double *in, double *out, const double *dotv, double *partials, int slot, bool two, double *neg) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_ROTOP, st, (dotv ? 4.0 : 3.0) * T.rows_own * 8.0 * (d + 1) * d);
   double *part = (dotv && partials) ? partials + (size_t)slot * T.nseg_all : nullptr;
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, 0, X, in,
-                                        dotv, part, out));
+                                        dotv, part, out, T.nseg_all, two ? 1 : 0, neg));
 }
 
 void launch_retract_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
@@ -1827,7 +1988,7 @@ void launch_retract_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask,
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_ROTOP, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, 2, X, V,
-                                        nullptr, nullptr, out));
+                                        nullptr, nullptr, out, 0, 0, nullptr));
 }
 
 void launch_copy_indexed(int d, hipStream_t st, int count, const int *didx, const int *sidx, const double *src,
@@ -1864,6 +2025,29 @@ __global__ __launch_bounds__(256) void k_pack_panels(const SpdItem *items, const
     out[(size_t)k * it.ld + r] = in[(size_t)k * ps.src_ld + r];
   }
 }
+// Panels of the fused root tiles: tile i holds, for its columns c = first .. first + count, the rows k = 0 .. w of
+//   P = L11^-T L11^-1,   P[k][c] = sum_{j >= max(k, c)} Linv[j][k] Linv[j][c]      (Linv = L11^-1, lower triangular)
+// as panel[k * ld + (c - first)].  Linv: the root front's W_s (w x src_ld, row-major) at src + srcs[i].src_off.
+// One thread per entry, the sum taken in increasing j (a fixed order): set-up work, a few milliseconds.
+__global__ __launch_bounds__(256) void k_root_product(const SpdItem *items, const PanelSrc *srcs, const double *src, double *panels) {
+  const SpdItem it = load_item(items + blockIdx.x);
+  const PanelSrc ps = srcs[blockIdx.x];
+  const double *L = src + ps.src_off;
+  double *out = panels + it.mat_off;
+  const int w = it.w, cnt = it.count, ld = ps.src_ld;
+  const int r = threadIdx.x % 64, kq = threadIdx.x / 64;   // lane = column of the tile (coalesced), 4 rows k at a time
+  if (r >= cnt) return;
+  const int c = it.first + r;
+  for (int k = blockIdx.y * 4 + kq; k < w; k += 4 * gridDim.y) {
+    double a = 0.0;
+    for (int j = max(k, c); j < w; j++) a = fma(L[(size_t)j * ld + k], L[(size_t)j * ld + c], a);
+    out[(size_t)k * it.ld + r] = a;
+  }
+}
+void launch_root_product(hipStream_t st, const SpdItem *items, const PanelSrc *srcs, int ntiles, const double *src, double *panels) {
+  if (ntiles > 0) hipLaunchKernelGGL(k_root_product, dim3(ntiles, 32), dim3(256), 0, st, items, srcs, src, panels);
+}
+
 void launch_pack_panels(hipStream_t st, const SpdItem *items, const PanelSrc *srcs, int ntiles, const double *src, double *panels) {
   if (ntiles > 0) hipLaunchKernelGGL(k_pack_panels, dim3(ntiles), dim3(256), 0, st, items, srcs, src, panels);
 }
@@ -1873,18 +2057,20 @@ void spd_trace_set(unsigned long long *p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g
 #else
 void spd_trace_set(unsigned long long *) {}
 #endif
-void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, bool forward, int tile0, int nwide, int nnarrow,
-                      int rows, double *vec, double *ytmp, double scale, double level_bytes, bool stream_once,
-                      NodeMask mask) {
-  const int nw = SPD_NW(rows), npacks = nwide + (nnarrow + nw - 1) / nw;
-  if (npacks == 0) return;
-  ProfScope ps(forward ? PK_SPD_FWD : PK_SPD_BWD, st, level_bytes);
+int spd_waves(int rows) { return SPD_NW(rows); }
+void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, int mode, const SpdLevelMap &M, int rows,
+                      double *vec, double *ytmp, double scale, double level_bytes, bool stream_once, NodeMask mask) {
+  const int npacks = M.wide_wgs + M.narrow_wgs;
+  if (npacks == 0 || M.nlive == 0) return;
+  ProfScope ps(mode == 1 ? PK_SPD_BWD : PK_SPD_FWD, st, level_bytes);
 #define SPD_LAUNCH2(DOFV, ROWSV, NTV)                                                                            \
   do {                                                                                                         \
-    if (forward)                                                                                               \
-      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, true, NTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, mask, tile0, nwide, nnarrow, scale, vec, ytmp);  \
+    if (mode == 0)                                                                                             \
+      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, 0, NTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, mask, M, scale, vec, ytmp);  \
+    else if (mode == 1)                                                                                        \
+      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, 1, NTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, mask, M, scale, vec, ytmp); \
     else                                                                                                       \
-      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, false, NTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, mask, tile0, nwide, nnarrow, scale, vec, ytmp); \
+      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, 2, NTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, mask, M, scale, vec, ytmp); \
   } while (0)
 #define SPD_LAUNCH(DOFV, ROWSV)                \
   do {                                         \

@@ -33,6 +33,11 @@ int env_lag() {
   const char *e = getenv("DPGO_CG_LAG");
   return e ? atoi(e) : 1;
 }
+// DPGO_TNT_DEVICE_START=0: the host takes the norms and starts the CG (one more read-back per refinement; measurement hook)
+bool env_device_start() {
+  static const bool on = !(getenv("DPGO_TNT_DEVICE_START") && atoi(getenv("DPGO_TNT_DEVICE_START")) == 0);
+  return on;
+}
 enum { ST_GRADIENT = 0, ST_PRECON_GRADIENT, ST_REL_DECREASE, ST_STEPSIZE, ST_TRUST_REGION, ST_ITER_LIMIT };
 
 struct NodeTnt {
@@ -66,71 +71,135 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
   const int P2[MAX_DOTS] = {2, 2, 2, 2, 2, 2};
   // nabla = G Y + g and grad = Proj_Y(nabla) (rotation rows).  from_base: Y.t was just recovered from Y.R with
   // this g (recover_translations), so T1_ = G [0 ; Y.R] + g is there and only the translation column is missing.
+  // Returns true when the pass also left the four sums of the refinement's start (|grad|^2, <Y, nabla>, <Y, g>,
+  // <Y, g_alt>) in the partial slots 0..3 (its epilogue), so that no separate pass over the vectors is needed.
+  const double *ga = g_alt ? g_alt : g;
   auto quad_model = [&](const double *Y, bool from_base) {
     if (from_base) {
-      apply_tcol(Y, T1_.p, nabla, 1, Y, nullptr, nullptr, grad);   // nabla and grad in one pass
-      return;
+      apply_tcol(Y, T1_.p, nabla, 1, Y, nullptr, nullptr, grad, nullptr, partials_.p, g, ga);   // nabla, grad and the sums in one pass
+      return true;
     }
     launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Y, false, g, nabla, nullptr, 0, nullptr, nullptr, 0);
     launch_tangent_rot(d_, st_, T_, cur_mask_, Y, nabla, grad);
+    return false;
   };
-  auto precon = [&](const double *Y, const double *v, double *out) {
-    if (!use_precon) {
-      copy_rows(out, v, false, 0);
-      return;
-    }
+  // out = P(v) = Proj_Y(M^-1 v) with |out|^2 and <v, out> in the partial slots MAX_DOTS, MAX_DOTS + 1, and -out in pk
+  // (the first CG direction); only called with a preconditioner
+  auto precon_with_sums = [&](const double *Y, const double *v, double *out) {
     if (jacobi) launch_rot_rowscale(d_, st_, T_, cur_mask_, jacobi_.p, v, w1);
     else solve_rr(const_cast<double *>(v), w1, 1.0);   // w1.R = (G_RR + lambda I)^-1 v.R; the forward sweep only reads v
-    launch_tangent_rot(d_, st_, T_, cur_mask_, Y, w1, out);
+    launch_tangent_rot(d_, st_, T_, cur_mask_, Y, w1, out, v, partials_.p, MAX_DOTS, true, pk);
   };
   // gnorm, pgnorm (and rv0 = <grad, P grad>, the first CG scalar) of the nodes in `set` (mask == set).
   // with_f: f(X | g) in the same read-back, from the model gradient nabla = G X + g that is there anyway:
   //   f = <X, g> + 1/2 <X, G X> = 1/2 (<X, nabla> + <X, g>)      (DPGOProblem.cpp:180-205)
   // lin / lin_alt = <X, g> / <X, g_alt> let the caller re-base f on g_alt without another G X.
   std::vector<double> rv0(L, 0.0), lin(L, 0.0), lin_alt(L, 0.0);
-  const double *ga = g_alt ? g_alt : g;
-  auto norms = [&](const std::vector<int> &set, bool with_f) {
-    {
+  // the dot products (partial slots 0..3 and MAX_DOTS, MAX_DOTS + 1) and the first CG direction pk = -P(grad); who
+  // reduces the sums is the caller's choice: k_reduce + wait (norms) or k_tnt_begin (no wait).
+  // have_sums: slots 0..3 were already left there by quad_model's epilogue
+  auto norms_enqueue = [&](bool with_f, bool have_sums) {
+    if (!have_sums) {
       const double *pa[MAX_DOTS] = {grad, X, X, X}, *pb[MAX_DOTS] = {grad, nabla, g, ga};
       const int parts[MAX_DOTS] = {2, 0, 0, 0, 0, 0};
       launch_dots(d_, st_, T_, cur_mask_, with_f ? 4 : 1, pa, pb, parts, partials_.p, 0);
     }
+    if (use_precon) precon_with_sums(X, grad, pg);
+    else launch_cg_init(d_, st_, T_, cur_mask_, grad, grad, nullptr, nullptr, nullptr, nullptr, pk);
+  };
+  auto norms_take = [&](int a, bool with_f, double g2, double xn, double xg, double xga, double pg2, double gpg) {
+    S[a].gnorm = S[a].pgnorm = std::sqrt(g2);
+    rv0[a] = g2;
     if (use_precon) {
-      precon(X, grad, pg);
-      const double *pa[MAX_DOTS] = {pg, grad}, *pb[MAX_DOTS] = {pg, pg};
-      launch_dots(d_, st_, T_, cur_mask_, 2, pa, pb, P2, partials_.p, MAX_DOTS);
+      S[a].pgnorm = std::sqrt(pg2);
+      rv0[a] = gpg;
     }
-    fetch(MAX_DOTS + 2, false);
+    if (with_f) {
+      S[a].fx = 0.5 * (xn + xg) + res_[a].f;
+      lin[a] = xg;
+      lin_alt[a] = xga;
+    }
+  };
+  // ... from the pinned summary of k_tnt_begin
+  auto norms_read = [&](const std::vector<int> &set, bool with_f) {
     for (int a : set) {
-      S[a].gnorm = S[a].pgnorm = std::sqrt(scal(a, 0));
-      rv0[a] = scal(a, 0);
-      if (use_precon) {
-        S[a].pgnorm = std::sqrt(scal(a, MAX_DOTS));
-        rv0[a] = scal(a, MAX_DOTS + 1);
-      }
-      if (with_f) {
-        S[a].fx = 0.5 * (scal(a, 1) + scal(a, 2)) + res_[a].f;
-        lin[a] = scal(a, 2);
-        lin_alt[a] = scal(a, 3);
-      }
+      const double *t = h_tnt_ + a * TNT_SUMMARY;
+      norms_take(a, with_f, t[0], t[1], t[2], t[3], t[4], t[5]);
     }
+  };
+  auto norms = [&](const std::vector<int> &set, bool with_f, bool have_sums) {
+    norms_enqueue(with_f, have_sums);
+    fetch(MAX_DOTS + 2, false);
+    for (int a : set) norms_take(a, with_f, scal(a, 0), scal(a, 1), scal(a, 2), scal(a, 3), scal(a, MAX_DOTS), scal(a, MAX_DOTS + 1));
   };
 
   const double sqrt_eps = std::sqrt(std::numeric_limits<double>::epsilon());
   const double eta1 = .05, eta2 = .9, alpha1 = .25, alpha2 = 2.5, Delta_tol = 1e-6;   // TNT.h:83-97,129
+  constexpr int NSUM = 6;   // the sums a trial point needs (TNT.h:505-536)
+  // trial point of the nodes in `m`: x+ = retract(x, s), f(x+) and, for an accepted step, the next model gradient
+  auto enqueue_trial = [&](NodeMask m) {
+    cur_mask_ = m;
+    launch_retract_rot(d_, st_, T_, cur_mask_, X, sk, xprop);
+    recover_translations(xprop, g);
+    // nprop = G xprop + g: gives f(xprop) and, if accepted, the next model; its epilogue leaves the six sums
+    // <s,s>, <grad,s>, <s,Hs>, <x+,g>, <x+,g_alt>, <x+,nprop> in the partial slots 0..5
+    apply_tcol(xprop, T1_.p, nprop, 0, nullptr, nullptr, nullptr, nullptr, nullptr, partials_.p, g, ga, sk, grad, hh);
+  };
+  // acceptance test and trust-region update of node a from the sums of its trial point (TNT.h:537-607)
+  std::vector<int> acc, requad;
+  auto judge = [&](int a, const double *t) {
+    NodeTnt &s = S[a];
+    const double fx_prop = 0.5 * (t[5] + t[3]) + res_[a].f;
+    const double h_norm = std::sqrt(t[0]);
+    const double dm = -t[1] - 0.5 * t[2];
+    const double df = s.fx - fx_prop;
+    const double rel_dec = df / (sqrt_eps + std::fabs(s.fx));
+    const double rho = df / dm;
+    const bool ok = (!std::isnan(rho)) && rho > eta1;
+    s.accepted += ok;
+    bool stop = false;
+    if (ok) {
+      acc.push_back(a);
+      s.fx = fx_prop;
+      lin[a] = t[3];
+      lin_alt[a] = t[4];
+      if (rel_dec < o.rel_func_decrease_tol) { s.status = ST_REL_DECREASE; stop = true; }
+      else if (h_norm < o.stepsize_tol) { s.status = ST_STEPSIZE; stop = true; }
+      else if (s.iteration + 1 < o.max_iterations && s.accepted < o.max_iterations_accepted)
+        requad.push_back(a);   // the new model is only needed if another iteration follows (TNT.h:446-449)
+    }
+    if (!stop) {   // trust-region update (TNT.h:593-607)
+      if ((!std::isnan(rho)) && rho >= eta2) s.Delta = std::max(alpha2 * s.h_M_norm, s.Delta);
+      else if (std::isnan(rho) || rho < eta1) {
+        s.Delta = alpha1 * s.h_M_norm;
+        if (s.Delta < Delta_tol) { s.status = ST_TRUST_REGION; stop = true; }
+      }
+    }
+    if (stop) s.active = false;
+    else s.iteration++;
+  };
+  auto cgs = [&](int a, int k) { return h_cg_[a * CG_SUMMARY + k]; };
   set_mask(nodes);
-  quad_model(X, base_ready);
-  norms(nodes, true);
+  const bool have_sums = quad_model(X, base_ready);
+  // The first trust-region iteration starts without a host round trip: the norms, the gradient tests and the start
+  // values of the CG are taken on the device (k_tnt_begin); the host reads the same sums at its first wait below.
+  const bool device_start = o.max_iterations > 0 && o.max_iterations_accepted > 0 && env_device_start();
+  if (device_start) norms_enqueue(true, have_sums);
+  else norms(nodes, true, have_sums);
 
-  for (;;) {
-    // ---- nodes that start another trust-region iteration (TNT.h:446-484)
+  for (bool first_iteration = true;; first_iteration = false) {
+    const bool dev = first_iteration && device_start;
+    // ---- nodes that start another trust-region iteration (TNT.h:446-484); with `dev` the gradient tests are the
+    // device's, and A holds the candidates until the host has seen the summary
     std::vector<int> A;
     for (int a : nodes) {
       NodeTnt &s = S[a];
       if (!s.active) continue;
       if (!(s.iteration < o.max_iterations && s.accepted < o.max_iterations_accepted)) { s.active = false; continue; }
-      if (s.gnorm < o.grad_norm_tol) { s.status = ST_GRADIENT; s.active = false; continue; }
-      if (s.pgnorm < o.preconditioned_grad_norm_tol) { s.status = ST_PRECON_GRADIENT; s.active = false; continue; }
+      if (!dev) {
+        if (s.gnorm < o.grad_norm_tol) { s.status = ST_GRADIENT; s.active = false; continue; }
+        if (s.pgnorm < o.preconditioned_grad_norm_tol) { s.status = ST_PRECON_GRADIENT; s.active = false; continue; }
+      }
       A.push_back(a);
     }
     if (A.empty()) break;
@@ -142,11 +211,17 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     // kernels of the surplus step find an empty device mask and return at once.
     set_mask(A);
     const NodeBits bitsA = cur_mask_.v;
-    // p_0 = -v_0, v_0 = P(grad) (already there from the preconditioned gradient norm);
-    // s_0 = 0, H s_0 = 0, r_0 = grad are not materialised: the first step of the run takes them as given
-    launch_cg_init(d_, st_, T_, cur_mask_, grad, use_precon ? pg : grad, nullptr, nullptr, nullptr, nullptr, pk);
+    // p_0 = -v_0, v_0 = P(grad): written by the pass that took the preconditioned gradient norm (norms_enqueue);
+    // s_0 = 0, H s_0 = 0, r_0 = grad are not materialised: the first step of the run takes them as given.
+    // A later iteration of a node whose step was rejected starts from the same gradient: p_0 again (pk was overwritten)
+    if (!first_iteration) launch_cg_init(d_, st_, T_, cur_mask_, grad, use_precon ? pg : grad, nullptr, nullptr, nullptr, nullptr, pk);
     bool first_step = true;
-    {
+    if (dev) {
+      std::vector<double> Delta(L, 0.0);
+      for (int a : A) Delta[a] = S[a].Delta;
+      launch_tnt_begin(st_, T_, L, bitsA, use_precon, o.max_tCG_iterations, o.grad_norm_tol, o.preconditioned_grad_norm_tol,
+                       o.STPCG_kappa, o.STPCG_theta, Delta.data(), partials_.p, cg_.p, dmask_.p, h_tnt_);
+    } else {
       CgStart cs;
       for (int a = 0; a < L; a++) cs.rv[a] = cs.Delta[a] = cs.target[a] = 0.0;
       for (int a : A) {
@@ -157,14 +232,16 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       }
       launch_cg_begin(st_, L, bitsA, cs, o.max_tCG_iterations, cg_.p, dmask_.p);
     }
-    const NodeMask mA{bitsA, dmask_.p}, mB{bitsA, dmask_.p + 1};
+    // by value: the nodes the host last saw iterating (it sizes the launches -- the solves shrink their grids with it);
+    // by pointer: the device's own, more recent masks
+    NodeMask mA{bitsA, dmask_.p}, mB{bitsA, dmask_.p + 1};
     // first half of a step: H p and its four scalars, then the step-length logic (:296-362)
     auto stepA = [&]() {
       cur_mask_ = mA;
       launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, pk, true, nullptr, w1, nullptr, 0, nullptr, nullptr, 0);   // G [0 ; p.R]
       solve_tt(w1, w3, -1.0);
       apply_tcol(w3, w1, nullptr, 2, X, nabla, pk, Hp, first_step ? grad : rk, partials_.p);   // Hp and <p,Hp>, <Hp,Hp>, <p,p>, <p,r>
-      launch_cg_scal(st_, T_, L, 0, partials_.p, cg_.p, dmask_.p, h_scal_, reduce_arrived_.p, h_flag_, ++fetch_seq_);
+      launch_cg_scal(st_, T_, L, 0, partials_.p, cg_.p, dmask_.p, h_cg_, reduce_arrived_.p, h_flag_, ++fetch_seq_);
       // s += c1 p, H s += c1 H p for every node of the step (a node that stops here takes its boundary step), r += alpha H p
       // for those that go on
       // (the first step runs for every node of A, live or not: a node that stops before its first step has c1 = 0 and
@@ -186,19 +263,55 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
         const double *pa[MAX_DOTS] = {rk}, *pb[MAX_DOTS] = {vk};
         launch_dots(d_, st_, T_, cur_mask_, 1, pa, pb, P2, partials_.p, 0);
       }
-      launch_cg_scal(st_, T_, L, 1, partials_.p, cg_.p, dmask_.p, h_scal_, reduce_arrived_.p, h_flag_, ++fetch_seq_);
+      launch_cg_scal(st_, T_, L, 1, partials_.p, cg_.p, dmask_.p, h_cg_, reduce_arrived_.p, h_flag_, ++fetch_seq_);
       launch_cg_dir(d_, st_, T_, cur_mask_, cg_.p, vk, pk);
       return fetch_seq_;
     };
+    // (the summary of a later step may already have overwritten the one waited for: the set only shrinks, so whatever
+    // is read is a superset of the nodes that will still be live when the next launches run)
     auto any_live = [&]() {
+      NodeBits live = 0;
       for (int a : A)
-        if (scal(a, 0) != 0.0) return true;
-      return false;
+        if (cgs(a, 0) != 0.0) live |= 1ull << a;
+      mA.v = mB.v = live;
+      return live != 0;
     };
     static const int lag = env_lag();
-    // the first step is awaited at once: in the early regime every node ends it on the trust-region boundary
-    wait_flag(stepA());
-    if (any_live()) {
+    // The first step.  In the early regime every node ends it on the trust-region boundary, so -- as long as that was
+    // the case the last time -- the trial point of the nodes whose CG is over (dmask[2]) is enqueued right behind it
+    // and ONE wait brings the norms, the CG summary and the trial point's sums.  Otherwise the step is awaited at once.
+    std::vector<double> tsum((size_t)L * NSUM, 0.0);
+    std::vector<char> tried(L, 0);
+    const bool spec = dev && tnt_speculate_;
+    const unsigned long long seqA = stepA();
+    if (spec) {
+      enqueue_trial(NodeMask{bitsA, dmask_.p + 2});
+      fetch(NSUM, false);
+    } else {
+      wait_flag(seqA);
+    }
+    if (dev) {
+      // the sums k_tnt_begin reduced, and its verdict on the gradient tests
+      norms_read(A, true);
+      std::vector<int> act;
+      for (int a : A) {
+        if (h_tnt_[a * TNT_SUMMARY + 6] != 0.0) { act.push_back(a); continue; }
+        S[a].status = S[a].gnorm < o.grad_norm_tol ? ST_GRADIENT : ST_PRECON_GRADIENT;
+        S[a].active = false;
+      }
+      A.swap(act);
+    }
+    if (spec)
+      for (int a : A)
+        if (cgs(a, 0) == 0.0) {   // its CG ended with (or before) the first step: the sums just read are its trial point's
+          tried[a] = 1;
+          for (int q = 0; q < NSUM; q++) tsum[(size_t)a * NSUM + q] = scal(a, q);
+          S[a].h_M_norm = cgs(a, 1);
+          S[a].cg_it = (int)cgs(a, 2);
+        }
+    const bool more_steps = any_live();
+    if (dev) tnt_speculate_ = !more_steps;   // speculate next time if nobody needed a second step this time
+    if (more_steps) {
       unsigned long long seqB = stepB();
       for (;;) {
         if (!lag) {
@@ -214,55 +327,28 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
         seqB = next;
       }
     }
+    std::vector<int> rest;
     for (int a : A) {
-      S[a].h_M_norm = scal(a, 1);
-      S[a].cg_it = (int)scal(a, 2);
+      if (tried[a]) continue;
+      rest.push_back(a);
+      S[a].h_M_norm = cgs(a, 1);
+      S[a].cg_it = (int)cgs(a, 2);
+    }
+    for (int a : A) {
       S[a].cg = false;
+      S[a].inner_total += S[a].cg_it;
     }
-    for (int a : A) S[a].inner_total += S[a].cg_it;
-    // ---- trial point (TNT.h:505-536)
-    set_mask(A);
-    launch_retract_rot(d_, st_, T_, cur_mask_, X, sk, xprop);
-    recover_translations(xprop, g);
-    apply_tcol(xprop, T1_.p, nprop);          // nprop = G xprop + g: gives f(xprop) and, if accepted, the next model
-    {
-      const double *pa[MAX_DOTS] = {sk, grad, sk, xprop, xprop, xprop}, *pb[MAX_DOTS] = {sk, sk, hh, g, ga, nprop};
-      const int parts[MAX_DOTS] = {2, 2, 2, 0, 0, 0};
-      launch_dots(d_, st_, T_, cur_mask_, 6, pa, pb, parts, partials_.p, 0);
+    // ---- trial point (TNT.h:505-536) of the nodes that have not had theirs
+    if (!rest.empty()) {
+      set_mask(rest);
+      enqueue_trial(cur_mask_);
+      fetch(NSUM, false);
+      for (int a : rest)
+        for (int q = 0; q < NSUM; q++) tsum[(size_t)a * NSUM + q] = scal(a, q);
     }
-    fetch(MAX_DOTS, false);
-    std::vector<int> acc, requad;
-    for (int a : A) {
-      NodeTnt &s = S[a];
-      const double fx_prop = 0.5 * (scal(a, 5) + scal(a, 3)) + res_[a].f;
-      const double h_norm = std::sqrt(scal(a, 0));
-      const double dm = -scal(a, 1) - 0.5 * scal(a, 2);
-      const double df = s.fx - fx_prop;
-      const double rel_dec = df / (sqrt_eps + std::fabs(s.fx));
-      const double rho = df / dm;
-      const bool ok = (!std::isnan(rho)) && rho > eta1;
-      s.accepted += ok;
-      bool stop = false;
-      if (ok) {
-        acc.push_back(a);
-        s.fx = fx_prop;
-        lin[a] = scal(a, 3);
-        lin_alt[a] = scal(a, 4);
-        if (rel_dec < o.rel_func_decrease_tol) { s.status = ST_REL_DECREASE; stop = true; }
-        else if (h_norm < o.stepsize_tol) { s.status = ST_STEPSIZE; stop = true; }
-        else if (s.iteration + 1 < o.max_iterations && s.accepted < o.max_iterations_accepted)
-          requad.push_back(a);   // the new model is only needed if another iteration follows (TNT.h:446-449)
-      }
-      if (!stop) {   // trust-region update (TNT.h:593-607)
-        if ((!std::isnan(rho)) && rho >= eta2) s.Delta = std::max(alpha2 * s.h_M_norm, s.Delta);
-        else if (std::isnan(rho) || rho < eta1) {
-          s.Delta = alpha1 * s.h_M_norm;
-          if (s.Delta < Delta_tol) { s.status = ST_TRUST_REGION; stop = true; }
-        }
-      }
-      if (stop) s.active = false;
-      else s.iteration++;
-    }
+    acc.clear();
+    requad.clear();
+    for (int a : A) judge(a, &tsum[(size_t)a * NSUM]);
     if (!acc.empty()) {
       set_mask(acc);
       copy_rows(X, xprop, false, 0);
@@ -271,9 +357,12 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       set_mask(requad);
       copy_rows(nabla, nprop, false, 0);   // the model gradient at the accepted point
       launch_tangent_rot(d_, st_, T_, cur_mask_, X, nabla, grad);
-      norms(requad, false);
+      norms(requad, false, false);
     }
   }
+  // scalars the caller parked in the partial sums (amm: the half step's three) ride with the first read-back of this
+  // function; if there was none (every node left at the gradient tests), fetch them now
+  if (deferred_slots_) fetch(deferred_slots_, false);
   if (o.verbose) {
     static const char *names[] = {"gradient", "preconditioned gradient", "relative decrease", "step size", "trust region", "iteration limit"};
     for (int a : nodes)

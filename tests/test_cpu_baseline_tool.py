@@ -47,7 +47,11 @@ def test_cpu_tool_follows_the_oracle(fixtures_dir, tmp_path, name, nn, loss, ite
 
 @pytest.mark.gpu
 def test_headline_size_trace_against_the_cpu_restatement(tmp_path):
-    """BASELINE config 4 at FULL size (100 000 poses / 400 000 edges, Huber, AMM-PGO#, 8 nodes): the objective trace of
+    """(Independence: the tool's iteration logic, kernels, solves' sweeps and TNT are its own code, but it is BUILT ON the
+    product's host set-up sources -- graph.cpp, assemble.cpp, spd.cpp, chordal.cpp (tools/cpu_baseline/Makefile) -- so a
+    bug in the operator assembly or in the factorisation would be shared by both sides of this comparison; those two are
+    held to the oracle's explicit matrices and to scipy separately, tests/test_host_logic.py and tests/test_gpu_factor.py.)
+    BASELINE config 4 at FULL size (100 000 poses / 400 000 edges, Huber, AMM-PGO#, 8 nodes): the objective trace of
     the HIP path against the independent C++ CPU restatement (host multifrontal solves, host TNT; pinned to the oracle
     by the test above), iteration by iteration to 1e-8 relative (measured: 2e-11) over 88 iterations, the last ten of them
     with inner CG steps -- the sizes the numpy oracle cannot afford."""

@@ -106,3 +106,41 @@ def test_tnt_unit_test_known_answers():
         assert r["status"] == "Gradient"
         assert np.linalg.norm(gradF(r["x"])) < 1e-8
         assert f(r["x"]) < f(X0)
+
+
+def _pgo_cases(golden_dir):
+    with open(os.path.join(golden_dir, "tnt_pgo_ref.jsonl")) as fh:
+        return [json.loads(l) for l in fh if l.strip()]
+
+
+def _capture(recipe):
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_tnt_pgo_golden", os.path.join(here, "golden", "make_tnt_pgo_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.capture(recipe["dataset"], recipe["num_nodes"], recipe["loss"], recipe["accelerated"], recipe["node"],
+                       recipe["call"], recipe["overrides"])
+
+
+def test_tnt_on_pgo_problems_matches_reference(golden_dir):
+    """the reference's TNT (TNT.h:242-693, compiled where it lies) driven by DPGO-shaped operators on one
+    node's surrogate of smallGrid3D / tinyGrid3D (tests/golden/tnt_pgo_ref.jsonl, made by make_tnt_pgo_golden.py with
+    oracle/ref_tnt/harness_pgo.cpp's own dense restatement of the operators) against the oracle's TNT call of
+    DPGOHash (oracle/hash.py::_tnt with the operators of oracle/problem.py): same objective values, radii, gain ratios,
+    CG iteration counts, status and final point.  This pins the a11 pieces (reduced gradient, Hessian-vector product,
+    preconditioner, retraction) and their wiring into TNT, not only the solver on toy problems."""
+    cases = _pgo_cases(golden_dir)
+    assert len(cases) >= 7
+    for c in cases:
+        _, nd, got = _capture(c["recipe"])
+        res, log = got["res"], got["log"]
+        assert got["outer"] == c["recipe"]["outer_iteration"], c["case"]
+        assert res["status"] == STATUS[c["status"]], c["case"]
+        assert math.isclose(res["f"], c["f"], rel_tol=1e-11), c["case"]
+        assert [l["inner"] for l in log] == [int(v) for v in c["inner_iterations"]], c["case"]
+        np.testing.assert_allclose([l["Delta"] for l in log], c["trust_region_radius"][:len(log)], rtol=1e-9, err_msg=c["case"])
+        # (a gain ratio is a quotient of differences of nearly equal objective values: the last iterations of the tight
+        # case have df / f ~ 1e-10, so it carries about five digits)
+        np.testing.assert_allclose([l["rho"] for l in log], c["gain_ratios"], rtol=1e-4, atol=1e-9, err_msg=c["case"])
+        np.testing.assert_allclose(res["x"], np.asarray(c["x"]).reshape(res["x"].shape), atol=1e-10, err_msg=c["case"])

@@ -557,13 +557,17 @@ int main(int argc, char **argv) {
     init_state();
     omp_set_num_threads(threads);          // the timed part runs on the requested number of threads
     for (auto &nd : nodes) update(nd, o);   // the update before the loop (dist_pgo.cpp:455-462), untimed
-    if (trace) fprintf(stderr, "0: %.12e\n", F2());
+    if (trace) fprintf(stderr, "0: %.12e 0\n", F2());   // iteration, 2 F, timed seconds so far (iterate + update)
     t_timed = 0;
     for (int it = 0; it < iters; it++) {
       timed([&](Node &nd) { iterate(nd, o); });
       communicate();
       timed([&](Node &nd) { update(nd, o); });
-      if (trace) fprintf(stderr, "%d: %.12e\n", it + 1, F2());
+      if (trace) {
+        long cgn = 0;
+        for (auto &nd : nodes) cgn += nd.cg_steps;
+        fprintf(stderr, "%d: %.12e %.6f %ld\n", it + 1, F2(), t_timed, cgn);
+      }
     }
     long cg = 0;
     for (auto &nd : nodes) cg += nd.cg_steps;
