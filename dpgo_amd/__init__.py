@@ -467,6 +467,50 @@ class NodeGroup:
         assert X.flags.f_contiguous
         return lib().dpgo_group_scatter_global(self._h, _dp(X), X.shape[0])
 
+    def connect_torch(self):
+        """Connect this group to the groups of the other processes of an initialised torch.distributed process group
+        (one process per GPU: backend nccl = RCCL; gloo: staged through the host, lets several processes share a GPU
+        in tests): the recv lay-out of the boundary poses and the two collectives the library needs when the nodes
+        of the graph are spread over several groups (AMM-PGO*, the distributed chordal initialisation, global
+        evaluations).  Returns (dist, torch, send, gathered, stream, allgather)."""
+        import torch
+        import torch.distributed as dist
+        world, RS = dist.get_world_size(), (self.d + 1) * self.d
+        host = dist.get_backend() == "gloo"          # gloo: staged through pinned host tensors
+        keys = self.sent_keys()
+        allkeys = [None] * world
+        dist.all_gather_object(allkeys, (keys[0].tolist(), keys[1].tolist()))
+        stride = max(max(len(k[0]) for k in allkeys), 1)
+        self.set_recv_layout(stride, [(np.asarray(k[0], np.int32), np.asarray(k[1], np.int32)) for k in allkeys])
+        send = torch.zeros(stride * RS, dtype=torch.float64, device="cuda")
+        gathered = torch.zeros(world * stride * RS, dtype=torch.float64, device="cuda")
+        send_h = torch.zeros(stride * RS, dtype=torch.float64) if host else None
+        gathered_h = torch.zeros(world * stride * RS, dtype=torch.float64) if host else None
+        ext = torch.cuda.ExternalStream(self.stream())
+        torch.cuda.synchronize()
+
+        def allgather():
+            with torch.cuda.stream(ext):
+                if host:
+                    send_h.copy_(send)
+                    dist.all_gather_into_tensor(gathered_h, send_h)
+                    gathered.copy_(gathered_h)
+                else:
+                    dist.all_gather_into_tensor(gathered, send)
+            return 0
+
+        def allreduce(vals):
+            t = torch.from_numpy(vals.copy())
+            if not host:
+                t = t.cuda()
+            dist.all_reduce(t)                       # same reduction order on every rank: identical branches
+            vals[:] = t.cpu().numpy()
+            return 0
+        if self.set_collectives(send.data_ptr(), gathered.data_ptr(), allgather, allreduce) != 0:
+            raise RuntimeError("dpgo_group_set_collectives failed")
+        self._torch_link = (dist, torch, send, gathered, ext, allgather)
+        return self._torch_link
+
     def dist_chordal_initialization(self, options=None, X_local=None):
         """The --dist_init true branch of dist_pgo (dist_pgo.cpp:144-416): returns (X, objectives) -- the initial
         guess ((d+1)N x d) and the stage objectives sampled every 20 iterations."""
@@ -675,42 +719,7 @@ class DPGOStar:
             self._connect()
 
     def _connect(self):
-        import torch
-        import torch.distributed as dist
-        world, RS = dist.get_world_size(), (self.graph.d + 1) * self.graph.d
-        host = dist.get_backend() == "gloo"          # gloo: staged through pinned host tensors
-        keys = self.group.sent_keys()
-        allkeys = [None] * world
-        dist.all_gather_object(allkeys, (keys[0].tolist(), keys[1].tolist()))
-        stride = max(max(len(k[0]) for k in allkeys), 1)
-        self.group.set_recv_layout(stride, [(np.asarray(k[0], np.int32), np.asarray(k[1], np.int32)) for k in allkeys])
-        send = torch.zeros(stride * RS, dtype=torch.float64, device="cuda")
-        gathered = torch.zeros(world * stride * RS, dtype=torch.float64, device="cuda")
-        send_h = torch.zeros(stride * RS, dtype=torch.float64) if host else None
-        gathered_h = torch.zeros(world * stride * RS, dtype=torch.float64) if host else None
-        ext = torch.cuda.ExternalStream(self.group.stream())
-        torch.cuda.synchronize()
-
-        def allgather():
-            with torch.cuda.stream(ext):
-                if host:
-                    send_h.copy_(send)
-                    dist.all_gather_into_tensor(gathered_h, send_h)
-                    gathered.copy_(gathered_h)
-                else:
-                    dist.all_gather_into_tensor(gathered, send)
-            return 0
-
-        def allreduce(vals):
-            t = torch.from_numpy(vals.copy())
-            if not host:
-                t = t.cuda()
-            dist.all_reduce(t)                       # same reduction order on every rank: identical branches
-            vals[:] = t.cpu().numpy()
-            return 0
-        self._dist = (dist, torch, send, gathered, ext, allgather)
-        if self.group.set_collectives(send.data_ptr(), gathered.data_ptr(), allgather, allreduce) != 0:
-            raise RuntimeError("dpgo_group_set_collectives failed")
+        self._dist = self.group.connect_torch()
 
     def initialize(self, X):
         X, ld = _fcol(X)

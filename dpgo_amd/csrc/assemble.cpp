@@ -153,12 +153,14 @@ int assemble_node(const DataInfo &info, double xi, bool trivial, NodeOperators &
   Q.finish(ops.Q);
   if (trivial) { S.finish(ops.S); P.finish(ops.P); P0.finish(ops.P0); }
   ops.D.assign((size_t)n0 * B * B, 0.0);
+  ops.Hd.assign((size_t)n0 * B * B, 0.0);
   ops.Tinv.assign(n0, 0.0);
   ops.N.assign((size_t)n0 * d, 0.0);
   ops.V.assign((size_t)n0 * d * d, 0.0);
   for (int i = 0; i < n0; i++) {
     std::memcpy(&ops.D[(size_t)i * B * B], Dd.at(i, i), sizeof(double) * B * B);
     const double *h = H.at(i, i);
+    std::memcpy(&ops.Hd[(size_t)i * B * B], h, sizeof(double) * B * B);
     // T = diag(H_tt)^-1, N = T H_tR, V = H_RR - H_Rt T H_tR (:2280-2282 / :2958-2964)
     const double T = 1.0 / h[0];
     ops.Tinv[i] = T;

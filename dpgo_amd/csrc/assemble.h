@@ -33,6 +33,7 @@ struct NodeOperators {
   BsrMatrix P, P0;    // (own+nbr)^2         (trivial)
   BsrMatrix Q;        // (own+nbr)^2: trivial -> -1/2 E+ - xi ; robust -> block diagonal 2 bd(E) + 2 xi
   std::vector<double> D;      // own block diagonal, B*B per pose
+  std::vector<double> Hd;     // diagonal blocks of the proximal majoriser H (what T, N, V are made of), B*B per pose
   std::vector<double> Tinv;   // T_i = 1 / h_tt                         (n0)
   std::vector<double> N;      // N_i = T_i h_tR                         (n0 x d)
   std::vector<double> V;      // V_i = H_RR - h_tR^T T_i h_tR           (n0 x d x d)

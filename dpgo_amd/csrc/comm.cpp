@@ -225,6 +225,7 @@ int Comm::cb_allgather(void *user) {
 
 int Comm::cb_allreduce(void *user, double *vals, int n) {
   try {
+    if (n > 4096) return static_cast<Comm *>(user)->allreduce_large(vals, (size_t)n);   // (global arrays of the distributed initialisation)
     return static_cast<Comm *>(user)->allreduce(vals, n);
   } catch (const std::exception &) {
     return -1;

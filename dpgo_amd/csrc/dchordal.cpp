@@ -150,15 +150,6 @@ std::map<int, int> make_n_index(const DataInfo &info) {
   return out;
 }
 
-// n_communicate (DChordalReduced.h:24-51): the neighbours' own blocks into Xk
-void n_communicate(std::vector<ReducedNode> &st) {
-  for (auto &s : st)
-    for (const auto &bi : s.n_index) {
-      if (bi.first == s.a) continue;
-      const ReducedNode &o = st[bi.first];
-      std::copy(o.Xk.begin(), o.Xk.begin() + (size_t)s.p * s.d, s.Xk.begin() + (size_t)bi.second * s.p * s.d);
-    }
-}
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------
@@ -343,7 +334,13 @@ int Group::chordal_step() {
   launch_extrapolate(d_, st_, T_, true, cur_mask_, gam, Zc_.p, Zp_.p, Y_.p);
   launch_bsr(d_, st_, T_, false, cur_mask_, ch_->S.dev, Y_.p, false, ch_->gconst.p, T1_.p, nullptr, 0, nullptr, nullptr, 0);
   spd_run(d_, st_, ch_->L, cur_mask_, T1_.p, Xk_.p, -1.0);   // Xak = -G^-1 (g_ + S Y), straight into Xk's own rows
-  return communicate_local();
+  if (communicate_local() != 0) return -1;
+  if (coll_allgather_) {   // neighbours hosted by other groups: the boundary rows travel like the iterate's (DChordal.h:26-84)
+    launch_copy_indexed(d_, st_, (int)sent_rows_.size(), nullptr, sent_rows_dev_.p, Xk_.p, coll_send_);
+    if (coll_allgather_(coll_user_) != 0) { fprintf(stderr, "[dpgo_amd] ERROR: all-gather callback failed.\n"); return -1; }
+    launch_copy_indexed(d_, st_, (int)recv_dst_.n, recv_dst_.p, recv_src_.p, coll_gathered_, Xk_.p);
+  }
+  return 0;
 }
 
 // 0.5 * sum_a |B Xk + b|^2 (DChordal_utils.h:129-140), on the host from a copy of Xk
@@ -402,27 +399,93 @@ int Group::chordal_get(std::vector<std::vector<double>> &Xak) {
 // ---------------------------------------------------------------------------------------------------------
 // The driver schedule (dist_pgo.cpp:144-416)
 // ---------------------------------------------------------------------------------------------------------
+// The nodes of the graph may be spread over several groups (one per GPU / process) connected by the collectives of
+// dpgo_group_set_collectives / dpgo_comm_create: every group runs the schedule for ITS nodes, and what a node needs from
+// another one travels the way the reference's halo exchanges do (DChordal.h:26-84, DChordalReduced.h:24-51) --
+//   * per iteration of a sparse stage: the boundary rows of Xk, the device all-gather of the main exchange (chordal_step);
+//   * per iteration of a reduced stage: every node's own block, a sum over the groups of an array with one slot per node;
+//   * between the stages: own-pose blocks by global pose id / per-node blocks by node id, summed the same way (each
+//     entry has exactly one owner, so the sum is a gather and every group ends up with the same bits);
+//   * the sampled objectives: sums over the groups.
+// With one group that hosts every node the same code runs on local copies.
 int Group::dist_chordal_initialization(const DChordalOptions &o, const double *Xlocal, int ldl, double *X, int ld,
                                        std::vector<double> *objectives) {
   finish_update();
-  const int N = num_local(), d = d_, NP = num_poses_global_;
+  const int N = num_local(), Nn = num_nodes_total_, d = d_, NP = num_poses_global_;
   SetupClock clk;   // (DPGO_SETUP_TIMING=1)
-  if (N != num_nodes_total_) {
-    fprintf(stderr, "[dpgo_amd] ERROR: the distributed chordal initialisation needs every node of the graph in the group.\n");
+  const bool spread = N != Nn;
+  if (spread && !(coll_allreduce_ && coll_allgather_)) {
+    fprintf(stderr, "[dpgo_amd] ERROR: the distributed chordal initialisation needs every node of the graph in the group, or "
+                    "collectives (dpgo_group_set_collectives / dpgo_comm_create) that connect the groups.\n");
     return -1;
   }
-  if (N < 2) {   // the reference reads inter_measurements[0] unguarded (DChordal_utils.cpp:86,383,627,937)
+  if (Nn < 2) {   // the reference reads inter_measurements[0] unguarded (DChordal_utils.cpp:86,383,627,937)
     fprintf(stderr, "[dpgo_amd] ERROR: the distributed chordal initialisation needs at least two nodes (use the centralised one).\n");
     return -1;
   }
   if (ld < (d + 1) * NP || (Xlocal && ldl < (d + 1) * NP)) return -1;
-  for (int a = 0; a < N; a++)
-    if (nodes_[a] != a) {
+  for (int a = 0; a + 1 < N; a++)
+    if (nodes_[a] >= nodes_[a + 1]) {
       fprintf(stderr, "[dpgo_amd] ERROR: the distributed chordal initialisation expects the nodes in order.\n");
       return -1;
     }
   if (objectives) objectives->clear();
   auto gid = [&](int a, int k) { return g_index_[a].at(info_[a].own_pose[k]); };
+  // global id of a neighbour pose from the partition rule (DPGO_utils.cpp:147-158)
+  const int pq = NP / Nn, pinc = NP - Nn * pq;
+  auto key_gid = [&](const std::pair<int, int> &key) {
+    return (key.first < pinc ? key.first * (pq + 1) : pinc * (pq + 1) + (key.first - pinc) * pq) + key.second;
+  };
+  auto allsum = [&](double *v, size_t n) -> int {
+    if (!coll_allreduce_) return 0;
+    for (size_t off = 0; off < n; off += (size_t)1 << 28) {
+      const int m = (int)std::min<size_t>((size_t)1 << 28, n - off);
+      if (coll_allreduce_(coll_user_, v + off, m) != 0) return -1;
+    }
+    return 0;
+  };
+  // own-pose blocks of bs doubles -> every group; then the neighbour rows of v[a] (behind its n0 own rows) are filled
+  auto share = [&](std::vector<std::vector<double>> &v, int bs) -> int {
+    std::vector<double> glob((size_t)NP * bs, 0.0);
+    for (int a = 0; a < N; a++)
+      for (int k = 0; k < info_[a].n[0]; k++) std::copy(&v[a][(size_t)k * bs], &v[a][(size_t)(k + 1) * bs], &glob[(size_t)gid(a, k) * bs]);
+    if (allsum(glob.data(), glob.size()) != 0) return -1;
+    for (int a = 0; a < N; a++) {
+      const int n0 = info_[a].n[0], n1 = info_[a].n[1];
+      v[a].resize((size_t)(n0 + n1) * bs);
+      for (int k = 0; k < n1; k++) {
+        const size_t g = (size_t)key_gid(info_[a].nbr_key[k]) * bs;
+        std::copy(&glob[g], &glob[g + bs], &v[a][(size_t)(n0 + k) * bs]);
+      }
+    }
+    return 0;
+  };
+  // one block of len doubles per NODE of the graph (by node id): the owners fill theirs, everybody gets all of them
+  auto share_nodes = [&](std::vector<std::vector<double>> &by_node, int len) -> int {
+    std::vector<double> flat((size_t)Nn * len, 0.0);
+    for (int a = 0; a < N; a++) std::copy(by_node[nodes_[a]].begin(), by_node[nodes_[a]].begin() + len, &flat[(size_t)nodes_[a] * len]);
+    if (allsum(flat.data(), flat.size()) != 0) return -1;
+    for (int b = 0; b < Nn; b++) by_node[b].assign(&flat[(size_t)b * len], &flat[(size_t)(b + 1) * len]);
+    return 0;
+  };
+  // n_communicate (DChordalReduced.h:24-51): the neighbours' own blocks into Xk
+  auto n_communicate = [&](std::vector<ReducedNode> &st) -> int {
+    if (st.empty()) return 0;
+    const int len = st[0].p * d;
+    std::vector<double> flat((size_t)Nn * len, 0.0);
+    for (int a = 0; a < N; a++) std::copy(st[a].Xk.begin(), st[a].Xk.begin() + len, &flat[(size_t)nodes_[a] * len]);
+    if (allsum(flat.data(), flat.size()) != 0) return -1;
+    for (auto &sn : st)
+      for (const auto &bi : sn.n_index) {
+        if (bi.first == sn.a) continue;
+        std::copy(&flat[(size_t)bi.first * len], &flat[(size_t)(bi.first + 1) * len], sn.Xk.begin() + (size_t)bi.second * len);
+      }
+    return 0;
+  };
+  auto sum_groups = [&](double v) -> double {
+    if (allsum(&v, 1) != 0) return NAN;
+    return v;
+  };
   // ---- stage 0: local solutions, X_a = [t (n0 x d) ; Y blocks], then the gauge of :156-157 (first rotation = I)
   std::vector<double> Xl;
   if (!Xlocal) {
@@ -436,7 +499,7 @@ int Group::dist_chordal_initialization(const DChordalOptions &o, const double *X
         m.inode = m.jnode = 0;
         gi.all.push_back(m);
       }
-    if (partition(gi, N) != 0) return -1;
+    if (partition(gi, Nn) != 0) return -1;
     Xl.assign((size_t)(d + 1) * NP * d, 0.0);
     const int ldx = (d + 1) * NP;
     for (int a = 0; a < N; a++) {   // chordal initialisation of the node's own subgraph (local pose ids)
@@ -477,16 +540,8 @@ int Group::dist_chordal_initialization(const DChordalOptions &o, const double *X
   clk.lap("dist-init: stage 0 (local solutions)");
   // xs[a]: (n0 + n1) poses, each [t (d) | Y (d x d)] -- own poses in the node's gauge, neighbours filled by communicate
   std::vector<std::vector<double>> xt(N), xY(N);
-  auto fill_neighbours = [&]() {   // DPGO::communicate (DPGO_utils.h:397-453)
-    for (int a = 0; a < N; a++) {
-      const int n0 = info_[a].n[0];
-      for (int k = 0; k < info_[a].n[1]; k++) {
-        const auto key = info_[a].nbr_key[k];
-        const int b = key.first, j = info_[b].index.at(key);
-        std::copy(&xt[b][(size_t)j * d], &xt[b][(size_t)(j + 1) * d], &xt[a][(size_t)(n0 + k) * d]);
-        std::copy(&xY[b][(size_t)j * d * d], &xY[b][(size_t)(j + 1) * d * d], &xY[a][(size_t)(n0 + k) * d * d]);
-      }
-    }
+  auto fill_neighbours = [&]() -> int {   // DPGO::communicate (DPGO_utils.h:397-453)
+    return (share(xt, d) != 0 || share(xY, d * d) != 0) ? -1 : 0;
   };
   for (int a = 0; a < N; a++) {
     const int n0 = info_[a].n[0], n1 = info_[a].n[1];
@@ -507,7 +562,7 @@ int Group::dist_chordal_initialization(const DChordalOptions &o, const double *X
       }
     }
   }
-  fill_neighbours();
+  if (fill_neighbours() != 0) return -1;
   std::vector<std::map<int, int>> nidx(N);
   for (int a = 0; a < N; a++) nidx[a] = make_n_index(info_[a]);
   auto sample = [&](double v) { if (objectives) objectives->push_back(v); };
@@ -515,7 +570,7 @@ int Group::dist_chordal_initialization(const DChordalOptions &o, const double *X
   std::vector<ReducedNode> rr(N);
   for (int a = 0; a < N; a++) {
     ReducedNode &s = rr[a];
-    s.a = a; s.d = d; s.p = d; s.n_index = nidx[a]; s.nn = (int)nidx[a].size() - 1;
+    s.a = nodes_[a]; s.d = d; s.p = d; s.n_index = nidx[a]; s.nn = (int)nidx[a].size() - 1;
     const int rows = (s.nn + 1) * d;
     s.M = (int)info_[a].inter.size();
     std::vector<double> G((size_t)d * d, 0.0);
@@ -526,7 +581,7 @@ int Group::dist_chordal_initialization(const DChordalOptions &o, const double *X
     int e = 0;
     for (const auto &m : info_[a].inter) {
       const int i = info_[a].tail(m), j = info_[a].head(m);
-      const bool tail_local = m.inode == a;
+      const bool tail_local = m.inode == nodes_[a];
       double tmp[9], nR[9];
       mul_tn(d, &xY[a][(size_t)i * d * d], m.R, tmp);      // Y_i^T R_e
       mul_nn(d, tmp, &xY[a][(size_t)j * d * d], nR);       // ... Y_j          (:255-258)
@@ -554,48 +609,41 @@ int Group::dist_chordal_initialization(const DChordalOptions &o, const double *X
     if (it % 20 == 0) {
       double f = 0;
       for (auto &s : rr) f += s.objective();
-      sample(0.5 * f);
+      sample(0.5 * sum_groups(f));
     }
-    for (int a = 1; a < N; a++) { rr[a].update(); rr[a].iterate(); }
-    n_communicate(rr);
+    for (int a = 0; a < N; a++)
+      if (nodes_[a] != 0) { rr[a].update(); rr[a].iterate(); }   // node 0 keeps its gauge (:160-225)
+    if (n_communicate(rr) != 0) return -1;
   }
-  std::vector<std::vector<double>> rots_n(N);
+  std::vector<std::vector<double>> rots_n(Nn, std::vector<double>((size_t)d * d, 0.0));   // by node id
   for (int a = 0; a < N; a++) {
-    rots_n[a].assign(rr[a].Xk.begin(), rr[a].Xk.begin() + d * d);
-    project_to_SOd_host(d, rots_n[a].data());
+    rots_n[nodes_[a]].assign(rr[a].Xk.begin(), rr[a].Xk.begin() + d * d);
+    project_to_SOd_host(d, rots_n[nodes_[a]].data());
   }
+  if (share_nodes(rots_n, d * d) != 0) return -1;
   clk.lap("dist-init: stage 1 (reduced rotations, host)");
   // ---- stage 2: rotations on the device (:230-304)
   std::vector<std::vector<double>> rots(N);
-  auto halo = [&](std::vector<std::vector<double>> &v, int bs) {   // DChordal::communicate (DChordal_utils.h:196-240)
-    for (int a = 0; a < N; a++) {
-      const int n0 = info_[a].n[0];
-      v[a].resize((size_t)(n0 + info_[a].n[1]) * bs);
-      for (int k = 0; k < info_[a].n[1]; k++) {
-        const auto key = info_[a].nbr_key[k];
-        const int j = info_[key.first].index.at(key);
-        std::copy(&v[key.first][(size_t)j * bs], &v[key.first][(size_t)(j + 1) * bs], &v[a][(size_t)(n0 + k) * bs]);
-      }
-    }
-  };
+  auto halo = [&](std::vector<std::vector<double>> &v, int bs) -> int { return share(v, bs); };   // DChordal::communicate (DChordal_utils.h:196-240)
   for (int a = 0; a < N; a++) {
     const int n0 = info_[a].n[0];
     rots[a].assign((size_t)n0 * d * d, 0.0);
-    for (int k = 0; k < n0; k++) mul_nn(d, &xY[a][(size_t)k * d * d], rots_n[a].data(), &rots[a][(size_t)k * d * d]);
+    for (int k = 0; k < n0; k++) mul_nn(d, &xY[a][(size_t)k * d * d], rots_n[nodes_[a]].data(), &rots[a][(size_t)k * d * d]);
   }
-  halo(rots, d * d);
+  if (halo(rots, d * d) != 0) return -1;
   if (chordal_setup(0, o.reg_G, {}) != 0 || chordal_initialize(rots) != 0) return -1;
   for (int it = 0; it < o.iters[1]; it++) {
-    if (it % 20 == 0) sample(chordal_objective());
+    if (it % 20 == 0) sample(sum_groups(chordal_objective()));
     if (chordal_step() != 0) return -1;
   }
   if (chordal_get(rots) != 0) return -1;
   for (int a = 0; a < N; a++) {
     const int n0 = info_[a].n[0];
     for (int k = 0; k < n0; k++) project_to_SOd_host(d, &rots[a][(size_t)k * d * d]);   // per-block projection (:292-298)
-    rots_n[a].assign(rots[a].begin(), rots[a].begin() + d * d);
-    for (int k = 0; k < n0; k++) mul_nt(d, &rots[a][(size_t)k * d * d], rots_n[a].data(), &xY[a][(size_t)k * d * d]);   // back to the node's gauge
+    rots_n[nodes_[a]].assign(rots[a].begin(), rots[a].begin() + d * d);
+    for (int k = 0; k < n0; k++) mul_nt(d, &rots[a][(size_t)k * d * d], rots_n[nodes_[a]].data(), &xY[a][(size_t)k * d * d]);   // back to the node's gauge
   }
+  if (share_nodes(rots_n, d * d) != 0) return -1;
   clk.lap("dist-init: stage 2 (rotations, device)");
   // ---- stage 3: reduced translations (:311-359)
   {
@@ -635,7 +683,7 @@ int Group::dist_chordal_initialization(const DChordalOptions &o, const double *X
         for (int c = 0; c < d; c++) xt[a][(size_t)k * d + c] = -(rhs[(size_t)(off + k) * d + c] - rhs[(size_t)off * d + c]);
     }
   }
-  fill_neighbours();
+  if (fill_neighbours() != 0) return -1;
   std::vector<std::vector<double>> nRs(N);
   for (int a = 0; a < N; a++) {   // DChordal::n_communicate(problems_red_R, rots_n)  (DChordal_utils.h:148-190)
     nRs[a].assign((size_t)nidx[a].size() * d * d, 0.0);
@@ -644,7 +692,7 @@ int Group::dist_chordal_initialization(const DChordalOptions &o, const double *X
   std::vector<ReducedNode> rt(N);
   for (int a = 0; a < N; a++) {
     ReducedNode &s = rt[a];
-    s.a = a; s.d = d; s.p = 1; s.n_index = nidx[a]; s.nn = (int)nidx[a].size() - 1;
+    s.a = nodes_[a]; s.d = d; s.p = 1; s.n_index = nidx[a]; s.nn = (int)nidx[a].size() - 1;
     const int rows = s.nn + 1;
     s.M = (int)info_[a].inter.size();
     double G = 0;
@@ -655,7 +703,7 @@ int Group::dist_chordal_initialization(const DChordalOptions &o, const double *X
     int e = 0;
     for (const auto &m : info_[a].inter) {
       const int i = info_[a].tail(m), j = info_[a].head(m);
-      const bool tail_local = m.inode == a;
+      const bool tail_local = m.inode == nodes_[a];
       const int ni0 = tail_local ? 0 : nidx[a].at(m.inode), ni1 = tail_local ? nidx[a].at(m.jnode) : 0;
       double ti[3], nt[3];
       for (int c = 0; c < d; c++) {
@@ -687,10 +735,11 @@ int Group::dist_chordal_initialization(const DChordalOptions &o, const double *X
     if (it % 20 == 0) {
       double f = 0;
       for (auto &s : rt) f += s.objective();
-      sample(0.5 * f);
+      sample(0.5 * sum_groups(f));
     }
-    for (int a = 1; a < N; a++) { rt[a].update(); rt[a].iterate(); }
-    n_communicate(rt);
+    for (int a = 0; a < N; a++)
+      if (nodes_[a] != 0) { rt[a].update(); rt[a].iterate(); }
+    if (n_communicate(rt) != 0) return -1;
   }
   clk.lap("dist-init: stage 3 (reduced translations, host)");
   // ---- stage 4: translations on the device (:365-407)
@@ -701,16 +750,15 @@ int Group::dist_chordal_initialization(const DChordalOptions &o, const double *X
     for (int k = 0; k < n0; k++)
       for (int c = 0; c < d; c++) {
         double acc = rt[a].Xk[c];
-        for (int q = 0; q < d; q++) acc += xt[a][(size_t)k * d + q] * rots_n[a][q * d + c];
+        for (int q = 0; q < d; q++) acc += xt[a][(size_t)k * d + q] * rots_n[nodes_[a]][q * d + c];
         ts[a][(size_t)k * d + c] = acc;
       }
     rots[a].resize((size_t)n0 * d * d);
   }
-  halo(rots, d * d);
-  halo(ts, d);
+  if (halo(rots, d * d) != 0 || halo(ts, d) != 0) return -1;
   if (chordal_setup(1, o.reg_G, rots) != 0 || chordal_initialize(ts) != 0) return -1;
   for (int it = 0; it < o.iters[3]; it++) {
-    if (it % 20 == 0) sample(chordal_objective());
+    if (it % 20 == 0) sample(sum_groups(chordal_objective()));
     if (chordal_step() != 0) return -1;
   }
   if (chordal_get(ts) != 0) return -1;
@@ -724,6 +772,22 @@ int Group::dist_chordal_initialization(const DChordalOptions &o, const double *X
         for (int r = 0; r < d; r++) X[(size_t)c * ld + NP + gp * d + r] = rots[a][(size_t)k * d * d + r * d + c];
       }
     }
+  if (spread) {   // every group wrote its own poses: the sum over the groups is the whole initial guess
+    for (int c = 0; c < d; c++) {
+      double *col = X + (size_t)c * ld;
+      // (rows of poses hosted elsewhere must be zero before the sum)
+      std::vector<char> mine((size_t)(d + 1) * NP, 0);
+      for (int a = 0; a < N; a++)
+        for (int k = 0; k < info_[a].n[0]; k++) {
+          const int gp = gid(a, k);
+          mine[gp] = 1;
+          for (int r = 0; r < d; r++) mine[(size_t)NP + gp * d + r] = 1;
+        }
+      for (size_t i = 0; i < mine.size(); i++)
+        if (!mine[i]) col[i] = 0.0;
+      if (allsum(col, (size_t)(d + 1) * NP) != 0) return -1;
+    }
+  }
   return 0;
 }
 

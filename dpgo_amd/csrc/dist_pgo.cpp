@@ -91,9 +91,8 @@ int main(int argc, char **argv) {
   std::vector<double> X((size_t)ld * d, 0.0);
   if (num_nodes % world != 0) { fprintf(stderr, "The number of nodes must be a multiple of the number of ranks.\n"); return -1; }
   const int per = num_nodes / world;
-  std::vector<int> ids(per), all_ids(num_nodes);
+  std::vector<int> ids(per);
   for (int a = 0; a < per; a++) ids[a] = rank * per + a;
-  for (int a = 0; a < num_nodes; a++) all_ids[a] = a;
   const bool root = rank == 0;
   dpgo_group_t *grp = nullptr;
   if (dpgo_group_create(g, ids.data(), per, &opt, gpu, &grp) != 0) return -1;
@@ -106,17 +105,14 @@ int main(int argc, char **argv) {
     dpgo_comm_barrier(comm);
   }
   if (dist_init) {
-    // every node of the graph takes part in the distributed initialisation; with several ranks each computes it on
-    // its own GPU with a temporary group over all nodes (set-up, deterministic: the ranks agree to the last bit)
-    dpgo_group_t *ig = grp;
-    if (world > 1 && dpgo_group_create(g, all_ids.data(), num_nodes, &opt, gpu, &ig) != 0) return -1;
+    // every node of the graph takes part in the distributed initialisation; with several ranks each runs the schedule
+    // for its own nodes and the stage halos travel through the communicator (dchordal.cpp)
     dpgo_dchordal_options_t co;
     dpgo_dchordal_options_default(&co);
     int cap = 0;
     for (int k = 0; k < 4; k++) cap += (co.iters[k] + 19) / 20;
     std::vector<double> obj(cap);
-    if (dpgo_group_dist_chordal_initialization(ig, &co, nullptr, 0, X.data(), ld, obj.data(), &cap) != 0) return -1;
-    if (ig != grp) dpgo_group_free(ig);
+    if (dpgo_group_dist_chordal_initialization(grp, &co, nullptr, 0, X.data(), ld, obj.data(), &cap) != 0) return -1;
     const char *names[4] = {"Initialize the reduced rotation", "Initialize the rotation", "Initialize the reduced translation",
                             "Initialize the translation"};
     int at = 0;

@@ -56,6 +56,7 @@ template struct DevBuf<CgNode>;
 template struct DevBuf<NodeBits>;
 template struct DevBuf<PanelSrc>;
 template struct DevBuf<InterInc>;
+template struct DevBuf<RootDesc>;
 
 // tuning hooks (tools/env_ab.sh): an integer from the environment, or the default
 static int env_int(const char *name, int dflt) {
@@ -226,7 +227,7 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
         if (fwd) srcs[i] = PanelSrc{(long long)(F.wt_off[t.f] + t.first), F.ldm[t.f], (int)t.len};
         else srcs[i] = PanelSrc{(long long)(F.w_off[t.f] + (int64_t)t.first * F.ldw[t.f] + t.first), F.ldw[t.f], (int)t.len};
       }
-      DevBuf<PanelSrc> srcs_dev;
+      DevBuf<PanelSrc> &srcs_dev = fwd ? fwd_srcs : bwd_srcs;   // kept: repack() cuts the panels again after a refactorisation
       srcs_dev.upload(srcs);
       panels_dev.alloc((size_t)std::max<int64_t>(total, 1));   // (zero-filled: the padding of a panel row stays zero)
       launch_pack_panels(nullptr, items_dev.p, srcs_dev.p, (int)tiles.size(), fwd ? F.dev_WT : F.dev_W, panels_dev.p);
@@ -282,14 +283,23 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
     }
     std::vector<SpdItem> items(tiles.size());
     std::vector<PanelSrc> srcs(tiles.size());
-    // where the roots' W_s = L11^-1 are: still on the device after a device factorisation, else uploaded here
+    // where the roots' W_s = L11^-1 are: still on the device after a device factorisation, else uploaded here; the dense
+    // products P_f = L11^-T L11^-1 go to a buffer of their own (Proot), the tiles' panels are cut out of it
     std::vector<double> host_src;
-    std::vector<int64_t> src_off(F.nfronts, 0);
-    if (!F.dev_W)
-      for (int f : roots) {
-        src_off[f] = (int64_t)host_src.size();
-        host_src.insert(host_src.end(), F.W.begin() + F.w_off[f], F.W.begin() + F.w_off[f] + (size_t)F.w[f] * F.ldw[f]);
-      }
+    std::vector<RootDesc> rdesc;
+    std::vector<int64_t> p_off(F.nfronts, 0);
+    int64_t ptotal = 0;
+    root_max_w = 0;
+    for (int f : roots) {
+      RootDesc rd;
+      rd.src_off = F.dev_W ? F.w_off[f] : (long long)host_src.size();
+      if (!F.dev_W) host_src.insert(host_src.end(), F.W.begin() + F.w_off[f], F.W.begin() + F.w_off[f] + (size_t)F.w[f] * F.ldw[f]);
+      rd.dst_off = ptotal; rd.ld = F.ldw[f]; rd.w = F.w[f];
+      p_off[f] = ptotal;
+      ptotal += (int64_t)F.w[f] * F.w[f];
+      root_max_w = std::max(root_max_w, F.w[f]);
+      rdesc.push_back(rd);
+    }
     int64_t total = 0;
     for (size_t i = 0; i < tiles.size(); i++) {
       const Tile &t = tiles[i];
@@ -303,18 +313,21 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
       it.mat_off = total;
       it.pad2 = 0;
       items[i] = it;
-      srcs[i] = PanelSrc{(long long)(F.dev_W ? F.w_off[f] : src_off[f]), F.ldw[f], F.w[f]};
+      srcs[i] = PanelSrc{(long long)(p_off[f] + t.first), F.w[f], F.w[f]};   // columns first.. of the dense w x w product
       total += (int64_t)F.w[f] * ld;
     }
     if (!tiles.empty()) {
       root_items.upload(items);
-      DevBuf<PanelSrc> srcs_dev;
-      srcs_dev.upload(srcs);
+      root_srcs.upload(srcs);
+      root_desc.upload(rdesc);
       DevBuf<double> src_dev;
       if (!F.dev_W) src_dev.upload(host_src);
+      Proot.alloc((size_t)ptotal, false);
       Wroot.alloc((size_t)total);   // (zero-filled: the padding of a panel row stays zero)
-      launch_root_product(nullptr, root_items.p, srcs_dev.p, (int)tiles.size(), F.dev_W ? F.dev_W : src_dev.p, Wroot.p);
+      launch_root_syrk(nullptr, root_desc.p, (int)rdesc.size(), root_max_w, F.dev_W ? F.dev_W : src_dev.p, Proot.p);
+      launch_pack_panels(nullptr, root_items.p, root_srcs.p, (int)tiles.size(), Proot.p, Wroot.p);
       HIP_CHECK(hipDeviceSynchronize());
+      if (!F.keep_numeric) Proot.release();   // (kept for repack() when the factor is re-done with new values)
     }
     if (getenv("DPGO_SPD_DUMP"))
       fprintf(stderr, "[spd] dof %d fused roots: %zu fronts, %zu tiles x %d rows, %.1f MB of panels\n", dof, roots.size(), tiles.size(), rows, total * 8e-6);
@@ -334,6 +347,20 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
 }
 
 static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec);
+
+// New values in the same factor (F.dev_W / F.dev_WT after spd_refactor_device): the panels of every tile are cut out
+// again on the device, with the tile lists and sources the first upload() left there.  Enqueued on `st`.
+int SpdSolverDev::repack(hipStream_t st) {
+  if (!F.dev_W || !F.dev_WT || fwd_srcs.n != fwd_items.n || bwd_srcs.n != bwd_items.n) return -1;
+  launch_pack_panels(st, fwd_items.p, fwd_srcs.p, (int)fwd_items.n, F.dev_WT, WT.p);
+  launch_pack_panels(st, bwd_items.p, bwd_srcs.p, (int)bwd_items.n, F.dev_W, W.p);
+  if (fused_root && root_items.n > 0) {
+    if (root_srcs.n != root_items.n || Proot.n == 0) return -1;
+    launch_root_syrk(st, root_desc.p, (int)root_desc.n, root_max_w, F.dev_W, Proot.p);
+    launch_pack_panels(st, root_items.p, root_srcs.p, (int)root_items.n, Proot.p, Wroot.p);
+  }
+  return 0;
+}
 
 // lambda_max of a symmetric matrix by Lanczos with full reorthogonalisation (stands in for the
 // Spectra call of DPGOProblem.cpp:106-118, tolerance 1e-4).
@@ -497,13 +524,14 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   cur_mask_ = ALL_NODES;
   // pinned: [scalars of k_reduce | a cache line | the flag's cache line | CG summaries | TNT summaries]
   const size_t nsc = (size_t)std::max(L, 1) * MAX_SLOTS;
-  HIP_CHECK(hipHostMalloc((void **)&h_scal_, sizeof(double) * (nsc + 16 + (size_t)std::max(L, 1) * (CG_SUMMARY + TNT_SUMMARY)),
+  HIP_CHECK(hipHostMalloc((void **)&h_scal_, sizeof(double) * (nsc + 16 + (size_t)std::max(L, 1) * (CG_SUMMARY + TNT_SUMMARY + 1)),
                           hipHostMallocMapped | hipHostMallocCoherent));
   h_flag_ = reinterpret_cast<unsigned long long *>(h_scal_ + nsc + 8);
   *h_flag_ = 0;
   h_cg_ = h_scal_ + nsc + 16;
   h_tnt_ = h_cg_ + (size_t)std::max(L, 1) * CG_SUMMARY;
-  for (int i = 0; i < std::max(L, 1) * (CG_SUMMARY + TNT_SUMMARY); i++) h_cg_[i] = 0.0;
+  h_rs_ = h_tnt_ + (size_t)std::max(L, 1) * TNT_SUMMARY;
+  for (int i = 0; i < std::max(L, 1) * (CG_SUMMARY + TNT_SUMMARY + 1); i++) h_cg_[i] = 0.0;
   reduce_arrived_.alloc(1);
   partials_.alloc((size_t)MAX_SLOTS * std::max(T_.nseg_all, 1));
   cg_.alloc(MAX_LOCAL_NODES);
@@ -553,7 +581,13 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
     E_.nrows_own = P0_; E_.nrows_all = P0_ + P1_;
     E_.m = (int)tail.size(); E_.tail = e_tail_.p; E_.head = e_head_.p; E_.R = e_R_.p; E_.t = e_t_.p;
     E_.kappa = e_kappa_.p; E_.tau = e_tau_.p; E_.inc_ptr = e_inc_ptr_.p; E_.inc = e_inc_.p;
-    if (dynamic()) e_w_.alloc(std::max<size_t>(tail.size(), 1));
+    if (dynamic()) {
+      e_w_.alloc(std::max<size_t>(tail.size(), 1));
+      e_scale_.upload(std::vector<double>(std::max<size_t>(tail.size(), 1), 1.0));   // all ones at construction (DPGOProblem.cpp:34)
+      e_off_dev_.upload(e_off_);
+      rs_count_.alloc(std::max(L, 1));
+      rs_flags_.alloc(std::max(L, 1));
+    }
   }
   {
     std::vector<int> tail, head;
@@ -582,6 +616,7 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   }
   // ---- SPD solvers: one block-diagonal system over all local nodes
   if (refactor_tt() != 0) return;
+  if (dynamic() && Ltt_.F.numeric) setup_device_rescale();
   {
     SetupClock clk;
     CsrMatrix Arr;
@@ -719,6 +754,18 @@ int Group::refactor_tt() {
   }
   Att.n = (int)Att.ptr.size() - 1;
   SetupClock clk;
+  // Rescale::Dynamic re-factors G_tt every few iterations: the numeric phase keeps its device state, and the values it
+  // reads stay on the GPU where k_rescale_apply rewrites the diagonal (att_pos_: where each pose's diagonal entry is)
+  const bool keep = dynamic() && env_int("DPGO_RESCALE_HOST", 0) == 0 && env_int("DPGO_SPD_DEVICE_PANELS", 1) != 0 &&
+                    env_int("DPGO_SPD_HOST_FACTOR", 0) == 0;
+  Ltt_.F.keep_numeric = keep;
+  if (keep && att_pos_.n == 0) {
+    std::vector<int> pos(std::max(Att.n, 1), 0);
+    for (int i = 0; i < Att.n; i++)
+      for (int e = Att.ptr[i]; e < Att.ptr[i + 1]; e++)
+        if (Att.col[e] == i) pos[i] = e;
+    att_pos_.upload(pos);
+  }
   if (Ltt_.F.n == Att.n && Ltt_.F.nfronts > 0 && !Ltt_.F.children.empty()) {
     // same pattern, new values (a Dynamic rescale): numeric phase only, on the GPU
     if (spd_refactor(Att, Ltt_.F) != 0) return -1;
@@ -1054,6 +1101,7 @@ int Group::initialize(int a, const double *X, int ld) {
   res_[a] = NodeResults();
   res_[a].updated = 0;
   rescale_count_[a] = 0;   // DPGOResult::clear (DPGO_types.h:301); the scales belong to the problem and stay
+  if (device_rescale_) HIP_CHECK(hipMemset(rs_count_.p + a, 0, sizeof(int)));
   return 0;
 }
 
@@ -1447,6 +1495,74 @@ std::vector<int> Group::maybe_rescale(const std::vector<int> &set) {
   return changed;
 }
 
+// What the device-side rescale needs beside the scales: the diagonal blocks of G and of the proximal majoriser H with
+// every scale at zero (the intra-node part + the regulariser), and where the diagonal block of every own pose sits in
+// the uploaded block values of G.
+void Group::setup_device_rescale() {
+  const int L = num_local(), BB = B_ * B_;
+  std::vector<double> Gb((size_t)std::max(P0_, 1) * BB, 0.0), Hb((size_t)std::max(P0_, 1) * BB, 0.0);
+  std::vector<int> gpos((size_t)std::max(P0_, 1) * 4, 0);
+  int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(std::max(1, std::min(L, host_threads()))) reduction(+ : bad)
+  for (int a = 0; a < L; a++) {
+    NodeOperators base;
+    const std::vector<double> zeros(std::max<size_t>(info_[a].inter.size(), 1), 0.0);
+    if (assemble_node(info_[a], opt_.regularizer, false, base, zeros.data()) != 0) { bad++; continue; }
+    for (int r = 0; r < info_[a].n[0]; r++) {
+      for (int k = base.G.ptr[r]; k < base.G.ptr[r + 1]; k++)
+        if (base.G.col[k] == r) std::copy(&base.G.val[(size_t)k * BB], &base.G.val[(size_t)(k + 1) * BB], &Gb[(size_t)(own_off_[a] + r) * BB]);
+      std::copy(&base.Hd[(size_t)r * BB], &base.Hd[(size_t)(r + 1) * BB], &Hb[(size_t)(own_off_[a] + r) * BB]);
+    }
+  }
+  if (bad) throw DeviceError("assemble_node");
+  // the unified block-CSR of G (upload_bsr): rows of node a at own_off_[a], its blocks in the order of ops_[a].G
+  int kuni = 0;
+  for (int a = 0; a < L; a++) {
+    const BsrMatrix &M = ops_[a].G;
+    for (int r = 0; r < M.nrows; r++) {
+      const int k0row = kuni, cntrow = M.ptr[r + 1] - M.ptr[r];
+      for (int k = M.ptr[r]; k < M.ptr[r + 1]; k++)
+        if (M.col[k] == r) {
+          const int kk = k - M.ptr[r], round0 = k0row + (kk / BSR_LPR) * BSR_LPR;
+          int *g = &gpos[(size_t)(own_off_[a] + r) * 4];
+          g[0] = round0 * BB;
+          g[1] = std::min(BSR_LPR, k0row + cntrow - round0);
+          g[2] = kk % BSR_LPR;
+          g[3] = k0row + kk;
+        }
+      kuni += cntrow;
+    }
+  }
+  Gbase_.upload(Gb);
+  Hbase_.upload(Hb);
+  gpos_.upload(gpos);
+  device_rescale_ = true;
+}
+
+// The decision of k_rescale_decide has arrived (h_rs_): rebuild the block-diagonal terms of the rescaled nodes on the
+// device, re-factor G_tt from the values that are already there, cut the solve's panels again.
+std::vector<int> Group::rescale_device(const std::vector<int> &set) {
+  SetupClock clk;   // (DPGO_SETUP_TIMING=1)
+  std::vector<int> changed;
+  for (int a : set)
+    if (h_rs_[a] != 0.0) changed.push_back(a);
+  if (changed.empty()) return changed;
+  RescaleArgs A;
+  A.flags = rs_flags_.p; A.scale = e_scale_.p; A.Gbase = Gbase_.p; A.Hbase = Hbase_.p; A.gpos = gpos_.p; A.att_pos = att_pos_.p;
+  A.Gval = G_.val.p; A.Gtcol = G_.tcol.p; A.Dd = Dd_.p; A.Qd = Qd_.p; A.Tinv = Tinv_.p; A.N = N_.p; A.V = V_.p;
+  A.att_val = spd_numeric_values(Ltt_.F);
+  A.xi = opt_.regularizer;
+  launch_rescale_apply(d_, st_, T_, E_, A);
+  HIP_CHECK(hipStreamSynchronize(st_));   // the factorisation runs on a stream of its own
+  clk.lap("rescale: block-diagonal terms (device)");
+  if (spd_refactor_device(Ltt_.F) != 0) throw DeviceError("G_tt is not positive definite after a rescale");
+  clk.lap("rescale: numeric factorisation of G_tt (device)");
+  if (Ltt_.repack(st_) != 0) throw DeviceError("repack");
+  if (clk.on) HIP_CHECK(hipStreamSynchronize(st_));
+  clk.lap("rescale: panels");
+  return changed;
+}
+
 int Group::update(const std::vector<int> &locals_in) {
   finish_update();
   std::vector<int> locals;
@@ -1545,13 +1661,16 @@ int Group::update(const std::vector<int> &locals_in) {
       launch_inter(d_, st_, T_, cur_mask_, E_, opt_.loss, opt_.loss_reg, 0, pass == 1, Zc_.p, Zp_.p, Qd_.p, Dd_.p, DfE_.p,
                    gc_.p, partials_.p, dynamic() ? e_w_.p : nullptr);   // slots 0, 1 and 2 = <X, g>
       std::vector<double> rho(num_local(), 0.0), gap(num_local(), 0.0);
+      if (dynamic() && device_rescale_)   // the rescale test on the weights just computed; its verdict rides with the sums below
+        launch_rescale_decide(st_, num_local(), cur_mask_.v, e_off_dev_.p, e_w_.p, e_scale_.p, rs_count_.p, opt_.max_rescale_count,
+                              rs_flags_.p, h_rs_);
       if (dynamic()) {
         // Rescale::Dynamic: the sum of rho and the majorisation gap (under the OLD Q) are final; whether the
         // surrogate is rescaled depends on the edge weights just computed (:300-321, :464-485).  Rescaled nodes get
         // their D, G, T, N, V, Q and the factor of G_tt rebuilt, and g, G X are taken again with the new operators.
         fetch(3, true);
         for (int a : set) { rho[a] = scal(a, 0); gap[a] = scal(a, 1); }
-        const std::vector<int> changed = maybe_rescale(set);
+        const std::vector<int> changed = device_rescale_ ? rescale_device(set) : maybe_rescale(set);
         if (!changed.empty()) {
           set_mask(changed);
           launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Zc_.p, false, nullptr, T1_.p, Zc_.p, 0.5, nullptr, partials_.p, 5);

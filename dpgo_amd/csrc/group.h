@@ -119,7 +119,7 @@ struct SetupClock {
 
 struct SpdSolverDev {
   SpdFactor F;   // host copy kept for sizes / host solves
-  ~SpdSolverDev() { spd_release_device(F); }
+  ~SpdSolverDev() { spd_release_device(F); spd_release_numeric(F); }
   DevBuf<int> piv_idx, upd_idx, asm_ptr, ubuf_dst;
   DevBuf<double> W, WT, ubuf, ytmp;   // W / WT: backward / forward panels (see upload)
   DevBuf<SpdItem> fwd_items, bwd_items;
@@ -138,12 +138,16 @@ struct SpdSolverDev {
   Level root_level{0, 0, 0, 64, {}, {}, {}, {}, {}};
   bool fused_root = false;
   DevBuf<SpdItem> root_items;
-  DevBuf<double> Wroot;
+  DevBuf<double> Wroot, Proot;   // the root tiles' panels; the dense products they are cut from (kept with keep_numeric)
+  DevBuf<RootDesc> root_desc;
+  int root_max_w = 0;
   std::vector<double> fwd_level_bytes, bwd_level_bytes;
   SpdDev dev;
   int dof = 1;
   bool stream_once = true;   // panels read with non-temporal loads (see upload)
   void upload(int dcols, const std::vector<int> &node_of_unknown);   // node_of_unknown: local node of every row of A
+  DevBuf<PanelSrc> fwd_srcs, bwd_srcs, root_srcs;   // where every tile's panel comes from in the front-major factor
+  int repack(hipStream_t st);   // the panels again from F.dev_W / F.dev_WT (same pattern, new values)
 };
 
 // out <- scale * A^-1 in on the unknowns' entries of the records (everything else in `out` is left alone); in != out
@@ -314,6 +318,15 @@ class Group {
   std::vector<int> e_off_;          // first inter edge of every node in E_
   DevBuf<double> e_w_;
   bool dynamic() const { return opt_.loss != 0 && opt_.rescale == 1; }
+  // ... on the device (DPGO_RESCALE_HOST=1 keeps the host path: weights read back, operators re-assembled and uploaded):
+  // the scales, counters and decisions live in device memory, the block-diagonal terms are rebuilt by k_rescale_apply
+  // and G_tt is re-factored from values that never leave the GPU (SpdFactor::keep_numeric)
+  bool device_rescale_ = false;
+  DevBuf<double> e_scale_, Gbase_, Hbase_;
+  DevBuf<int> rs_count_, rs_flags_, gpos_, att_pos_, e_off_dev_;
+  double *h_rs_ = nullptr;   // pinned (same allocation as h_scal_): the rescale decision of every node
+  std::vector<int> rescale_device(const std::vector<int> &set);   // after the decision arrived: apply + refactor; returns the rescaled nodes
+  void setup_device_rescale();
   // decide per node whether its surrogate is rescaled (weights in e_w_), rebuild what changed; returns the nodes
   // that were rescaled
   std::vector<int> maybe_rescale(const std::vector<int> &set);

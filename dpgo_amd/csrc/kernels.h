@@ -135,6 +135,21 @@ void launch_inter(int d, hipStream_t st, const SegTable &T, NodeMask mask, const
                   const double *Qdiag, const double *Ddiag, double *DfE, double *g, double *partials,
                   double *wout = nullptr);   // wout (mode 0): the loss weight of every edge
 
+// ---- Rescale::Dynamic on the device (see k_rescale_decide / k_rescale_apply) ----
+// decide: flags[a] / host_flags[a] = node a (of `nodes`) is rescaled; its scales and counter are updated
+void launch_rescale_decide(hipStream_t st, int nnodes, NodeBits nodes, const int *e_off, const double *w, double *scale,
+                           int *count, int max_count, int *flags, double *host_flags);
+struct RescaleArgs {
+  const int *flags = nullptr;
+  const double *scale = nullptr, *Gbase = nullptr, *Hbase = nullptr;
+  const int *gpos = nullptr;      // 4 ints per own pose: offset of the round's values in Gval, blocks in the round, lane, CSR block index
+  const int *att_pos = nullptr;
+  double *Gval = nullptr, *Gtcol = nullptr, *Dd = nullptr, *Qd = nullptr, *Tinv = nullptr, *N = nullptr, *V = nullptr, *att_val = nullptr;
+  double xi = 0.0;
+};
+// apply: diagonal blocks of G, D, Q, the proximal coefficients and the diagonal of G_tt of the flagged nodes from the scales
+void launch_rescale_apply(int d, hipStream_t st, const SegTable &T, const InterEdgesDev &E, const RescaleArgs &A);
+
 // Objective of every node at Z (own + neighbour rows): partial[slot0] = sum of intra-edge costs,
 // partial[slot0 + 1] = sum of rho over inter-edge costs; eform selects the data-matrix form (trivial loss).
 void launch_cost(int d, hipStream_t st, const SegTable &T, NodeMask mask, const InterEdgesDev &Ei,
@@ -273,8 +288,10 @@ int spd_waves(int rows);   // waves (= narrow tiles) per workgroup of the class 
 void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, int mode, const SpdLevelMap &M, int rows,
                       double *vec, double *ytmp, double scale, double level_bytes = 0.0, bool stream_once = true,
                       NodeMask mask = ALL_NODES);   // mask.p: the device-side mask (nodes that stopped since the host last looked)
-// panels of the fused root tiles from the roots' L11^-1 (see k_root_product); srcs[i].src_off / src_ld locate the front's W_s
-void launch_root_product(hipStream_t st, const SpdItem *items, const PanelSrc *srcs, int ntiles, const double *src, double *panels);
+// the dense w x w products L11^-T L11^-1 of the root fronts (k_root_syrk): front i reads its W_s (w x ld) at src + src_off and
+// writes at dst + dst_off; the fused root tiles' panels are then cut out of dst with launch_pack_panels
+struct RootDesc { long long src_off, dst_off; int ld, w; };
+void launch_root_syrk(hipStream_t st, const RootDesc *rd, int nroots, int max_w, const double *src, double *dst);
 
 // ---- optional per-launch timing (HIP events on the launch stream), off by default ----
 enum ProfKind { PK_BSR = 0, PK_INTER, PK_PROX, PK_AXPBY, PK_DOT, PK_ROTOP, PK_COPYIDX, PK_BDIAG, PK_REDUCE,

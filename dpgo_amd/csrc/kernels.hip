@@ -628,6 +628,122 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask ma
 }
 
 // ---------------------------------------------------------------------------
+// Rescale::Dynamic on the device (DPGOProblem.cpp:289-358, 426-514: the test; :751-840: update_quadratic_mat).
+// k_rescale_decide: one workgroup per node.  A node is rescaled when its counter has reached max_count or the loss
+// weight of one of its inter-node edges exceeds the edge's scale (:300-321); its new scales are clamp(1.25 w, 0.01, 1)
+// (DPGOProblem.h:17-18).  flags[a] (device) and host_flags[a] (pinned) = 1 for a rescaled node.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rescale_decide(NodeBits nodes, const int *e_off, const double *w, double *scale,
+                                                        int *count, int max_count, int *flags, double *host_flags) {
+  const int a = blockIdx.x;
+  __shared__ int any;
+  if (threadIdx.x == 0) any = 0;
+  __syncthreads();
+  const bool mine = (nodes >> a) & 1ull;
+  const int e0 = e_off[a], e1 = e_off[a + 1];
+  if (mine) {
+    int hit = 0;
+    for (int e = e0 + threadIdx.x; e < e1; e += 256) hit |= w[e] > scale[e];
+    if (hit) atomicOr(&any, 1);
+  }
+  __syncthreads();
+  const bool rescaled = mine && (count[a] >= max_count || any);
+  __syncthreads();   // (count[a] is read by every thread above, written by one below)
+  if (rescaled)
+    for (int e = e0 + threadIdx.x; e < e1; e += 256) scale[e] = fmin(1.0, fmax(0.01, 1.25 * w[e]));
+  if (threadIdx.x == 0) {
+    if (mine) count[a] = rescaled ? 0 : count[a] + 1;
+    flags[a] = rescaled ? 1 : 0;
+    __hip_atomic_store(host_flags + a, rescaled ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// k_rescale_apply: the rescaled nodes' surrogate with the new scales -- only block-diagonal terms change.  Every inter-node
+// edge e adds 2 s_e E_end(e) to the diagonal block of its own endpoint in G, D and the proximal majoriser H, and to Q on
+// both endpoints (assemble.cpp, the `scale` branch); here one thread per pose sums its incidences (records of k_inter) and
+// writes: the diagonal block of G (interleaved block values + the translation column copy), D, Q, T / N / V from H, and the
+// diagonal entry of G_tt among the values the numeric factorisation reads.  Gbase / Hbase: the blocks with all scales zero.
+struct RescaleDev {
+  const int *flags;            // per node
+  const double *scale;         // per inter edge
+  const double *Gbase, *Hbase; // per own pose, B x B
+  const int4 *gpos;            // per own pose: offset of the round's values, blocks in the round, lane, CSR index of the block
+  const int *att_pos;          // per own pose: index of its diagonal entry in att_val
+  double *Gval, *Gtcol, *Dd, *Qd, *Tinv, *N, *V, *att_val;
+  double xi;
+};
+template <int D>
+__global__ __launch_bounds__(SEG_ROWS) void k_rescale_apply(const Seg *segs, InterEdgesDev E, RescaleDev R, int nseg_own) {
+  constexpr int B = Dim<D>::B, BB = B * B, PS = BB % 2 == 0 ? 2 : 1;
+  const Seg s = segs[SEGB];
+  if (!R.flags[s.node]) return;
+  const bool own = SEGB < nseg_own;
+  const int row = s.begin + threadIdx.x;
+  if (row >= s.end) return;
+  double acc[BB];
+#pragma unroll
+  for (int k = 0; k < BB; k++) acc[k] = 0.0;
+  const int k1 = E.inc_ptr[row + 1];
+  for (int k = E.inc_ptr[row]; k < k1; k++) {
+    union { double2 q[8]; InterInc r; } u8;
+    const double2 *rq = reinterpret_cast<const double2 *>(E.rec + k);
+#pragma unroll
+    for (int i = 0; i < 8; i++) u8.q[i] = rq[i];
+    const int e = u8.r.code >> 1, role = u8.r.code & 1;
+    const double w2 = 2.0 * R.scale[e], tau = u8.r.tau, kap = u8.r.kappa;
+    // E_end: AA for the tail [tau, tau t^T; tau t, kappa I + tau t t^T], II for the head [tau, 0; 0, kappa I]
+    acc[0] = fma(w2, tau, acc[0]);
+#pragma unroll
+    for (int r = 0; r < D; r++) {
+      acc[(1 + r) * B + 1 + r] = fma(w2, kap, acc[(1 + r) * B + 1 + r]);
+      if (role == 0) {
+        const double tt = tau * u8.r.t[r];
+        acc[1 + r] = fma(w2, tt, acc[1 + r]);
+        acc[(1 + r) * B] = fma(w2, tt, acc[(1 + r) * B]);
+#pragma unroll
+        for (int c = 0; c < D; c++) acc[(1 + r) * B + 1 + c] = fma(w2, tt * u8.r.t[c], acc[(1 + r) * B + 1 + c]);
+      }
+    }
+  }
+  double q[BB];
+#pragma unroll
+  for (int k = 0; k < BB; k++) q[k] = acc[k];
+  if (own) {
+#pragma unroll
+    for (int k = 0; k < B; k++) q[k * B + k] += 2.0 * R.xi;
+  }
+#pragma unroll
+  for (int k = 0; k < BB; k++) R.Qd[(size_t)row * BB + k] = q[k];
+  if (!own) return;
+  double g[BB], h[BB], dd[BB];
+#pragma unroll
+  for (int k = 0; k < BB; k++) {
+    g[k] = R.Gbase[(size_t)row * BB + k] + acc[k];
+    h[k] = R.Hbase[(size_t)row * BB + k] + acc[k];
+    dd[k] = acc[k];
+  }
+#pragma unroll
+  for (int k = 0; k < B; k++) dd[k * B + k] += R.xi;
+#pragma unroll
+  for (int k = 0; k < BB; k++) R.Dd[(size_t)row * BB + k] = dd[k];
+  const int4 gp = R.gpos[row];
+#pragma unroll
+  for (int e = 0; e < BB; e++) R.Gval[(size_t)gp.x + (size_t)((e / PS) * gp.y + gp.z) * PS + e % PS] = g[e];
+#pragma unroll
+  for (int r = 0; r < B; r++) R.Gtcol[(size_t)gp.w * B + r] = g[r * B];
+  R.att_val[R.att_pos[row]] = g[0];
+  // T = 1 / H_tt, N = T H_tR, V = H_RR - H_Rt T H_tR   (DPGO_utils.cpp:2958-2964)
+  const double T = 1.0 / h[0];
+  R.Tinv[row] = T;
+#pragma unroll
+  for (int k = 0; k < D; k++) R.N[(size_t)row * D + k] = T * h[1 + k];
+#pragma unroll
+  for (int r = 0; r < D; r++)
+#pragma unroll
+    for (int c = 0; c < D; c++) R.V[((size_t)row * D + r) * D + c] = h[(1 + r) * B + 1 + c] - h[(1 + r) * B] * (T * h[1 + c]);
+}
+
+// ---------------------------------------------------------------------------
 // Objective of a node at an arbitrary point Z (DPGOStar::evaluate_f, C++/DPGO/src/DPGOStar.cpp:713-761).
 // Every edge is charged to its tail pose.  slot 0: sum over intra edges of the quadratic cost,
 // slot 1: sum over inter edges of rho(|r_e|^2).  eform = 1 uses the quadratic form of the data
@@ -1834,6 +1950,19 @@ void launch_inter(int d, hipStream_t st, const SegTable &T, NodeMask mask, const
                                         T.nseg_all, mode == 0 ? wout : nullptr));
 }
 
+void launch_rescale_decide(hipStream_t st, int nnodes, NodeBits nodes, const int *e_off, const double *w, double *scale,
+                           int *count, int max_count, int *flags, double *host_flags) {
+  if (nnodes > 0) hipLaunchKernelGGL(k_rescale_decide, dim3(nnodes), dim3(256), 0, st, nodes, e_off, w, scale, count, max_count, flags, host_flags);
+}
+void launch_rescale_apply(int d, hipStream_t st, const SegTable &T, const InterEdgesDev &E, const RescaleArgs &A) {
+  if (T.nseg_all == 0) return;
+  RescaleDev R;
+  R.flags = A.flags; R.scale = A.scale; R.Gbase = A.Gbase; R.Hbase = A.Hbase; R.gpos = reinterpret_cast<const int4 *>(A.gpos);
+  R.att_pos = A.att_pos; R.Gval = A.Gval; R.Gtcol = A.Gtcol; R.Dd = A.Dd; R.Qd = A.Qd; R.Tinv = A.Tinv; R.N = A.N; R.V = A.V;
+  R.att_val = A.att_val; R.xi = A.xi;
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rescale_apply<D>), dim3(T.nseg_all), dim3(SEG_ROWS), 0, st, T.segs, E, R, T.nseg_own));
+}
+
 void launch_cost(int d, hipStream_t st, const SegTable &T, NodeMask mask, const InterEdgesDev &Ei,
                  const InterEdgesDev &Ee, bool eform, int loss, double loss_reg, const double *Z, double *partials,
                  int slot0) {
@@ -2025,27 +2154,53 @@ __global__ __launch_bounds__(256) void k_pack_panels(const SpdItem *items, const
     out[(size_t)k * it.ld + r] = in[(size_t)k * ps.src_ld + r];
   }
 }
-// Panels of the fused root tiles: tile i holds, for its columns c = first .. first + count, the rows k = 0 .. w of
-//   P = L11^-T L11^-1,   P[k][c] = sum_{j >= max(k, c)} Linv[j][k] Linv[j][c]      (Linv = L11^-1, lower triangular)
-// as panel[k * ld + (c - first)].  Linv: the root front's W_s (w x src_ld, row-major) at src + srcs[i].src_off.
-// One thread per entry, the sum taken in increasing j (a fixed order): set-up work, a few milliseconds.
-__global__ __launch_bounds__(256) void k_root_product(const SpdItem *items, const PanelSrc *srcs, const double *src, double *panels) {
-  const SpdItem it = load_item(items + blockIdx.x);
-  const PanelSrc ps = srcs[blockIdx.x];
-  const double *L = src + ps.src_off;
-  double *out = panels + it.mat_off;
-  const int w = it.w, cnt = it.count, ld = ps.src_ld;
-  const int r = threadIdx.x % 64, kq = threadIdx.x / 64;   // lane = column of the tile (coalesced), 4 rows k at a time
-  if (r >= cnt) return;
-  const int c = it.first + r;
-  for (int k = blockIdx.y * 4 + kq; k < w; k += 4 * gridDim.y) {
-    double a = 0.0;
-    for (int j = max(k, c); j < w; j++) a = fma(L[(size_t)j * ld + k], L[(size_t)j * ld + c], a);
-    out[(size_t)k * it.ld + r] = a;
+// The dense product behind the fused root tiles: P = L11^-T L11^-1, P[k][c] = sum_{j >= max(k, c)} Linv[j][k] Linv[j][c],
+// for every root front (Linv = L11^-1 = the front's W_s, w x ld row-major, zeros above the diagonal), written as a dense
+// w x w matrix; launch_pack_panels then cuts the tiles' panels out of it.  64 x 64 output tiles, 4 x 4 per thread, the
+// sum taken in increasing j (a fixed order).  Set-up work (and a Dynamic rescale's): about a millisecond.
+__global__ __launch_bounds__(256) void k_root_syrk(const RootDesc *rd, const double *src, double *dst) {
+  const RootDesc d = rd[blockIdx.z];
+  const int w = d.w, k0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  if (k0 >= w || c0 >= w) return;
+  __shared__ double As[16][65], Bs[16][65];
+  const double *L = src + d.src_off;
+  const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
+  for (int j0 = (max(k0, c0) / 16) * 16; j0 < w; j0 += 16) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int idx = threadIdx.x + q * 256, jj = idx / 64, kk = idx % 64, j = j0 + jj;
+      As[jj][kk] = (j < w && k0 + kk < w) ? L[(size_t)j * d.ld + k0 + kk] : 0.0;
+      Bs[jj][kk] = (j < w && c0 + kk < w) ? L[(size_t)j * d.ld + c0 + kk] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 16; jj++) {
+      double a[4], bq[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) { a[i] = As[jj][ty * 4 + i]; bq[i] = Bs[jj][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = fma(a[i], bq[j], acc[i][j]);
+    }
+    __syncthreads();
   }
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int k = k0 + ty * 4 + i, c = c0 + tx * 4 + j;
+      if (k < w && c < w) dst[d.dst_off + (size_t)k * w + c] = acc[i][j];
+    }
 }
-void launch_root_product(hipStream_t st, const SpdItem *items, const PanelSrc *srcs, int ntiles, const double *src, double *panels) {
-  if (ntiles > 0) hipLaunchKernelGGL(k_root_product, dim3(ntiles, 32), dim3(256), 0, st, items, srcs, src, panels);
+void launch_root_syrk(hipStream_t st, const RootDesc *rd, int nroots, int max_w, const double *src, double *dst) {
+  const int nt = (max_w + 63) / 64;
+  if (nroots > 0 && nt > 0) hipLaunchKernelGGL(k_root_syrk, dim3(nt, nt, nroots), dim3(256), 0, st, rd, src, dst);
 }
 
 void launch_pack_panels(hipStream_t st, const SpdItem *items, const PanelSrc *srcs, int ntiles, const double *src, double *panels) {

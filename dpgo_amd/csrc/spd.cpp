@@ -21,6 +21,7 @@ int spd_factor_numeric_device(const CsrMatrix &A, SpdFactor &F, const std::vecto
                               double *flops_out, double *mfma_ms_out);
 #ifdef DPGO_NO_DEVICE
 void spd_release_device(SpdFactor &) {}
+void spd_release_numeric(SpdFactor &) {}
 #endif
 namespace {
 
@@ -459,9 +460,12 @@ static int spd_factor_impl(const CsrMatrix &A, SpdFactor &F, int leaf, int colla
   double t_lap = omp_get_wtime();
   omp_set_num_threads(host_threads());
   spd_release_device(F);
+  const bool keep_numeric = F.keep_numeric;
+  spd_release_numeric(F);   // (a kept numeric context belongs to the pattern that is about to be replaced)
   F = SpdFactor();
   F.n = n;
   F.keep_device = keep_device;
+  F.keep_numeric = keep_numeric;
   // adjacency without the diagonal
   CsrMatrix adj;
   adj.n = n;

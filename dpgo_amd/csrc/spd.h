@@ -23,6 +23,8 @@
 
 namespace dpgo {
 
+struct SpdNumericCtx;
+
 struct CsrMatrix {
   int n = 0;
   std::vector<int> ptr, col;
@@ -53,6 +55,10 @@ struct SpdFactor {
   // lower bound of the condition number -- W_s holds the explicit L11^-1, so a huge ratio costs digits in every solve
   double pivot_min = 0.0, pivot_max = 0.0;
   bool keep_device = false;
+  // keep_numeric (with keep_device): the device state of the numeric phase stays with the factor (`numeric`), dev_W / dev_WT
+  // are borrowed from it, and spd_refactor_device() re-factors from values that are already on the GPU
+  bool keep_numeric = false, dev_borrowed = false;
+  struct SpdNumericCtx *numeric = nullptr;
   int leaf = 32, collapse = 0, block = 1;   // the parameters this factor was built with (spd_refactor's host path repeats them)
   double *dev_W = nullptr, *dev_WT = nullptr;
   int64_t nnz() const { return entries; }
@@ -71,6 +77,12 @@ void spd_release_device(SpdFactor &F);
 // New values, same pattern (a Dynamic rescale changes the diagonal of G_tt): the numeric phase only, on the GPU
 // (spd_dev.hip); without a GPU the whole factorisation is redone.  F must come from spd_factor of the same pattern.
 int spd_refactor(const CsrMatrix &A, SpdFactor &F);
+
+// With keep_numeric: the device copy of A's values (CSR order of the matrix that was factored), the numeric phase from
+// them, and the release of the kept state (a factor that owns one must not be copied)
+double *spd_numeric_values(SpdFactor &F);
+int spd_refactor_device(SpdFactor &F);
+void spd_release_numeric(SpdFactor &F);
 
 // Host solve (setup paths and tests): X (n x ncols, row-major) <- A^-1 X.
 void spd_solve_host(const SpdFactor &F, double *X, int ncols);

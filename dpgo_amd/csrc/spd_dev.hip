@@ -9,8 +9,8 @@
 // Level by level (fronts of one tree height are independent, one launch serves them all):
 //   1. assemble   F_s <- entries of A (k_fa_scatter) + the children's Schur complements (k_fa_extend; one launch per
 //                 child slot, so two children never add to the same entry at once: deterministic, no atomics)
-//   2. eliminate  right-looking in block columns of 32: k_fa_potrf factors the 32 x 32 diagonal block in LDS and
-//                 inverts it, k_fa_panel scales the rows below (a row times a 32 x 32 triangle), k_fa_abt subtracts
+//   2. eliminate  right-looking in block columns of 32: k_fa_potrf_panel factors the 32 x 32 diagonal block in registers,
+//                 inverts it and scales the rows below (a row times a 32 x 32 triangle) in one launch, k_fa_abt subtracts
 //                 the rank-32 update P_I P_J^T from the trailing tiles with v_mfma_f64_16x16x4_f64.
 //      Each front carries w extra rows holding the identity: after the elimination they hold L11^-T (the same
 //      row operations that turn F21 into L21 = F21 L11^-T), so the triangular inverse costs no kernel of its own.
@@ -81,76 +81,85 @@ __global__ __launch_bounds__(256) void k_fa_extend(const FrontDesc *fd, const Ex
   }
 }
 
-// Cholesky of the diagonal block [kb, kb + nb) and its inverse (one wave per front)
-// fail[0]: 1 + front of a non-positive pivot; pivr[0] / pivr[1]: smallest / largest pivot d_kk seen (bit patterns of positive
-// doubles order like integers)
-__global__ __launch_bounds__(64) void k_fa_potrf(const FrontDesc *fd, const int *lvl, int kb, double *Fm, double *dinv, int *fail,
-                                                 unsigned long long *pivr) {
-  const FrontDesc f = fd[lvl[blockIdx.x]];
-  if (f.w <= kb) return;
-  const int nb = min(NB, f.w - kb), t = threadIdx.x;
-  __shared__ double L[NB][LDT], X[NB][LDT];
-  double *A = Fm + f.fm_off + (long long)kb * f.m + kb;
-  for (int idx = t; idx < NB * NB; idx += 64) {
-    const int i = idx / NB, j = idx % NB;
-    L[i][j] = (i < nb && j <= i) ? A[(long long)i * f.m + j] : 0.0;
-    X[i][j] = 0.0;
-  }
-  __syncthreads();
-  double dmin = 1e300, dmax = 0.0;
-  for (int k = 0; k < nb; k++) {
-    const double dkk = L[k][k];
-    if (!(dkk > 0.0)) {
-      if (t == 0) atomicExch(fail, 1 + lvl[blockIdx.x]);
-      return;
-    }
-    dmin = fmin(dmin, dkk);
-    dmax = fmax(dmax, dkk);
-    const double lkk = sqrt(dkk), inv = 1.0 / lkk;
-    __syncthreads();
-    if (t == 0) L[k][k] = lkk;
-    if (t > k && t < nb) L[t][k] *= inv;
-    __syncthreads();
-    // rank-1 update of the remaining lower triangle: lane i owns row i
-    if (t > k && t < nb) {
-      const double lik = L[t][k];
-      for (int j = k + 1; j <= t; j++) L[t][j] -= lik * L[j][k];
-    }
-    __syncthreads();
-  }
-  if (t == 0) {
-    atomicMin(pivr, (unsigned long long)__double_as_longlong(dmin));
-    atomicMax(pivr + 1, (unsigned long long)__double_as_longlong(dmax));
-  }
-  // X = L^-1: lane j owns column j (forward substitution on e_j)
-  if (t < nb) {
-    for (int i = t; i < nb; i++) {
-      double s = (i == t) ? 1.0 : 0.0;
-      for (int k = t; k < i; k++) s -= L[i][k] * X[k][t];
-      X[i][t] = s / L[i][i];
-    }
-  }
-  __syncthreads();
-  double *D = dinv + (long long)f.slot * NB * NB;
-  for (int idx = t; idx < NB * NB; idx += 64) {
-    const int i = idx / NB, j = idx % NB;
-    if (i < nb && j <= i) A[(long long)i * f.m + j] = L[i][j];
-    D[idx] = X[i][j];
-  }
+// a double from lane `src` (uniform) to every lane
+__device__ __forceinline__ double bcast(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// rows below the diagonal block: F[i, kb:ke] <- F[i, kb:ke] L_kk^-T   (row i times the transposed inverse)
-__global__ __launch_bounds__(256) void k_fa_panel(const FrontDesc *fd, const int *lvl, int kb, double *Fm, const double *dinv) {
+// One block column of the elimination in ONE launch: the Cholesky of the diagonal block [kb, kb + nb) and its inverse,
+// then the rows below times the transposed inverse,  F[i, kb:ke] <- F[i, kb:ke] L_kk^-T.
+// Every workgroup of a front (256 rows each) first factors the 32 x 32 diagonal block itself -- wave 0, a row of the
+// block per lane, everything in registers: 496 broadcasts + multiply-adds for the factor, as many for the inverse, a few
+// microseconds, against a launch of its own and a trip through memory for the inverse -- and hands X = L_kk^-1 to the
+// other waves through LDS.  (The factored diagonal block itself is never read again -- later steps touch the rows below
+// and the identity rows only -- so nobody writes it back and the workgroups need not agree on who would.)
+// fail[0]: 1 + front of a non-positive pivot; pivr[0] / pivr[1]: smallest / largest pivot d_kk seen (bit patterns of
+// positive doubles order like integers); both reported by the front's first workgroup.
+__global__ __launch_bounds__(256) void k_fa_potrf_panel(const FrontDesc *fd, const int *lvl, int kb, double *Fm, int *fail,
+                                                        unsigned long long *pivr) {
   const FrontDesc f = fd[lvl[blockIdx.y]];
   if (f.w <= kb) return;
   const int nb = min(NB, f.w - kb), ke = kb + nb;
-  __shared__ double D[NB][LDT];
-  const double *Dg = dinv + (long long)f.slot * NB * NB;
-  for (int idx = threadIdx.x; idx < NB * NB; idx += 256) D[idx / NB][idx % NB] = Dg[idx];
-  __syncthreads();
   // regular rows [ke, m) and the identity rows whose one has come into play: [m, m + ke)
   const int nrows = (f.m - ke) + ke;
-  const int q = blockIdx.x * 256 + threadIdx.x;
+  if ((int)blockIdx.x * 256 >= nrows) return;
+  __shared__ double D[NB][LDT];
+  __shared__ int bad;
+  const int t = threadIdx.x;
+  if (t < 64) {
+    const int lane = t;
+    // row `lane` of the diagonal block (lanes >= nb and columns >= nb: the identity, which factors to itself)
+    double L[NB], X[NB];
+    const double *A = Fm + f.fm_off + (long long)kb * f.m + kb;
+#pragma unroll
+    for (int j = 0; j < NB; j++) L[j] = (lane < nb && j <= lane) ? A[(long long)lane * f.m + j] : ((lane == j) ? 1.0 : 0.0);
+    double dmin = 1e300, dmax = 0.0;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      const double dkk = bcast(L[k], k);
+      if (k < nb) {
+        ok = ok && (dkk > 0.0);
+        dmin = fmin(dmin, dkk);
+        dmax = fmax(dmax, dkk);
+      }
+      const double lkk = sqrt(dkk), inv = 1.0 / lkk;
+      L[k] = lane == k ? lkk : L[k] * inv;           // column k: the pivot, and the rows below it scaled
+#pragma unroll
+      for (int j = k + 1; j < NB; j++) {
+        const double ljk = bcast(L[k], j);           // L[j][k]
+        L[j] = lane >= j ? fma(-L[k], ljk, L[j]) : L[j];
+      }
+    }
+    // X = L^-1, lane j its column j: X[i][j] = (delta_ij - sum_{k<i} L[i][k] X[k][j]) / L[i][i]  (zeros above the diagonal
+    // come out by themselves)
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      double sum = lane == i ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < i; k++) sum = fma(-bcast(L[k], i), X[k], sum);
+      X[i] = sum / bcast(L[i], i);
+    }
+    if (lane < NB) {
+#pragma unroll
+      for (int i = 0; i < NB; i++) D[i][lane] = X[i];
+    }
+    if (lane == 0) {
+      bad = !ok;
+      if (blockIdx.x == 0) {
+        if (!ok) atomicExch(fail, 1 + lvl[blockIdx.y]);
+        else {
+          atomicMin(pivr, (unsigned long long)__double_as_longlong(dmin));
+          atomicMax(pivr + 1, (unsigned long long)__double_as_longlong(dmax));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (bad) return;
+  const int q = blockIdx.x * 256 + t;
   if (q >= nrows) return;
   const int i = ke + q;   // rows ke .. m + ke - 1 are contiguous in the front matrix
   double *row = Fm + f.fm_off + (long long)i * f.m + kb;
@@ -284,19 +293,48 @@ __global__ __launch_bounds__(256) void k_fa_wtop(const FrontDesc *fd, const int 
 }
 }  // namespace
 
-// children[f]: the fronts whose update rows are assembled into f.  Fills F.W and F.WT (host vectors).
-// flops (optional): floating-point operations of the MFMA kernel; mfma_ms: time spent in it.
-int spd_factor_numeric_device(const CsrMatrix &A, SpdFactor &F, const std::vector<std::vector<int>> &children,
-                              double *flops_out, double *mfma_ms_out) {
-  const int nt = F.nfronts, n = A.n;
-  std::vector<FrontDesc> fd(nt);
+// The state of a numeric factorisation on the device: the maps from the entries of A into the fronts, the front
+// storage, the outputs W / WT.  One-shot callers build it, run it and drop it; a factor that is re-done with new values
+// every few iterations (Rescale::Dynamic re-factors G_tt) keeps it (SpdFactor::keep_numeric): a refactorisation is
+// then nothing but the kernels -- no host pass over A, no allocation, no upload -- and the values of A themselves
+// live on the device (spd_numeric_values), where the kernel that rescales the surrogate writes the new diagonal.
+struct SpdNumericCtx {
+  int nt = 0, maxh = 0;
+  long long fm_total = 0;
+  size_t max_lvl = 1, n_aval = 0;
+  int64_t w_total = 0, wt_total = 0;
+  std::vector<FrontDesc> fd;
+  std::vector<std::vector<int>> lvl;
+  std::vector<int> lvl_ptr;
+  std::vector<std::vector<std::pair<int, int>>> pair_rng;   // per level: (first pair, count) per child slot
+  std::vector<std::vector<int>> pair_maxu;
+  FrontDesc *d_fd = nullptr;
+  long long *d_dst = nullptr;
+  int *d_src = nullptr, *d_cmap = nullptr, *d_lvl = nullptr, *d_fail = nullptr;
+  double *d_aval = nullptr, *d_Fm = nullptr, *d_dinv = nullptr, *d_W = nullptr, *d_WT = nullptr;
+  ExtendPair *d_pairs = nullptr;
+  hipStream_t st = nullptr;
+  ~SpdNumericCtx() {
+    for (void *q : {(void *)d_fd, (void *)d_dst, (void *)d_src, (void *)d_cmap, (void *)d_lvl, (void *)d_fail, (void *)d_aval,
+                    (void *)d_Fm, (void *)d_dinv, (void *)d_W, (void *)d_WT, (void *)d_pairs})
+      if (q) (void)hipFree(q);
+    if (st) (void)hipStreamDestroy(st);
+  }
+  int build(const CsrMatrix &A, const SpdFactor &F, const std::vector<std::vector<int>> &children);
+  int factor(SpdFactor &F, const double *aval_host, double *flops_out, double *mfma_ms_out);
+};
+
+int SpdNumericCtx::build(const CsrMatrix &A, const SpdFactor &F, const std::vector<std::vector<int>> &children) {
+  nt = F.nfronts;
+  const int n = A.n;
+  fd.assign(nt, FrontDesc());
   std::vector<int> height(nt, 0);
   for (int f = 0; f < nt; f++)
     if (F.parent[f] >= 0) height[F.parent[f]] = std::max(height[F.parent[f]], height[f] + 1);
-  int maxh = 0;
+  maxh = 0;
   for (int f = 0; f < nt; f++) maxh = std::max(maxh, height[f]);
-  std::vector<std::vector<int>> lvl(maxh + 1);
-  long long fm_total = 0;
+  lvl.assign(maxh + 1, {});
+  fm_total = 0;
   for (int f = 0; f < nt; f++) {
     FrontDesc &d = fd[f];
     d.w = F.w[f]; d.u = F.u[f]; d.m = d.w + d.u;
@@ -310,6 +348,8 @@ int spd_factor_numeric_device(const CsrMatrix &A, SpdFactor &F, const std::vecto
     fm_total += (long long)(d.m + d.w) * d.m;
     d.w_off = F.w_off[f]; d.wt_off = F.wt_off[f]; d.ldw = F.ldw[f]; d.ldm = F.ldm[f];
   }
+  w_total = F.w_off[nt];
+  wt_total = F.wt_off[nt];
   // entries of A per front (and the ones of the identity rows), child -> parent position maps
   std::vector<long long> dst;
   std::vector<int> src, cmap(std::max(F.total_upd, 1), 0), loc(n, -1);
@@ -340,30 +380,24 @@ int spd_factor_numeric_device(const CsrMatrix &A, SpdFactor &F, const std::vecto
     for (int k = 0; k < d.w; k++) loc[piv[k]] = -1;
     for (int k = 0; k < d.u; k++) loc[up[k]] = -1;
   }
-  // device buffers
-  FrontDesc *d_fd = nullptr;
-  long long *d_dst = nullptr;
-  int *d_src = nullptr, *d_cmap = nullptr, *d_lvl = nullptr, *d_fail = nullptr;
-  double *d_aval = nullptr, *d_Fm = nullptr, *d_dinv = nullptr, *d_W = nullptr, *d_WT = nullptr;
-  ExtendPair *d_pairs = nullptr;
-  size_t max_lvl = 1;
+  max_lvl = 1;
   for (const auto &l : lvl) max_lvl = std::max(max_lvl, l.size());
   std::vector<int> lvl_flat;
-  std::vector<int> lvl_ptr(1, 0);
+  lvl_ptr.assign(1, 0);
   for (const auto &l : lvl) { lvl_flat.insert(lvl_flat.end(), l.begin(), l.end()); lvl_ptr.push_back((int)lvl_flat.size()); }
   // extend pairs per (level, child slot)
   std::vector<ExtendPair> pairs;
-  std::vector<std::vector<std::pair<int, int>>> pair_rng(maxh + 1);   // per level: (first pair, count) per slot
-  std::vector<std::vector<int>> pair_maxu(maxh + 1);
+  pair_rng.assign(maxh + 1, {});
+  pair_maxu.assign(maxh + 1, {});
   for (int h = 0; h <= maxh; h++) {
     size_t maxc = 0;
     for (int f : lvl[h]) maxc = std::max(maxc, children[f].size());
-    for (size_t s = 0; s < maxc; s++) {
+    for (size_t sl = 0; sl < maxc; sl++) {
       const int first = (int)pairs.size();
       int mu = 0;
       for (int f : lvl[h])
-        if (children[f].size() > s && F.u[children[f][s]] > 0) {
-          const int c = children[f][s];
+        if (children[f].size() > sl && F.u[children[f][sl]] > 0) {
+          const int c = children[f][sl];
           pairs.push_back({f, c, cmap_off[c], 0});
           mu = std::max(mu, F.u[c]);
         }
@@ -371,159 +405,210 @@ int spd_factor_numeric_device(const CsrMatrix &A, SpdFactor &F, const std::vecto
       pair_maxu[h].push_back(mu);
     }
   }
-  hipStream_t st = nullptr;
-  int rc = 0;
-  auto run = [&]() -> int {
-    FA_OK(hipMalloc((void **)&d_fd, sizeof(FrontDesc) * std::max(nt, 1)));
-    FA_OK(hipMalloc((void **)&d_dst, sizeof(long long) * std::max<size_t>(dst.size(), 1)));
-    FA_OK(hipMalloc((void **)&d_src, sizeof(int) * std::max<size_t>(src.size(), 1)));
-    FA_OK(hipMalloc((void **)&d_cmap, sizeof(int) * cmap.size()));
-    FA_OK(hipMalloc((void **)&d_lvl, sizeof(int) * std::max<size_t>(lvl_flat.size(), 1)));
-    FA_OK(hipMalloc((void **)&d_fail, 24));   // int fail; then two 64-bit words: smallest / largest pivot
-    FA_OK(hipMalloc((void **)&d_aval, sizeof(double) * std::max<size_t>(A.val.size(), 1)));
-    FA_OK(hipMalloc((void **)&d_Fm, sizeof(double) * std::max<long long>(fm_total, 1)));
-    FA_OK(hipMalloc((void **)&d_dinv, sizeof(double) * max_lvl * NB * NB));
-    FA_OK(hipMalloc((void **)&d_W, sizeof(double) * std::max<int64_t>(F.w_off[nt], 1)));
-    FA_OK(hipMalloc((void **)&d_WT, sizeof(double) * std::max<int64_t>(F.wt_off[nt], 1)));
-    FA_OK(hipMalloc((void **)&d_pairs, sizeof(ExtendPair) * std::max<size_t>(pairs.size(), 1)));
-    FA_OK(hipStreamCreate(&st));
-    FA_OK(hipMemcpyAsync(d_fd, fd.data(), sizeof(FrontDesc) * nt, hipMemcpyHostToDevice, st));
-    FA_OK(hipMemcpyAsync(d_dst, dst.data(), sizeof(long long) * dst.size(), hipMemcpyHostToDevice, st));
-    FA_OK(hipMemcpyAsync(d_src, src.data(), sizeof(int) * src.size(), hipMemcpyHostToDevice, st));
-    FA_OK(hipMemcpyAsync(d_cmap, cmap.data(), sizeof(int) * cmap.size(), hipMemcpyHostToDevice, st));
-    FA_OK(hipMemcpyAsync(d_lvl, lvl_flat.data(), sizeof(int) * lvl_flat.size(), hipMemcpyHostToDevice, st));
-    FA_OK(hipMemcpyAsync(d_aval, A.val.data(), sizeof(double) * A.val.size(), hipMemcpyHostToDevice, st));
-    if (!pairs.empty()) FA_OK(hipMemcpyAsync(d_pairs, pairs.data(), sizeof(ExtendPair) * pairs.size(), hipMemcpyHostToDevice, st));
-    {
-      unsigned long long init[3] = {0ull, 0x7ff0000000000000ull, 0ull};
-      FA_OK(hipMemcpyAsync(d_fail, init, 24, hipMemcpyHostToDevice, st));
-      FA_OK(hipStreamSynchronize(st));
-    }
-    FA_OK(hipMemsetAsync(d_Fm, 0, sizeof(double) * std::max<long long>(fm_total, 1), st));
-    FA_OK(hipMemsetAsync(d_W, 0, sizeof(double) * std::max<int64_t>(F.w_off[nt], 1), st));
-    FA_OK(hipMemsetAsync(d_WT, 0, sizeof(double) * std::max<int64_t>(F.wt_off[nt], 1), st));
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (mfma_ms_out) { FA_OK(hipEventCreate(&e0)); FA_OK(hipEventCreate(&e1)); }
-    double flops = 0, mfma_ms = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
-    for (int h = 0; h <= maxh; h++) {
-      const int nf = (int)lvl[h].size();
-      if (nf == 0) continue;
-      const int *L = d_lvl + lvl_ptr[h];
-      int max_ent = 0, max_w = 0, max_m = 0, max_u = 0;
-      for (int f : lvl[h]) {
-        max_ent = std::max(max_ent, fd[f].ent_end - fd[f].ent_ptr);
-        max_w = std::max(max_w, fd[f].w);
-        max_m = std::max(max_m, fd[f].m);
-        max_u = std::max(max_u, fd[f].u);
-      }
-      hipLaunchKernelGGL(k_fa_scatter, dim3((max_ent + 255) / 256, nf), dim3(256), 0, st, d_fd, L, d_dst, d_src, d_aval, d_Fm);
-      for (size_t s = 0; s < pair_rng[h].size(); s++)
-        if (pair_rng[h][s].second > 0)
-          hipLaunchKernelGGL(k_fa_extend, dim3(pair_maxu[h][s], pair_rng[h][s].second), dim3(256), 0, st, d_fd,
-                             d_pairs + pair_rng[h][s].first, d_cmap, d_Fm);
-      auto abt0 = [&](int k_lo, int k_hi, int sb_end, int wide) -> int {
-        // upper bounds over the fronts of the level (a front's block column may end before k_hi: columns from k_lo + 1 on)
-        const int nrt = (max_m + TS - 1) / TS, nct = (max_m - k_lo + TS - 1) / TS;
-        if (nct <= 0) return 0;
-        hipEvent_t a = nullptr, b = nullptr;
-        if (mfma_ms_out) {
-          FA_OK(hipEventCreate(&a)); FA_OK(hipEventCreate(&b));
-          FA_OK(hipEventRecord(a, st));
-        }
-        hipLaunchKernelGGL((k_fa_abt<0>), dim3(nrt * nct, nf), dim3(256), 0, st, d_fd, L, k_lo, k_hi, sb_end, wide, d_Fm, d_W, d_WT);
-        if (mfma_ms_out) {
-          FA_OK(hipEventRecord(b, st));
-          evs.push_back({a, b});
-        }
-        return 0;
-      };
-      for (int sb = 0; sb < max_w; sb += SB) {
-        const int se = sb + SB;
-        for (int kb = sb; kb < std::min(se, max_w); kb += NB) {
-          hipLaunchKernelGGL(k_fa_potrf, dim3(nf), dim3(64), 0, st, d_fd, L, kb, d_Fm, d_dinv, d_fail,
-                             reinterpret_cast<unsigned long long *>(d_fail) + 1);
-          hipLaunchKernelGGL(k_fa_panel, dim3((max_m + 255) / 256, nf), dim3(256), 0, st, d_fd, L, kb, d_Fm, d_dinv);
-          if (abt0(kb, kb + NB, se, 0) != 0) return -1;      // the rest of the super-block (of the front, if it ends here), K = 32
-        }
-        if (se < max_w && abt0(sb, se, se, 1) != 0) return -1;   // everything right of the super-block, K = 128
-      }
-      // the products the MFMA kernel carries for this level (useful flops: lower triangle of the trailing update)
-      for (int f : lvl[h]) {
-        const double w = fd[f].w, u = fd[f].u;
-        flops += w * w * w / 3.0 + u * w * w + u * u * w      // trailing updates of regular rows (2 flops per multiply-add, half by symmetry)
-                 + w * w * w / 3.0                              // identity rows
-                 + 2.0 * u * w * w / 2.0;                       // W_bottom (triangular operand)
-      }
-      hipLaunchKernelGGL(k_fa_wtop, dim3(std::max(max_w, 1), nf), dim3(256), 0, st, d_fd, L, d_Fm, d_W, d_WT);
-      if (max_u > 0) {
-        const int nrt = (max_u + TS - 1) / TS, nct = (max_w + TS - 1) / TS;
-        if (mfma_ms_out) {
-          hipEvent_t a, b;
-          FA_OK(hipEventCreate(&a)); FA_OK(hipEventCreate(&b));
-          FA_OK(hipEventRecord(a, st));
-          hipLaunchKernelGGL((k_fa_abt<1>), dim3(nrt * nct, nf), dim3(256), 0, st, d_fd, L, 0, 0, 0, 0, d_Fm, d_W, d_WT);
-          FA_OK(hipEventRecord(b, st));
-          evs.push_back({a, b});
-        } else {
-          hipLaunchKernelGGL((k_fa_abt<1>), dim3(nrt * nct, nf), dim3(256), 0, st, d_fd, L, 0, 0, 0, 0, d_Fm, d_W, d_WT);
-        }
-      }
-    }
-    int fail = 0;
-    unsigned long long back[3] = {0, 0, 0};
-    FA_OK(hipMemcpyAsync(back, d_fail, 24, hipMemcpyDeviceToHost, st));
+  n_aval = A.val.size();
+  FA_OK(hipMalloc((void **)&d_fd, sizeof(FrontDesc) * std::max(nt, 1)));
+  FA_OK(hipMalloc((void **)&d_dst, sizeof(long long) * std::max<size_t>(dst.size(), 1)));
+  FA_OK(hipMalloc((void **)&d_src, sizeof(int) * std::max<size_t>(src.size(), 1)));
+  FA_OK(hipMalloc((void **)&d_cmap, sizeof(int) * cmap.size()));
+  FA_OK(hipMalloc((void **)&d_lvl, sizeof(int) * std::max<size_t>(lvl_flat.size(), 1)));
+  FA_OK(hipMalloc((void **)&d_fail, 24));   // int fail; then two 64-bit words: smallest / largest pivot
+  FA_OK(hipMalloc((void **)&d_aval, sizeof(double) * std::max<size_t>(n_aval, 1)));
+  FA_OK(hipMalloc((void **)&d_Fm, sizeof(double) * std::max<long long>(fm_total, 1)));
+  FA_OK(hipMalloc((void **)&d_dinv, sizeof(double) * max_lvl * NB * NB));
+  FA_OK(hipMalloc((void **)&d_W, sizeof(double) * std::max<int64_t>(w_total, 1)));
+  FA_OK(hipMalloc((void **)&d_WT, sizeof(double) * std::max<int64_t>(wt_total, 1)));
+  FA_OK(hipMalloc((void **)&d_pairs, sizeof(ExtendPair) * std::max<size_t>(pairs.size(), 1)));
+  FA_OK(hipStreamCreate(&st));
+  FA_OK(hipMemcpyAsync(d_fd, fd.data(), sizeof(FrontDesc) * nt, hipMemcpyHostToDevice, st));
+  FA_OK(hipMemcpyAsync(d_dst, dst.data(), sizeof(long long) * dst.size(), hipMemcpyHostToDevice, st));
+  FA_OK(hipMemcpyAsync(d_src, src.data(), sizeof(int) * src.size(), hipMemcpyHostToDevice, st));
+  FA_OK(hipMemcpyAsync(d_cmap, cmap.data(), sizeof(int) * cmap.size(), hipMemcpyHostToDevice, st));
+  FA_OK(hipMemcpyAsync(d_lvl, lvl_flat.data(), sizeof(int) * lvl_flat.size(), hipMemcpyHostToDevice, st));
+  if (!pairs.empty()) FA_OK(hipMemcpyAsync(d_pairs, pairs.data(), sizeof(ExtendPair) * pairs.size(), hipMemcpyHostToDevice, st));
+  FA_OK(hipStreamSynchronize(st));   // (the host vectors go out of scope)
+  return 0;
+}
+
+// aval_host: the values of A in CSR order (nullptr: they are already in d_aval).  Leaves W / WT in d_W / d_WT.
+int SpdNumericCtx::factor(SpdFactor &F, const double *aval_host, double *flops_out, double *mfma_ms_out) {
+  if (aval_host && n_aval) FA_OK(hipMemcpyAsync(d_aval, aval_host, sizeof(double) * n_aval, hipMemcpyHostToDevice, st));
+  {
+    unsigned long long init[3] = {0ull, 0x7ff0000000000000ull, 0ull};
+    FA_OK(hipMemcpyAsync(d_fail, init, 24, hipMemcpyHostToDevice, st));
     FA_OK(hipStreamSynchronize(st));
-    fail = (int)(back[0] & 0xffffffffull);
-    {
-      double lo, hi;
-      memcpy(&lo, &back[1], 8);
-      memcpy(&hi, &back[2], 8);
-      F.pivot_min = lo;
-      F.pivot_max = hi;
+  }
+  FA_OK(hipMemsetAsync(d_Fm, 0, sizeof(double) * std::max<long long>(fm_total, 1), st));
+  FA_OK(hipMemsetAsync(d_W, 0, sizeof(double) * std::max<int64_t>(w_total, 1), st));
+  FA_OK(hipMemsetAsync(d_WT, 0, sizeof(double) * std::max<int64_t>(wt_total, 1), st));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (mfma_ms_out) { FA_OK(hipEventCreate(&e0)); FA_OK(hipEventCreate(&e1)); }
+  double flops = 0, mfma_ms = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+  {
+  for (int h = 0; h <= maxh; h++) {
+    const int nf = (int)lvl[h].size();
+    if (nf == 0) continue;
+    const int *L = d_lvl + lvl_ptr[h];
+    int max_ent = 0, max_w = 0, max_m = 0, max_u = 0;
+    for (int f : lvl[h]) {
+      max_ent = std::max(max_ent, fd[f].ent_end - fd[f].ent_ptr);
+      max_w = std::max(max_w, fd[f].w);
+      max_m = std::max(max_m, fd[f].m);
+      max_u = std::max(max_u, fd[f].u);
     }
-    FA_OK(hipGetLastError());
-    if (fail) {
-      fprintf(stderr, "[dpgo_amd] ERROR: spd_factor (device): non-positive pivot in front %d\n", fail - 1);
-      return -1;
+    hipLaunchKernelGGL(k_fa_scatter, dim3((max_ent + 255) / 256, nf), dim3(256), 0, st, d_fd, L, d_dst, d_src, d_aval, d_Fm);
+    for (size_t s = 0; s < pair_rng[h].size(); s++)
+      if (pair_rng[h][s].second > 0)
+        hipLaunchKernelGGL(k_fa_extend, dim3(pair_maxu[h][s], pair_rng[h][s].second), dim3(256), 0, st, d_fd,
+                           d_pairs + pair_rng[h][s].first, d_cmap, d_Fm);
+    auto abt0 = [&](int k_lo, int k_hi, int sb_end, int wide) -> int {
+      // upper bounds over the fronts of the level (a front's block column may end before k_hi: columns from k_lo + 1 on)
+      const int nrt = (max_m + TS - 1) / TS, nct = (max_m - k_lo + TS - 1) / TS;
+      if (nct <= 0) return 0;
+      hipEvent_t a = nullptr, b = nullptr;
+      if (mfma_ms_out) {
+        FA_OK(hipEventCreate(&a)); FA_OK(hipEventCreate(&b));
+        FA_OK(hipEventRecord(a, st));
+      }
+      hipLaunchKernelGGL((k_fa_abt<0>), dim3(nrt * nct, nf), dim3(256), 0, st, d_fd, L, k_lo, k_hi, sb_end, wide, d_Fm, d_W, d_WT);
+      if (mfma_ms_out) {
+        FA_OK(hipEventRecord(b, st));
+        evs.push_back({a, b});
+      }
+      return 0;
+    };
+    for (int sb = 0; sb < max_w; sb += SB) {
+      const int se = sb + SB;
+      for (int kb = sb; kb < std::min(se, max_w); kb += NB) {
+        hipLaunchKernelGGL(k_fa_potrf_panel, dim3((max_m + 255) / 256, nf), dim3(256), 0, st, d_fd, L, kb, d_Fm, d_fail,
+                           reinterpret_cast<unsigned long long *>(d_fail) + 1);
+        if (abt0(kb, kb + NB, se, 0) != 0) return -1;      // the rest of the super-block (of the front, if it ends here), K = 32
+      }
+      if (se < max_w && abt0(sb, se, se, 1) != 0) return -1;   // everything right of the super-block, K = 128
     }
-    for (auto &ev : evs) {
-      float t = 0;
-      (void)hipEventElapsedTime(&t, ev.first, ev.second);
-      mfma_ms += t;
-      (void)hipEventDestroy(ev.first);
-      (void)hipEventDestroy(ev.second);
+    // the products the MFMA kernel carries for this level (useful flops: lower triangle of the trailing update)
+    for (int f : lvl[h]) {
+      const double w = fd[f].w, u = fd[f].u;
+      flops += w * w * w / 3.0 + u * w * w + u * u * w      // trailing updates of regular rows (2 flops per multiply-add, half by symmetry)
+               + w * w * w / 3.0                              // identity rows
+               + 2.0 * u * w * w / 2.0;                       // W_bottom (triangular operand)
     }
-    if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
-    if (F.keep_device) {   // the caller packs its solve panels from the device copies (Group: SpdSolverDev::upload)
-      spd_release_device(F);
-      F.dev_W = d_W;
-      F.dev_WT = d_WT;
-      d_W = d_WT = nullptr;
+    hipLaunchKernelGGL(k_fa_wtop, dim3(std::max(max_w, 1), nf), dim3(256), 0, st, d_fd, L, d_Fm, d_W, d_WT);
+    if (max_u > 0) {
+      const int nrt = (max_u + TS - 1) / TS, nct = (max_w + TS - 1) / TS;
+      if (mfma_ms_out) {
+        hipEvent_t a, b;
+        FA_OK(hipEventCreate(&a)); FA_OK(hipEventCreate(&b));
+        FA_OK(hipEventRecord(a, st));
+        hipLaunchKernelGGL((k_fa_abt<1>), dim3(nrt * nct, nf), dim3(256), 0, st, d_fd, L, 0, 0, 0, 0, d_Fm, d_W, d_WT);
+        FA_OK(hipEventRecord(b, st));
+        evs.push_back({a, b});
+      } else {
+        hipLaunchKernelGGL((k_fa_abt<1>), dim3(nrt * nct, nf), dim3(256), 0, st, d_fd, L, 0, 0, 0, 0, d_Fm, d_W, d_WT);
+      }
+    }
+  }
+  }
+  int fail = 0;
+  unsigned long long back[3] = {0, 0, 0};
+  FA_OK(hipMemcpyAsync(back, d_fail, 24, hipMemcpyDeviceToHost, st));
+  FA_OK(hipStreamSynchronize(st));
+  fail = (int)(back[0] & 0xffffffffull);
+  {
+    double lo, hi;
+    memcpy(&lo, &back[1], 8);
+    memcpy(&hi, &back[2], 8);
+    F.pivot_min = lo;
+    F.pivot_max = hi;
+  }
+  FA_OK(hipGetLastError());
+  if (fail) {
+    fprintf(stderr, "[dpgo_amd] ERROR: spd_factor (device): non-positive pivot in front %d\n", fail - 1);
+    return -1;
+  }
+  for (auto &ev : evs) {
+    float t = 0;
+    (void)hipEventElapsedTime(&t, ev.first, ev.second);
+    mfma_ms += t;
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+  if (flops_out) *flops_out = flops;
+  if (mfma_ms_out) *mfma_ms_out = mfma_ms;
+  return 0;
+}
+
+// children[f]: the fronts whose update rows are assembled into f.  Fills F.W and F.WT (host vectors), or -- keep_device --
+// leaves them on the GPU as dev_W / dev_WT.  keep_numeric: the context stays with the factor (F.numeric) and dev_W / dev_WT
+// are BORROWED from it (dev_borrowed; spd_release_device then only forgets them).
+// flops (optional): floating-point operations of the MFMA kernel; mfma_ms: time spent in it.
+int spd_factor_numeric_device(const CsrMatrix &A, SpdFactor &F, const std::vector<std::vector<int>> &children,
+                              double *flops_out, double *mfma_ms_out) {
+  spd_release_device(F);
+  SpdNumericCtx *ctx = F.numeric;
+  if (ctx && (ctx->nt != F.nfronts || ctx->n_aval != A.val.size())) { spd_release_numeric(F); ctx = nullptr; }
+  if (!ctx) {
+    ctx = new SpdNumericCtx();
+    if (ctx->build(A, F, children) != 0) { delete ctx; return -1; }
+  }
+  const bool kept = F.keep_numeric && F.keep_device;
+  if (kept) F.numeric = ctx;
+  int rc = ctx->factor(F, A.val.data(), flops_out, mfma_ms_out);
+  if (rc == 0) {
+    const int nt = F.nfronts;
+    if (kept) {
+      F.dev_W = ctx->d_W;
+      F.dev_WT = ctx->d_WT;
+      F.dev_borrowed = true;
+      std::vector<double>().swap(F.W);
+      std::vector<double>().swap(F.WT);
+    } else if (F.keep_device) {   // the caller packs its solve panels from the device copies (Group: SpdSolverDev::upload)
+      F.dev_W = ctx->d_W;
+      F.dev_WT = ctx->d_WT;
+      F.dev_borrowed = false;
+      ctx->d_W = ctx->d_WT = nullptr;
       std::vector<double>().swap(F.W);
       std::vector<double>().swap(F.WT);
     } else {
       F.W.assign(F.w_off[nt], 0.0);
       F.WT.assign(F.wt_off[nt], 0.0);
-      if (F.w_off[nt] > 0) FA_OK(hipMemcpy(F.W.data(), d_W, sizeof(double) * F.w_off[nt], hipMemcpyDeviceToHost));
-      if (F.wt_off[nt] > 0) FA_OK(hipMemcpy(F.WT.data(), d_WT, sizeof(double) * F.wt_off[nt], hipMemcpyDeviceToHost));
+      if (F.w_off[nt] > 0 && hipMemcpy(F.W.data(), ctx->d_W, sizeof(double) * F.w_off[nt], hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
+      if (F.wt_off[nt] > 0 && hipMemcpy(F.WT.data(), ctx->d_WT, sizeof(double) * F.wt_off[nt], hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
     }
-    if (flops_out) *flops_out = flops;
-    if (mfma_ms_out) *mfma_ms_out = mfma_ms;
-    return 0;
-  };
-  rc = run();
-  for (void *p : {(void *)d_fd, (void *)d_dst, (void *)d_src, (void *)d_cmap, (void *)d_lvl, (void *)d_fail, (void *)d_aval, (void *)d_Fm,
-                  (void *)d_dinv, (void *)d_W, (void *)d_WT, (void *)d_pairs})
-    if (p) (void)hipFree(p);
-  if (st) (void)hipStreamDestroy(st);
+  }
+  if (!kept) {
+    if (F.numeric == ctx) F.numeric = nullptr;
+    delete ctx;
+  }
   return rc;
 }
 
+double *spd_numeric_values(SpdFactor &F) { return F.numeric ? F.numeric->d_aval : nullptr; }
+
+// the numeric phase again, from the values in spd_numeric_values(F); dev_W / dev_WT (borrowed) hold the new factor
+int spd_refactor_device(SpdFactor &F) {
+  if (!F.numeric) return -1;
+  if (F.numeric->factor(F, nullptr, nullptr, nullptr) != 0) return -1;
+  F.dev_W = F.numeric->d_W;
+  F.dev_WT = F.numeric->d_WT;
+  F.dev_borrowed = true;
+  return 0;
+}
+
+void spd_release_numeric(SpdFactor &F) {
+  if (F.dev_borrowed) { F.dev_W = F.dev_WT = nullptr; F.dev_borrowed = false; }
+  delete F.numeric;
+  F.numeric = nullptr;
+}
+
 void spd_release_device(SpdFactor &F) {
-  if (F.dev_W) (void)hipFree(F.dev_W);
-  if (F.dev_WT) (void)hipFree(F.dev_WT);
+  if (!F.dev_borrowed) {
+    if (F.dev_W) (void)hipFree(F.dev_W);
+    if (F.dev_WT) (void)hipFree(F.dev_WT);
+  }
   F.dev_W = F.dev_WT = nullptr;
+  F.dev_borrowed = false;
 }
 
 }  // namespace dpgo
