@@ -360,9 +360,28 @@ def main():
                           sum(int(grp.results(k).tnt_inner_iterations) for k in range(len(grp)) if grp.results(k).refined) / len(grp),
                           sum(int(grp.results(k).refined) for k in range(len(grp)))))
         best = min(f for _, f, _, _ in trace)
-        hit = next(i for i, (_, f, _, _) in enumerate(trace) if f <= best * (1 + 1e-6))
+        # the reference objective: the one the CPU path reaches on this instance (tools/cpu_convergence.py, committed once
+        # per round as profiles/rNN_cpu_convergence.json); without that file, the lowest objective of this run
+        cpu_ref = None
+        try:
+            import glob
+            cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_convergence.json")))
+            cj = json.load(open(cand[-1]))
+            if args.grid == "50,50,40,400000" and args.nodes == 8 and args.loss == "huber":
+                cpu_ref = {"objective_2F": cj["lowest_2F"], "iterations_to_1e-6": cj["iterations_to_1e-6"],
+                           "seconds_to_1e-6": cj["seconds_to_1e-6"], "cores": cj["cores"], "cpu_model": cj["cpu_model"],
+                           "source": os.path.basename(cand[-1]) + " (tools/cpu_convergence.py: the C++ CPU restatement run to its own 1e-6 on all granted cores; not measured in this run)"}
+        except Exception:
+            cpu_ref = None
+        target = cpu_ref["objective_2F"] if cpu_ref else best
+        hit = next((i for i, (_, f, _, _) in enumerate(trace) if f <= target * (1 + 1e-6)), None)
+        if hit is None:       # (the run stopped short of the CPU's objective: report against its own lowest, and say so)
+            target, cpu_ref = best, dict(cpu_ref or {}, not_reached=True)
+            hit = next(i for i, (_, f, _, _) in enumerate(trace) if f <= target * (1 + 1e-6))
         tail = trace[-21:] if len(trace) > 21 else trace
-        convergence = {"iterations_run": args.converge, "lowest_2F": best, "iterations_to_1e-6": hit + 1,
+        convergence = {"iterations_run": args.converge, "lowest_2F": best, "target_2F": target,
+                       "target": "the objective the CPU path reaches (cpu_reference)" if cpu_ref and not cpu_ref.get("not_reached") else "lowest objective of this run",
+                       "cpu_reference": cpu_ref, "iterations_to_1e-6": hit + 1,
                        "seconds_to_1e-6": trace[hit][0], "mean_ms_per_iter_to_1e-6": 1e3 * trace[hit][0] / (hit + 1),
                        "mean_ms_per_iter_whole_run": 1e3 * trace[-1][0] / len(trace),
                        "last20_ms_per_iter": 1e3 * (tail[-1][0] - tail[0][0]) / max(len(tail) - 1, 1),

@@ -530,9 +530,11 @@ int Group::dist_chordal_initialization(const DChordalOptions &o, const double *X
     lo.accepted_delta = 0.0;  // refinement on in every iteration
     lo.preconditioner = 3;
     std::unique_ptr<Group> loc(new Group(gi, nodes_, lo, device_));
-    if (!loc->ok() || loc->initialize_global(Xl.data(), ldx) != 0 || loc->update(nodes_) != 0) return -1;
+    std::vector<int> every(N);   // (update / iterate take LOCAL indices)
+    for (int a = 0; a < N; a++) every[a] = a;
+    if (!loc->ok() || loc->initialize_global(Xl.data(), ldx) != 0 || loc->update(every) != 0) return -1;
     for (int it = 0; it < o.local_iters; it++)
-      if (loc->iterate(nodes_) != 0 || loc->update(nodes_) != 0) return -1;
+      if (loc->iterate(every) != 0 || loc->update(every) != 0) return -1;
     if (loc->scatter_global(Xl.data(), ldx) != 0) return -1;
     Xlocal = Xl.data();
     ldl = ldx;
@@ -562,7 +564,9 @@ int Group::dist_chordal_initialization(const DChordalOptions &o, const double *X
       }
     }
   }
+  clk.lap("dist-init:   local gauges");
   if (fill_neighbours() != 0) return -1;
+  clk.lap("dist-init:   neighbours' poses (shared)");
   std::vector<std::map<int, int>> nidx(N);
   for (int a = 0; a < N; a++) nidx[a] = make_n_index(info_[a]);
   auto sample = [&](double v) { if (objectives) objectives->push_back(v); };
@@ -605,6 +609,7 @@ int Group::dist_chordal_initialization(const DChordalOptions &o, const double *X
       for (int r = 0; r < d; r++) R0[(size_t)(k * d + r) * d + r] = 1.0;
     s.initialize(R0);
   }
+  clk.lap("dist-init:   reduced rotation problems");
   for (int it = 0; it < o.iters[0]; it++) {
     if (it % 20 == 0) {
       double f = 0;
