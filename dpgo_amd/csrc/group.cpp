@@ -690,6 +690,8 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   const size_t nall = (size_t)(P0_ + P1_) * RS_, nown = (size_t)P0_ * RS_;
   for (DevBuf<double> *b : {&Xk_, &Zc_, &Zp_, &Y_, &DfE_, &Tall_}) b->alloc(nall);
   for (DevBuf<double> *b : {&Xak_, &Xakh_, &gc_, &gp_, &Dfc_, &Dfp_, &gx_, &Dfx_, &T1_}) b->alloc(nown);
+  gx_lin_ = env_int("DPGO_GX_LINEAR", 1) != 0;
+  if (keep_gx()) { GXc_.alloc(nown); GXp_.alloc(nown); }
   for (auto &b : tmp_) b.alloc(nown);
   if (getenv("DPGO_SPD_DUMP")) {
     spd_profile(d_, st_, Ltt_, T1_.p);
@@ -1586,12 +1588,14 @@ int Group::update(const std::vector<int> &locals_in) {
     Zp_.swap(Zc_);
     gp_.swap(gc_);
     Dfp_.swap(Dfc_);
+    if (keep_gx()) GXp_.swap(GXc_);
     zc_done = zc_ready_;   // iterate() already left Xk's own rows in what is X[iter] now
   } else if (!adv.empty()) {
     set_mask(adv);
     copy_rows(Zp_.p, Zc_.p, true);
     copy_rows(gp_.p, gc_.p, false);
     copy_rows(Dfp_.p, Dfc_.p, false);
+    if (keep_gx()) copy_rows(GXp_.p, GXc_.p, false);
     set_mask(locals);
   }
   // The new linearisation point needs the neighbours' poses, which may still be on their way (an exchange on the
@@ -1618,12 +1622,15 @@ int Group::update(const std::vector<int> &locals_in) {
   };
   zc_ready_ = false;
   if (!zc_done) copy_rows(Zc_.p, Xk_.p, false);
+  double *GX = (!trivial && keep_gx()) ? GXc_.p : T1_.p;
   if (trivial)   // T1 = G Xak and <Xak, 1/2 G Xak>   (half of evaluate_G, DPGOProblem.cpp:180-205)
     launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xak_.p, false, nullptr, T1_.p, Xak_.p, 0.5, nullptr, partials_.p, 5);
-  else           // T1 = G X and <X, 1/2 G X>
-    launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Zc_.p, false, nullptr, T1_.p, Zc_.p, 0.5, nullptr, partials_.p, 5);
+  else           // T1 = G X and <X, 1/2 G X>  (kept as G X[k] where the next extrapolation reuses it)
+    launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Zc_.p, false, nullptr, GX, Zc_.p, 0.5, nullptr, partials_.p, 5);
   join_exchange();
-  launch_copy_nbr_rows(d_, st_, T_, cur_mask_, Xk_.p, Zc_.p);
+  // X[iter]'s neighbour rows <- Xk's: a launch of its own for the trivial loss; the robust losses' inter-edge pass does it
+  // on the way (it reads the neighbour rows from Xk and stores them)
+  if (trivial) launch_copy_nbr_rows(d_, st_, T_, cur_mask_, Xk_.p, Zc_.p);
   if (trivial) {
     // g = S Z  (evaluate_none_g_and_f0 / _f, DPGOProblem.cpp:269-287, 516-542), with <Xak, g> alongside
     launch_bsr(d_, st_, T_, false, cur_mask_, S_.dev, Zc_.p, false, nullptr, gc_.p, Xak_.p, 1.0, nullptr, partials_.p, 1);
@@ -1659,7 +1666,7 @@ int Group::update(const std::vector<int> &locals_in) {
       if (set.empty()) continue;
       set_mask(set);
       launch_inter(d_, st_, T_, cur_mask_, E_, opt_.loss, opt_.loss_reg, 0, pass == 1, Zc_.p, Zp_.p, Qd_.p, Dd_.p, DfE_.p,
-                   gc_.p, partials_.p, dynamic() ? e_w_.p : nullptr);   // slots 0, 1 and 2 = <X, g>
+                   gc_.p, partials_.p, dynamic() ? e_w_.p : nullptr, nullptr, nullptr, nullptr, nullptr, Xk_.p);   // slots 0, 1 and 2 = <X, g>
       std::vector<double> rho(num_local(), 0.0), gap(num_local(), 0.0);
       if (dynamic() && device_rescale_)   // the rescale test on the weights just computed; its verdict rides with the sums below
         launch_rescale_decide(st_, num_local(), cur_mask_.v, e_off_dev_.p, e_w_.p, e_scale_.p, rs_count_.p, opt_.max_rescale_count,
@@ -1673,14 +1680,25 @@ int Group::update(const std::vector<int> &locals_in) {
         const std::vector<int> changed = device_rescale_ ? rescale_device(set) : maybe_rescale(set);
         if (!changed.empty()) {
           set_mask(changed);
-          launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Zc_.p, false, nullptr, T1_.p, Zc_.p, 0.5, nullptr, partials_.p, 5);
+          launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Zc_.p, false, nullptr, GX, Zc_.p, 0.5, nullptr, partials_.p, 5);
           launch_inter(d_, st_, T_, cur_mask_, E_, opt_.loss, opt_.loss_reg, 1, false, Zc_.p, nullptr, nullptr, Dd_.p, nullptr,
                        gc_.p, partials_.p);   // g = DfobjE_own - D X with the new D (slot 2 = <X, g> again)
           set_mask(set);
         }
       }
       if (pass == 0) launch_bdiag_dot(d_, st_, T_, cur_mask_, Dd_.p, Zc_.p, 0.5, DfE_.p, -1.0, partials_.p, 3);
-      launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, partials_.p, 4, gc_.p, Dfc_.p);   // Dfobj = G X + g
+      launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, GX, nullptr, partials_.p, 4, gc_.p, Dfc_.p);   // Dfobj = G X + g
+      // (a node's first update: there is no X[k-1] yet -- gamma is 0 there, but the buffer must hold numbers)
+      if (keep_gx()) {
+        std::vector<int> fresh;
+        for (int a : set)
+          if (res_[a].iters == 0) fresh.push_back(a);
+        if (!fresh.empty()) {
+          set_mask(fresh);
+          copy_rows(GXp_.p, GXc_.p, false);
+          set_mask(set);
+        }
+      }
       const bool dyn = dynamic();
       end_with(6, set, [this, set, pass, dyn, rho, gap] {
         for (int a : set) {
@@ -1773,9 +1791,14 @@ void Group::prepare_extrapolated() {
     launch_extrapolate(d_, st_, T_, false, cur_mask_, gam, Dfc_.p, Dfp_.p, Dfx_.p);
   } else {
     // evaluate_g_and_Df(Y) (:264 -> DPGOProblem.cpp:683-749)
-    launch_inter(d_, st_, T_, cur_mask_, E_, o.loss, o.loss_reg, 1, false, Y_.p, nullptr, nullptr, Dd_.p, nullptr, gx_.p,
-                 partials_.p);
-    launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Y_.p, false, gx_.p, Dfx_.p, nullptr, 0, nullptr, nullptr, 0);
+    if (keep_gx()) {   // G Y = G X[k] + gamma (G X[k] - G X[k-1]): Df comes out of the inter-edge pass
+      launch_inter(d_, st_, T_, cur_mask_, E_, o.loss, o.loss_reg, 1, false, Y_.p, nullptr, nullptr, Dd_.p, nullptr, gx_.p,
+                   partials_.p, nullptr, GXc_.p, GXp_.p, &gam, Dfx_.p);
+    } else {
+      launch_inter(d_, st_, T_, cur_mask_, E_, o.loss, o.loss_reg, 1, false, Y_.p, nullptr, nullptr, Dd_.p, nullptr, gx_.p,
+                   partials_.p);
+      launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Y_.p, false, gx_.p, Dfx_.p, nullptr, 0, nullptr, nullptr, 0);
+    }
   }
 }
 

@@ -291,6 +291,11 @@ class Group {
   // vectors (records)
   DevBuf<double> Xk_, Zc_, Zp_, Y_, DfE_, Tall_;                 // P0+P1 rows
   DevBuf<double> Xak_, Xakh_, gc_, gp_, Dfc_, Dfp_, gx_, Dfx_, T1_;   // P0 rows
+  // robust loss, Static rescale: G X[k] and G X[k-1] (own rows), rotated with the history of X: the product with G at the
+  // extrapolated point is their linear combination (prepare_extrapolated), one pass over the operator less per iteration
+  DevBuf<double> GXc_, GXp_;
+  bool keep_gx() const { return opt_.loss != 0 && !dynamic() && gx_lin_; }
+  bool gx_lin_ = true;   // DPGO_GX_LINEAR=0 switches it off (measurement hook)
   DevBuf<double> tmp_[14];                                       // P0 rows, TNT work vectors
   hipEvent_t xchg_done_ = nullptr;   // pending boundary exchange (not owned)
   void join_exchange();              // the group's stream waits for it

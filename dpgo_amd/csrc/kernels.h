@@ -133,7 +133,12 @@ void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, co
 void launch_inter(int d, hipStream_t st, const SegTable &T, NodeMask mask, const InterEdgesDev &E, int loss,
                   double loss_reg, int mode, bool quad, const double *Z, const double *Zprev,
                   const double *Qdiag, const double *Ddiag, double *DfE, double *g, double *partials,
-                  double *wout = nullptr);   // wout (mode 0): the loss weight of every edge
+                  double *wout = nullptr,   // wout (mode 0): the loss weight of every edge
+                  // mode 1 with all four: also Df_out = g + GXc + gamma[node] (GXc - GXp) over own rows -- Df at the extrapolated
+                  // point from the products G X[k], G X[k-1] the last two update()s left (no pass over G)
+                  const double *GXc = nullptr, const double *GXp = nullptr, const NodeCoefs *gamma = nullptr, double *Df_out = nullptr,
+                  // mode 0 with Znbr: the neighbour rows are read from Znbr and copied into Z on the way (the halo copy of update())
+                  const double *Znbr = nullptr);
 
 // ---- Rescale::Dynamic on the device (see k_rescale_decide / k_rescale_apply) ----
 // decide: flags[a] / host_flags[a] = node a (of `nodes`) is rescaled; its scales and counter are updated

@@ -517,11 +517,17 @@ __device__ __forceinline__ void loss_weight(int loss, double dl, double s, doubl
   }
 }
 
+struct InterLin {   // (k_inter mode 1) Df at the extrapolated point from the kept products G X[k], G X[k-1]
+  const double *GXc = nullptr, *GXp = nullptr;
+  double *out = nullptr;
+  NodeCoefs gamma;
+};
 template <int D>
 __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask mask, InterEdgesDev E, int loss,
                                                double dl, int mode, int quad, int nseg_own, const double *Z,
                                                const double *Zprev, const double *Qd, const double *Dd,
-                                               double *DfE, double *g, double *partial, int pstride, double *wout) {
+                                               double *DfE, double *g, double *partial, int pstride, double *wout,
+                                               InterLin lin, const double *Znbr) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
   const bool active = node_on(mask, s.node);
@@ -530,7 +536,11 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask ma
   const int row = s.begin + threadIdx.x;
   if (active && row < s.end) {
     double zp[RS], acc[RS];
-    load_vec<RS>(Z + (size_t)row * RS, zp);
+    // Znbr (mode 0): the neighbour rows are taken from there (the iterate the exchange just delivered) and copied into Z
+    // on the way -- update()'s halo copy without a launch of its own.  Nobody reads Z's neighbour rows in this pass.
+    const bool from_nbr = Znbr && row >= E.nrows_own;
+    load_vec<RS>((from_nbr ? Znbr : Z) + (size_t)row * RS, zp);
+    if (from_nbr) store_vec<RS>(const_cast<double *>(Z) + (size_t)row * RS, zp);
 #pragma unroll
     for (int k = 0; k < RS; k++) acc[k] = 0.0;
     const int k1 = E.inc_ptr[row + 1];
@@ -543,7 +553,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask ma
       const int code = u8.r.code, e = code >> 1, role = code & 1;
       const int other = u8.r.other;
       double zo[RS], Re[D * D], te[D];
-      load_vec<RS>(Z + (size_t)other * RS, zo);
+      load_vec<RS>(((Znbr && other >= E.nrows_own) ? Znbr : Z) + (size_t)other * RS, zo);
 #pragma unroll
       for (int i = 0; i < D * D; i++) Re[i] = u8.r.R[i];
 #pragma unroll
@@ -622,6 +632,17 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask ma
       }
       part[2] = zg;
       store_vec<RS>(g + (size_t)row * RS, acc);
+      if (lin.out) {
+        // Df = g + G Y at the extrapolated point Y = X[k] + gamma (X[k] - X[k-1]), without another pass over G:
+        // G Y = G X[k] + gamma (G X[k] - G X[k-1]), both products kept from the last two update()s
+        double a[RS], b[RS];
+        load_vec<RS>(lin.GXc + (size_t)row * RS, a);
+        load_vec<RS>(lin.GXp + (size_t)row * RS, b);
+        const double gm = lin.gamma.a[s.node];
+#pragma unroll
+        for (int k = 0; k < RS; k++) acc[k] += fma(gm, a[k] - b[k], a[k]);
+        store_vec<RS>(lin.out + (size_t)row * RS, acc);
+      }
     }
   }
   if (active) block_store<3>(part, partial + SEGB, pstride);
@@ -1941,13 +1962,16 @@ void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, co
 
 void launch_inter(int d, hipStream_t st, const SegTable &T, NodeMask mask, const InterEdgesDev &E, int loss,
                   double loss_reg, int mode, bool quad, const double *Z, const double *Zprev,
-                  const double *Qdiag, const double *Ddiag, double *DfE, double *g, double *partials, double *wout) {
+                  const double *Qdiag, const double *Ddiag, double *DfE, double *g, double *partials, double *wout,
+                  const double *GXc, const double *GXp, const NodeCoefs *gamma, double *Df_out, const double *Znbr) {
   const int nb = mode == 0 ? T.nseg_all : T.nseg_own;
   if (nb == 0) return;
   ProfScope ps(PK_INTER, st, (double)E.m * (8.0 * (d * d + d + 2) + 8) + 2.0 * (mode == 0 ? E.nrows_all : E.nrows_own) * 8.0 * (d + 1) * d);
+  InterLin lin;
+  if (mode == 1 && Df_out && GXc && GXp && gamma) { lin.GXc = GXc; lin.GXp = GXp; lin.out = Df_out; lin.gamma = *gamma; }
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_inter<D>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, E, loss, loss_reg,
                                         mode, quad ? 1 : 0, T.nseg_own, Z, Zprev, Qdiag, Ddiag, DfE, g, partials,
-                                        T.nseg_all, mode == 0 ? wout : nullptr));
+                                        T.nseg_all, mode == 0 ? wout : nullptr, lin, mode == 0 ? Znbr : nullptr));
 }
 
 void launch_rescale_decide(hipStream_t st, int nnodes, NodeBits nodes, const int *e_off, const double *w, double *scale,

@@ -349,7 +349,12 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     acc.clear();
     requad.clear();
     for (int a : A) judge(a, &tsum[(size_t)a * NSUM]);
-    if (!acc.empty()) {
+    if ((int)acc.size() == L && X == Xak_.p && xprop == tmp_[7].p) {
+      // every node of the group took its step: the trial buffer simply becomes the iterate (no copy)
+      Xak_.swap(tmp_[7]);
+      X = Xak_.p;
+      xprop = tmp_[7].p;
+    } else if (!acc.empty()) {
       set_mask(acc);
       copy_rows(X, xprop, false, 0);
     }
