@@ -111,6 +111,48 @@ def launch_ranks(n, argv):
     return rc
 
 
+def measure_traffic(args):
+    """HBM bytes per launch of every kernel family from the PMC counters, measured for THIS run: two rocprofv3 passes
+    (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass; counters only, with --kernel-trace) over a short child run of this
+    same script and workload, summarised as /opt/skills/guides/MI355X_MICROARCH.md prescribes (tools/pmc_summary.py: KiB
+    units, read side doubled on gfx950).  Runs before this process touches the GPU; returns {family: bytes per launch} or
+    None (no rocprofv3, a failed pass, ...: the caller then quotes the committed summary and says so)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_summary
+    except Exception:
+        return None
+    tmp = tempfile.mkdtemp(prefix="dpgo_pmc_", dir="/tmp")
+    agg = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--no-cpu", "--no-prof", "--converge", "0", "--steps", "5", "--warmup", "2",
+                   "--traffic", "off", "--grid", args.grid, "--nodes", str(args.nodes), "--loss", args.loss]
+            r = subprocess.run(cmd, timeout=400, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd="/tmp",
+                               env=dict(os.environ, TMPDIR="/tmp"))
+            if r.returncode != 0:
+                return None
+            agg[ctr] = pmc_summary.collect(d, ctr)
+        res = {}
+        for k in set(agg["FETCH_SIZE"]) | set(agg["WRITE_SIZE"]):
+            nf, sf = agg["FETCH_SIZE"].get(k, [0, 0.0])
+            nw, sw = agg["WRITE_SIZE"].get(k, [0, 0.0])
+            if nf and nw:
+                res[k] = 2.0 * 1024.0 * sf / nf + 1024.0 * sw / nw
+        return res or None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     # started by hand with --gpus N > 1 and no launcher around it: become the launcher (before any torch / HIP import)
     if "WORLD_SIZE" not in os.environ:
@@ -152,6 +194,9 @@ def main():
                          "(relative) of the lowest one reached (SURVEY 8d: iterations and wall time to the reference "
                          "objective), the whole-run mean ms/iter and the ms/iter + CG steps/iter of the last 20 "
                          "iterations (the interior-step regime); 0 skips it")
+    ap.add_argument("--traffic", type=str, default="auto",
+                    help="auto: measure roofline.traffic with two rocprofv3 --pmc passes over a short child run before the "
+                         "timed run (N = 1, about 40 s); off: quote the committed summary")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="stop after the ranks have met (no GPU needed): checks the launcher")
     ap.add_argument("--force-exchange", action="store_true",
@@ -159,11 +204,16 @@ def main():
                          "what it adds to a step")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    measured_traffic = None
+    if (args.traffic == "auto" and world == 1 and args.gpus == 1 and not args.no_prof and args.prof_steps > 0
+            and not args.emulate_world and not args.rendezvous_only):
+        measured_traffic = measure_traffic(args)       # (child processes; this one has not touched the GPU yet)
+
     import torch
     import dpgo_amd
     from dpgo_amd import synthetic
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -329,7 +379,15 @@ def main():
         # same command (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process); the committed
         # summary (tools/pmc_summary.py) is quoted when it covers this workload and kernel
         traffic = traffic_source = None
+        if measured_traffic and dom[0] in measured_traffic:
+            traffic = measured_traffic[dom[0]]
+            traffic_source = ("measured for this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over a 5-step child run of this "
+                              "command (2 x FETCH_SIZE + WRITE_SIZE, KiB, gfx950 correction; tools/pmc_summary.py)")
+            for name in kernels:
+                if name in measured_traffic:
+                    kernels[name]["hbm_MB_per_launch_measured"] = measured_traffic[name] / 1e6
         try:
+          if traffic is None:
             import glob
             cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
             pm = json.load(open(cand[-1]))

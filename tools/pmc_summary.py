@@ -24,9 +24,9 @@ import sys
 def family(name):
     m = re.search(r"\b(k_[a-z_0-9]+)", name)
     n = m.group(1) if m else name
-    if n == "k_spd_level":   # template <D, DOF, ROWS, FWD, NT>: the bench reports the two sweeps separately
-        a = re.search(r"k_spd_level<([^>]*)>", name)
-        fwd = a is not None and a.group(1).split(",")[3].strip() in ("true", "1")
+    if n == "k_spd_level":   # template <D, DOF, ROWS, MODE, NT>: MODE 0 forward level, 1 backward level, 2 the fused roots
+        a = re.search(r"k_spd_level<([^>]*)>", name)   # (the bench's profiler counts the roots with the forward sweep)
+        fwd = a is not None and a.group(1).split(",")[3].strip() in ("0", "2")
         return "k_spd_fwd" if fwd else "k_spd_bwd"
     return {"k_cg_init": "k_axpby", "k_extrapolate": "k_axpby", "k_axpby_node": "k_axpby", "k_dots": "k_dot",
             "k_tangent_full": "k_rot_op"}.get(n, n)

@@ -18,14 +18,14 @@ K, r = j["kernels"], j["roofline"]
 
 def rocprof_avg_us(kernel):
     """average duration of the family in the committed rocprofv3 --stats summary (the k_spd_level template is
-    reported as k_spd_fwd / k_spd_bwd by its FWD argument)"""
+    reported as k_spd_fwd / k_spd_bwd by its MODE argument)"""
     import csv
     import re
     calls = tot = 0
     for row in csv.DictReader(open(os.path.join(ROOT, "profiles", tag + "_kernel_stats_bench_default.csv"))):
         m = re.search(r"k_spd_level<([^>]*)>", row["Name"])
         if m:
-            name = "k_spd_fwd" if m.group(1).split(",")[3].strip() == "true" else "k_spd_bwd"
+            name = "k_spd_fwd" if m.group(1).split(",")[3].strip() in ("0", "2") else "k_spd_bwd"   # MODE 0 / 2 (roots) / 1
         else:
             m2 = re.search(r"\b(k_[a-z_0-9]+)", row["Name"])
             name = m2.group(1) if m2 else row["Name"]
