@@ -67,6 +67,31 @@ class Options(C.Structure):
         return o
 
 
+def p2p_plan(rank, exported, needed):
+    """The neighbour-to-neighbour exchange plan of `rank` (comm.cpp::p2p_plan through dpgo_debug_p2p_plan).
+    exported[r] / needed[r]: lists of (node, pose) keys of every rank.  Returns (peers, send_keys, recv_keys) with
+    peers = [(rank, send_off, send_cnt, recv_off, recv_cnt), ...]."""
+    n = len(exported)
+    def flat(lists):
+        cnt = np.asarray([len(l) for l in lists], np.int32)
+        nodes = np.asarray([k[0] for l in lists for k in l] or [0], np.int32)
+        poses = np.asarray([k[1] for l in lists for k in l] or [0], np.int32)
+        return cnt, nodes, poses
+    ec, en, ep = flat(exported)
+    nc, nn_, npz = flat(needed)
+    sizes = np.zeros(3, np.int32)
+    if lib().dpgo_debug_p2p_plan(rank, n, _ip(ec), _ip(en), _ip(ep), _ip(nc), _ip(nn_), _ip(npz), None, None, None, _ip(sizes)) != 0:
+        raise ValueError("p2p_plan")
+    peers = np.zeros(max(5 * int(sizes[0]), 1), np.int32)
+    sk = np.zeros(max(2 * int(sizes[1]), 1), np.int32)
+    rk = np.zeros(max(2 * int(sizes[2]), 1), np.int32)
+    lib().dpgo_debug_p2p_plan(rank, n, _ip(ec), _ip(en), _ip(ep), _ip(nc), _ip(nn_), _ip(npz), _ip(peers), _ip(sk), _ip(rk), _ip(sizes))
+    P = [tuple(int(v) for v in peers[5 * i:5 * i + 5]) for i in range(int(sizes[0]))]
+    S = [(int(sk[2 * i]), int(sk[2 * i + 1])) for i in range(int(sizes[1]))]
+    R = [(int(rk[2 * i]), int(rk[2 * i + 1])) for i in range(int(sizes[2]))]
+    return P, S, R
+
+
 class DChordalOptions(C.Structure):
     """DChordal::Options::reg_G + the driver's stage schedule (dist_pgo.cpp:205,274,344,383) + stage-0 length."""
     _fields_ = [("iters", C.c_int * 4), ("local_iters", C.c_int), ("reg_G", C.c_double)]
@@ -160,6 +185,7 @@ SYMBOLS = {
     "dpgo_debug_node_proximal": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Options), _DP, _DP, _DP]),
     "dpgo_debug_spd_solve": (C.c_int, [C.c_int, _IP, _IP, _DP, _DP, C.c_int, C.c_int]),
     "dpgo_debug_spd_stats": (C.c_int, [C.c_int, _IP, _IP, _DP, C.c_int, C.POINTER(C.c_long), _IP, _IP]),
+    "dpgo_debug_p2p_plan": (C.c_int, [C.c_int, C.c_int, _IP, _IP, _IP, _IP, _IP, _IP, _IP, _IP, _IP, _IP]),
     "dpgo_group_debug_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, _DP, C.c_int, _DP, C.c_int]),
 }
 

@@ -564,6 +564,35 @@ int dpgo_write_g2o(const dpgo_graph_t *g, const double *X, int ld, const char *f
   return 0;
 }
 
+// test hook: the neighbour-to-neighbour exchange plan of rank `rank` (comm.cpp: p2p_plan) from every rank's exported and
+// needed keys.  exp_counts / need_counts: keys per rank; *_nodes / *_poses: the keys, rank after rank.
+// Out (may be null to query sizes): npeers; per peer 5 ints (rank, send_off, send_cnt, recv_off, recv_cnt); the send and
+// the receive keys (node, pose interleaved).  sizes[0..2] = npeers, send keys, recv keys.
+int dpgo_debug_p2p_plan(int rank, int nranks, const int *exp_counts, const int *exp_nodes, const int *exp_poses,
+                        const int *need_counts, const int *need_nodes, const int *need_poses, int *peers, int *send_keys,
+                        int *recv_keys, int *sizes) {
+  if (nranks < 1 || rank < 0 || rank >= nranks || !exp_counts || !need_counts || !sizes) return -1;
+  return guarded([&] {
+    std::vector<std::vector<dpgo::PoseKey>> ex(nranks), nd(nranks);
+    size_t a = 0, b = 0;
+    for (int r = 0; r < nranks; r++) {
+      for (int k = 0; k < exp_counts[r]; k++, a++) ex[r].push_back({exp_nodes[a], exp_poses[a]});
+      for (int k = 0; k < need_counts[r]; k++, b++) nd[r].push_back({need_nodes[b], need_poses[b]});
+    }
+    const dpgo::P2PPlan P = dpgo::p2p_plan(rank, ex, nd);
+    sizes[0] = (int)P.peers.size(); sizes[1] = (int)P.send_keys.size(); sizes[2] = (int)P.recv_keys.size();
+    if (peers)
+      for (size_t i = 0; i < P.peers.size(); i++) {
+        const auto &q = P.peers[i];
+        const int v[5] = {q.rank, q.send_off, q.send_cnt, q.recv_off, q.recv_cnt};
+        std::copy(v, v + 5, peers + 5 * i);
+      }
+    if (send_keys) for (size_t i = 0; i < P.send_keys.size(); i++) { send_keys[2 * i] = P.send_keys[i].first; send_keys[2 * i + 1] = P.send_keys[i].second; }
+    if (recv_keys) for (size_t i = 0; i < P.recv_keys.size(); i++) { recv_keys[2 * i] = P.recv_keys[i].first; recv_keys[2 * i + 1] = P.recv_keys[i].second; }
+    return 0;
+  });
+}
+
 // ---- RCCL exchange (comm.cpp) ----
 int dpgo_comm_unique_id(void *id128) {
   if (!id128) return -1;

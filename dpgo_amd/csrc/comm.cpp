@@ -19,8 +19,11 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <iterator>
+#include <map>
 #include <cstdio>
 #include <cstring>
+#include <string>
 
 #include "comm.h"
 
@@ -34,6 +37,10 @@ struct Rccl {
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   bool ok = false;
 };
@@ -52,6 +59,7 @@ Rccl &rccl() {
   }
 #define BIND(f) r.f = reinterpret_cast<decltype(r.f)>(dlsym(r.h, "nccl" #f))
   BIND(GetUniqueId); BIND(CommInitRank); BIND(CommDestroy); BIND(AllGather); BIND(AllReduce); BIND(GetErrorString);
+  BIND(Send); BIND(Recv); BIND(GroupStart); BIND(GroupEnd);   // (optional: without them the all-gather stays)
 #undef BIND
   r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.AllReduce && r.GetErrorString;
   if (!r.ok) fprintf(stderr, "[dpgo_amd] ERROR: librccl.so.1 lacks an expected symbol.\n");
@@ -74,6 +82,29 @@ Rccl &rccl() {
     }                                                                                               \
   } while (0)
 }  // namespace
+
+P2PPlan p2p_plan(int rank, const std::vector<std::vector<PoseKey>> &exported, const std::vector<std::vector<PoseKey>> &needed) {
+  P2PPlan P;
+  const int n = (int)exported.size();
+  auto common = [](const std::vector<PoseKey> &a, const std::vector<PoseKey> &b) {
+    std::vector<PoseKey> x(a), y(b), out;
+    std::sort(x.begin(), x.end());
+    x.erase(std::unique(x.begin(), x.end()), x.end());
+    std::sort(y.begin(), y.end());
+    y.erase(std::unique(y.begin(), y.end()), y.end());
+    std::set_intersection(x.begin(), x.end(), y.begin(), y.end(), std::back_inserter(out));
+    return out;   // ascending (node, pose)
+  };
+  for (int q = 0; q < n; q++) {
+    if (q == rank) continue;
+    const std::vector<PoseKey> snd = common(exported[rank], needed[q]), rcv = common(needed[rank], exported[q]);
+    if (snd.empty() && rcv.empty()) continue;
+    P.peers.push_back({q, (int)P.send_keys.size(), (int)snd.size(), (int)P.recv_keys.size(), (int)rcv.size()});
+    P.send_keys.insert(P.send_keys.end(), snd.begin(), snd.end());
+    P.recv_keys.insert(P.recv_keys.end(), rcv.begin(), rcv.end());
+  }
+  return P;
+}
 
 int Comm::unique_id(void *id128) {
   static_assert(sizeof(ncclUniqueId) == 128, "the C ABI hands the id over as 128 bytes");
@@ -137,6 +168,15 @@ void Comm::init(const void *id128) {
   if (grp->set_recv_layout(nranks, stride_, counts.data(), nodes.data(), poses.data()) != 0) return;
   send_.alloc((size_t)stride_ * RS);
   gathered_.alloc((size_t)stride_ * RS * nranks);
+  {
+    std::vector<std::vector<PoseKey>> exported(nranks);
+    size_t at = 0;
+    for (int r = 0; r < nranks; r++)
+      for (int k = 0; k < counts[r]; k++, at++) exported[r].push_back({nodes[at], poses[at]});
+    const char *kind = getenv("DPGO_EXCHANGE");
+    if (nranks > 1 && !(kind && std::string(kind) == "allgather") && rccl().Send && rccl().Recv && rccl().GroupStart && rccl().GroupEnd)
+      if (setup_p2p(exported) != 0) p2p_ = false;
+  }
   // AMM-PGO* and the global evaluations borrow the same buffers on the group's own stream
   if (grp->set_collectives(send_.p, gathered_.p, &Comm::cb_allgather, &Comm::cb_allreduce, this) != 0) return;
   ok_ = true;
@@ -162,6 +202,107 @@ void Comm::release() {
   ok_ = false;
 }
 
+// The neighbour-to-neighbour exchange: all-gather the keys every rank NEEDS (set-up only), derive the plan (p2p_plan),
+// upload the pack / unpack lists, and CHECK the whole path once with a message whose records carry their own keys: only
+// if every rank received exactly what it expected (a vote through ncclAllReduce) does exchange() use it; otherwise the
+// all-gather stays and a line says why.  RCCL with more than one rank cannot run on the boxes this was written on, so
+// the first 8-GPU run is also this path's first execution: the check is what makes it a safe default.
+int Comm::setup_p2p(const std::vector<std::vector<PoseKey>> &exported) {
+  Group *grp = grp_;
+  const int RS = (grp->d() + 1) * grp->d();
+  std::vector<PoseKey> need;
+  std::vector<int> need_rows;
+  grp->needed_keys(need, need_rows);
+  // ---- all-gather of the needed keys (counts, then padded key lists)
+  DevBuf<int> cnt_d, cnts_d;
+  cnt_d.upload(std::vector<int>{(int)need.size()});
+  cnts_d.alloc(nranks_);
+  NCCL_OK(rccl().AllGather(cnt_d.p, cnts_d.p, 1, ncclInt32, (ncclComm_t)comm_, cs_));
+  HIP_OK(hipStreamSynchronize(cs_));
+  std::vector<int> counts;
+  cnts_d.download(counts);
+  const int stride = std::max(1, *std::max_element(counts.begin(), counts.end()));
+  std::vector<int> mine(2 * (size_t)stride, -1), all;
+  for (size_t k = 0; k < need.size(); k++) { mine[2 * k] = need[k].first; mine[2 * k + 1] = need[k].second; }
+  DevBuf<int> mine_d, all_d;
+  mine_d.upload(mine);
+  all_d.alloc(2 * (size_t)stride * nranks_);
+  NCCL_OK(rccl().AllGather(mine_d.p, all_d.p, 2 * (size_t)stride, ncclInt32, (ncclComm_t)comm_, cs_));
+  HIP_OK(hipStreamSynchronize(cs_));
+  all_d.download(all);
+  std::vector<std::vector<PoseKey>> needed(nranks_);
+  for (int r = 0; r < nranks_; r++)
+    for (int k = 0; k < counts[r]; k++) needed[r].push_back({all[2 * ((size_t)r * stride + k)], all[2 * ((size_t)r * stride + k) + 1]});
+  plan_ = p2p_plan(rank_, exported, needed);
+  // ---- pack list: the own row of every key sent; unpack lists: every neighbour row that wants a received key
+  std::map<PoseKey, int> own_row;
+  {
+    const auto &keys = grp->sent_keys();
+    const auto &rows = grp->sent_rows();
+    for (size_t k = 0; k < keys.size(); k++) own_row[keys[k]] = rows[k];
+  }
+  // (whatever goes wrong locally, the lists keep the sizes of the plan: every rank must be able to run the checking
+  // exchange, or its peers would wait for it)
+  std::vector<int> srows;
+  bool ok = true;
+  for (const PoseKey &k : plan_.send_keys) {
+    auto it = own_row.find(k);
+    if (it == own_row.end()) ok = false;
+    srows.push_back(it == own_row.end() ? 0 : it->second);
+  }
+  std::map<PoseKey, int> slot;
+  for (size_t i = 0; i < plan_.recv_keys.size(); i++) slot[plan_.recv_keys[i]] = (int)i;
+  std::vector<int> rdst, rsrc;
+  for (size_t i = 0; i < need.size(); i++) {   // (a key may be wanted by several local nodes: one row each)
+    auto it = slot.find(need[i]);
+    if (it == slot.end()) { ok = false; continue; }
+    rdst.push_back(need_rows[i]);
+    rsrc.push_back(it->second);
+  }
+  p2p_send_rows_.upload(srows);
+  p2p_recv_dst_.upload(rdst);
+  p2p_recv_src_.upload(rsrc);
+  p2p_send_.alloc(std::max<size_t>(plan_.send_keys.size(), 1) * RS);
+  p2p_recv_.alloc(std::max<size_t>(plan_.recv_keys.size(), 1) * RS);
+  // ---- self-check: records that carry (node, pose) of their key travel the whole path once
+  const int nrec = grp->num_records();
+  std::vector<double> probe((size_t)nrec * RS, -1.0), back;
+  {
+    const auto &keys = grp->sent_keys();
+    const auto &rows = grp->sent_rows();
+    for (size_t k = 0; k < keys.size(); k++) { probe[(size_t)rows[k] * RS] = keys[k].first; probe[(size_t)rows[k] * RS + 1] = keys[k].second; }
+  }
+  DevBuf<double> probe_d;
+  probe_d.upload(probe);
+  if (run_p2p(probe_d.p, probe_d.p) != 0) ok = false;
+  HIP_OK(hipStreamSynchronize(cs_));
+  probe_d.download(back);
+  for (size_t i = 0; i < need.size() && ok; i++)
+    ok = back[(size_t)need_rows[i] * RS] == (double)need[i].first && back[(size_t)need_rows[i] * RS + 1] == (double)need[i].second;
+  double vote = ok ? 0.0 : 1.0;
+  if (allreduce_impl(&vote, 1) != 0) return -1;
+  if (vote != 0.0) {
+    if (rank_ == 0) fprintf(stderr, "[dpgo_amd] WARNING: the neighbour-to-neighbour exchange failed its self-check on %d rank(s); using the all-gather.\n", (int)vote);
+    return -1;
+  }
+  p2p_ = true;
+  return 0;
+}
+
+// pack the send keys' rows of src_records -> grouped send / recv with the real neighbours -> unpack into dst_records
+int Comm::run_p2p(const double *src_records, double *dst_records) {
+  const int RS = (grp_->d() + 1) * grp_->d();
+  grp_->copy_records(cs_, (int)p2p_send_rows_.n, nullptr, p2p_send_rows_.p, src_records, p2p_send_.p);
+  NCCL_OK(rccl().GroupStart());
+  for (const auto &pr : plan_.peers) {
+    if (pr.send_cnt) NCCL_OK(rccl().Send(p2p_send_.p + (size_t)pr.send_off * RS, (size_t)pr.send_cnt * RS, ncclFloat64, pr.rank, (ncclComm_t)comm_, cs_));
+    if (pr.recv_cnt) NCCL_OK(rccl().Recv(p2p_recv_.p + (size_t)pr.recv_off * RS, (size_t)pr.recv_cnt * RS, ncclFloat64, pr.rank, (ncclComm_t)comm_, cs_));
+  }
+  NCCL_OK(rccl().GroupEnd());
+  grp_->copy_records(cs_, (int)p2p_recv_dst_.n, p2p_recv_dst_.p, p2p_recv_src_.p, p2p_recv_.p, dst_records);
+  return 0;
+}
+
 // DPGOHash::communicate for the neighbours hosted by other ranks (DPGOHash.h:64-82), asynchronous: the group's
 // stream is not held up; Group::update() joins (Group::pending_exchange).
 int Comm::exchange() {
@@ -169,9 +310,13 @@ int Comm::exchange() {
   const int RS = (grp_->d() + 1) * grp_->d();
   HIP_OK(hipEventRecord(ev_ready_, grp_->stream()));      // Xk of this iteration is final
   HIP_OK(hipStreamWaitEvent(cs_, ev_ready_, 0));
-  grp_->pack_sent(send_.p, cs_);
-  NCCL_OK(rccl().AllGather(send_.p, gathered_.p, (size_t)stride_ * RS, ncclFloat64, (ncclComm_t)comm_, cs_));
-  grp_->unpack_recv(gathered_.p, cs_);
+  if (p2p_) {
+    if (run_p2p(grp_->Xk_records(), grp_->Xk_records()) != 0) return -1;
+  } else {
+    grp_->pack_sent(send_.p, cs_);
+    NCCL_OK(rccl().AllGather(send_.p, gathered_.p, (size_t)stride_ * RS, ncclFloat64, (ncclComm_t)comm_, cs_));
+    grp_->unpack_recv(gathered_.p, cs_);
+  }
   HIP_OK(hipEventRecord(ev_done_, cs_));
   grp_->set_pending_exchange(ev_done_);
   return 0;
@@ -180,6 +325,10 @@ int Comm::exchange() {
 // sum of n host doubles over all ranks (every rank gets the same bits: one ring, same order)
 int Comm::allreduce(double *vals, int n) {
   if (!ok_ || n < 0) return -1;
+  return allreduce_impl(vals, n);
+}
+
+int Comm::allreduce_impl(double *vals, int n) {
   hipStream_t st = grp_->stream();
   for (int off = 0; off < n; off += 64) {
     const int m = std::min(64, n - off);

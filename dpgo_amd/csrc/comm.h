@@ -1,10 +1,25 @@
 // RCCL communicator of one group (one process per GPU): see comm.cpp.
 #pragma once
 #include <cstddef>
+#include <utility>
+#include <vector>
 
 #include "group.h"
 
 namespace dpgo {
+
+// Who sends what to whom when every rank talks to its real neighbours only.  exported[r] / needed[r]: the (node, pose)
+// keys rank r's group exports / needs from other groups.  Rank `rank` sends peer q the keys q needs among its exports
+// and receives from q the keys it needs among q's exports, both in ascending (node, pose) order -- the same rule on
+// both ends, so a message's lay-out needs no negotiation.  Pure host logic (tests/test_exchange_gloo.py drives it
+// through dpgo_debug_p2p_plan with gloo messages on the CPU).
+typedef std::pair<int, int> PoseKey;
+struct P2PPlan {
+  struct Peer { int rank, send_off, send_cnt, recv_off, recv_cnt; };
+  std::vector<Peer> peers;                 // ascending rank, only peers with traffic
+  std::vector<PoseKey> send_keys, recv_keys;   // concatenated over the peers
+};
+P2PPlan p2p_plan(int rank, const std::vector<std::vector<PoseKey>> &exported, const std::vector<std::vector<PoseKey>> &needed);
 
 class Comm {
  public:
@@ -16,8 +31,10 @@ class Comm {
   bool ok() const { return ok_; }
   int rank() const { return rank_; }
   int nranks() const { return nranks_; }
-  int exchange();                          // pack -> ncclAllGather -> unpack on the communicator's stream
+  int exchange();                          // pack -> (grouped send / recv | ncclAllGather) -> unpack on the communicator's stream
+  const char *exchange_kind() const { return p2p_ ? "p2p" : "allgather"; }
   int allreduce(double *vals, int n);      // in-place sum of host doubles over the ranks
+  int allreduce_impl(double *vals, int n);
   int allreduce_large(double *vals, size_t n);
   int barrier();
 
@@ -34,6 +51,14 @@ class Comm {
   hipEvent_t ev_ready_ = nullptr, ev_done_ = nullptr;
   DevBuf<double> send_, gathered_, red_;
   double *h_red_ = nullptr;
+  // neighbour-to-neighbour exchange (grouped ncclSend / ncclRecv): the default with more than one rank once its
+  // self-check has passed on every rank; DPGO_EXCHANGE=allgather keeps the all-gather
+  bool p2p_ = false;
+  P2PPlan plan_;
+  DevBuf<double> p2p_send_, p2p_recv_;
+  DevBuf<int> p2p_send_rows_, p2p_recv_dst_, p2p_recv_src_;
+  int setup_p2p(const std::vector<std::vector<PoseKey>> &exported);
+  int run_p2p(const double *src_records, double *dst_records);   // pack from / unpack into record arrays, on cs_
 };
 
 }  // namespace dpgo

@@ -1367,6 +1367,22 @@ int Group::unpack_recv(const double *dev_gathered, hipStream_t st) {
   return 0;
 }
 
+void Group::needed_keys(std::vector<std::pair<int, int>> &keys, std::vector<int> &rows) const {
+  keys.clear();
+  rows.clear();
+  for (int a = 0; a < num_local(); a++)
+    for (int k = 0; k < info_[a].n[1]; k++) {
+      const auto key = info_[a].nbr_key[k];
+      if (local_of_node_.count(key.first)) continue;
+      keys.push_back(key);
+      rows.push_back(P0_ + nbr_off_[a] + k);
+    }
+}
+
+void Group::copy_records(hipStream_t st, int count, const int *didx, const int *sidx, const double *src, double *dst) const {
+  launch_copy_indexed(d_, st, count, didx, sidx, src, dst);
+}
+
 int Group::set_collectives(double *send_dev, double *gathered_dev, AllGatherFn ag, AllReduceFn ar, void *user) {
   if ((ag && (!send_dev || !gathered_dev)) || (ag && !ar)) return -1;
   coll_send_ = send_dev;

@@ -236,6 +236,13 @@ class Group {
   double lambda_max(int local) const { return lambda_max_[local]; }
   // (sent list across groups) unified own row of every boundary pose this group exports, with key
   const std::vector<std::pair<int, int>> &sent_keys() const { return sent_keys_; }
+  const std::vector<int> &sent_rows() const { return sent_rows_; }
+  // (node, pose) of every neighbour row whose owner lives in another group, and that row (unified numbering)
+  void needed_keys(std::vector<std::pair<int, int>> &keys, std::vector<int> &rows) const;
+  int num_records() const { return P0_ + P1_; }
+  double *Xk_records() { return Xk_.p; }
+  // dst[didx[k]] = src[sidx[k]] over pose records (didx may be null: dst[k]) on stream st
+  void copy_records(hipStream_t st, int count, const int *didx, const int *sidx, const double *src, double *dst) const;
 
  private:
   bool ok_ = false;

@@ -263,6 +263,14 @@ int dpgo_debug_spd_solve(int n, const int *ptr, const int *col, const double *va
 /* Host: size of the multifrontal factor of a CSR SPD matrix for a given nested-dissection leaf size. */
 int dpgo_debug_spd_stats(int n, const int *ptr, const int *col, const double *val, int leaf, long *nnz, int *levels,
                          int *max_front);
+/* Host: the neighbour-to-neighbour exchange plan of `rank` (what dpgo_comm_exchange uses with more than one rank) from
+ * every rank's exported and needed (node, pose) keys (dpgo_graph_exchange_plan of its nodes): per peer 5 ints (rank,
+ * send_off, send_cnt, recv_off, recv_cnt), the send and receive keys (node, pose interleaved, concatenated over the peers
+ * in the order both ends agree on: ascending (node, pose)); sizes[0..2] = peers, send keys, receive keys.  Output
+ * pointers may be NULL to query the sizes. */
+int dpgo_debug_p2p_plan(int rank, int nranks, const int *exp_counts, const int *exp_nodes, const int *exp_poses,
+                        const int *need_counts, const int *need_nodes, const int *need_poses, int *peers, int *send_keys,
+                        int *recv_keys, int *sizes);
 /* Device: single operators of one node on reference-layout inputs:
  *  "project" (d n0 x d -> nearest rotations), "solve_tt" ((d+1) n0 x d, translation rows),
  *  "solve_rr" (rotation rows), "G" ((d+1) n0 x d -> G X), "proximal" (in = [Z ; Df] stacked). */

@@ -105,3 +105,61 @@ def test_plan_matches_oracle_recv_sets(fixtures_dir):
                 want_sent |= {(a, p) for p in poses}
     assert set(zip(rn.tolist(), rp.tolist())) == want_recv
     assert set(zip(sn.tolist(), sp_.tolist())) == want_sent
+
+
+def _p2p_worker(rank, world, port, path, nn, out):
+    """Every rank sends each real neighbour exactly the poses the plan says (gloo isend / irecv of host buffers laid out
+    by the plan) and must end up with its oracle neighbour rows."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dpgo_amd
+    from oracle import g2o as og
+    G = dpgo_amd.read_g2o(path, nn)
+    per = nn // world
+    plans = [G.exchange_plan(list(range(r * per, (r + 1) * per))) for r in range(world)]
+    exported = [list(zip(p[0][0].tolist(), p[0][1].tolist())) for p in plans]
+    needed = [list(zip(p[1][0].tolist(), p[1][1].tolist())) for p in plans]
+    peers, skeys, rkeys = dpgo_amd.p2p_plan(rank, exported, needed)
+    # a "pose record" that identifies itself: (node, pose, 1000 node + pose)
+    rec = lambda k: [float(k[0]), float(k[1]), 1000.0 * k[0] + k[1]]
+    send = torch.tensor([rec(k) for k in skeys] or [[0.0, 0.0, 0.0]], dtype=torch.float64)
+    recv = torch.full((max(len(rkeys), 1), 3), -1.0, dtype=torch.float64)
+    reqs = []
+    for (q, so, sc, ro, rc) in peers:
+        if sc:
+            reqs.append(dist.isend(send[so:so + sc].contiguous(), dst=q))
+        if rc:
+            buf = torch.empty((rc, 3), dtype=torch.float64)
+            reqs.append((dist.irecv(buf, src=q), buf, ro, rc))
+    for r in reqs:
+        if isinstance(r, tuple):
+            r[0].wait()
+            recv[r[2]:r[2] + r[3]] = r[1]
+        else:
+            r.wait()
+    got = {(int(v[0]), int(v[1])): float(v[2]) for v in recv.tolist() if v[0] >= 0}
+    ok = set(got) == set(needed[rank]) and all(abs(got[k] - (1000.0 * k[0] + k[1])) == 0 for k in got)
+    ok = ok and [tuple(k) for k in rkeys] == sorted(set(needed[rank]) & set().union(*[set(exported[q]) for q in range(world) if q != rank]))
+    ok = ok and all(k in set(exported[rank]) for k in skeys)
+    out[rank] = (bool(ok), len(peers), len(skeys), len(rkeys), sum(len(e) for e in exported))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,nn,world", [("smallGrid3D", 4, 4), ("torus3D", 8, 4), ("M3500", 4, 2)])
+def test_neighbour_to_neighbour_plan_delivers_every_needed_pose(fixtures_dir, name, nn, world):
+    """dpgo_comm_exchange with several ranks talks to the real neighbours only (grouped ncclSend / ncclRecv laid out by
+    comm.cpp::p2p_plan).  RCCL cannot run several ranks here, so the plan is exercised with gloo messages on the CPU:
+    every rank receives exactly the (node, pose) records it needs, each from the rank that exports it, and nothing else;
+    the traffic is what the neighbours need, not world x the largest export."""
+    path = os.path.join(fixtures_dir, name + ".g2o")
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_p2p_worker, args=(world, _free_port(), path, nn, out), nprocs=world, join=True)
+    assert all(out[r][0] for r in range(world)), dict(out)
+    assert sum(out[r][2] for r in range(world)) == sum(out[r][3] for r in range(world))   # everything sent is received once
+    for r in range(world):
+        assert out[r][1] <= world - 1

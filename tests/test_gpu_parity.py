@@ -122,6 +122,9 @@ BASELINE_CASES = [
 ]
 
 
+_DIVERGED = {}   # case -> iteration at which the "refine decision flipped near its threshold" branch was taken (None: never)
+
+
 @pytest.mark.parametrize("name,nn,loss,acc,iters", BASELINE_CASES)
 def test_baseline_configs_match_oracle(fixtures_dir, name, nn, loss, acc, iters):
     """The BASELINE.json datasets: per-node objective trace within 1e-7 relative, final global objective
@@ -156,6 +159,7 @@ def test_baseline_configs_match_oracle(fixtures_dir, name, nn, loss, acc, iters)
             ro, rg = orc.nodes[a].results, gpu.group.results(a)
             np.testing.assert_allclose(rg.fobj, ro.fobj[0], rtol=1e-7, err_msg="fobj it=%d node=%d" % (it, a))
             np.testing.assert_allclose(rg.Gk, ro.Gk, rtol=1e-7, err_msg="Gk it=%d node=%d" % (it, a))
+    _DIVERGED[(name, nn, loss, acc)] = it if diverged else None
     if diverged:
         assert it >= 8      # a long common prefix was compared before the flip
         for _ in range(120):
@@ -174,6 +178,17 @@ def test_baseline_configs_match_oracle(fixtures_dir, name, nn, loss, acc, iters)
         np.testing.assert_allclose(tg, to, atol=1e-5)
     Fo = orc.star.evaluate_f(orc.gather())
     assert abs(orc.star.evaluate_f(gpu.X()) - Fo) <= 1e-6 * abs(Fo)
+
+
+def test_baseline_cases_rarely_leave_the_per_iteration_comparison():
+    """How often test_baseline_configs_match_oracle falls back from the per-iteration trace comparison to the final
+    objective (a refine decision that flipped within 5 % of its threshold): measured on the MI355X box in round 3 --
+    none of the nine cases takes that branch within its compared iterations.  At most one may (a different box's
+    rounding), otherwise the fallback would be hiding something."""
+    if not _DIVERGED:
+        pytest.skip("the baseline cases did not run in this process")
+    took = {k: v for k, v in _DIVERGED.items() if v is not None}
+    assert len(took) <= 1, took
 
 
 def test_synthetic_lattice_matches_oracle():
