@@ -462,7 +462,8 @@ def main():
                        "refined_nodes_last_step": refined, "tnt_inner_iterations_last_step": inner},
             "objective_2F": 2 * fsum,
             "exchange": None if not do_exchange else ("gloo, staged through the host" if host_staged else
-                                                     "RCCL all-gather behind the C ABI (dpgo_comm_exchange) on the communicator's stream, joined in update()"),
+                                                     ("RCCL, neighbour to neighbour (grouped ncclSend / ncclRecv)" if comm.exchange_kind() == "p2p"
+                                                      else "RCCL all-gather") + " behind the C ABI (dpgo_comm_exchange) on the communicator's stream, joined in update()"),
             "setup_s": {"graph+chordal_init": t_init, "operators+factorizations": t_group},
             "solver": grp.solver_stats(),
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,

@@ -144,6 +144,7 @@ SYMBOLS = {
     "dpgo_comm_exchange": (C.c_int, [C.c_void_p]),
     "dpgo_comm_allreduce_sum": (C.c_int, [C.c_void_p, _DP, C.c_long]),
     "dpgo_comm_barrier": (C.c_int, [C.c_void_p]),
+    "dpgo_comm_exchange_kind": (C.c_int, [C.c_void_p]),
     "dpgo_host_pack_sent": (C.c_int, [C.c_void_p, _IP, C.c_int, _DP, C.c_int, _DP]),
     "dpgo_host_unpack_recv": (C.c_int, [C.c_void_p, _IP, C.c_int, C.c_int, C.c_int, C.c_int, _IP, _IP, _IP, _DP, _DP,
                                         C.c_int]),
@@ -627,6 +628,10 @@ class Comm:
 
     def exchange(self):
         return lib().dpgo_comm_exchange(self._h)
+
+    def exchange_kind(self):
+        """"p2p" (grouped ncclSend / ncclRecv to the real neighbours) or "allgather"."""
+        return "p2p" if lib().dpgo_comm_exchange_kind(self._h) == 1 else "allgather"
 
     def allreduce_sum(self, vals):
         a = np.ascontiguousarray(vals, np.float64).ravel().copy()

@@ -630,6 +630,11 @@ int dpgo_comm_allreduce_sum(dpgo_comm_t *c, double *vals, long n) {
   return guarded([&] { return n <= 4096 ? c->c->allreduce(vals, (int)n) : c->c->allreduce_large(vals, (size_t)n); });
 }
 
+int dpgo_comm_exchange_kind(const dpgo_comm_t *c) {
+  if (!c || !c->c) return -1;
+  return std::string(c->c->exchange_kind()) == "p2p" ? 1 : 0;
+}
+
 int dpgo_comm_barrier(dpgo_comm_t *c) {
   if (!c) return -1;
   return guarded([&] { return c->c->barrier(); });

@@ -267,7 +267,7 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
       if (is_root(f)) roots.push_back(f);
     int t64 = 0;
     for (int f : roots) t64 += (F.w[f] + 63) / 64;
-    const int rows = t64 < env_int("DPGO_SPD_FINE_FWD", 192) ? 16 : 64;   // few tiles: 16-row tiles reach 4x more CUs
+    const int rows = t64 < env_int("DPGO_SPD_FINE_ROOT", 192) ? 16 : 64;   // few tiles: 16-row tiles reach 4x more CUs
     root_level.rows = rows;
     std::vector<Tile> tiles;
     for (int a = 0; a < nnodes; a++) {

@@ -220,6 +220,9 @@ void dpgo_comm_free(dpgo_comm_t *comm);
 int dpgo_comm_exchange(dpgo_comm_t *comm);
 int dpgo_comm_allreduce_sum(dpgo_comm_t *comm, double *vals, long n);
 int dpgo_comm_barrier(dpgo_comm_t *comm);
+/* How dpgo_comm_exchange moves the boundary poses: 1 = neighbour to neighbour (grouped ncclSend / ncclRecv, the default with
+ * several ranks once its self-check passed on every rank), 0 = all-gather of fixed-size buffers; -1 on error. */
+int dpgo_comm_exchange_kind(const dpgo_comm_t *comm);
 /* The same pack / unpack on host matrices (no GPU needed; what a host-staged transport or a test uses): records
  * of the poses a group exports, in key order, from a global X ((d+1)N x d) into buf (count x (d+1)d doubles,
  * [t | rows of R^T] per pose); and the neighbour rows of node `node` ((d+1)(n0+n1) x d matrix Z, DPGOHash::initialize
