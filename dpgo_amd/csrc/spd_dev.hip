@@ -88,17 +88,81 @@ __device__ __forceinline__ double bcast(double v, int src) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// One block column of the elimination in ONE launch: the Cholesky of the diagonal block [kb, kb + nb) and its inverse,
-// then the rows below times the transposed inverse,  F[i, kb:ke] <- F[i, kb:ke] L_kk^-T.
-// Every workgroup of a front (256 rows each) first factors the 32 x 32 diagonal block itself -- wave 0, a row of the
-// block per lane, everything in registers: 496 broadcasts + multiply-adds for the factor, as many for the inverse, a few
-// microseconds, against a launch of its own and a trip through memory for the inverse -- and hands X = L_kk^-1 to the
-// other waves through LDS.  (The factored diagonal block itself is never read again -- later steps touch the rows below
-// and the identity rows only -- so nobody writes it back and the workgroups need not agree on who would.)
+// the factor and the inverse of the diagonal block [kb, kb + nb) of front f by ONE wave, a row of the block per lane,
+// in registers; lane j ends up with column j of X = L_kk^-1.  Returns false on a non-positive pivot.
+__device__ __forceinline__ bool potrf_inv_wave(const FrontDesc &f, const double *Fm, int kb, int nb, int lane, double (&X)[NB],
+                                               double &dmin, double &dmax) {
+  // row `lane` of the diagonal block (lanes >= nb and columns >= nb: the identity, which factors to itself)
+  double L[NB];
+  const double *A = Fm + f.fm_off + (long long)kb * f.m + kb;
+#pragma unroll
+  for (int j = 0; j < NB; j++) L[j] = (lane < nb && j <= lane) ? A[(long long)lane * f.m + j] : ((lane == j) ? 1.0 : 0.0);
+  dmin = 1e300;
+  dmax = 0.0;
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < NB; k++) {
+    const double dkk = bcast(L[k], k);
+    if (k < nb) {
+      ok = ok && (dkk > 0.0);
+      dmin = fmin(dmin, dkk);
+      dmax = fmax(dmax, dkk);
+    }
+    const double lkk = sqrt(dkk), inv = 1.0 / lkk;
+    L[k] = lane == k ? lkk : L[k] * inv;           // column k: the pivot, and the rows below it scaled
+#pragma unroll
+    for (int j = k + 1; j < NB; j++) {
+      const double ljk = bcast(L[k], j);           // L[j][k]
+      L[j] = lane >= j ? fma(-L[k], ljk, L[j]) : L[j];
+    }
+  }
+  // X = L^-1, lane j its column j: X[i][j] = (delta_ij - sum_{k<i} L[i][k] X[k][j]) / L[i][i]  (zeros above the diagonal
+  // come out by themselves)
+#pragma unroll
+  for (int i = 0; i < NB; i++) {
+    double sum = lane == i ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < i; k++) sum = fma(-bcast(L[k], i), X[k], sum);
+    X[i] = sum / bcast(L[i], i);
+  }
+  return ok;
+}
+
+// One block column of the elimination: the Cholesky of the diagonal block [kb, kb + nb) and its inverse, then the rows below
+// times the transposed inverse,  F[i, kb:ke] <- F[i, kb:ke] L_kk^-T.
+// FUSED (levels with few fronts: a launch is what costs): every workgroup of a front (256 rows each) first factors the
+// 32 x 32 diagonal block itself -- wave 0, in registers (potrf_inv_wave), a few microseconds against a launch of its own and
+// a trip through memory for the inverse -- and hands X = L_kk^-1 to the other waves through LDS.  Not FUSED (levels with
+// thousands of fronts: throughput is what costs, and a workgroup per 256 rows that idles three of its four waves during
+// the factorisation wastes it): k_fa_potrf_reg has done the diagonal blocks, one wave per front, and left X in `dinv`.
+// (The factored diagonal block itself is never read again -- later steps touch the rows below and the identity rows
+// only -- so nobody writes it back.)
 // fail[0]: 1 + front of a non-positive pivot; pivr[0] / pivr[1]: smallest / largest pivot d_kk seen (bit patterns of
-// positive doubles order like integers); both reported by the front's first workgroup.
-__global__ __launch_bounds__(256) void k_fa_potrf_panel(const FrontDesc *fd, const int *lvl, int kb, double *Fm, int *fail,
-                                                        unsigned long long *pivr) {
+// positive doubles order like integers); both reported once per front.
+__global__ __launch_bounds__(64) void k_fa_potrf_reg(const FrontDesc *fd, const int *lvl, int kb, const double *Fm, double *dinv,
+                                                     int *fail, unsigned long long *pivr) {
+  const FrontDesc f = fd[lvl[blockIdx.x]];
+  if (f.w <= kb) return;
+  const int nb = min(NB, f.w - kb), lane = threadIdx.x;
+  double X[NB], dmin, dmax;
+  const bool ok = potrf_inv_wave(f, Fm, kb, nb, lane, X, dmin, dmax);
+  double *D = dinv + (long long)f.slot * NB * NB;
+  if (lane < NB) {
+#pragma unroll
+    for (int i = 0; i < NB; i++) D[i * NB + lane] = ok ? X[i] : 0.0;
+  }
+  if (lane == 0) {
+    if (!ok) atomicExch(fail, 1 + lvl[blockIdx.x]);
+    else {
+      atomicMin(pivr, (unsigned long long)__double_as_longlong(dmin));
+      atomicMax(pivr + 1, (unsigned long long)__double_as_longlong(dmax));
+    }
+  }
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_fa_potrf_panel(const FrontDesc *fd, const int *lvl, int kb, double *Fm, const double *dinv,
+                                                        int *fail, unsigned long long *pivr) {
   const FrontDesc f = fd[lvl[blockIdx.y]];
   if (f.w <= kb) return;
   const int nb = min(NB, f.w - kb), ke = kb + nb;
@@ -108,54 +172,29 @@ __global__ __launch_bounds__(256) void k_fa_potrf_panel(const FrontDesc *fd, con
   __shared__ double D[NB][LDT];
   __shared__ int bad;
   const int t = threadIdx.x;
-  if (t < 64) {
-    const int lane = t;
-    // row `lane` of the diagonal block (lanes >= nb and columns >= nb: the identity, which factors to itself)
-    double L[NB], X[NB];
-    const double *A = Fm + f.fm_off + (long long)kb * f.m + kb;
+  if constexpr (FUSED) {
+    if (t < 64) {
+      double X[NB], dmin, dmax;
+      const bool ok = potrf_inv_wave(f, Fm, kb, nb, t, X, dmin, dmax);
+      if (t < NB) {
 #pragma unroll
-    for (int j = 0; j < NB; j++) L[j] = (lane < nb && j <= lane) ? A[(long long)lane * f.m + j] : ((lane == j) ? 1.0 : 0.0);
-    double dmin = 1e300, dmax = 0.0;
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-      const double dkk = bcast(L[k], k);
-      if (k < nb) {
-        ok = ok && (dkk > 0.0);
-        dmin = fmin(dmin, dkk);
-        dmax = fmax(dmax, dkk);
+        for (int i = 0; i < NB; i++) D[i][t] = X[i];
       }
-      const double lkk = sqrt(dkk), inv = 1.0 / lkk;
-      L[k] = lane == k ? lkk : L[k] * inv;           // column k: the pivot, and the rows below it scaled
-#pragma unroll
-      for (int j = k + 1; j < NB; j++) {
-        const double ljk = bcast(L[k], j);           // L[j][k]
-        L[j] = lane >= j ? fma(-L[k], ljk, L[j]) : L[j];
-      }
-    }
-    // X = L^-1, lane j its column j: X[i][j] = (delta_ij - sum_{k<i} L[i][k] X[k][j]) / L[i][i]  (zeros above the diagonal
-    // come out by themselves)
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-      double sum = lane == i ? 1.0 : 0.0;
-#pragma unroll
-      for (int k = 0; k < i; k++) sum = fma(-bcast(L[k], i), X[k], sum);
-      X[i] = sum / bcast(L[i], i);
-    }
-    if (lane < NB) {
-#pragma unroll
-      for (int i = 0; i < NB; i++) D[i][lane] = X[i];
-    }
-    if (lane == 0) {
-      bad = !ok;
-      if (blockIdx.x == 0) {
-        if (!ok) atomicExch(fail, 1 + lvl[blockIdx.y]);
-        else {
-          atomicMin(pivr, (unsigned long long)__double_as_longlong(dmin));
-          atomicMax(pivr + 1, (unsigned long long)__double_as_longlong(dmax));
+      if (t == 0) {
+        bad = !ok;
+        if (blockIdx.x == 0) {
+          if (!ok) atomicExch(fail, 1 + lvl[blockIdx.y]);
+          else {
+            atomicMin(pivr, (unsigned long long)__double_as_longlong(dmin));
+            atomicMax(pivr + 1, (unsigned long long)__double_as_longlong(dmax));
+          }
         }
       }
     }
+  } else {
+    const double *Dg = dinv + (long long)f.slot * NB * NB;
+    for (int idx = t; idx < NB * NB; idx += 256) D[idx / NB][idx % NB] = Dg[idx];
+    if (t == 0) bad = 0;   // (a failed front holds zeros: its rows are zeroed, the failure is already reported)
   }
   __syncthreads();
   if (bad) return;
@@ -480,8 +519,18 @@ int SpdNumericCtx::factor(SpdFactor &F, const double *aval_host, double *flops_o
     for (int sb = 0; sb < max_w; sb += SB) {
       const int se = sb + SB;
       for (int kb = sb; kb < std::min(se, max_w); kb += NB) {
-        hipLaunchKernelGGL(k_fa_potrf_panel, dim3((max_m + 255) / 256, nf), dim3(256), 0, st, d_fd, L, kb, d_Fm, d_fail,
-                           reinterpret_cast<unsigned long long *>(d_fail) + 1);
+        // few workgroups in the launch: every one factors the diagonal block itself (one launch); many: one wave per
+        // front does it first (the workgroups of the panel would idle three waves of four meanwhile)
+        const int bx = (max_m + 255) / 256;
+        if ((long long)bx * nf <= 768) {
+          hipLaunchKernelGGL((k_fa_potrf_panel<true>), dim3(bx, nf), dim3(256), 0, st, d_fd, L, kb, d_Fm, d_dinv, d_fail,
+                             reinterpret_cast<unsigned long long *>(d_fail) + 1);
+        } else {
+          hipLaunchKernelGGL(k_fa_potrf_reg, dim3(nf), dim3(64), 0, st, d_fd, L, kb, d_Fm, d_dinv, d_fail,
+                             reinterpret_cast<unsigned long long *>(d_fail) + 1);
+          hipLaunchKernelGGL((k_fa_potrf_panel<false>), dim3(bx, nf), dim3(256), 0, st, d_fd, L, kb, d_Fm, d_dinv, d_fail,
+                             reinterpret_cast<unsigned long long *>(d_fail) + 1);
+        }
         if (abt0(kb, kb + NB, se, 0) != 0) return -1;      // the rest of the super-block (of the front, if it ends here), K = 32
       }
       if (se < max_w && abt0(sb, se, se, 1) != 0) return -1;   // everything right of the super-block, K = 128

@@ -183,11 +183,14 @@ def test_baseline_configs_match_oracle(fixtures_dir, name, nn, loss, acc, iters)
 def test_baseline_cases_rarely_leave_the_per_iteration_comparison():
     """How often test_baseline_configs_match_oracle falls back from the per-iteration trace comparison to the final
     objective (a refine decision that flipped within 5 % of its threshold): measured on the MI355X box in round 3 --
-    none of the nine cases takes that branch within its compared iterations.  At most one may (a different box's
-    rounding), otherwise the fallback would be hiding something."""
+    one of the five cases does (sphere2500 with one node, at iteration 23 of its 25: G_tt is singular along the gauge
+    there and the trajectories part at rounding level; its common prefix of 23 iterations is compared at 1e-7 like the
+    others), the other four are compared iteration by iteration to the end.  More than one would mean the fallback is
+    hiding something."""
     if not _DIVERGED:
         pytest.skip("the baseline cases did not run in this process")
     took = {k: v for k, v in _DIVERGED.items() if v is not None}
+    print("baseline cases that left the per-iteration comparison: %d of %d %s" % (len(took), len(_DIVERGED), took))
     assert len(took) <= 1, took
 
 
