@@ -57,6 +57,7 @@ template struct DevBuf<NodeBits>;
 template struct DevBuf<PanelSrc>;
 template struct DevBuf<InterInc>;
 template struct DevBuf<RootDesc>;
+template struct DevBuf<float>;
 
 // tuning hooks (tools/env_ab.sh): an integer from the environment, or the default
 static int env_int(const char *name, int dflt) {
@@ -344,6 +345,29 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
   dev.piv_idx = piv_idx.p; dev.upd_idx = upd_idx.p; dev.asm_ptr = asm_ptr.p; dev.ubuf_dst = ubuf_dst.p;
   dev.W = W.p; dev.WT = WT.p; dev.fwd_items = fwd_items.p; dev.bwd_items = bwd_items.p; dev.ubuf = ubuf.p;
   dev.root_items = root_items.p; dev.Wroot = Wroot.p;
+  dev.f32 = 0;
+  if (want_f32 && !F.keep_numeric) {
+    // the experiment: fp32 copies of the panels, the fp64 ones are dropped
+    W32.alloc(std::max<size_t>(W.n, 1), false);
+    WT32.alloc(std::max<size_t>(WT.n, 1), false);
+    Wroot32.alloc(std::max<size_t>(Wroot.n, 1), false);
+    launch_to_f32(nullptr, W.p, W32.p, W.n);
+    launch_to_f32(nullptr, WT.p, WT32.p, WT.n);
+    launch_to_f32(nullptr, Wroot.p, Wroot32.p, Wroot.n);
+    HIP_CHECK(hipDeviceSynchronize());
+    stream_once = sizeof(float) * (W.n + WT.n + Wroot.n) > keep;
+    W.release(); WT.release(); Wroot.release();
+    dev.W = reinterpret_cast<const double *>(W32.p);
+    dev.WT = reinterpret_cast<const double *>(WT32.p);
+    dev.Wroot = reinterpret_cast<const double *>(Wroot32.p);
+    dev.f32 = 1;
+    for (double &b : fwd_level_bytes) b *= 0.5;   // (approximately: the vectors stay fp64)
+    for (double &b : bwd_level_bytes) b *= 0.5;
+    for (auto *lv : {&fwd_levels, &bwd_levels})
+      for (auto &l : *lv)
+        for (double &b : l.node_bytes) b *= 0.5;
+    for (double &b : root_level.node_bytes) b *= 0.5;
+  }
 }
 
 static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec);
@@ -646,6 +670,7 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
       std::vector<int> node_of_row((size_t)P0_ * d_);
       for (int a = 0; a < L; a++)
         for (int p = 0; p < info_[a].n[0] * d_; p++) node_of_row[(size_t)own_off_[a] * d_ + p] = a;
+      Lrr_.want_f32 = env_int("DPGO_PRECON_FP32", 0) != 0;   // (experiment, see SpdSolverDev::want_f32)
       Lrr_.upload(d_, node_of_row);
       clk.lap("G_RR: panels (pack + upload)");
     }

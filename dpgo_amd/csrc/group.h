@@ -137,6 +137,11 @@ struct SpdSolverDev {
   // complement (k_spd_level MODE 2); DPGO_SPD_FUSE_ROOT=0 keeps them in the two sweeps
   Level root_level{0, 0, 0, 64, {}, {}, {}, {}, {}};
   bool fused_root = false;
+  // EXPERIMENT, never the default and never part of the headline: the panels of this factor stored in fp32 (half the
+  // bytes of every solve; the arithmetic stays fp64).  Only offered for the preconditioner's factor (DPGO_PRECON_FP32=1),
+  // where SURVEY 7 allows mixed precision: it changes the CG's path, not the surrogate or the accepted steps' test.
+  bool want_f32 = false;
+  DevBuf<float> W32, WT32, Wroot32;
   DevBuf<SpdItem> root_items;
   DevBuf<double> Wroot, Proot;   // the root tiles' panels; the dense products they are cut from (kept with keep_numeric)
   DevBuf<RootDesc> root_desc;

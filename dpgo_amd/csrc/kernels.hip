@@ -8,6 +8,8 @@
 // reproducible run to run.
 #include "kernels.h"
 
+#include <algorithm>
+
 #include <cstdlib>
 #include <vector>
 
@@ -1466,7 +1468,7 @@ __device__ unsigned long long *g_spd_trace = nullptr;
 // NT: the panels are read once per solve; non-temporal loads keep a factor that cannot stay in the Infinity
 // Cache anyway from displacing what the kernels between two solves re-read (operators, vectors, and a
 // smaller factor that does fit)
-#define LDW(p) (NT ? __builtin_nontemporal_load(p) : *(p))
+#define LDW(p) ((double)(NT ? __builtin_nontemporal_load(p) : *(p)))   // (panels in fp64, or -- an opt-in experiment -- fp32)
 // waves per workgroup of the 16-row class (16 waves per tile measured 5 % slower than 8)
 #ifndef SPD_NW16
 #define SPD_NW16 8
@@ -1530,8 +1532,8 @@ __device__ __forceinline__ void pull_updates(const SpdDev &S, int pos, double (&
 // before the products of the current one, so a lane always has HB..2 HB loads in flight (a single batch that is
 // waited for as a whole drains to zero between batches).  `pre`: the first half-batch, issued by stream_first()
 // before the chunk's input vector was gathered.
-template <int D, int KQ, bool NT, int HB>
-__device__ __forceinline__ bool stream_first(const double *wp, int ld, int kq, int kn, double (&a)[HB]) {
+template <int D, int KQ, bool NT, int HB, typename PT>
+__device__ __forceinline__ bool stream_first(const PT *wp, int ld, int kq, int kn, double (&a)[HB]) {
   const bool full = kq + (HB - 1) * KQ < kn;
   if (full) {
 #pragma unroll
@@ -1539,8 +1541,8 @@ __device__ __forceinline__ bool stream_first(const double *wp, int ld, int kq, i
   }
   return full;
 }
-template <int D, int KQ, bool NT, int HB>
-__device__ __forceinline__ void stream_rest(const double *wp, int ld, int kq, int kn, const double *fw, bool have,
+template <int D, int KQ, bool NT, int HB, typename PT>
+__device__ __forceinline__ void stream_rest(const PT *wp, int ld, int kq, int kn, const double *fw, bool have,
                                             double (&a)[HB], double (&acc)[D]) {
   double b[HB];
   int kk = kq;
@@ -1595,7 +1597,7 @@ __device__ __forceinline__ int spd_chunk(int len) {
 // its forward step y = L11^-1 f is followed at once by its backward step x = L11^-T y: the tile streams rows of the
 // explicit product L11^-T L11^-1 (= the inverse of the root's Schur complement, S.Wroot) and writes scale * x straight
 // into `out` -- one launch instead of two, the same bytes (w^2 entries against two triangles).
-template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool NT, bool ROOT = false>
+template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool NT, bool ROOT = false, typename PT = double>
 __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it, const double *vec, double *ytmp,
                                              double *fw, double *red, const int wv, const int lane,
                                              int trace_slot = 0, unsigned long long trace_t0 = 0, double *out = nullptr,
@@ -1609,7 +1611,7 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
   const int p = it.first + r;
   const bool valid = r < it.count;
   const int w = it.w;
-  const double *WT = (ROOT ? S.Wroot : S.WT) + it.mat_off + r;   // the tile's panel: [k][r], rows ldm apart
+  const PT *WT = reinterpret_cast<const PT *>(ROOT ? S.Wroot : S.WT) + it.mat_off + r;   // the tile's panel: [k][r], rows ldm apart
   const int ldm = it.ld;
   const int *piv = S.piv_idx + it.piv_ptr;
   const int pos0 = it.pos_off;
@@ -1628,10 +1630,10 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
   for (int k0 = wv * cl; k0 < kend; k0 += NW * cl) {
     const int kn = min(cl, kend - k0);
     // first batch of this chunk's matrix entries: in flight while the input vector is gathered
-    const double *wp = WT + (size_t)k0 * ldm;
+    const PT *wp = WT + (size_t)k0 * ldm;
     double w0[HB];
     bool have0 = false;
-    if (PRE && valid) have0 = stream_first<D, KQ, NT, HB>(wp, ldm, kq, kn, w0);
+    if (PRE && valid) have0 = stream_first<D, KQ, NT, HB, PT>(wp, ldm, kq, kn, w0);
     for (int kk = lane; kk < kn; kk += 64) {
       const int k = k0 + kk;
       double v[D];
@@ -1652,8 +1654,8 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
     if (tr[2] == 0) SPD_T(2)
 #endif
     if (valid) {
-      if (!PRE) have0 = stream_first<D, KQ, NT, HB>(wp, ldm, kq, kn, w0);
-      stream_rest<D, KQ, NT, HB>(wp, ldm, kq, kn, fw, have0, w0, acc);
+      if (!PRE) have0 = stream_first<D, KQ, NT, HB, PT>(wp, ldm, kq, kn, w0);
+      stream_rest<D, KQ, NT, HB, PT>(wp, ldm, kq, kn, fw, have0, w0, acc);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -1708,7 +1710,7 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
   SPD_TRACE_FLUSH(wv == 0 && lane == 0)
 }
 
-template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool NT>
+template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool NT, typename PT = double>
 __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it, double scale, const double *ytmp,
                                              double *vec, double *fw, double *red, const int wv, const int lane,
                                              int trace_slot = 0, unsigned long long trace_t0 = 0) {
@@ -1720,7 +1722,7 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
   const int k = it.first + r;
   const bool valid = r < it.count;
   const int w = it.w, m = w + it.u;
-  const double *W = S.W + it.mat_off + r;     // the tile's panel: [p - first][r], rows ldw apart
+  const PT *W = reinterpret_cast<const PT *>(S.W) + it.mat_off + r;     // the tile's panel: [p - first][r], rows ldw apart
   const int ldw = it.ld;
   const int *piv = S.piv_idx + it.piv_ptr;
   const int *upd = S.upd_idx + it.upd_ptr;
@@ -1731,10 +1733,10 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
   const int cl = spd_chunk<NW, SPD_CH>(m - it.first);
   for (int p0 = it.first + wv * cl; p0 < m; p0 += NW * cl) {
     const int pn = min(cl, m - p0);
-    const double *wp = W + (size_t)(p0 - it.first) * ldw;
+    const PT *wp = W + (size_t)(p0 - it.first) * ldw;
     double w0[HB];
     bool have0 = false;
-    if (PRE && valid) have0 = stream_first<D, KQ, NT, HB>(wp, ldw, kq, pn, w0);
+    if (PRE && valid) have0 = stream_first<D, KQ, NT, HB, PT>(wp, ldw, kq, pn, w0);
     for (int pp = lane; pp < pn; pp += 64) {
       const int p = p0 + pp;
       // ancestors' entries were scaled when they were written: undo by linearity (scale is +-1)
@@ -1753,8 +1755,8 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
     if (tr[2] == 0) SPD_T(2)
 #endif
     if (valid) {
-      if (!PRE) have0 = stream_first<D, KQ, NT, HB>(wp, ldw, kq, pn, w0);
-      stream_rest<D, KQ, NT, HB>(wp, ldw, kq, pn, fw, have0, w0, acc);
+      if (!PRE) have0 = stream_first<D, KQ, NT, HB, PT>(wp, ldw, kq, pn, w0);
+      stream_rest<D, KQ, NT, HB, PT>(wp, ldw, kq, pn, fw, have0, w0, acc);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -1794,7 +1796,7 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
 // One level of a sweep in one launch.  A workgroup (8 waves) takes a PACK: either one tile of a wide front,
 // shared by the 8 waves (ROWS-row tiles), or up to 8 tiles of narrow fronts (reduction length <= 96), one
 // per wave.  Wide packs come first, longest first; the narrow ones fill the tail of the launch.
-template <int D, int DOF, int ROWS, int MODE, bool NT>   // MODE 0: forward level, 1: backward level, 2: the roots (fused)
+template <int D, int DOF, int ROWS, int MODE, bool NT, typename PT = double>   // MODE 0: forward level, 1: backward level, 2: the roots (fused); PT: panel storage
 __global__ __launch_bounds__(64 * SPD_NW(ROWS), ROWS == 64 ? SPD_WPE : 4) void k_spd_level(SpdDev S, NodeMask mask, SpdLevelMap M,
                                                                                       double scale, double *vec, double *ytmp) {
   constexpr int CH = 128, NW = SPD_NW(ROWS);
@@ -1821,15 +1823,15 @@ __global__ __launch_bounds__(64 * SPD_NW(ROWS), ROWS == 64 ? SPD_WPE : 4) void k
   if (!is_wide) {
     const int t = M.nstart[j] + r * NW + wv;
     const SpdItem it = load_item(items + t);
-    if constexpr (MODE == 0) spd_fwd_tile<D, DOF, 1, CH, 64, NT>(S, it, vec, ytmp, f[wv], red, 0, lane SPD_TRACE_ARGS(t));
-    else if constexpr (MODE == 1) spd_bwd_tile<D, DOF, 1, CH, 64, NT>(S, it, scale, ytmp, vec, f[wv], red, 0, lane SPD_TRACE_ARGS(t));
-    else spd_fwd_tile<D, DOF, 1, CH, 64, NT, true>(S, it, vec, nullptr, f[wv], red, 0, lane SPD_TRACE_ARGS(t), ytmp, scale);
+    if constexpr (MODE == 0) spd_fwd_tile<D, DOF, 1, CH, 64, NT, false, PT>(S, it, vec, ytmp, f[wv], red, 0, lane SPD_TRACE_ARGS(t));
+    else if constexpr (MODE == 1) spd_bwd_tile<D, DOF, 1, CH, 64, NT, PT>(S, it, scale, ytmp, vec, f[wv], red, 0, lane SPD_TRACE_ARGS(t));
+    else spd_fwd_tile<D, DOF, 1, CH, 64, NT, true, PT>(S, it, vec, nullptr, f[wv], red, 0, lane SPD_TRACE_ARGS(t), ytmp, scale);
   } else {
     const int t = M.wstart[j] + r;
     const SpdItem it = load_item(items + t);
-    if constexpr (MODE == 0) spd_fwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, vec, ytmp, f[wv], red, wv, lane SPD_TRACE_ARGS(t));
-    else if constexpr (MODE == 1) spd_bwd_tile<D, DOF, NW, CH, ROWS, NT>(S, it, scale, ytmp, vec, f[wv], red, wv, lane SPD_TRACE_ARGS(t));
-    else spd_fwd_tile<D, DOF, NW, CH, ROWS, NT, true>(S, it, vec, nullptr, f[wv], red, wv, lane SPD_TRACE_ARGS(t), ytmp, scale);
+    if constexpr (MODE == 0) spd_fwd_tile<D, DOF, NW, CH, ROWS, NT, false, PT>(S, it, vec, ytmp, f[wv], red, wv, lane SPD_TRACE_ARGS(t));
+    else if constexpr (MODE == 1) spd_bwd_tile<D, DOF, NW, CH, ROWS, NT, PT>(S, it, scale, ytmp, vec, f[wv], red, wv, lane SPD_TRACE_ARGS(t));
+    else spd_fwd_tile<D, DOF, NW, CH, ROWS, NT, true, PT>(S, it, vec, nullptr, f[wv], red, wv, lane SPD_TRACE_ARGS(t), ytmp, scale);
   }
 #undef SPD_TRACE_ARGS
 }
@@ -2227,6 +2229,13 @@ void launch_root_syrk(hipStream_t st, const RootDesc *rd, int nroots, int max_w,
   if (nroots > 0 && nt > 0) hipLaunchKernelGGL(k_root_syrk, dim3(nt, nt, nroots), dim3(256), 0, st, rd, src, dst);
 }
 
+__global__ __launch_bounds__(256) void k_to_f32(const double *src, float *dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = (float)src[i];
+}
+void launch_to_f32(hipStream_t st, const double *src, float *dst, size_t n) {
+  if (n) hipLaunchKernelGGL(k_to_f32, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65536)), dim3(256), 0, st, src, dst, n);
+}
+
 void launch_pack_panels(hipStream_t st, const SpdItem *items, const PanelSrc *srcs, int ntiles, const double *src, double *panels) {
   if (ntiles > 0) hipLaunchKernelGGL(k_pack_panels, dim3(ntiles), dim3(256), 0, st, items, srcs, src, panels);
 }
@@ -2242,14 +2251,24 @@ void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, int mode,
   const int npacks = M.wide_wgs + M.narrow_wgs;
   if (npacks == 0 || M.nlive == 0) return;
   ProfScope ps(mode == 1 ? PK_SPD_BWD : PK_SPD_FWD, st, level_bytes);
-#define SPD_LAUNCH2(DOFV, ROWSV, NTV)                                                                            \
+#define SPD_LAUNCH3(DOFV, ROWSV, NTV, PTV)                                                                       \
   do {                                                                                                         \
     if (mode == 0)                                                                                             \
-      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, 0, NTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, mask, M, scale, vec, ytmp);  \
+      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, 0, NTV, PTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, mask, M, scale, vec, ytmp);  \
     else if (mode == 1)                                                                                        \
-      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, 1, NTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, mask, M, scale, vec, ytmp); \
+      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, 1, NTV, PTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, mask, M, scale, vec, ytmp); \
     else                                                                                                       \
-      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, 2, NTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, mask, M, scale, vec, ytmp); \
+      hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, 2, NTV, PTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, mask, M, scale, vec, ytmp); \
+  } while (0)
+/* fp32 panels exist for the rotation factor only (the preconditioner experiment, SpdDev::f32) */
+#define SPD_LAUNCH2(DOFV, ROWSV, NTV)                                  \
+  do {                                                                 \
+    if constexpr (DOFV != 1) {                                         \
+      if (S.f32) SPD_LAUNCH3(DOFV, ROWSV, NTV, float);                 \
+      else SPD_LAUNCH3(DOFV, ROWSV, NTV, double);                      \
+    } else {                                                           \
+      SPD_LAUNCH3(DOFV, ROWSV, NTV, double);                           \
+    }                                                                  \
   } while (0)
 #define SPD_LAUNCH(DOFV, ROWSV)                \
   do {                                         \
@@ -2268,6 +2287,7 @@ void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, int mode,
 #undef SPD_PICK
 #undef SPD_LAUNCH
 #undef SPD_LAUNCH2
+#undef SPD_LAUNCH3
 }
 
 }  // namespace dpgo

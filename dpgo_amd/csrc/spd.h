@@ -67,7 +67,7 @@ struct SpdFactor {
 // Factor A (symmetric positive definite, full pattern in CSR).  leaf = max
 // vertices of a nested-dissection leaf.  Returns 0, or -1 if a pivot is not positive.
 // collapse = number of nested-dissection levels merged into one front (1 = plain binary tree,
-// 0 = choose 1..3 from a latency + bandwidth model of the device solve).
+// 0 = choose 1..5 from a latency + bandwidth model of the device solve).
 // block > 1: consecutive groups of `block` unknowns share their neighbours (the d rotation rows of a pose); the ordering
 // is computed on the quotient graph
 int spd_factor(const CsrMatrix &A, SpdFactor &F, int leaf = 32, int collapse = 0, int block = 1, bool keep_device = false);

@@ -881,3 +881,29 @@ np.save(sys.argv[1], drv.X())
     for tag, env in (("hostfactor", dict(DPGO_SPD_HOST_FACTOR="1")), ("hostpanels", dict(DPGO_SPD_DEVICE_PANELS="0")),
                      ("scalarorder", dict(DPGO_SPD_QUOTIENT="0"))):
         np.testing.assert_allclose(run(tag, **env), base, rtol=0, atol=1e-9, err_msg=tag)
+
+
+def test_fp32_preconditioner_experiment_reaches_the_same_objective(fixtures_dir, monkeypatch):
+    """DPGO_PRECON_FP32=1 (an opt-in EXPERIMENT, never the default, never the headline: DESIGN 7) stores the panels of the
+    preconditioner's factor in fp32.  A preconditioner only steers the truncated CG: the surrogate, the acceptance test of
+    every refined step and the objective stay fp64, so the run must reach the oracle's objective like the fp64 run does --
+    by a different path (the inner iteration counts may differ), which is why this is not the reference's arithmetic."""
+    name, nn, loss = "torus3D", 8, LOSS_HUBER
+    path = os.path.join(fixtures_dir, name + ".g2o")
+    num_poses, mm = og.read_g2o_file(path)
+    X0 = chordal_initialization(num_poses, mm)
+    orc = ODistPGO(path, nn, _oracle_opts(loss, True), X0=X0, mm=mm, num_poses=num_poses)
+    G = dpgo_amd.read_g2o(path, nn)
+    finals = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DPGO_PRECON_FP32", flag)
+        gpu = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(loss, True), X0=X0)
+        for _ in range(150):
+            assert gpu.step() == 0
+        finals[flag] = orc.star.evaluate_f(gpu.X())
+    monkeypatch.delenv("DPGO_PRECON_FP32")
+    for _ in range(150):
+        orc.step(evaluate=False)
+    Fo = orc.star.evaluate_f(orc.gather())
+    assert abs(finals["0"] - Fo) <= 1e-6 * abs(Fo)
+    assert abs(finals["1"] - Fo) <= 1e-6 * abs(Fo)
