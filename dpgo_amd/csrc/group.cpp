@@ -268,7 +268,9 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
       if (is_root(f)) roots.push_back(f);
     int t64 = 0;
     for (int f : roots) t64 += (F.w[f] + 63) / 64;
-    const int rows = t64 < env_int("DPGO_SPD_FINE_ROOT", 192) ? 16 : 64;   // few tiles: 16-row tiles reach 4x more CUs
+    // few tiles: 16-row tiles reach 4x more CUs; a single root per GPU (one node per GPU): 8-row tiles, 8x
+    const bool f32 = want_f32 && !F.keep_numeric;
+    const int rows = (t64 < env_int("DPGO_SPD_FINE_ROOT8", 64) && !f32) ? 8 : (t64 < env_int("DPGO_SPD_FINE_ROOT", 192) ? 16 : 64);
     root_level.rows = rows;
     std::vector<Tile> tiles;
     for (int a = 0; a < nnodes; a++) {
@@ -304,7 +306,7 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
     int64_t total = 0;
     for (size_t i = 0; i < tiles.size(); i++) {
       const Tile &t = tiles[i];
-      const int f = t.f, ld = (t.count + 15) / 16 * 16;
+      const int f = t.f, ld = rows == 8 ? 8 : (t.count + 15) / 16 * 16;   // (8-row tiles: a wave's load spans 8 consecutive 64-byte rows)
       SpdItem it;
       it.front = f; it.first = t.first; it.count = t.count; it.w = F.w[f];
       it.u = 0; it.ld = ld; it.piv_ptr = F.piv_ptr[f]; it.upd_ptr = F.upd_ptr[f];

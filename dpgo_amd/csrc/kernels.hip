@@ -2275,9 +2275,16 @@ void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, int mode,
     if (stream_once) SPD_LAUNCH2(DOFV, ROWSV, true); \
     else SPD_LAUNCH2(DOFV, ROWSV, false);      \
   } while (0)
+/* 8-row tiles exist for the fused roots only (a single root front per GPU: twice the workgroups on it), fp64 panels */
+#define SPD_ROOT8(DOFV, NTV) \
+  hipLaunchKernelGGL((k_spd_level<D, DOFV, 8, 2, NTV, double>), dim3(npacks), dim3(64 * SPD_NW(8)), 0, st, S, mask, M, scale, vec, ytmp)
 #define SPD_PICK(DOFV)                  \
   do {                                  \
-    if (rows == 16) SPD_LAUNCH(DOFV, 16); \
+    if (rows == 8) {                    \
+      if (mode != 2 || S.f32) { fprintf(stderr, "[dpgo_amd] ERROR: 8-row solve tiles are a root-level class.\n"); return; } \
+      if (stream_once) SPD_ROOT8(DOFV, true); \
+      else SPD_ROOT8(DOFV, false);      \
+    } else if (rows == 16) SPD_LAUNCH(DOFV, 16); \
     else SPD_LAUNCH(DOFV, 64);          \
   } while (0)
   DPGO_DISPATCH_D(d, {
@@ -2285,6 +2292,7 @@ void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, int mode,
     else SPD_PICK(D);
   });
 #undef SPD_PICK
+#undef SPD_ROOT8
 #undef SPD_LAUNCH
 #undef SPD_LAUNCH2
 #undef SPD_LAUNCH3
