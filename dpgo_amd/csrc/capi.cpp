@@ -413,7 +413,7 @@ int dpgo_prof_enable(int on) { dpgo::prof_enable(on != 0); if (on) dpgo::prof_re
 int dpgo_prof_num_kinds(void) { return dpgo::PK_COUNT; }
 const char *dpgo_prof_kind_name(int k) {
   static const char *names[] = {"k_bsr", "k_inter", "k_proximal", "k_axpby", "k_dot", "k_rot_op", "k_copy_indexed",
-                                "k_bdiag_dot", "k_reduce", "k_spd_fwd", "k_spd_bwd"};
+                                "k_bdiag_dot", "k_reduce", "k_spd_fwd", "k_spd_bwd", "k_spd_flow"};
   return (k >= 0 && k < dpgo::PK_COUNT) ? names[k] : "";
 }
 int dpgo_prof_collect(double *ms, double *bytes, long *count) { dpgo::prof_collect(ms, bytes, count); return 0; }

@@ -878,9 +878,25 @@ np.save(sys.argv[1], drv.X())
 
     base = run("base")
     assert np.array_equal(run("lag0", DPGO_CG_LAG="0"), base)
+    # the one-launch solve (an experiment that lost): the same tiles in the same order of operations
+    assert np.array_equal(run("flow", DPGO_SPD_FLOW="1"), base)
     for tag, env in (("hostfactor", dict(DPGO_SPD_HOST_FACTOR="1")), ("hostpanels", dict(DPGO_SPD_DEVICE_PANELS="0")),
-                     ("scalarorder", dict(DPGO_SPD_QUOTIENT="0"))):
+                     ("scalarorder", dict(DPGO_SPD_QUOTIENT="0")),
+                     # round 3: the refinement started by the host, the tree roots in two sweeps, G Y by a pass over the operator
+                     ("hoststart", dict(DPGO_TNT_DEVICE_START="0")), ("tworootsweeps", dict(DPGO_SPD_FUSE_ROOT="0")),
+                     ("gy_by_pass", dict(DPGO_GX_LINEAR="0"))):
         np.testing.assert_allclose(run(tag, **env), base, rtol=0, atol=1e-9, err_msg=tag)
+    # Rescale::Dynamic: the device path (decision, block-diagonal rebuild, refactorisation from device-resident values)
+    # against the host path (weights read back, nodes re-assembled, operators re-uploaded)
+    dyn = code.replace("Options.driver(1, True)", "Options.driver(1, True, rescale=1)")
+    assert dyn != code
+
+    def run_dyn(tag, **env):
+        path = str(tmp_path / (tag + ".npy"))
+        subprocess.check_call([sys.executable, "-c", dyn, path], env=dict(os.environ, **env))
+        return np.load(path)
+
+    np.testing.assert_allclose(run_dyn("dyn_host", DPGO_RESCALE_HOST="1"), run_dyn("dyn_dev"), rtol=0, atol=1e-9, err_msg="dynamic")
 
 
 def test_fp32_preconditioner_experiment_reaches_the_same_objective(fixtures_dir, monkeypatch):
