@@ -90,8 +90,13 @@ __device__ __forceinline__ double bcast(double v, int src) {
 
 // the factor and the inverse of the diagonal block [kb, kb + nb) of front f by ONE wave, a row of the block per lane,
 // in registers; lane j ends up with column j of X = L_kk^-1.  Returns false on a non-positive pivot.
+// What one lane needs from another -- the scaled column k in the elimination, row i of L in the inversion -- goes through
+// LDS (`Ls`, NB x (NB + 1) doubles of the wave's own): a lane publishes its entry once and everybody reads it with one
+// broadcast load that does not sit on the dependent chain of the fused multiply-adds.  (Until round 3 every such value
+// was two v_readlane per use, ~2 000 of them in series: 48 us per block column, which IS the factorisation's critical
+// path at the top of a tree; the arithmetic and its order are unchanged, so are the bits.)
 __device__ __forceinline__ bool potrf_inv_wave(const FrontDesc &f, const double *Fm, int kb, int nb, int lane, double (&X)[NB],
-                                               double &dmin, double &dmax) {
+                                               double &dmin, double &dmax, double (*Ls)[NB + 1]) {
   // row `lane` of the diagonal block (lanes >= nb and columns >= nb: the identity, which factors to itself)
   double L[NB];
   const double *A = Fm + f.fm_off + (long long)kb * f.m + kb;
@@ -110,9 +115,13 @@ __device__ __forceinline__ bool potrf_inv_wave(const FrontDesc &f, const double 
     }
     const double lkk = sqrt(dkk), inv = 1.0 / lkk;
     L[k] = lane == k ? lkk : L[k] * inv;           // column k: the pivot, and the rows below it scaled
+    if (lane < NB) Ls[lane][k] = L[k];             // L[lane][k], final
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int j = k + 1; j < NB; j++) {
-      const double ljk = bcast(L[k], j);           // L[j][k]
+      const double ljk = Ls[j][k];                 // L[j][k], the same address for every lane
       L[j] = lane >= j ? fma(-L[k], ljk, L[j]) : L[j];
     }
   }
@@ -122,8 +131,8 @@ __device__ __forceinline__ bool potrf_inv_wave(const FrontDesc &f, const double 
   for (int i = 0; i < NB; i++) {
     double sum = lane == i ? 1.0 : 0.0;
 #pragma unroll
-    for (int k = 0; k < i; k++) sum = fma(-bcast(L[k], i), X[k], sum);
-    X[i] = sum / bcast(L[i], i);
+    for (int k = 0; k < i; k++) sum = fma(-Ls[i][k], X[k], sum);
+    X[i] = sum / Ls[i][i];
   }
   return ok;
 }
@@ -144,8 +153,9 @@ __global__ __launch_bounds__(64) void k_fa_potrf_reg(const FrontDesc *fd, const 
   const FrontDesc f = fd[lvl[blockIdx.x]];
   if (f.w <= kb) return;
   const int nb = min(NB, f.w - kb), lane = threadIdx.x;
+  __shared__ double Ls[NB][NB + 1];
   double X[NB], dmin, dmax;
-  const bool ok = potrf_inv_wave(f, Fm, kb, nb, lane, X, dmin, dmax);
+  const bool ok = potrf_inv_wave(f, Fm, kb, nb, lane, X, dmin, dmax, Ls);
   double *D = dinv + (long long)f.slot * NB * NB;
   if (lane < NB) {
 #pragma unroll
@@ -170,12 +180,13 @@ __global__ __launch_bounds__(256) void k_fa_potrf_panel(const FrontDesc *fd, con
   const int nrows = (f.m - ke) + ke;
   if ((int)blockIdx.x * 256 >= nrows) return;
   __shared__ double D[NB][LDT];
+  __shared__ double Ls[FUSED ? NB : 1][NB + 1];
   __shared__ int bad;
   const int t = threadIdx.x;
   if constexpr (FUSED) {
     if (t < 64) {
       double X[NB], dmin, dmax;
-      const bool ok = potrf_inv_wave(f, Fm, kb, nb, t, X, dmin, dmax);
+      const bool ok = potrf_inv_wave(f, Fm, kb, nb, t, X, dmin, dmax, Ls);
       if (t < NB) {
 #pragma unroll
         for (int i = 0; i < NB; i++) D[i][t] = X[i];
@@ -353,6 +364,7 @@ struct SpdNumericCtx {
   double *d_aval = nullptr, *d_Fm = nullptr, *d_dinv = nullptr, *d_W = nullptr, *d_WT = nullptr;
   ExtendPair *d_pairs = nullptr;
   hipStream_t st = nullptr;
+  bool outputs_zeroed = false;
   ~SpdNumericCtx() {
     for (void *q : {(void *)d_fd, (void *)d_dst, (void *)d_src, (void *)d_cmap, (void *)d_lvl, (void *)d_fail, (void *)d_aval,
                     (void *)d_Fm, (void *)d_dinv, (void *)d_W, (void *)d_WT, (void *)d_pairs})
@@ -477,8 +489,13 @@ int SpdNumericCtx::factor(SpdFactor &F, const double *aval_host, double *flops_o
     FA_OK(hipStreamSynchronize(st));
   }
   FA_OK(hipMemsetAsync(d_Fm, 0, sizeof(double) * std::max<long long>(fm_total, 1), st));
-  FA_OK(hipMemsetAsync(d_W, 0, sizeof(double) * std::max<int64_t>(w_total, 1), st));
-  FA_OK(hipMemsetAsync(d_WT, 0, sizeof(double) * std::max<int64_t>(wt_total, 1), st));
+  if (!outputs_zeroed) {
+    // (what the kernels do not write -- the padding of a row, a zero triangle -- they never write: once is enough for a
+    // context that is used again, Rescale::Dynamic)
+    FA_OK(hipMemsetAsync(d_W, 0, sizeof(double) * std::max<int64_t>(w_total, 1), st));
+    FA_OK(hipMemsetAsync(d_WT, 0, sizeof(double) * std::max<int64_t>(wt_total, 1), st));
+    outputs_zeroed = true;
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (mfma_ms_out) { FA_OK(hipEventCreate(&e0)); FA_OK(hipEventCreate(&e1)); }
   double flops = 0, mfma_ms = 0;
