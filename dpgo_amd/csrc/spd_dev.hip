@@ -122,7 +122,8 @@ __device__ __forceinline__ bool potrf_inv_wave(const FrontDesc &f, const double 
 #pragma unroll
     for (int j = k + 1; j < NB; j++) {
       const double ljk = Ls[j][k];                 // L[j][k], the same address for every lane
-      L[j] = lane >= j ? fma(-L[k], ljk, L[j]) : L[j];
+      // (no select for the lanes above the diagonal: their entries are zeros that stay zeros and nobody reads them)
+      L[j] = fma(-L[k], ljk, L[j]);
     }
   }
   // X = L^-1, lane j its column j: X[i][j] = (delta_ij - sum_{k<i} L[i][k] X[k][j]) / L[i][i]  (zeros above the diagonal
