@@ -320,10 +320,17 @@ def main():
                 gathered.copy_(gathered_h)
                 grp.unpack_recv(gathered.data_ptr())
 
+    native_step = not (do_exchange and host_staged) and os.environ.get("DPGO_BENCH_PY_STEP") != "1"   # (A/B switch)
+
     def step():
-        rc = grp.iterate()
-        exchange()
-        rc |= grp.update()
+        if native_step:
+            # iterate -> exchange (the communicator's own stream) -> communicate -> update in one native call, as the
+            # C++ driver's loop does: no interpreter overhead between the launches
+            rc = grp.step(comm)
+        else:
+            rc = grp.iterate()
+            exchange()
+            rc |= grp.update()
         if rc != 0:
             raise SystemExit("step failed")
 

@@ -157,6 +157,7 @@ SYMBOLS = {
     "dpgo_group_update": (C.c_int, [C.c_void_p, _IP, C.c_int]),
     "dpgo_group_iterate": (C.c_int, [C.c_void_p, _IP, C.c_int]),
     "dpgo_group_communicate_local": (C.c_int, [C.c_void_p]),
+    "dpgo_group_step": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dpgo_group_message_sizes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _IP, _IP]),
     "dpgo_group_send": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _DP, C.c_int]),
     "dpgo_group_receive": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _DP, C.c_int]),
@@ -444,6 +445,11 @@ class NodeGroup:
     def communicate_local(self):
         return lib().dpgo_group_communicate_local(self._h)
 
+    def step(self, comm=None):
+        """iterate() of every node, the boundary exchange of `comm` (a Comm of this group) if any, communicate(), update():
+        the body of the driver's loop (dist_pgo.cpp:496-521) in one native call."""
+        return lib().dpgo_group_step(self._h, comm._h if comm is not None else None)
+
     def sync(self):
         return lib().dpgo_group_sync(self._h)
 
@@ -710,11 +716,7 @@ class DistPGO:
         self.group.update()
 
     def step(self):
-        g = self.group
-        rc = g.iterate()
-        rc |= g.communicate_local()
-        rc |= g.update()
-        return rc
+        return self.group.step()
 
     def X(self):
         X = np.zeros(((self.graph.d + 1) * self.graph.num_poses, self.graph.d), order="F")

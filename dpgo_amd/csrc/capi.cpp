@@ -281,6 +281,18 @@ int dpgo_group_iterate(dpgo_group_t *h, const int *locals, int n) {
   return guarded([&] { return h->grp->iterate(v); });
 }
 int dpgo_group_communicate_local(dpgo_group_t *h) { return guarded([&] { return h->grp->communicate_local(); }); }
+int dpgo_group_step(dpgo_group_t *h, struct dpgo_comm *comm) {
+  if (!h) return -1;
+  return guarded([&] {
+    std::vector<int> all(h->grp->num_local());
+    for (int a = 0; a < (int)all.size(); a++) all[a] = a;
+    int rc = h->grp->iterate(all);
+    if (rc != 0) return rc;
+    if (comm && comm->c && (rc = comm->c->exchange()) != 0) return rc;
+    if ((rc = h->grp->communicate_local()) != 0) return rc;
+    return h->grp->update(all);
+  });
+}
 int dpgo_group_set_collectives(dpgo_group_t *h, void *send_dev, void *gathered_dev, dpgo_allgather_fn ag, dpgo_allreduce_fn ar,
                                void *user) {
   return guarded([&] { return h->grp->set_collectives((double *)send_dev, (double *)gathered_dev, ag, ar, user); });

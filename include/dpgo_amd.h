@@ -153,6 +153,12 @@ int dpgo_group_update(dpgo_group_t *grp, const int *locals, int n);
 int dpgo_group_iterate(dpgo_group_t *grp, const int *locals, int n);
 /* DPGOHash::communicate -- C++/DPGO/include/DPGO/DPGOHash.h:28-86 -- for neighbours hosted by this group. */
 int dpgo_group_communicate_local(dpgo_group_t *grp);
+/* One pass of the driver's loop body -- C++/examples/dist_pgo.cpp:496-521: iterate() of every node of the group, the
+ * boundary exchange (`comm`: a communicator made by dpgo_comm_create for this group, or NULL when every neighbour is hosted
+ * here), communicate(), update() of every node -- in one call, so that a host in another language does not put its own
+ * call overhead between the launches. */
+struct dpgo_comm;
+int dpgo_group_step(dpgo_group_t *grp, struct dpgo_comm *comm);
 /* DPGOHash::receive -- C++/DPGO/src/DPGOHash.cpp:45-82: one message per neighbour node beta, a
  * ((d+1) |recv[beta]|) x d matrix [translation rows ; rotation rows] with the poses in the order of
  * recv[beta].  dpgo_group_send builds the message node `local` owes node beta (the poses of sent[beta],
