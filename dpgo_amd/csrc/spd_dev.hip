@@ -34,6 +34,7 @@ constexpr int NB = 32;    // block column
 constexpr int SB = 128;   // super-block: the update of its block columns reaches the rest of the front in one pass
 constexpr int TS = 64;    // MFMA tile: 64 x 64 per workgroup, 4 waves of 32 x 32 (2 x 2 instructions of 16 x 16 x 4)
 constexpr int LDT = NB + 1;
+constexpr int PIV_SLOTS = 64;   // the pivot range is collected in this many (min, max) pairs: 600 fronts on ONE address is 10 us of atomics
 
 struct FrontDesc {
   int w, u, m, slot;          // slot: index inside its level (scratch of the diagonal block inverse)
@@ -88,52 +89,76 @@ __device__ __forceinline__ double bcast(double v, int src) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// the factor and the inverse of the diagonal block [kb, kb + nb) of front f by ONE wave, a row of the block per lane,
-// in registers; lane j ends up with column j of X = L_kk^-1.  Returns false on a non-positive pivot.
-// What one lane needs from another -- the scaled column k in the elimination, row i of L in the inversion -- goes through
-// LDS (`Ls`, NB x (NB + 1) doubles of the wave's own): a lane publishes its entry once and everybody reads it with one
-// broadcast load that does not sit on the dependent chain of the fused multiply-adds.  (Until round 3 every such value
-// was two v_readlane per use, ~2 000 of them in series: 48 us per block column, which IS the factorisation's critical
-// path at the top of a tree; the arithmetic and its order are unchanged, so are the bits.)
-__device__ __forceinline__ bool potrf_inv_wave(const FrontDesc &f, const double *Fm, int kb, int nb, int lane, double (&X)[NB],
-                                               double &dmin, double &dmax, double (*Ls)[NB + 1]) {
-  // row `lane` of the diagonal block (lanes >= nb and columns >= nb: the identity, which factors to itself)
-  double L[NB];
+// The factor and the inverse of the diagonal block [kb, kb + nb) of front f by ONE wave, in registers and LDS.
+// Lane = (row r = lane & 31, half h = lane >> 5): half h holds the columns j of its row with j % 2 == h, so an elimination
+// step issues half the multiply-adds of a row-per-lane scheme (one wave is bound by the number of fp64 instructions it
+// issues, ~9 cycles each, not by their latency: tools/probes/potrf_probe.hip); what a lane needs from another -- the scaled
+// column k, row i of L -- goes through LDS (`Ls`, NB x (NB + 2) doubles of the wave's own), published once and read with
+// broadcast loads off the dependent chain; 1 / l_kk comes from v_rsq_f64 and two Newton steps (error of X against a
+// long-double inverse: 2.6e-16 of its largest entry, 1.8e-16 with sqrt and a division) and is kept for the inversion,
+// which splits its sums over the halves the same way.  On return lane (c, h) holds Xh[q] = X[2 q + h][c], X = L_kk^-1.
+// 11.5 us per launch against 30 us for the row-per-lane version of round 2 (48 us before its v_readlane broadcasts went).
+// Returns false on a non-positive pivot.
+__device__ __forceinline__ bool potrf_inv_wave(const FrontDesc &f, const double *Fm, int kb, int nb, int lane, double (&Xh)[NB / 2],
+                                               double &dmin, double &dmax, double (*Ls)[NB + 2]) {
+  const int r = lane & 31, h = lane >> 5;
+  // row r of the diagonal block (rows and columns >= nb: the identity, which factors to itself)
+  double L[NB / 2];
   const double *A = Fm + f.fm_off + (long long)kb * f.m + kb;
 #pragma unroll
-  for (int j = 0; j < NB; j++) L[j] = (lane < nb && j <= lane) ? A[(long long)lane * f.m + j] : ((lane == j) ? 1.0 : 0.0);
+  for (int q = 0; q < NB / 2; q++) {
+    const int j = 2 * q + h;
+    L[q] = (r < nb && j <= r) ? A[(long long)r * f.m + j] : ((r == j) ? 1.0 : 0.0);
+  }
   dmin = 1e300;
   dmax = 0.0;
   bool ok = true;
 #pragma unroll
   for (int k = 0; k < NB; k++) {
-    const double dkk = bcast(L[k], k);
+    // column k lives in half k & 1, register k >> 1; its diagonal entry in lane k + 32 (k & 1)
+    const double dkk = bcast(L[k >> 1], k + 32 * (k & 1));
     if (k < nb) {
       ok = ok && (dkk > 0.0);
       dmin = fmin(dmin, dkk);
       dmax = fmax(dmax, dkk);
     }
-    const double lkk = sqrt(dkk), inv = 1.0 / lkk;
-    L[k] = lane == k ? lkk : L[k] * inv;           // column k: the pivot, and the rows below it scaled
-    if (lane < NB) Ls[lane][k] = L[k];             // L[lane][k], final
+    double inv = __builtin_amdgcn_rsq(dkk);
+    inv = inv * fma(-0.5 * dkk * inv, inv, 1.5);
+    inv = inv * fma(-0.5 * dkk * inv, inv, 1.5);
+    const double lkk = dkk * inv;
+    if (h == (k & 1)) {
+      const double v = r == k ? lkk : L[k >> 1] * inv;   // column k: the pivot, and the rows below it scaled
+      L[k >> 1] = v;
+      Ls[r][k] = v;                                      // L[r][k], final
+      if (r == 0) Ls[k][NB] = inv;                       // 1 / L[k][k] for the inversion
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double lrk = Ls[r][k];   // this row's entry of column k (the other half holds it for every other k)
 #pragma unroll
-    for (int j = k + 1; j < NB; j++) {
-      const double ljk = Ls[j][k];                 // L[j][k], the same address for every lane
-      // (no select for the lanes above the diagonal: their entries are zeros that stay zeros and nobody reads them)
-      L[j] = fma(-L[k], ljk, L[j]);
+    for (int q = (k + 1) >> 1; q < NB / 2; q++) {
+      const int j = 2 * q + h;
+      // (no select for the entries above the diagonal: zeros that stay zeros, and nobody reads them)
+      if (j > k) L[q] = fma(-lrk, Ls[j][k], L[q]);
     }
   }
-  // X = L^-1, lane j its column j: X[i][j] = (delta_ij - sum_{k<i} L[i][k] X[k][j]) / L[i][i]  (zeros above the diagonal
-  // come out by themselves)
+  // X = L^-1, lane (c = r, h) its column c: X[i][c] = (delta_ic - sum_{k<i} L[i][k] X[k][c]) / L[i][i]; half h keeps X[k][c]
+  // for k % 2 == h and sums over those k, the halves meet in a swap (zeros above the diagonal come out by themselves)
+#pragma unroll
+  for (int q = 0; q < NB / 2; q++) Xh[q] = 0.0;
 #pragma unroll
   for (int i = 0; i < NB; i++) {
-    double sum = lane == i ? 1.0 : 0.0;
+    double sum = (r == i && h == 0) ? 1.0 : 0.0;
 #pragma unroll
-    for (int k = 0; k < i; k++) sum = fma(-Ls[i][k], X[k], sum);
-    X[i] = sum / Ls[i][i];
+    for (int q = 0; q < (i + 1) / 2; q++) {
+      const int k = 2 * q + h;
+      const double t = fma(-Ls[i][k], Xh[q], sum);
+      sum = k < i ? t : sum;
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const double x = sum * Ls[i][NB];
+    if ((i & 1) == h) Xh[i >> 1] = x;
   }
   return ok;
 }
@@ -154,19 +179,18 @@ __global__ __launch_bounds__(64) void k_fa_potrf_reg(const FrontDesc *fd, const 
   const FrontDesc f = fd[lvl[blockIdx.x]];
   if (f.w <= kb) return;
   const int nb = min(NB, f.w - kb), lane = threadIdx.x;
-  __shared__ double Ls[NB][NB + 1];
-  double X[NB], dmin, dmax;
-  const bool ok = potrf_inv_wave(f, Fm, kb, nb, lane, X, dmin, dmax, Ls);
+  __shared__ double Ls[NB][NB + 2];
+  double Xh[NB / 2], dmin, dmax;
+  const bool ok = potrf_inv_wave(f, Fm, kb, nb, lane, Xh, dmin, dmax, Ls);
   double *D = dinv + (long long)f.slot * NB * NB;
-  if (lane < NB) {
 #pragma unroll
-    for (int i = 0; i < NB; i++) D[i * NB + lane] = ok ? X[i] : 0.0;
-  }
+  for (int q = 0; q < NB / 2; q++) D[(2 * q + (lane >> 5)) * NB + (lane & 31)] = ok ? Xh[q] : 0.0;
   if (lane == 0) {
     if (!ok) atomicExch(fail, 1 + lvl[blockIdx.x]);
     else {
-      atomicMin(pivr, (unsigned long long)__double_as_longlong(dmin));
-      atomicMax(pivr + 1, (unsigned long long)__double_as_longlong(dmax));
+      unsigned long long *pr = pivr + 2 * (blockIdx.x % PIV_SLOTS);
+      atomicMin(pr, (unsigned long long)__double_as_longlong(dmin));
+      atomicMax(pr + 1, (unsigned long long)__double_as_longlong(dmax));
     }
   }
 }
@@ -181,24 +205,24 @@ __global__ __launch_bounds__(256) void k_fa_potrf_panel(const FrontDesc *fd, con
   const int nrows = (f.m - ke) + ke;
   if ((int)blockIdx.x * 256 >= nrows) return;
   __shared__ double D[NB][LDT];
-  __shared__ double Ls[FUSED ? NB : 1][NB + 1];
+  __shared__ double T[4][NB][NB + 1];   // a wave's 32 rows of the strip
+  __shared__ double Ls[FUSED ? NB : 1][NB + 2];
   __shared__ int bad;
   const int t = threadIdx.x;
   if constexpr (FUSED) {
     if (t < 64) {
-      double X[NB], dmin, dmax;
-      const bool ok = potrf_inv_wave(f, Fm, kb, nb, t, X, dmin, dmax, Ls);
-      if (t < NB) {
+      double Xh[NB / 2], dmin, dmax;
+      const bool ok = potrf_inv_wave(f, Fm, kb, nb, t, Xh, dmin, dmax, Ls);
 #pragma unroll
-        for (int i = 0; i < NB; i++) D[i][t] = X[i];
-      }
+      for (int q = 0; q < NB / 2; q++) D[2 * q + (t >> 5)][t & 31] = Xh[q];
       if (t == 0) {
         bad = !ok;
         if (blockIdx.x == 0) {
           if (!ok) atomicExch(fail, 1 + lvl[blockIdx.y]);
           else {
-            atomicMin(pivr, (unsigned long long)__double_as_longlong(dmin));
-            atomicMax(pivr + 1, (unsigned long long)__double_as_longlong(dmax));
+            unsigned long long *pr = pivr + 2 * (blockIdx.y % PIV_SLOTS);
+            atomicMin(pr, (unsigned long long)__double_as_longlong(dmin));
+            atomicMax(pr + 1, (unsigned long long)__double_as_longlong(dmax));
           }
         }
       }
@@ -210,20 +234,64 @@ __global__ __launch_bounds__(256) void k_fa_potrf_panel(const FrontDesc *fd, con
   }
   __syncthreads();
   if (bad) return;
-  const int q = blockIdx.x * 256 + t;
-  if (q >= nrows) return;
-  const int i = ke + q;   // rows ke .. m + ke - 1 are contiguous in the front matrix
-  double *row = Fm + f.fm_off + (long long)i * f.m + kb;
-  double x[NB];
+  // The rows times the transposed inverse: X <- X D^T, a wave taking 64 rows in two passes of 32.  A row of the strip is
+  // 256 contiguous bytes and the rows are a front's width apart, so the strip moves through LDS: loads and stores with
+  // half a wave per row (two whole rows per instruction, against 64 rows x 8 bytes for a row per lane), the product on the
+  // matrix cores -- 32 v_mfma_f64_16x16x4 per pass, A = the rows, B = D (lower triangular, its zeros included).
+  const int wv = t >> 6, lane = t & 63;
+  double (*Tw)[NB + 1] = T[wv];
+  double *Fb = Fm + f.fm_off + kb;
+#define WAVE_SYNC()                                              \
+  do {                                                           \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       \
+    __builtin_amdgcn_wave_barrier();                             \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
+  } while (0)
+  for (int half = 0; half < 2; half++) {
+    const int q0 = blockIdx.x * 256 + wv * 64 + half * 32;   // rows ke + q0 .. (regular rows, then the identity rows in play)
+    if (q0 >= nrows) break;
+    const int rr0 = lane >> 5, c = lane & 31;
 #pragma unroll
-  for (int k = 0; k < NB; k++) x[k] = k < nb ? row[k] : 0.0;
+    for (int p = 0; p < 16; p++) {
+      const int rr = 2 * p + rr0, q = q0 + rr;
+      Tw[rr][c] = (q < nrows && c < nb) ? Fb[(long long)(ke + q) * f.m + c] : 0.0;
+    }
+    WAVE_SYNC();
+    v4d acc[2][2];
 #pragma unroll
-  for (int c = 0; c < NB; c++) {
-    double s = 0;
+    for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int k = 0; k < NB; k++) s = (k <= c) ? fma(x[k], D[c][k], s) : s;
-    if (c < nb) row[c] = s;
+      for (int b = 0; b < 2; b++) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < NB; kk += 4) {
+      const int kq = kk + (lane >> 4), r16 = lane & 15;
+      double av[2], bv[2];
+#pragma unroll
+      for (int a = 0; a < 2; a++) av[a] = Tw[a * 16 + r16][kq];
+#pragma unroll
+      for (int b = 0; b < 2; b++) bv[b] = D[b * 16 + r16][kq];
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+    WAVE_SYNC();
+    // C/D lay-out of v_mfma_f64_16x16x4_f64: register r of lane l = C[(l >> 4) + 4 r][l & 15]
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) Tw[a * 16 + (lane >> 4) + 4 * r][b * 16 + (lane & 15)] = acc[a][b][r];
+    WAVE_SYNC();
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+      const int rr = 2 * p + rr0, q = q0 + rr;
+      if (q < nrows && c < nb) Fb[(long long)(ke + q) * f.m + c] = Tw[rr][c];
+    }
+    WAVE_SYNC();
   }
+#undef WAVE_SYNC
 }
 
 // C[I, J] -= A[I, K] B[J, K]^T on 64 x 64 tiles with v_mfma_f64_16x16x4_f64.
@@ -463,7 +531,7 @@ int SpdNumericCtx::build(const CsrMatrix &A, const SpdFactor &F, const std::vect
   FA_OK(hipMalloc((void **)&d_src, sizeof(int) * std::max<size_t>(src.size(), 1)));
   FA_OK(hipMalloc((void **)&d_cmap, sizeof(int) * cmap.size()));
   FA_OK(hipMalloc((void **)&d_lvl, sizeof(int) * std::max<size_t>(lvl_flat.size(), 1)));
-  FA_OK(hipMalloc((void **)&d_fail, 24));   // int fail; then two 64-bit words: smallest / largest pivot
+  FA_OK(hipMalloc((void **)&d_fail, 8 + 16 * PIV_SLOTS));   // int fail; then PIV_SLOTS pairs of 64-bit words: smallest / largest pivot
   FA_OK(hipMalloc((void **)&d_aval, sizeof(double) * std::max<size_t>(n_aval, 1)));
   FA_OK(hipMalloc((void **)&d_Fm, sizeof(double) * std::max<long long>(fm_total, 1)));
   FA_OK(hipMalloc((void **)&d_dinv, sizeof(double) * max_lvl * NB * NB));
@@ -485,8 +553,10 @@ int SpdNumericCtx::build(const CsrMatrix &A, const SpdFactor &F, const std::vect
 int SpdNumericCtx::factor(SpdFactor &F, const double *aval_host, double *flops_out, double *mfma_ms_out) {
   if (aval_host && n_aval) FA_OK(hipMemcpyAsync(d_aval, aval_host, sizeof(double) * n_aval, hipMemcpyHostToDevice, st));
   {
-    unsigned long long init[3] = {0ull, 0x7ff0000000000000ull, 0ull};
-    FA_OK(hipMemcpyAsync(d_fail, init, 24, hipMemcpyHostToDevice, st));
+    unsigned long long init[1 + 2 * PIV_SLOTS];
+    init[0] = 0ull;
+    for (int q = 0; q < PIV_SLOTS; q++) { init[1 + 2 * q] = 0x7ff0000000000000ull; init[2 + 2 * q] = 0ull; }
+    FA_OK(hipMemcpyAsync(d_fail, init, sizeof(init), hipMemcpyHostToDevice, st));
     FA_OK(hipStreamSynchronize(st));
   }
   FA_OK(hipMemsetAsync(d_Fm, 0, sizeof(double) * std::max<long long>(fm_total, 1), st));
@@ -577,14 +647,19 @@ int SpdNumericCtx::factor(SpdFactor &F, const double *aval_host, double *flops_o
   }
   }
   int fail = 0;
-  unsigned long long back[3] = {0, 0, 0};
-  FA_OK(hipMemcpyAsync(back, d_fail, 24, hipMemcpyDeviceToHost, st));
+  unsigned long long back[1 + 2 * PIV_SLOTS] = {0};
+  FA_OK(hipMemcpyAsync(back, d_fail, sizeof(back), hipMemcpyDeviceToHost, st));
   FA_OK(hipStreamSynchronize(st));
   fail = (int)(back[0] & 0xffffffffull);
   {
-    double lo, hi;
-    memcpy(&lo, &back[1], 8);
-    memcpy(&hi, &back[2], 8);
+    double lo = 1e300, hi = 0.0;
+    for (int q = 0; q < PIV_SLOTS; q++) {
+      double a, b;
+      memcpy(&a, &back[1 + 2 * q], 8);
+      memcpy(&b, &back[2 + 2 * q], 8);
+      lo = std::min(lo, a);   // (an unused slot still holds +inf / 0)
+      hi = std::max(hi, b);
+    }
     F.pivot_min = lo;
     F.pivot_max = hi;
   }

@@ -465,6 +465,26 @@ def test_runs_are_bit_reproducible(fixtures_dir):
     assert np.array_equal(outs[0], outs[1])
 
 
+def test_native_step_equals_the_three_calls(fixtures_dir):
+    """dpgo_group_step (the loop body of dist_pgo.cpp:496-521 in one call) is iterate + communicate + update: the same
+    launches in the same order, so the same bits."""
+    path = os.path.join(fixtures_dir, "torus3D.g2o")
+    num_poses, mm = og.read_g2o_file(path)
+    X0 = chordal_initialization(num_poses, mm)
+    outs = []
+    for native in (True, False):
+        G = dpgo_amd.read_g2o(path, 8)
+        drv = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(LOSS_HUBER, True), X0=X0)
+        for _ in range(12):
+            if native:
+                assert drv.step() == 0
+            else:
+                g = drv.group
+                assert g.iterate() == 0 and g.communicate_local() == 0 and g.update() == 0
+        outs.append(drv.X().copy())
+    assert np.array_equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("kw", [
     dict(max_iterations_accepted=3, max_iterations=12),          # several accepted TNT steps: the model is rebuilt
     dict(preconditioner=0),                                      # Preconditioner::None (identity)
