@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -99,16 +100,16 @@ __device__ __forceinline__ double bcast(double v, int src) {
 // which splits its sums over the halves the same way.  On return lane (c, h) holds Xh[q] = X[2 q + h][c], X = L_kk^-1.
 // 11.5 us per launch against 30 us for the row-per-lane version of round 2 (48 us before its v_readlane broadcasts went).
 // Returns false on a non-positive pivot.
-__device__ __forceinline__ bool potrf_inv_wave(const FrontDesc &f, const double *Fm, int kb, int nb, int lane, double (&Xh)[NB / 2],
+// A, lda: the block (global memory, or the copy a left-looking panel kernel has just updated in LDS).
+__device__ __forceinline__ bool potrf_inv_wave(const double *A, long long lda, int nb, int lane, double (&Xh)[NB / 2],
                                                double &dmin, double &dmax, double (*Ls)[NB + 2]) {
   const int r = lane & 31, h = lane >> 5;
   // row r of the diagonal block (rows and columns >= nb: the identity, which factors to itself)
   double L[NB / 2];
-  const double *A = Fm + f.fm_off + (long long)kb * f.m + kb;
 #pragma unroll
   for (int q = 0; q < NB / 2; q++) {
     const int j = 2 * q + h;
-    L[q] = (r < nb && j <= r) ? A[(long long)r * f.m + j] : ((r == j) ? 1.0 : 0.0);
+    L[q] = (r < nb && j <= r) ? A[(long long)r * lda + j] : ((r == j) ? 1.0 : 0.0);
   }
   dmin = 1e300;
   dmax = 0.0;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(64) void k_fa_potrf_reg(const FrontDesc *fd, const 
   const int nb = min(NB, f.w - kb), lane = threadIdx.x;
   __shared__ double Ls[NB][NB + 2];
   double Xh[NB / 2], dmin, dmax;
-  const bool ok = potrf_inv_wave(f, Fm, kb, nb, lane, Xh, dmin, dmax, Ls);
+  const bool ok = potrf_inv_wave(Fm + f.fm_off + (long long)kb * f.m + kb, f.m, nb, lane, Xh, dmin, dmax, Ls);
   double *D = dinv + (long long)f.slot * NB * NB;
 #pragma unroll
   for (int q = 0; q < NB / 2; q++) D[(2 * q + (lane >> 5)) * NB + (lane & 31)] = ok ? Xh[q] : 0.0;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void k_fa_potrf_panel(const FrontDesc *fd, con
   if constexpr (FUSED) {
     if (t < 64) {
       double Xh[NB / 2], dmin, dmax;
-      const bool ok = potrf_inv_wave(f, Fm, kb, nb, t, Xh, dmin, dmax, Ls);
+      const bool ok = potrf_inv_wave(Fm + f.fm_off + (long long)kb * f.m + kb, f.m, nb, t, Xh, dmin, dmax, Ls);
 #pragma unroll
       for (int q = 0; q < NB / 2; q++) D[2 * q + (t >> 5)][t & 31] = Xh[q];
       if (t == 0) {
@@ -294,6 +295,188 @@ __global__ __launch_bounds__(256) void k_fa_potrf_panel(const FrontDesc *fd, con
 #undef WAVE_SYNC
 }
 
+// One block column, LEFT-LOOKING inside its super-block (levels with few fronts, where a launch is what costs): the
+// updates the block columns [sb, kb) of the super-block owe the strip [kb, ke) are applied here, to the rows this
+// workgroup holds and -- by every workgroup of the front again -- to the diagonal block, which is then factored and
+// inverted (potrf_inv_wave) and multiplied into the rows.  The right-looking scheme above needs a launch of k_fa_abt per
+// block column for the same updates (K = 32 each, 17-30 us at the top of a tree); here they ride in the launch that was
+// there anyway, and the rest of the front gets the super-block's update in one wide pass (K = 128) as before.
+//   rows of a workgroup: 128 (four waves x 32), of [ke, m + ke): the regular rows below the block and the identity rows.
+//   Bs: rows kb.. of the panels [sb, kb) (32 x K, K <= 96); Dg: the diagonal block, then its inverse; T / U: a wave's
+//   32 x 32 tile of the strip / of a panel.
+__global__ __launch_bounds__(256) void k_fa_panel_ll(const FrontDesc *fd, const int *lvl, int sb, int kb, double *Fm, int *fail,
+                                                     unsigned long long *pivr) {
+  const FrontDesc f = fd[lvl[blockIdx.y]];
+  if (f.w <= kb) return;
+  const int nb = min(NB, f.w - kb), ke = kb + nb, K = kb - sb;
+  const int nrows = f.m;   // rows [ke, m + ke)
+  if ((int)blockIdx.x * 128 >= nrows) return;
+  __shared__ double Bs[NB][SB - NB + 1];
+  __shared__ double Dg[NB][LDT];
+  __shared__ double Ls[NB][NB + 2];
+  __shared__ double T[4][NB][NB + 1];
+  __shared__ double U[4][NB][NB + 1];
+  __shared__ int bad;
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
+  double *F = Fm + f.fm_off;
+#define WAVE_SYNC()                                              \
+  do {                                                           \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       \
+    __builtin_amdgcn_wave_barrier();                             \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
+  } while (0)
+  {
+    // (every load issued before the first is waited for: a loop with a run-time trip count takes a memory latency per trip,
+    // 18 us at K = 96)
+    const int r = t >> 3, l8 = t & 7;   // eight threads per row, 64 contiguous bytes per row and step
+    const double *src = F + (long long)(kb + r) * f.m + sb;
+    double bq[(SB - NB) / 8], dq[NB / 8];
+#pragma unroll
+    for (int j = 0; j < (SB - NB) / 8; j++) bq[j] = (r < nb && j * 8 + l8 < K) ? src[j * 8 + l8] : 0.0;
+#pragma unroll
+    for (int j = 0; j < NB / 8; j++) {
+      const int c = j * 8 + l8;
+      dq[j] = (r < nb && c < nb) ? src[K + c] : (r == c ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int j = 0; j < (SB - NB) / 8; j++) Bs[r][j * 8 + l8] = bq[j];
+#pragma unroll
+    for (int j = 0; j < NB / 8; j++) Dg[r][j * 8 + l8] = dq[j];
+  }
+  __syncthreads();
+  const int kq4 = lane >> 4, r16 = lane & 15;
+  if (wv == 0) {
+    if (K > 0) {   // the diagonal block's share of the updates: Dg -= Bs Bs^T
+      v4d acc[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+      for (int kk = 0; kk < K; kk += 4) {
+        double av[2];
+#pragma unroll
+        for (int a = 0; a < 2; a++) av[a] = Bs[a * 16 + r16][kk + kq4];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], av[b], acc[a][b], 0, 0, 0);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) Dg[a * 16 + kq4 + 4 * r][b * 16 + r16] -= acc[a][b][r];
+      WAVE_SYNC();
+    }
+    double Xh[NB / 2], dmin, dmax;
+    const bool ok = potrf_inv_wave(&Dg[0][0], LDT, nb, lane, Xh, dmin, dmax, Ls);
+    WAVE_SYNC();   // (every lane has read its row of Dg: the inverse may take its place)
+#pragma unroll
+    for (int q = 0; q < NB / 2; q++) Dg[2 * q + (lane >> 5)][lane & 31] = Xh[q];
+    if (lane == 0) {
+      bad = !ok;
+      if (blockIdx.x == 0) {
+        if (!ok) atomicExch(fail, 1 + lvl[blockIdx.y]);
+        else {
+          unsigned long long *pr = pivr + 2 * (blockIdx.y % PIV_SLOTS);
+          atomicMin(pr, (unsigned long long)__double_as_longlong(dmin));
+          atomicMax(pr + 1, (unsigned long long)__double_as_longlong(dmax));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (bad) return;
+  const int q0 = blockIdx.x * 128 + wv * 32;
+  if (q0 >= nrows) return;
+  double (*Tw)[NB + 1] = T[wv];
+  double (*Uw)[NB + 1] = U[wv];
+  const int rr0 = lane >> 5, c = lane & 31;
+  // the strip's tile, two whole rows per load
+#pragma unroll
+  for (int p = 0; p < 16; p++) {
+    const int rr = 2 * p + rr0, q = q0 + rr;
+    Tw[rr][c] = (q < nrows && c < nb) ? F[(long long)(ke + q) * f.m + kb + c] : 0.0;
+  }
+  v4d acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+  // the rows' own entries of the panels [sb, kb), 32 columns at a time: all of them requested up front
+  double ua[(SB - NB) / NB][16];
+#pragma unroll
+  for (int ch = 0; ch < (SB - NB) / NB; ch++)
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+      const int rr = 2 * p + rr0, q = q0 + rr;
+      ua[ch][p] = (ch * NB < K && q < nrows) ? F[(long long)(ke + q) * f.m + sb + ch * NB + c] : 0.0;
+    }
+#pragma unroll
+  for (int ch = 0; ch < (SB - NB) / NB; ch++) {
+    const int kc = ch * NB;
+    if (kc >= K) break;
+#pragma unroll
+    for (int p = 0; p < 16; p++) Uw[2 * p + rr0][c] = ua[ch][p];
+    WAVE_SYNC();
+#pragma unroll
+    for (int kk = 0; kk < NB; kk += 4) {
+      double av[2], bv[2];
+#pragma unroll
+      for (int a = 0; a < 2; a++) av[a] = Uw[a * 16 + r16][kk + kq4];
+#pragma unroll
+      for (int b = 0; b < 2; b++) bv[b] = Bs[b * 16 + r16][kc + kk + kq4];
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+    WAVE_SYNC();
+  }
+  WAVE_SYNC();
+  if (K > 0) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) Tw[a * 16 + kq4 + 4 * r][b * 16 + r16] -= acc[a][b][r];
+    WAVE_SYNC();
+  }
+  // times the transposed inverse
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < NB; kk += 4) {
+    double av[2], bv[2];
+#pragma unroll
+    for (int a = 0; a < 2; a++) av[a] = Tw[a * 16 + r16][kk + kq4];
+#pragma unroll
+    for (int b = 0; b < 2; b++) bv[b] = Dg[b * 16 + r16][kk + kq4];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+  }
+  WAVE_SYNC();
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) Tw[a * 16 + kq4 + 4 * r][b * 16 + r16] = acc[a][b][r];
+  WAVE_SYNC();
+#pragma unroll
+  for (int p = 0; p < 16; p++) {
+    const int rr = 2 * p + rr0, q = q0 + rr;
+    if (q < nrows && c < nb) F[(long long)(ke + q) * f.m + kb + c] = Tw[rr][c];
+  }
+#undef WAVE_SYNC
+}
+
 // C[I, J] -= A[I, K] B[J, K]^T on 64 x 64 tiles with v_mfma_f64_16x16x4_f64.
 //  MODE 0 (trailing update of block column kb): A = B = the panel F[:, kb:ke]; rows I over [ke, m + ke), columns J
 //         over [ke, m); an element (i, j) is touched iff (i < m and j <= i) or (i >= m and j < w).
@@ -311,7 +494,7 @@ __global__ __launch_bounds__(256) void k_fa_abt(const FrontDesc *fd, const int *
   int r0, c0, nrt, nct, kbeg, kend, cend = 0;
   if (MODE == 0) {
     if (f.w <= k_lo) return;
-    if (wide && f.w <= sb_end) return;
+    if (wide == 1 && f.w <= sb_end) return;   // (wide == 2, behind left-looking block columns: every front with pivots here)
     const int ke = min(k_hi, f.w);
     c0 = ke;
     cend = (wide || sb_end >= f.w) ? f.m : sb_end;
@@ -604,12 +787,21 @@ int SpdNumericCtx::factor(SpdFactor &F, const double *aval_host, double *flops_o
       }
       return 0;
     };
+    static const bool ll_enabled = getenv("DPGO_SPD_LEFT_LOOKING") ? atoi(getenv("DPGO_SPD_LEFT_LOOKING")) != 0 : true;
+    const bool left_looking = ll_enabled && (long long)((max_m + 255) / 256) * nf <= 768;
     for (int sb = 0; sb < max_w; sb += SB) {
       const int se = sb + SB;
       for (int kb = sb; kb < std::min(se, max_w); kb += NB) {
         // few workgroups in the launch: every one factors the diagonal block itself (one launch); many: one wave per
         // front does it first (the workgroups of the panel would idle three waves of four meanwhile)
         const int bx = (max_m + 255) / 256;
+        if (left_looking) {
+          // few workgroups in the level: the block column takes the super-block's pending updates itself (no k_fa_abt
+          // per block column); the rest of the front gets them in the wide pass below
+          hipLaunchKernelGGL(k_fa_panel_ll, dim3((max_m + 127) / 128, nf), dim3(256), 0, st, d_fd, L, sb, kb, d_Fm, d_fail,
+                             reinterpret_cast<unsigned long long *>(d_fail) + 1);
+          continue;
+        }
         if ((long long)bx * nf <= 768) {
           hipLaunchKernelGGL((k_fa_potrf_panel<true>), dim3(bx, nf), dim3(256), 0, st, d_fd, L, kb, d_Fm, d_dinv, d_fail,
                              reinterpret_cast<unsigned long long *>(d_fail) + 1);
@@ -621,7 +813,8 @@ int SpdNumericCtx::factor(SpdFactor &F, const double *aval_host, double *flops_o
         }
         if (abt0(kb, kb + NB, se, 0) != 0) return -1;      // the rest of the super-block (of the front, if it ends here), K = 32
       }
-      if (se < max_w && abt0(sb, se, se, 1) != 0) return -1;   // everything right of the super-block, K = 128
+      if (left_looking) { if (abt0(sb, se, se, 2) != 0) return -1; }   // ... of every front with pivots in the super-block
+      else if (se < max_w && abt0(sb, se, se, 1) != 0) return -1;   // everything right of the super-block, K = 128
     }
     // the products the MFMA kernel carries for this level (useful flops: lower triangle of the trailing update)
     for (int f : lvl[h]) {
@@ -629,6 +822,14 @@ int SpdNumericCtx::factor(SpdFactor &F, const double *aval_host, double *flops_o
       flops += w * w * w / 3.0 + u * w * w + u * u * w      // trailing updates of regular rows (2 flops per multiply-add, half by symmetry)
                + w * w * w / 3.0                              // identity rows
                + 2.0 * u * w * w / 2.0;                       // W_bottom (triangular operand)
+      if (left_looking) {
+        // ... less what the left-looking block columns carry themselves (k_fa_panel_ll: the strip's updates from the
+        // block columns of its super-block; not in the time of the tile kernel either)
+        for (int kb = 0; kb < fd[f].w; kb += NB) {
+          const double nbk = std::min(NB, fd[f].w - kb), K = kb % SB;
+          flops -= 2.0 * K * nbk * fd[f].m;   // rows [kb, m) and the identity rows [m, m + ke): ~m of them, K x nb products each
+        }
+      }
     }
     hipLaunchKernelGGL(k_fa_wtop, dim3(std::max(max_w, 1), nf), dim3(256), 0, st, d_fd, L, d_Fm, d_W, d_WT);
     if (max_u > 0) {
