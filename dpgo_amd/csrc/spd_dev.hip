@@ -9,9 +9,13 @@
 // Level by level (fronts of one tree height are independent, one launch serves them all):
 //   1. assemble   F_s <- entries of A (k_fa_scatter) + the children's Schur complements (k_fa_extend; one launch per
 //                 child slot, so two children never add to the same entry at once: deterministic, no atomics)
-//   2. eliminate  right-looking in block columns of 32: k_fa_potrf_panel factors the 32 x 32 diagonal block in registers,
-//                 inverts it and scales the rows below (a row times a 32 x 32 triangle) in one launch, k_fa_abt subtracts
-//                 the rank-32 update P_I P_J^T from the trailing tiles with v_mfma_f64_16x16x4_f64.
+//   2. eliminate  in block columns of 32.  Levels with thousands of fronts (the leaves), right-looking: k_fa_potrf_reg factors
+//                 and inverts the 32 x 32 diagonal block (one wave per front), k_fa_potrf_panel scales the rows below
+//                 (through LDS, on the matrix cores), k_fa_abt subtracts the rank-32 update P_I P_J^T from the rest of the
+//                 128-wide super-block with v_mfma_f64_16x16x4_f64, and once per super-block from everything right of it
+//                 (K = 128).  Levels with few fronts (the top of a tree: a launch is what costs), left-looking inside the
+//                 super-block: k_fa_panel_ll applies the earlier block columns' updates to the strip itself, factors,
+//                 inverts and scales in ONE launch per block column; k_fa_abt only runs the wide pass.
 //      Each front carries w extra rows holding the identity: after the elimination they hold L11^-T (the same
 //      row operations that turn F21 into L21 = F21 L11^-T), so the triangular inverse costs no kernel of its own.
 //   3. finish     W_bottom = -L21 (L11^-T)^T is the same "A B^T" tile product (k_fa_abt, K = w) written straight into
