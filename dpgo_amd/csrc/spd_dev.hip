@@ -308,8 +308,10 @@ __global__ __launch_bounds__(256) void k_fa_potrf_panel(const FrontDesc *fd, con
 //   rows of a workgroup: 128 (four waves x 32), of [ke, m + ke): the regular rows below the block and the identity rows.
 //   Bs: rows kb.. of the panels [sb, kb) (32 x K, K <= 96); Dg: the diagonal block, then its inverse; T / U: a wave's
 //   32 x 32 tile of the strip / of a panel.
-__global__ __launch_bounds__(256) void k_fa_panel_ll(const FrontDesc *fd, const int *lvl, int sb, int kb, double *Fm, int *fail,
+__global__ __launch_bounds__(320) void k_fa_panel_ll(const FrontDesc *fd, const int *lvl, int sb, int kb, double *Fm, int *fail,
                                                      unsigned long long *pivr) {
+  // five waves: four take 32 rows each, the fifth the diagonal block -- its 11 us run beside the rows' loads and updates,
+  // not in front of them
   const FrontDesc f = fd[lvl[blockIdx.y]];
   if (f.w <= kb) return;
   const int nb = min(NB, f.w - kb), ke = kb + nb, K = kb - sb;
@@ -329,33 +331,49 @@ __global__ __launch_bounds__(256) void k_fa_panel_ll(const FrontDesc *fd, const 
     __builtin_amdgcn_wave_barrier();                             \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
   } while (0)
-  {
-    // (every load issued before the first is waited for: a loop with a run-time trip count takes a memory latency per trip,
-    // 18 us at K = 96)
-    const int r = t >> 3, l8 = t & 7;   // eight threads per row, 64 contiguous bytes per row and step
+  const int kq4 = lane >> 4, r16 = lane & 15;
+  const int q0 = blockIdx.x * 128 + wv * 32;
+  const bool rows_on = wv < 4 && q0 < nrows;
+  const int rr0 = lane >> 5, c = lane & 31;
+  // every load of the launch is requested before the first is waited for (a loop with a run-time trip count takes a
+  // memory latency per trip): the 32 rows kb.. of the panels [sb, kb) and the diagonal block, eight threads per row; the
+  // wave's tile of the strip and its rows' own entries of the panels, two whole rows per load
+  double bq[(SB - NB) / 8], dq[NB / 8], tq[16], ua[(SB - NB) / NB][16];
+  if (wv < 4) {
+    const int r = t >> 3, l8 = t & 7;
     const double *src = F + (long long)(kb + r) * f.m + sb;
-    double bq[(SB - NB) / 8], dq[NB / 8];
 #pragma unroll
     for (int j = 0; j < (SB - NB) / 8; j++) bq[j] = (r < nb && j * 8 + l8 < K) ? src[j * 8 + l8] : 0.0;
 #pragma unroll
     for (int j = 0; j < NB / 8; j++) {
-      const int c = j * 8 + l8;
-      dq[j] = (r < nb && c < nb) ? src[K + c] : (r == c ? 1.0 : 0.0);
+      const int cc = j * 8 + l8;
+      dq[j] = (r < nb && cc < nb) ? src[K + cc] : (r == cc ? 1.0 : 0.0);
     }
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+      const int q = q0 + 2 * p + rr0;
+      tq[p] = (rows_on && q < nrows && c < nb) ? F[(long long)(ke + q) * f.m + kb + c] : 0.0;
+    }
+#pragma unroll
+    for (int ch = 0; ch < (SB - NB) / NB; ch++)
+#pragma unroll
+      for (int p = 0; p < 16; p++) {
+        const int q = q0 + 2 * p + rr0;
+        ua[ch][p] = (rows_on && ch * NB < K && q < nrows) ? F[(long long)(ke + q) * f.m + sb + ch * NB + c] : 0.0;
+      }
 #pragma unroll
     for (int j = 0; j < (SB - NB) / 8; j++) Bs[r][j * 8 + l8] = bq[j];
 #pragma unroll
     for (int j = 0; j < NB / 8; j++) Dg[r][j * 8 + l8] = dq[j];
   }
   __syncthreads();
-  const int kq4 = lane >> 4, r16 = lane & 15;
-  if (wv == 0) {
+  v4d acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+  if (wv == 4) {
     if (K > 0) {   // the diagonal block's share of the updates: Dg -= Bs Bs^T
-      v4d acc[2][2];
-#pragma unroll
-      for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
       for (int kk = 0; kk < K; kk += 4) {
         double av[2];
 #pragma unroll
@@ -389,65 +407,45 @@ __global__ __launch_bounds__(256) void k_fa_panel_ll(const FrontDesc *fd, const 
         }
       }
     }
-  }
-  __syncthreads();
-  if (bad) return;
-  const int q0 = blockIdx.x * 128 + wv * 32;
-  if (q0 >= nrows) return;
-  double (*Tw)[NB + 1] = T[wv];
-  double (*Uw)[NB + 1] = U[wv];
-  const int rr0 = lane >> 5, c = lane & 31;
-  // the strip's tile, two whole rows per load
+  } else if (rows_on) {
+    double (*Tw)[NB + 1] = T[wv];
+    double (*Uw)[NB + 1] = U[wv];
 #pragma unroll
-  for (int p = 0; p < 16; p++) {
-    const int rr = 2 * p + rr0, q = q0 + rr;
-    Tw[rr][c] = (q < nrows && c < nb) ? F[(long long)(ke + q) * f.m + kb + c] : 0.0;
-  }
-  v4d acc[2][2];
+    for (int p = 0; p < 16; p++) Tw[2 * p + rr0][c] = tq[p];
 #pragma unroll
-  for (int a = 0; a < 2; a++)
+    for (int ch = 0; ch < (SB - NB) / NB; ch++) {
+      const int kc = ch * NB;
+      if (kc >= K) break;
 #pragma unroll
-    for (int b = 0; b < 2; b++) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
-  // the rows' own entries of the panels [sb, kb), 32 columns at a time: all of them requested up front
-  double ua[(SB - NB) / NB][16];
+      for (int p = 0; p < 16; p++) Uw[2 * p + rr0][c] = ua[ch][p];
+      WAVE_SYNC();
 #pragma unroll
-  for (int ch = 0; ch < (SB - NB) / NB; ch++)
+      for (int kk = 0; kk < NB; kk += 4) {
+        double av[2], bv[2];
 #pragma unroll
-    for (int p = 0; p < 16; p++) {
-      const int rr = 2 * p + rr0, q = q0 + rr;
-      ua[ch][p] = (ch * NB < K && q < nrows) ? F[(long long)(ke + q) * f.m + sb + ch * NB + c] : 0.0;
+        for (int a = 0; a < 2; a++) av[a] = Uw[a * 16 + r16][kk + kq4];
+#pragma unroll
+        for (int b = 0; b < 2; b++) bv[b] = Bs[b * 16 + r16][kc + kk + kq4];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+      }
+      WAVE_SYNC();
     }
-#pragma unroll
-  for (int ch = 0; ch < (SB - NB) / NB; ch++) {
-    const int kc = ch * NB;
-    if (kc >= K) break;
-#pragma unroll
-    for (int p = 0; p < 16; p++) Uw[2 * p + rr0][c] = ua[ch][p];
     WAVE_SYNC();
-#pragma unroll
-    for (int kk = 0; kk < NB; kk += 4) {
-      double av[2], bv[2];
-#pragma unroll
-      for (int a = 0; a < 2; a++) av[a] = Uw[a * 16 + r16][kk + kq4];
-#pragma unroll
-      for (int b = 0; b < 2; b++) bv[b] = Bs[b * 16 + r16][kc + kk + kq4];
+    if (K > 0) {
 #pragma unroll
       for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) Tw[a * 16 + kq4 + 4 * r][b * 16 + r16] -= acc[a][b][r];
     }
-    WAVE_SYNC();
   }
-  WAVE_SYNC();
-  if (K > 0) {
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int b = 0; b < 2; b++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) Tw[a * 16 + kq4 + 4 * r][b * 16 + r16] -= acc[a][b][r];
-    WAVE_SYNC();
-  }
+  __syncthreads();   // the inverse of the diagonal block is in Dg; the strips carry their updates
+  if (bad || !rows_on) return;
+  double (*Tw)[NB + 1] = T[wv];
   // times the transposed inverse
 #pragma unroll
   for (int a = 0; a < 2; a++)
@@ -802,7 +800,7 @@ int SpdNumericCtx::factor(SpdFactor &F, const double *aval_host, double *flops_o
         if (left_looking) {
           // few workgroups in the level: the block column takes the super-block's pending updates itself (no k_fa_abt
           // per block column); the rest of the front gets them in the wide pass below
-          hipLaunchKernelGGL(k_fa_panel_ll, dim3((max_m + 127) / 128, nf), dim3(256), 0, st, d_fd, L, sb, kb, d_Fm, d_fail,
+          hipLaunchKernelGGL(k_fa_panel_ll, dim3((max_m + 127) / 128, nf), dim3(320), 0, st, d_fd, L, sb, kb, d_Fm, d_fail,
                              reinterpret_cast<unsigned long long *>(d_fail) + 1);
           continue;
         }
