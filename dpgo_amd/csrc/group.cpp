@@ -936,6 +936,13 @@ void Group::upload_bsr(const std::vector<const BsrMatrix *> &per_node, bool rows
 void Group::sync() const {
   if (xchg_done_) HIP_CHECK(hipEventSynchronize(xchg_done_));   // an exchange on the communicator's stream
   HIP_CHECK(hipStreamSynchronize(st_));
+  check_tt_verdict(false);
+}
+
+void Group::check_tt_verdict(bool wait) const {
+  if (!tt_verdict_pending_) return;
+  tt_verdict_pending_ = false;
+  if (spd_refactor_finish(const_cast<SpdFactor &>(Ltt_.F), wait) != 0) throw DeviceError("G_tt is not positive definite after a rescale");
 }
 
 // The nodes the following launches work on: a bit mask passed to every kernel by value (no upload).
@@ -983,6 +990,7 @@ void Group::wait_flag(unsigned long long seq) {
       throw DeviceError("read-back flag never arrived");
     }
   }
+  if (tt_verdict_pending_ && seq >= tt_verdict_seq_) check_tt_verdict(false);   // (the stream has passed the factorisation)
 }
 
 void Group::copy_rows(double *dst, const double *src, bool all_rows, int part) {
@@ -1719,13 +1727,15 @@ std::vector<int> Group::rescale_device(const std::vector<int> &set) {
   A.att_val = spd_numeric_values(Ltt_.F);
   A.xi = opt_.regularizer;
   launch_rescale_apply(d_, st_, T_, E_, A);
-  HIP_CHECK(hipStreamSynchronize(st_));   // the factorisation runs on a stream of its own
-  clk.lap("rescale: block-diagonal terms (device)");
-  if (spd_refactor_device(Ltt_.F) != 0) throw DeviceError("G_tt is not positive definite after a rescale");
-  clk.lap("rescale: numeric factorisation of G_tt (device)");
+  // everything on the group's stream, enqueued in one go: the new values, the factorisation, the panels (three waits
+  // before, with the GPU idle across each)
+  if (spd_refactor_device(Ltt_.F, (void *)st_, true) != 0) throw DeviceError("G_tt: refactorisation could not be enqueued");
   if (Ltt_.repack(st_) != 0) throw DeviceError("repack");
-  if (clk.on) HIP_CHECK(hipStreamSynchronize(st_));
-  clk.lap("rescale: panels");
+  // the verdict is read at the next read-back that was enqueued behind the factorisation: nothing waits for it here
+  tt_verdict_pending_ = true;
+  tt_verdict_seq_ = fetch_seq_ + 1;
+  if (clk.on) sync();
+  clk.lap("rescale: block-diagonal terms, numeric factorisation of G_tt, panels (device)");
   return changed;
 }
 

@@ -287,6 +287,11 @@ class Group {
   NodeMask cur_mask_ = ALL_NODES;  // the nodes the launches work on (set_mask), passed to the kernels by value
   double *h_scal_ = nullptr;       // pinned, written by k_reduce; the flag (one cache line further) follows the scalars
   unsigned long long *h_flag_ = nullptr, fetch_seq_ = 0;
+  // a refactorisation of G_tt whose verdict (positive definite or not) has not been read yet: it is read at the first
+  // wait for a read-back that was enqueued behind it (sequence number >= tt_verdict_seq_), or at sync()
+  mutable bool tt_verdict_pending_ = false;
+  unsigned long long tt_verdict_seq_ = 0;
+  void check_tt_verdict(bool wait) const;
   double *h_cg_ = nullptr, *h_tnt_ = nullptr;   // pinned summaries of k_cg_scal / k_tnt_begin (same allocation as h_scal_)
   bool zc_ready_ = false;       // iterate() wrote Xk's own rows into the buffer the next update() rotates into X[iter]
   bool tnt_speculate_ = true;   // run_tnt: take the trial point behind the first CG step without waiting for its outcome

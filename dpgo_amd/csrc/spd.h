@@ -81,7 +81,11 @@ int spd_refactor(const CsrMatrix &A, SpdFactor &F);
 // With keep_numeric: the device copy of A's values (CSR order of the matrix that was factored), the numeric phase from
 // them, and the release of the kept state (a factor that owns one must not be copied)
 double *spd_numeric_values(SpdFactor &F);
-int spd_refactor_device(SpdFactor &F);
+// stream (a hipStream_t, nullptr: the factorisation's own): where the kernels run; defer: return as soon as they are
+// enqueued -- the caller queues what depends on the new factor behind them on the same stream and calls
+// spd_refactor_finish, which waits and returns -1 on a non-positive pivot
+int spd_refactor_device(SpdFactor &F, void *stream = nullptr, bool defer = false);
+int spd_refactor_finish(SpdFactor &F, bool wait = true);   // wait = false: the stream is known to have passed the factorisation
 void spd_release_numeric(SpdFactor &F);
 
 // Host solve (setup paths and tests): X (n x ncols, row-major) <- A^-1 X.

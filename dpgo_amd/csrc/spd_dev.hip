@@ -624,9 +624,16 @@ struct SpdNumericCtx {
                     (void *)d_Fm, (void *)d_dinv, (void *)d_W, (void *)d_WT, (void *)d_pairs})
       if (q) (void)hipFree(q);
     if (st) (void)hipStreamDestroy(st);
+    if (h_io) (void)hipHostFree(h_io);
   }
   int build(const CsrMatrix &A, const SpdFactor &F, const std::vector<std::vector<int>> &children);
-  int factor(SpdFactor &F, const double *aval_host, double *flops_out, double *mfma_ms_out);
+  // on: the stream to run on (nullptr: the context's own); defer: return once everything is enqueued -- finish() waits
+  // and reads the verdict (a caller that has more to enqueue behind the factorisation, Rescale::Dynamic)
+  int factor(SpdFactor &F, const double *aval_host, double *flops_out, double *mfma_ms_out, hipStream_t on = nullptr, bool defer = false);
+  int finish(SpdFactor &F, bool wait = true);   // wait = false: the caller knows the stream has passed the read-back
+  unsigned long long *h_io = nullptr;   // pinned: the start values of d_fail, and its read-back
+  hipStream_t pending_on = nullptr;
+  bool pending = false;
 };
 
 int SpdNumericCtx::build(const CsrMatrix &A, const SpdFactor &F, const std::vector<std::vector<int>> &children) {
@@ -735,15 +742,22 @@ int SpdNumericCtx::build(const CsrMatrix &A, const SpdFactor &F, const std::vect
 }
 
 // aval_host: the values of A in CSR order (nullptr: they are already in d_aval).  Leaves W / WT in d_W / d_WT.
-int SpdNumericCtx::factor(SpdFactor &F, const double *aval_host, double *flops_out, double *mfma_ms_out) {
-  if (aval_host && n_aval) FA_OK(hipMemcpyAsync(d_aval, aval_host, sizeof(double) * n_aval, hipMemcpyHostToDevice, st));
-  {
-    unsigned long long init[1 + 2 * PIV_SLOTS];
-    init[0] = 0ull;
-    for (int q = 0; q < PIV_SLOTS; q++) { init[1 + 2 * q] = 0x7ff0000000000000ull; init[2 + 2 * q] = 0ull; }
-    FA_OK(hipMemcpyAsync(d_fail, init, sizeof(init), hipMemcpyHostToDevice, st));
-    FA_OK(hipStreamSynchronize(st));
+int SpdNumericCtx::factor(SpdFactor &F, const double *aval_host, double *flops_out, double *mfma_ms_out, hipStream_t on, bool defer) {
+  if (pending && finish(F) != 0) return -1;
+  // (everything below is written against `st`: for the length of this call it names the stream to run on)
+  struct Swap {
+    hipStream_t &ref, keep;
+    Swap(hipStream_t &r, hipStream_t v) : ref(r), keep(r) { if (v) ref = v; }
+    ~Swap() { ref = keep; }
+  } swap(st, on);
+  constexpr int NIO = 1 + 2 * PIV_SLOTS;
+  if (!h_io) {
+    FA_OK(hipHostMalloc((void **)&h_io, sizeof(unsigned long long) * 2 * NIO, hipHostMallocDefault));
+    h_io[0] = 0ull;
+    for (int q = 0; q < PIV_SLOTS; q++) { h_io[1 + 2 * q] = 0x7ff0000000000000ull; h_io[2 + 2 * q] = 0ull; }
   }
+  if (aval_host && n_aval) FA_OK(hipMemcpyAsync(d_aval, aval_host, sizeof(double) * n_aval, hipMemcpyHostToDevice, st));
+  FA_OK(hipMemcpyAsync(d_fail, h_io, sizeof(unsigned long long) * NIO, hipMemcpyHostToDevice, st));   // (pinned, kept: no wait)
   FA_OK(hipMemsetAsync(d_Fm, 0, sizeof(double) * std::max<long long>(fm_total, 1), st));
   if (!outputs_zeroed) {
     // (what the kernels do not write -- the padding of a row, a zero triangle -- they never write: once is enough for a
@@ -849,11 +863,35 @@ int SpdNumericCtx::factor(SpdFactor &F, const double *aval_host, double *flops_o
     }
   }
   }
-  int fail = 0;
-  unsigned long long back[1 + 2 * PIV_SLOTS] = {0};
-  FA_OK(hipMemcpyAsync(back, d_fail, sizeof(back), hipMemcpyDeviceToHost, st));
-  FA_OK(hipStreamSynchronize(st));
-  fail = (int)(back[0] & 0xffffffffull);
+  FA_OK(hipMemcpyAsync(h_io + NIO, d_fail, sizeof(unsigned long long) * NIO, hipMemcpyDeviceToHost, st));
+  pending = true;
+  pending_on = st;
+  if (defer && !mfma_ms_out) {
+    if (flops_out) *flops_out = flops;
+    return 0;
+  }
+  if (finish(F) != 0) return -1;
+  for (auto &ev : evs) {
+    float t = 0;
+    (void)hipEventElapsedTime(&t, ev.first, ev.second);
+    mfma_ms += t;
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+  if (flops_out) *flops_out = flops;
+  if (mfma_ms_out) *mfma_ms_out = mfma_ms;
+  return 0;
+}
+
+// waits for the factorisation enqueued by factor(..., defer) and reads its verdict: 0, or -1 on a non-positive pivot
+int SpdNumericCtx::finish(SpdFactor &F, bool wait) {
+  if (!pending) return 0;
+  pending = false;
+  constexpr int NIO = 1 + 2 * PIV_SLOTS;
+  if (wait) FA_OK(hipStreamSynchronize(pending_on));
+  const unsigned long long *back = h_io + NIO;
+  const int fail = (int)(back[0] & 0xffffffffull);
   {
     double lo = 1e300, hi = 0.0;
     for (int q = 0; q < PIV_SLOTS; q++) {
@@ -871,16 +909,6 @@ int SpdNumericCtx::factor(SpdFactor &F, const double *aval_host, double *flops_o
     fprintf(stderr, "[dpgo_amd] ERROR: spd_factor (device): non-positive pivot in front %d\n", fail - 1);
     return -1;
   }
-  for (auto &ev : evs) {
-    float t = 0;
-    (void)hipEventElapsedTime(&t, ev.first, ev.second);
-    mfma_ms += t;
-    (void)hipEventDestroy(ev.first);
-    (void)hipEventDestroy(ev.second);
-  }
-  if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
-  if (flops_out) *flops_out = flops;
-  if (mfma_ms_out) *mfma_ms_out = mfma_ms;
   return 0;
 }
 
@@ -932,14 +960,15 @@ int spd_factor_numeric_device(const CsrMatrix &A, SpdFactor &F, const std::vecto
 double *spd_numeric_values(SpdFactor &F) { return F.numeric ? F.numeric->d_aval : nullptr; }
 
 // the numeric phase again, from the values in spd_numeric_values(F); dev_W / dev_WT (borrowed) hold the new factor
-int spd_refactor_device(SpdFactor &F) {
+int spd_refactor_device(SpdFactor &F, void *stream, bool defer) {
   if (!F.numeric) return -1;
-  if (F.numeric->factor(F, nullptr, nullptr, nullptr) != 0) return -1;
+  if (F.numeric->factor(F, nullptr, nullptr, nullptr, (hipStream_t)stream, defer) != 0) return -1;
   F.dev_W = F.numeric->d_W;
   F.dev_WT = F.numeric->d_WT;
   F.dev_borrowed = true;
   return 0;
 }
+int spd_refactor_finish(SpdFactor &F, bool wait) { return F.numeric ? F.numeric->finish(F, wait) : -1; }
 
 void spd_release_numeric(SpdFactor &F) {
   if (F.dev_borrowed) { F.dev_W = F.dev_WT = nullptr; F.dev_borrowed = false; }
