@@ -201,8 +201,8 @@ __global__ __launch_bounds__(64) void k_fa_potrf_reg(const FrontDesc *fd, const 
 }
 
 template <bool FUSED>
-__global__ __launch_bounds__(256) void k_fa_potrf_panel(const FrontDesc *fd, const int *lvl, int kb, double *Fm, const double *dinv,
-                                                        int *fail, unsigned long long *pivr) {
+__global__ __launch_bounds__(FUSED ? 320 : 256) void k_fa_potrf_panel(const FrontDesc *fd, const int *lvl, int kb, double *Fm, const double *dinv,
+                                                                      int *fail, unsigned long long *pivr) {
   const FrontDesc f = fd[lvl[blockIdx.y]];
   if (f.w <= kb) return;
   const int nb = min(NB, f.w - kb), ke = kb + nb;
@@ -213,14 +213,35 @@ __global__ __launch_bounds__(256) void k_fa_potrf_panel(const FrontDesc *fd, con
   __shared__ double T[4][NB][NB + 1];   // a wave's 32 rows of the strip
   __shared__ double Ls[FUSED ? NB : 1][NB + 2];
   __shared__ int bad;
-  const int t = threadIdx.x;
-  if constexpr (FUSED) {
-    if (t < 64) {
-      double Xh[NB / 2], dmin, dmax;
-      const bool ok = potrf_inv_wave(Fm + f.fm_off + (long long)kb * f.m + kb, f.m, nb, t, Xh, dmin, dmax, Ls);
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
+  // The rows times the transposed inverse: X <- X D^T, a wave taking 64 rows in two passes of 32.  A row of the strip is
+  // 256 contiguous bytes and the rows are a front's width apart, so the strip moves through LDS: loads and stores with
+  // half a wave per row (two whole rows per instruction, against 64 rows x 8 bytes for a row per lane), the product on the
+  // matrix cores -- 32 v_mfma_f64_16x16x4 per pass, A = the rows, B = D (lower triangular, its zeros included).
+  // FUSED: a fifth wave factors and inverts the diagonal block meanwhile (every workgroup of the front its own copy: the
+  // 11 us run beside the first pass's loads instead of in a launch of their own).
+  // (which of the five waves factors: not the same one in every workgroup -- a wave's number picks its SIMD, and three
+  // workgroups of a CU would queue their 11 us on one SIMD)
+  const int pw = FUSED ? 1 + (int)((blockIdx.x + blockIdx.y) % 4) : -1;
+  const int rw = (FUSED && wv > pw) ? wv - 1 : wv;   // the wave's number among the four that take rows
+  double (*Tw)[NB + 1] = T[rw & 3];
+  double *Fb = Fm + f.fm_off + kb;
+  const int rr0 = lane >> 5, c = lane & 31;
+  auto load_pass = [&](int q0) {
 #pragma unroll
-      for (int q = 0; q < NB / 2; q++) D[2 * q + (t >> 5)][t & 31] = Xh[q];
-      if (t == 0) {
+    for (int p = 0; p < 16; p++) {
+      const int rr = 2 * p + rr0, q = q0 + rr;
+      Tw[rr][c] = (q < nrows && c < nb) ? Fb[(long long)(ke + q) * f.m + c] : 0.0;
+    }
+  };
+  const int qw = blockIdx.x * 256 + (rw & 3) * 64;   // this wave's first row (q); its passes: qw, qw + 32
+  if constexpr (FUSED) {
+    if (wv == pw) {
+      double Xh[NB / 2], dmin, dmax;
+      const bool ok = potrf_inv_wave(Fm + f.fm_off + (long long)kb * f.m + kb, f.m, nb, lane, Xh, dmin, dmax, Ls);
+#pragma unroll
+      for (int q = 0; q < NB / 2; q++) D[2 * q + (lane >> 5)][lane & 31] = Xh[q];
+      if (lane == 0) {
         bad = !ok;
         if (blockIdx.x == 0) {
           if (!ok) atomicExch(fail, 1 + lvl[blockIdx.y]);
@@ -231,6 +252,8 @@ __global__ __launch_bounds__(256) void k_fa_potrf_panel(const FrontDesc *fd, con
           }
         }
       }
+    } else if (qw < nrows) {
+      load_pass(qw);
     }
   } else {
     const double *Dg = dinv + (long long)f.slot * NB * NB;
@@ -238,14 +261,7 @@ __global__ __launch_bounds__(256) void k_fa_potrf_panel(const FrontDesc *fd, con
     if (t == 0) bad = 0;   // (a failed front holds zeros: its rows are zeroed, the failure is already reported)
   }
   __syncthreads();
-  if (bad) return;
-  // The rows times the transposed inverse: X <- X D^T, a wave taking 64 rows in two passes of 32.  A row of the strip is
-  // 256 contiguous bytes and the rows are a front's width apart, so the strip moves through LDS: loads and stores with
-  // half a wave per row (two whole rows per instruction, against 64 rows x 8 bytes for a row per lane), the product on the
-  // matrix cores -- 32 v_mfma_f64_16x16x4 per pass, A = the rows, B = D (lower triangular, its zeros included).
-  const int wv = t >> 6, lane = t & 63;
-  double (*Tw)[NB + 1] = T[wv];
-  double *Fb = Fm + f.fm_off + kb;
+  if (bad || wv == pw) return;
 #define WAVE_SYNC()                                              \
   do {                                                           \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       \
@@ -253,14 +269,9 @@ __global__ __launch_bounds__(256) void k_fa_potrf_panel(const FrontDesc *fd, con
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
   } while (0)
   for (int half = 0; half < 2; half++) {
-    const int q0 = blockIdx.x * 256 + wv * 64 + half * 32;   // rows ke + q0 .. (regular rows, then the identity rows in play)
+    const int q0 = qw + half * 32;   // rows ke + q0 .. (regular rows, then the identity rows in play)
     if (q0 >= nrows) break;
-    const int rr0 = lane >> 5, c = lane & 31;
-#pragma unroll
-    for (int p = 0; p < 16; p++) {
-      const int rr = 2 * p + rr0, q = q0 + rr;
-      Tw[rr][c] = (q < nrows && c < nb) ? Fb[(long long)(ke + q) * f.m + c] : 0.0;
-    }
+    if (!(FUSED && half == 0)) load_pass(q0);
     WAVE_SYNC();
     v4d acc[2][2];
 #pragma unroll
@@ -804,6 +815,11 @@ int SpdNumericCtx::factor(SpdFactor &F, const double *aval_host, double *flops_o
       return 0;
     };
     static const bool ll_enabled = getenv("DPGO_SPD_LEFT_LOOKING") ? atoi(getenv("DPGO_SPD_LEFT_LOOKING")) != 0 : true;
+    // right-looking levels: up to this many workgroups factor the diagonal block themselves, beside their rows' loads (one
+    // launch per block column instead of two); beyond, one wave per front does it first (measured on the leaf level of the
+    // headline's G_tt, 1 256 workgroups: 63-110 us fused against 22 + 39 us in two launches -- three workgroups per CU
+    // each bring a factoring wave)
+    static const long long fuse_limit = getenv("DPGO_SPD_FUSE_POTRF_WGS") ? atoll(getenv("DPGO_SPD_FUSE_POTRF_WGS")) : 768;
     const bool left_looking = ll_enabled && (long long)((max_m + 255) / 256) * nf <= 768;
     for (int sb = 0; sb < max_w; sb += SB) {
       const int se = sb + SB;
@@ -818,8 +834,8 @@ int SpdNumericCtx::factor(SpdFactor &F, const double *aval_host, double *flops_o
                              reinterpret_cast<unsigned long long *>(d_fail) + 1);
           continue;
         }
-        if ((long long)bx * nf <= 768) {
-          hipLaunchKernelGGL((k_fa_potrf_panel<true>), dim3(bx, nf), dim3(256), 0, st, d_fd, L, kb, d_Fm, d_dinv, d_fail,
+        if ((long long)bx * nf <= fuse_limit) {
+          hipLaunchKernelGGL((k_fa_potrf_panel<true>), dim3(bx, nf), dim3(320), 0, st, d_fd, L, kb, d_Fm, d_dinv, d_fail,
                              reinterpret_cast<unsigned long long *>(d_fail) + 1);
         } else {
           hipLaunchKernelGGL(k_fa_potrf_reg, dim3(nf), dim3(64), 0, st, d_fd, L, kb, d_Fm, d_dinv, d_fail,
