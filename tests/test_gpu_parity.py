@@ -906,7 +906,9 @@ np.save(sys.argv[1], drv.X())
                      ("hoststart", dict(DPGO_TNT_DEVICE_START="0")), ("tworootsweeps", dict(DPGO_SPD_FUSE_ROOT="0")),
                      ("gy_by_pass", dict(DPGO_GX_LINEAR="0")),
                      # the factorisation's block columns right-looking at every level (another order of the same updates)
-                     ("rightlooking", dict(DPGO_SPD_LEFT_LOOKING="0"))):
+                     ("rightlooking", dict(DPGO_SPD_LEFT_LOOKING="0")),
+                     # ... with the diagonal blocks in a launch of their own (the path of levels with thousands of fronts)
+                     ("rightlooking_unfused", dict(DPGO_SPD_LEFT_LOOKING="0", DPGO_SPD_FUSE_POTRF_WGS="0"))):
         np.testing.assert_allclose(run(tag, **env), base, rtol=0, atol=1e-9, err_msg=tag)
     # Rescale::Dynamic: the device path (decision, block-diagonal rebuild, refactorisation from device-resident values)
     # against the host path (weights read back, nodes re-assembled, operators re-uploaded)
