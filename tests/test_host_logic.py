@@ -254,3 +254,21 @@ def test_chordal_initialization_does_not_depend_on_the_thread_count(fixtures_dir
         subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, DPGO_HOST_THREADS=nt))
         outs.append(np.load(path))
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_documented_switches_exist_in_the_sources():
+    """Every DPGO_* environment switch DESIGN.md names is read somewhere in the library, the driver, bench.py or the
+    tools (a table that outlives its switches misleads whoever tunes next)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "DESIGN.md")).read()
+    names = set(re.findall(r"`(DPGO_[A-Z0-9_]+)", doc))
+    assert len(names) > 20
+    src = ""
+    for pat in ("dpgo_amd/**/*", "tools/**/*", "tests/*.py", "bench.py"):
+        for f in glob.glob(os.path.join(root, pat), recursive=True):
+            if f.endswith((".cpp", ".h", ".hpp", ".hip", ".py", ".sh")):
+                src += open(f, errors="ignore").read()
+    missing = sorted(n for n in names if n not in src)
+    assert not missing, missing
