@@ -55,12 +55,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, rank_timeout=600.0):
     """`python bench.py --gpus N` started directly (no torch.distributed.run around it): this parent -- which has not
     imported torch nor touched HIP, and never does -- starts N fresh children of this same script, one per GPU, with
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (a free port) set, relays rank 0's single JSON line,
-    and returns non-zero when any rank fails.  The reference analogue is one `dist_pgo` process that runs all nodes
-    (C++/examples/dist_pgo.cpp:96-126, 492-531)."""
+    and returns non-zero when any rank fails.  The ranks get `rank_timeout` seconds (--rank-timeout): a collective that
+    hangs (a peer that never joined, an exchange that never completes) ends with the ranks that were still alive named
+    on stderr, their process groups stopped, and exit code 124 -- not with the caller's own, much later, timeout.  Only
+    fresh children are ever started or stopped; no process that touched the GPU is re-executed.  The reference analogue
+    is one `dist_pgo` process that runs all nodes (C++/examples/dist_pgo.cpp:96-126, 492-531)."""
     import signal
     import subprocess
     port = _free_port()
@@ -78,6 +81,7 @@ def launch_ranks(n, argv):
     chunks = []
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     reader.start()
+    deadline = time.time() + rank_timeout
     try:
         # a rank that dies leaves the others waiting in a collective: poll, and stop everybody when one has failed
         pending = set(range(n))
@@ -87,8 +91,14 @@ def launch_ranks(n, argv):
                 if c is not None:
                     pending.discard(r)
                     if c != 0:
+                        sys.stderr.write("[bench] rank %d exited with code %d\n" % (r, c))
                         rc = rc or c
             if rc:
+                break
+            if pending and time.time() > deadline:
+                sys.stderr.write("[bench] ranks %s still running after --rank-timeout %.0f s (finished: %s): stopping them\n"
+                                 % (sorted(pending), rank_timeout, sorted(set(range(n)) - pending)))
+                rc = 124
                 break
             time.sleep(0.05)
     finally:
@@ -99,6 +109,17 @@ def launch_ranks(n, argv):
                 else:
                     try:
                         os.killpg(p.pid, signal.SIGTERM)    # the exact process groups started above
+                    except ProcessLookupError:
+                        pass
+        if rc != 0:
+            # a rank stuck inside a device wait may not act on SIGTERM: give it a moment, then SIGKILL its group
+            t_end = time.time() + 5.0
+            while time.time() < t_end and any(p.poll() is None for p in procs):
+                time.sleep(0.05)
+            for p in procs:
+                if p.poll() is None:
+                    try:
+                        os.killpg(p.pid, signal.SIGKILL)
                     except ProcessLookupError:
                         pass
     reader.join(timeout=10)
@@ -135,9 +156,21 @@ def measure_traffic(args):
             cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--no-cpu", "--no-prof", "--converge", "0", "--steps", "5", "--warmup", "2",
                    "--traffic", "off", "--grid", args.grid, "--nodes", str(args.nodes), "--loss", args.loss]
-            r = subprocess.run(cmd, timeout=400, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd="/tmp",
-                               env=dict(os.environ, TMPDIR="/tmp"))
-            if r.returncode != 0:
+            # (its own session: on a timeout the whole group goes -- rocprofv3 AND the python child under it, which would
+            # otherwise keep the GPU busy during the timed run)
+            child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd="/tmp",
+                                     env=dict(os.environ, TMPDIR="/tmp"), start_new_session=True)
+            try:
+                child.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(child.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                child.wait()
+                return None
+            if child.returncode != 0:
                 return None
             agg[ctr] = pmc_summary.collect(d, ctr)
         res = {}
@@ -158,9 +191,10 @@ def main():
     if "WORLD_SIZE" not in os.environ:
         pre = argparse.ArgumentParser(add_help=False)
         pre.add_argument("--gpus", type=int, default=1)
-        n = pre.parse_known_args()[0].gpus
-        if n > 1:
-            sys.exit(launch_ranks(n, sys.argv[1:]))
+        pre.add_argument("--rank-timeout", type=float, default=600.0)
+        known = pre.parse_known_args()[0]
+        if known.gpus > 1:
+            sys.exit(launch_ranks(known.gpus, sys.argv[1:], known.rank_timeout))
 
     # The contract is ONE JSON line on stdout.  RCCL prints its banner and warnings to the C-level stdout (the GPU
     # boxes export NCCL_DEBUG=VERSION), so everything this process writes to fd 1 goes to stderr from here on and
@@ -199,6 +233,9 @@ def main():
                          "timed run (N = 1, about 40 s); off: quote the committed summary")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="stop after the ranks have met (no GPU needed): checks the launcher")
+    ap.add_argument("--rank-timeout", type=float, default=600.0,
+                    help="--gpus N > 1 started without a launcher: seconds the ranks get before they are stopped and bench.py "
+                         "returns 124 with the ranks that were still alive named on stderr")
     ap.add_argument("--force-exchange", action="store_true",
                     help="diagnostic: run the boundary exchange (pack, all-gather, unpack) even with one rank, to see "
                          "what it adds to a step")
@@ -247,6 +284,11 @@ def main():
         seen = [None] * world
         if world > 1:
             dist.all_gather_object(seen, (rank, local_rank, os.environ.get("MASTER_PORT")))
+            # (tests of the launcher's deadline and of a rank that dies while the others sit in a collective)
+            if os.environ.get("DPGO_BENCH_TEST_DIE_RANK") == str(rank):
+                os._exit(3)
+            if os.environ.get("DPGO_BENCH_TEST_HANG_RANK") == str(rank):
+                time.sleep(3600)
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
@@ -350,6 +392,20 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = None
+    if do_exchange:
+        # every rank's own time over the timed region and what it hands to the transport per exchange (the N > 1 line
+        # carries both: the max over ranks is `value`'s clock, the spread says whether one rank holds the others up)
+        mine = [elapsed, float(comm.bytes_sent()) if comm is not None else float(len(grp.sent_keys()[0]) * RS * 8)]
+        if world > 1:
+            allr = [None] * world
+            dist.all_gather_object(allr, mine)
+        else:
+            allr = [mine]
+        per_rank = {"ms_per_step": [1e3 * a[0] / args.steps for a in allr],
+                    "ms_per_step_min": 1e3 * min(a[0] for a in allr) / args.steps,
+                    "ms_per_step_max": 1e3 * max(a[0] for a in allr) / args.steps,
+                    "bytes_sent_per_exchange": [int(a[1]) for a in allr]}
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -479,6 +535,7 @@ def main():
             "exchange": None if not do_exchange else ("gloo, staged through the host" if host_staged else
                                                      ("RCCL, neighbour to neighbour (grouped ncclSend / ncclRecv)" if comm.exchange_kind() == "p2p"
                                                       else "RCCL all-gather") + " behind the C ABI (dpgo_comm_exchange) on the communicator's stream, joined in update()"),
+            "ranks": per_rank,
             "setup_s": {"graph+chordal_init": t_init, "operators+factorizations": t_group},
             "solver": grp.solver_stats(),
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,

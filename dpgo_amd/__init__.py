@@ -145,6 +145,8 @@ SYMBOLS = {
     "dpgo_comm_allreduce_sum": (C.c_int, [C.c_void_p, _DP, C.c_long]),
     "dpgo_comm_barrier": (C.c_int, [C.c_void_p]),
     "dpgo_comm_exchange_kind": (C.c_int, [C.c_void_p]),
+    "dpgo_comm_bytes_sent": (C.c_long, [C.c_void_p]),
+    "dpgo_debug_comm_p2p_self": (C.c_int, [C.c_void_p]),
     "dpgo_host_pack_sent": (C.c_int, [C.c_void_p, _IP, C.c_int, _DP, C.c_int, _DP]),
     "dpgo_host_unpack_recv": (C.c_int, [C.c_void_p, _IP, C.c_int, C.c_int, C.c_int, C.c_int, _IP, _IP, _IP, _DP, _DP,
                                         C.c_int]),
@@ -445,6 +447,11 @@ class NodeGroup:
     def communicate_local(self):
         return lib().dpgo_group_communicate_local(self._h)
 
+    def p2p_self_check(self):
+        """Test hook (dpgo_debug_comm_p2p_self): the grouped ncclSend / ncclRecv path of the boundary exchange on a one-rank
+        communicator that is its own peer, for the rows this group exports."""
+        return lib().dpgo_debug_comm_p2p_self(self._h)
+
     def step(self, comm=None):
         """iterate() of every node, the boundary exchange of `comm` (a Comm of this group) if any, communicate(), update():
         the body of the driver's loop (dist_pgo.cpp:496-521) in one native call."""
@@ -638,6 +645,10 @@ class Comm:
     def exchange_kind(self):
         """"p2p" (grouped ncclSend / ncclRecv to the real neighbours) or "allgather"."""
         return "p2p" if lib().dpgo_comm_exchange_kind(self._h) == 1 else "allgather"
+
+    def bytes_sent(self):
+        """Bytes this rank hands to RCCL per exchange."""
+        return int(lib().dpgo_comm_bytes_sent(self._h))
 
     def allreduce_sum(self, vals):
         a = np.ascontiguousarray(vals, np.float64).ravel().copy()

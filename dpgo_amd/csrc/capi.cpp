@@ -647,6 +647,21 @@ int dpgo_comm_exchange_kind(const dpgo_comm_t *c) {
   return std::string(c->c->exchange_kind()) == "p2p" ? 1 : 0;
 }
 
+long dpgo_comm_bytes_sent(const dpgo_comm_t *c) {
+  if (!c || !c->c) return -1;
+  return (long)c->c->bytes_sent_per_exchange();
+}
+
+int dpgo_debug_comm_p2p_self(dpgo_group_t *h) {
+  if (!h) return -1;
+  return guarded([&] {
+    unsigned char id[128];
+    if (dpgo::Comm::unique_id(id) != 0) return -1;
+    dpgo::Comm c(h->grp, 0, 1, id, /*layout=*/false);   // a communicator of one rank: the group's neighbours need no host
+    return c.p2p_self_check();
+  });
+}
+
 int dpgo_comm_barrier(dpgo_comm_t *c) {
   if (!c) return -1;
   return guarded([&] { return c->c->barrier(); });

@@ -19,7 +19,10 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <iterator>
+#include <thread>
 #include <map>
 #include <cstdio>
 #include <cstring>
@@ -35,6 +38,7 @@ struct Rccl {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclSend) Send = nullptr;
@@ -60,6 +64,7 @@ Rccl &rccl() {
 #define BIND(f) r.f = reinterpret_cast<decltype(r.f)>(dlsym(r.h, "nccl" #f))
   BIND(GetUniqueId); BIND(CommInitRank); BIND(CommDestroy); BIND(AllGather); BIND(AllReduce); BIND(GetErrorString);
   BIND(Send); BIND(Recv); BIND(GroupStart); BIND(GroupEnd);   // (optional: without them the all-gather stays)
+  BIND(CommAbort);                                             // (optional: lets a timed-out communicator go)
 #undef BIND
   r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.AllReduce && r.GetErrorString;
   if (!r.ok) fprintf(stderr, "[dpgo_amd] ERROR: librccl.so.1 lacks an expected symbol.\n");
@@ -115,18 +120,18 @@ int Comm::unique_id(void *id128) {
   return 0;
 }
 
-Comm::Comm(Group *grp, int rank, int nranks, const void *id128) : grp_(grp), rank_(rank), nranks_(nranks) {
+Comm::Comm(Group *grp, int rank, int nranks, const void *id128, bool layout) : grp_(grp), rank_(rank), nranks_(nranks) {
   if (!rccl().ok || !grp || rank < 0 || rank >= nranks) return;
   // a constructor that throws never runs its destructor: release what was created, then pass the error on
   try {
-    init(id128);
+    init(id128, layout);
   } catch (...) {
     release();
     throw;
   }
 }
 
-void Comm::init(const void *id128) {
+void Comm::init(const void *id128, bool layout) {
   Group *grp = grp_;
   const int rank = rank_, nranks = nranks_;
   ncclUniqueId id;
@@ -139,15 +144,16 @@ void Comm::init(const void *id128) {
   HIP_OK(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
   const int RS = (grp->d() + 1) * grp->d();
-  // ---- who exports what: all-gather of the key counts, then of the (node, pose) keys, through RCCL itself
-  const auto &keys = grp->sent_keys();
   red_.alloc(64);
   HIP_OK(hipHostMalloc((void **)&h_red_, sizeof(double) * 64, hipHostMallocDefault));
+  if (!layout) return;   // (ok_ stays false: no exchange, no collectives lent to the group)
+  // ---- who exports what: all-gather of the key counts, then of the (node, pose) keys, through RCCL itself
+  const auto &keys = grp->sent_keys();
   DevBuf<int> cnt_d, cnts_d;
   cnt_d.upload(std::vector<int>{(int)keys.size()});
   cnts_d.alloc(nranks);
   NCCL_OK(rccl().AllGather(cnt_d.p, cnts_d.p, 1, ncclInt32, (ncclComm_t)comm_, cs_));
-  HIP_OK(hipStreamSynchronize(cs_));
+  sync_comm_stream();
   std::vector<int> counts;
   cnts_d.download(counts);
   stride_ = std::max(1, *std::max_element(counts.begin(), counts.end()));
@@ -157,7 +163,7 @@ void Comm::init(const void *id128) {
   mine_d.upload(mine);
   all_d.alloc(2 * (size_t)stride_ * nranks);
   NCCL_OK(rccl().AllGather(mine_d.p, all_d.p, 2 * (size_t)stride_, ncclInt32, (ncclComm_t)comm_, cs_));
-  HIP_OK(hipStreamSynchronize(cs_));
+  sync_comm_stream();
   all_d.download(all);
   std::vector<int> nodes, poses;
   for (int r = 0; r < nranks; r++)
@@ -173,9 +179,16 @@ void Comm::init(const void *id128) {
     size_t at = 0;
     for (int r = 0; r < nranks; r++)
       for (int k = 0; k < counts[r]; k++, at++) exported[r].push_back({nodes[at], poses[at]});
+    // Whether the neighbour-to-neighbour path is even tried is decided per PROCESS (environment, the symbols this
+    // process's RCCL exports), so the ranks agree on it first: one dissenting rank and everybody keeps the all-gather --
+    // nobody may enter setup_p2p()'s collectives alone.
     const char *kind = getenv("DPGO_EXCHANGE");
-    if (nranks > 1 && !(kind && std::string(kind) == "allgather") && rccl().Send && rccl().Recv && rccl().GroupStart && rccl().GroupEnd)
-      if (setup_p2p(exported) != 0) p2p_ = false;
+    const bool want = !(kind && std::string(kind) == "allgather") && rccl().Send && rccl().Recv && rccl().GroupStart && rccl().GroupEnd;
+    if (nranks > 1) {
+      double against = want ? 0.0 : 1.0;
+      if (allreduce_impl(&against, 1) != 0) return;
+      if (against == 0.0 && setup_p2p(exported) != 0) p2p_ = false;
+    }
   }
   // AMM-PGO* and the global evaluations borrow the same buffers on the group's own stream
   if (grp->set_collectives(send_.p, gathered_.p, &Comm::cb_allgather, &Comm::cb_allreduce, this) != 0) return;
@@ -188,15 +201,17 @@ void Comm::release() {
   if (grp_) {
     // an exchange that no update() has joined yet: let it finish, and take its event away from the group before the
     // event is destroyed
-    if (ev_done_) (void)hipEventSynchronize(ev_done_);
+    if (ev_done_ && !broken_) (void)hipEventSynchronize(ev_done_);
     grp_->set_pending_exchange(nullptr);
     grp_->set_collectives(nullptr, nullptr, nullptr, nullptr, nullptr);
   }
-  if (cs_) (void)hipStreamSynchronize(cs_);
-  if (comm_ && rccl().ok) (void)rccl().CommDestroy((ncclComm_t)comm_);
+  // (a communicator whose stream ran into a deadline holds a kernel that will never end: it is aborted, not waited for)
+  if (broken_ && comm_ && rccl().CommAbort) { (void)rccl().CommAbort((ncclComm_t)comm_); comm_ = nullptr; }
+  if (cs_ && !broken_) (void)hipStreamSynchronize(cs_);
+  if (comm_ && rccl().ok && !broken_) (void)rccl().CommDestroy((ncclComm_t)comm_);
   if (ev_ready_) (void)hipEventDestroy(ev_ready_);
   if (ev_done_) (void)hipEventDestroy(ev_done_);
-  if (cs_) (void)hipStreamDestroy(cs_);
+  if (cs_ && !broken_) (void)hipStreamDestroy(cs_);
   if (h_red_) (void)hipHostFree(h_red_);
   comm_ = nullptr; ev_ready_ = ev_done_ = nullptr; cs_ = nullptr; h_red_ = nullptr;
   ok_ = false;
@@ -206,19 +221,30 @@ void Comm::release() {
 // upload the pack / unpack lists, and CHECK the whole path once with a message whose records carry their own keys: only
 // if every rank received exactly what it expected (a vote through ncclAllReduce) does exchange() use it; otherwise the
 // all-gather stays and a line says why.  RCCL with more than one rank cannot run on the boxes this was written on, so
-// the first 8-GPU run is also this path's first execution: the check is what makes it a safe default.
+// the first 8-GPU run is also this path's first execution (one rank talking to itself: p2p_self_check, run on the
+// MI355X by tests/test_gpu_comm.py).  Hence the rules of this function: every rank runs the SAME sequence of
+// collectives whatever happens to it locally -- a local failure (a key it cannot place, an exception from a kernel
+// launch or an upload) becomes a "no" in the vote, never an early return that leaves the peers inside a collective --
+// and every wait on the communicator's stream has a deadline (sync_comm_stream), after which the communicator counts
+// as broken and its creation fails on this rank (bench.py and dist_pgo vote on THAT through their control plane).
 int Comm::setup_p2p(const std::vector<std::vector<PoseKey>> &exported) {
   Group *grp = grp_;
   const int RS = (grp->d() + 1) * grp->d();
+  P2P &x = p2p_state_;
   std::vector<PoseKey> need;
   std::vector<int> need_rows;
-  grp->needed_keys(need, need_rows);
+  bool ok = true;
+  try {
+    grp->needed_keys(need, need_rows);
+  } catch (...) {
+    ok = false; need.clear(); need_rows.clear();
+  }
   // ---- all-gather of the needed keys (counts, then padded key lists)
   DevBuf<int> cnt_d, cnts_d;
   cnt_d.upload(std::vector<int>{(int)need.size()});
   cnts_d.alloc(nranks_);
   NCCL_OK(rccl().AllGather(cnt_d.p, cnts_d.p, 1, ncclInt32, (ncclComm_t)comm_, cs_));
-  HIP_OK(hipStreamSynchronize(cs_));
+  sync_comm_stream();
   std::vector<int> counts;
   cnts_d.download(counts);
   const int stride = std::max(1, *std::max_element(counts.begin(), counts.end()));
@@ -228,57 +254,80 @@ int Comm::setup_p2p(const std::vector<std::vector<PoseKey>> &exported) {
   mine_d.upload(mine);
   all_d.alloc(2 * (size_t)stride * nranks_);
   NCCL_OK(rccl().AllGather(mine_d.p, all_d.p, 2 * (size_t)stride, ncclInt32, (ncclComm_t)comm_, cs_));
-  HIP_OK(hipStreamSynchronize(cs_));
+  sync_comm_stream();
   all_d.download(all);
   std::vector<std::vector<PoseKey>> needed(nranks_);
   for (int r = 0; r < nranks_; r++)
     for (int k = 0; k < counts[r]; k++) needed[r].push_back({all[2 * ((size_t)r * stride + k)], all[2 * ((size_t)r * stride + k) + 1]});
-  plan_ = p2p_plan(rank_, exported, needed);
-  // ---- pack list: the own row of every key sent; unpack lists: every neighbour row that wants a received key
-  std::map<PoseKey, int> own_row;
-  {
-    const auto &keys = grp->sent_keys();
-    const auto &rows = grp->sent_rows();
-    for (size_t k = 0; k < keys.size(); k++) own_row[keys[k]] = rows[k];
-  }
-  // (whatever goes wrong locally, the lists keep the sizes of the plan: every rank must be able to run the checking
-  // exchange, or its peers would wait for it)
-  std::vector<int> srows;
-  bool ok = true;
-  for (const PoseKey &k : plan_.send_keys) {
-    auto it = own_row.find(k);
-    if (it == own_row.end()) ok = false;
-    srows.push_back(it == own_row.end() ? 0 : it->second);
-  }
-  std::map<PoseKey, int> slot;
-  for (size_t i = 0; i < plan_.recv_keys.size(); i++) slot[plan_.recv_keys[i]] = (int)i;
-  std::vector<int> rdst, rsrc;
-  for (size_t i = 0; i < need.size(); i++) {   // (a key may be wanted by several local nodes: one row each)
-    auto it = slot.find(need[i]);
-    if (it == slot.end()) { ok = false; continue; }
-    rdst.push_back(need_rows[i]);
-    rsrc.push_back(it->second);
-  }
-  p2p_send_rows_.upload(srows);
-  p2p_recv_dst_.upload(rdst);
-  p2p_recv_src_.upload(rsrc);
-  p2p_send_.alloc(std::max<size_t>(plan_.send_keys.size(), 1) * RS);
-  p2p_recv_.alloc(std::max<size_t>(plan_.recv_keys.size(), 1) * RS);
-  // ---- self-check: records that carry (node, pose) of their key travel the whole path once
+  x.plan = p2p_plan(rank_, exported, needed);   // (the same pure function of the same inputs on every rank)
+  // ---- local part: lists, buffers, and the probe records; whatever fails here only changes this rank's vote
+  DevBuf<double> probe_d;
+  std::vector<double> back;
   const int nrec = grp->num_records();
-  std::vector<double> probe((size_t)nrec * RS, -1.0), back;
-  {
+  try {
+    // pack list: the own row of every key sent; unpack lists: every neighbour row that wants a received key
+    std::map<PoseKey, int> own_row;
+    {
+      const auto &keys = grp->sent_keys();
+      const auto &rows = grp->sent_rows();
+      for (size_t k = 0; k < keys.size(); k++) own_row[keys[k]] = rows[k];
+    }
+    // (the lists keep the sizes of the plan even when a key cannot be placed: this rank must be able to run the checking
+    // exchange, or its peers would wait for it)
+    std::vector<int> srows;
+    for (const PoseKey &k : x.plan.send_keys) {
+      auto it = own_row.find(k);
+      if (it == own_row.end()) ok = false;
+      srows.push_back(it == own_row.end() ? 0 : it->second);
+    }
+    std::map<PoseKey, int> slot;
+    for (size_t i = 0; i < x.plan.recv_keys.size(); i++) slot[x.plan.recv_keys[i]] = (int)i;
+    std::vector<int> rdst, rsrc;
+    for (size_t i = 0; i < need.size(); i++) {   // (a key may be wanted by several local nodes: one row each)
+      auto it = slot.find(need[i]);
+      if (it == slot.end()) { ok = false; continue; }
+      rdst.push_back(need_rows[i]);
+      rsrc.push_back(it->second);
+    }
+    x.send_rows.upload(srows);
+    x.recv_dst.upload(rdst);
+    x.recv_src.upload(rsrc);
+    x.send.alloc(std::max<size_t>(x.plan.send_keys.size(), 1) * RS);
+    x.recv.alloc(std::max<size_t>(x.plan.recv_keys.size(), 1) * RS);
+    // self-check records: (node, pose) of their key in the first two entries
+    std::vector<double> probe((size_t)nrec * RS, -1.0);
     const auto &keys = grp->sent_keys();
     const auto &rows = grp->sent_rows();
     for (size_t k = 0; k < keys.size(); k++) { probe[(size_t)rows[k] * RS] = keys[k].first; probe[(size_t)rows[k] * RS + 1] = keys[k].second; }
+    probe_d.upload(probe);
+  } catch (...) {
+    ok = false;
   }
-  DevBuf<double> probe_d;
-  probe_d.upload(probe);
-  if (run_p2p(probe_d.p, probe_d.p) != 0) ok = false;
-  HIP_OK(hipStreamSynchronize(cs_));
-  probe_d.download(back);
-  for (size_t i = 0; i < need.size() && ok; i++)
-    ok = back[(size_t)need_rows[i] * RS] == (double)need[i].first && back[(size_t)need_rows[i] * RS + 1] == (double)need[i].second;
+  // ---- the checking exchange.  A rank whose local part failed still posts its sends and receives (from / into whatever
+  // buffers it has: the sizes are the plan's), so that its peers' GroupEnd returns.
+  if (!x.send.p) x.send.alloc(std::max<size_t>(x.plan.send_keys.size(), 1) * RS);
+  if (!x.recv.p) x.recv.alloc(std::max<size_t>(x.plan.recv_keys.size(), 1) * RS);
+  if (ok) {
+    if (run_p2p(x, probe_d.p, probe_d.p) != 0) ok = false;
+  } else {
+    P2P bare;   // no pack / unpack lists: the messages alone
+    bare.plan = x.plan;
+    bare.send.swap(x.send);
+    bare.recv.swap(x.recv);
+    (void)run_p2p(bare, nullptr, nullptr);
+    bare.send.swap(x.send);
+    bare.recv.swap(x.recv);
+  }
+  sync_comm_stream();
+  if (ok) {
+    try {
+      probe_d.download(back);
+      for (size_t i = 0; i < need.size() && ok; i++)
+        ok = back[(size_t)need_rows[i] * RS] == (double)need[i].first && back[(size_t)need_rows[i] * RS + 1] == (double)need[i].second;
+    } catch (...) {
+      ok = false;
+    }
+  }
   double vote = ok ? 0.0 : 1.0;
   if (allreduce_impl(&vote, 1) != 0) return -1;
   if (vote != 0.0) {
@@ -290,17 +339,99 @@ int Comm::setup_p2p(const std::vector<std::vector<PoseKey>> &exported) {
 }
 
 // pack the send keys' rows of src_records -> grouped send / recv with the real neighbours -> unpack into dst_records
-int Comm::run_p2p(const double *src_records, double *dst_records) {
+// (null record arrays: the messages alone).  Between GroupStart and GroupEnd nothing returns early: a Send or Recv that
+// fails is remembered and GroupEnd is still called, so the group is never left open.
+int Comm::run_p2p(P2P &x, const double *src_records, double *dst_records) {
   const int RS = (grp_->d() + 1) * grp_->d();
-  grp_->copy_records(cs_, (int)p2p_send_rows_.n, nullptr, p2p_send_rows_.p, src_records, p2p_send_.p);
+  if (src_records && x.send_rows.n > 0) grp_->copy_records(cs_, (int)x.send_rows.n, nullptr, x.send_rows.p, src_records, x.send.p);
+  ncclResult_t bad = ncclSuccess;
   NCCL_OK(rccl().GroupStart());
-  for (const auto &pr : plan_.peers) {
-    if (pr.send_cnt) NCCL_OK(rccl().Send(p2p_send_.p + (size_t)pr.send_off * RS, (size_t)pr.send_cnt * RS, ncclFloat64, pr.rank, (ncclComm_t)comm_, cs_));
-    if (pr.recv_cnt) NCCL_OK(rccl().Recv(p2p_recv_.p + (size_t)pr.recv_off * RS, (size_t)pr.recv_cnt * RS, ncclFloat64, pr.rank, (ncclComm_t)comm_, cs_));
+  for (const auto &pr : x.plan.peers) {
+    ncclResult_t r = ncclSuccess;
+    if (pr.send_cnt) r = rccl().Send(x.send.p + (size_t)pr.send_off * RS, (size_t)pr.send_cnt * RS, ncclFloat64, pr.rank, (ncclComm_t)comm_, cs_);
+    if (r != ncclSuccess) bad = r;
+    r = ncclSuccess;
+    if (pr.recv_cnt) r = rccl().Recv(x.recv.p + (size_t)pr.recv_off * RS, (size_t)pr.recv_cnt * RS, ncclFloat64, pr.rank, (ncclComm_t)comm_, cs_);
+    if (r != ncclSuccess) bad = r;
   }
-  NCCL_OK(rccl().GroupEnd());
-  grp_->copy_records(cs_, (int)p2p_recv_dst_.n, p2p_recv_dst_.p, p2p_recv_src_.p, p2p_recv_.p, dst_records);
+  const ncclResult_t fin = rccl().GroupEnd();
+  if (bad != ncclSuccess) NCCL_OK(bad);
+  NCCL_OK(fin);
+  if (dst_records && x.recv_dst.n > 0) grp_->copy_records(cs_, (int)x.recv_dst.n, x.recv_dst.p, x.recv_src.p, x.recv.p, dst_records);
   return 0;
+}
+
+// Wait for the communicator's stream, but not for ever: a peer that died or never posted its half of a message leaves an
+// RCCL kernel spinning on the device.  After the deadline the communicator is marked broken (release() then aborts it
+// instead of waiting for its stream) and the caller gets an exception, i.e. dpgo_comm_create / the entry point returns -1.
+void Comm::sync_comm_stream() { sync_stream(cs_); }
+
+void Comm::sync_stream(hipStream_t st) {
+  double limit = 120.0;
+  if (const char *e = getenv("DPGO_COMM_TIMEOUT")) limit = std::max(1.0, atof(e));
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) return;
+    if (q != hipErrorNotReady) HIP_OK(q);
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+      broken_ = true;
+      fprintf(stderr, "[dpgo_amd] ERROR: rank %d: an RCCL collective did not finish within %.0f s (a peer is gone or "
+                      "never joined); the communicator is abandoned.\n", rank_, limit);
+      throw DeviceError("RCCL collective timed out");
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+
+// One rank talking to itself through the grouped send / recv path (tests: the first execution of this code on real
+// hardware must not be the first multi-GPU run).  Every exported row is sent to this rank and unpacked into the same row
+// of a scratch record array; the records carry their (node, pose) keys.
+int Comm::p2p_self_check() {
+  if (!comm_ || !cs_ || !(rccl().Send && rccl().Recv && rccl().GroupStart && rccl().GroupEnd)) return -1;
+  Group *grp = grp_;
+  const int RS = (grp->d() + 1) * grp->d();
+  const auto &keys = grp->sent_keys();
+  const auto &rows = grp->sent_rows();
+  const int n = (int)keys.size();
+  if (n == 0) return -1;   // (a group that exports nothing has nothing to check: the caller picks a group with neighbours elsewhere)
+  P2P x;
+  x.plan.peers.push_back({rank_, 0, n, 0, n});
+  x.plan.send_keys = keys;
+  x.plan.recv_keys = keys;
+  std::vector<int> ident(n);
+  for (int i = 0; i < n; i++) ident[i] = i;
+  x.send_rows.upload(rows);
+  x.recv_dst.upload(rows);
+  x.recv_src.upload(ident);
+  x.send.alloc((size_t)n * RS);
+  x.recv.alloc((size_t)n * RS);
+  const int nrec = grp->num_records();
+  std::vector<double> probe((size_t)nrec * RS, -1.0), back;
+  for (int k = 0; k < n; k++)
+    for (int c = 0; c < RS; c++) probe[(size_t)rows[k] * RS + c] = c == 0 ? keys[k].first : (c == 1 ? keys[k].second : 1000.0 * k + c);
+  DevBuf<double> src_d, dst_d;
+  src_d.upload(probe);
+  dst_d.upload(std::vector<double>((size_t)nrec * RS, -7.0));
+  HIP_OK(hipDeviceSynchronize());   // (the uploads ran on the null stream; cs_ does not wait for it)
+  if (run_p2p(x, src_d.p, dst_d.p) != 0) return -1;
+  sync_comm_stream();
+  dst_d.download(back);
+  std::vector<char> sent(nrec, 0);
+  for (int k = 0; k < n; k++) sent[rows[k]] = 1;
+  for (int r = 0; r < nrec; r++)
+    for (int c = 0; c < RS; c++)
+      if (back[(size_t)r * RS + c] != (sent[r] ? probe[(size_t)r * RS + c] : -7.0)) {
+        fprintf(stderr, "[dpgo_amd] ERROR: p2p self check: record %d entry %d is %.17g\n", r, c, back[(size_t)r * RS + c]);
+        return -1;
+      }
+  return 0;
+}
+
+size_t Comm::bytes_sent_per_exchange() const {
+  const size_t RS = (size_t)(grp_->d() + 1) * grp_->d();
+  if (p2p_) return p2p_state_.plan.send_keys.size() * RS * sizeof(double);
+  return (size_t)stride_ * RS * sizeof(double);
 }
 
 // DPGOHash::communicate for the neighbours hosted by other ranks (DPGOHash.h:64-82), asynchronous: the group's
@@ -311,7 +442,7 @@ int Comm::exchange() {
   HIP_OK(hipEventRecord(ev_ready_, grp_->stream()));      // Xk of this iteration is final
   HIP_OK(hipStreamWaitEvent(cs_, ev_ready_, 0));
   if (p2p_) {
-    if (run_p2p(grp_->Xk_records(), grp_->Xk_records()) != 0) return -1;
+    if (run_p2p(p2p_state_, grp_->Xk_records(), grp_->Xk_records()) != 0) return -1;
   } else {
     grp_->pack_sent(send_.p, cs_);
     NCCL_OK(rccl().AllGather(send_.p, gathered_.p, (size_t)stride_ * RS, ncclFloat64, (ncclComm_t)comm_, cs_));
@@ -336,7 +467,7 @@ int Comm::allreduce_impl(double *vals, int n) {
     HIP_OK(hipMemcpyAsync(red_.p, h_red_, sizeof(double) * m, hipMemcpyHostToDevice, st));
     NCCL_OK(rccl().AllReduce(red_.p, red_.p, m, ncclFloat64, ncclSum, (ncclComm_t)comm_, st));
     HIP_OK(hipMemcpyAsync(h_red_, red_.p, sizeof(double) * m, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipStreamSynchronize(st));
+    sync_stream(st);
     std::memcpy(vals + off, h_red_, sizeof(double) * m);
   }
   return 0;
@@ -351,7 +482,7 @@ int Comm::allreduce_large(double *vals, size_t n) {
   HIP_OK(hipMemcpyAsync(buf.p, vals, sizeof(double) * n, hipMemcpyHostToDevice, st));
   NCCL_OK(rccl().AllReduce(buf.p, buf.p, n, ncclFloat64, ncclSum, (ncclComm_t)comm_, st));
   HIP_OK(hipMemcpyAsync(vals, buf.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
-  HIP_OK(hipStreamSynchronize(st));
+  sync_stream(st);
   return 0;
 }
 

@@ -24,7 +24,9 @@ P2PPlan p2p_plan(int rank, const std::vector<std::vector<PoseKey>> &exported, co
 class Comm {
  public:
   static int unique_id(void *id128);                                  // ncclGetUniqueId, 128 bytes
-  Comm(Group *grp, int rank, int nranks, const void *id128);          // ncclCommInitRank + exchange lay-out
+  // ncclCommInitRank + exchange lay-out (layout = false: the communicator and its stream only, for p2p_self_check on a group
+  // whose neighbours no rank hosts)
+  Comm(Group *grp, int rank, int nranks, const void *id128, bool layout = true);
   ~Comm();
   Comm(const Comm &) = delete;
   Comm &operator=(const Comm &) = delete;
@@ -37,9 +39,13 @@ class Comm {
   int allreduce_impl(double *vals, int n);
   int allreduce_large(double *vals, size_t n);
   int barrier();
+  // test hook (one rank is enough): the grouped ncclSend / ncclRecv path with THIS rank as its own peer -- pack, GroupStart,
+  // Send + Recv to self, GroupEnd, unpack, on records that carry their own keys; 0 = every record arrived where it should
+  int p2p_self_check();
+  size_t bytes_sent_per_exchange() const;   // what this rank hands to RCCL per exchange (p2p: its peers' records; all-gather: one padded block)
 
  private:
-  void init(const void *id128);
+  void init(const void *id128, bool layout);
   void release();
   static int cb_allgather(void *user);
   static int cb_allreduce(void *user, double *vals, int n);
@@ -54,11 +60,17 @@ class Comm {
   // neighbour-to-neighbour exchange (grouped ncclSend / ncclRecv): the default with more than one rank once its
   // self-check has passed on every rank; DPGO_EXCHANGE=allgather keeps the all-gather
   bool p2p_ = false;
-  P2PPlan plan_;
-  DevBuf<double> p2p_send_, p2p_recv_;
-  DevBuf<int> p2p_send_rows_, p2p_recv_dst_, p2p_recv_src_;
+  bool broken_ = false;   // a wait on the communicator's stream ran into its deadline: the stream is never waited for again
+  struct P2P {            // one neighbour-to-neighbour exchange: the plan, its message buffers, its pack / unpack lists
+    P2PPlan plan;
+    DevBuf<double> send, recv;
+    DevBuf<int> send_rows, recv_dst, recv_src;
+  };
+  P2P p2p_state_;
   int setup_p2p(const std::vector<std::vector<PoseKey>> &exported);
-  int run_p2p(const double *src_records, double *dst_records);   // pack from / unpack into record arrays, on cs_
+  int run_p2p(P2P &x, const double *src_records, double *dst_records);   // pack from / unpack into record arrays, on cs_
+  void sync_comm_stream();   // hipStreamSynchronize(cs_) with a deadline (DPGO_COMM_TIMEOUT seconds, default 120)
+  void sync_stream(hipStream_t st);
 };
 
 }  // namespace dpgo

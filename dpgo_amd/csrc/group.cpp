@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <set>
+#include <thread>
 
 namespace dpgo {
 
@@ -984,7 +985,14 @@ void Group::wait_flag(unsigned long long seq) {
   for (unsigned spins = 0; __atomic_load_n(h_flag_, __ATOMIC_ACQUIRE) < seq; spins++) {
     __builtin_ia32_pause();
     if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
-      HIP_CHECK(hipStreamSynchronize(st_));   // surfaces a kernel fault, if that is why the flag never came
+      // surfaces a kernel fault, if that is why the flag never came -- without waiting for ever on a stream that is itself
+      // waiting for an exchange whose peer is gone
+      hipError_t q = hipStreamQuery(st_);
+      for (int i = 0; i < 600 && q == hipErrorNotReady && __atomic_load_n(h_flag_, __ATOMIC_ACQUIRE) < seq; i++) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        q = hipStreamQuery(st_);
+      }
+      if (q != hipErrorNotReady) HIP_CHECK(q);
       if (__atomic_load_n(h_flag_, __ATOMIC_ACQUIRE) >= seq) break;
       fprintf(stderr, "[dpgo_amd] ERROR: read-back flag never arrived\n");
       throw DeviceError("read-back flag never arrived");

@@ -229,6 +229,14 @@ int dpgo_comm_barrier(dpgo_comm_t *comm);
 /* How dpgo_comm_exchange moves the boundary poses: 1 = neighbour to neighbour (grouped ncclSend / ncclRecv, the default with
  * several ranks once its self-check passed on every rank), 0 = all-gather of fixed-size buffers; -1 on error. */
 int dpgo_comm_exchange_kind(const dpgo_comm_t *comm);
+/* Bytes this rank hands to RCCL per dpgo_comm_exchange (neighbour to neighbour: the records its peers need; all-gather: one
+ * padded block); -1 on error.  Reported per rank by bench.py's N > 1 line. */
+long dpgo_comm_bytes_sent(const dpgo_comm_t *comm);
+/* Test hook: the grouped ncclSend / ncclRecv path of dpgo_comm_exchange on a communicator of ONE rank that is its own peer
+ * (legal inside ncclGroupStart / End): every row `grp` exports travels pack kernel -> group call -> unpack kernel on the
+ * communicator's stream, on records that carry their own keys.  `grp` may host any subset of the nodes.  0 = every record
+ * arrived in its row and no other row was touched; -1 otherwise (also when the group exports nothing). */
+int dpgo_debug_comm_p2p_self(dpgo_group_t *grp);
 /* The same pack / unpack on host matrices (no GPU needed; what a host-staged transport or a test uses): records
  * of the poses a group exports, in key order, from a global X ((d+1)N x d) into buf (count x (d+1)d doubles,
  * [t | rows of R^T] per pose); and the neighbour rows of node `node` ((d+1)(n0+n1) x d matrix Z, DPGOHash::initialize

@@ -63,6 +63,29 @@ def test_bench_launches_its_own_ranks():
     assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
 
 
+def test_launcher_names_and_stops_ranks_that_hang_or_die():
+    """The first N > 1 run must end with an exit code and a message, never at the caller's own timeout: (i) a rank that
+    dies while the other waits in a collective makes `bench.py --gpus 2` return non-zero at once, (ii) a rank that hangs
+    is stopped at --rank-timeout with the ranks still alive named on stderr (exit code 124).  gloo on the CPU; the
+    launcher only ever starts and stops fresh children."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--rendezvous-only"]
+    t0 = time.time()
+    died = subprocess.run(cmd + ["--rank-timeout", "240"], capture_output=True, text=True, cwd=ROOT, timeout=300,
+                          env=dict(env, DPGO_BENCH_TEST_DIE_RANK="1"))
+    assert died.returncode not in (0, 124) and time.time() - t0 < 200, died.stderr[-2000:]
+    assert "rank 1 exited with code 3" in died.stderr and not [l for l in died.stdout.splitlines() if l.startswith("{")]
+    t0 = time.time()
+    hung = subprocess.run(cmd + ["--rank-timeout", "45"], capture_output=True, text=True, cwd=ROOT, timeout=300,
+                          env=dict(env, DPGO_BENCH_TEST_HANG_RANK="1"))
+    assert hung.returncode == 124, hung.stderr[-2000:]
+    assert 40 < time.time() - t0 < 120
+    # (rank 1 sleeps, rank 0 waits for it in the barrier: both are named)
+    assert "ranks [0, 1] still running after --rank-timeout 45 s" in hung.stderr, hung.stderr[-2000:]
+    assert not [l for l in hung.stdout.splitlines() if l.startswith("{")]
+
+
 @pytest.mark.gpu
 def test_fresh_bench_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--grid", "20,20,16,25000", "--steps", "5",

@@ -83,3 +83,20 @@ def test_dist_pgo_one_rank_with_comm(fixtures_dir, tmp_path):
     assert one.returncode == 0 and two.returncode == 0, (one.stderr[-1000:], two.stderr[-1000:])
     pick = lambda s: [l for l in s.splitlines() if l[:1].isdigit() or l.startswith("final")]
     assert pick(one.stdout) == pick(two.stdout)
+
+
+@pytest.mark.parametrize("name,nodes,mine", [("torus3D.g2o", 4, [1, 2]), ("M3500.g2o", 4, [0]), ("smallGrid3D.g2o", 2, [1])])
+def test_grouped_send_recv_path_runs_on_the_device_with_one_rank(fixtures_dir, name, nodes, mine):
+    """The neighbour-to-neighbour exchange (comm.cpp: run_p2p) is the default with more than one rank, and RCCL refuses two
+    ranks on one device -- so its FIRST execution on an MI355X would otherwise be an 8-GPU run.  Here one rank is its own
+    peer: every row the group exports goes pack kernel -> ncclGroupStart, ncclSend + ncclRecv to self, ncclGroupEnd ->
+    unpack kernel on the communicator's stream, on records that carry their own keys, and every record must arrive in
+    its row with no other row touched (DPGOHash.h:28-86 is what the path replaces)."""
+    G = dpgo_amd.read_g2o(os.path.join(fixtures_dir, name), nodes)
+    grp = dpgo_amd.NodeGroup(G, mine, dpgo_amd.Options.driver(LOSS_HUBER, True))
+    assert len(grp.sent_keys()[0]) > 0
+    assert grp.p2p_self_check() == 0
+    assert grp.p2p_self_check() == 0       # (a second communicator on the same group: nothing was left behind)
+    # a group that hosts every node exports nothing: the hook says so instead of passing vacuously
+    whole = dpgo_amd.NodeGroup(G, list(range(nodes)), dpgo_amd.Options.driver(LOSS_HUBER, True))
+    assert whole.p2p_self_check() == -1
