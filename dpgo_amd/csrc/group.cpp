@@ -59,6 +59,7 @@ template struct DevBuf<NodeBits>;
 template struct DevBuf<PanelSrc>;
 template struct DevBuf<InterInc>;
 template struct DevBuf<RootDesc>;
+template struct DevBuf<RootRow>;
 template struct DevBuf<float>;
 
 // tuning hooks (tools/env_ab.sh): an integer from the environment, or the default
@@ -269,7 +270,114 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
                      std::vector<int>(nnodes, 0), std::vector<double>(nnodes, 0.0)};
   root_items.release();
   Wroot.release();
+  root_sym = false;
+  root_rows.release();
+  root_part.release();
+  root_pack.release();
   if (fused_root) {
+    // one triangle instead of the full product when the roots are big enough for the second (combine) launch to pay
+    // (measured, DESIGN 3.4: an item pays three dependent loads for its inputs before 32 KB of stream, and the second
+    // launch costs 5 us -- the form wins where ONE root holds tens of megabytes (a single node per GPU: 19.5 -> 15.8 us
+    // for G_tt's 44 MB root) and is a wash on eight roots of 8-23 MB each, which keep the full product)
+    std::vector<int> roots;
+    double largest_mb = 0;
+    for (int f = 0; f < F.nfronts; f++)
+      if (is_root(f)) { roots.push_back(f); largest_mb = std::max(largest_mb, 8e-6 * (double)F.w[f] * F.w[f]); }
+    const int force = env_int("DPGO_SPD_ROOT_SYM", -1);
+    root_sym = !roots.empty() && !want_f32 && env_int("DPGO_SPD_FLOW", 0) == 0 && nnodes <= MAX_LOCAL_NODES &&
+               (force == 1 || (force != 0 && largest_mb >= env_int("DPGO_SPD_ROOT_SYM_MB", 32)));
+  }
+  if (fused_root && root_sym) {
+    std::vector<int> roots;
+    for (int f = 0; f < F.nfronts; f++)
+      if (is_root(f)) roots.push_back(f);
+    long long nblocks = 0;
+    for (int f : roots) { const long long nb = (F.w[f] + 63) / 64; nblocks += nb * (nb + 1) / 2; }
+    // blocks per item (a workgroup each, one dependent gather per item): as many as still leave the chip three workgroups
+    // per CU, at most ROOT_SYM_MAXJ
+    const int S = (int)std::min<long long>(ROOT_SYM_MAXJ, std::max<long long>(1, env_int("DPGO_SPD_ROOT_SYM_BLOCKS", (int)(nblocks / 768))));
+    root_sym_level = Level{0, 0, 0, 64, std::vector<int>(nnodes, 0), std::vector<int>(nnodes, 0), std::vector<int>(nnodes, 0),
+                           std::vector<int>(nnodes, 0), std::vector<double>(nnodes, 0.0)};
+    root_rows_level = root_sym_level;
+    std::vector<SpdItem> items, pack;
+    std::vector<PanelSrc> srcs;
+    std::vector<RootRow> rows;
+    std::vector<RootDesc> rdesc;
+    std::vector<double> host_src;
+    std::vector<int64_t> p_off(F.nfronts, 0);
+    int64_t ptotal = 0, total = 0;
+    int nslots = 0;
+    root_max_w = 0;
+    for (int f : roots) {
+      RootDesc rd;
+      rd.src_off = F.dev_W ? F.w_off[f] : (long long)host_src.size();
+      if (!F.dev_W) host_src.insert(host_src.end(), F.W.begin() + F.w_off[f], F.W.begin() + F.w_off[f] + (size_t)F.w[f] * F.ldw[f]);
+      rd.dst_off = ptotal; rd.ld = F.ldw[f]; rd.w = F.w[f];
+      p_off[f] = ptotal;
+      ptotal += (int64_t)F.w[f] * F.w[f];
+      root_max_w = std::max(root_max_w, F.w[f]);
+      rdesc.push_back(rd);
+    }
+    for (int a = 0; a < nnodes; a++) {
+      root_sym_level.nstart[a] = (int)items.size();
+      root_rows_level.wstart[a] = (int)rows.size();
+      for (int f : roots) {
+        if (node_of_front(f) != a) continue;
+        const int w = F.w[f], nb = (w + 63) / 64;
+        const int tbase = nslots;               // transposed slot of block (I, J), J < I: tbase + I (I - 1) / 2 + J
+        nslots += nb * (nb - 1) / 2;
+        for (int I = 0; I < nb; I++) {
+          RootRow rr;
+          rr.piv_ptr = F.piv_ptr[f]; rr.first = I * 64; rr.count = std::min(64, w - I * 64); rr.node = a;
+          rr.dslot = nslots; rr.ndslots = 0; rr.tbase = tbase; rr.nb = nb; rr.R = I; rr.pad0 = rr.pad1 = rr.pad2 = 0;
+          for (int J0 = 0; J0 <= I; J0 += S) {
+            const int nJ = std::min(S, I + 1 - J0);
+            SpdItem it;
+            it.front = f; it.first = I * 64; it.count = rr.count; it.w = w;
+            it.u = J0; it.ld = nJ; it.piv_ptr = F.piv_ptr[f]; it.upd_ptr = nslots++;   // its direct slot
+            it.pos_off = F.pos_off[f]; it.ubuf_off = tbase + I * (I - 1) / 2 + J0;     // its first transposed slot
+            it.node = a; it.wait_ctr = -1; it.mat_off = total; it.wait_need = 0; it.signal_ctr = -1;
+            items.push_back(it);
+            rr.ndslots++;
+            for (int J = J0; J < J0 + nJ; J++) {
+              // block (I, J) k-major: row k of the panel = entries (I*64 .. , J*64 + k) of P = row J*64 + k of the symmetric P
+              SpdItem pk = it;
+              pk.mat_off = total; pk.ld = 64; pk.count = rr.count;
+              pack.push_back(pk);
+              srcs.push_back(PanelSrc{(long long)(p_off[f] + (int64_t)(J * 64) * w + I * 64), w, std::min(64, w - J * 64)});
+              total += 4096;
+            }
+          }
+          rows.push_back(rr);
+          root_sym_level.node_bytes[a] += 8.0 * 4096.0 * (I + 1);
+        }
+        root_sym_level.node_bytes[a] += 2.0 * 8.0 * dcols * w;
+      }
+      root_sym_level.ncount[a] = (int)items.size() - root_sym_level.nstart[a];
+      root_sym_level.nnarrow += root_sym_level.ncount[a];
+      root_rows_level.wcount[a] = (int)rows.size() - root_rows_level.wstart[a];
+      root_rows_level.nwide += root_rows_level.wcount[a];
+    }
+    root_level = root_sym_level;   // (what the dumps and the byte counts look at)
+    h_root.clear();                // (no tile of the one-launch solve: it is off with this form)
+    root_items.upload(items);
+    root_pack.upload(pack);
+    root_srcs.upload(srcs);
+    root_rows.upload(rows);
+    root_desc.upload(rdesc);
+    root_part.alloc((size_t)std::max(nslots, 1) * 64 * dcols);
+    DevBuf<double> src_dev;
+    if (!F.dev_W) src_dev.upload(host_src);
+    Proot.alloc((size_t)ptotal, false);
+    Wroot.alloc((size_t)total);   // (zero-filled: rows and columns of a block past w stay zero)
+    launch_root_syrk(nullptr, root_desc.p, (int)rdesc.size(), root_max_w, F.dev_W ? F.dev_W : src_dev.p, Proot.p);
+    launch_pack_panels(nullptr, root_pack.p, root_srcs.p, (int)pack.size(), Proot.p, Wroot.p);
+    HIP_CHECK(hipDeviceSynchronize());
+    if (!F.keep_numeric) Proot.release();
+    if (getenv("DPGO_SPD_DUMP"))
+      fprintf(stderr, "[spd] dof %d fused roots as one triangle: %zu fronts, %zu items of <= %d blocks, %zu block rows, %d slots, %.1f MB of panels\n",
+              dof, roots.size(), items.size(), S, rows.size(), nslots, total * 8e-6);
+  } else if (fused_root) {
     std::vector<int> roots;
     for (int f = 0; f < F.nfronts; f++)
       if (is_root(f)) roots.push_back(f);
@@ -355,7 +463,7 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
     // (an experiment that lost, DESIGN 3.4: handing results from tile to tile through memory-side counters costs more
     // than the kernel boundary it replaces -- 1.40 against 1.27 ms per iteration with eight nodes, 0.60 against 0.37 with
     // one -- so it is off unless asked for)
-    flow = env_int("DPGO_SPD_FLOW", 0) != 0 && nnodes <= MAX_LOCAL_NODES;
+    flow = env_int("DPGO_SPD_FLOW", 0) != 0 && nnodes <= MAX_LOCAL_NODES && !root_sym;
     // (a front that passes contributions on without a tile of its own would break the chain of waits)
     for (int f = 0; f < nfr; f++)
       if (needA[f] > 0 && nf[f] + nr[f] == 0) flow = false;
@@ -447,9 +555,10 @@ int SpdSolverDev::repack(hipStream_t st) {
   launch_pack_panels(st, fwd_items.p, fwd_srcs.p, (int)fwd_items.n, F.dev_WT, WT.p);
   launch_pack_panels(st, bwd_items.p, bwd_srcs.p, (int)bwd_items.n, F.dev_W, W.p);
   if (fused_root && root_items.n > 0) {
-    if (root_srcs.n != root_items.n || Proot.n == 0) return -1;
+    const DevBuf<SpdItem> &cut = root_sym ? root_pack : root_items;   // (one triangle: a descriptor per block)
+    if (root_srcs.n != cut.n || Proot.n == 0) return -1;
     launch_root_syrk(st, root_desc.p, (int)root_desc.n, root_max_w, F.dev_W, Proot.p);
-    launch_pack_panels(st, root_items.p, root_srcs.p, (int)root_items.n, Proot.p, Wroot.p);
+    launch_pack_panels(st, cut.p, root_srcs.p, (int)cut.n, Proot.p, Wroot.p);
   }
   return 0;
 }
@@ -1096,16 +1205,19 @@ void spd_run(int d, hipStream_t st, SpdSolverDev &S, NodeMask mask, double *in, 
     if ((fon[l] = S.fwd_levels[l].map(mask.v, fm[l], &fby[l]))) { bf += fby[l]; nf++; }
   for (size_t l = 0; l < bm.size(); l++)
     if ((bon[l] = S.bwd_levels[l].map(mask.v, bm[l], &bby[l]))) { bb += bby[l]; nb++; }
-  SpdLevelMap rm;
+  SpdLevelMap rm, rrm;
   double rby = 0;
-  const bool ron = S.root_level.map(mask.v, rm, &rby);
+  const bool ron = S.root_sym ? (S.root_sym_level.map(mask.v, rm, &rby) && S.root_rows_level.map(mask.v, rrm)) : S.root_level.map(mask.v, rm, &rby);
   if (ron && in == out) throw DeviceError("spd_run: the fused root step cannot solve in place");
   {
-  ProfSweep sweep(true, st, bf + rby, nf + (ron ? 1 : 0));
+  ProfSweep sweep(true, st, bf + rby, nf + (ron ? (S.root_sym ? 2 : 1) : 0));
   for (size_t l = 0; l < fm.size(); l++)
     if (fon[l]) launch_spd_level(d, S.dof, st, S.dev, 0, fm[l], S.fwd_levels[l].rows, in, S.ytmp.p, scale, fby[l], S.stream_once, mask);
   // the roots: right-hand side from `in` (+ the children's updates), solution straight into `out`
-  if (ron) launch_spd_level(d, S.dof, st, S.dev, 2, rm, S.root_level.rows, in, out, scale, rby, S.stream_once, mask);
+  if (ron && S.root_sym) {
+    launch_root_sym(d, S.dof, st, S.dev, rm, in, S.root_part.p, rby, S.stream_once, mask);
+    launch_root_combine(d, S.dof, st, S.dev, rrm, S.root_rows.p, S.root_part.p, scale, out, mask);
+  } else if (ron) launch_spd_level(d, S.dof, st, S.dev, 2, rm, S.root_level.rows, in, out, scale, rby, S.stream_once, mask);
   }
   ProfSweep sweep(false, st, bb, nb);
   for (size_t l = 0; l < bm.size(); l++)
@@ -1147,6 +1259,12 @@ static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec) {
       SpdLevelMap M;
       v.map(~0ull, M);
       // (mode 2 on a zero vector: in and out may be the same array here, nothing is compared)
+      if (mode == 2 && S.root_sym) {
+        SpdLevelMap R;
+        S.root_rows_level.map(~0ull, R);
+        launch_root_sym(d, S.dof, st, S.dev, M, vec, S.root_part.p, 0.0, S.stream_once, ALL_NODES);
+        launch_root_combine(d, S.dof, st, S.dev, R, S.root_rows.p, S.root_part.p, 1.0, vec, ALL_NODES);
+      } else
       launch_spd_level(d, S.dof, st, S.dev, mode, M, v.rows, vec, mode == 2 ? vec : S.ytmp.p, 1.0, 0.0, S.stream_once, ALL_NODES);
       HIP_CHECK(hipEventRecord(e1, st));
       HIP_CHECK(hipEventSynchronize(e1));

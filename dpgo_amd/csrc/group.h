@@ -143,6 +143,16 @@ struct SpdSolverDev {
   bool want_f32 = false;
   DevBuf<float> W32, WT32, Wroot32;
   DevBuf<SpdItem> root_items;
+  // The fused roots stored as ONE TRIANGLE of 64 x 64 blocks (kernels.h: RootRow; k_root_sym + k_root_combine): half the
+  // bytes of the level for one small launch more, taken when a single root holds at least DPGO_SPD_ROOT_SYM_MB (32) megabytes
+  // (DPGO_SPD_ROOT_SYM=1 / 0 forces it on / off).  root_items are then the wave-sized items, root_sym_level / root_rows_level
+  // their and the block rows' per-node ranges, root_part the partial-sum slots, root_pack the per-block descriptors the
+  // panels are cut with (also by repack()).
+  bool root_sym = false;
+  Level root_sym_level{0, 0, 0, 64, {}, {}, {}, {}, {}}, root_rows_level{0, 0, 0, 64, {}, {}, {}, {}, {}};
+  DevBuf<RootRow> root_rows;
+  DevBuf<double> root_part;
+  DevBuf<SpdItem> root_pack;
   DevBuf<double> Wroot, Proot;   // the root tiles' panels; the dense products they are cut from (kept with keep_numeric)
   DevBuf<RootDesc> root_desc;
   int root_max_w = 0;

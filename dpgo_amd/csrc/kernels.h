@@ -322,6 +322,30 @@ void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, int mode,
 struct RootDesc { long long src_off, dst_off; int ld, w; };
 void launch_root_syrk(hipStream_t st, const RootDesc *rd, int nroots, int max_w, const double *src, double *dst);
 
+// ---- the roots as ONE TRIANGLE (k_root_sym + k_root_combine) ----
+// The product P = L11^-T L11^-1 a fused root streams is symmetric: storing its lower triangle in 64 x 64 blocks halves the
+// bytes of the level.  Block (I, J), J <= I, is stored k-major ([k][r]: entry (I*64 + r, J*64 + k); 4096 doubles, rows and
+// columns past w are zero) and serves BOTH x_I += P_IJ f_J (lane = row, plain FMAs) and, for J < I, x_J += P_IJ^T f_I (the
+// block's 8-column strips go through LDS so that lane = column can take its dot product down the rows).  The diagonal
+// blocks are stored in full and take the first product only.  An ITEM (one workgroup of four waves; SpdItem with first = I*64, count = rows
+// of block row I, u = J0, ld = number of blocks, upd_ptr = its direct slot, ubuf_off = its first transposed slot,
+// mat_off = its blocks, consecutive) covers blocks (I, J0 .. J0 + ld - 1) and writes 64 x D partial sums per output block:
+// one "direct" slot and one "transposed" slot per off-diagonal block.  k_root_combine then adds the slots of every block
+// row in a FIXED order -- no atomics, results independent of the schedule -- scales and writes the solution records.
+struct alignas(16) RootRow {
+  int piv_ptr, first, count, node;   // block row R of a root front: pivots piv_ptr + first .. + count, local node
+  int dslot, ndslots, tbase, nb;     // its direct slots; transposed slot of block (I, R), I > R: tbase + I (I - 1) / 2 + R
+  int R, pad0, pad1, pad2;
+};
+static_assert(sizeof(RootRow) == 48, "RootRow is loaded as three int4");
+constexpr int ROOT_SYM_MAXJ = 8;     // blocks per item at most
+// items: M.nstart / ncount (one workgroup each) index S.root_items; part: the partial-sum slots
+void launch_root_sym(int d, int dof, hipStream_t st, const SpdDev &S, const SpdLevelMap &M, const double *vec, double *part,
+                     double bytes, bool stream_once, NodeMask mask);
+// rows: M.wstart / wcount index `rows`; out receives scale * (sum of the slots) on the roots' unknowns
+void launch_root_combine(int d, int dof, hipStream_t st, const SpdDev &S, const SpdLevelMap &M, const RootRow *rows,
+                         const double *part, double scale, double *out, NodeMask mask);
+
 // ---- optional per-launch timing (HIP events on the launch stream), off by default ----
 enum ProfKind { PK_BSR = 0, PK_INTER, PK_PROX, PK_AXPBY, PK_DOT, PK_ROTOP, PK_COPYIDX, PK_BDIAG, PK_REDUCE,
                 PK_SPD_FWD, PK_SPD_BWD, PK_SPD_FLOW, PK_COUNT };

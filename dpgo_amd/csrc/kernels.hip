@@ -1659,13 +1659,13 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
       const double *src = S.ubuf + (size_t)(it.piv_ptr + k) * D;
 #else
       const double *src = vec + vaddr<D, DOF>(piv[k]);
-#endif
 #pragma unroll
       for (int c = 0; c < D; c++) v[c] = *(src + c);
       pull_updates<D, PULLB, COH>(S, pos0 + k, v);
 #pragma unroll
       for (int c = 0; c < D; c++) fw[kk * D + c] = v[c];
     }
+#endif
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #ifdef SPD_TRACE
@@ -1852,6 +1852,233 @@ __global__ __launch_bounds__(64 * SPD_NW(ROWS), ROWS == 64 ? SPD_WPE : 4) void k
     else spd_fwd_tile<D, DOF, NW, CH, ROWS, NT, true, PT>(S, it, vec, nullptr, f[wv], red, wv, lane SPD_TRACE_ARGS(t), ytmp, scale);
   }
 #undef SPD_TRACE_ARGS
+}
+
+// ---- the roots as one triangle (kernels.h: RootRow) ---------------------------------------------------------------
+// One workgroup of four waves per item: blocks (I, J0 .. J0 + nJ - 1) of the lower triangle of P = L11^-T L11^-1, 32 KB
+// each.  A block is eight 8-column strips; wave v takes strips v and v + 4 (16 loads per lane, all in flight at once: a
+// block is ONE memory round trip for the workgroup).  Lane = row r of block row I:
+//   direct      acc[c]  += P[I r][J k] f_J[k][c]                       (f_J broadcast from LDS; the four waves' sums meet
+//                                                                       through LDS at the end, in a fixed order)
+//   transposed  t_k[c]  += P[I r][J k] f_I[r][c]  summed over r: the strip goes through LDS, lane (k, q) takes rows
+//               8q .. 8q + 7 of column k; the two strips of a wave meet across lane bit 5 (each half keeps one strip),
+//               two more exchanges complete the sums over q: the wave ends with the 16 column sums of its strips.
+// The input entries f = rhs + the children's contributions are gathered once per item, one 64-entry chunk per wave (chunk
+// 0: block row I, chunks 1 .. nJ: the block columns): index loads, then vector loads, then the pulls round by round.
+template <int D>
+__device__ __forceinline__ void root_xchg(double (&a)[D], const double (&b)[D], int lane, int bit) {
+  // lanes with `bit` clear keep a (+ the partner's a), the others keep b (+ the partner's b)
+  const bool hi = (lane & bit) != 0;
+#pragma unroll
+  for (int c = 0; c < D; c++) {
+    const double keep = hi ? b[c] : a[c], send = hi ? a[c] : b[c];
+    a[c] = keep + __shfl_xor(send, bit, 64);
+  }
+}
+
+template <int D, int DOF, bool NT>
+__global__ __launch_bounds__(256, 3) void k_root_sym(SpdDev S, NodeMask mask, SpdLevelMap M, const double *vec, double *part) {
+  constexpr int NWV = 4, TS = 66, MAXJ = ROOT_SYM_MAXJ, NCH = (MAXJ + 1 + NWV - 1) / NWV;   // NCH: gather chunks per wave
+  typedef double PT;
+  __shared__ double f_s[MAXJ + 1][64 * D];                            // chunk 0: f_I, chunks 1..: f_J
+  // a wave's two strips on their way to lane = column; at the end the same memory carries the waves' direct sums
+  __shared__ __attribute__((aligned(16))) double T_s[NWV][2][8 * TS];
+  static_assert(sizeof(double) * NWV * 2 * 8 * TS >= sizeof(double) * NWV * 64 * D, "the direct sums fit the strip buffers");
+  double (*red)[64 * D] = reinterpret_cast<double (*)[64 * D]>(&T_s[0][0][0]);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int b = blockIdx.x, j = b % M.nlive, rr = b / M.nlive;
+  if (rr >= M.ncount[j]) return;
+  if (mask.p && !((*mask.p >> M.node[j]) & 1ull)) return;
+  SpdItem it = load_item(S.root_items + M.nstart[j] + rr);
+  // (the descriptor is the same in every lane: in scalar registers its tests become scalar branches)
+  it.first = __builtin_amdgcn_readfirstlane(it.first); it.w = __builtin_amdgcn_readfirstlane(it.w);
+  it.u = __builtin_amdgcn_readfirstlane(it.u); it.ld = __builtin_amdgcn_readfirstlane(it.ld);
+  it.piv_ptr = __builtin_amdgcn_readfirstlane(it.piv_ptr); it.pos_off = __builtin_amdgcn_readfirstlane(it.pos_off);
+  it.upd_ptr = __builtin_amdgcn_readfirstlane(it.upd_ptr); it.ubuf_off = __builtin_amdgcn_readfirstlane(it.ubuf_off);
+  {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(it.mat_off & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((unsigned)(it.mat_off >> 32));
+    it.mat_off = (int64_t)(((unsigned long long)hi << 32) | lo);
+  }
+  const int w = it.w, I = it.first >> 6, J0 = it.u, nJ = it.ld;
+  // this wave's strips of block jb: rows (wv * 8 + i) and ((wv + 4) * 8 + i) of the k-major block
+  const PT *blk = reinterpret_cast<const PT *>(S.Wroot) + it.mat_off + (size_t)wv * 512 + lane;
+  // the first block's loads go out before anything else: they depend on nothing but the descriptor
+  double ma[8], mb[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { ma[i] = LDW(blk + i * 64); mb[i] = LDW(blk + 2048 + i * 64); }
+  // ---- gather: wave v takes chunks v, v + 4, ...; every stage of the chain for all of them at once
+  {
+    int idx[NCH], a0[NCH], a1[NCH];
+    double f[NCH][D];
+#pragma unroll
+    for (int q = 0; q < NCH; q++) {
+      const int ch = wv + NWV * q;
+      const int k = (ch == 0 ? I : J0 + ch - 1) * 64 + lane;
+      const bool v = ch <= nJ && k < w;
+      idx[q] = v ? S.piv_idx[it.piv_ptr + k] : -1;
+      a0[q] = v ? S.asm_ptr[it.pos_off + k] : 0;
+      a1[q] = v ? S.asm_ptr[it.pos_off + k + 1] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < NCH; q++)
+#pragma unroll
+      for (int c = 0; c < D; c++) f[q][c] = idx[q] >= 0 ? vec[vaddr<D, DOF>(idx[q]) + c] : 0.0;
+    // the children's contributions, in list order (the order of the host solve), two list positions per round
+    for (int r = 0;; r += 2) {
+      bool any = false;
+      double u[NCH][2][D];
+#pragma unroll
+      for (int q = 0; q < NCH; q++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const bool on = a0[q] + r + e < a1[q];
+          any |= on;
+#pragma unroll
+          for (int c = 0; c < D; c++) u[q][e][c] = on ? S.ubuf[(size_t)(a0[q] + r + e) * D + c] : 0.0;
+        }
+      if (!__any(any)) break;
+#pragma unroll
+      for (int q = 0; q < NCH; q++)
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+          if (a0[q] + r + e < a1[q]) {
+#pragma unroll
+            for (int c = 0; c < D; c++) f[q][c] += u[q][e][c];
+          }
+    }
+#pragma unroll
+    for (int q = 0; q < NCH; q++)
+      if (wv + NWV * q <= nJ) {
+#pragma unroll
+        for (int c = 0; c < D; c++) f_s[wv + NWV * q][lane * D + c] = f[q][c];
+      }
+  }
+  __syncthreads();
+  const int k8 = lane & 7, q8 = lane >> 3;
+  double fIt[8][D];   // rows 8 q8 .. 8 q8 + 7 of f_I: what this lane multiplies its strip column with
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int c = 0; c < D; c++) fIt[i][c] = f_s[0][(8 * q8 + i) * D + c];
+  double acc[D];
+#pragma unroll
+  for (int c = 0; c < D; c++) acc[c] = 0.0;
+  // the diagonal block, if the item has it, is its last one; the blocks before it take both products
+  const bool has_diag = J0 + nJ - 1 == I;
+  for (int jb = 0; jb < nJ; jb++) {
+    const double *fj = f_s[jb + 1];
+    const bool offdiag = !(has_diag && jb == nJ - 1);
+    double na[8], nb2[8];
+    if (jb + 1 < nJ) {   // the next block's strips
+#pragma unroll
+      for (int i = 0; i < 8; i++) { na[i] = LDW(blk + (size_t)(jb + 1) * 4096 + i * 64); nb2[i] = LDW(blk + (size_t)(jb + 1) * 4096 + 2048 + i * 64); }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+      for (int c = 0; c < D; c++) {
+        acc[c] = fma(ma[i], fj[(wv * 8 + i) * D + c], acc[c]);
+        acc[c] = fma(mb[i], fj[((wv + 4) * 8 + i) * D + c], acc[c]);
+      }
+    // (pins the products here: left alone, the compiler defers them behind the transposed part and spills their LDS operands)
+#pragma unroll
+    for (int c = 0; c < D; c++) asm volatile("" : "+v"(acc[c]) :: "memory");
+    if (offdiag) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) { T_s[wv][0][i * TS + lane] = ma[i]; T_s[wv][1][i * TS + lane] = mb[i]; }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      double ta[D], tb[D];
+#pragma unroll
+      for (int c = 0; c < D; c++) ta[c] = tb[c] = 0.0;
+      const double2 *pa = reinterpret_cast<const double2 *>(&T_s[wv][0][k8 * TS + 8 * q8]);
+      const double2 *pb = reinterpret_cast<const double2 *>(&T_s[wv][1][k8 * TS + 8 * q8]);
+#pragma unroll
+      for (int h = 0; h < 4; h++) {
+        const double2 va = pa[h], vb = pb[h];
+#pragma unroll
+        for (int c = 0; c < D; c++) {
+          ta[c] = fma(va.x, fIt[2 * h][c], ta[c]);
+          ta[c] = fma(va.y, fIt[2 * h + 1][c], ta[c]);
+          tb[c] = fma(vb.x, fIt[2 * h][c], tb[c]);
+          tb[c] = fma(vb.y, fIt[2 * h + 1][c], tb[c]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      // lanes 0..31 keep strip wv, lanes 32..63 strip wv + 4; then the sums over the remaining two bits of q
+      root_xchg<D>(ta, tb, lane, 32);
+#pragma unroll
+      for (int c = 0; c < D; c++) ta[c] += __shfl_xor(ta[c], 16, 64);
+#pragma unroll
+      for (int c = 0; c < D; c++) ta[c] += __shfl_xor(ta[c], 8, 64);
+      if ((q8 & 3) == 0) {
+        const int col = (wv + (lane >= 32 ? 4 : 0)) * 8 + k8;
+        double *dst = part + ((size_t)(it.ubuf_off + jb) * 64 + col) * D;
+#pragma unroll
+        for (int c = 0; c < D; c++) dst[c] = ta[c];
+      }
+    }
+    if (jb + 1 < nJ) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) { ma[i] = na[i]; mb[i] = nb2[i]; }
+    }
+  }
+  __syncthreads();   // (every wave is done with its strip buffers)
+#pragma unroll
+  for (int c = 0; c < D; c++) red[wv][lane * D + c] = acc[c];
+  __syncthreads();
+  if (wv != 0) return;
+  double *dst = part + ((size_t)it.upd_ptr * 64 + lane) * D;
+#pragma unroll
+  for (int c = 0; c < D; c++) dst[c] = ((red[0][lane * D + c] + red[1][lane * D + c]) + red[2][lane * D + c]) + red[3][lane * D + c];
+}
+
+// x on block row R of a root = scale * (its direct slots, then the transposed slots of blocks (R + 1 .. nb - 1, R)): four
+// waves take every fourth slot each and meet through LDS, always in the same order.
+template <int D, int DOF>
+__global__ __launch_bounds__(256) void k_root_combine(SpdDev S, NodeMask mask, SpdLevelMap M, const RootRow *rows, const double *part,
+                                                      double scale, double *out) {
+  __shared__ double red[4][64 * D];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x, j = b % M.nlive, rr = b / M.nlive;
+  if (rr >= M.wcount[j]) return;
+  if (mask.p && !((*mask.p >> M.node[j]) & 1ull)) return;
+  union { int4 v[3]; RootRow r; } u;
+  const int4 *rp = reinterpret_cast<const int4 *>(rows + M.wstart[j] + rr);
+  u.v[0] = rp[0]; u.v[1] = rp[1]; u.v[2] = rp[2];
+  const RootRow row = u.r;
+  const int nslots = row.ndslots + row.nb - 1 - row.R;
+  // (the pivot's record is looked up while the slots arrive)
+  const int pidx = (wv == 0 && lane < row.count) ? S.piv_idx[row.piv_ptr + row.first + lane] : -1;
+  double acc[D];
+#pragma unroll
+  for (int c = 0; c < D; c++) acc[c] = 0.0;
+  auto slot_of = [&](int s) {
+    if (s < row.ndslots) return (long long)(row.dslot + s);
+    const long long I = row.R + 1 + (s - row.ndslots);
+    return (long long)row.tbase + I * (I - 1) / 2 + row.R;
+  };
+  for (int s0 = wv; s0 < nslots; s0 += 4 * 4) {
+    double t[4][D];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int s = s0 + 4 * q;
+#pragma unroll
+      for (int c = 0; c < D; c++) t[q][c] = s < nslots ? part[((size_t)slot_of(s) * 64 + lane) * D + c] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int c = 0; c < D; c++) acc[c] += t[q][c];
+  }
+#pragma unroll
+  for (int c = 0; c < D; c++) red[wv][lane * D + c] = acc[c];
+  __syncthreads();
+  if (wv != 0 || pidx < 0) return;
+  double *dst = out + vaddr<D, DOF>(pidx);
+#pragma unroll
+  for (int c = 0; c < D; c++) dst[c] = scale * (((red[0][lane * D + c] + red[1][lane * D + c]) + red[2][lane * D + c]) + red[3][lane * D + c]);
 }
 
 // ---- the whole solve in one launch -------------------------------------------------------------------------------
@@ -2376,6 +2603,33 @@ void launch_spd_flow(int d, int dof, hipStream_t st, const SpdDev &S, const SpdF
 #undef SPD_FLOW
 #undef SPD_FLOW2
 #undef SPD_FLOW3
+}
+void launch_root_sym(int d, int dof, hipStream_t st, const SpdDev &S, const SpdLevelMap &M, const double *vec, double *part,
+                     double bytes, bool stream_once, NodeMask mask) {
+  int maxn = 0;
+  for (int j = 0; j < M.nlive; j++) maxn = std::max(maxn, M.ncount[j]);
+  const int grid = M.nlive * maxn;
+  if (grid == 0) return;
+  ProfScope ps(PK_SPD_FWD, st, bytes);
+#define ROOT_SYM(DOFV)                                                                                                       \
+  do {                                                                                                                       \
+    if (stream_once) hipLaunchKernelGGL((k_root_sym<D, DOFV, true>), dim3(grid), dim3(256), 0, st, S, mask, M, vec, part);    \
+    else hipLaunchKernelGGL((k_root_sym<D, DOFV, false>), dim3(grid), dim3(256), 0, st, S, mask, M, vec, part);               \
+  } while (0)
+  DPGO_DISPATCH_D(d, {
+    if (dof == 1) ROOT_SYM(1);
+    else ROOT_SYM(D);
+  });
+#undef ROOT_SYM
+}
+void launch_root_combine(int d, int dof, hipStream_t st, const SpdDev &S, const SpdLevelMap &M, const RootRow *rows,
+                         const double *part, double scale, double *out, NodeMask mask) {
+  if (M.wide_wgs == 0 || M.nlive == 0) return;
+  ProfScope ps(PK_SPD_FWD, st, 0.0);
+  DPGO_DISPATCH_D(d, {
+    if (dof == 1) hipLaunchKernelGGL((k_root_combine<D, 1>), dim3(M.wide_wgs), dim3(256), 0, st, S, mask, M, rows, part, scale, out);
+    else hipLaunchKernelGGL((k_root_combine<D, D>), dim3(M.wide_wgs), dim3(256), 0, st, S, mask, M, rows, part, scale, out);
+  });
 }
 void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, int mode, const SpdLevelMap &M, int rows,
                       double *vec, double *ytmp, double scale, double level_bytes, bool stream_once, NodeMask mask) {

@@ -905,6 +905,9 @@ np.save(sys.argv[1], drv.X())
                      # round 3: the refinement started by the host, the tree roots in two sweeps, G Y by a pass over the operator
                      ("hoststart", dict(DPGO_TNT_DEVICE_START="0")), ("tworootsweeps", dict(DPGO_SPD_FUSE_ROOT="0")),
                      ("gy_by_pass", dict(DPGO_GX_LINEAR="0")),
+                     # round 4: the fused roots stored as one triangle (forced on: these roots are below its size threshold)
+                     ("roots_one_triangle_2_blocks", dict(DPGO_SPD_ROOT_SYM="1", DPGO_SPD_ROOT_SYM_BLOCKS="2")),
+                     ("roots_one_triangle_8_blocks", dict(DPGO_SPD_ROOT_SYM="1", DPGO_SPD_ROOT_SYM_BLOCKS="8")),
                      # the factorisation's block columns right-looking at every level (another order of the same updates)
                      ("rightlooking", dict(DPGO_SPD_LEFT_LOOKING="0")),
                      # ... with the diagonal blocks in a launch of their own (the path of levels with thousands of fronts)
