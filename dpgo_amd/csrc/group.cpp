@@ -737,6 +737,7 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   partials_.alloc((size_t)MAX_SLOTS * std::max(T_.nseg_all, 1));
   cg_.alloc(MAX_LOCAL_NODES);
   dmask_.alloc(4);
+  dev_seq_.alloc(1);
 
   upload_operators();
   // ---- inter-node edges (residual form) and their incidence lists
@@ -907,6 +908,7 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
 // The operators of every local node on the device (block-CSR G, S, P, P0, Q; the per-pose arrays D, T, N, V, robust Q).
 // Called at construction and after a Dynamic rescale.
 void Group::upload_operators() {
+  cg_graphs_release();   // (captured CG steps carry the operators' addresses)
   const int L = num_local();
   const bool trivial = (opt_.loss == 0);
   auto uni = [&](int a, int p) { return p < info_[a].n[0] ? own_off_[a] + p : P0_ + nbr_off_[a] + (p - info_[a].n[0]); };
@@ -981,12 +983,14 @@ int Group::refactor_tt() {
   std::vector<int> node_of_pose(P0_);
   for (int a = 0; a < L; a++)
     for (int p = 0; p < info_[a].n[0]; p++) node_of_pose[own_off_[a] + p] = a;
+  cg_graphs_release();   // (... and the panels')
   Ltt_.upload(d_, node_of_pose);
   clk.lap("G_tt: panels (pack + upload)");
   return 0;
 }
 
 Group::~Group() {
+  cg_graphs_release();
   chordal_release();
   if (h_scal_) (void)hipHostFree(h_scal_);
   if (st_) (void)hipStreamDestroy(st_);

@@ -305,6 +305,15 @@ class Group {
   double *h_cg_ = nullptr, *h_tnt_ = nullptr;   // pinned summaries of k_cg_scal / k_tnt_begin (same allocation as h_scal_)
   bool zc_ready_ = false;       // iterate() wrote Xk's own rows into the buffer the next update() rotates into X[iter]
   bool tnt_speculate_ = true;   // run_tnt: take the trial point behind the first CG step without waiting for its outcome
+  // A whole CG step (Hessian product, both solves, the scalar kernels: ~20 launches with fixed arguments once masks, step
+  // lengths and the flag's sequence number live on the device) captured as a HIP graph and replayed with ONE submission per
+  // step (tnt.cpp).  For groups whose steps are bound by the host's launch rate (small graphs, one node per GPU);
+  // DPGO_CG_GRAPH=0 / 1 forces it off / on.  Keyed by every pointer a step carries (the iterate's buffers swap).
+  struct CgGraph { std::vector<const void *> key; hipGraphExec_t exec = nullptr; };
+  std::vector<CgGraph> cg_graphs_;
+  DevBuf<unsigned long long> dev_seq_;   // the device's copy of the last sequence number a CG scalar kernel raised the flag to
+  bool cg_graph_wanted() const;
+  void cg_graphs_release();
   DevBuf<unsigned> reduce_arrived_;
   DevBuf<double> partials_;
   DevBuf<CgNode> cg_;       // device-resident state of the truncated CG (tnt.cpp, k_cg_scal)

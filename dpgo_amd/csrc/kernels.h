@@ -240,9 +240,11 @@ void launch_cg_begin(hipStream_t st, int nnodes, NodeBits bits, const CgStart &S
 // dmask[2] collects the nodes whose CG has ended (their trial point may be taken).
 // Either phase ends by writing, per node, (live, h_M_norm, cg_it) to host_scalars[node * CG_SUMMARY + 0..2] and
 // raising *host_flag to seq (same protocol as launch_reduce).
+// seq == 0 (a launch captured into a graph): the flag is raised to *dev_seq + 1; *dev_seq always ends up holding the value used.
 void launch_cg_scal(hipStream_t st, const SegTable &T, int nnodes, int phase, const double *partials, CgNode *cg,
                     NodeBits *dmask, double *host_scalars, unsigned *arrived, unsigned long long *host_flag,
-                    unsigned long long seq);
+                    unsigned long long seq, unsigned long long *dev_seq);
+bool prof_enabled();
 
 // ---- multifrontal SPD solve (spd.h) ----
 // One tile of the solve with everything it needs to know about its front: 64 bytes, one load.

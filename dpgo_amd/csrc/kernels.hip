@@ -1361,9 +1361,13 @@ __global__ __launch_bounds__(384) void k_tnt_begin(SegTable T, int nnodes, TntBe
 }
 
 // one wave per node; the partial sums are combined in the order of k_reduce
+// seq: the value the host's flag is raised to.  A launch replayed from a captured graph cannot carry a fresh value in its
+// arguments: with seq == 0 the value is the device word *dev_seq + 1; either way *dev_seq ends up holding the value used,
+// so that eager launches and replays can follow each other (the host counts along: Group::fetch_seq_).
 __global__ __launch_bounds__(256) void k_cg_scal(SegTable T, int phase, const double *partials, CgNode *cg,
                                                  NodeBits *dmask, double *host_scalars, unsigned *arrived,
-                                                 unsigned long long *host_flag, unsigned long long seq) {
+                                                 unsigned long long *host_flag, unsigned long long seq,
+                                                 unsigned long long *dev_seq) {
   // one workgroup per node; the (up to) four sums of a phase are reduced side by side, one wave each
   __shared__ double sums[4];
   const int a = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1436,6 +1440,8 @@ __global__ __launch_bounds__(256) void k_cg_scal(SegTable T, int phase, const do
     if (done == gridDim.x - 1) {
       if (phase == 1) dmask[0] = __hip_atomic_load(dmask + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next step's nodes
       __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (seq == 0) seq = *dev_seq + 1;
+      *dev_seq = seq;
       __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
@@ -2237,6 +2243,7 @@ void prof_enable(bool on) {
   g_prof.flush();
   g_prof.on = on;
 }
+bool prof_enabled() { return g_prof.on; }
 void prof_reset() {
   g_prof.flush();
   for (int k = 0; k < PK_COUNT; k++) { g_prof.ms[k] = 0; g_prof.bytes[k] = 0; g_prof.count[k] = 0; }
@@ -2412,10 +2419,10 @@ void launch_tnt_begin(hipStream_t st, const SegTable &T, int nnodes, NodeBits bi
 
 void launch_cg_scal(hipStream_t st, const SegTable &T, int nnodes, int phase, const double *partials, CgNode *cg,
                     NodeBits *dmask, double *host_scalars, unsigned *arrived, unsigned long long *host_flag,
-                    unsigned long long seq) {
+                    unsigned long long seq, unsigned long long *dev_seq) {
   ProfScope ps(PK_REDUCE, st, 8.0 * (phase == 0 ? 4 : 1) * T.nseg_own);
   hipLaunchKernelGGL(k_cg_scal, dim3(nnodes), dim3(256), 0, st, T, phase, partials, cg, dmask, host_scalars, arrived,
-                     host_flag, seq);
+                     host_flag, seq, dev_seq);
 }
 
 void launch_dots(int d, hipStream_t st, const SegTable &T, NodeMask mask, int n, const double *const *a,

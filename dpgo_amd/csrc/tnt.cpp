@@ -19,6 +19,7 @@
 // a launch works on travel as kernel arguments (NodeCoefs, NodeMask: no uploads),
 // and the handful of reductions per CG step come back through one polled read-back.
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <limits>
@@ -26,6 +27,15 @@
 #include "group.h"
 
 namespace dpgo {
+
+#define HIP_CHECK(x)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (x);                                                                          \
+    if (e_ != hipSuccess) {                                                                       \
+      fprintf(stderr, "[dpgo_amd] ERROR: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      throw DeviceError(hipGetErrorString(e_));                                                   \
+    }                                                                                             \
+  } while (0)
 
 namespace {
 // DPGO_CG_LAG=0: wait for every CG step's outcome before enqueueing the next (measurement hook)
@@ -51,6 +61,23 @@ struct NodeTnt {
   int cg_it = 0;
 };
 }  // namespace
+
+// The CG steps of a group go out as one graph replay each when the group is small enough for its steps to be bound by the
+// host's launch rate (a step of the headline's eight-node group streams gigabytes: nothing to gain, and its launches
+// shrink with the set of nodes that still iterate, which a replay cannot do).  Never while launches are being timed.
+bool Group::cg_graph_wanted() const {
+  static const int force = [] { const char *e = getenv("DPGO_CG_GRAPH"); return e ? atoi(e) : -1; }();
+  // (the one-launch solve experiment hands a per-solve epoch to its kernel by value: nothing a replay could carry)
+  if (prof_enabled() || force == 0 || Ltt_.flow || Lrr_.flow) return false;
+  if (force == 1) return true;
+  return P0_ <= 40000;
+}
+
+void Group::cg_graphs_release() {
+  for (auto &c : cg_graphs_)
+    if (c.exec) (void)hipGraphExecDestroy(c.exec);
+  cg_graphs_.clear();
+}
 
 void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, const double *g_alt, bool base_ready) {
   finish_update();
@@ -236,12 +263,15 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     // by pointer: the device's own, more recent masks
     NodeMask mA{bitsA, dmask_.p}, mB{bitsA, dmask_.p + 1};
     // first half of a step: H p and its four scalars, then the step-length logic (:296-362)
+    // (captured: the launches go into a graph under capture -- the flag's sequence number then comes from the device's own
+    // word, k_cg_scal -- and the host's counter is advanced when the graph is replayed, not here)
+    bool capturing = false;
     auto stepA = [&]() {
       cur_mask_ = mA;
       launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, pk, true, nullptr, w1, nullptr, 0, nullptr, nullptr, 0);   // G [0 ; p.R]
       solve_tt(w1, w3, -1.0);
       apply_tcol(w3, w1, nullptr, 2, X, nabla, pk, Hp, first_step ? grad : rk, partials_.p);   // Hp and <p,Hp>, <Hp,Hp>, <p,p>, <p,r>
-      launch_cg_scal(st_, T_, L, 0, partials_.p, cg_.p, dmask_.p, h_cg_, reduce_arrived_.p, h_flag_, ++fetch_seq_);
+      launch_cg_scal(st_, T_, L, 0, partials_.p, cg_.p, dmask_.p, h_cg_, reduce_arrived_.p, h_flag_, capturing ? 0ull : ++fetch_seq_, dev_seq_.p);
       // s += c1 p, H s += c1 H p for every node of the step (a node that stops here takes its boundary step), r += alpha H p
       // for those that go on
       // (the first step runs for every node of A, live or not: a node that stops before its first step has c1 = 0 and
@@ -263,10 +293,55 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
         const double *pa[MAX_DOTS] = {rk}, *pb[MAX_DOTS] = {vk};
         launch_dots(d_, st_, T_, cur_mask_, 1, pa, pb, P2, partials_.p, 0);
       }
-      launch_cg_scal(st_, T_, L, 1, partials_.p, cg_.p, dmask_.p, h_cg_, reduce_arrived_.p, h_flag_, ++fetch_seq_);
+      launch_cg_scal(st_, T_, L, 1, partials_.p, cg_.p, dmask_.p, h_cg_, reduce_arrived_.p, h_flag_, capturing ? 0ull : ++fetch_seq_, dev_seq_.p);
       launch_cg_dir(d_, st_, T_, cur_mask_, cg_.p, vk, pk);
       return fetch_seq_;
     };
+    // One whole step (A then B, not the first) as ONE submission: captured once per set of argument values, replayed ever
+    // after.  The by-value node sets of a replay are the group's nodes -- the device's own masks keep the nodes that are
+    // not (or no longer) part of the CG out, as they do for a node that stopped since the host last looked.
+    hipGraphExec_t step_graph = nullptr;
+    auto graph_step = [&]() {
+      if (!step_graph) {
+        const NodeBits all = L >= 64 ? ~0ull : ((1ull << L) - 1);
+        std::vector<const void *> key = {X, nabla, grad, sk, rk, vk, pk, Hp, w1, w3, hh, partials_.p, cg_.p, dmask_.p, jacobi ? jacobi_.p : nullptr,
+                                         (const void *)(uintptr_t)(use_precon ? 1 : 0)};
+        for (auto &c : cg_graphs_)
+          if (c.key == key) { step_graph = c.exec; break; }
+        if (!step_graph) {
+          const NodeMask sA = mA, sB = mB;
+          mA = NodeMask{all, dmask_.p};
+          mB = NodeMask{all, dmask_.p + 1};
+          capturing = true;
+          hipGraph_t g = nullptr;
+          HIP_CHECK(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
+          try {
+            stepA();
+            stepB();
+          } catch (...) {
+            (void)hipStreamEndCapture(st_, &g);
+            if (g) (void)hipGraphDestroy(g);
+            capturing = false; mA = sA; mB = sB;
+            throw;
+          }
+          HIP_CHECK(hipStreamEndCapture(st_, &g));
+          capturing = false; mA = sA; mB = sB;
+          hipGraphExec_t exec = nullptr;
+          HIP_CHECK(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
+          HIP_CHECK(hipGraphDestroy(g));
+          if (cg_graphs_.size() >= 8) {   // (the iterate alternates between two buffers: more than a few keys means something else varies)
+            (void)hipGraphExecDestroy(cg_graphs_.front().exec);
+            cg_graphs_.erase(cg_graphs_.begin());
+          }
+          cg_graphs_.push_back(CgGraph{key, exec});
+          step_graph = exec;
+        }
+      }
+      HIP_CHECK(hipGraphLaunch(step_graph, st_));
+      fetch_seq_ += 2;   // the two scalar kernels of the replay raise the flag to the device word + 1, + 2
+      return fetch_seq_;
+    };
+    const bool use_graph = cg_graph_wanted();
     // (the summary of a later step may already have overwritten the one waited for: the set only shrinks, so whatever
     // is read is a superset of the nodes that will still be live when the next launches run)
     auto any_live = [&]() {
@@ -318,8 +393,9 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
           wait_flag(seqB);
           if (!any_live()) break;
         }
-        stepA();
-        const unsigned long long next = stepB();
+        unsigned long long next;
+        if (use_graph) next = graph_step();
+        else { stepA(); next = stepB(); }
         if (lag) {
           wait_flag(seqB);   // the outcome of the step before the one just enqueued
           if (!any_live()) break;

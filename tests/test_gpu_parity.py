@@ -898,6 +898,9 @@ np.save(sys.argv[1], drv.X())
 
     base = run("base")
     assert np.array_equal(run("lag0", DPGO_CG_LAG="0"), base)
+    # round 4: the CG steps replayed from a captured HIP graph (the default for a group this small) against eager launches
+    assert np.array_equal(run("nograph", DPGO_CG_GRAPH="0"), base)
+    assert np.array_equal(run("nograph_lag0", DPGO_CG_GRAPH="0", DPGO_CG_LAG="0"), base)
     # the one-launch solve (an experiment that lost): the same tiles in the same order of operations
     assert np.array_equal(run("flow", DPGO_SPD_FLOW="1"), base)
     for tag, env in (("hostfactor", dict(DPGO_SPD_HOST_FACTOR="1")), ("hostpanels", dict(DPGO_SPD_DEVICE_PANELS="0")),

@@ -1,6 +1,7 @@
 # On the GPU box: the parity tests that exercise the iteration (fast subset), then the three headline numbers.
 # Usage: bash tools/quick_check.sh <tag> [full]
 tag=${1:-x}
+mkdir -p gpurun_out/$(dirname $tag)
 if [ "$2" = "full" ]; then
   timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/${tag}_tests.txt
 else

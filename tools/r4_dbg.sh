@@ -1,2 +1,2 @@
 mkdir -p gpurun_out/r4
-DPGO_AMD_LIB=$PWD/.ab/lib_nocontract.so python tools/probes/flow_diff.py > gpurun_out/r4/flow_diff.txt 2>&1
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k engineering_switches 2>&1 | grep -B30 "AssertionError" | head -80 > gpurun_out/r4/dbg.txt
