@@ -192,6 +192,7 @@ void Comm::init(const void *id128, bool layout) {
   }
   // AMM-PGO* and the global evaluations borrow the same buffers on the group's own stream
   if (grp->set_collectives(send_.p, gathered_.p, &Comm::cb_allgather, &Comm::cb_allreduce, this) != 0) return;
+  grp->set_device_allreduce(&Comm::cb_allreduce_dev);   // (sums that are born on the device stay there: Group::star_sums)
   ok_ = true;
 }
 
@@ -204,6 +205,7 @@ void Comm::release() {
     if (ev_done_ && !broken_) (void)hipEventSynchronize(ev_done_);
     grp_->set_pending_exchange(nullptr);
     grp_->set_collectives(nullptr, nullptr, nullptr, nullptr, nullptr);
+    grp_->set_device_allreduce(nullptr);
   }
   // (a communicator whose stream ran into a deadline holds a kernel that will never end: it is aborted, not waited for)
   if (broken_ && comm_ && rccl().CommAbort) { (void)rccl().CommAbort((ncclComm_t)comm_); comm_ = nullptr; }
@@ -497,6 +499,17 @@ int Comm::cb_allgather(void *user) {
   try {
     NCCL_OK(rccl().AllGather(c->send_.p, c->gathered_.p, (size_t)c->stride_ * RS, ncclFloat64, (ncclComm_t)c->comm_,
                              c->grp_->stream()));
+  } catch (const std::exception &) {
+    return -1;
+  }
+  return 0;
+}
+
+// in-place sum of n device doubles over the ranks, enqueued on the group's stream: no host in between
+int Comm::cb_allreduce_dev(void *user, double *dev_vals, int n) {
+  Comm *c = static_cast<Comm *>(user);
+  try {
+    NCCL_OK(rccl().AllReduce(dev_vals, dev_vals, (size_t)n, ncclFloat64, ncclSum, (ncclComm_t)c->comm_, c->grp_->stream()));
   } catch (const std::exception &) {
     return -1;
   }

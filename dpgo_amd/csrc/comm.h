@@ -49,6 +49,7 @@ class Comm {
   void release();
   static int cb_allgather(void *user);
   static int cb_allreduce(void *user, double *vals, int n);
+  static int cb_allreduce_dev(void *user, double *dev_vals, int n);
   Group *grp_ = nullptr;
   int rank_ = 0, nranks_ = 1, stride_ = 1;
   bool ok_ = false;

@@ -1675,6 +1675,7 @@ int Group::set_collectives(double *send_dev, double *gathered_dev, AllGatherFn a
   coll_gathered_ = gathered_dev;
   coll_allgather_ = ag;
   coll_allreduce_ = ar;
+  coll_allreduce_dev_ = nullptr;   // (belongs to whoever lends the collectives: set again by set_device_allreduce)
   coll_user_ = user;
   return 0;
 }
@@ -2300,32 +2301,57 @@ namespace dpgo {
 // Global objective F(X) (DPGOStar::evaluate_f, :713-761) at the point whose own rows are X_own:
 // neighbour rows are gathered from the same trial vector, every node evaluates its intra edges and
 // its inter edges (charged 1/2 per node), the host adds the per-node sums (the master's aggregate).
-double Group::global_objective(const double *X_own) {
-  std::vector<int> all(num_local());
-  for (int a = 0; a < num_local(); a++) all[a] = a;
-  set_mask(all);
+void Group::enqueue_objective(const double *X_own, int slot0) {
   copy_rows(Tall_.p, X_own, false, 0);
   launch_copy_indexed(d_, st_, (int)gather_dst_.n, gather_dst_.p, gather_src_.p, Tall_.p, Tall_.p);
   if (coll_allgather_) {   // boundary poses of the trial point hosted by other groups
     launch_copy_indexed(d_, st_, (int)sent_rows_.size(), nullptr, sent_rows_dev_.p, X_own, coll_send_);
-    if (coll_allgather_(coll_user_) != 0) { fprintf(stderr, "[dpgo_amd] ERROR: all-gather callback failed.\n"); return NAN; }
+    if (coll_allgather_(coll_user_) != 0) throw DeviceError("all-gather callback failed");
     launch_copy_indexed(d_, st_, (int)recv_dst_.n, recv_dst_.p, recv_src_.p, coll_gathered_, Tall_.p);
   }
-  launch_cost(d_, st_, T_, cur_mask_, Ei_, E_, opt_.loss == 0, opt_.loss, opt_.loss_reg, Tall_.p, partials_.p, 0);
-  fetch(2, true);
-  double F = 0;
-  for (int a = 0; a < num_local(); a++) F += 0.5 * scal(a, 0) + 0.25 * scal(a, 1);
-  if (coll_allreduce_ && coll_allreduce_(coll_user_, &F, 1) != 0) return NAN;
-  return F;
+  launch_cost(d_, st_, T_, cur_mask_, Ei_, E_, opt_.loss == 0, opt_.loss, opt_.loss_reg, Tall_.p, partials_.p, slot0);
 }
 
-double Group::global_sqdist(const double *A_own, const double *B_own) {
-  launch_sqdist(d_, st_, T_, cur_mask_, A_own, B_own, partials_.p, 0);
-  fetch(1, false);
-  double s = 0;
-  for (int a = 0; a < num_local(); a++) s += scal(a, 0);
-  if (coll_allreduce_ && coll_allreduce_(coll_user_, &s, 1) != 0) return NAN;
-  return s;
+// Everything the master's tests of one AMM-PGO* iteration need (DPGOStar.cpp:147-192), enqueued back to back and read
+// ONCE: the passes leave their partial sums in slots 0..5, k_star_sums folds them over the nodes on the device, the sum
+// over the groups -- if there are several -- is an all-reduce on the same stream (set_device_allreduce) or, for a host
+// that lent only host collectives, one call after the read-back; k_publish raises the flag.  (Before: up to four
+// read-backs and as many host-staged all-reduces per iteration.)
+int Group::star_sums(const double *X1_own, const double *X2_own, const double *ref_own, double *F1, double *F2, double *d1, double *d2) {
+  finish_update();
+  std::vector<int> all(num_local());
+  for (int a = 0; a < num_local(); a++) all[a] = a;
+  set_mask(all);
+  if (star_vals_.n == 0) star_vals_.alloc(8);
+  // Slots: update() and evaluate_global() reduce slots 0..2 over ALL rows and count on the neighbour segments of slot 2
+  // never having been written; k_cost writes every segment of its two slots.  So the first point's pair is 0, 1 (as it
+  // always was) and the second point's pair the last two slots, which nobody else touches; the distances are own-row sums.
+  static const int slots[6] = {0, 1, MAX_SLOTS - 2, MAX_SLOTS - 1, 4, 5};
+  unsigned valid = 0;
+  if (F1) { enqueue_objective(X1_own, slots[0]); valid |= 0x3; }
+  if (X2_own && F2) { enqueue_objective(X2_own, slots[2]); valid |= 0xc; }
+  if (ref_own) {
+    if (d1) { launch_sqdist(d_, st_, T_, cur_mask_, X1_own, ref_own, partials_.p, slots[4]); valid |= 0x10; }
+    if (X2_own && d2) { launch_sqdist(d_, st_, T_, cur_mask_, X2_own, ref_own, partials_.p, slots[5]); valid |= 0x20; }
+  }
+  launch_star_sums(st_, T_, num_local(), valid, slots, partials_.p, star_vals_.p);
+  const bool dev_sum = coll_allreduce_dev_ != nullptr;
+  if (dev_sum && coll_allreduce_dev_(coll_user_, star_vals_.p, 4) != 0) return -1;
+  launch_publish(st_, star_vals_.p, 4, h_scal_, h_flag_, ++fetch_seq_);
+  wait_flag(fetch_seq_);
+  double v[4] = {h_scal_[0], h_scal_[1], h_scal_[2], h_scal_[3]};
+  if (!dev_sum && coll_allreduce_ && coll_allreduce_(coll_user_, v, 4) != 0) return -1;
+  if (F1) *F1 = v[0];
+  if (F2) *F2 = v[1];
+  if (d1) *d1 = v[2];
+  if (d2) *d2 = v[3];
+  return 0;
+}
+
+double Group::global_objective(const double *X_own) {
+  double F = NAN;
+  if (star_sums(X_own, nullptr, nullptr, &F, nullptr, nullptr, nullptr) != 0) return NAN;
+  return F;
 }
 
 int Group::star_initialize_global(const double *X, int ld) {
@@ -2377,17 +2403,18 @@ int Group::star_iterate() {
   copy_rows(Xak_.p, Xakh_.p, false, 2);
   recover_translations(Xak_.p, gx_.p);
   if (!ref.empty()) run_tnt(ref, Xak_.p, gx_.p, nullptr, true);
-  // ---- the master's tests (:147-192); Xk = own rows of X[k] (Zc_)
-  double fobjh = global_objective(Xakh_.p);
+  // ---- the master's tests (:147-192); Xk = own rows of X[k] (Zc_).  The two objectives and the two distances of the
+  // common path come with one read-back (the first test's branch changes Xakh only, so F(Xak) may be taken before it)
+  double fobjh = NAN, fobj = NAN, sqh = NAN, sq = NAN;
+  if (star_sums(Xakh_.p, Xak_.p, Zc_.p, &fobjh, &fobj, &sqh, &sq) != 0) return -1;
   set_mask(all);
-  if (fobjh > starF_ - o.psi * global_sqdist(Xakh_.p, Zc_.p)) {
+  if (fobjh > starF_ - o.psi * sqh) {
     star_branches_ |= 1;   // pm_pgo_n (:685-711)
     launch_proximal(d_, st_, T_, cur_mask_, Zc_.p, Dfc_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, nullptr, nullptr, 0);
     fobjh = global_objective(Xakh_.p);
   }
-  double fobj = global_objective(Xak_.p);
   set_mask(all);
-  if (fobj > starF_ - o.psi * global_sqdist(Xak_.p, Zc_.p)) {
+  if (fobj > starF_ - o.psi * sq) {
     star_branches_ |= 2;   // mm_pgo_n (:552-683) and halve s
     copy_rows(Xak_.p, Xakh_.p, false, 2);
     recover_translations(Xak_.p, gc_.p);

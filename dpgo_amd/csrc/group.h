@@ -248,6 +248,10 @@ class Group {
   typedef int (*AllGatherFn)(void *user);
   typedef int (*AllReduceFn)(void *user, double *vals, int n);
   int set_collectives(double *send_dev, double *gathered_dev, AllGatherFn ag, AllReduceFn ar, void *user);
+  // optional: an in-place sum of n DEVICE doubles over the groups, enqueued on this group's stream (RCCL: comm.cpp).  With
+  // it AMM-PGO*'s master sums never visit the host between the kernels that produce them and the one read-back.
+  typedef int (*AllReduceDevFn)(void *user, double *dev_vals, int n);
+  void set_device_allreduce(AllReduceDevFn f) { coll_allreduce_dev_ = f; }
   // results
   int get_Xk(int local, double *X, int ld) const;       // (d+1)(n0+n1) x d column-major
   int get_X_own(int local, double *X, int ld) const;    // Xak: (d+1) n0 x d
@@ -353,13 +357,17 @@ class Group {
   double *coll_send_ = nullptr, *coll_gathered_ = nullptr;
   AllGatherFn coll_allgather_ = nullptr;
   AllReduceFn coll_allreduce_ = nullptr;
+  AllReduceDevFn coll_allreduce_dev_ = nullptr;
+  DevBuf<double> star_vals_;   // AMM-PGO*: the master's four sums on the device (k_star_sums)
   void *coll_user_ = nullptr;
   double starF_ = 0, star_fobj_ = 0, star_fobjh_ = 0;
   int star_branches_ = 0;
   void node_rows_of_global(int a, const double *X, int ld, std::vector<double> &Z) const;
   void prepare_extrapolated();                             // Y, g_x, Df_x for the masked nodes
   double global_objective(const double *X_own);           // F at the point whose own rows are X_own
-  double global_sqdist(const double *A_own, const double *B_own);
+  // the master's numbers in ONE read-back: F(X1) [, F(X2)] [, |X1 - ref|^2, |X2 - ref|^2] (null pointers: not wanted)
+  int star_sums(const double *X1_own, const double *X2_own, const double *ref_own, double *F1, double *F2, double *d1, double *d2);
+  void enqueue_objective(const double *X_own, int slot0);   // k_cost partials of the point into slots slot0, slot0 + 1
 
   void upload_bsr(const std::vector<const BsrMatrix *> &per_node, bool rows_all, BsrBufs &out);
   void upload_operators();

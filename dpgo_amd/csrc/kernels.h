@@ -223,6 +223,12 @@ void launch_bdiag_dot(int d, hipStream_t st, const SegTable &T, NodeMask mask, c
 void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows, int nslots, const double *partials,
                    double *host_scalars, unsigned *arrived, unsigned long long *host_flag, unsigned long long seq);
 
+// AMM-PGO*'s master sums (k_star_sums): out[0..3] (device) from the partial slots 0..5; launch_publish: n <= 64 device values
+// to pinned host memory, then *host_flag = seq
+void launch_star_sums(hipStream_t st, const SegTable &T, int nnodes, unsigned valid_slots, const int *slots6, const double *partials,
+                      double *out);   // valid_slots: bit q = sum q was produced; slots6[q]: the partial-sum slot it is in
+void launch_publish(hipStream_t st, const double *vals, int n, double *host, unsigned long long *host_flag, unsigned long long seq);
+
 // ---- device-side control of the truncated CG (tnt.cpp) ----
 constexpr int CG_SUMMARY = 4;    // doubles per node k_cg_scal writes to pinned memory: live, |h|_M, iterations
 constexpr int TNT_SUMMARY = 8;   // doubles per node k_tnt_begin writes: the six sums it reduced, then `active`

@@ -2498,6 +2498,60 @@ void launch_bdiag_dot(int d, hipStream_t st, const SegTable &T, NodeMask mask, c
                                         coef, add, addcoef, partials + (size_t)slot * T.nseg_all));
 }
 
+// ---- AMM-PGO*: the master's sums on the device (DPGOStar.cpp:147-192, 713-761) ---------------------------------------
+// The global objective of up to two trial points and up to two squared distances, from the partial sums their passes left
+// (six partial-sum slots: k_cost's intra and inter sums of point 1 / 2, over all rows; k_sqdist's of pair 1 / 2, own rows):
+//   out[0] = sum_a 1/2 s0 + 1/4 s1,  out[1] = sum_a 1/2 s2 + 1/4 s3,  out[2] = sum_a s4,  out[3] = sum_a s5
+// One wave per slot sums a node's partials in k_reduce's order, one thread adds the nodes in index order: the same
+// numbers whatever the schedule.  The four values stay in device memory -- an all-reduce over the groups can follow on
+// the same stream -- and k_publish hands them to the host with the usual flag.
+struct StarSlots { int s[6]; };   // where the six partial sums are (the second point's pair lives in slots nobody else reduces over all rows)
+__global__ __launch_bounds__(384) void k_star_sums(SegTable T, int nnodes, unsigned valid, StarSlots sl, const double *partials, double *out) {
+  __shared__ double ns[6][MAX_LOCAL_NODES];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double *p = partials + (size_t)sl.s[wv] * T.nseg_all;
+  const bool on = (valid >> wv) & 1u;   // (a slot no pass has filled counts as zero)
+  for (int a = 0; a < nnodes; a++) {
+    double v = 0;
+    if (on) {
+      for (int k = T.own_ptr[a] + lane; k < T.own_ptr[a + 1]; k += 64) v += p[k];
+      if (wv < 4)
+        for (int k = T.nbr_ptr[a] + lane; k < T.nbr_ptr[a + 1]; k += 64) v += p[k];
+    }
+    v = wave_sum(v);
+    if (lane == 0) ns[wv][a] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double f1 = 0, f2 = 0, d1 = 0, d2 = 0;
+    for (int a = 0; a < nnodes; a++) {
+      f1 += 0.5 * ns[0][a] + 0.25 * ns[1][a];
+      f2 += 0.5 * ns[2][a] + 0.25 * ns[3][a];
+      d1 += ns[4][a];
+      d2 += ns[5][a];
+    }
+    out[0] = f1; out[1] = f2; out[2] = d1; out[3] = d2;
+  }
+}
+__global__ void k_publish(const double *vals, int n, double *host, unsigned long long *host_flag, unsigned long long seq) {
+  if (threadIdx.x < n) __hip_atomic_store(host + threadIdx.x, vals[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+void launch_star_sums(hipStream_t st, const SegTable &T, int nnodes, unsigned valid_slots, const int *slots6, const double *partials, double *out) {
+  ProfScope ps(PK_REDUCE, st, 8.0 * 6 * T.nseg_all);
+  StarSlots sl;
+  for (int q = 0; q < 6; q++) sl.s[q] = slots6[q];
+  hipLaunchKernelGGL(k_star_sums, dim3(1), dim3(384), 0, st, T, nnodes, valid_slots, sl, partials, out);
+}
+void launch_publish(hipStream_t st, const double *vals, int n, double *host, unsigned long long *host_flag, unsigned long long seq) {
+  ProfScope ps(PK_REDUCE, st, 8.0 * n);
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, vals, n, host, host_flag, seq);
+}
+
 void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows, int nslots, const double *partials,
                    double *host_scalars, unsigned *arrived, unsigned long long *host_flag, unsigned long long seq) {
   ProfScope ps(PK_REDUCE, st, 8.0 * nslots * T.nseg_all);

@@ -1,2 +1,3 @@
 mkdir -p gpurun_out/r4
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k engineering_switches 2>&1 | grep -B30 "AssertionError" | head -80 > gpurun_out/r4/dbg.txt
+python tools/probes/star_trace.py 2>&1 | md5sum > gpurun_out/r4/star_det.txt
+DPGO_STAR_BATCH=0 python tools/probes/star_trace.py 2>&1 | md5sum >> gpurun_out/r4/star_det.txt
