@@ -428,13 +428,21 @@ def main():
             step()
         barrier()
         stats = dpgo_amd.prof_collect()
+        operands = dpgo_amd.prof_collect_operands()
         dpgo_amd.prof_enable(False)
         tot = sum(v[0] for v in stats.values())
         for name, (ms, by, cnt) in sorted(stats.items(), key=lambda kv: -kv[1][0]):
             if cnt:
                 kernels[name] = dict(ms_per_step=ms / args.prof_steps, launches_per_step=cnt / args.prof_steps,
                                      avg_us=1e3 * ms / cnt, algo_MB_per_launch=by / cnt / 1e6,
-                                     GBps=(by / 1e9) / (ms / 1e3) if ms > 0 else 0.0, share=ms / tot)
+                                     GBps=(by / 1e9) / (ms / 1e3) if ms > 0 else 0.0, share=ms / tot,
+                                     frac_of_hbm_peak=((by / 1e9) / (ms / 1e3) / HBM_PEAK_GBS) if ms > 0 else 0.0)
+                # the fused passes: SURVEY 8(d)'s formula prices a bare residual / proximal pass; what the kernel has to move,
+                # operand by operand (its per-pose blocks, the previous iterate, the halo copy ...), is reported beside it
+                if operands.get(name, 0.0) > 0 and ms > 0:
+                    kernels[name].update(operand_MB_per_launch=operands[name] / cnt / 1e6,
+                                         GBps_operands=(operands[name] / 1e9) / (ms / 1e3),
+                                         frac_of_hbm_peak_operands=(operands[name] / 1e9) / (ms / 1e3) / HBM_PEAK_GBS)
         dom = max(stats.items(), key=lambda kv: kv[1][0])
         ms, by, cnt = dom[1]
         ach = (by / 1e9) / (ms / 1e3)

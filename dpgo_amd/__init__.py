@@ -184,6 +184,7 @@ SYMBOLS = {
     "dpgo_prof_num_kinds": (C.c_int, []),
     "dpgo_prof_kind_name": (C.c_char_p, [C.c_int]),
     "dpgo_prof_collect": (C.c_int, [_DP, _DP, C.POINTER(C.c_long)]),
+    "dpgo_prof_collect_operands": (C.c_int, [_DP]),
     "dpgo_group_solver_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long), _IP, _IP]),
     "dpgo_debug_node_matrix": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Options), C.c_char_p, _IP, _IP, _DP]),
     "dpgo_debug_node_proximal": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Options), _DP, _DP, _DP]),
@@ -388,6 +389,15 @@ def prof_collect():
     ms, by, cnt = np.zeros(n), np.zeros(n), np.zeros(n, np.int64)
     lib().dpgo_prof_collect(_dp(ms), _dp(by), cnt.ctypes.data_as(C.POINTER(C.c_long)))
     return {lib().dpgo_prof_kind_name(k).decode(): (float(ms[k]), float(by[k]), int(cnt[k])) for k in range(n)}
+
+
+def prof_collect_operands():
+    """{kernel family: bytes of every operand its launches moved, counted one by one} -- non-zero for the fused passes
+    (k_inter, k_proximal), whose duties SURVEY 8(d)'s per-unit formula does not price."""
+    n = lib().dpgo_prof_num_kinds()
+    ob = np.zeros(n)
+    lib().dpgo_prof_collect_operands(_dp(ob))
+    return {lib().dpgo_prof_kind_name(k).decode(): float(ob[k]) for k in range(n)}
 
 
 def spd_stats(A_csr, leaf):

@@ -425,10 +425,12 @@ int dpgo_prof_enable(int on) { dpgo::prof_enable(on != 0); if (on) dpgo::prof_re
 int dpgo_prof_num_kinds(void) { return dpgo::PK_COUNT; }
 const char *dpgo_prof_kind_name(int k) {
   static const char *names[] = {"k_bsr", "k_inter", "k_proximal", "k_axpby", "k_dot", "k_rot_op", "k_copy_indexed",
-                                "k_bdiag_dot", "k_reduce", "k_spd_fwd", "k_spd_bwd", "k_spd_flow"};
+                                "k_bdiag_dot", "k_reduce", "k_spd_fwd", "k_spd_bwd", "k_spd_flow", "k_bsr_tcol"};
+  static_assert(sizeof(names) / sizeof(names[0]) == dpgo::PK_COUNT, "one name per profiled kernel family");
   return (k >= 0 && k < dpgo::PK_COUNT) ? names[k] : "";
 }
 int dpgo_prof_collect(double *ms, double *bytes, long *count) { dpgo::prof_collect(ms, bytes, count); return 0; }
+int dpgo_prof_collect_operands(double *operand_bytes) { if (!operand_bytes) return -1; dpgo::prof_collect_operands(operand_bytes); return 0; }
 int dpgo_group_solver_stats(const dpgo_group_t *h, long *nnz_tt, long *nnz_rr, int *levels_tt, int *levels_rr) {
   *nnz_tt = (long)h->grp->factor_tt().nnz();
   *nnz_rr = (long)h->grp->factor_rr().nnz();

@@ -174,6 +174,7 @@ void Group::chordal_release() {
 // + 2 tau per inter edge + xi, g_ from the fixed rotations R (per node (n0 + n1) d x d blocks, Y = R^T as everywhere).
 int Group::chordal_setup(int kind, double xi, const std::vector<std::vector<double>> &R) {
   chordal_release();
+  zc_ready_ = false;   // (the stages use the history buffers as their own)
   ch_ = new ChordalState();
   ch_->kind = kind;
   const int L = num_local(), d = d_, B = B_;

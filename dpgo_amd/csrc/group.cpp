@@ -1056,7 +1056,13 @@ void Group::sync() const {
 void Group::check_tt_verdict(bool wait) const {
   if (!tt_verdict_pending_) return;
   tt_verdict_pending_ = false;
-  if (spd_refactor_finish(const_cast<SpdFactor &>(Ltt_.F), wait) != 0) throw DeviceError("G_tt is not positive definite after a rescale");
+  // (DPGO_DEBUG_FAIL_REFACTOR=1, a test hook: the verdict counts as "not positive definite")
+  static const bool forced = env_int("DPGO_DEBUG_FAIL_REFACTOR", 0) != 0;
+  if (spd_refactor_finish(const_cast<SpdFactor &>(Ltt_.F), wait) != 0 || forced) {
+    failed_ = true;
+    fprintf(stderr, "[dpgo_amd] ERROR: G_tt is not positive definite after a rescale; the group cannot go on (create a new one).\n");
+    throw DeviceError("G_tt is not positive definite after a rescale");
+  }
 }
 
 // The nodes the following launches work on: a bit mask passed to every kernel by value (no upload).
@@ -1369,6 +1375,7 @@ static void from_records(int d, int n, const double *rec, double *X, int ld, int
 
 int Group::initialize(int a, const double *X, int ld) {
   finish_update();
+  zc_ready_ = false;   // (whatever an earlier iterate() left in the history buffers is overwritten here)
   if (a < 0 || a >= num_local()) return -1;
   const int n0 = info_[a].n[0], n1 = info_[a].n[1];
   if (ld < (d_ + 1) * (n0 + n1)) {
@@ -1871,6 +1878,7 @@ std::vector<int> Group::rescale_device(const std::vector<int> &set) {
 }
 
 int Group::update(const std::vector<int> &locals_in) {
+  if (failed_) return -1;
   finish_update();
   std::vector<int> locals;
   for (int a : locals_in)
@@ -2031,6 +2039,7 @@ int Group::update(const std::vector<int> &locals_in) {
 // DPGOHash::iterate  (DPGOHash.cpp:583-628)
 // ---------------------------------------------------------------------------
 int Group::iterate(const std::vector<int> &locals) {
+  if (failed_) return -1;
   for (int a : locals)
     if (!res_[a].updated) {
       fprintf(stderr, "[dpgo_amd] ERROR: The optimizer has not been updated (node %d).\n", nodes_[a]);

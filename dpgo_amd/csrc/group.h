@@ -277,6 +277,11 @@ class Group {
 
  private:
   bool ok_ = false;
+  // A Dynamic rescale on the device commits its scales before the verdict on the new factor of G_tt is in (the host never
+  // waits for it: rescale_device).  A non-positive pivot -- which the reference reports from inside its CHOLMOD call --
+  // therefore leaves the group with operators it cannot solve with: it is marked failed and every later update() /
+  // iterate() returns -1 (a new group is the way on; nothing is silently computed with a broken factor).
+  mutable bool failed_ = false;
   int d_ = 0, RS_ = 0, B_ = 0, device_ = 0;
   Options opt_;
   std::vector<int> nodes_;

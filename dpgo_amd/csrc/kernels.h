@@ -356,7 +356,7 @@ void launch_root_combine(int d, int dof, hipStream_t st, const SpdDev &S, const 
 
 // ---- optional per-launch timing (HIP events on the launch stream), off by default ----
 enum ProfKind { PK_BSR = 0, PK_INTER, PK_PROX, PK_AXPBY, PK_DOT, PK_ROTOP, PK_COPYIDX, PK_BDIAG, PK_REDUCE,
-                PK_SPD_FWD, PK_SPD_BWD, PK_SPD_FLOW, PK_COUNT };
+                PK_SPD_FWD, PK_SPD_BWD, PK_SPD_FLOW, PK_BSR_TCOL, PK_COUNT };
 void prof_enable(bool on);
 // One timing scope around the back-to-back launches of a solve sweep (profiling pass only; nothing otherwise)
 struct ProfSweep {
@@ -369,5 +369,8 @@ struct ProfSweep {
 };
 void prof_reset();
 void prof_collect(double *ms, double *bytes, long *count);
+// ... and, for the fused passes (k_inter, k_proximal), the bytes of every operand the pass has to move, counted one by one
+// (DESIGN 7): SURVEY 8(d)'s formula prices a bare residual pass, the kernels also carry the surrogate's per-pose blocks
+void prof_collect_operands(double *operand_bytes);
 
 }  // namespace dpgo

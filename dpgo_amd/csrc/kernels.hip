@@ -2186,6 +2186,7 @@ struct Prof {
   size_t used = 0;
   double ms[PK_COUNT] = {0};
   double bytes[PK_COUNT] = {0};
+  double obytes[PK_COUNT] = {0};   // operand-by-operand bytes of the fused passes
   long count[PK_COUNT] = {0};
   int nested = 0;
   void flush() {
@@ -2205,7 +2206,7 @@ struct ProfScope {
   bool on;
   // n launches share the scope (a sweep of the solve: one event pair around its back-to-back launches, so that the
   // events do not sit between the kernels they time); scopes opened inside such a scope do nothing
-  ProfScope(int kind, hipStream_t s, double bytes, int n = 1) : st(s), on(g_prof.on && g_prof.nested == 0) {
+  ProfScope(int kind, hipStream_t s, double bytes, int n = 1, double operand_bytes = 0.0) : st(s), on(g_prof.on && g_prof.nested == 0) {
     if (g_prof.on && n > 1) { g_prof.nested++; outer = true; }
     if (!on) return;
     if (g_prof.used == g_prof.kind.size()) {
@@ -2222,6 +2223,7 @@ struct ProfScope {
     g_prof.kind[g_prof.used] = kind;
     g_prof.count[kind] += n;
     g_prof.bytes[kind] += bytes;
+    g_prof.obytes[kind] += operand_bytes;
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
   }
   bool outer = false;
@@ -2251,6 +2253,9 @@ void prof_reset() {
 void prof_collect(double *ms, double *bytes, long *count) {
   g_prof.flush();
   for (int k = 0; k < PK_COUNT; k++) { ms[k] = g_prof.ms[k]; bytes[k] = g_prof.bytes[k]; count[k] = g_prof.count[k]; }
+}
+void prof_collect_operands(double *operand_bytes) {
+  for (int k = 0; k < PK_COUNT; k++) operand_bytes[k] = g_prof.obytes[k];
 }
 
 // ---------------------------------------------------------------------------
@@ -2289,7 +2294,7 @@ void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, co
                      const double *Rdot, double *out2, const double *rres, double *partials, const double *dg,
                      const double *dga, const double *ds, const double *dgrad, const double *dhs) {
   if (T.nseg_own == 0) return;
-  ProfScope ps(PK_BSR, st, (double)A.nnzb * (8.0 * (d + 1) + 4 + 8.0 * d) + 2.0 * A.nrows * 8.0 * (d + 1) * d);
+  ProfScope ps(PK_BSR_TCOL, st, (double)A.nnzb * (8.0 * (d + 1) + 4 + 8.0 * d) + 2.0 * A.nrows * 8.0 * (d + 1) * d);
   TcolDots E;
   E.g = dg; E.ga = dga; E.s = ds; E.grad = dgrad; E.hs = dhs;
   // which epilogue sums are produced: mode 2 with rres (a CG step's four), mode 1 with dg (a refinement's start), mode 0 with ds (a trial point's six)
@@ -2304,7 +2309,17 @@ void launch_inter(int d, hipStream_t st, const SegTable &T, NodeMask mask, const
                   const double *GXc, const double *GXp, const NodeCoefs *gamma, double *Df_out, const double *Znbr) {
   const int nb = mode == 0 ? T.nseg_all : T.nseg_own;
   if (nb == 0) return;
-  ProfScope ps(PK_INTER, st, (double)E.m * (8.0 * (d * d + d + 2) + 8) + 2.0 * (mode == 0 ? E.nrows_all : E.nrows_own) * 8.0 * (d + 1) * d);
+  // operand by operand: per incidence its 128-byte record and the other endpoint's pose; per own pose its record, the previous
+  // iterate (majorisation gap), the previous DfobjE read and the new one written, the Q and D blocks, g written, the
+  // incidence pointer, and (iterate()) the two kept products G X read and Df written; per neighbour row the same without
+  // D and g but with the halo copy it performs on the way
+  const double P = 8.0 * (d + 1) * d, B = 8.0 * (d + 1) * (d + 1);
+  const double own_b = P + (Zprev ? P : 0) + (DfE ? 2 * P : 0) + (Qdiag ? B : 0) + (Ddiag ? B : 0) + (g ? P : 0) + 8 +
+                       ((mode == 1 && Df_out && GXc && GXp) ? 3 * P : 0);
+  const double nbr_b = P + (Zprev ? P : 0) + (DfE ? 2 * P : 0) + (Qdiag ? B : 0) + 8 + (Znbr ? 2 * P : 0);
+  const double operands = (double)E.m * (mode == 0 ? 2 : 1) * (128.0 + P) + (double)E.nrows_own * own_b +
+                          (mode == 0 ? (double)(E.nrows_all - E.nrows_own) * nbr_b : 0.0);
+  ProfScope ps(PK_INTER, st, (double)E.m * (8.0 * (d * d + d + 2) + 8) + 2.0 * (mode == 0 ? E.nrows_all : E.nrows_own) * 8.0 * (d + 1) * d, 1, operands);
   InterLin lin;
   if (mode == 1 && Df_out && GXc && GXp && gamma) { lin.GXc = GXc; lin.GXp = GXp; lin.out = Df_out; lin.gamma = *gamma; }
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_inter<D>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, E, loss, loss_reg,
@@ -2348,7 +2363,10 @@ void launch_proximal(int d, hipStream_t st, const SegTable &T, NodeMask mask, co
                      double *partials, int slot) {
   if (T.nseg_own == 0) return;
   double *part = (Xref && partials) ? partials + (size_t)slot * T.nseg_all : nullptr;
-  ProfScope ps(PK_PROX, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
+  // operand by operand: Z, Df and Xout records, the coefficients T (1), N (d), V (d x d) and, with Xref, its record read and
+  // its rotation rows written
+  ProfScope ps(PK_PROX, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d, 1,
+               (double)T.rows_own * (3.0 * 8.0 * (d + 1) * d + 8.0 * (1 + d + d * d) + (part ? 8.0 * (d + 1) * d + 8.0 * d * d : 0.0)));
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_proximal<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, Z, Df,
                                         Tinv, N, V, Xout, part ? Xref : nullptr, part));
 }

@@ -19,6 +19,7 @@
 // atomic-free.  W is kept in both orientations so both sweeps read coalesced.
 #pragma once
 #include <cstdint>
+#include <utility>
 #include <vector>
 
 namespace dpgo {
@@ -31,7 +32,7 @@ struct CsrMatrix {
   std::vector<double> val;
 };
 
-struct SpdFactor {
+struct SpdFactorData {
   int n = 0;
   int nfronts = 0;
   std::vector<int> w, u;                 // pivots / update rows per front
@@ -62,6 +63,24 @@ struct SpdFactor {
   int leaf = 32, collapse = 0, block = 1;   // the parameters this factor was built with (spd_refactor's host path repeats them)
   double *dev_W = nullptr, *dev_WT = nullptr;
   int64_t nnz() const { return entries; }
+};
+// The factor OWNS `numeric` and (unless borrowed from it) dev_W / dev_WT -- released by spd_release_numeric /
+// spd_release_device, which the holder calls -- so a copy would free them twice: factors move, they are never copied.
+struct SpdFactor : SpdFactorData {
+  SpdFactor() = default;
+  SpdFactor(const SpdFactor &) = delete;
+  SpdFactor &operator=(const SpdFactor &) = delete;
+  SpdFactor(SpdFactor &&o) noexcept : SpdFactorData(std::move(static_cast<SpdFactorData &>(o))) { o.disown(); }
+  SpdFactor &operator=(SpdFactor &&o) noexcept {
+    if (this != &o) {
+      static_cast<SpdFactorData &>(*this) = std::move(static_cast<SpdFactorData &>(o));
+      o.disown();
+    }
+    return *this;
+  }
+
+ private:
+  void disown() { numeric = nullptr; dev_W = dev_WT = nullptr; dev_borrowed = false; }
 };
 
 // Factor A (symmetric positive definite, full pattern in CSR).  leaf = max

@@ -263,6 +263,8 @@ int dpgo_prof_enable(int on);
 int dpgo_prof_num_kinds(void);
 const char *dpgo_prof_kind_name(int kind);
 int dpgo_prof_collect(double *ms, double *bytes, long *count);   /* arrays of dpgo_prof_num_kinds() */
+/* for the fused passes (k_inter, k_proximal): the bytes of every operand they move, counted one by one (0 for the others) */
+int dpgo_prof_collect_operands(double *operand_bytes);
 /* size of the two multifrontal factors: dense front entries and number of tree levels */
 int dpgo_group_solver_stats(const dpgo_group_t *grp, long *nnz_tt, long *nnz_rr, int *levels_tt, int *levels_rr);
 

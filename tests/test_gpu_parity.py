@@ -953,3 +953,27 @@ def test_fp32_preconditioner_experiment_reaches_the_same_objective(fixtures_dir,
     Fo = orc.star.evaluate_f(orc.gather())
     assert abs(finals["0"] - Fo) <= 1e-6 * abs(Fo)
     assert abs(finals["1"] - Fo) <= 1e-6 * abs(Fo)
+
+
+def test_failed_refactorisation_after_a_rescale_fails_the_group(fixtures_dir, tmp_path):
+    """Rescale::Dynamic on the device commits its scales before the verdict on the re-factored G_tt is read (the host never
+    waits for it).  A non-positive pivot there -- which the reference reports from inside its Cholesky call
+    (DPGOProblem.cpp:315, 479) -- must not leave a half-updated group computing on a broken factor: the call that reads
+    the verdict returns -1 and so does every update() / iterate() after it.  (The verdict is forced by a test hook.)"""
+    import subprocess
+    import sys
+    code = """
+import sys
+sys.path.insert(0, %r)
+import dpgo_amd
+G = dpgo_amd.read_g2o(%r, 2)
+drv = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(1, True, rescale=1))
+rcs = [drv.step() for _ in range(12)]
+first = next(i for i, r in enumerate(rcs) if r != 0)
+assert all(r != 0 for r in rcs[first:]), rcs
+assert drv.group.iterate() == -1 and drv.group.update() == -1
+print("failed at step", first)
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(fixtures_dir, "smallGrid3D.g2o"))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DPGO_DEBUG_FAIL_REFACTOR="1"), capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "failed at step" in out.stdout and "not positive definite after a rescale" in out.stderr

@@ -28,8 +28,9 @@ def family(name):
         a = re.search(r"k_spd_level<([^>]*)>", name)   # (the bench's profiler counts the roots with the forward sweep)
         fwd = a is not None and a.group(1).split(",")[3].strip() in ("0", "2")
         return "k_spd_fwd" if fwd else "k_spd_bwd"
+    # (the roots stored as one triangle and their combine pass are part of the forward sweep's scope in the bench's profiler)
     return {"k_cg_init": "k_axpby", "k_extrapolate": "k_axpby", "k_axpby_node": "k_axpby", "k_dots": "k_dot",
-            "k_tangent_full": "k_rot_op"}.get(n, n)
+            "k_tangent_full": "k_rot_op", "k_root_sym": "k_spd_fwd", "k_root_combine": "k_spd_fwd"}.get(n, n)
 
 
 def collect(d, counter):
