@@ -735,7 +735,7 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   for (int i = 0; i < std::max(L, 1) * (CG_SUMMARY + TNT_SUMMARY + 1); i++) h_cg_[i] = 0.0;
   reduce_arrived_.alloc(1);
   partials_.alloc((size_t)MAX_SLOTS * std::max(T_.nseg_all, 1));
-  cg_.alloc(MAX_LOCAL_NODES);
+  cg_.alloc(2 * MAX_LOCAL_NODES);   // two state buffers: a fused scalar + vector step reads one and writes the other (tnt.cpp)
   dmask_.alloc(4);
   dev_seq_.alloc(1);
 

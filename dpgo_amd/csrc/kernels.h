@@ -251,6 +251,16 @@ void launch_cg_scal(hipStream_t st, const SegTable &T, int nnodes, int phase, co
                     NodeBits *dmask, double *host_scalars, unsigned *arrived, unsigned long long *host_flag,
                     unsigned long long seq, unsigned long long *dev_seq);
 bool prof_enabled();
+// The same scalar steps taken inside the vector update that needs them (k_cg_step_fused / k_cg_dir_fused): one launch
+// instead of two per phase.  cg_in / cg_out: the two state buffers (the step reads one and writes the other); upd: the
+// nodes whose vectors the first kernel updates (the scalar step is taken by the nodes of dmask[0] / dmask[1] & bits).
+void launch_cg_step_fused(int d, hipStream_t st, const SegTable &T, int nnodes, NodeMask upd, const double *partials,
+                          const CgNode *cg_in, CgNode *cg_out, NodeBits *dmask, double *host_scalars, unsigned *arrived,
+                          unsigned long long *host_flag, unsigned long long seq, unsigned long long *dev_seq, const double *p,
+                          const double *Hp, double *s, double *hs, double *r, const double *r0);
+void launch_cg_dir_fused(int d, hipStream_t st, const SegTable &T, int nnodes, NodeBits bits, const double *partials,
+                         const CgNode *cg_in, CgNode *cg_out, NodeBits *dmask, double *host_scalars, unsigned *arrived,
+                         unsigned long long *host_flag, unsigned long long seq, unsigned long long *dev_seq, const double *v, double *p);
 
 // ---- multifrontal SPD solve (spd.h) ----
 // One tile of the solve with everything it needs to know about its front: 64 bytes, one load.

@@ -1360,6 +1360,45 @@ __global__ __launch_bounds__(384) void k_tnt_begin(SegTable T, int nnodes, TntBe
   }
 }
 
+// The scalar step of STPCG for one node from the sums of a phase (v[0..3]: phase 0 <p, H p>, <H p, H p>, <p, p>, <p, r>;
+// phase 1: v[0] = <r, v>), IterativeSolvers.h:296-390 -- shared by k_cg_scal and by the vector kernels that take the
+// step themselves (k_cg_step_fused / k_cg_dir_fused), so that every path does the same arithmetic.
+__device__ __forceinline__ void cg_scal_logic(int phase, const double (&v)[4], CgNode &c) {
+  if (phase == 0) {
+    const double kappa_k = v[0];
+    bool stop = false;
+    if (sqrt(v[1]) / sqrt(v[2]) < 1e-8) {   // p is (numerically) in the kernel of H (:305-338)
+      double sgn = 1.0;
+      if (v[3] < 0) { sgn = -1.0; c.sk_M_pk = -c.sk_M_pk; }
+      const double sigma = (-c.sk_M_pk + sqrt(c.sk_M_pk * c.sk_M_pk + c.pk_M_2 * (c.Delta_2 - c.sk_M_2))) / c.pk_M_2;
+      c.c1 = sgn * sigma;
+      stop = true;
+    } else {
+      const double alpha = c.rv / kappa_k;
+      const double skp1 = c.sk_M_2 + 2 * alpha * c.sk_M_pk + alpha * alpha * c.pk_M_2;
+      if (kappa_k <= 0 || skp1 > c.Delta_2) {   // negative curvature or the step leaves the region (:347-362)
+        c.c1 = (-c.sk_M_pk + sqrt(c.sk_M_pk * c.sk_M_pk + c.pk_M_2 * (c.Delta_2 - c.sk_M_2))) / c.pk_M_2;
+        stop = true;
+      } else {
+        c.c1 = alpha; c.cr = alpha; c.al = alpha; c.kap = kappa_k; c.sk_M_2 = skp1;
+      }
+    }
+    if (stop) { c.cr = 0.0; c.h_M_norm = c.Delta; c.live = 0; }
+  } else {
+    const double rk_vk = v[0];
+    const double be = rk_vk / (c.al * c.kap);   // (:364-390)
+    c.sk_M_pk = be * (c.sk_M_pk + c.al * c.pk_M_2);
+    c.pk_M_2 = rk_vk + be * be * c.pk_M_2;
+    c.rv = rk_vk;
+    c.be = be;
+    c.cg_it++;
+    if (c.cg_it >= c.max_it || sqrt(c.rv) <= c.target) {   // the stopping test of the next step (:285-291)
+      c.h_M_norm = sqrt(c.sk_M_2);
+      c.live = 0;
+    }
+  }
+}
+
 // one wave per node; the partial sums are combined in the order of k_reduce
 // seq: the value the host's flag is raised to.  A launch replayed from a captured graph cannot carry a fresh value in its
 // arguments: with seq == 0 the value is the device word *dev_seq + 1; either way *dev_seq ends up holding the value used,
@@ -1388,39 +1427,7 @@ __global__ __launch_bounds__(256) void k_cg_scal(SegTable T, int phase, const do
   }
   if (threadIdx.x == 0) {
     CgNode c = cg[a];
-    if (mine && phase == 0) {
-      const double kappa_k = v[0];
-      bool stop = false;
-      if (sqrt(v[1]) / sqrt(v[2]) < 1e-8) {   // p is (numerically) in the kernel of H (:305-338)
-        double sgn = 1.0;
-        if (v[3] < 0) { sgn = -1.0; c.sk_M_pk = -c.sk_M_pk; }
-        const double sigma = (-c.sk_M_pk + sqrt(c.sk_M_pk * c.sk_M_pk + c.pk_M_2 * (c.Delta_2 - c.sk_M_2))) / c.pk_M_2;
-        c.c1 = sgn * sigma;
-        stop = true;
-      } else {
-        const double alpha = c.rv / kappa_k;
-        const double skp1 = c.sk_M_2 + 2 * alpha * c.sk_M_pk + alpha * alpha * c.pk_M_2;
-        if (kappa_k <= 0 || skp1 > c.Delta_2) {   // negative curvature or the step leaves the region (:347-362)
-          c.c1 = (-c.sk_M_pk + sqrt(c.sk_M_pk * c.sk_M_pk + c.pk_M_2 * (c.Delta_2 - c.sk_M_2))) / c.pk_M_2;
-          stop = true;
-        } else {
-          c.c1 = alpha; c.cr = alpha; c.al = alpha; c.kap = kappa_k; c.sk_M_2 = skp1;
-        }
-      }
-      if (stop) { c.cr = 0.0; c.h_M_norm = c.Delta; c.live = 0; }
-    } else if (mine) {
-      const double rk_vk = v[0];
-      const double be = rk_vk / (c.al * c.kap);   // (:364-390)
-      c.sk_M_pk = be * (c.sk_M_pk + c.al * c.pk_M_2);
-      c.pk_M_2 = rk_vk + be * be * c.pk_M_2;
-      c.rv = rk_vk;
-      c.be = be;
-      c.cg_it++;
-      if (c.cg_it >= c.max_it || sqrt(c.rv) <= c.target) {   // the stopping test of the next step (:285-291)
-        c.h_M_norm = sqrt(c.sk_M_2);
-        c.live = 0;
-      }
-    }
+    if (mine) cg_scal_logic(phase, v, c);
     if (mine) {
       cg[a] = c;
       // a node that stops leaves dmask[1] now; dmask[0] (the nodes of the step under way, which still take the
@@ -1445,6 +1452,144 @@ __global__ __launch_bounds__(256) void k_cg_scal(SegTable T, int phase, const do
       __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+}
+
+// ---- the scalar step taken by the vector kernel that needs it --------------------------------------------------------
+// k_cg_scal is a launch of its own between the pass that leaves a phase's dot products and the vector update that uses
+// the step length: 5 us of a CG step whose other launches are 5-10 us each when few nodes still iterate.  Here every
+// workgroup of the vector update (one 64-row segment of a node) sums its node's partial sums itself -- in k_cg_scal's
+// order, so every workgroup of a node and k_cg_scal get the same bits -- and takes the scalar step in registers.  The
+// node's FIRST segment also does what k_cg_scal does for the others: it writes the new state (to the OTHER of two state
+// buffers: the node's remaining workgroups still read the old one), moves the node's bits in the device masks, writes
+// the summary the host polls and counts itself in; the last of these raises the flag.  A node that is not part of the
+// step carries its state over unchanged.
+struct CgFusedArgs {
+  const int *own_ptr;              // SegTable::own_ptr
+  int nseg_all, nnodes;
+  const double *partials;
+  const CgNode *cg_in;
+  CgNode *cg_out;
+  NodeBits *dmask;
+  double *host_scalars;
+  unsigned *arrived;
+  unsigned long long *host_flag, seq, *dev_seq;
+};
+// returns the node's new state; `mine`: the node takes this phase's scalar step
+template <int PHASE>
+__device__ __forceinline__ CgNode cg_fused_scalar(const CgFusedArgs &F, int a, int seg_index, bool mine) {
+  const int lane = threadIdx.x & 63;
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  constexpr int NS = PHASE == 0 ? 4 : 1;
+  CgNode c = F.cg_in[a];   // (in flight while the sums are taken)
+  if (mine) {
+    // the NS sums side by side (their loads and their shuffle ladders interleave); per sum the order of k_cg_scal
+    double t[NS];
+#pragma unroll
+    for (int q = 0; q < NS; q++) t[q] = 0.0;
+    const int k1 = F.own_ptr[a + 1];
+    for (int k = F.own_ptr[a] + lane; k < k1; k += 64) {
+#pragma unroll
+      for (int q = 0; q < NS; q++) t[q] += F.partials[(size_t)q * F.nseg_all + k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int q = 0; q < NS; q++) t[q] += __shfl_down(t[q], o, 64);
+    }
+#pragma unroll
+    for (int q = 0; q < NS; q++) v[q] = __shfl(t[q], 0, 64);
+  }
+  if (mine) cg_scal_logic(PHASE, v, c);
+  if (seg_index == F.own_ptr[a] && lane == 0) {   // the node's first segment: k_cg_scal's duties
+    F.cg_out[a] = c;
+    if (mine && !c.live) {
+      atomicAnd(F.dmask + 1, ~(1ull << a));
+      atomicOr(F.dmask + 2, 1ull << a);
+    }
+    __hip_atomic_store(F.host_scalars + a * CG_SUMMARY + 0, (double)c.live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(F.host_scalars + a * CG_SUMMARY + 1, c.h_M_norm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(F.host_scalars + a * CG_SUMMARY + 2, (double)c.cg_it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    const unsigned done = __hip_atomic_fetch_add(F.arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (done == (unsigned)F.nnodes - 1) {
+      if (PHASE == 1) F.dmask[0] = __hip_atomic_load(F.dmask + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next step's nodes
+      __hip_atomic_store(F.arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long seq = F.seq;
+      if (seq == 0) seq = *F.dev_seq + 1;
+      *F.dev_seq = seq;
+      __hip_atomic_store(F.host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  return c;
+}
+
+// phase 0 + k_cg_step.  upd: the nodes whose vectors are updated (the first step of a run: every node of the run, live or
+// not -- a node that stops before its first step has c1 = 0 and gets s = H s = 0 written); the scalar step is taken by
+// the nodes of the device mask dmask[0].
+template <int D>
+__global__ __launch_bounds__(SEG_ROWS) void k_cg_step_fused(const Seg *segs, NodeMask upd, CgFusedArgs F, const double *p,
+                                                            const double *Hp, double *s, double *hs, double *r, const double *r0) {
+  constexpr int RS = Dim<D>::RS;
+  const int si = SEGB;
+  const Seg sg = segs[si];
+  const bool mine = (F.dmask[0] >> sg.node) & 1ull;
+  const bool upd_on = node_on(upd, sg.node);
+  const int row = sg.begin + threadIdx.x;
+  const bool on = upd_on && row < sg.end;
+  // the vectors first: their loads are in flight while the node's scalar step is taken (a chain of dependent loads and
+  // a few square roots and divisions that would otherwise sit in front of them)
+  double vp[RS], vh[RS], vs[RS], vhs[RS], vr[RS];
+#pragma unroll
+  for (int k = 0; k < RS; k++) { vp[k] = vh[k] = vs[k] = vhs[k] = vr[k] = 0.0; }
+  if (on) {
+    load_vec<RS>(p + (size_t)row * RS, vp);
+    load_vec<RS>(Hp + (size_t)row * RS, vh);
+    if (!r0) {
+      load_vec<RS>(s + (size_t)row * RS, vs);
+      load_vec<RS>(hs + (size_t)row * RS, vhs);
+    }
+    load_vec<RS>((r0 ? r0 : r) + (size_t)row * RS, vr);
+  }
+  const CgNode c = cg_fused_scalar<0>(F, sg.node, si, mine);
+  if (!on) return;
+  const double cc = c.c1, cc_r = c.cr;
+#pragma unroll
+  for (int k = 0; k < RS; k++) vs[k] = fma(cc, vp[k], 1.0 * vs[k]);
+  store_vec<RS>(s + (size_t)row * RS, vs);
+#pragma unroll
+  for (int k = 0; k < RS; k++) vhs[k] = fma(cc, vh[k], 1.0 * vhs[k]);
+  store_vec<RS>(hs + (size_t)row * RS, vhs);
+  if (cc_r != 0.0) {
+#pragma unroll
+    for (int k = 0; k < RS; k++) vr[k] = fma(cc_r, vh[k], 1.0 * vr[k]);
+    store_vec<RS>(r + (size_t)row * RS, vr);
+  }
+}
+
+// phase 1 + k_cg_dir: p = -v + beta p for the nodes that go on (the nodes of dmask[1] that do not stop with this step)
+template <int D>
+__global__ __launch_bounds__(SEG_ROWS) void k_cg_dir_fused(const Seg *segs, NodeBits bits, CgFusedArgs F, const double *v, double *p) {
+  constexpr int RS = Dim<D>::RS;
+  const int si = SEGB;
+  const Seg sg = segs[si];
+  // (a node's first segment may already have cleared the node's bit -- then the node stops with this step, and there is
+  // nothing to update: either way of reading the word gives the same result)
+  const bool mine = ((F.dmask[1] & bits) >> sg.node) & 1ull;
+  const int row = sg.begin + threadIdx.x;
+  const bool on = mine && row < sg.end;
+  double vv[RS], vp[RS];
+#pragma unroll
+  for (int k = 0; k < RS; k++) { vv[k] = vp[k] = 0.0; }
+  if (on) {   // (in flight while the scalar step is taken)
+    load_vec<RS>(v + (size_t)row * RS, vv);
+    load_vec<RS>(p + (size_t)row * RS, vp);
+  }
+  const CgNode c = cg_fused_scalar<1>(F, sg.node, si, mine);
+  if (!on || !c.live) return;
+  const double be = c.be;
+#pragma unroll
+  for (int k = 0; k < RS; k++) vp[k] = fma(be, vp[k], -1.0 * vv[k]);
+  store_vec<RS>(p + (size_t)row * RS, vp);
 }
 
 #ifdef SPD_TRACE   /* measurement build only: per-tile phase timestamps (100 MHz wall clock), see spd_profile() */
@@ -2418,6 +2563,32 @@ void launch_cg_dir(int d, hipStream_t st, const SegTable &T, NodeMask mask, cons
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_AXPBY, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cg_dir<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, cg, v, p));
+}
+
+static CgFusedArgs cg_fused_args(const SegTable &T, int nnodes, const double *partials, const CgNode *cg_in, CgNode *cg_out,
+                                 NodeBits *dmask, double *host_scalars, unsigned *arrived, unsigned long long *host_flag,
+                                 unsigned long long seq, unsigned long long *dev_seq) {
+  CgFusedArgs F;
+  F.own_ptr = T.own_ptr; F.nseg_all = T.nseg_all; F.nnodes = nnodes; F.partials = partials; F.cg_in = cg_in; F.cg_out = cg_out;
+  F.dmask = dmask; F.host_scalars = host_scalars; F.arrived = arrived; F.host_flag = host_flag; F.seq = seq; F.dev_seq = dev_seq;
+  return F;
+}
+void launch_cg_step_fused(int d, hipStream_t st, const SegTable &T, int nnodes, NodeMask upd, const double *partials,
+                          const CgNode *cg_in, CgNode *cg_out, NodeBits *dmask, double *host_scalars, unsigned *arrived,
+                          unsigned long long *host_flag, unsigned long long seq, unsigned long long *dev_seq, const double *p,
+                          const double *Hp, double *s, double *hs, double *r, const double *r0) {
+  if (T.nseg_own == 0) return;
+  ProfScope ps(PK_AXPBY, st, (r0 ? 6.0 : 8.0) * T.rows_own * 8.0 * (d + 1) * d);
+  const CgFusedArgs F = cg_fused_args(T, nnodes, partials, cg_in, cg_out, dmask, host_scalars, arrived, host_flag, seq, dev_seq);
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cg_step_fused<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, upd, F, p, Hp, s, hs, r, r0));
+}
+void launch_cg_dir_fused(int d, hipStream_t st, const SegTable &T, int nnodes, NodeBits bits, const double *partials,
+                         const CgNode *cg_in, CgNode *cg_out, NodeBits *dmask, double *host_scalars, unsigned *arrived,
+                         unsigned long long *host_flag, unsigned long long seq, unsigned long long *dev_seq, const double *v, double *p) {
+  if (T.nseg_own == 0) return;
+  ProfScope ps(PK_AXPBY, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
+  const CgFusedArgs F = cg_fused_args(T, nnodes, partials, cg_in, cg_out, dmask, host_scalars, arrived, host_flag, seq, dev_seq);
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cg_dir_fused<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, bits, F, v, p));
 }
 
 void launch_cg_begin(hipStream_t st, int nnodes, NodeBits bits, const CgStart &S, int max_it, CgNode *cg, NodeBits *dmask) {

@@ -266,18 +266,29 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     // (captured: the launches go into a graph under capture -- the flag's sequence number then comes from the device's own
     // word, k_cg_scal -- and the host's counter is advanced when the graph is replayed, not here)
     bool capturing = false;
+    // (measured, DESIGN 7: the fused form LOSES -- city10000 2 250 -> 1 940 it/s, seconds to the objective 2.05 -> 2.09 --
+    // because the system-scope release that publishes a node's summary now sits inside a kernel whose other workgroups
+    // have just written the vectors, and has to wait for their write-back; it stays behind DPGO_CG_FUSE_SCAL=1)
+    static const bool fuse_scal = getenv("DPGO_CG_FUSE_SCAL") && atoi(getenv("DPGO_CG_FUSE_SCAL")) != 0;
     auto stepA = [&]() {
       cur_mask_ = mA;
       launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, pk, true, nullptr, w1, nullptr, 0, nullptr, nullptr, 0);   // G [0 ; p.R]
       solve_tt(w1, w3, -1.0);
       apply_tcol(w3, w1, nullptr, 2, X, nabla, pk, Hp, first_step ? grad : rk, partials_.p);   // Hp and <p,Hp>, <Hp,Hp>, <p,p>, <p,r>
-      launch_cg_scal(st_, T_, L, 0, partials_.p, cg_.p, dmask_.p, h_cg_, reduce_arrived_.p, h_flag_, capturing ? 0ull : ++fetch_seq_, dev_seq_.p);
-      // s += c1 p, H s += c1 H p for every node of the step (a node that stops here takes its boundary step), r += alpha H p
-      // for those that go on
+      // the step-length logic (k_cg_scal), then s += c1 p, H s += c1 H p for every node of the step (a node that stops here
+      // takes its boundary step), r += alpha H p for those that go on -- in two launches, or (DPGO_CG_FUSE_SCAL=1, an
+      // experiment that lost) in one: k_cg_step_fused, every workgroup of the update takes its node's scalar step itself
       // (the first step runs for every node of A, live or not: a node that stops before its first step has c1 = 0 and
       // gets its s = H s = 0 written here)
-      launch_cg_step(d_, st_, T_, first_step ? NodeMask{bitsA, nullptr} : mA, NodeCoefs(), pk, Hp, sk, hh, rk, cg_.p,
-                     first_step ? grad : nullptr);
+      if (fuse_scal) {
+        launch_cg_step_fused(d_, st_, T_, L, first_step ? NodeMask{bitsA, nullptr} : mA, partials_.p, cg_.p, cg_.p + MAX_LOCAL_NODES,
+                             dmask_.p, h_cg_, reduce_arrived_.p, h_flag_, capturing ? 0ull : ++fetch_seq_, dev_seq_.p, pk, Hp, sk, hh, rk,
+                             first_step ? grad : nullptr);
+      } else {
+        launch_cg_scal(st_, T_, L, 0, partials_.p, cg_.p, dmask_.p, h_cg_, reduce_arrived_.p, h_flag_, capturing ? 0ull : ++fetch_seq_, dev_seq_.p);
+        launch_cg_step(d_, st_, T_, first_step ? NodeMask{bitsA, nullptr} : mA, NodeCoefs(), pk, Hp, sk, hh, rk, cg_.p,
+                       first_step ? grad : nullptr);
+      }
       first_step = false;
       return fetch_seq_;
     };
@@ -293,8 +304,13 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
         const double *pa[MAX_DOTS] = {rk}, *pb[MAX_DOTS] = {vk};
         launch_dots(d_, st_, T_, cur_mask_, 1, pa, pb, P2, partials_.p, 0);
       }
-      launch_cg_scal(st_, T_, L, 1, partials_.p, cg_.p, dmask_.p, h_cg_, reduce_arrived_.p, h_flag_, capturing ? 0ull : ++fetch_seq_, dev_seq_.p);
-      launch_cg_dir(d_, st_, T_, cur_mask_, cg_.p, vk, pk);
+      if (fuse_scal) {   // (state: the first half wrote the second buffer, this half writes the first again)
+        launch_cg_dir_fused(d_, st_, T_, L, cur_mask_.v, partials_.p, cg_.p + MAX_LOCAL_NODES, cg_.p, dmask_.p, h_cg_, reduce_arrived_.p,
+                            h_flag_, capturing ? 0ull : ++fetch_seq_, dev_seq_.p, vk, pk);
+      } else {
+        launch_cg_scal(st_, T_, L, 1, partials_.p, cg_.p, dmask_.p, h_cg_, reduce_arrived_.p, h_flag_, capturing ? 0ull : ++fetch_seq_, dev_seq_.p);
+        launch_cg_dir(d_, st_, T_, cur_mask_, cg_.p, vk, pk);
+      }
       return fetch_seq_;
     };
     // One whole step (A then B, not the first) as ONE submission: captured once per set of argument values, replayed ever
@@ -304,7 +320,7 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     auto graph_step = [&]() {
       if (!step_graph) {
         const NodeBits all = L >= 64 ? ~0ull : ((1ull << L) - 1);
-        std::vector<const void *> key = {X, nabla, grad, sk, rk, vk, pk, Hp, w1, w3, hh, partials_.p, cg_.p, dmask_.p, jacobi ? jacobi_.p : nullptr,
+        std::vector<const void *> key = {X, nabla, grad, sk, rk, vk, pk, Hp, w1, w3, hh, partials_.p, cg_.p, dmask_.p, jacobi ? jacobi_.p : nullptr, (const void *)(uintptr_t)(fuse_scal ? 2 : 0),
                                          (const void *)(uintptr_t)(use_precon ? 1 : 0)};
         for (auto &c : cg_graphs_)
           if (c.key == key) { step_graph = c.exec; break; }
