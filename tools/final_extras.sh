@@ -1,6 +1,6 @@
 # The auxiliary round artefacts (run on the GPU box after tools/final_profile.sh): per-level solve tables, the one-node
 # timeline, the Dynamic-rescale probe and the launches of one refactorisation.  Usage: bash tools/final_extras.sh r03
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/final
 mkdir -p $out
 bash tools/spd_profile.sh $tag

@@ -1,6 +1,6 @@
 # Round artefacts (run on the GPU box): GPU tests, default bench line, emulated 8-GPU rank, rocprofv3 kernel
 # stats and the two PMC passes.  Usage: bash tools/final_profile.sh r01
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/final
 mkdir -p $out
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $out/gpu_tests.txt

@@ -36,7 +36,8 @@ def rocprof_avg_us(kernel):
 
 tr = pm["kernels"][r["kernel"]]["hbm_bytes_per_launch"]
 spd = K["k_spd_fwd"]["ms_per_step"] + K["k_spd_bwd"]["ms_per_step"]
-other = sum(v["ms_per_step"] for k, v in K.items() if not k.startswith("k_spd") and k != "k_bsr")
+ops = K["k_bsr"]["ms_per_step"] + K.get("k_bsr_tcol", {"ms_per_step": 0.0})["ms_per_step"]   # (the translation-column passes are a family of their own since round 4)
+other = sum(v["ms_per_step"] for k, v in K.items() if not k.startswith("k_spd") and k not in ("k_bsr", "k_bsr_tcol"))
 rows = [
     "| quantity | value | source |", "|---|---|---|",
     "| throughput | **%.1f outer iterations / s**, %.2f ms / iteration | `profiles/%s_bench_n1.json` |" % (j["value"], j["ms_per_step"], tag),
@@ -56,7 +57,7 @@ rows = [
     "| its measured HBM traffic | %.1f MB / launch (2×FETCH_SIZE + WRITE_SIZE) = %.2f × algorithmic; the bench line's own PMC passes: %.1f MB | `profiles/%s_pmc_hbm_traffic.json`, `roofline.traffic` |" % (
         tr / 1e6, tr / r["algorithmic_bytes_per_launch"], (r["traffic"] or 0) / 1e6, tag),
     "| time split per iteration (instrumented pass) | SPD solves %.2f ms (1 `G_RR+λI` solve + 3 `G_tt` solves), operator applies %.2f ms, everything else %.2f ms | `%s_bench_n1.json` `kernels` |" % (
-        spd, K["k_bsr"]["ms_per_step"], other, tag),
+        spd, ops, other, tag),
     "| factorisation on the GPU (MFMA tile kernel `k_fa_abt`) | %s | `profiles/%s_mfma_utilisation.json` |" % (
         "; ".join("%.1f GFLOP in %.1f ms = %.1f TFLOP/s (%.2f of the 78.6 TFLOP/s FP64 matrix peak)" % (r_["GFLOP"], r_["ms"], r_["TFLOPs"], r_["fraction_of_peak"])
                   for r_ in mf["hip_event_rates_G_tt_then_G_RR"]) +
