@@ -453,7 +453,8 @@ def main():
         if measured_traffic and dom[0] in measured_traffic:
             traffic = measured_traffic[dom[0]]
             traffic_source = ("measured for this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over a 5-step child run of this "
-                              "command (2 x FETCH_SIZE + WRITE_SIZE, KiB, gfx950 correction; tools/pmc_summary.py)")
+                              "command (2 x FETCH_SIZE + WRITE_SIZE, KiB, gfx950 correction; tools/pmc_summary.py); the average is over "
+                              "every launch of the family in the child run, its set-up (chordal initialisation) and warm-up included")
             for name in kernels:
                 if name in measured_traffic:
                     kernels[name]["hbm_MB_per_launch_measured"] = measured_traffic[name] / 1e6

@@ -1872,7 +1872,10 @@ std::vector<int> Group::rescale_device(const std::vector<int> &set) {
   // the verdict is read at the next read-back that was enqueued behind the factorisation: nothing waits for it here
   tt_verdict_pending_ = true;
   tt_verdict_seq_ = fetch_seq_ + 1;
-  if (clk.on) sync();
+  if (clk.on) {
+    sync();
+    fprintf(stderr, "[setup] rescale: %zu of %zu nodes\n", changed.size(), set.size());
+  }
   clk.lap("rescale: block-diagonal terms, numeric factorisation of G_tt, panels (device)");
   return changed;
 }
