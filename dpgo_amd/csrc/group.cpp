@@ -990,6 +990,7 @@ int Group::refactor_tt() {
 }
 
 Group::~Group() {
+  if (st_) (void)hipStreamSynchronize(st_);   // (a replay may still be running: its executable graph goes next)
   cg_graphs_release();
   chordal_release();
   if (h_scal_) (void)hipHostFree(h_scal_);
