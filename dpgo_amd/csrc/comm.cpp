@@ -192,6 +192,7 @@ void Comm::init(const void *id128, bool layout) {
   }
   // AMM-PGO* and the global evaluations borrow the same buffers on the group's own stream
   if (grp->set_collectives(send_.p, gathered_.p, &Comm::cb_allgather, &Comm::cb_allreduce, this) != 0) return;
+  lent_ = true;
   grp->set_device_allreduce(&Comm::cb_allreduce_dev);   // (sums that are born on the device stay there: Group::star_sums)
   ok_ = true;
 }
@@ -203,9 +204,14 @@ void Comm::release() {
     // an exchange that no update() has joined yet: let it finish, and take its event away from the group before the
     // event is destroyed
     if (ev_done_ && !broken_) (void)hipEventSynchronize(ev_done_);
-    grp_->set_pending_exchange(nullptr);
-    grp_->set_collectives(nullptr, nullptr, nullptr, nullptr, nullptr);
-    grp_->set_device_allreduce(nullptr);
+    // (only what THIS communicator lent the group is taken back: a lay-out-free one, p2p_self_check's, lent nothing, and
+    // the group may be working with another communicator's collectives)
+    if (lent_) {
+      grp_->set_pending_exchange(nullptr);
+      grp_->set_collectives(nullptr, nullptr, nullptr, nullptr, nullptr);
+      grp_->set_device_allreduce(nullptr);
+      lent_ = false;
+    }
   }
   // (a communicator whose stream ran into a deadline holds a kernel that will never end: it is aborted, not waited for)
   if (broken_ && comm_ && rccl().CommAbort) { (void)rccl().CommAbort((ncclComm_t)comm_); comm_ = nullptr; }

@@ -62,6 +62,7 @@ class Comm {
   // self-check has passed on every rank; DPGO_EXCHANGE=allgather keeps the all-gather
   bool p2p_ = false;
   bool broken_ = false;   // a wait on the communicator's stream ran into its deadline: the stream is never waited for again
+  bool lent_ = false;     // the group works with this communicator's collectives (taken back by release())
   struct P2P {            // one neighbour-to-neighbour exchange: the plan, its message buffers, its pack / unpack lists
     P2PPlan plan;
     DevBuf<double> send, recv;
