@@ -70,7 +70,10 @@ bool Group::cg_graph_wanted() const {
   // (the one-launch solve experiment hands a per-solve epoch to its kernel by value: nothing a replay could carry)
   if (prof_enabled() || force == 0 || Ltt_.flow || Lrr_.flow) return false;
   if (force == 1) return true;
-  return P0_ <= 40000;
+  // (measured on a fast host: city10000 / 8 nodes +8..13 %; a group of ONE node -- sphere2500, one rank of the headline
+  // graph -- loses 2.5..7 %: a replay's start-up against a dozen very short launches.  Where the host is the slower side
+  // a replay wins either way: DPGO_CG_GRAPH=1)
+  return P0_ <= 40000 && num_local() >= 2;
 }
 
 void Group::cg_graphs_release() {
