@@ -709,6 +709,7 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
     // nbr_ptr is used as [nptr[a], nptr[a+1]) : make it monotone per node
     segs_.upload(segs);
     own_seg_ptr_.upload(optr);
+    own_seg_ptr_host_ = optr;
     nbr_seg_ptr_.upload(nptr);
     T_.segs = segs_.p;
     T_.nseg_own = nown;
@@ -1070,7 +1071,27 @@ void Group::check_tt_verdict(bool wait) const {
 void Group::set_mask(const std::vector<int> &locals) {
   NodeBits m = 0;
   for (int a : locals) m |= 1ull << a;
-  cur_mask_ = NodeMask{m, nullptr};
+  cur_mask_ = live_mask(m, nullptr);
+}
+
+NodeMask Group::live_mask(NodeBits bits, const NodeBits *p) const {
+  NodeMask m{bits, p};
+  const int L = num_local();
+  static const bool on = env_int("DPGO_LIVE_GRIDS", 1) != 0;
+  int n = 0, idle = -1;
+  for (int a = 0; a < L; a++) {
+    if ((bits >> a) & 1ull) n++;
+    else if (idle < 0) idle = a;
+  }
+  if (!on || n == 0 || n > MAX_LIVE_SEGS || idle < 0 || (int)own_seg_ptr_host_.size() != L + 1) return m;   // (every node, or too many: the whole grid)
+  for (int a = 0; a < L; a++)
+    if ((bits >> a) & 1ull) {
+      m.seg0[m.nlive] = own_seg_ptr_host_[a];
+      m.nseg[m.nlive] = own_seg_ptr_host_[a + 1] - own_seg_ptr_host_[a];
+      m.nlive++;
+    }
+  m.idle_seg = own_seg_ptr_host_[idle];
+  return m;
 }
 
 unsigned long long Group::fetch_async(int nslots, bool all_rows) {

@@ -322,6 +322,10 @@ class Group {
   std::vector<CgGraph> cg_graphs_;
   DevBuf<unsigned long long> dev_seq_;   // the device's copy of the last sequence number a CG scalar kernel raised the flag to
   bool cg_graph_wanted() const;
+  // the mask of the nodes in `bits` (and-ed on the device with *p, if any) with the map that lets own-segment launches
+  // cover these nodes only (kernels.h: NodeMask::nlive) when they are few
+  NodeMask live_mask(NodeBits bits, const NodeBits *p) const;
+  std::vector<int> own_seg_ptr_host_;
   void cg_graphs_release();
   DevBuf<unsigned> reduce_arrived_;
   DevBuf<double> partials_;

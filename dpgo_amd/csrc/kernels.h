@@ -44,9 +44,17 @@ constexpr int MAX_LOCAL_NODES = 64;
 // `p` (optional) points at a device-resident mask that the kernel ands in -- the truncated CG keeps its set of
 // still-iterating nodes on the device (k_cg_scal), so the host need not read it back before the next launch
 typedef unsigned long long NodeBits;
+// A launch over the OWN segments of a few nodes only (the late steps of the truncated CG run on one to four of a group's
+// nodes): with nlive > 0 the grid holds nlive * max(nseg) workgroups and workgroup b works on segment seg0[b % nlive] +
+// b / nlive -- a node's segments then spread over all eight XCDs (round-robin dispatch), where the whole-group grid,
+// which gives every XCD one contiguous eighth of the rows, would leave a single live node to one XCD; surplus workgroups
+// land on idle_seg, a segment of a node outside v, and leave at once.  nlive = 0: the grid covers every segment.
+constexpr int MAX_LIVE_SEGS = 8;
 struct NodeMask {
   NodeBits v;
   const NodeBits *p;
+  int nlive = 0, idle_seg = 0;
+  int seg0[MAX_LIVE_SEGS] = {0, 0, 0, 0, 0, 0, 0, 0}, nseg[MAX_LIVE_SEGS] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 constexpr NodeMask ALL_NODES = {~0ull, nullptr};
 struct NodeCoefs {

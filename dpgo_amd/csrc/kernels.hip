@@ -279,6 +279,13 @@ __device__ __forceinline__ int xcd_seg(int b, int n) {
   return x * q + min(x, r) + (b >> 3);
 }
 #define SEGB xcd_seg((int)blockIdx.x, (int)gridDim.x)
+// ... or, for a launch that covers the own segments of a few nodes only (NodeMask::nlive), the node's r-th segment
+__device__ __forceinline__ int seg_live(const NodeMask &m, int b, int n) {
+  if (m.nlive == 0) return xcd_seg(b, n);
+  const int j = b % m.nlive, r = b / m.nlive;
+  return r < m.nseg[j] ? m.seg0[j] + r : m.idle_seg;
+}
+#define SEGM(mask) seg_live(mask, (int)blockIdx.x, (int)gridDim.x)
 
 // ---------------------------------------------------------------------------
 // Block-sparse operator apply over pose records.
@@ -294,7 +301,8 @@ __global__ __launch_bounds__(BSR_LPR * SEG_ROWS) void k_bsr(const Seg *segs, Nod
                                               const double *addv, double *y, const double *dotv, double coef,
                                               const double *dotadd, double *partial) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
-  const Seg s = segs[SEGB];
+  const int si = SEGM(mask);
+  const Seg s = segs[si];
   const bool active = node_on(mask, s.node);
   double part[1] = {0.0};
   constexpr int LPR = BSR_LPR;
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(BSR_LPR * SEG_ROWS) void k_bsr(const Seg *segs, Nod
       }
     }
   }
-  if (partial && active) block_store<1, LPR * SEG_ROWS / 64>(part, partial + SEGB, 0);
+  if (partial && active) block_store<1, LPR * SEG_ROWS / 64>(part, partial + si, 0);
 }
 
 // out (d x d) = Proj_R(E - sym(nabla R^T) Rdot): the rotation rows of the Riemannian Hessian-vector product
@@ -404,7 +412,8 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr_tcol(const Seg *segs, Node
                                                          double *out2, const double *rres, double *partial,
                                                          int pstride, TcolDots E) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
-  const Seg s = segs[SEGB];
+  const int si = SEGM(mask);
+  const Seg s = segs[si];
   if (!node_on(mask, s.node)) return;   // (partials of a node outside the mask are never read)
   const int row = s.begin + (threadIdx.x >> 2), j = threadIdx.x & 3;
   double pr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -495,7 +504,7 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr_tcol(const Seg *segs, Node
       store_vec<RS>(out2 + (size_t)row * RS, o);
     }
   }
-  if (partial) block_store<6, 4 * SEG_ROWS / 64>(pr, partial + SEGB, pstride);
+  if (partial) block_store<6, 4 * SEG_ROWS / 64>(pr, partial + si, pstride);
 }
 
 // ---------------------------------------------------------------------------
@@ -1013,7 +1022,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_cg_step(const Seg *segs, NodeMask 
                                                       const double *Hp, double *s, double *hs, double *r,
                                                       const CgNode *cg, const double *r0) {
   constexpr int RS = Dim<D>::RS;
-  const Seg sg = segs[SEGB];
+  const Seg sg = segs[SEGM(mask)];
   if (!node_on(mask, sg.node)) return;
   const int row = sg.begin + threadIdx.x;
   if (row >= sg.end) return;
@@ -1053,7 +1062,7 @@ template <int D>
 __global__ __launch_bounds__(SEG_ROWS) void k_cg_dir(const Seg *segs, NodeMask mask, const CgNode *cg, const double *v,
                                                      double *p) {
   constexpr int RS = Dim<D>::RS;
-  const Seg sg = segs[SEGB];
+  const Seg sg = segs[SEGM(mask)];
   if (!node_on(mask, sg.node)) return;
   const int row = sg.begin + threadIdx.x;
   if (row >= sg.end) return;
@@ -1165,7 +1174,8 @@ __global__ __launch_bounds__(SEG_ROWS) void k_rot_op(const Seg *segs, NodeMask m
                                                 const double *in, const double *dotv, double *partial,
                                                 double *out, int pstride, int two, double *neg) {
   constexpr int RS = Dim<D>::RS;
-  const Seg s = segs[SEGB];
+  const int si = SEGM(mask);
+  const Seg s = segs[si];
   if (!node_on(mask, s.node)) return;
   const int row = s.begin + threadIdx.x;
   double pr[2] = {0.0, 0.0};
@@ -1204,8 +1214,8 @@ __global__ __launch_bounds__(SEG_ROWS) void k_rot_op(const Seg *segs, NodeMask m
     }
   }
   if (partial) {
-    if (two) block_store<2>(pr, partial + SEGB, pstride);
-    else block_store<1>(reinterpret_cast<const double(&)[1]>(pr), partial + SEGB, 0);
+    if (two) block_store<2>(pr, partial + si, pstride);
+    else block_store<1>(reinterpret_cast<const double(&)[1]>(pr), partial + si, 0);
   }
 }
 
@@ -2413,11 +2423,20 @@ void prof_collect_operands(double *operand_bytes) {
   } while (0)
 
 static inline int nseg(const SegTable &T, bool all_rows) { return all_rows ? T.nseg_all : T.nseg_own; }
+// the grid of a launch over own segments: all of them, or -- NodeMask::nlive -- the live nodes' only
+static inline int own_grid(const SegTable &T, const NodeMask &m) {
+  if (m.nlive == 0) return T.nseg_own;
+  int mx = 0;
+  for (int j = 0; j < m.nlive; j++) mx = std::max(mx, m.nseg[j]);
+  return m.nlive * mx;
+}
+static inline NodeMask whole_grid(NodeMask m) { m.nlive = 0; return m; }   // (launches that also cover the neighbour segments)
 
 void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask, const BsrDev &A,
                 const double *x, int mode, const double *addv, double *y, const double *dotv,
                 double coef, const double *dotadd, double *partials, int slot) {
-  const int nb = nseg(T, all_rows);
+  if (all_rows) mask = whole_grid(mask);
+  const int nb = all_rows ? T.nseg_all : own_grid(T, mask);
   if (nb == 0) return;
   double *part = (dotv && partials) ? partials + (size_t)slot * T.nseg_all : nullptr;
   ProfScope ps(PK_BSR, st, (double)A.nnzb * (8.0 * (d + 1) * (d + 1) + 4) + 2.0 * A.nrows * 8.0 * (d + 1) * d);
@@ -2444,7 +2463,7 @@ void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, co
   E.g = dg; E.ga = dga; E.s = ds; E.grad = dgrad; E.hs = dhs;
   // which epilogue sums are produced: mode 2 with rres (a CG step's four), mode 1 with dg (a refinement's start), mode 0 with ds (a trial point's six)
   const bool sums = partials && ((mode == 2 && rres) || (mode == 1 && dg) || (mode == 0 && ds));
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_bsr_tcol<D>), dim3(T.nseg_own), dim3(4 * SEG_ROWS), 0, st, T.segs, mask, A, tval,
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_bsr_tcol<D>), dim3(own_grid(T, mask)), dim3(4 * SEG_ROWS), 0, st, T.segs, mask, A, tval,
                                         xt, base, y, mode, X, nabla, Rdot, out2, rres, sums ? partials : nullptr, T.nseg_all, E));
 }
 
@@ -2555,14 +2574,14 @@ void launch_cg_step(int d, hipStream_t st, const SegTable &T, NodeMask mask, con
                     const double *Hp, double *s, double *hs, double *r, const CgNode *cg, const double *r0) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_AXPBY, st, (r0 ? 6.0 : 8.0) * T.rows_own * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cg_step<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, C, p, Hp, s, hs,
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cg_step<D>), dim3(own_grid(T, mask)), dim3(SEG_ROWS), 0, st, T.segs, mask, C, p, Hp, s, hs,
                                         r, cg, r0));
 }
 
 void launch_cg_dir(int d, hipStream_t st, const SegTable &T, NodeMask mask, const CgNode *cg, const double *v, double *p) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_AXPBY, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cg_dir<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, cg, v, p));
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cg_dir<D>), dim3(own_grid(T, mask)), dim3(SEG_ROWS), 0, st, T.segs, mask, cg, v, p));
 }
 
 static CgFusedArgs cg_fused_args(const SegTable &T, int nnodes, const double *partials, const CgNode *cg_in, CgNode *cg_out,
@@ -2659,7 +2678,7 @@ void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask,
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_ROTOP, st, (dotv ? 4.0 : 3.0) * T.rows_own * 8.0 * (d + 1) * d);
   double *part = (dotv && partials) ? partials + (size_t)slot * T.nseg_all : nullptr;
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, 0, X, in,
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(own_grid(T, mask)), dim3(SEG_ROWS), 0, st, T.segs, mask, 0, X, in,
                                         dotv, part, out, T.nseg_all, two ? 1 : 0, neg));
 }
 
@@ -2667,7 +2686,7 @@ void launch_retract_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask,
                         const double *V, double *out) {
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_ROTOP, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, 2, X, V,
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(own_grid(T, mask)), dim3(SEG_ROWS), 0, st, T.segs, mask, 2, X, V,
                                         nullptr, nullptr, out, 0, 0, nullptr));
 }
 

@@ -264,7 +264,7 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     }
     // by value: the nodes the host last saw iterating (it sizes the launches -- the solves shrink their grids with it);
     // by pointer: the device's own, more recent masks
-    NodeMask mA{bitsA, dmask_.p}, mB{bitsA, dmask_.p + 1};
+    NodeMask mA = live_mask(bitsA, dmask_.p), mB = live_mask(bitsA, dmask_.p + 1);
     // first half of a step: H p and its four scalars, then the step-length logic (:296-362)
     // (captured: the launches go into a graph under capture -- the flag's sequence number then comes from the device's own
     // word, k_cg_scal -- and the host's counter is advanced when the graph is replayed, not here)
@@ -367,7 +367,8 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       NodeBits live = 0;
       for (int a : A)
         if (cgs(a, 0) != 0.0) live |= 1ull << a;
-      mA.v = mB.v = live;
+      mA = live_mask(live, dmask_.p);       // (few live nodes: the own-segment launches cover them alone)
+      mB = live_mask(live, dmask_.p + 1);
       return live != 0;
     };
     static const int lag = env_lag();

@@ -901,6 +901,9 @@ np.save(sys.argv[1], drv.X())
     # round 4: the CG steps replayed from a captured HIP graph (the default for a group this small) against eager launches
     assert np.array_equal(run("nograph", DPGO_CG_GRAPH="0"), base)
     assert np.array_equal(run("nograph_lag0", DPGO_CG_GRAPH="0", DPGO_CG_LAG="0"), base)
+    # ... own-segment launches that cover only the few nodes still in the CG (their segments dealt to all XCDs) against
+    # whole-group grids
+    assert np.array_equal(run("whole_grids", DPGO_LIVE_GRIDS="0"), base)
     # ... and the CG's scalar steps taken inside the vector updates (one launch instead of two per half step; an experiment
     # that lost) against the separate k_cg_scal launches: the same sums in the same order
     assert np.array_equal(run("scal_fused", DPGO_CG_FUSE_SCAL="1"), base)
