@@ -445,6 +445,54 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
       Wroot.alloc((size_t)total);   // (zero-filled: the padding of a panel row stays zero)
       launch_root_syrk(nullptr, root_desc.p, (int)rdesc.size(), root_max_w, F.dev_W ? F.dev_W : src_dev.p, Proot.p);
       launch_pack_panels(nullptr, root_items.p, root_srcs.p, (int)tiles.size(), Proot.p, Wroot.p);
+      // The tile height above fits ALL roots of the group.  The late steps of the truncated CG run on one to four of the
+      // group's nodes: a launch over so few roots gets the next finer class (64 -> 16, 16 -> 8 rows: four / two times the
+      // workgroups on the same bytes), cut from the same products -- spd_run picks by the number of live tiles.  Not for
+      // a factor that is re-done (its panels would have to be cut twice) nor for the fp32 experiment.
+      root_fine_rows = 0;
+      root_fine_items.release();
+      Wroot_fine.release();
+      const int fine = rows == 64 ? 16 : (rows == 16 ? 8 : 0);
+      if (fine && nnodes > 1 && !F.keep_numeric && !f32 && env_int("DPGO_SPD_ROOT_FINE_LIVE", 1) != 0) {
+        std::vector<Tile> ft;
+        root_fine_level = Level{0, 0, 0, fine, std::vector<int>(nnodes, 0), std::vector<int>(nnodes, 0), std::vector<int>(nnodes, 0),
+                                std::vector<int>(nnodes, 0), root_level.node_bytes};
+        for (int a = 0; a < nnodes; a++) {
+          const size_t begin = ft.size();
+          for (int f : roots) {
+            if (node_of_front(f) != a) continue;
+            for (int r = 0; r < F.w[f]; r += fine) ft.push_back({f, r, std::min(fine, F.w[f] - r), fine, (int64_t)F.w[f]});
+          }
+          root_fine_level.wstart[a] = (int)begin;
+          root_fine_level.wcount[a] = (int)(ft.size() - begin);
+          root_fine_level.nwide += (int)(ft.size() - begin);
+        }
+        std::vector<SpdItem> fitems(ft.size());
+        std::vector<PanelSrc> fsrcs(ft.size());
+        int64_t ftotal = 0;
+        for (size_t i = 0; i < ft.size(); i++) {
+          const Tile &t = ft[i];
+          const int f = t.f, ld = fine == 8 ? 8 : (t.count + 15) / 16 * 16;
+          SpdItem it;
+          it.front = f; it.first = t.first; it.count = t.count; it.w = F.w[f];
+          it.u = 0; it.ld = ld; it.piv_ptr = F.piv_ptr[f]; it.upd_ptr = F.upd_ptr[f];
+          it.pos_off = F.pos_off[f]; it.ubuf_off = F.ubuf_off[f];
+          it.node = node_of_front(f);
+          it.wait_ctr = -1; it.mat_off = ftotal; it.wait_need = 0; it.signal_ctr = -1;
+          fitems[i] = it;
+          fsrcs[i] = PanelSrc{(long long)(p_off[f] + t.first), F.w[f], F.w[f]};
+          ftotal += (int64_t)F.w[f] * ld;
+        }
+        DevBuf<PanelSrc> fsrcs_dev;
+        root_fine_items.upload(fitems);
+        fsrcs_dev.upload(fsrcs);
+        Wroot_fine.alloc((size_t)ftotal);
+        launch_pack_panels(nullptr, root_fine_items.p, fsrcs_dev.p, (int)ft.size(), Proot.p, Wroot_fine.p);
+        HIP_CHECK(hipDeviceSynchronize());
+        root_fine_rows = fine;
+        // (live tiles of the coarse class below which the fine one is taken: the thresholds the class itself was chosen by)
+        root_fine_below = rows == 64 ? env_int("DPGO_SPD_FINE_ROOT", 192) : env_int("DPGO_SPD_FINE_ROOT8", 64);
+      }
       HIP_CHECK(hipDeviceSynchronize());
       if (!F.keep_numeric) Proot.release();   // (kept for repack() when the factor is re-done with new values)
     }
@@ -1239,7 +1287,17 @@ void spd_run(int d, hipStream_t st, SpdSolverDev &S, NodeMask mask, double *in, 
     if ((bon[l] = S.bwd_levels[l].map(mask.v, bm[l], &bby[l]))) { bb += bby[l]; nb++; }
   SpdLevelMap rm, rrm;
   double rby = 0;
-  const bool ron = S.root_sym ? (S.root_sym_level.map(mask.v, rm, &rby) && S.root_rows_level.map(mask.v, rrm)) : S.root_level.map(mask.v, rm, &rby);
+  bool ron = S.root_sym ? (S.root_sym_level.map(mask.v, rm, &rby) && S.root_rows_level.map(mask.v, rrm)) : S.root_level.map(mask.v, rm, &rby);
+  // few live roots: the finer tile class (upload()), counted in 64-row tiles as the classes are chosen
+  bool fine_root = false;
+  if (ron && !S.root_sym && S.root_fine_rows) {
+    int live_tiles = 0;
+    for (int j = 0; j < rm.nlive; j++) live_tiles += rm.wcount[j];
+    if (live_tiles * S.root_level.rows / 64 < S.root_fine_below) {
+      fine_root = S.root_fine_level.map(mask.v, rm, &rby);
+      ron = fine_root;
+    }
+  }
   if (ron && in == out) throw DeviceError("spd_run: the fused root step cannot solve in place");
   {
   ProfSweep sweep(true, st, bf + rby, nf + (ron ? (S.root_sym ? 2 : 1) : 0));
@@ -1249,6 +1307,11 @@ void spd_run(int d, hipStream_t st, SpdSolverDev &S, NodeMask mask, double *in, 
   if (ron && S.root_sym) {
     launch_root_sym(d, S.dof, st, S.dev, rm, in, S.root_part.p, rby, S.stream_once, mask);
     launch_root_combine(d, S.dof, st, S.dev, rrm, S.root_rows.p, S.root_part.p, scale, out, mask);
+  } else if (ron && fine_root) {
+    SpdDev dv = S.dev;
+    dv.root_items = S.root_fine_items.p;
+    dv.Wroot = S.Wroot_fine.p;
+    launch_spd_level(d, S.dof, st, dv, 2, rm, S.root_fine_rows, in, out, scale, rby, S.stream_once, mask);
   } else if (ron) launch_spd_level(d, S.dof, st, S.dev, 2, rm, S.root_level.rows, in, out, scale, rby, S.stream_once, mask);
   }
   ProfSweep sweep(false, st, bb, nb);

@@ -148,6 +148,11 @@ struct SpdSolverDev {
   // (DPGO_SPD_ROOT_SYM=1 / 0 forces it on / off).  root_items are then the wave-sized items, root_sym_level / root_rows_level
   // their and the block rows' per-node ranges, root_part the partial-sum slots, root_pack the per-block descriptors the
   // panels are cut with (also by repack()).
+  // the next finer tile class of the full-product roots, for launches over few live roots (upload(), spd_run)
+  Level root_fine_level{0, 0, 0, 16, {}, {}, {}, {}, {}};
+  DevBuf<SpdItem> root_fine_items;
+  DevBuf<double> Wroot_fine;
+  int root_fine_rows = 0, root_fine_below = 0;
   bool root_sym = false;
   Level root_sym_level{0, 0, 0, 64, {}, {}, {}, {}, {}}, root_rows_level{0, 0, 0, 64, {}, {}, {}, {}, {}};
   DevBuf<RootRow> root_rows;

@@ -917,6 +917,8 @@ np.save(sys.argv[1], drv.X())
                      ("gy_by_pass", dict(DPGO_GX_LINEAR="0")),
                      # round 4: the fused roots stored as one triangle (forced on: these roots are below its size threshold)
                      ("roots_one_triangle_2_blocks", dict(DPGO_SPD_ROOT_SYM="1", DPGO_SPD_ROOT_SYM_BLOCKS="2")),
+                     # one tile class for the roots whatever the number of live nodes (another split of the same sums)
+                     ("one_root_class", dict(DPGO_SPD_ROOT_FINE_LIVE="0")),
                      ("roots_one_triangle_8_blocks", dict(DPGO_SPD_ROOT_SYM="1", DPGO_SPD_ROOT_SYM_BLOCKS="8")),
                      # the factorisation's block columns right-looking at every level (another order of the same updates)
                      ("rightlooking", dict(DPGO_SPD_LEFT_LOOKING="0")),
