@@ -128,14 +128,17 @@ __device__ __forceinline__ void blk_mul_acc(const double *blk, const double *rec
 // JacobiSVD path (C++/DPGO/include/DPGO/DPGO_utils.h:485-514).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void jacobi_pair(double &app, double &aqq, double &apq, double &arp, double &arq,
-                                            double *V, int p, int q) {
-  const double tiny = 1e-300;
-  const bool go = fabs(apq) > tiny;
-  const double theta = (aqq - app) / (2.0 * (go ? apq : 1.0));
-  double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
-  t = theta < 0.0 ? -t : t;
+                                            double *V, int p, int q, bool live) {
+  // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)) with theta = (aqq - app) / (2 apq), written without theta: one
+  // square root and one division on the chain instead of two and two (the kernels that project are bound by this chain of
+  // dependent fp64 operations, not by their bytes); S is scaled to trace ~ 1 by the caller, so a^2 + b^2 cannot overflow and
+  // underflows only where the rotation would be the identity to 1e-150
+  const double a = aqq - app, b = 2.0 * apq;
+  const double h = sqrt(fma(a, a, b * b));
+  const bool go = live && h > 1e-150 && apq != 0.0;
+  double t = b / (a + (a < 0.0 ? -h : h));
   t = go ? t : 0.0;
-  const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+  const double c = rsqrt(fma(t, t, 1.0)), s = t * c;
   app -= t * apq;
   aqq += t * apq;
   apq = 0.0;
@@ -173,10 +176,24 @@ __device__ void project_so3(const double *M, double *R) {
     s12 = fma(M[k * 3 + 1], M[k * 3 + 2], s12);
   }
   double V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  for (int sweep = 0; sweep < 8; sweep++) {   // same sweep count as the reference's 8 x 3 conjugations
-    jacobi_pair(s00, s11, s01, s02, s12, V, 0, 1);
-    jacobi_pair(s00, s22, s02, s01, s12, V, 0, 2);
-    jacobi_pair(s11, s22, s12, s01, s02, V, 1, 2);
+  {
+    // S / 2^e with 2^e <= trace < 2^(e+1): the eigenvectors are those of S, the pair's a^2 + b^2 stays in range
+    const double tr = s00 + s11 + s22;
+    const int e = (tr > 0.0 && tr < 1.7e308) ? -ilogb(tr) : 0;
+    s00 = ldexp(s00, e); s11 = ldexp(s11, e); s22 = ldexp(s22, e);
+    s01 = ldexp(s01, e); s02 = ldexp(s02, e); s12 = ldexp(s12, e);
+  }
+  // at most the reference's 8 x 3 conjugations; a lane stops turning once its off-diagonal part is below 1e-20 of the trace
+  // (the sweeps converge quadratically: what is skipped would turn V by less than 1e-20 where the eigenvalues are apart, and
+  // where they are not U V^T does not depend on the turn), the wave leaves when every lane has stopped -- a pose's result
+  // depends on its own matrix only, not on the poses it shares a wave with
+  bool live = true;
+  for (int sweep = 0; sweep < 8; sweep++) {
+    jacobi_pair(s00, s11, s01, s02, s12, V, 0, 1, live);
+    jacobi_pair(s00, s22, s02, s01, s12, V, 0, 2, live);
+    jacobi_pair(s11, s22, s12, s01, s02, V, 1, 2, live);
+    live = live && fabs(s01) + fabs(s02) + fabs(s12) > 1e-20;
+    if (!__any(live)) break;
   }
   double Bm[9];
 #pragma unroll
@@ -199,7 +216,7 @@ __device__ void project_so3(const double *M, double *R) {
   { double a = sw ? n2 : n1, b = sw ? n1 : n2; n1 = a; n2 = b; }
   double u1[3], u2[3], u3[3];
   const bool ok1 = n0 > 1e-300;
-  const double i1 = 1.0 / sqrt(ok1 ? n0 : 1.0);
+  const double i1 = rsqrt(ok1 ? n0 : 1.0);
   u1[0] = ok1 ? Bm[0] * i1 : 1.0; u1[1] = ok1 ? Bm[3] * i1 : 0.0; u1[2] = ok1 ? Bm[6] * i1 : 0.0;
   const double pr = u1[0] * Bm[1] + u1[1] * Bm[4] + u1[2] * Bm[7];
   u2[0] = Bm[1] - pr * u1[0]; u2[1] = Bm[4] - pr * u1[1]; u2[2] = Bm[7] - pr * u1[2];
@@ -212,7 +229,7 @@ __device__ void project_so3(const double *M, double *R) {
     u2[0] = u1[1] * e[2] - u1[2] * e[1]; u2[1] = u1[2] * e[0] - u1[0] * e[2]; u2[2] = u1[0] * e[1] - u1[1] * e[0];
     m2 = u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2];
   }
-  const double i2 = 1.0 / sqrt(m2);
+  const double i2 = rsqrt(m2);
   u2[0] *= i2; u2[1] *= i2; u2[2] *= i2;
   u3[0] = u1[1] * u2[2] - u1[2] * u2[1];
   u3[1] = u1[2] * u2[0] - u1[0] * u2[2];

@@ -706,6 +706,9 @@ def test_projection_kernel_matches_reference_avx_vectors(fixtures_dir, golden_di
     d_out = np.linalg.norm((out - A).reshape(len(A), -1), axis=1)
     d_ref = np.linalg.norm((U - A).reshape(len(A), -1), axis=1)
     np.testing.assert_allclose(d_out, d_ref, rtol=1e-8, atol=1e-12)
+    # rotations to rounding, whatever the input (the sweeps stop early per pose, the rotation's cosine comes from rsqrt)
+    np.testing.assert_allclose(np.einsum("nij,nkj->nik", out, out), np.tile(np.eye(3), (len(A), 1, 1)), rtol=0, atol=4e-15)
+    np.testing.assert_allclose(np.linalg.det(out), 1.0, rtol=0, atol=4e-15)
     G2 = dpgo_amd.read_g2o(os.path.join(fixtures_dir, "M3500.g2o"), 1)
     grp2 = dpgo_amd.NodeGroup(G2, [0], dpgo_amd.Options.driver())
     n2, A2, U2 = 3500, z["A2"], z["U2"]
