@@ -571,17 +571,31 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask ma
     if (from_nbr) store_vec<RS>(const_cast<double *>(Z) + (size_t)row * RS, zp);
 #pragma unroll
     for (int k = 0; k < RS; k++) acc[k] = 0.0;
-    const int k1 = E.inc_ptr[row + 1];
-    for (int k = E.inc_ptr[row]; k < k1; k++) {
-      // the incidence's record: eight 16-byte loads of one line, then the other pose
-      union { double2 q[8]; InterInc r; } u8;
-      const double2 *rq = reinterpret_cast<const double2 *>(E.rec + k);
+    const int k0 = E.inc_ptr[row], k1 = E.inc_ptr[row + 1];
+    // the incidence's record: eight 16-byte loads of one line, then the other pose.  A pose's incidences are a chain of
+    // dependent round trips (record -> other pose -> arithmetic), and the wave waits for its pose with the most
+    // incidences: the NEXT record is requested together with this one's other pose, so an incidence costs one round trip,
+    // not two
+    union Rec { double2 q[8]; InterInc r; };
+    Rec nxt;
+    if (k0 < k1) {
+      const double2 *rq = reinterpret_cast<const double2 *>(E.rec + k0);
 #pragma unroll
-      for (int i = 0; i < 8; i++) u8.q[i] = rq[i];
+      for (int i = 0; i < 8; i++) nxt.q[i] = rq[i];
+    }
+    for (int k = k0; k < k1; k++) {
+      Rec u8;
+#pragma unroll
+      for (int i = 0; i < 8; i++) u8.q[i] = nxt.q[i];
       const int code = u8.r.code, e = code >> 1, role = code & 1;
       const int other = u8.r.other;
       double zo[RS], Re[D * D], te[D];
       load_vec<RS>(((Znbr && other >= E.nrows_own) ? Znbr : Z) + (size_t)other * RS, zo);
+      if (k + 1 < k1) {
+        const double2 *rq = reinterpret_cast<const double2 *>(E.rec + k + 1);
+#pragma unroll
+        for (int i = 0; i < 8; i++) nxt.q[i] = rq[i];
+      }
 #pragma unroll
       for (int i = 0; i < D * D; i++) Re[i] = u8.r.R[i];
 #pragma unroll
