@@ -1,3 +1,4 @@
+# per-kernel A/B of two library builds on ONE box: .ab/lib_base.so against the current one (bench.py kernels block)
 mkdir -p gpurun_out/r4/kab
 for rep in 1 2; do for n in base cur; do
   L=$PWD/.ab/lib_$n.so; [ $n = cur ] && L=$PWD/dpgo_amd/libdpgo_amd.so
