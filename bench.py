@@ -236,12 +236,21 @@ def main():
     ap.add_argument("--rank-timeout", type=float, default=600.0,
                     help="--gpus N > 1 started without a launcher: seconds the ranks get before they are stopped and bench.py "
                          "returns 124 with the ranks that were still alive named on stderr")
+    ap.add_argument("--starve-host", type=int, default=-1,
+                    help="diagnostic: pin this process (and every runtime thread it starts later) to ONE core and keep this many "
+                         "busy-looping sibling processes on the same core (tools/starve.py) -- what a slow or crowded host does to "
+                         "the step time; -1: off")
     ap.add_argument("--force-exchange", action="store_true",
                     help="diagnostic: run the boundary exchange (pack, all-gather, unpack) even with one rank, to see "
                          "what it adds to a step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    starved = None
+    if args.starve_host >= 0:           # (before anything touches the GPU)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import starve
+        starved = starve.starve_host(args.starve_host)
     measured_traffic = None
     if (args.traffic == "auto" and world == 1 and args.gpus == 1 and not args.no_prof and args.prof_steps > 0
             and not args.emulate_world and not args.rendezvous_only):
@@ -533,6 +542,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64" if not experiment else "f64 arithmetic, fp32-stored preconditioner panels",
             "experiment": experiment, "data": "synthetic",
+            "diagnostic_starved_host": starved,
             "diagnostic_emulated_rank": ("%d of %d" % (args.emulate_rank, args.emulate_world)) if args.emulate_world else None,
             "config": {"workload": "synthetic SE(3) lattice %dx%dx%d, %d poses / %d edges, %s loss, AMM-PGO#, "
                                    "num_nodes=%d (%d per GPU), chordal init" % (nx, ny, nz, g["num_poses"], len(g["I"]),
@@ -547,6 +557,7 @@ def main():
             "ranks": per_rank,
             "setup_s": {"graph+chordal_init": t_init, "operators+factorizations": t_group},
             "solver": grp.solver_stats(),
+            "graphs": grp.graph_stats(),
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
         }
         if convergence is not None:

@@ -186,6 +186,7 @@ SYMBOLS = {
     "dpgo_prof_collect": (C.c_int, [_DP, _DP, C.POINTER(C.c_long)]),
     "dpgo_prof_collect_operands": (C.c_int, [_DP]),
     "dpgo_group_solver_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long), _IP, _IP]),
+    "dpgo_group_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "dpgo_debug_node_matrix": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Options), C.c_char_p, _IP, _IP, _DP]),
     "dpgo_debug_node_proximal": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Options), _DP, _DP, _DP]),
     "dpgo_debug_spd_solve": (C.c_int, [C.c_int, _IP, _IP, _DP, _DP, C.c_int, C.c_int]),
@@ -609,6 +610,12 @@ class NodeGroup:
         a, b, c, d = C.c_long(), C.c_long(), C.c_int(), C.c_int()
         lib().dpgo_group_solver_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
         return dict(nnz_tt=a.value, nnz_rr=b.value, levels_tt=c.value, levels_rr=d.value)
+
+    def graph_stats(self):
+        """Segments of the iteration replayed from captured graphs, graphs captured, segments launched eagerly."""
+        a, b, c = C.c_long(), C.c_long(), C.c_long()
+        lib().dpgo_group_graph_stats(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return dict(replays=a.value, captures=b.value, eager=c.value)
 
     def debug_apply(self, k, op, X, out_rows):
         X, ld = _fcol(X)

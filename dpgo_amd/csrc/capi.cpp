@@ -439,6 +439,12 @@ int dpgo_group_solver_stats(const dpgo_group_t *h, long *nnz_tt, long *nnz_rr, i
   return 0;
 }
 
+int dpgo_group_graph_stats(const dpgo_group_t *h, long *replays, long *captures, long *eager) {
+  if (!h || !h->grp || !replays || !captures || !eager) return -1;
+  h->grp->graph_stats(replays, captures, eager);
+  return 0;
+}
+
 int dpgo_debug_spd_stats(int n, const int *ptr, const int *col, const double *val, int leaf, long *nnz, int *levels,
                          int *max_front) {
   dpgo::CsrMatrix A;

@@ -213,7 +213,8 @@ void Comm::release() {
       lent_ = false;
     }
   }
-  // (a communicator whose stream ran into a deadline holds a kernel that will never end: it is aborted, not waited for)
+  // (a communicator whose stream ran into a deadline holds a kernel that will never end: it was aborted at the timeout
+  // site -- abandon() -- not waited for)
   if (broken_ && comm_ && rccl().CommAbort) { (void)rccl().CommAbort((ncclComm_t)comm_); comm_ = nullptr; }
   if (cs_ && !broken_) (void)hipStreamSynchronize(cs_);
   if (comm_ && rccl().ok && !broken_) (void)rccl().CommDestroy((ncclComm_t)comm_);
@@ -247,23 +248,38 @@ int Comm::setup_p2p(const std::vector<std::vector<PoseKey>> &exported) {
   } catch (...) {
     ok = false; need.clear(); need_rows.clear();
   }
-  // ---- all-gather of the needed keys (counts, then padded key lists)
-  DevBuf<int> cnt_d, cnts_d;
-  cnt_d.upload(std::vector<int>{(int)need.size()});
-  cnts_d.alloc(nranks_);
-  NCCL_OK(rccl().AllGather(cnt_d.p, cnts_d.p, 1, ncclInt32, (ncclComm_t)comm_, cs_));
-  sync_comm_stream();
+  // ---- all-gather of the needed keys (counts, then padded key lists).  Nothing between here and the final vote may
+  // leave this rank's peers inside a collective it never joins: the small all-gathers run out of buffers that exist
+  // already (small_allgather: no allocation, so no throw site but the enqueue itself), and a rank whose local work fails
+  // -- the list of needed keys, an allocation, an upload -- SAYS so in the next of them (a count of -1, a "not ready"),
+  // upon which every rank leaves together, before the collective the failed rank could not have posted.
   std::vector<int> counts;
-  cnts_d.download(counts);
+  if (small_allgather(ok ? (int)need.size() : -1, counts) != 0) return -1;
+  if (*std::min_element(counts.begin(), counts.end()) < 0) return p2p_refused("a rank could not list the poses it needs");
   const int stride = std::max(1, *std::max_element(counts.begin(), counts.end()));
   std::vector<int> mine(2 * (size_t)stride, -1), all;
   for (size_t k = 0; k < need.size(); k++) { mine[2 * k] = need[k].first; mine[2 * k + 1] = need[k].second; }
   DevBuf<int> mine_d, all_d;
-  mine_d.upload(mine);
-  all_d.alloc(2 * (size_t)stride * nranks_);
+  int ready = 1;
+  try {
+    mine_d.upload(mine);
+    all_d.alloc(2 * (size_t)stride * nranks_);
+  } catch (...) {
+    ready = 0;
+  }
+  std::vector<int> readies;
+  if (small_allgather(ready, readies) != 0) return -1;
+  if (*std::min_element(readies.begin(), readies.end()) == 0) return p2p_refused("a rank could not allocate its key lists");
   NCCL_OK(rccl().AllGather(mine_d.p, all_d.p, 2 * (size_t)stride, ncclInt32, (ncclComm_t)comm_, cs_));
   sync_comm_stream();
-  all_d.download(all);
+  int got = 1;
+  try {
+    all_d.download(all);
+  } catch (...) {
+    got = 0;
+  }
+  if (small_allgather(got, readies) != 0) return -1;   // (without the keys a rank has no plan: it could not post its messages)
+  if (*std::min_element(readies.begin(), readies.end()) == 0) return p2p_refused("a rank could not read the gathered keys");
   std::vector<std::vector<PoseKey>> needed(nranks_);
   for (int r = 0; r < nranks_; r++)
     for (int k = 0; k < counts[r]; k++) needed[r].push_back({all[2 * ((size_t)r * stride + k)], all[2 * ((size_t)r * stride + k) + 1]});
@@ -346,6 +362,24 @@ int Comm::setup_p2p(const std::vector<std::vector<PoseKey>> &exported) {
   return 0;
 }
 
+// One int per rank through buffers that exist since init() (red_: 64 doubles = 128 ints; ranks beyond that keep the
+// all-gather exchange, refused by the caller's vote).  No allocation: the only thing that can fail locally is the enqueue.
+int Comm::small_allgather(int mine, std::vector<int> &all) {
+  if (2 * nranks_ + 2 > 128) return -1;
+  int *dev = reinterpret_cast<int *>(red_.p);
+  HIP_OK(hipMemcpyAsync(dev, &mine, sizeof(int), hipMemcpyHostToDevice, cs_));   // (pageable source: returns when staged)
+  NCCL_OK(rccl().AllGather(dev, dev + 2, 1, ncclInt32, (ncclComm_t)comm_, cs_));
+  sync_comm_stream();
+  all.assign(nranks_, 0);
+  HIP_OK(hipMemcpy(all.data(), dev + 2, sizeof(int) * nranks_, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int Comm::p2p_refused(const char *why) {
+  if (rank_ == 0) fprintf(stderr, "[dpgo_amd] WARNING: the neighbour-to-neighbour exchange is not used (%s); using the all-gather.\n", why);
+  return -1;
+}
+
 // pack the send keys' rows of src_records -> grouped send / recv with the real neighbours -> unpack into dst_records
 // (null record arrays: the messages alone).  Between GroupStart and GroupEnd nothing returns early: a Send or Recv that
 // fails is remembered and GroupEnd is still called, so the group is never left open.
@@ -383,13 +417,32 @@ void Comm::sync_stream(hipStream_t st) {
     if (q == hipSuccess) return;
     if (q != hipErrorNotReady) HIP_OK(q);
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
-      broken_ = true;
       fprintf(stderr, "[dpgo_amd] ERROR: rank %d: an RCCL collective did not finish within %.0f s (a peer is gone or "
                       "never joined); the communicator is abandoned.\n", rank_, limit);
+      abandon(st);
       throw DeviceError("RCCL collective timed out");
     }
     std::this_thread::sleep_for(std::chrono::microseconds(50));
   }
+}
+
+// A wait ran into its deadline: an RCCL kernel is spinning on `st` and will never end by itself.  The unwinding that
+// follows frees device buffers (the temporaries of init() / setup_p2p() / allreduce_large(), later the members), and
+// hipFree waits for every stream of the device -- so the stuck kernel has to go FIRST: ncclCommAbort here, at the
+// timeout site, not in release().  Without ncclCommAbort (an RCCL that does not export it) nothing can end that kernel:
+// from then on no device buffer of this process is freed any more (DevBuf leaks, dev_leak_buffers) -- a leak in a process
+// that is about to report failure, instead of a hang.  The group whose stream the collective ran on cannot be used
+// again either way: it is marked failed (its update() / iterate() return -1, its destructor does not wait).
+void Comm::abandon(hipStream_t st) {
+  broken_ = true;
+  ok_ = false;
+  if (comm_ && rccl().CommAbort) {
+    (void)rccl().CommAbort((ncclComm_t)comm_);
+    comm_ = nullptr;
+  } else {
+    dev_leak_buffers(true);
+  }
+  if (grp_ && (st == grp_->stream() || lent_)) grp_->mark_failed();
 }
 
 // One rank talking to itself through the grouped send / recv path (tests: the first execution of this code on real
@@ -468,6 +521,7 @@ int Comm::allreduce(double *vals, int n) {
 }
 
 int Comm::allreduce_impl(double *vals, int n) {
+  if (broken_ || !comm_) return -1;
   hipStream_t st = grp_->stream();
   for (int off = 0; off < n; off += 64) {
     const int m = std::min(64, n - off);
@@ -483,7 +537,7 @@ int Comm::allreduce_impl(double *vals, int n) {
 
 // large host arrays (the global X for the result files): staged through a device buffer of their own
 int Comm::allreduce_large(double *vals, size_t n) {
-  if (!ok_) return -1;
+  if (!ok_ || broken_ || !comm_) return -1;
   DevBuf<double> buf;
   buf.alloc(n, false);
   hipStream_t st = grp_->stream();
@@ -501,6 +555,7 @@ int Comm::barrier() {
 
 int Comm::cb_allgather(void *user) {
   Comm *c = static_cast<Comm *>(user);
+  if (c->broken_ || !c->comm_) return -1;
   const int RS = (c->grp_->d() + 1) * c->grp_->d();
   try {
     NCCL_OK(rccl().AllGather(c->send_.p, c->gathered_.p, (size_t)c->stride_ * RS, ncclFloat64, (ncclComm_t)c->comm_,
@@ -514,6 +569,7 @@ int Comm::cb_allgather(void *user) {
 // in-place sum of n device doubles over the ranks, enqueued on the group's stream: no host in between
 int Comm::cb_allreduce_dev(void *user, double *dev_vals, int n) {
   Comm *c = static_cast<Comm *>(user);
+  if (c->broken_ || !c->comm_) return -1;
   try {
     NCCL_OK(rccl().AllReduce(dev_vals, dev_vals, (size_t)n, ncclFloat64, ncclSum, (ncclComm_t)c->comm_, c->grp_->stream()));
   } catch (const std::exception &) {

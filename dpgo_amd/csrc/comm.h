@@ -73,6 +73,9 @@ class Comm {
   int run_p2p(P2P &x, const double *src_records, double *dst_records);   // pack from / unpack into record arrays, on cs_
   void sync_comm_stream();   // hipStreamSynchronize(cs_) with a deadline (DPGO_COMM_TIMEOUT seconds, default 120)
   void sync_stream(hipStream_t st);
+  void abandon(hipStream_t st);                             // a wait timed out: abort the communicator NOW (comm.cpp)
+  int small_allgather(int mine, std::vector<int> &all);     // one int per rank, no allocation
+  int p2p_refused(const char *why);
 };
 
 }  // namespace dpgo

@@ -22,8 +22,11 @@ namespace dpgo {
     }                                                                                             \
   } while (0)
 
+static bool g_leak_device_buffers = false;
+void dev_leak_buffers(bool on) { g_leak_device_buffers = on; }
 template <class T>
 void DevBuf<T>::release() {
+  if (g_leak_device_buffers) { p = nullptr; n = 0; return; }
   if (p) (void)hipFree(p);
   p = nullptr;
   n = 0;
@@ -784,9 +787,10 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   for (int i = 0; i < std::max(L, 1) * (CG_SUMMARY + TNT_SUMMARY + 1); i++) h_cg_[i] = 0.0;
   reduce_arrived_.alloc(1);
   partials_.alloc((size_t)MAX_SLOTS * std::max(T_.nseg_all, 1));
-  cg_.alloc(2 * MAX_LOCAL_NODES);   // two state buffers: a fused scalar + vector step reads one and writes the other (tnt.cpp)
+  cg_.alloc(MAX_LOCAL_NODES);
   dmask_.alloc(4);
   dev_seq_.alloc(1);
+  coefs_dev_.alloc(MAX_LOCAL_NODES);
 
   upload_operators();
   // ---- inter-node edges (residual form) and their incidence lists
@@ -957,7 +961,7 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
 // The operators of every local node on the device (block-CSR G, S, P, P0, Q; the per-pose arrays D, T, N, V, robust Q).
 // Called at construction and after a Dynamic rescale.
 void Group::upload_operators() {
-  cg_graphs_release();   // (captured CG steps carry the operators' addresses)
+  graphs_invalidate();   // (captured launches carry the operators' addresses)
   const int L = num_local();
   const bool trivial = (opt_.loss == 0);
   auto uni = [&](int a, int p) { return p < info_[a].n[0] ? own_off_[a] + p : P0_ + nbr_off_[a] + (p - info_[a].n[0]); };
@@ -1032,18 +1036,43 @@ int Group::refactor_tt() {
   std::vector<int> node_of_pose(P0_);
   for (int a = 0; a < L; a++)
     for (int p = 0; p < info_[a].n[0]; p++) node_of_pose[own_off_[a] + p] = a;
-  cg_graphs_release();   // (... and the panels')
+  graphs_invalidate();   // (... and the panels')
   Ltt_.upload(d_, node_of_pose);
   clk.lap("G_tt: panels (pack + upload)");
   return 0;
 }
 
+// Wait until the group's stream is idle, for at most `seconds`: true when it is.  (hipStreamSynchronize would wait for
+// ever behind an exchange whose peer is gone.)
+bool Group::drain(double seconds) const {
+  if (!st_) return true;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(st_);
+    if (q != hipErrorNotReady) return q == hipSuccess;
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+
 Group::~Group() {
-  if (st_) (void)hipStreamSynchronize(st_);   // (a replay may still be running: its executable graph goes next)
-  cg_graphs_release();
+  // A replay may still be running (its executable graph goes next), a kernel may still write the pinned block.  A group
+  // whose stream never drains -- it waits for an exchange whose peer is gone, or a kernel faulted -- LEAKS what the
+  // device might still touch instead of freeing it under the device's feet (or waiting for ever).
+  if (host_timing_)
+    fprintf(stderr, "[host] node group of %d: %ld replays %.3f s in hipGraphLaunch (%.1f us each), %ld eager segments %.3f s, %ld waits %.3f s (%.1f us each)\n",
+            num_local(), seg_replays_, t_graph_launch_, seg_replays_ ? 1e6 * t_graph_launch_ / seg_replays_ : 0.0, seg_eager_, t_eager_seg_,
+            n_wait_, t_wait_, n_wait_ ? 1e6 * t_wait_ / n_wait_ : 0.0);
+  const bool idle = drain(failed_ ? 2.0 : 60.0);
+  if (idle) {
+    graphs_destroy();
+  } else {
+    fprintf(stderr, "[dpgo_amd] WARNING: the group's stream did not drain; its graphs, pinned block and stream are leaked.\n");
+    seg_graphs_.clear();
+  }
   chordal_release();
-  if (h_scal_) (void)hipHostFree(h_scal_);
-  if (st_) (void)hipStreamDestroy(st_);
+  if (h_scal_ && idle) (void)hipHostFree(h_scal_);
+  if (st_ && idle) (void)hipStreamDestroy(st_);
 }
 
 void Group::upload_bsr(const std::vector<const BsrMatrix *> &per_node, bool rows_all, BsrBufs &out) {
@@ -1142,12 +1171,110 @@ NodeMask Group::live_mask(NodeBits bits, const NodeBits *p) const {
   return m;
 }
 
+// ---------------------------------------------------------------------------
+// Segments of an iteration as graph replays (group.h)
+// ---------------------------------------------------------------------------
+bool Group::iter_graph_wanted() const {
+  static const int force = env_int("DPGO_ITER_GRAPH", -1);
+  if (graphs_broken_ || force == 0 || prof_enabled() || Ltt_.flow || Lrr_.flow) return false;   // (never while launches are timed)
+  if (force == 1) return true;
+  // Where a segment streams gigabytes (the headline's eight nodes on one GPU) the host is never what bounds it, and its
+  // launches shrink with the set of nodes that still iterate, which a replay's frozen grids cannot do.
+  return P0_ <= 40000;
+}
+
+void Group::graphs_destroy() {
+  for (auto &g : seg_graphs_)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  seg_graphs_.clear();
+}
+
+// Whatever a captured launch carries by value has changed (operators re-uploaded, panels re-cut, options set): the
+// graphs go.  A graph that may still be executing must not be destroyed, so the stream is drained first -- bounded;
+// a stream that never drains keeps (leaks) its graphs.
+void Group::graphs_invalidate() {
+  graph_gen_++;
+  if (seg_graphs_.empty()) return;
+  if (drain(60.0)) graphs_destroy();
+  else seg_graphs_.clear();
+}
+
+void Group::segment(int id, std::initializer_list<unsigned long long> extra, const std::function<void()> &body) {
+  if (capturing_) { body(); return; }   // (a segment inside a segment is part of it)
+  if (!iter_graph_wanted()) {
+    seg_eager_++;
+    if (!host_timing_) { body(); return; }
+    const auto t0 = std::chrono::steady_clock::now();
+    body();
+    t_eager_seg_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return;
+  }
+  std::vector<unsigned long long> key;
+  key.reserve(16 + extra.size());
+  key.push_back((unsigned long long)id);
+  key.push_back(graph_gen_);
+  // the buffers that rotate with the history or swap with an accepted step
+  for (const DevBuf<double> *b : {&Zc_, &Zp_, &gc_, &gp_, &Dfc_, &Dfp_, &GXc_, &GXp_, &Xak_, &tmp_[7]})
+    key.push_back((unsigned long long)(uintptr_t)b->p);
+  key.insert(key.end(), extra.begin(), extra.end());
+  SegGraph *hit = nullptr;
+  for (auto &g : seg_graphs_)
+    if (g.key == key) { hit = &g; break; }
+  if (!hit) {
+    hipGraph_t graph = nullptr;
+    capturing_ = true;
+    captured_flags_ = 0;
+    bool ok = hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+      try {
+        body();
+      } catch (...) {
+        ok = false;
+      }
+      if (hipStreamEndCapture(st_, &graph) != hipSuccess) ok = false;
+    }
+    capturing_ = false;
+    hipGraphExec_t exec = nullptr;
+    if (ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) ok = false;
+    if (graph) (void)hipGraphDestroy(graph);
+    if (!ok) {
+      // nothing of the body has run (a capture only records): run it eagerly, and stop trying
+      (void)hipGetLastError();
+      graphs_broken_ = true;
+      fprintf(stderr, "[dpgo_amd] WARNING: a segment of the iteration could not be captured as a graph; eager launches from here on.\n");
+      seg_eager_++;
+      body();
+      return;
+    }
+    if (seg_graphs_.size() >= 32) {   // (a handful of keys per segment is normal: the history rotates, the iterate swaps)
+      size_t old = 0;
+      for (size_t i = 1; i < seg_graphs_.size(); i++)
+        if (seg_graphs_[i].used < seg_graphs_[old].used) old = i;
+      // (the least recently used one was replayed many waits ago; still: never destroy a graph that may be executing)
+      if (drain(60.0)) (void)hipGraphExecDestroy(seg_graphs_[old].exec);
+      seg_graphs_.erase(seg_graphs_.begin() + old);
+    }
+    seg_graphs_.push_back(SegGraph{key, exec, captured_flags_, 0});
+    hit = &seg_graphs_.back();
+    seg_captures_++;
+  }
+  hit->used = ++seg_clock_;
+  if (host_timing_) {
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_CHECK(hipGraphLaunch(hit->exec, st_));
+    t_graph_launch_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  } else
+  HIP_CHECK(hipGraphLaunch(hit->exec, st_));
+  fetch_seq_ += hit->flags;   // the flag-raising kernels of the replay count on from the device's own word
+  seg_replays_++;
+}
+
 unsigned long long Group::fetch_async(int nslots, bool all_rows) {
   finish_update();
   nslots = std::max(nslots, deferred_slots_);
   deferred_slots_ = 0;
-  launch_reduce(st_, T_, num_local(), all_rows, nslots, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, ++fetch_seq_);
-  return fetch_seq_;
+  launch_reduce(st_, T_, num_local(), all_rows, nslots, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
+  return fetch_seq_;   // (under capture: the caller adds the replay's flags itself, segment())
 }
 
 // The deferred end of update(): wait for its reduction, then the scalar logic that needs the numbers.
@@ -1163,7 +1290,7 @@ void Group::fetch(int nslots, bool all_rows) {
   finish_update();   // (its scalars sit in the pinned slots the next reduction overwrites)
   nslots = std::max(nslots, deferred_slots_);
   deferred_slots_ = 0;
-  launch_reduce(st_, T_, num_local(), all_rows, nslots, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, ++fetch_seq_);
+  launch_reduce(st_, T_, num_local(), all_rows, nslots, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
   wait_flag(fetch_seq_);
 }
 
@@ -1171,6 +1298,10 @@ void Group::fetch(int nslots, bool all_rows) {
 // seeing it means everything enqueued before that kernel is done.
 void Group::wait_flag(unsigned long long seq) {
   const auto t0 = std::chrono::steady_clock::now();
+  struct Acc {   // (DPGO_HOST_TIMING)
+    Group *g; std::chrono::steady_clock::time_point t;
+    ~Acc() { if (g->host_timing_) { g->t_wait_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); g->n_wait_++; } }
+  } acc{this, t0};
   for (unsigned spins = 0; __atomic_load_n(h_flag_, __ATOMIC_ACQUIRE) < seq; spins++) {
     __builtin_ia32_pause();
     if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
@@ -2008,39 +2139,73 @@ int Group::update(const std::vector<int> &locals_in) {
   // depends on it at once: not for AMM-PGO* (the master decides on the sums right away) nor with Dynamic rescale
   static const bool defer_enabled = env_int("DPGO_DEFER_UPDATE", 1) != 0;
   const bool can_defer = defer_enabled && !star_ && !dynamic() && (first.empty() != later.empty());
-  auto end_with = [&](int nslots, const std::vector<int> &set, std::function<void()> logic) {
+  NodeBits mask_locals_bits = 0;
+  for (int a : locals) mask_locals_bits |= 1ull << a;
+  // `launches`: the rest of the surrogate build of the nodes in `set`, ending with the reduction of its sums -- a branch-free
+  // sequence, replayed from a captured graph where the host's launch rate would bound it (segment()); it may be empty when
+  // the caller has already enqueued everything but the reduction
+  auto end_with = [&](int seg_id, unsigned long long variant, int nslots, const std::vector<int> &set,
+                      const std::function<void()> &launches, std::function<void()> logic) {
+    nslots = std::max(nslots, deferred_slots_);
+    deferred_slots_ = 0;
+    NodeBits bits = 0;
+    for (int a : set) bits |= 1ull << a;
+    segment(seg_id, {bits, mask_locals_bits, variant, (unsigned long long)nslots}, [&] {
+      launches();
+      launch_reduce(st_, T_, num_local(), true, nslots, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
+    });
     if (can_defer) {
-      pending_seq_ = fetch_async(nslots, true);
+      pending_seq_ = fetch_seq_;
       for (int a : set) {
         host_update_pre(a);
         res_[a].updated = 1;
       }
       pending_update_ = std::move(logic);
     } else {
-      fetch(nslots, true);
+      wait_flag(fetch_seq_);
       logic();
     }
   };
   zc_ready_ = false;
   if (!zc_done) copy_rows(Zc_.p, Xk_.p, false);
   double *GX = (!trivial && keep_gx()) ? GXc_.p : T1_.p;
-  if (trivial)   // T1 = G Xak and <Xak, 1/2 G Xak>   (half of evaluate_G, DPGOProblem.cpp:180-205)
-    launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xak_.p, false, nullptr, T1_.p, Xak_.p, 0.5, nullptr, partials_.p, 5);
-  else           // T1 = G X and <X, 1/2 G X>  (kept as G X[k] where the next extrapolation reuses it)
-    launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Zc_.p, false, nullptr, GX, Zc_.p, 0.5, nullptr, partials_.p, 5);
-  join_exchange();
-  // X[iter]'s neighbour rows <- Xk's: a launch of its own for the trivial loss; the robust losses' inter-edge pass does it
-  // on the way (it reads the neighbour rows from Xk and stores them)
-  if (trivial) launch_copy_nbr_rows(d_, st_, T_, cur_mask_, Xk_.p, Zc_.p);
+  // the product with G: the part of the build that needs no neighbour row, ahead of the exchange's arrival.  Without a
+  // pending exchange it is simply the head of the segment below.
+  const bool split = xchg_done_ != nullptr;
+  auto product_with_G = [&] {
+    if (trivial)   // T1 = G Xak and <Xak, 1/2 G Xak>   (half of evaluate_G, DPGOProblem.cpp:180-205)
+      launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xak_.p, false, nullptr, T1_.p, Xak_.p, 0.5, nullptr, partials_.p, 5);
+    else           // T1 = G X and <X, 1/2 G X>  (kept as G X[k] where the next extrapolation reuses it)
+      launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Zc_.p, false, nullptr, GX, Zc_.p, 0.5, nullptr, partials_.p, 5);
+  };
+  const NodeMask mask_locals = cur_mask_;
+  if (split) {
+    product_with_G();
+    join_exchange();
+  }
+  auto head = [&] {   // (what a segment starts with when the product has not gone ahead)
+    if (!split) { cur_mask_ = mask_locals; product_with_G(); }
+  };
   if (trivial) {
+    // X[iter]'s neighbour rows <- Xk's: a launch of its own for the trivial loss; the robust losses' inter-edge pass does it
+    // on the way (it reads the neighbour rows from Xk and stores them)
     // g = S Z  (evaluate_none_g_and_f0 / _f, DPGOProblem.cpp:269-287, 516-542), with <Xak, g> alongside
-    launch_bsr(d_, st_, T_, false, cur_mask_, S_.dev, Zc_.p, false, nullptr, gc_.p, Xak_.p, 1.0, nullptr, partials_.p, 1);
+    auto common = [&] {
+      head();
+      cur_mask_ = mask_locals;
+      launch_copy_nbr_rows(d_, st_, T_, cur_mask_, Xk_.p, Zc_.p);
+      launch_bsr(d_, st_, T_, false, cur_mask_, S_.dev, Zc_.p, false, nullptr, gc_.p, Xak_.p, 1.0, nullptr, partials_.p, 1);
+    };
+    const bool both = !first.empty() && !later.empty();
+    if (both) common();   // (nodes at different iterations: two read-backs, nothing deferred, the shared part goes first)
     if (!first.empty()) {
-      set_mask(first);
-      launch_bsr(d_, st_, T_, true, cur_mask_, P0m_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 0);
-      // fobj = G(Xak | g, f0) = f0 + <Xak, g> + <Xak, 1/2 G Xak>: slots 1 and 5; Dfobj = g + G Xak
-      launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, partials_.p, 2, gc_.p, Dfc_.p);
-      end_with(6, first, [this, first] {
+      end_with(1, (split ? 1ull : 0ull) | (both ? 2ull : 0ull), 6, first, [&] {
+        if (!both) common();
+        set_mask(first);
+        launch_bsr(d_, st_, T_, true, cur_mask_, P0m_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 0);
+        // fobj = G(Xak | g, f0) = f0 + <Xak, g> + <Xak, 1/2 G Xak>: slots 1 and 5; Dfobj = g + G Xak
+        launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, partials_.p, 2, gc_.p, Dfc_.p);
+      }, [this, first] {
         for (int a : first) {
           const double f0 = scal(a, 0);
           host_update_logic(a, f0 + (scal(a, 1) + scal(a, 5)), f0, std::sqrt(scal(a, 2)));
@@ -2048,12 +2213,14 @@ int Group::update(const std::vector<int> &locals_in) {
       });
     }
     if (!later.empty()) {
-      set_mask(later);
-      launch_axpby(d_, st_, T_, true, cur_mask_, 1.0, Zc_.p, -1.0, Zp_.p, Tall_.p, 0);
-      launch_bsr(d_, st_, T_, true, cur_mask_, Q_.dev, Tall_.p, false, nullptr, nullptr, Tall_.p, 0.5, nullptr, partials_.p, 0);
-      launch_bsr(d_, st_, T_, true, cur_mask_, P_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 3);
-      launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, partials_.p, 2, gc_.p, Dfc_.p);
-      end_with(4, later, [this, later] {
+      end_with(2, (split ? 1ull : 0ull) | (both ? 2ull : 0ull), 4, later, [&] {
+        if (!both) common();
+        set_mask(later);
+        launch_axpby(d_, st_, T_, true, cur_mask_, 1.0, Zc_.p, -1.0, Zp_.p, Tall_.p, 0);
+        launch_bsr(d_, st_, T_, true, cur_mask_, Q_.dev, Tall_.p, false, nullptr, nullptr, Tall_.p, 0.5, nullptr, partials_.p, 0);
+        launch_bsr(d_, st_, T_, true, cur_mask_, P_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 3);
+        launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, partials_.p, 2, gc_.p, Dfc_.p);
+      }, [this, later] {
         for (int a : later) {
           const double fobj = res_[a].Gk + scal(a, 0);
           host_update_logic(a, fobj, fobj + scal(a, 3), std::sqrt(scal(a, 2)));
@@ -2062,17 +2229,25 @@ int Group::update(const std::vector<int> &locals_in) {
     }
   } else {
     // evaluate_g_and_f0 / evaluate_g_and_f (DPGOProblem.cpp:222-267, 360-424); _rescale variants (:289-358, :426-514)
+    const bool both = !first.empty() && !later.empty();
+    if (both || dynamic()) {   // (the product covers every node of `locals`: it cannot sit inside one of two segments)
+      head();
+    }
+    const bool head_inside = !(both || dynamic());
     for (int pass = 0; pass < 2; pass++) {
       const std::vector<int> &set = pass == 0 ? first : later;
       if (set.empty()) continue;
-      set_mask(set);
-      launch_inter(d_, st_, T_, cur_mask_, E_, opt_.loss, opt_.loss_reg, 0, pass == 1, Zc_.p, Zp_.p, Qd_.p, Dd_.p, DfE_.p,
-                   gc_.p, partials_.p, dynamic() ? e_w_.p : nullptr, nullptr, nullptr, nullptr, nullptr, Xk_.p);   // slots 0, 1 and 2 = <X, g>
       std::vector<double> rho(num_local(), 0.0), gap(num_local(), 0.0);
-      if (dynamic() && device_rescale_)   // the rescale test on the weights just computed; its verdict rides with the sums below
-        launch_rescale_decide(st_, num_local(), cur_mask_.v, e_off_dev_.p, e_w_.p, e_scale_.p, rs_count_.p, opt_.max_rescale_count,
-                              rs_flags_.p, h_rs_);
+      auto inter_pass = [&] {
+        set_mask(set);
+        launch_inter(d_, st_, T_, cur_mask_, E_, opt_.loss, opt_.loss_reg, 0, pass == 1, Zc_.p, Zp_.p, Qd_.p, Dd_.p, DfE_.p,
+                     gc_.p, partials_.p, dynamic() ? e_w_.p : nullptr, nullptr, nullptr, nullptr, nullptr, Xk_.p);   // slots 0, 1 and 2 = <X, g>
+      };
       if (dynamic()) {
+        inter_pass();
+        if (device_rescale_)   // the rescale test on the weights just computed; its verdict rides with the sums below
+          launch_rescale_decide(st_, num_local(), cur_mask_.v, e_off_dev_.p, e_w_.p, e_scale_.p, rs_count_.p, opt_.max_rescale_count,
+                                rs_flags_.p, h_rs_);
         // Rescale::Dynamic: the sum of rho and the majorisation gap (under the OLD Q) are final; whether the
         // surrogate is rescaled depends on the edge weights just computed (:300-321, :464-485).  Rescaled nodes get
         // their D, G, T, N, V, Q and the factor of G_tt rebuilt, and g, G X are taken again with the new operators.
@@ -2087,21 +2262,26 @@ int Group::update(const std::vector<int> &locals_in) {
           set_mask(set);
         }
       }
-      if (pass == 0) launch_bdiag_dot(d_, st_, T_, cur_mask_, Dd_.p, Zc_.p, 0.5, DfE_.p, -1.0, partials_.p, 3);
-      launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, GX, nullptr, partials_.p, 4, gc_.p, Dfc_.p);   // Dfobj = G X + g
       // (a node's first update: there is no X[k-1] yet -- gamma is 0 there, but the buffer must hold numbers)
-      if (keep_gx()) {
-        std::vector<int> fresh;
+      std::vector<int> fresh;
+      if (keep_gx())
         for (int a : set)
           if (res_[a].iters == 0) fresh.push_back(a);
+      const bool dyn = dynamic();
+      NodeBits fresh_bits = 0;
+      for (int a : fresh) fresh_bits |= 1ull << a;
+      end_with(3 + pass, (split ? 1ull : 0ull) | (head_inside ? 2ull : 0ull) | (dyn ? 4ull : 0ull) | (fresh_bits << 3), 6, set, [&] {
+        if (head_inside) head();
+        if (!dyn) inter_pass();
+        set_mask(set);
+        if (pass == 0) launch_bdiag_dot(d_, st_, T_, cur_mask_, Dd_.p, Zc_.p, 0.5, DfE_.p, -1.0, partials_.p, 3);
+        launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, GX, nullptr, partials_.p, 4, gc_.p, Dfc_.p);   // Dfobj = G X + g
         if (!fresh.empty()) {
           set_mask(fresh);
           copy_rows(GXp_.p, GXc_.p, false);
           set_mask(set);
         }
-      }
-      const bool dyn = dynamic();
-      end_with(6, set, [this, set, pass, dyn, rho, gap] {
+      }, [this, set, pass, dyn, rho, gap] {
         for (int a : set) {
           NodeResults &r = res_[a];
           const double fobjE = 0.5 * (dyn ? rho[a] : scal(a, 0));
@@ -2154,9 +2334,11 @@ int Group::iterate(const std::vector<int> &locals) {
 int Group::mm(const std::vector<int> &locals) {
   const Options &o = opt_;
   set_mask(locals);
-  launch_proximal(d_, st_, T_, cur_mask_, Zc_.p, Dfc_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, nullptr, nullptr, 0);
-  recover_translations(Xakh_.p, gc_.p);
-  copy_rows(Xak_.p, Xakh_.p, false);
+  segment(12, {cur_mask_.v}, [&] {
+    launch_proximal(d_, st_, T_, cur_mask_, Zc_.p, Dfc_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, nullptr, nullptr, 0);
+    recover_translations(Xakh_.p, gc_.p);
+    copy_rows(Xak_.p, Xakh_.p, false);
+  });
   finish_update();   // the scalars of the last update(): needed from here on (the GPU has the launches above to chew on)
   std::vector<int> plain;
   for (int a : locals) {
@@ -2181,21 +2363,23 @@ int Group::mm(const std::vector<int> &locals) {
 }
 
 // Y = X[k] + gamma (X[k] - X[k-1]) and the surrogate gradient data at Y, for the masked nodes
-void Group::prepare_extrapolated() {
+// (gam_dev: the same gammas in device memory -- the launches may be replayed from a captured graph, whose by-value
+// arguments are frozen: amm())
+void Group::prepare_extrapolated(const double *gam_dev) {
   const Options &o = opt_;
   const bool trivial = (o.loss == 0);
   NodeCoefs gam;
   for (int a = 0; a < num_local(); a++) gam.a[a] = gam.b[a] = res_[a].gamma;
   // own AND neighbour rows are extrapolated with the local gamma (DPGOHash.cpp:255-256)
-  launch_extrapolate(d_, st_, T_, true, cur_mask_, gam, Zc_.p, Zp_.p, Y_.p);
+  launch_extrapolate(d_, st_, T_, true, cur_mask_, gam, Zc_.p, Zp_.p, Y_.p, gam_dev);
   if (trivial) {
-    launch_extrapolate(d_, st_, T_, false, cur_mask_, gam, gc_.p, gp_.p, gx_.p);      // :259-262
-    launch_extrapolate(d_, st_, T_, false, cur_mask_, gam, Dfc_.p, Dfp_.p, Dfx_.p);
+    launch_extrapolate(d_, st_, T_, false, cur_mask_, gam, gc_.p, gp_.p, gx_.p, gam_dev);      // :259-262
+    launch_extrapolate(d_, st_, T_, false, cur_mask_, gam, Dfc_.p, Dfp_.p, Dfx_.p, gam_dev);
   } else {
     // evaluate_g_and_Df(Y) (:264 -> DPGOProblem.cpp:683-749)
     if (keep_gx()) {   // G Y = G X[k] + gamma (G X[k] - G X[k-1]): Df comes out of the inter-edge pass
       launch_inter(d_, st_, T_, cur_mask_, E_, o.loss, o.loss_reg, 1, false, Y_.p, nullptr, nullptr, Dd_.p, nullptr, gx_.p,
-                   partials_.p, nullptr, GXc_.p, GXp_.p, &gam, Dfx_.p);
+                   partials_.p, nullptr, GXc_.p, GXp_.p, &gam, Dfx_.p, nullptr, gam_dev);
     } else {
       launch_inter(d_, st_, T_, cur_mask_, E_, o.loss, o.loss_reg, 1, false, Y_.p, nullptr, nullptr, Dd_.p, nullptr, gx_.p,
                    partials_.p);
@@ -2208,15 +2392,26 @@ void Group::prepare_extrapolated() {
 int Group::amm(const std::vector<int> &locals) {
   const Options &o = opt_;
   set_mask(locals);
-  prepare_extrapolated();
-  // Xakh = proximal(Y, Df); Gkh = G(Xakh | g[k], f); |Xakh - Xak|^2    (:363-367)
-  // (these three scalars sit in slots DS.. and are read back together with the first scalars of TNT)
   constexpr int DS = 2 * MAX_DOTS;
-  launch_proximal(d_, st_, T_, cur_mask_, Y_.p, Dfx_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, Xak_.p, partials_.p, DS);
-  // Gkh = G(Xakh | g[k]) needs G Xakh; the translations of Xak = [. ; Xakh.R] need G [0 ; Xakh.R] + g: one pass over
-  // G gives both (T1_ = G [0 ; R] + gx, slot DS + 1 = <Xakh, 1/2 G Xakh + gc>), then the solve   (:363-372)
-  launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xakh_.p, 2, gx_.p, T1_.p, Xakh_.p, 0.5, gc_.p, partials_.p, DS + 1);
-  solve_tt(T1_.p, Xak_.p, -1.0);
+  // The head of the iteration -- extrapolation, proximal half step, translation solve -- is branch-free: one replay where
+  // the host's launch rate would bound it.  The gammas then come from device memory, written by the eager launch in front.
+  const double *gam_dev = nullptr;
+  if (iter_graph_wanted()) {
+    NodeCoefs gam;
+    for (int a = 0; a < num_local(); a++) gam.a[a] = gam.b[a] = res_[a].gamma;
+    launch_set_coefs(st_, gam, num_local(), coefs_dev_.p);
+    gam_dev = coefs_dev_.p;
+  }
+  segment(10, {cur_mask_.v}, [&] {
+    prepare_extrapolated(gam_dev);
+    // Xakh = proximal(Y, Df); Gkh = G(Xakh | g[k], f); |Xakh - Xak|^2    (:363-367)
+    // (these three scalars sit in slots DS.. and are read back together with the first scalars of TNT)
+    launch_proximal(d_, st_, T_, cur_mask_, Y_.p, Dfx_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, Xak_.p, partials_.p, DS);
+    // Gkh = G(Xakh | g[k]) needs G Xakh; the translations of Xak = [. ; Xakh.R] need G [0 ; Xakh.R] + g: one pass over
+    // G gives both (T1_ = G [0 ; R] + gx, slot DS + 1 = <Xakh, 1/2 G Xakh + gc>), then the solve   (:363-372)
+    launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xakh_.p, 2, gx_.p, T1_.p, Xakh_.p, 0.5, gc_.p, partials_.p, DS + 1);
+    solve_tt(T1_.p, Xak_.p, -1.0);
+  });
   finish_update();   // the scalars of the last update(): needed from here on (the GPU has the launches above to chew on)
   for (int a : locals) {
     NodeResults &r = res_[a];
@@ -2226,10 +2421,15 @@ int Group::amm(const std::vector<int> &locals) {
   std::vector<int> plain, ref;
   for (int a : locals) (res_[a].refined ? ref : plain).push_back(a);
   // Gk for nodes that are not refined; refined nodes run TNT first (:374-383)
-  if (!plain.empty()) eval_G(Xak_.p, gc_.p, DS + 2);
-  deferred_slots_ = DS + 3;
-  if (ref.empty()) fetch(DS + 3, false);
-  else {
+  if (ref.empty()) {   // (the regime once the gradient is small: the pass and its read-back as one segment)
+    segment(11, {cur_mask_.v}, [&] {
+      eval_G(Xak_.p, gc_.p, DS + 2);
+      launch_reduce(st_, T_, num_local(), false, DS + 3, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
+    });
+    wait_flag(fetch_seq_);
+  } else {
+    if (!plain.empty()) eval_G(Xak_.p, gc_.p, DS + 2);
+    deferred_slots_ = DS + 3;
     // TNT minimises G(. | g extrapolated); Gk is G(. | g[k]) at the refined point (:377-383)
     run_tnt(ref, Xak_.p, gx_.p, gc_.p, true);
     for (int a : ref) res_[a].Gk = res_[a].Gk_alt;
@@ -2434,7 +2634,7 @@ int Group::star_sums(const double *X1_own, const double *X2_own, const double *r
   launch_star_sums(st_, T_, num_local(), valid, slots, partials_.p, star_vals_.p);
   const bool dev_sum = coll_allreduce_dev_ != nullptr;
   if (dev_sum && coll_allreduce_dev_(coll_user_, star_vals_.p, 4) != 0) return -1;
-  launch_publish(st_, star_vals_.p, 4, h_scal_, h_flag_, ++fetch_seq_);
+  launch_publish(st_, star_vals_.p, 4, h_scal_, h_flag_, next_seq(), dev_seq_.p);
   wait_flag(fetch_seq_);
   double v[4] = {h_scal_[0], h_scal_[1], h_scal_[2], h_scal_[3]};
   if (!dev_sum && coll_allreduce_ && coll_allreduce_(coll_user_, v, 4) != 0) return -1;

@@ -90,6 +90,9 @@ struct DChordalOptions {
   double reg_G = 1e-12;
 };
 
+// After this, DevBuf never calls hipFree again in this process: a stuck RCCL kernel that cannot be aborted would make
+// every hipFree wait for ever (comm.cpp: Comm::abandon).
+void dev_leak_buffers(bool on);
 template <class T>
 struct DevBuf {
   T *p = nullptr;
@@ -190,6 +193,9 @@ class Group {
   Group(const Graph &g, const std::vector<int> &node_ids, const Options &opt, int device);
   ~Group();
   bool ok() const { return ok_; }
+  // the group cannot go on (a collective on its stream timed out, a refactorisation failed): update() / iterate() return -1
+  // from now on and the destructor does not wait for the stream
+  void mark_failed() { failed_ = true; }
   int d() const { return d_; }
   int num_local() const { return (int)nodes_.size(); }
   const DataInfo &info(int local) const { return info_[local]; }
@@ -323,15 +329,47 @@ class Group {
   // lengths and the flag's sequence number live on the device) captured as a HIP graph and replayed with ONE submission per
   // step (tnt.cpp).  For groups whose steps are bound by the host's launch rate (small graphs, one node per GPU);
   // DPGO_CG_GRAPH=0 / 1 forces it off / on.  Keyed by every pointer a step carries (the iterate's buffers swap).
-  struct CgGraph { std::vector<const void *> key; hipGraphExec_t exec = nullptr; };
-  std::vector<CgGraph> cg_graphs_;
-  DevBuf<unsigned long long> dev_seq_;   // the device's copy of the last sequence number a CG scalar kernel raised the flag to
+  DevBuf<unsigned long long> dev_seq_;   // the device's copy of the last sequence number a kernel raised the flag to
   bool cg_graph_wanted() const;
+  // ---- The branch-free SEGMENTS of an iteration as graph replays (round 5).  Between two read-backs an iteration is a fixed
+  // sequence of launches -- update() behind the exchange, the start of iterate() up to the translation solve, a refinement
+  // from its model gradient to the trial point's sums -- whose arguments are pointers, node sets and constants: everything
+  // that changes from one iteration to the next lives in device memory (the Nesterov gammas: coefs_dev_, written by the one
+  // eager launch of update(); the flag's sequence number: dev_seq_; the CG's masks and step lengths, as before).  segment()
+  // runs such a sequence eagerly, or -- when the host's launch rate is what bounds the group (iter_graph_wanted) -- captures
+  // it once per key (the buffers it touches, which rotate; the node set; the variant) and replays it with ONE submission.
+  // Rare branches (a rejected step, a restart, a fallback, a Dynamic rescale) stay eager.  Bitwise the same results.
+  struct SegGraph { std::vector<unsigned long long> key; hipGraphExec_t exec = nullptr; int flags = 0; unsigned long long used = 0; };
+  std::vector<SegGraph> seg_graphs_;
+  unsigned long long seg_clock_ = 0, graph_gen_ = 0;   // graph_gen_: bumped by whatever invalidates captured arguments
+  bool capturing_ = false, graphs_broken_ = false;
+  int captured_flags_ = 0;
+  long seg_replays_ = 0, seg_captures_ = 0, seg_eager_ = 0;
+  // DPGO_HOST_TIMING=1: where the host's time goes (seconds in hipGraphLaunch, in eagerly launched segments, in waits), on
+  // stderr when the group goes
+  bool host_timing_ = getenv("DPGO_HOST_TIMING") != nullptr;
+  double t_graph_launch_ = 0, t_eager_seg_ = 0, t_wait_ = 0;
+  long n_wait_ = 0;
+  // the sequence number the next flag-raising launch carries: a fresh one, or 0 under capture (the kernel then takes the
+  // device's count + 1, and the host counts along when the graph is replayed)
+  unsigned long long next_seq() {
+    if (capturing_) { captured_flags_++; return 0ull; }
+    return ++fetch_seq_;
+  }
+  bool iter_graph_wanted() const;
+  void segment(int id, std::initializer_list<unsigned long long> extra, const std::function<void()> &body);
+  void graphs_invalidate();   // waits (bounded) for the stream, destroys every captured graph, bumps graph_gen_
+  void graphs_destroy();      // (the stream is known to be idle)
+  bool drain(double seconds) const;
+  DevBuf<double> coefs_dev_;  // per local node: gamma of the iteration under way (k_set_coefs)
+ public:
+  // (counters for the tests and the API-trace summary: replays, captures, segments run eagerly)
+  void graph_stats(long *replays, long *captures, long *eager) const { *replays = seg_replays_; *captures = seg_captures_; *eager = seg_eager_; }
+ private:
   // the mask of the nodes in `bits` (and-ed on the device with *p, if any) with the map that lets own-segment launches
   // cover these nodes only (kernels.h: NodeMask::nlive) when they are few
   NodeMask live_mask(NodeBits bits, const NodeBits *p) const;
   std::vector<int> own_seg_ptr_host_;
-  void cg_graphs_release();
   DevBuf<unsigned> reduce_arrived_;
   DevBuf<double> partials_;
   DevBuf<CgNode> cg_;       // device-resident state of the truncated CG (tnt.cpp, k_cg_scal)
@@ -377,7 +415,7 @@ class Group {
   double starF_ = 0, star_fobj_ = 0, star_fobjh_ = 0;
   int star_branches_ = 0;
   void node_rows_of_global(int a, const double *X, int ld, std::vector<double> &Z) const;
-  void prepare_extrapolated();                             // Y, g_x, Df_x for the masked nodes
+  void prepare_extrapolated(const double *gam_dev = nullptr);   // Y, g_x, Df_x for the masked nodes
   double global_objective(const double *X_own);           // F at the point whose own rows are X_own
   // the master's numbers in ONE read-back: F(X1) [, F(X2)] [, |X1 - ref|^2, |X2 - ref|^2] (null pointers: not wanted)
   int star_sums(const double *X1_own, const double *X2_own, const double *ref_own, double *F1, double *F2, double *d1, double *d2);

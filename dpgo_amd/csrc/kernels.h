@@ -146,7 +146,10 @@ void launch_inter(int d, hipStream_t st, const SegTable &T, NodeMask mask, const
                   // point from the products G X[k], G X[k-1] the last two update()s left (no pass over G)
                   const double *GXc = nullptr, const double *GXp = nullptr, const NodeCoefs *gamma = nullptr, double *Df_out = nullptr,
                   // mode 0 with Znbr: the neighbour rows are read from Znbr and copied into Z on the way (the halo copy of update())
-                  const double *Znbr = nullptr);
+                  const double *Znbr = nullptr,
+                  // gamma_dev: the same gammas in device memory (launch_set_coefs) -- read instead of `gamma` by a launch that may be
+                  // replayed from a captured graph, whose by-value arguments are frozen
+                  const double *gamma_dev = nullptr);
 
 // ---- Rescale::Dynamic on the device (see k_rescale_decide / k_rescale_apply) ----
 // decide: flags[a] / host_flags[a] = node a (of `nodes`) is rescaled; its scales and counter are updated
@@ -179,7 +182,9 @@ void launch_proximal(int d, hipStream_t st, const SegTable &T, NodeMask mask, co
 
 // out = a + gamma[node] * (a - b) over all rows (own + neighbour)      (DPGOHash.cpp:255-262)
 void launch_extrapolate(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask,
-                        const NodeCoefs &gamma, const double *a, const double *b, double *out);
+                        const NodeCoefs &gamma, const double *a, const double *b, double *out, const double *gamma_dev = nullptr);
+// dev[a] = C.a[a], a < n: the per-iteration coefficients where replayed launches find them (k_set_coefs)
+void launch_set_coefs(hipStream_t st, const NodeCoefs &C, int n, double *dev);
 // out = alpha * a + beta * b  (b may be null); parts: 0 whole record, 1 translation only, 2 rotation only
 // out2 (part 0 only): a second copy of the result
 void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask, double alpha,
@@ -229,13 +234,15 @@ void launch_bdiag_dot(int d, hipStream_t st, const SegTable &T, NodeMask mask, c
 // host_scalars[node * MAX_SLOTS + s] = sum of the node's partials, s < nslots, written straight to pinned host
 // memory; *host_flag = seq once all of them are there (arrived: a zeroed device counter)
 void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows, int nslots, const double *partials,
-                   double *host_scalars, unsigned *arrived, unsigned long long *host_flag, unsigned long long seq);
+                   double *host_scalars, unsigned *arrived, unsigned long long *host_flag, unsigned long long seq,
+                   unsigned long long *dev_seq);   // seq == 0: *dev_seq + 1 (a replayed launch); *dev_seq ends up holding the value used
 
 // AMM-PGO*'s master sums (k_star_sums): out[0..3] (device) from the partial slots 0..5; launch_publish: n <= 64 device values
 // to pinned host memory, then *host_flag = seq
 void launch_star_sums(hipStream_t st, const SegTable &T, int nnodes, unsigned valid_slots, const int *slots6, const double *partials,
                       double *out);   // valid_slots: bit q = sum q was produced; slots6[q]: the partial-sum slot it is in
-void launch_publish(hipStream_t st, const double *vals, int n, double *host, unsigned long long *host_flag, unsigned long long seq);
+void launch_publish(hipStream_t st, const double *vals, int n, double *host, unsigned long long *host_flag, unsigned long long seq,
+                    unsigned long long *dev_seq);
 
 // ---- device-side control of the truncated CG (tnt.cpp) ----
 constexpr int CG_SUMMARY = 4;    // doubles per node k_cg_scal writes to pinned memory: live, |h|_M, iterations
@@ -259,16 +266,6 @@ void launch_cg_scal(hipStream_t st, const SegTable &T, int nnodes, int phase, co
                     NodeBits *dmask, double *host_scalars, unsigned *arrived, unsigned long long *host_flag,
                     unsigned long long seq, unsigned long long *dev_seq);
 bool prof_enabled();
-// The same scalar steps taken inside the vector update that needs them (k_cg_step_fused / k_cg_dir_fused): one launch
-// instead of two per phase.  cg_in / cg_out: the two state buffers (the step reads one and writes the other); upd: the
-// nodes whose vectors the first kernel updates (the scalar step is taken by the nodes of dmask[0] / dmask[1] & bits).
-void launch_cg_step_fused(int d, hipStream_t st, const SegTable &T, int nnodes, NodeMask upd, const double *partials,
-                          const CgNode *cg_in, CgNode *cg_out, NodeBits *dmask, double *host_scalars, unsigned *arrived,
-                          unsigned long long *host_flag, unsigned long long seq, unsigned long long *dev_seq, const double *p,
-                          const double *Hp, double *s, double *hs, double *r, const double *r0);
-void launch_cg_dir_fused(int d, hipStream_t st, const SegTable &T, int nnodes, NodeBits bits, const double *partials,
-                         const CgNode *cg_in, CgNode *cg_out, NodeBits *dmask, double *host_scalars, unsigned *arrived,
-                         unsigned long long *host_flag, unsigned long long seq, unsigned long long *dev_seq, const double *v, double *p);
 
 // ---- multifrontal SPD solve (spd.h) ----
 // One tile of the solve with everything it needs to know about its front: 64 bytes, one load.

@@ -548,6 +548,7 @@ __device__ __forceinline__ void loss_weight(int loss, double dl, double s, doubl
 struct InterLin {   // (k_inter mode 1) Df at the extrapolated point from the kept products G X[k], G X[k-1]
   const double *GXc = nullptr, *GXp = nullptr;
   double *out = nullptr;
+  const double *gamma_dev = nullptr;   // per-node gamma in device memory (a launch that may be replayed), else `gamma`
   NodeCoefs gamma;
 };
 template <int D>
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask ma
         double a[RS], b[RS];
         load_vec<RS>(lin.GXc + (size_t)row * RS, a);
         load_vec<RS>(lin.GXp + (size_t)row * RS, b);
-        const double gm = lin.gamma.a[s.node];
+        const double gm = lin.gamma_dev ? lin.gamma_dev[s.node] : lin.gamma.a[s.node];
 #pragma unroll
         for (int k = 0; k < RS; k++) acc[k] += fma(gm, a[k] - b[k], a[k]);
         store_vec<RS>(lin.out + (size_t)row * RS, acc);
@@ -971,14 +972,14 @@ __global__ __launch_bounds__(SEG_ROWS) void k_proximal(const Seg *segs, NodeMask
 }
 
 template <int D>
-__global__ __launch_bounds__(SEG_ROWS) void k_extrapolate(const Seg *segs, NodeMask mask, NodeCoefs gamma,
+__global__ __launch_bounds__(SEG_ROWS) void k_extrapolate(const Seg *segs, NodeMask mask, NodeCoefs gamma, const double *gamma_dev,
                                                      const double *a, const double *b, double *out) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
   if (!node_on(mask, s.node)) return;
   const int row = s.begin + threadIdx.x;
   if (row >= s.end) return;
-  const double gm = gamma.a[s.node];
+  const double gm = gamma_dev ? gamma_dev[s.node] : gamma.a[s.node];   // (gamma_dev: a launch that may be replayed, k_set_coefs)
   double va[RS], vb[RS];
   load_vec<RS>(a + (size_t)row * RS, va);
   load_vec<RS>(b + (size_t)row * RS, vb);
@@ -1292,7 +1293,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_bdiag_dot(const Seg *segs, NodeMas
 // host gets the numbers by polling a cache line instead of a copy + stream synchronisation.
 __global__ __launch_bounds__(64) void k_reduce(SegTable T, int all_rows, int nslots, const double *partials,
                                                double *host_scalars, unsigned *arrived, unsigned long long *host_flag,
-                                               unsigned long long seq) {
+                                               unsigned long long seq, unsigned long long *dev_seq) {
   const int a = blockIdx.x / nslots, s = blockIdx.x % nslots, lane = threadIdx.x;
   const double *p = partials + (size_t)s * T.nseg_all;
   double v = 0;
@@ -1306,9 +1307,19 @@ __global__ __launch_bounds__(64) void k_reduce(SegTable T, int all_rows, int nsl
     const unsigned done = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
     if (done == gridDim.x - 1) {
       __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (seq == 0: a launch replayed from a captured graph takes the next value from the device's own count, see k_cg_scal)
+      if (seq == 0) seq = *dev_seq + 1;
+      *dev_seq = seq;
       __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+}
+
+// The per-iteration coefficients of a node (the Nesterov gamma of the extrapolation) as a DEVICE array: launches replayed from
+// a captured graph cannot carry fresh by-value arguments, so the one eager launch of an iteration that knows them writes
+// them here and the replayed kernels read them (k_extrapolate, k_inter).
+__global__ __launch_bounds__(64) void k_set_coefs(NodeCoefs C, int n, double *dev) {
+  if ((int)threadIdx.x < n) dev[threadIdx.x] = C.a[threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------
@@ -1403,7 +1414,7 @@ __global__ __launch_bounds__(384) void k_tnt_begin(SegTable T, int nnodes, TntBe
 
 // The scalar step of STPCG for one node from the sums of a phase (v[0..3]: phase 0 <p, H p>, <H p, H p>, <p, p>, <p, r>;
 // phase 1: v[0] = <r, v>), IterativeSolvers.h:296-390 -- shared by k_cg_scal and by the vector kernels that take the
-// step themselves (k_cg_step_fused / k_cg_dir_fused), so that every path does the same arithmetic.
+// step (kept apart from the launch plumbing).
 __device__ __forceinline__ void cg_scal_logic(int phase, const double (&v)[4], CgNode &c) {
   if (phase == 0) {
     const double kappa_k = v[0];
@@ -1493,144 +1504,6 @@ __global__ __launch_bounds__(256) void k_cg_scal(SegTable T, int phase, const do
       __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
-}
-
-// ---- the scalar step taken by the vector kernel that needs it --------------------------------------------------------
-// k_cg_scal is a launch of its own between the pass that leaves a phase's dot products and the vector update that uses
-// the step length: 5 us of a CG step whose other launches are 5-10 us each when few nodes still iterate.  Here every
-// workgroup of the vector update (one 64-row segment of a node) sums its node's partial sums itself -- in k_cg_scal's
-// order, so every workgroup of a node and k_cg_scal get the same bits -- and takes the scalar step in registers.  The
-// node's FIRST segment also does what k_cg_scal does for the others: it writes the new state (to the OTHER of two state
-// buffers: the node's remaining workgroups still read the old one), moves the node's bits in the device masks, writes
-// the summary the host polls and counts itself in; the last of these raises the flag.  A node that is not part of the
-// step carries its state over unchanged.
-struct CgFusedArgs {
-  const int *own_ptr;              // SegTable::own_ptr
-  int nseg_all, nnodes;
-  const double *partials;
-  const CgNode *cg_in;
-  CgNode *cg_out;
-  NodeBits *dmask;
-  double *host_scalars;
-  unsigned *arrived;
-  unsigned long long *host_flag, seq, *dev_seq;
-};
-// returns the node's new state; `mine`: the node takes this phase's scalar step
-template <int PHASE>
-__device__ __forceinline__ CgNode cg_fused_scalar(const CgFusedArgs &F, int a, int seg_index, bool mine) {
-  const int lane = threadIdx.x & 63;
-  double v[4] = {0.0, 0.0, 0.0, 0.0};
-  constexpr int NS = PHASE == 0 ? 4 : 1;
-  CgNode c = F.cg_in[a];   // (in flight while the sums are taken)
-  if (mine) {
-    // the NS sums side by side (their loads and their shuffle ladders interleave); per sum the order of k_cg_scal
-    double t[NS];
-#pragma unroll
-    for (int q = 0; q < NS; q++) t[q] = 0.0;
-    const int k1 = F.own_ptr[a + 1];
-    for (int k = F.own_ptr[a] + lane; k < k1; k += 64) {
-#pragma unroll
-      for (int q = 0; q < NS; q++) t[q] += F.partials[(size_t)q * F.nseg_all + k];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-      for (int q = 0; q < NS; q++) t[q] += __shfl_down(t[q], o, 64);
-    }
-#pragma unroll
-    for (int q = 0; q < NS; q++) v[q] = __shfl(t[q], 0, 64);
-  }
-  if (mine) cg_scal_logic(PHASE, v, c);
-  if (seg_index == F.own_ptr[a] && lane == 0) {   // the node's first segment: k_cg_scal's duties
-    F.cg_out[a] = c;
-    if (mine && !c.live) {
-      atomicAnd(F.dmask + 1, ~(1ull << a));
-      atomicOr(F.dmask + 2, 1ull << a);
-    }
-    __hip_atomic_store(F.host_scalars + a * CG_SUMMARY + 0, (double)c.live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(F.host_scalars + a * CG_SUMMARY + 1, c.h_M_norm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(F.host_scalars + a * CG_SUMMARY + 2, (double)c.cg_it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __atomic_thread_fence(__ATOMIC_RELEASE);
-    const unsigned done = __hip_atomic_fetch_add(F.arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (done == (unsigned)F.nnodes - 1) {
-      if (PHASE == 1) F.dmask[0] = __hip_atomic_load(F.dmask + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next step's nodes
-      __hip_atomic_store(F.arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned long long seq = F.seq;
-      if (seq == 0) seq = *F.dev_seq + 1;
-      *F.dev_seq = seq;
-      __hip_atomic_store(F.host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-  return c;
-}
-
-// phase 0 + k_cg_step.  upd: the nodes whose vectors are updated (the first step of a run: every node of the run, live or
-// not -- a node that stops before its first step has c1 = 0 and gets s = H s = 0 written); the scalar step is taken by
-// the nodes of the device mask dmask[0].
-template <int D>
-__global__ __launch_bounds__(SEG_ROWS) void k_cg_step_fused(const Seg *segs, NodeMask upd, CgFusedArgs F, const double *p,
-                                                            const double *Hp, double *s, double *hs, double *r, const double *r0) {
-  constexpr int RS = Dim<D>::RS;
-  const int si = SEGB;
-  const Seg sg = segs[si];
-  const bool mine = (F.dmask[0] >> sg.node) & 1ull;
-  const bool upd_on = node_on(upd, sg.node);
-  const int row = sg.begin + threadIdx.x;
-  const bool on = upd_on && row < sg.end;
-  // the vectors first: their loads are in flight while the node's scalar step is taken (a chain of dependent loads and
-  // a few square roots and divisions that would otherwise sit in front of them)
-  double vp[RS], vh[RS], vs[RS], vhs[RS], vr[RS];
-#pragma unroll
-  for (int k = 0; k < RS; k++) { vp[k] = vh[k] = vs[k] = vhs[k] = vr[k] = 0.0; }
-  if (on) {
-    load_vec<RS>(p + (size_t)row * RS, vp);
-    load_vec<RS>(Hp + (size_t)row * RS, vh);
-    if (!r0) {
-      load_vec<RS>(s + (size_t)row * RS, vs);
-      load_vec<RS>(hs + (size_t)row * RS, vhs);
-    }
-    load_vec<RS>((r0 ? r0 : r) + (size_t)row * RS, vr);
-  }
-  const CgNode c = cg_fused_scalar<0>(F, sg.node, si, mine);
-  if (!on) return;
-  const double cc = c.c1, cc_r = c.cr;
-#pragma unroll
-  for (int k = 0; k < RS; k++) vs[k] = fma(cc, vp[k], 1.0 * vs[k]);
-  store_vec<RS>(s + (size_t)row * RS, vs);
-#pragma unroll
-  for (int k = 0; k < RS; k++) vhs[k] = fma(cc, vh[k], 1.0 * vhs[k]);
-  store_vec<RS>(hs + (size_t)row * RS, vhs);
-  if (cc_r != 0.0) {
-#pragma unroll
-    for (int k = 0; k < RS; k++) vr[k] = fma(cc_r, vh[k], 1.0 * vr[k]);
-    store_vec<RS>(r + (size_t)row * RS, vr);
-  }
-}
-
-// phase 1 + k_cg_dir: p = -v + beta p for the nodes that go on (the nodes of dmask[1] that do not stop with this step)
-template <int D>
-__global__ __launch_bounds__(SEG_ROWS) void k_cg_dir_fused(const Seg *segs, NodeBits bits, CgFusedArgs F, const double *v, double *p) {
-  constexpr int RS = Dim<D>::RS;
-  const int si = SEGB;
-  const Seg sg = segs[si];
-  // (a node's first segment may already have cleared the node's bit -- then the node stops with this step, and there is
-  // nothing to update: either way of reading the word gives the same result)
-  const bool mine = ((F.dmask[1] & bits) >> sg.node) & 1ull;
-  const int row = sg.begin + threadIdx.x;
-  const bool on = mine && row < sg.end;
-  double vv[RS], vp[RS];
-#pragma unroll
-  for (int k = 0; k < RS; k++) { vv[k] = vp[k] = 0.0; }
-  if (on) {   // (in flight while the scalar step is taken)
-    load_vec<RS>(v + (size_t)row * RS, vv);
-    load_vec<RS>(p + (size_t)row * RS, vp);
-  }
-  const CgNode c = cg_fused_scalar<1>(F, sg.node, si, mine);
-  if (!on || !c.live) return;
-  const double be = c.be;
-#pragma unroll
-  for (int k = 0; k < RS; k++) vp[k] = fma(be, vp[k], -1.0 * vv[k]);
-  store_vec<RS>(p + (size_t)row * RS, vp);
 }
 
 #ifdef SPD_TRACE   /* measurement build only: per-tile phase timestamps (100 MHz wall clock), see spd_profile() */
@@ -2501,7 +2374,8 @@ void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, co
 void launch_inter(int d, hipStream_t st, const SegTable &T, NodeMask mask, const InterEdgesDev &E, int loss,
                   double loss_reg, int mode, bool quad, const double *Z, const double *Zprev,
                   const double *Qdiag, const double *Ddiag, double *DfE, double *g, double *partials, double *wout,
-                  const double *GXc, const double *GXp, const NodeCoefs *gamma, double *Df_out, const double *Znbr) {
+                  const double *GXc, const double *GXp, const NodeCoefs *gamma, double *Df_out, const double *Znbr,
+                  const double *gamma_dev) {
   const int nb = mode == 0 ? T.nseg_all : T.nseg_own;
   if (nb == 0) return;
   // operand by operand: per incidence its 128-byte record and the other endpoint's pose; per own pose its record, the previous
@@ -2516,7 +2390,7 @@ void launch_inter(int d, hipStream_t st, const SegTable &T, NodeMask mask, const
                           (mode == 0 ? (double)(E.nrows_all - E.nrows_own) * nbr_b : 0.0);
   ProfScope ps(PK_INTER, st, (double)E.m * (8.0 * (d * d + d + 2) + 8) + 2.0 * (mode == 0 ? E.nrows_all : E.nrows_own) * 8.0 * (d + 1) * d, 1, operands);
   InterLin lin;
-  if (mode == 1 && Df_out && GXc && GXp && gamma) { lin.GXc = GXc; lin.GXp = GXp; lin.out = Df_out; lin.gamma = *gamma; }
+  if (mode == 1 && Df_out && GXc && GXp && gamma) { lin.GXc = GXc; lin.GXp = GXp; lin.out = Df_out; lin.gamma = *gamma; lin.gamma_dev = gamma_dev; }
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_inter<D>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, E, loss, loss_reg,
                                         mode, quad ? 1 : 0, T.nseg_own, Z, Zprev, Qdiag, Ddiag, DfE, g, partials,
                                         T.nseg_all, mode == 0 ? wout : nullptr, lin, mode == 0 ? Znbr : nullptr));
@@ -2567,12 +2441,12 @@ void launch_proximal(int d, hipStream_t st, const SegTable &T, NodeMask mask, co
 }
 
 void launch_extrapolate(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask,
-                        const NodeCoefs &gamma, const double *a, const double *b, double *out) {
+                        const NodeCoefs &gamma, const double *a, const double *b, double *out, const double *gamma_dev) {
   const int nb = nseg(T, all_rows);
   if (nb == 0) return;
   ProfScope ps(PK_AXPBY, st, 3.0 * (all_rows ? T.rows_all : T.rows_own) * 8.0 * (d + 1) * d);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_extrapolate<D>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, gamma, a, b,
-                                        out));
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_extrapolate<D>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, gamma, gamma_dev,
+                                        a, b, out));
 }
 
 void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask, double alpha,
@@ -2613,32 +2487,6 @@ void launch_cg_dir(int d, hipStream_t st, const SegTable &T, NodeMask mask, cons
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_AXPBY, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cg_dir<D>), dim3(own_grid(T, mask)), dim3(SEG_ROWS), 0, st, T.segs, mask, cg, v, p));
-}
-
-static CgFusedArgs cg_fused_args(const SegTable &T, int nnodes, const double *partials, const CgNode *cg_in, CgNode *cg_out,
-                                 NodeBits *dmask, double *host_scalars, unsigned *arrived, unsigned long long *host_flag,
-                                 unsigned long long seq, unsigned long long *dev_seq) {
-  CgFusedArgs F;
-  F.own_ptr = T.own_ptr; F.nseg_all = T.nseg_all; F.nnodes = nnodes; F.partials = partials; F.cg_in = cg_in; F.cg_out = cg_out;
-  F.dmask = dmask; F.host_scalars = host_scalars; F.arrived = arrived; F.host_flag = host_flag; F.seq = seq; F.dev_seq = dev_seq;
-  return F;
-}
-void launch_cg_step_fused(int d, hipStream_t st, const SegTable &T, int nnodes, NodeMask upd, const double *partials,
-                          const CgNode *cg_in, CgNode *cg_out, NodeBits *dmask, double *host_scalars, unsigned *arrived,
-                          unsigned long long *host_flag, unsigned long long seq, unsigned long long *dev_seq, const double *p,
-                          const double *Hp, double *s, double *hs, double *r, const double *r0) {
-  if (T.nseg_own == 0) return;
-  ProfScope ps(PK_AXPBY, st, (r0 ? 6.0 : 8.0) * T.rows_own * 8.0 * (d + 1) * d);
-  const CgFusedArgs F = cg_fused_args(T, nnodes, partials, cg_in, cg_out, dmask, host_scalars, arrived, host_flag, seq, dev_seq);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cg_step_fused<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, upd, F, p, Hp, s, hs, r, r0));
-}
-void launch_cg_dir_fused(int d, hipStream_t st, const SegTable &T, int nnodes, NodeBits bits, const double *partials,
-                         const CgNode *cg_in, CgNode *cg_out, NodeBits *dmask, double *host_scalars, unsigned *arrived,
-                         unsigned long long *host_flag, unsigned long long seq, unsigned long long *dev_seq, const double *v, double *p) {
-  if (T.nseg_own == 0) return;
-  ProfScope ps(PK_AXPBY, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
-  const CgFusedArgs F = cg_fused_args(T, nnodes, partials, cg_in, cg_out, dmask, host_scalars, arrived, host_flag, seq, dev_seq);
-  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cg_dir_fused<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, bits, F, v, p));
 }
 
 void launch_cg_begin(hipStream_t st, int nnodes, NodeBits bits, const CgStart &S, int max_it, CgNode *cg, NodeBits *dmask) {
@@ -2772,11 +2620,14 @@ __global__ __launch_bounds__(384) void k_star_sums(SegTable T, int nnodes, unsig
     out[0] = f1; out[1] = f2; out[2] = d1; out[3] = d2;
   }
 }
-__global__ void k_publish(const double *vals, int n, double *host, unsigned long long *host_flag, unsigned long long seq) {
+__global__ void k_publish(const double *vals, int n, double *host, unsigned long long *host_flag, unsigned long long seq,
+                          unsigned long long *dev_seq) {
   if (threadIdx.x < n) __hip_atomic_store(host + threadIdx.x, vals[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __syncthreads();
   if (threadIdx.x == 0) {
     __atomic_thread_fence(__ATOMIC_RELEASE);
+    if (seq == 0) seq = *dev_seq + 1;   // (replayed from a graph: see k_reduce)
+    *dev_seq = seq;
     __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
@@ -2786,16 +2637,22 @@ void launch_star_sums(hipStream_t st, const SegTable &T, int nnodes, unsigned va
   for (int q = 0; q < 6; q++) sl.s[q] = slots6[q];
   hipLaunchKernelGGL(k_star_sums, dim3(1), dim3(384), 0, st, T, nnodes, valid_slots, sl, partials, out);
 }
-void launch_publish(hipStream_t st, const double *vals, int n, double *host, unsigned long long *host_flag, unsigned long long seq) {
+void launch_publish(hipStream_t st, const double *vals, int n, double *host, unsigned long long *host_flag, unsigned long long seq,
+                    unsigned long long *dev_seq) {
   ProfScope ps(PK_REDUCE, st, 8.0 * n);
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, vals, n, host, host_flag, seq);
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, vals, n, host, host_flag, seq, dev_seq);
 }
 
 void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows, int nslots, const double *partials,
-                   double *host_scalars, unsigned *arrived, unsigned long long *host_flag, unsigned long long seq) {
+                   double *host_scalars, unsigned *arrived, unsigned long long *host_flag, unsigned long long seq,
+                   unsigned long long *dev_seq) {
   ProfScope ps(PK_REDUCE, st, 8.0 * nslots * T.nseg_all);
   hipLaunchKernelGGL(k_reduce, dim3(nnodes * nslots), dim3(64), 0, st, T, all_rows ? 1 : 0, nslots, partials, host_scalars,
-                     arrived, host_flag, seq);
+                     arrived, host_flag, seq, dev_seq);
+}
+
+void launch_set_coefs(hipStream_t st, const NodeCoefs &C, int n, double *dev) {
+  hipLaunchKernelGGL(k_set_coefs, dim3(1), dim3(64), 0, st, C, n, dev);
 }
 
 __global__ __launch_bounds__(256) void k_pack_panels(const SpdItem *items, const PanelSrc *srcs, const double *src, double *panels) {

@@ -62,24 +62,11 @@ struct NodeTnt {
 };
 }  // namespace
 
-// The CG steps of a group go out as one graph replay each when the group is small enough for its steps to be bound by the
-// host's launch rate (a step of the headline's eight-node group streams gigabytes: nothing to gain, and its launches
-// shrink with the set of nodes that still iterate, which a replay cannot do).  Never while launches are being timed.
+// The CG steps of a group go out as one graph replay each wherever the segments of the iteration do (Group::segment,
+// iter_graph_wanted); DPGO_CG_GRAPH=0 keeps just these eager (A/B hook).
 bool Group::cg_graph_wanted() const {
   static const int force = [] { const char *e = getenv("DPGO_CG_GRAPH"); return e ? atoi(e) : -1; }();
-  // (the one-launch solve experiment hands a per-solve epoch to its kernel by value: nothing a replay could carry)
-  if (prof_enabled() || force == 0 || Ltt_.flow || Lrr_.flow) return false;
-  if (force == 1) return true;
-  // (measured on a fast host: city10000 / 8 nodes +8..13 %; a group of ONE node -- sphere2500, one rank of the headline
-  // graph -- loses 2.5..7 %: a replay's start-up against a dozen very short launches.  Where the host is the slower side
-  // a replay wins either way: DPGO_CG_GRAPH=1)
-  return P0_ <= 40000 && num_local() >= 2;
-}
-
-void Group::cg_graphs_release() {
-  for (auto &c : cg_graphs_)
-    if (c.exec) (void)hipGraphExecDestroy(c.exec);
-  cg_graphs_.clear();
+  return force != 0 && iter_graph_wanted();
 }
 
 void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, const double *g_alt, bool base_ready) {
@@ -209,19 +196,127 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     else s.iteration++;
   };
   auto cgs = [&](int a, int k) { return h_cg_[a * CG_SUMMARY + k]; };
-  set_mask(nodes);
-  const bool have_sums = quad_model(X, base_ready);
+  // ---- STPCG (IterativeSolvers.h:207-426).  The scalar recurrences (alpha, beta, the boundary / negative
+  // curvature / kernel tests, the stopping test) run on the device (k_cg_scal); the vector kernels take their
+  // step lengths and the set of still-iterating nodes from device memory, so a whole CG step is enqueued
+  // without a host round trip.  The host only polls the summary (live, |h|_M, iterations) of a step it enqueued
+  // earlier: step i+1 is already queued when the outcome of step i arrives; once every node has stopped, the
+  // kernels of the surplus step find an empty device mask and return at once.
+  // by value: the nodes the host last saw iterating (it sizes the launches -- the solves shrink their grids with it);
+  // by pointer: the device's own, more recent masks
+  NodeBits bitsA = 0;
+  NodeMask mA = ALL_NODES, mB = ALL_NODES;
+  // first half of a step: H p and its four scalars, then the step-length logic (:296-362)
+  // first: the first step of a run -- s_0 = 0, H s_0 = 0, r_0 = grad are not materialised, the step takes them as given, and
+  // it runs for every node of the run, live or not: a node that stops before its first step has c1 = 0 and gets its
+  // s = H s = 0 written here
+  auto stepA = [&](bool first) {
+    cur_mask_ = mA;
+    launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, pk, true, nullptr, w1, nullptr, 0, nullptr, nullptr, 0);   // G [0 ; p.R]
+    solve_tt(w1, w3, -1.0);
+    apply_tcol(w3, w1, nullptr, 2, X, nabla, pk, Hp, first ? grad : rk, partials_.p);   // Hp and <p,Hp>, <Hp,Hp>, <p,p>, <p,r>
+    // the step-length logic (k_cg_scal), then s += c1 p, H s += c1 H p for every node of the step (a node that stops here
+    // takes its boundary step), r += alpha H p for those that go on
+    launch_cg_scal(st_, T_, L, 0, partials_.p, cg_.p, dmask_.p, h_cg_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
+    launch_cg_step(d_, st_, T_, first ? NodeMask{bitsA, nullptr} : mA, NodeCoefs(), pk, Hp, sk, hh, rk, cg_.p, first ? grad : nullptr);
+  };
+  // second half: preconditioner; beta and the recurrences, next stopping test (:364-390, :285-291)
+  auto stepB = [&]() {
+    cur_mask_ = mB;
+    if (use_precon) {
+      if (jacobi) launch_rot_rowscale(d_, st_, T_, cur_mask_, jacobi_.p, rk, w1);
+      else solve_rr(rk, w1, 1.0);
+      launch_tangent_rot(d_, st_, T_, cur_mask_, X, w1, vk, rk, partials_.p, 0);   // v = Proj(M^-1 r) and <r, v>
+    } else {
+      copy_rows(vk, rk, false, 0);
+      const double *pa[MAX_DOTS] = {rk}, *pb[MAX_DOTS] = {vk};
+      launch_dots(d_, st_, T_, cur_mask_, 1, pa, pb, P2, partials_.p, 0);
+    }
+    launch_cg_scal(st_, T_, L, 1, partials_.p, cg_.p, dmask_.p, h_cg_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
+    launch_cg_dir(d_, st_, T_, cur_mask_, cg_.p, vk, pk);
+  };
+  // what a segment's key must hold beside the rotating buffers (segment()): the vectors of this call and its variant
+  // (X is looked up at the time of use: an accepted step swaps the iterate's buffers)
+  auto K = [](const void *q) { return (unsigned long long)(uintptr_t)q; };
+  const unsigned long long kg = K(g), kga = K(ga), kvar = (use_precon ? 1ull : 0ull) | (jacobi ? 2ull : 0ull) | (base_ready ? 4ull : 0ull);
+  // One whole step (A then B, not the first) as ONE submission: captured once per set of argument values, replayed ever
+  // after.  The by-value node sets of a replay are the group's nodes -- the device's own masks keep the nodes that are
+  // not (or no longer) part of the CG out, as they do for a node that stopped since the host last looked.
+  auto graph_step = [&]() {
+    const NodeBits all = L >= 64 ? ~0ull : ((1ull << L) - 1);
+    const NodeMask sA = mA, sB = mB;
+    segment(21, {K(X), kvar}, [&] {
+      mA = NodeMask{all, dmask_.p};
+      mB = NodeMask{all, dmask_.p + 1};
+      stepA(false);
+      stepB();
+    });
+    mA = sA; mB = sB;
+  };
+  const bool use_graph = cg_graph_wanted();
+  // (the summary of a later step may already have overwritten the one waited for: the set only shrinks, so whatever
+  // is read is a superset of the nodes that will still be live when the next launches run)
+  std::vector<int> A;
+  auto any_live = [&]() {
+    NodeBits live = 0;
+    for (int a : A)
+      if (cgs(a, 0) != 0.0) live |= 1ull << a;
+    mA = live_mask(live, dmask_.p);       // (few live nodes: the own-segment launches cover them alone)
+    mB = live_mask(live, dmask_.p + 1);
+    return live != 0;
+  };
+  static const int lag = env_lag();
+
   // The first trust-region iteration starts without a host round trip: the norms, the gradient tests and the start
   // values of the CG are taken on the device (k_tnt_begin); the host reads the same sums at its first wait below.
   const bool device_start = o.max_iterations > 0 && o.max_iterations_accepted > 0 && env_device_start();
-  if (device_start) norms_enqueue(true, have_sums);
-  else norms(nodes, true, have_sums);
+  // In the early regime every node ends its first CG step on the trust-region boundary, so -- as long as that was the case
+  // the last time -- the trial point of the nodes whose CG is over (dmask[2]) is enqueued right behind that step and ONE
+  // wait brings the norms, the CG summary and the trial point's sums.  Otherwise the step is awaited at once.
+  const bool spec = device_start && tnt_speculate_;
+  set_mask(nodes);
+  const NodeBits bits_nodes = cur_mask_.v;
+  unsigned long long seqA = 0;
+  if (device_start) {
+    // Everything from the model gradient to the first wait is branch-free: ONE segment (a replay where the host's launch
+    // rate would bound it).  Every node of `nodes` is a candidate (the iteration limits allow a first iteration), the radii
+    // are TNTParams::Delta0.
+    bitsA = bits_nodes;
+    int nslots = 0;
+    if (spec) {
+      nslots = std::max((int)NSUM, deferred_slots_);
+      deferred_slots_ = 0;
+    }
+    segment(20, {bits_nodes, K(X), kg, kga, kvar, spec ? 1ull : 0ull, (unsigned long long)nslots}, [&] {
+      cur_mask_ = live_mask(bits_nodes, nullptr);
+      const bool have_sums = quad_model(X, base_ready);
+      norms_enqueue(true, have_sums);
+      std::vector<double> Delta(L, 0.0);
+      for (int a : nodes) Delta[a] = S[a].Delta;
+      launch_tnt_begin(st_, T_, L, bitsA, use_precon, o.max_tCG_iterations, o.grad_norm_tol, o.preconditioned_grad_norm_tol,
+                       o.STPCG_kappa, o.STPCG_theta, Delta.data(), partials_.p, cg_.p, dmask_.p, h_tnt_);
+      mA = live_mask(bitsA, dmask_.p);
+      mB = live_mask(bitsA, dmask_.p + 1);
+      stepA(true);
+      if (spec) {
+        enqueue_trial(NodeMask{bitsA, dmask_.p + 2});
+        launch_reduce(st_, T_, L, false, nslots, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
+      }
+    });
+    mA = live_mask(bitsA, dmask_.p);   // (a replay does not run the body: the host's copies)
+    mB = live_mask(bitsA, dmask_.p + 1);
+    cur_mask_ = live_mask(bits_nodes, nullptr);
+    seqA = fetch_seq_ - (spec ? 1 : 0);
+  } else {
+    const bool have_sums = quad_model(X, base_ready);
+    norms(nodes, true, have_sums);
+  }
 
   for (bool first_iteration = true;; first_iteration = false) {
     const bool dev = first_iteration && device_start;
     // ---- nodes that start another trust-region iteration (TNT.h:446-484); with `dev` the gradient tests are the
     // device's, and A holds the candidates until the host has seen the summary
-    std::vector<int> A;
+    A.clear();
     for (int a : nodes) {
       NodeTnt &s = S[a];
       if (!s.active) continue;
@@ -233,25 +328,14 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       A.push_back(a);
     }
     if (A.empty()) break;
-    // ---- STPCG (IterativeSolvers.h:207-426).  The scalar recurrences (alpha, beta, the boundary / negative
-    // curvature / kernel tests, the stopping test) run on the device (k_cg_scal); the vector kernels take their
-    // step lengths and the set of still-iterating nodes from device memory, so a whole CG step is enqueued
-    // without a host round trip.  The host only polls the summary (live, |h|_M, iterations) of a step it enqueued
-    // earlier: step i+1 is already queued when the outcome of step i arrives; once every node has stopped, the
-    // kernels of the surplus step find an empty device mask and return at once.
-    set_mask(A);
-    const NodeBits bitsA = cur_mask_.v;
-    // p_0 = -v_0, v_0 = P(grad): written by the pass that took the preconditioned gradient norm (norms_enqueue);
-    // s_0 = 0, H s_0 = 0, r_0 = grad are not materialised: the first step of the run takes them as given.
-    // A later iteration of a node whose step was rejected starts from the same gradient: p_0 again (pk was overwritten)
-    if (!first_iteration) launch_cg_init(d_, st_, T_, cur_mask_, grad, use_precon ? pg : grad, nullptr, nullptr, nullptr, nullptr, pk);
-    bool first_step = true;
-    if (dev) {
-      std::vector<double> Delta(L, 0.0);
-      for (int a : A) Delta[a] = S[a].Delta;
-      launch_tnt_begin(st_, T_, L, bitsA, use_precon, o.max_tCG_iterations, o.grad_norm_tol, o.preconditioned_grad_norm_tol,
-                       o.STPCG_kappa, o.STPCG_theta, Delta.data(), partials_.p, cg_.p, dmask_.p, h_tnt_);
-    } else {
+    std::vector<double> tsum((size_t)L * NSUM, 0.0);
+    std::vector<char> tried(L, 0);
+    if (!dev) {
+      set_mask(A);
+      bitsA = cur_mask_.v;
+      // p_0 = -v_0, v_0 = P(grad): written by the pass that took the preconditioned gradient norm (norms_enqueue).
+      // A later iteration of a node whose step was rejected starts from the same gradient: p_0 again (pk was overwritten)
+      if (!first_iteration) launch_cg_init(d_, st_, T_, cur_mask_, grad, use_precon ? pg : grad, nullptr, nullptr, nullptr, nullptr, pk);
       CgStart cs;
       for (int a = 0; a < L; a++) cs.rv[a] = cs.Delta[a] = cs.target[a] = 0.0;
       for (int a : A) {
@@ -261,130 +345,14 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
         cs.target[a] = r0 * std::min(o.STPCG_kappa, std::pow(r0, o.STPCG_theta));
       }
       launch_cg_begin(st_, L, bitsA, cs, o.max_tCG_iterations, cg_.p, dmask_.p);
+      mA = live_mask(bitsA, dmask_.p);
+      mB = live_mask(bitsA, dmask_.p + 1);
+      stepA(true);
+      seqA = fetch_seq_;
     }
-    // by value: the nodes the host last saw iterating (it sizes the launches -- the solves shrink their grids with it);
-    // by pointer: the device's own, more recent masks
-    NodeMask mA = live_mask(bitsA, dmask_.p), mB = live_mask(bitsA, dmask_.p + 1);
-    // first half of a step: H p and its four scalars, then the step-length logic (:296-362)
-    // (captured: the launches go into a graph under capture -- the flag's sequence number then comes from the device's own
-    // word, k_cg_scal -- and the host's counter is advanced when the graph is replayed, not here)
-    bool capturing = false;
-    // (measured, DESIGN 7: the fused form LOSES -- city10000 2 250 -> 1 940 it/s, seconds to the objective 2.05 -> 2.09 --
-    // because the system-scope release that publishes a node's summary now sits inside a kernel whose other workgroups
-    // have just written the vectors, and has to wait for their write-back; it stays behind DPGO_CG_FUSE_SCAL=1)
-    static const bool fuse_scal = getenv("DPGO_CG_FUSE_SCAL") && atoi(getenv("DPGO_CG_FUSE_SCAL")) != 0;
-    auto stepA = [&]() {
-      cur_mask_ = mA;
-      launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, pk, true, nullptr, w1, nullptr, 0, nullptr, nullptr, 0);   // G [0 ; p.R]
-      solve_tt(w1, w3, -1.0);
-      apply_tcol(w3, w1, nullptr, 2, X, nabla, pk, Hp, first_step ? grad : rk, partials_.p);   // Hp and <p,Hp>, <Hp,Hp>, <p,p>, <p,r>
-      // the step-length logic (k_cg_scal), then s += c1 p, H s += c1 H p for every node of the step (a node that stops here
-      // takes its boundary step), r += alpha H p for those that go on -- in two launches, or (DPGO_CG_FUSE_SCAL=1, an
-      // experiment that lost) in one: k_cg_step_fused, every workgroup of the update takes its node's scalar step itself
-      // (the first step runs for every node of A, live or not: a node that stops before its first step has c1 = 0 and
-      // gets its s = H s = 0 written here)
-      if (fuse_scal) {
-        launch_cg_step_fused(d_, st_, T_, L, first_step ? NodeMask{bitsA, nullptr} : mA, partials_.p, cg_.p, cg_.p + MAX_LOCAL_NODES,
-                             dmask_.p, h_cg_, reduce_arrived_.p, h_flag_, capturing ? 0ull : ++fetch_seq_, dev_seq_.p, pk, Hp, sk, hh, rk,
-                             first_step ? grad : nullptr);
-      } else {
-        launch_cg_scal(st_, T_, L, 0, partials_.p, cg_.p, dmask_.p, h_cg_, reduce_arrived_.p, h_flag_, capturing ? 0ull : ++fetch_seq_, dev_seq_.p);
-        launch_cg_step(d_, st_, T_, first_step ? NodeMask{bitsA, nullptr} : mA, NodeCoefs(), pk, Hp, sk, hh, rk, cg_.p,
-                       first_step ? grad : nullptr);
-      }
-      first_step = false;
-      return fetch_seq_;
-    };
-    // second half: preconditioner; beta and the recurrences, next stopping test (:364-390, :285-291)
-    auto stepB = [&]() {
-      cur_mask_ = mB;
-      if (use_precon) {
-        if (jacobi) launch_rot_rowscale(d_, st_, T_, cur_mask_, jacobi_.p, rk, w1);
-        else solve_rr(rk, w1, 1.0);
-        launch_tangent_rot(d_, st_, T_, cur_mask_, X, w1, vk, rk, partials_.p, 0);   // v = Proj(M^-1 r) and <r, v>
-      } else {
-        copy_rows(vk, rk, false, 0);
-        const double *pa[MAX_DOTS] = {rk}, *pb[MAX_DOTS] = {vk};
-        launch_dots(d_, st_, T_, cur_mask_, 1, pa, pb, P2, partials_.p, 0);
-      }
-      if (fuse_scal) {   // (state: the first half wrote the second buffer, this half writes the first again)
-        launch_cg_dir_fused(d_, st_, T_, L, cur_mask_.v, partials_.p, cg_.p + MAX_LOCAL_NODES, cg_.p, dmask_.p, h_cg_, reduce_arrived_.p,
-                            h_flag_, capturing ? 0ull : ++fetch_seq_, dev_seq_.p, vk, pk);
-      } else {
-        launch_cg_scal(st_, T_, L, 1, partials_.p, cg_.p, dmask_.p, h_cg_, reduce_arrived_.p, h_flag_, capturing ? 0ull : ++fetch_seq_, dev_seq_.p);
-        launch_cg_dir(d_, st_, T_, cur_mask_, cg_.p, vk, pk);
-      }
-      return fetch_seq_;
-    };
-    // One whole step (A then B, not the first) as ONE submission: captured once per set of argument values, replayed ever
-    // after.  The by-value node sets of a replay are the group's nodes -- the device's own masks keep the nodes that are
-    // not (or no longer) part of the CG out, as they do for a node that stopped since the host last looked.
-    hipGraphExec_t step_graph = nullptr;
-    auto graph_step = [&]() {
-      if (!step_graph) {
-        const NodeBits all = L >= 64 ? ~0ull : ((1ull << L) - 1);
-        std::vector<const void *> key = {X, nabla, grad, sk, rk, vk, pk, Hp, w1, w3, hh, partials_.p, cg_.p, dmask_.p, jacobi ? jacobi_.p : nullptr, (const void *)(uintptr_t)(fuse_scal ? 2 : 0),
-                                         (const void *)(uintptr_t)(use_precon ? 1 : 0)};
-        for (auto &c : cg_graphs_)
-          if (c.key == key) { step_graph = c.exec; break; }
-        if (!step_graph) {
-          const NodeMask sA = mA, sB = mB;
-          mA = NodeMask{all, dmask_.p};
-          mB = NodeMask{all, dmask_.p + 1};
-          capturing = true;
-          hipGraph_t g = nullptr;
-          HIP_CHECK(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
-          try {
-            stepA();
-            stepB();
-          } catch (...) {
-            (void)hipStreamEndCapture(st_, &g);
-            if (g) (void)hipGraphDestroy(g);
-            capturing = false; mA = sA; mB = sB;
-            throw;
-          }
-          HIP_CHECK(hipStreamEndCapture(st_, &g));
-          capturing = false; mA = sA; mB = sB;
-          hipGraphExec_t exec = nullptr;
-          HIP_CHECK(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
-          HIP_CHECK(hipGraphDestroy(g));
-          if (cg_graphs_.size() >= 8) {   // (the iterate alternates between two buffers: more than a few keys means something else varies)
-            (void)hipGraphExecDestroy(cg_graphs_.front().exec);
-            cg_graphs_.erase(cg_graphs_.begin());
-          }
-          cg_graphs_.push_back(CgGraph{key, exec});
-          step_graph = exec;
-        }
-      }
-      HIP_CHECK(hipGraphLaunch(step_graph, st_));
-      fetch_seq_ += 2;   // the two scalar kernels of the replay raise the flag to the device word + 1, + 2
-      return fetch_seq_;
-    };
-    const bool use_graph = cg_graph_wanted();
-    // (the summary of a later step may already have overwritten the one waited for: the set only shrinks, so whatever
-    // is read is a superset of the nodes that will still be live when the next launches run)
-    auto any_live = [&]() {
-      NodeBits live = 0;
-      for (int a : A)
-        if (cgs(a, 0) != 0.0) live |= 1ull << a;
-      mA = live_mask(live, dmask_.p);       // (few live nodes: the own-segment launches cover them alone)
-      mB = live_mask(live, dmask_.p + 1);
-      return live != 0;
-    };
-    static const int lag = env_lag();
-    // The first step.  In the early regime every node ends it on the trust-region boundary, so -- as long as that was
-    // the case the last time -- the trial point of the nodes whose CG is over (dmask[2]) is enqueued right behind it
-    // and ONE wait brings the norms, the CG summary and the trial point's sums.  Otherwise the step is awaited at once.
-    std::vector<double> tsum((size_t)L * NSUM, 0.0);
-    std::vector<char> tried(L, 0);
-    const bool spec = dev && tnt_speculate_;
-    const unsigned long long seqA = stepA();
-    if (spec) {
-      enqueue_trial(NodeMask{bitsA, dmask_.p + 2});
-      fetch(NSUM, false);
-    } else {
-      wait_flag(seqA);
-    }
+    // The first step (enqueued above, or -- with `dev` -- in front of the loop).
+    if (dev && spec) wait_flag(fetch_seq_);   // (the trial point's reduction: everything before it is there too)
+    else wait_flag(seqA);
     if (dev) {
       // the sums k_tnt_begin reduced, and its verdict on the gradient tests
       norms_read(A, true);
@@ -396,7 +364,7 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       }
       A.swap(act);
     }
-    if (spec)
+    if (dev && spec)
       for (int a : A)
         if (cgs(a, 0) == 0.0) {   // its CG ended with (or before) the first step: the sums just read are its trial point's
           tried[a] = 1;
@@ -407,15 +375,16 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     const bool more_steps = any_live();
     if (dev) tnt_speculate_ = !more_steps;   // speculate next time if nobody needed a second step this time
     if (more_steps) {
-      unsigned long long seqB = stepB();
+      stepB();
+      unsigned long long seqB = fetch_seq_;
       for (;;) {
         if (!lag) {
           wait_flag(seqB);
           if (!any_live()) break;
         }
-        unsigned long long next;
-        if (use_graph) next = graph_step();
-        else { stepA(); next = stepB(); }
+        if (use_graph) graph_step();
+        else { stepA(false); stepB(); }
+        const unsigned long long next = fetch_seq_;
         if (lag) {
           wait_flag(seqB);   // the outcome of the step before the one just enqueued
           if (!any_live()) break;
@@ -437,8 +406,14 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     // ---- trial point (TNT.h:505-536) of the nodes that have not had theirs
     if (!rest.empty()) {
       set_mask(rest);
-      enqueue_trial(cur_mask_);
-      fetch(NSUM, false);
+      const NodeMask mrest = cur_mask_;
+      int nslots = std::max((int)NSUM, deferred_slots_);
+      deferred_slots_ = 0;
+      segment(22, {mrest.v, K(X), kg, kga, (unsigned long long)nslots}, [&] {
+        enqueue_trial(mrest);
+        launch_reduce(st_, T_, L, false, nslots, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
+      });
+      wait_flag(fetch_seq_);
       for (int a : rest)
         for (int q = 0; q < NSUM; q++) tsum[(size_t)a * NSUM + q] = scal(a, q);
     }

@@ -267,6 +267,10 @@ int dpgo_prof_collect(double *ms, double *bytes, long *count);   /* arrays of dp
 int dpgo_prof_collect_operands(double *operand_bytes);
 /* size of the two multifrontal factors: dense front entries and number of tree levels */
 int dpgo_group_solver_stats(const dpgo_group_t *grp, long *nnz_tt, long *nnz_rr, int *levels_tt, int *levels_rr);
+/* The branch-free segments of an iteration (C++/examples/dist_pgo.cpp:496-521: iterate, update) go to the GPU as replays of
+ * captured HIP graphs where the host's launch rate would bound the group (DPGO_ITER_GRAPH=0 / 1 forces it off / on):
+ * segments replayed, graphs captured, segments launched eagerly since the group was created. */
+int dpgo_group_graph_stats(const dpgo_group_t *grp, long *replays, long *captures, long *eager);
 
 /* ---- test hooks ------------------------------------------------------------------------- */
 /* Host: the assembled operator `name` in {"G","S","P","P0","Q","D"} of a node as COO triplets in

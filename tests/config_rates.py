@@ -9,6 +9,16 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import argparse                                                  # noqa: E402
+_ap = argparse.ArgumentParser()
+_ap.add_argument("--starve-host", type=int, default=-1, help="pin to one core with this many spinning siblings (tools/starve.py)")
+_ap.add_argument("--only", type=str, default="", help="substring of the configuration names to run")
+_ap.add_argument("--no-oracle", action="store_true", help="skip the oracle's side of the table")
+_args = _ap.parse_args()
+if _args.starve_host >= 0:      # (before anything touches the GPU)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import starve
+    starve.starve_host(_args.starve_host)
 import dpgo_amd                                                  # noqa: E402
 from oracle import g2o as og                                     # noqa: E402
 from oracle.hash import Options as OOptions                      # noqa: E402
@@ -23,6 +33,8 @@ CASES = [  # name, dataset, nodes, loss, accelerated, scheme, iterations
 ]
 out = []
 for name, ds, nn, loss, acc, scheme, iters in CASES:
+    if _args.only and _args.only not in name:
+        continue
     path = os.path.join(ROOT, "fixtures", "g2o", ds + ".g2o")
     num_poses, mm = og.read_g2o_file(path)
     X0 = chordal_initialization(num_poses, mm)
@@ -46,9 +58,9 @@ for name, ds, nn, loss, acc, scheme, iters in CASES:
     gpu.group.sync()
     tg = time.perf_counter() - t0
     t0 = time.perf_counter()
-    for _ in range(iters):
+    for _ in range(0 if _args.no_oracle else iters):
         ostep()
-    to = time.perf_counter() - t0
+    to = max(time.perf_counter() - t0, 1e-9)
     out.append({"config": name, "poses": num_poses, "edges": len(mm), "iterations": iters,
                 "gpu_iters_per_s": iters / tg, "oracle_1core_iters_per_s": iters / to})
     print("%-48s GPU %8.1f it/s   oracle %7.2f it/s" % (name, iters / tg, iters / to), file=sys.stderr)

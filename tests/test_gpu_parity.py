@@ -901,16 +901,16 @@ np.save(sys.argv[1], drv.X())
 
     base = run("base")
     assert np.array_equal(run("lag0", DPGO_CG_LAG="0"), base)
-    # round 4: the CG steps replayed from a captured HIP graph (the default for a group this small) against eager launches
-    assert np.array_equal(run("nograph", DPGO_CG_GRAPH="0"), base)
-    assert np.array_equal(run("nograph_lag0", DPGO_CG_GRAPH="0", DPGO_CG_LAG="0"), base)
+    # round 5: the branch-free segments of an iteration (update() behind the exchange, the head of iterate(), a refinement
+    # up to its trial point, every further CG step) replayed from captured HIP graphs -- the default for a group this
+    # small -- against eager launches; and just the CG steps eager (round 4's switch)
+    assert np.array_equal(run("nograph", DPGO_ITER_GRAPH="0"), base)
+    assert np.array_equal(run("graph_forced", DPGO_ITER_GRAPH="1"), base)
+    assert np.array_equal(run("nograph_lag0", DPGO_ITER_GRAPH="0", DPGO_CG_LAG="0"), base)
+    assert np.array_equal(run("no_cg_graph", DPGO_CG_GRAPH="0"), base)
     # ... own-segment launches that cover only the few nodes still in the CG (their segments dealt to all XCDs) against
     # whole-group grids
     assert np.array_equal(run("whole_grids", DPGO_LIVE_GRIDS="0"), base)
-    # ... and the CG's scalar steps taken inside the vector updates (one launch instead of two per half step; an experiment
-    # that lost) against the separate k_cg_scal launches: the same sums in the same order
-    assert np.array_equal(run("scal_fused", DPGO_CG_FUSE_SCAL="1"), base)
-    assert np.array_equal(run("scal_fused_nograph", DPGO_CG_FUSE_SCAL="1", DPGO_CG_GRAPH="0"), base)
     # the one-launch solve (an experiment that lost): the same tiles in the same order of operations
     assert np.array_equal(run("flow", DPGO_SPD_FLOW="1"), base)
     for tag, env in (("hostfactor", dict(DPGO_SPD_HOST_FACTOR="1")), ("hostpanels", dict(DPGO_SPD_DEVICE_PANELS="0")),
