@@ -250,7 +250,7 @@ def main():
     if args.starve_host >= 0:           # (before anything touches the GPU)
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import starve
-        starved = starve.starve_host(args.starve_host)
+        starved = starve.prepare(args.starve_host)      # (the spinners start after the untimed set-up)
     measured_traffic = None
     if (args.traffic == "auto" and world == 1 and args.gpus == 1 and not args.no_prof and args.prof_steps > 0
             and not args.emulate_world and not args.rendezvous_only):
@@ -336,6 +336,11 @@ def main():
             return box[0]
         try:
             comm = dpgo_amd.Comm(grp, rank, world, bcast if world > 1 else None)
+            if world == 1 and args.emulate_world:
+                # the emulated rank's neighbours live nowhere: run the neighbour-to-neighbour path against itself, in its
+                # steady state (pack, grouped send / recv of every exported record, unpack into a scratch array)
+                comm.self_exchange()
+            comm.enable_timing()
             ok = 1
         except Exception as e:
             sys.stderr.write("[bench] rank %d: RCCL communicator failed (%r)\n" % (rank, e))
@@ -393,6 +398,9 @@ def main():
         torch.cuda.synchronize()
 
     grp.update()
+    if starved is not None:
+        starve.release()
+        time.sleep(0.2)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -487,47 +495,23 @@ def main():
         cpu = cpu_baseline(g, args.nodes, loss, X0, args.cpu_steps)
 
     convergence = None
-    if args.converge > 0 and world == 1 and not args.emulate_world:
+    if args.converge > 0 and not args.emulate_world:
+        # every rank steps (the exchange included when there are several); each keeps ITS clock and ITS nodes' sums per
+        # iteration, and the ranks' traces are combined once after the loop (reduce_trace: objective = sum over the ranks,
+        # time = the slowest rank's) -- no collective inside the timed iterations beyond the exchange itself.  The reference
+        # driver logs the same pair per iteration for every num_nodes (C++/examples/dist_pgo.cpp:492-531).
         grp.initialize_global(X0)
         grp.update()
-        grp.sync()
+        barrier()
         trace, t0 = [], time.perf_counter()
         for _ in range(args.converge):
             step()
             grp.sync()
             trace.append((time.perf_counter() - t0, 2.0 * sum(grp.results(k).fobj for k in range(len(grp))),
-                          sum(int(grp.results(k).tnt_inner_iterations) for k in range(len(grp)) if grp.results(k).refined) / len(grp),
-                          sum(int(grp.results(k).refined) for k in range(len(grp)))))
-        best = min(f for _, f, _, _ in trace)
-        # the reference objective: the one the CPU path reaches on this instance (tools/cpu_convergence.py, committed once
-        # per round as profiles/rNN_cpu_convergence.json); without that file, the lowest objective of this run
-        cpu_ref = None
-        try:
-            import glob
-            cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_convergence.json")))
-            cj = json.load(open(cand[-1]))
-            if args.grid == "50,50,40,400000" and args.nodes == 8 and args.loss == "huber":
-                cpu_ref = {"objective_2F": cj["lowest_2F"], "iterations_to_1e-6": cj["iterations_to_1e-6"],
-                           "seconds_to_1e-6": cj["seconds_to_1e-6"], "cores": cj["cores"], "cpu_model": cj["cpu_model"],
-                           "source": os.path.basename(cand[-1]) + " (tools/cpu_convergence.py: the C++ CPU restatement run to its own 1e-6 on all granted cores; not measured in this run)"}
-        except Exception:
-            cpu_ref = None
-        target = cpu_ref["objective_2F"] if cpu_ref else best
-        hit = next((i for i, (_, f, _, _) in enumerate(trace) if f <= target * (1 + 1e-6)), None)
-        if hit is None:       # (the run stopped short of the CPU's objective: report against its own lowest, and say so)
-            target, cpu_ref = best, dict(cpu_ref or {}, not_reached=True)
-            hit = next(i for i, (_, f, _, _) in enumerate(trace) if f <= target * (1 + 1e-6))
-        tail = trace[-21:] if len(trace) > 21 else trace
-        convergence = {"iterations_run": args.converge, "lowest_2F": best, "target_2F": target,
-                       "target": "the objective the CPU path reaches (cpu_reference)" if cpu_ref and not cpu_ref.get("not_reached") else "lowest objective of this run",
-                       "cpu_reference": cpu_ref, "iterations_to_1e-6": hit + 1,
-                       "seconds_to_1e-6": trace[hit][0], "mean_ms_per_iter_to_1e-6": 1e3 * trace[hit][0] / (hit + 1),
-                       "mean_ms_per_iter_whole_run": 1e3 * trace[-1][0] / len(trace),
-                       "last20_ms_per_iter": 1e3 * (tail[-1][0] - tail[0][0]) / max(len(tail) - 1, 1),
-                       "last20_cg_steps_per_node_per_iter": sum(t[2] for t in tail[1:]) / max(len(tail) - 1, 1),
-                       "last20_refined_nodes_per_iter": sum(t[3] for t in tail[1:]) / max(len(tail) - 1, 1),
-                       "objective_2F_after_first_iteration": trace[0][1],
-                       "objective_2F_at": {str(k): trace[k - 1][1] for k in (1, 10, 50, 100, 200, 400, 800) if k <= len(trace)}}
+                          float(sum(int(grp.results(k).tnt_inner_iterations) for k in range(len(grp)) if grp.results(k).refined)),
+                          float(sum(int(grp.results(k).refined) for k in range(len(grp))))))
+        trace = reduce_trace(trace, dist if world > 1 else None, args.nodes)
+        convergence = summarize_convergence(trace, args.converge, load_cpu_reference(args))
     # DPGO_PRECON_FP32=1 (the opt-in experiment of DESIGN 7: the preconditioner's factor stored in fp32) must never pass for
     # the headline: the line says so in `metric`, `dtype` and `experiment`
     experiment = None
@@ -552,8 +536,9 @@ def main():
                        "refined_nodes_last_step": refined, "tnt_inner_iterations_last_step": inner},
             "objective_2F": 2 * fsum,
             "exchange": None if not do_exchange else ("gloo, staged through the host" if host_staged else
-                                                     ("RCCL, neighbour to neighbour (grouped ncclSend / ncclRecv)" if comm.exchange_kind() == "p2p"
-                                                      else "RCCL all-gather") + " behind the C ABI (dpgo_comm_exchange) on the communicator's stream, joined in update()"),
+                                                     (("RCCL, neighbour to neighbour (grouped ncclSend / ncclRecv)" + (", THIS RANK AS ITS OWN PEER (measurement mode)" if world == 1 and args.emulate_world else ""))
+                                                      if comm.exchange_kind() == "p2p" else "RCCL all-gather") + " behind the C ABI (dpgo_comm_exchange) on the communicator's stream, joined in update()"),
+            "exchange_us_ready_to_done": (lambda t: {"mean_us": t[0], "exchanges": t[1]})(comm.exchange_time()) if comm is not None else None,
             "ranks": per_rank,
             "setup_s": {"graph+chordal_init": t_init, "operators+factorizations": t_group},
             "solver": grp.solver_stats(),
@@ -562,11 +547,71 @@ def main():
         }
         if convergence is not None:
             out["convergence"] = convergence
+            # the two halves of BASELINE's metric side by side: `value` times the cheapest regime of the run (one CG step per
+            # refinement), this one the whole way to the reference objective
+            out["iters_per_s_to_objective"] = convergence["iters_per_s_to_objective"]
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.close()
     if do_exchange:
         dist.destroy_process_group()
+
+
+def reduce_trace(trace, dist, num_nodes):
+    """Per-iteration (seconds, 2 F, CG steps, refined nodes) of THIS rank's nodes -> the job's: the objective, the CG steps
+    and the refined nodes are sums over the ranks, the time stamp of an iteration is the slowest rank's.  dist: an
+    initialised torch.distributed (gloo control plane) or None for one rank.  Returns a list of
+    (seconds, 2F, CG steps per node, refined nodes)."""
+    import numpy as _np
+    a = _np.asarray(trace, dtype=_np.float64).reshape(-1, 4)
+    if dist is not None:
+        import torch
+        sums = torch.from_numpy(_np.ascontiguousarray(a[:, 1:]))
+        tmax = torch.from_numpy(_np.ascontiguousarray(a[:, 0]))
+        dist.all_reduce(sums)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        a = _np.concatenate([tmax.numpy()[:, None], sums.numpy()], axis=1)
+    return [(float(t), float(f), float(c) / num_nodes, float(r)) for t, f, c, r in a]
+
+
+def load_cpu_reference(args):
+    """The objective the CPU path reaches on the headline instance (tools/cpu_convergence.py, committed once per round as
+    profiles/rNN_cpu_convergence.json), or None."""
+    try:
+        import glob
+        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_convergence.json")))
+        cj = json.load(open(cand[-1]))
+        if args.grid == "50,50,40,400000" and args.nodes == 8 and args.loss == "huber":
+            return {"objective_2F": cj["lowest_2F"], "iterations_to_1e-6": cj["iterations_to_1e-6"],
+                    "seconds_to_1e-6": cj["seconds_to_1e-6"], "cores": cj["cores"], "cpu_model": cj["cpu_model"],
+                    "source": os.path.basename(cand[-1]) + " (tools/cpu_convergence.py: the C++ CPU restatement run to its own 1e-6 on all granted cores; not measured in this run)"}
+    except Exception:
+        pass
+    return None
+
+
+def summarize_convergence(trace, iterations_run, cpu_ref):
+    """The second half of BASELINE's metric from a per-iteration trace of (seconds, 2F, CG steps per node, refined nodes):
+    iterations and seconds until the objective first comes within 1e-6 (relative) of the objective the CPU path reaches
+    (cpu_ref; without it, or when the run stops short of it: the run's own lowest objective, and the block says so)."""
+    best = min(f for _, f, _, _ in trace)
+    target = cpu_ref["objective_2F"] if cpu_ref else best
+    hit = next((i for i, (_, f, _, _) in enumerate(trace) if f <= target * (1 + 1e-6)), None)
+    if hit is None:       # (the run stopped short of the CPU's objective: report against its own lowest, and say so)
+        target, cpu_ref = best, dict(cpu_ref or {}, not_reached=True)
+        hit = next(i for i, (_, f, _, _) in enumerate(trace) if f <= target * (1 + 1e-6))
+    tail = trace[-21:] if len(trace) > 21 else trace
+    return {"iterations_run": iterations_run, "lowest_2F": best, "target_2F": target,
+            "target": "the objective the CPU path reaches (cpu_reference)" if cpu_ref and not cpu_ref.get("not_reached") else "lowest objective of this run",
+            "cpu_reference": cpu_ref, "iterations_to_1e-6": hit + 1,
+            "seconds_to_1e-6": trace[hit][0], "mean_ms_per_iter_to_1e-6": 1e3 * trace[hit][0] / (hit + 1),
+            "iters_per_s_to_objective": (hit + 1) / trace[hit][0] if trace[hit][0] > 0 else None,
+            "mean_ms_per_iter_whole_run": 1e3 * trace[-1][0] / len(trace),
+            "last20_ms_per_iter": 1e3 * (tail[-1][0] - tail[0][0]) / max(len(tail) - 1, 1),
+            "last20_cg_steps_per_node_per_iter": sum(t[2] for t in tail[1:]) / max(len(tail) - 1, 1),
+            "last20_refined_nodes_per_iter": sum(t[3] for t in tail[1:]) / max(len(tail) - 1, 1),
+            "objective_2F_after_first_iteration": trace[0][1],
+            "objective_2F_at": {str(k): trace[k - 1][1] for k in (1, 10, 50, 100, 200, 400, 800) if k <= len(trace)}}
 
 
 def cpu_baseline(g, num_nodes, loss, X0, steps):

@@ -146,6 +146,9 @@ SYMBOLS = {
     "dpgo_comm_barrier": (C.c_int, [C.c_void_p]),
     "dpgo_comm_exchange_kind": (C.c_int, [C.c_void_p]),
     "dpgo_comm_bytes_sent": (C.c_long, [C.c_void_p]),
+    "dpgo_comm_self_exchange": (C.c_int, [C.c_void_p]),
+    "dpgo_comm_enable_timing": (C.c_int, [C.c_void_p]),
+    "dpgo_comm_exchange_time": (C.c_int, [C.c_void_p, _DP, C.POINTER(C.c_long)]),
     "dpgo_debug_comm_p2p_self": (C.c_int, [C.c_void_p]),
     "dpgo_host_pack_sent": (C.c_int, [C.c_void_p, _IP, C.c_int, _DP, C.c_int, _DP]),
     "dpgo_host_unpack_recv": (C.c_int, [C.c_void_p, _IP, C.c_int, C.c_int, C.c_int, C.c_int, _IP, _IP, _IP, _DP, _DP,
@@ -666,6 +669,23 @@ class Comm:
     def bytes_sent(self):
         """Bytes this rank hands to RCCL per exchange."""
         return int(lib().dpgo_comm_bytes_sent(self._h))
+
+    def self_exchange(self):
+        """One rank only: exchange() runs the neighbour-to-neighbour path with this rank as its own peer from now on
+        (a measurement mode, dpgo_comm_self_exchange)."""
+        if lib().dpgo_comm_self_exchange(self._h) != 0:
+            raise RuntimeError("dpgo_comm_self_exchange failed")
+
+    def enable_timing(self):
+        if lib().dpgo_comm_enable_timing(self._h) != 0:
+            raise RuntimeError("dpgo_comm_enable_timing failed")
+
+    def exchange_time(self):
+        """(mean microseconds from 'iterate final' to 'neighbour rows in place', exchanges counted)."""
+        us, n = C.c_double(), C.c_long()
+        if lib().dpgo_comm_exchange_time(self._h, C.byref(us), C.byref(n)) != 0:
+            raise RuntimeError("dpgo_comm_exchange_time failed")
+        return us.value, n.value
 
     def allreduce_sum(self, vals):
         a = np.ascontiguousarray(vals, np.float64).ravel().copy()

@@ -286,11 +286,9 @@ int dpgo_group_step(dpgo_group_t *h, struct dpgo_comm *comm) {
   return guarded([&] {
     std::vector<int> all(h->grp->num_local());
     for (int a = 0; a < (int)all.size(); a++) all[a] = a;
-    int rc = h->grp->iterate(all);
-    if (rc != 0) return rc;
-    if (comm && comm->c && (rc = comm->c->exchange()) != 0) return rc;
-    if ((rc = h->grp->communicate_local()) != 0) return rc;
-    return h->grp->update(all);
+    std::function<int()> xchg;
+    if (comm && comm->c) xchg = [comm] { return comm->c->exchange(); };
+    return h->grp->step(all, xchg);
   });
 }
 int dpgo_group_set_collectives(dpgo_group_t *h, void *send_dev, void *gathered_dev, dpgo_allgather_fn ag, dpgo_allreduce_fn ar,
@@ -668,6 +666,19 @@ int dpgo_debug_comm_p2p_self(dpgo_group_t *h) {
     dpgo::Comm c(h->grp, 0, 1, id, /*layout=*/false);   // a communicator of one rank: the group's neighbours need no host
     return c.p2p_self_check();
   });
+}
+
+int dpgo_comm_self_exchange(dpgo_comm_t *c) {
+  if (!c || !c->c) return -1;
+  return guarded([&] { return c->c->enable_self_exchange(); });
+}
+int dpgo_comm_enable_timing(dpgo_comm_t *c) {
+  if (!c || !c->c) return -1;
+  return guarded([&] { return c->c->enable_timing(); });
+}
+int dpgo_comm_exchange_time(dpgo_comm_t *c, double *mean_us, long *count) {
+  if (!c || !c->c) return -1;
+  return guarded([&] { return c->c->exchange_time(mean_us, count); });
 }
 
 int dpgo_comm_barrier(dpgo_comm_t *c) {

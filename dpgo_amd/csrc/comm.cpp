@@ -489,6 +489,63 @@ int Comm::p2p_self_check() {
   return 0;
 }
 
+int Comm::enable_self_exchange() {
+  if (!ok_ || nranks_ != 1 || !comm_ || !cs_ || !(rccl().Send && rccl().Recv && rccl().GroupStart && rccl().GroupEnd)) return -1;
+  Group *grp = grp_;
+  const int RS = (grp->d() + 1) * grp->d();
+  const auto &keys = grp->sent_keys();
+  const auto &rows = grp->sent_rows();
+  const int n = (int)keys.size();
+  if (n == 0) return -1;
+  P2P &x = p2p_state_;
+  x.plan = P2PPlan();
+  x.plan.peers.push_back({rank_, 0, n, 0, n});
+  x.plan.send_keys = keys;
+  x.plan.recv_keys = keys;
+  std::vector<int> ident(n);
+  for (int i = 0; i < n; i++) ident[i] = i;
+  x.send_rows.upload(rows);
+  x.recv_dst.upload(rows);      // (into the same rows of the SCRATCH array)
+  x.recv_src.upload(ident);
+  x.send.alloc((size_t)n * RS);
+  x.recv.alloc((size_t)n * RS);
+  self_scratch_.alloc((size_t)grp->num_records() * RS);
+  HIP_OK(hipDeviceSynchronize());
+  p2p_ = true;
+  self_ = true;
+  return 0;
+}
+
+int Comm::enable_timing() {
+  if (!cs_) return -1;
+  sync_comm_stream();
+  if (ev_ready_) (void)hipEventDestroy(ev_ready_);
+  if (ev_done_) (void)hipEventDestroy(ev_done_);
+  ev_ready_ = ev_done_ = nullptr;
+  grp_->set_pending_exchange(nullptr);
+  HIP_OK(hipEventCreate(&ev_ready_));
+  HIP_OK(hipEventCreate(&ev_done_));
+  timing_ = true; timed_pending_ = false; time_sum_us_ = 0; time_n_ = 0;
+  return 0;
+}
+
+// the last exchange's two events, once both have happened (looked at before they are recorded again)
+void Comm::take_time() {
+  if (!timing_ || !timed_pending_) return;
+  if (hipEventQuery(ev_done_) != hipSuccess) return;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, ev_ready_, ev_done_) == hipSuccess) { time_sum_us_ += 1e3 * ms; time_n_++; }
+  timed_pending_ = false;
+}
+
+int Comm::exchange_time(double *mean_us, long *count) {
+  if (!timing_) return -1;
+  if (timed_pending_) { sync_comm_stream(); take_time(); }
+  if (mean_us) *mean_us = time_n_ ? time_sum_us_ / time_n_ : 0.0;
+  if (count) *count = time_n_;
+  return 0;
+}
+
 size_t Comm::bytes_sent_per_exchange() const {
   const size_t RS = (size_t)(grp_->d() + 1) * grp_->d();
   if (p2p_) return p2p_state_.plan.send_keys.size() * RS * sizeof(double);
@@ -500,16 +557,22 @@ size_t Comm::bytes_sent_per_exchange() const {
 int Comm::exchange() {
   if (!ok_) return -1;
   const int RS = (grp_->d() + 1) * grp_->d();
+  if (timing_) {
+    // (the previous exchange was joined by an update() long ago; its events are about to be recorded again)
+    if (timed_pending_ && hipEventQuery(ev_done_) != hipSuccess) sync_comm_stream();
+    take_time();
+  }
   HIP_OK(hipEventRecord(ev_ready_, grp_->stream()));      // Xk of this iteration is final
   HIP_OK(hipStreamWaitEvent(cs_, ev_ready_, 0));
   if (p2p_) {
-    if (run_p2p(p2p_state_, grp_->Xk_records(), grp_->Xk_records()) != 0) return -1;
+    if (run_p2p(p2p_state_, grp_->Xk_records(), self_ ? self_scratch_.p : grp_->Xk_records()) != 0) return -1;
   } else {
     grp_->pack_sent(send_.p, cs_);
     NCCL_OK(rccl().AllGather(send_.p, gathered_.p, (size_t)stride_ * RS, ncclFloat64, (ncclComm_t)comm_, cs_));
     grp_->unpack_recv(gathered_.p, cs_);
   }
   HIP_OK(hipEventRecord(ev_done_, cs_));
+  timed_pending_ = timing_;
   grp_->set_pending_exchange(ev_done_);
   return 0;
 }

@@ -42,6 +42,16 @@ class Comm {
   // test hook (one rank is enough): the grouped ncclSend / ncclRecv path with THIS rank as its own peer -- pack, GroupStart,
   // Send + Recv to self, GroupEnd, unpack, on records that carry their own keys; 0 = every record arrived where it should
   int p2p_self_check();
+  // Measurement mode for a communicator of ONE rank (bench.py --emulate-world N --force-exchange): from now on exchange()
+  // runs the neighbour-to-neighbour path in its steady state with this rank as its own peer -- pack kernel, ncclGroupStart,
+  // one ncclSend + ncclRecv of every exported record, ncclGroupEnd, unpack kernel, on the communicator's stream, joined by
+  // update() -- the unpack going to a scratch record array, so that the iterate's trajectory is that of the run without
+  // it.  What the p2p path costs an iteration, short of the wire.
+  int enable_self_exchange();
+  // time from "Xk is final" (ev_ready_, the group's stream) to "the neighbour rows are in place" (ev_done_, the
+  // communicator's stream), mean over the exchanges since enable_timing(); events carry time stamps only in this mode
+  int enable_timing();
+  int exchange_time(double *mean_us, long *count);
   size_t bytes_sent_per_exchange() const;   // what this rank hands to RCCL per exchange (p2p: its peers' records; all-gather: one padded block)
 
  private:
@@ -63,6 +73,12 @@ class Comm {
   bool p2p_ = false;
   bool broken_ = false;   // a wait on the communicator's stream ran into its deadline: the stream is never waited for again
   bool lent_ = false;     // the group works with this communicator's collectives (taken back by release())
+  bool self_ = false;     // enable_self_exchange()
+  bool timing_ = false, timed_pending_ = false;
+  double time_sum_us_ = 0;
+  long time_n_ = 0;
+  void take_time();
+  DevBuf<double> self_scratch_;
   struct P2P {            // one neighbour-to-neighbour exchange: the plan, its message buffers, its pack / unpack lists
     P2PPlan plan;
     DevBuf<double> send, recv;

@@ -710,6 +710,10 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   }
   HIP_CHECK(hipSetDevice(device));
   HIP_CHECK(hipStreamCreate(&st_));
+  if (const char *w = getenv("DPGO_WAIT")) {
+    wait_mode_ = std::string(w) == "spin" ? 1 : (std::string(w) == "block" ? 2 : 0);
+    polite_ = wait_mode_ == 2;
+  }
   const int L = (int)nodes_.size();
   const bool trivial = (opt.loss == 0);
   info_.resize(L);
@@ -777,13 +781,14 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   cur_mask_ = ALL_NODES;
   // pinned: [scalars of k_reduce | a cache line | the flag's cache line | CG summaries | TNT summaries]
   const size_t nsc = (size_t)std::max(L, 1) * MAX_SLOTS;
-  HIP_CHECK(hipHostMalloc((void **)&h_scal_, sizeof(double) * (nsc + 16 + (size_t)std::max(L, 1) * (CG_SUMMARY + TNT_SUMMARY + 1)),
+  HIP_CHECK(hipHostMalloc((void **)&h_scal_, sizeof(double) * (nsc + 16 + (size_t)std::max(L, 1) * (CG_SUMMARY + TNT_SUMMARY + 1) + nsc),
                           hipHostMallocMapped | hipHostMallocCoherent));
   h_flag_ = reinterpret_cast<unsigned long long *>(h_scal_ + nsc + 8);
   *h_flag_ = 0;
   h_cg_ = h_scal_ + nsc + 16;
   h_tnt_ = h_cg_ + (size_t)std::max(L, 1) * CG_SUMMARY;
   h_rs_ = h_tnt_ + (size_t)std::max(L, 1) * TNT_SUMMARY;
+  h_upd_ = h_rs_ + std::max(L, 1);   // update()'s sums have a block of their own: the next refinement's sums may arrive before the host has read them
   for (int i = 0; i < std::max(L, 1) * (CG_SUMMARY + TNT_SUMMARY + 1); i++) h_cg_[i] = 0.0;
   reduce_arrived_.alloc(1);
   partials_.alloc((size_t)MAX_SLOTS * std::max(T_.nseg_all, 1));
@@ -1063,7 +1068,13 @@ Group::~Group() {
     fprintf(stderr, "[host] node group of %d: %ld replays %.3f s in hipGraphLaunch (%.1f us each), %ld eager segments %.3f s, %ld waits %.3f s (%.1f us each)\n",
             num_local(), seg_replays_, t_graph_launch_, seg_replays_ ? 1e6 * t_graph_launch_ / seg_replays_ : 0.0, seg_eager_, t_eager_seg_,
             n_wait_, t_wait_, n_wait_ ? 1e6 * t_wait_ / n_wait_ : 0.0);
+  if (host_timing_)
+    fprintf(stderr, "[host] waits: %ld slept on an event, %ld switches to polite waiting, %ld holes (longest %.0f us); waits of < 50 us / 200 us / 1 ms / 5 ms / 50 ms / longer: %ld %ld %ld %ld %ld %ld\n",
+            waits_polite_, polite_switches_, holes_total_, max_hole_us_, wait_hist_[0], wait_hist_[1], wait_hist_[2], wait_hist_[3], wait_hist_[4], wait_hist_[5]);
   const bool idle = drain(failed_ ? 2.0 : 60.0);
+  if (idle)
+    for (auto &e : wait_ev_)
+      if (e) (void)hipEventDestroy(e);
   if (idle) {
     graphs_destroy();
   } else {
@@ -1199,14 +1210,39 @@ void Group::graphs_invalidate() {
   else seg_graphs_.clear();
 }
 
-void Group::segment(int id, std::initializer_list<unsigned long long> extra, const std::function<void()> &body) {
-  if (capturing_) { body(); return; }   // (a segment inside a segment is part of it)
+void Group::defer_or_launch(unsigned long long key, std::function<void()> fn) {
+  if (!defer_armed_) { fn(); return; }
+  deferred_.push_back(std::move(fn));
+  deferred_key_ = deferred_key_ * 1000003ull + key;
+}
+
+void Group::flush_deferred() {
+  if (deferred_.empty()) return;
+  std::vector<std::function<void()>> d;
+  d.swap(deferred_);
+  deferred_key_ = 0;
+  for (auto &f : d) f();
+}
+
+void Group::segment(int id, std::initializer_list<unsigned long long> extra, const std::function<void()> &body_in) {
+  if (capturing_) { body_in(); return; }   // (a segment inside a segment is part of it)
+  // launches that were waiting for a segment to carry them (step()) become its head
+  std::vector<std::function<void()>> pro;
+  pro.swap(deferred_);
+  const unsigned long long pro_key = pro.empty() ? 0ull : deferred_key_;
+  deferred_key_ = 0;
+  const std::function<void()> with_pro = [&] {
+    for (auto &f : pro) f();
+    body_in();
+  };
+  const std::function<void()> &body = pro.empty() ? body_in : with_pro;
   if (!iter_graph_wanted()) {
     seg_eager_++;
-    if (!host_timing_) { body(); return; }
+    const unsigned long long before = fetch_seq_;
     const auto t0 = std::chrono::steady_clock::now();
     body();
-    t_eager_seg_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (host_timing_) t_eager_seg_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (fetch_seq_ != before) mark_flag_event();
     return;
   }
   std::vector<unsigned long long> key;
@@ -1217,6 +1253,7 @@ void Group::segment(int id, std::initializer_list<unsigned long long> extra, con
   for (const DevBuf<double> *b : {&Zc_, &Zp_, &gc_, &gp_, &Dfc_, &Dfp_, &GXc_, &GXp_, &Xak_, &tmp_[7]})
     key.push_back((unsigned long long)(uintptr_t)b->p);
   key.insert(key.end(), extra.begin(), extra.end());
+  key.push_back(pro_key);
   SegGraph *hit = nullptr;
   for (auto &g : seg_graphs_)
     if (g.key == key) { hit = &g; break; }
@@ -1267,6 +1304,7 @@ void Group::segment(int id, std::initializer_list<unsigned long long> extra, con
   HIP_CHECK(hipGraphLaunch(hit->exec, st_));
   fetch_seq_ += hit->flags;   // the flag-raising kernels of the replay count on from the device's own word
   seg_replays_++;
+  if (hit->flags) mark_flag_event();
 }
 
 unsigned long long Group::fetch_async(int nslots, bool all_rows) {
@@ -1294,29 +1332,92 @@ void Group::fetch(int nslots, bool all_rows) {
   wait_flag(fetch_seq_);
 }
 
-// Poll the pinned flag until the kernel that raises it to `seq` (or a later one of the in-order stream) has run:
-// seeing it means everything enqueued before that kernel is done.
+// polite mode: an event behind the submission that raises the flag to fetch_seq_ (group.h)
+void Group::mark_flag_event() {
+  if (!polite_ || capturing_) return;
+  const int i = wait_ev_next_;
+  wait_ev_next_ = (i + 1) % WAIT_EVENTS;
+  if (!wait_ev_[i]) HIP_CHECK(hipEventCreateWithFlags(&wait_ev_[i], hipEventBlockingSync | hipEventDisableTiming));
+  HIP_CHECK(hipEventRecord(wait_ev_[i], st_));
+  wait_ev_seq_[i] = fetch_seq_;
+}
+
+// Wait until the kernel that raises the pinned flag to `seq` (or a later one of the in-order stream) has run: seeing
+// the flag means everything enqueued before that kernel is done.  Polling, or -- on a host that keeps taking this thread
+// off its core -- sleeping on an event (group.h).
 void Group::wait_flag(unsigned long long seq) {
   const auto t0 = std::chrono::steady_clock::now();
   struct Acc {   // (DPGO_HOST_TIMING)
     Group *g; std::chrono::steady_clock::time_point t;
-    ~Acc() { if (g->host_timing_) { g->t_wait_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); g->n_wait_++; } }
+    ~Acc() {
+      if (!g->host_timing_) return;
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+      g->t_wait_ += dt; g->n_wait_++;
+      g->wait_hist_[dt < 50e-6 ? 0 : dt < 200e-6 ? 1 : dt < 1e-3 ? 2 : dt < 5e-3 ? 3 : dt < 50e-3 ? 4 : 5]++;
+    }
   } acc{this, t0};
-  for (unsigned spins = 0; __atomic_load_n(h_flag_, __ATOMIC_ACQUIRE) < seq; spins++) {
+  auto arrived = [&] { return __atomic_load_n(h_flag_, __ATOMIC_ACQUIRE) >= seq; };
+  if (!arrived() && polite_) {
+    // the event recorded behind the submission that raises the flag to `seq` (the earliest one that covers it); none --
+    // the mode was switched on after that submission -- means one recorded now, behind everything enqueued so far
+    int best = -1;
+    for (int i = 0; i < WAIT_EVENTS; i++)
+      if (wait_ev_[i] && wait_ev_seq_[i] >= seq && (best < 0 || wait_ev_seq_[i] < wait_ev_seq_[best])) best = i;
+    if (best < 0) {
+      mark_flag_event();
+      best = (wait_ev_next_ + WAIT_EVENTS - 1) % WAIT_EVENTS;
+    }
+    // (bounded like the polling below: a stream that waits for an exchange whose peer is gone must not hold the host for ever)
+    hipError_t q = hipEventQuery(wait_ev_[best]);
+    if (q == hipErrorNotReady) {
+      waits_polite_++;
+      q = hipEventSynchronize(wait_ev_[best]);
+    }
+    if (q != hipSuccess) HIP_CHECK(q);
+    if (wait_mode_ == 0 && --polite_left_ <= 0) { polite_ = false; holes_recent_ = 0; waits_since_hole_ = 0; }   // probe the host again
+  }
+  auto last = t0;
+  int holes = 0;
+  bool long_hole = false;
+  for (unsigned spins = 0; !arrived(); spins++) {
     __builtin_ia32_pause();
-    if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+    if ((spins & 15) != 15) continue;
+    const auto now = std::chrono::steady_clock::now();
+    if (now - last > std::chrono::microseconds(100)) {   // nobody pauses for 100 us: the thread was off its core
+      holes++;
+      holes_total_++;
+      long_hole = long_hole || now - last > std::chrono::milliseconds(1);
+      max_hole_us_ = std::max(max_hole_us_, 1e6 * std::chrono::duration<double>(now - last).count());
+    }
+    last = now;
+    if ((spins & 0xfffff) == 0xfffff && now - t0 > std::chrono::seconds(60)) {
       // surfaces a kernel fault, if that is why the flag never came -- without waiting for ever on a stream that is itself
       // waiting for an exchange whose peer is gone
       hipError_t q = hipStreamQuery(st_);
-      for (int i = 0; i < 600 && q == hipErrorNotReady && __atomic_load_n(h_flag_, __ATOMIC_ACQUIRE) < seq; i++) {
+      for (int i = 0; i < 600 && q == hipErrorNotReady && !arrived(); i++) {
         std::this_thread::sleep_for(std::chrono::milliseconds(100));
         q = hipStreamQuery(st_);
       }
       if (q != hipErrorNotReady) HIP_CHECK(q);
-      if (__atomic_load_n(h_flag_, __ATOMIC_ACQUIRE) >= seq) break;
+      if (arrived()) break;
       fprintf(stderr, "[dpgo_amd] ERROR: read-back flag never arrived\n");
       throw DeviceError("read-back flag never arrived");
     }
+  }
+  if (wait_mode_ == 0 && !polite_ && std::chrono::steady_clock::now() - last > std::chrono::microseconds(100)) {
+    // (a thread that was off its core usually finds the flag raised when it comes back: the loop ends before its next look)
+    holes++;
+    holes_total_++;
+    long_hole = long_hole || std::chrono::steady_clock::now() - last > std::chrono::milliseconds(1);
+    max_hole_us_ = std::max(max_hole_us_, 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - last).count());
+  }
+  if (wait_mode_ == 0 && !polite_) {
+    // holes in two of the last few dozen waits: this host does not leave the thread on its core -- wait politely for the
+    // next few thousand read-backs, then look again
+    if (holes > 0) { holes_recent_++; waits_since_hole_ = 0; }
+    else if (++waits_since_hole_ > 64) holes_recent_ = 0;
+    // (a hole of a millisecond or more is a whole time slice given to somebody else: no need to see it twice)
+    if (holes_recent_ >= 2 || long_hole) { polite_ = true; polite_left_ = 4000; polite_switches_++; }
   }
   if (tt_verdict_pending_ && seq >= tt_verdict_seq_) check_tt_verdict(false);   // (the stream has passed the factorisation)
 }
@@ -1776,8 +1877,20 @@ int Group::scatter_global(double *X, int ld) const {
 // ---------------------------------------------------------------------------
 int Group::communicate_local() {
   // neighbour rows whose owner lives in this group: one indexed device copy (DPGOHash.h:64-82)
-  launch_copy_indexed(d_, st_, (int)gather_dst_.n, gather_dst_.p, gather_src_.p, Xk_.p, Xk_.p);
+  if (gather_dst_.n == 0) return 0;
+  defer_or_launch(0x6c6f63ull, [this] { launch_copy_indexed(d_, st_, (int)gather_dst_.n, gather_dst_.p, gather_src_.p, Xk_.p, Xk_.p); });
   return 0;
+}
+
+int Group::step(const std::vector<int> &locals, const std::function<int()> &exchange) {
+  defer_armed_ = !exchange && iter_graph_wanted();
+  int rc = iterate(locals);
+  if (rc == 0 && exchange) rc = exchange();
+  if (rc == 0) rc = communicate_local();
+  defer_armed_ = false;
+  if (rc == 0) rc = update(locals);
+  flush_deferred();   // (nothing, unless update() had nothing to do)
+  return rc;
 }
 
 int Group::num_recv(int a, int beta) const {
@@ -2097,12 +2210,13 @@ std::vector<int> Group::rescale_device(const std::vector<int> &set) {
 }
 
 int Group::update(const std::vector<int> &locals_in) {
-  if (failed_) return -1;
+  if (failed_) { flush_deferred(); return -1; }
   finish_update();
   std::vector<int> locals;
   for (int a : locals_in)
     if (!res_[a].updated) locals.push_back(a);
   if (locals.empty()) {
+    flush_deferred();
     join_exchange();   // a pending exchange must still be ordered before whatever the caller does next on this stream
     return 0;
   }
@@ -2115,6 +2229,8 @@ int Group::update(const std::vector<int> &locals_in) {
   for (int a : locals)
     if (res_[a].hist_iter != res_[a].iters) adv.push_back(a);
   bool zc_done = false;
+  // (launches that wait for this update()'s first segment -- step() -- go now if something eager comes before it)
+  if ((int)adv.size() != num_local() || !zc_ready_ || xchg_done_ || dynamic() || star_) flush_deferred();
   if ((int)adv.size() == num_local()) {
     // every node advances: rotate the buffers instead of copying them
     Zp_.swap(Zc_);
@@ -2152,7 +2268,7 @@ int Group::update(const std::vector<int> &locals_in) {
     for (int a : set) bits |= 1ull << a;
     segment(seg_id, {bits, mask_locals_bits, variant, (unsigned long long)nslots}, [&] {
       launches();
-      launch_reduce(st_, T_, num_local(), true, nslots, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
+      launch_reduce(st_, T_, num_local(), true, nslots, partials_.p, h_upd_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
     });
     if (can_defer) {
       pending_seq_ = fetch_seq_;
@@ -2197,6 +2313,7 @@ int Group::update(const std::vector<int> &locals_in) {
       launch_bsr(d_, st_, T_, false, cur_mask_, S_.dev, Zc_.p, false, nullptr, gc_.p, Xak_.p, 1.0, nullptr, partials_.p, 1);
     };
     const bool both = !first.empty() && !later.empty();
+    if (both) flush_deferred();
     if (both) common();   // (nodes at different iterations: two read-backs, nothing deferred, the shared part goes first)
     if (!first.empty()) {
       end_with(1, (split ? 1ull : 0ull) | (both ? 2ull : 0ull), 6, first, [&] {
@@ -2207,8 +2324,8 @@ int Group::update(const std::vector<int> &locals_in) {
         launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, partials_.p, 2, gc_.p, Dfc_.p);
       }, [this, first] {
         for (int a : first) {
-          const double f0 = scal(a, 0);
-          host_update_logic(a, f0 + (scal(a, 1) + scal(a, 5)), f0, std::sqrt(scal(a, 2)));
+          const double f0 = uscal(a, 0);
+          host_update_logic(a, f0 + (uscal(a, 1) + uscal(a, 5)), f0, std::sqrt(uscal(a, 2)));
         }
       });
     }
@@ -2222,8 +2339,8 @@ int Group::update(const std::vector<int> &locals_in) {
         launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, partials_.p, 2, gc_.p, Dfc_.p);
       }, [this, later] {
         for (int a : later) {
-          const double fobj = res_[a].Gk + scal(a, 0);
-          host_update_logic(a, fobj, fobj + scal(a, 3), std::sqrt(scal(a, 2)));
+          const double fobj = res_[a].Gk + uscal(a, 0);
+          host_update_logic(a, fobj, fobj + uscal(a, 3), std::sqrt(uscal(a, 2)));
         }
       });
     }
@@ -2231,6 +2348,7 @@ int Group::update(const std::vector<int> &locals_in) {
     // evaluate_g_and_f0 / evaluate_g_and_f (DPGOProblem.cpp:222-267, 360-424); _rescale variants (:289-358, :426-514)
     const bool both = !first.empty() && !later.empty();
     if (both || dynamic()) {   // (the product covers every node of `locals`: it cannot sit inside one of two segments)
+      flush_deferred();
       head();
     }
     const bool head_inside = !(both || dynamic());
@@ -2284,18 +2402,18 @@ int Group::update(const std::vector<int> &locals_in) {
       }, [this, set, pass, dyn, rho, gap] {
         for (int a : set) {
           NodeResults &r = res_[a];
-          const double fobjE = 0.5 * (dyn ? rho[a] : scal(a, 0));
-          const double quad = scal(a, 2) + scal(a, 5);   // tr(X^T (g + 1/2 G X))
+          const double fobjE = 0.5 * (dyn ? rho[a] : uscal(a, 0));
+          const double quad = uscal(a, 2) + uscal(a, 5);   // tr(X^T (g + 1/2 G X))
           double fobj, f;
           if (pass == 0) {
-            f = 0.5 * fobjE + scal(a, 3);
+            f = 0.5 * fobjE + uscal(a, 3);
             fobj = f + quad;
           } else {
-            fobj = r.Gk - 0.5 * r.fobjE - 0.5 * (dyn ? gap[a] : scal(a, 1)) + 0.5 * fobjE;
+            fobj = r.Gk - 0.5 * r.fobjE - 0.5 * (dyn ? gap[a] : uscal(a, 1)) + 0.5 * fobjE;
             f = fobj - quad;
           }
           r.fobjE = fobjE;
-          host_update_logic(a, fobj, f, std::sqrt(scal(a, 4)));
+          host_update_logic(a, fobj, f, std::sqrt(uscal(a, 4)));
         }
       });
     }
@@ -2322,7 +2440,13 @@ int Group::iterate(const std::vector<int> &locals) {
   // update() turns into X[iter] (it rotates the history buffers when every node advances; X[iter-1], which that buffer
   // holds now, has had its last reader), so update() need not copy Xk's own rows again.
   zc_ready_ = (int)locals.size() == num_local() && !star_;
-  launch_axpby(d_, st_, T_, false, cur_mask_, 1.0, Xak_.p, 0.0, nullptr, Xk_.p, 0, zc_ready_ ? Zp_.p : nullptr);
+  {
+    // (the pointers' values of NOW: the launch may run as the head of update()'s first segment, after the history rotated)
+    const NodeMask m = cur_mask_;
+    const double *xak = Xak_.p;
+    double *xk = Xk_.p, *z = zc_ready_ ? Zp_.p : nullptr;
+    defer_or_launch(0x7461696cull ^ m.v, [this, m, xak, xk, z] { launch_axpby(d_, st_, T_, false, m, 1.0, xak, 0.0, nullptr, xk, 0, z); });
+  }
   for (int a : locals) {
     res_[a].iters++;
     res_[a].updated = 0;
@@ -2412,28 +2536,57 @@ int Group::amm(const std::vector<int> &locals) {
     launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xakh_.p, 2, gx_.p, T1_.p, Xakh_.p, 0.5, gc_.p, partials_.p, DS + 1);
     solve_tt(T1_.p, Xak_.p, -1.0);
   });
-  finish_update();   // the scalars of the last update(): needed from here on (the GPU has the launches above to chew on)
-  for (int a : locals) {
-    NodeResults &r = res_[a];
-    r.refined = (((r.gradFnorm * r.gradFnorm / r.fobj) > o.accepted_delta) || (r.num_oscillations >= o.max_oscillations)) &&
-                o.max_iterations > 0 && o.max_iterations_accepted > 0;   // :351-355
+  // the scalars of the last update() are needed from here on: `refined` (:351-355)
+  auto decide_refined = [&] {
+    finish_update();
+    bool all = true;
+    for (int a : locals) {
+      NodeResults &r = res_[a];
+      r.refined = (((r.gradFnorm * r.gradFnorm / r.fobj) > o.accepted_delta) || (r.num_oscillations >= o.max_oscillations)) &&
+                  o.max_iterations > 0 && o.max_iterations_accepted > 0;   // :351-355
+      all = all && r.refined;
+    }
+    return all;
+  };
+  // Where every node of the group was refined in the last iteration, the refinement of this one starts UNASKED: its head --
+  // model gradient, preconditioned gradient, first CG step, trial point -- goes to the GPU right behind the translation
+  // solve, and only then does the host take update()'s read-back and decide whether the nodes are refined at all (they
+  // are, for the whole early regime).  A wrong guess costs the GPU some work on scratch vectors; the stream never idles
+  // waiting for the decision.  DPGO_SPEC_REFINE=0 switches it off (measurement hook).
+  static const bool spec_on = env_int("DPGO_SPEC_REFINE", 1) != 0;
+  bool done_tnt = false, abandoned = false;
+  if (spec_on && spec_refined_ && (int)locals.size() == num_local() && pending_update_ && !star_ && !dynamic()) {
+    const std::function<bool()> confirm = decide_refined;
+    deferred_slots_ = DS + 3;
+    done_tnt = run_tnt(locals, Xak_.p, gx_.p, gc_.p, true, &confirm);
+    abandoned = !done_tnt;
+    if (done_tnt)
+      for (int a : locals) res_[a].Gk = res_[a].Gk_alt;
+    else
+      deferred_slots_ = 0;   // (T1_ no longer holds the product of the translation solve: base_ready is false below)
   }
   std::vector<int> plain, ref;
-  for (int a : locals) (res_[a].refined ? ref : plain).push_back(a);
-  // Gk for nodes that are not refined; refined nodes run TNT first (:374-383)
-  if (ref.empty()) {   // (the regime once the gradient is small: the pass and its read-back as one segment)
-    segment(11, {cur_mask_.v}, [&] {
-      eval_G(Xak_.p, gc_.p, DS + 2);
-      launch_reduce(st_, T_, num_local(), false, DS + 3, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
-    });
-    wait_flag(fetch_seq_);
-  } else {
-    if (!plain.empty()) eval_G(Xak_.p, gc_.p, DS + 2);
-    deferred_slots_ = DS + 3;
-    // TNT minimises G(. | g extrapolated); Gk is G(. | g[k]) at the refined point (:377-383)
-    run_tnt(ref, Xak_.p, gx_.p, gc_.p, true);
-    for (int a : ref) res_[a].Gk = res_[a].Gk_alt;
+  if (!done_tnt) {
+    if (!abandoned) decide_refined();   // (an abandoned attempt has taken the read-back and the decision)
+    for (int a : locals) (res_[a].refined ? ref : plain).push_back(a);
+    // Gk for nodes that are not refined; refined nodes run TNT first (:374-383)
+    if (ref.empty()) {   // (the regime once the gradient is small: the pass and its read-back as one segment)
+      segment(11, {cur_mask_.v}, [&] {
+        eval_G(Xak_.p, gc_.p, DS + 2);
+        launch_reduce(st_, T_, num_local(), false, DS + 3, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
+      });
+      wait_flag(fetch_seq_);
+    } else {
+      if (!plain.empty()) eval_G(Xak_.p, gc_.p, DS + 2);
+      deferred_slots_ = DS + 3;
+      // TNT minimises G(. | g extrapolated); Gk is G(. | g[k]) at the refined point (:377-383)
+      run_tnt(ref, Xak_.p, gx_.p, gc_.p, !abandoned);
+      for (int a : ref) res_[a].Gk = res_[a].Gk_alt;
+    }
   }
+  spec_refined_ = true;
+  for (int a : locals) spec_refined_ = spec_refined_ && res_[a].refined;
+  spec_refined_ = spec_refined_ && (int)locals.size() == num_local();
   std::vector<double> Gkh(num_local(), 0.0), minG(num_local(), 0.0);
   for (int a : locals) {
     NodeResults &r = res_[a];

@@ -214,6 +214,11 @@ class Group {
   int update(const std::vector<int> &locals);
   int iterate(const std::vector<int> &locals);
   int communicate_local();
+  // the driver's loop body (C++/examples/dist_pgo.cpp:496-521) for the nodes in `locals`: iterate -> exchange (the caller's:
+  // an RCCL exchange on the communicator's stream, or none) -> communicate_local -> update.  Without an exchange the tail
+  // of iterate() (Xk <- Xak) and the local halo copy are not launched on their own but become the head of update()'s first
+  // segment (deferred_): one submission less per iteration where the host's launch rate is what bounds the group.
+  int step(const std::vector<int> &locals, const std::function<int()> &exchange);
   // DPGOHash::receive (DPGOHash.cpp:45-82): msg for neighbour node beta is ((d+1) |recv[beta]|) x d,
   // [t rows ; R rows], poses in the order of recv[beta]; send() builds the message node `local` owes beta
   // from its current Xk (the poses of sent[beta], DPGO_utils.cpp:428-435)
@@ -349,13 +354,36 @@ class Group {
   // stderr when the group goes
   bool host_timing_ = getenv("DPGO_HOST_TIMING") != nullptr;
   double t_graph_launch_ = 0, t_eager_seg_ = 0, t_wait_ = 0;
-  long n_wait_ = 0;
+  long n_wait_ = 0, holes_total_ = 0, wait_hist_[6] = {0, 0, 0, 0, 0, 0};   // waits of < 50 us, < 200 us, < 1 ms, < 5 ms, < 50 ms, longer
+  double max_hole_us_ = 0;
   // the sequence number the next flag-raising launch carries: a fresh one, or 0 under capture (the kernel then takes the
   // device's count + 1, and the host counts along when the graph is replayed)
   unsigned long long next_seq() {
     if (capturing_) { captured_flags_++; return 0ull; }
     return ++fetch_seq_;
   }
+  // ---- How the host waits for a read-back (wait_flag).  Polling the pinned flag is the fastest way to learn that the GPU
+  // is done -- as long as the host thread has a core to itself.  On a crowded host (eight ranks on a few cores, a box whose
+  // other tenants are busy) a thread that spins burns its time slice doing nothing and is then descheduled for several
+  // slices of the others, while a thread that SLEEPS until the GPU's interrupt wakes it stays under its fair share and is
+  // scheduled at once when it wakes.  So: spin by default; while spinning, watch the clock for holes (a gap of > 100 us
+  // between two looks means the thread was taken off the core); when holes keep coming, wait POLITELY for a while --
+  // an event recorded behind every flag-raising submission, hipEventSynchronize on a blocking event -- and probe again
+  // later.  DPGO_WAIT=spin / block forces either.
+  enum { WAIT_EVENTS = 8 };
+  hipEvent_t wait_ev_[WAIT_EVENTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  unsigned long long wait_ev_seq_[WAIT_EVENTS] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int wait_ev_next_ = 0;
+  int wait_mode_ = 0;            // 0 auto, 1 spin, 2 block
+  bool polite_ = false;
+  long polite_left_ = 0, holes_recent_ = 0, waits_since_hole_ = 0, polite_switches_ = 0, waits_polite_ = 0;
+  void mark_flag_event();        // polite mode: an event behind the submission that raises the flag to fetch_seq_
+  // launches that wait for the next segment to carry them (step()): captured pointer values, launched in order
+  std::vector<std::function<void()>> deferred_;
+  unsigned long long deferred_key_ = 0;
+  bool defer_armed_ = false;
+  void defer_or_launch(unsigned long long key, std::function<void()> fn);
+  void flush_deferred();
   bool iter_graph_wanted() const;
   void segment(int id, std::initializer_list<unsigned long long> extra, const std::function<void()> &body);
   void graphs_invalidate();   // waits (bounded) for the stream, destroys every captured graph, bumps graph_gen_
@@ -448,6 +476,9 @@ class Group {
   void wait_flag(unsigned long long seq);
   int deferred_slots_ = 0;   // slots written earlier that ride along with the next fetch (saves a host round trip)
   double scal(int local, int s) const { return h_scal_[local * MAX_SLOTS + s]; }
+  double *h_upd_ = nullptr;   // pinned (same allocation): the sums update() ends with
+  double uscal(int local, int s) const { return h_upd_[local * MAX_SLOTS + s]; }
+  bool spec_refined_ = false; // amm(): every node of the group was refined in the last iteration (the next one starts its refinement unasked)
   void copy_rows(double *dst, const double *src, bool all_rows, int part = 0);
   void solve_tt(double *in, double *out, double scale);   // out.t <- scale * G_tt^-1 in.t
   void solve_rr(double *in, double *out, double scale);   // out.R <- scale * (G_RR + lambda I)^-1 in.R
@@ -473,8 +504,11 @@ class Group {
   int mm(const std::vector<int> &locals);
   // refine X in place (TNT on G(. | g)); sets Gk = G(X | g) and, with g_alt, Gk_alt = G(X | g_alt)
   // base_ready: X.t was just recovered from X.R with this g (recover_translations) and T1_ still holds that product
-  void run_tnt(const std::vector<int> &locals, double *X, const double *g, const double *g_alt = nullptr,
-               bool base_ready = false);
+  // confirm (optional): called once the start of the refinement is enqueued -- the caller's chance to take a read-back
+  // that decides whether these nodes are refined at all; false: the refinement is abandoned (returns false; what was
+  // enqueued only touched work vectors, and T1_)
+  bool run_tnt(const std::vector<int> &locals, double *X, const double *g, const double *g_alt = nullptr,
+               bool base_ready = false, const std::function<bool()> *confirm = nullptr);
 };
 
 }  // namespace dpgo

@@ -69,8 +69,9 @@ bool Group::cg_graph_wanted() const {
   return force != 0 && iter_graph_wanted();
 }
 
-void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, const double *g_alt, bool base_ready) {
-  finish_update();
+bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, const double *g_alt, bool base_ready,
+                    const std::function<bool()> *confirm) {
+  if (!confirm) finish_update();
   const Options &o = opt_;
   const int L = num_local();
   const bool jacobi = (o.preconditioner == 1) && jacobi_.n > 0;       // Preconditioner::Jacobi
@@ -306,8 +307,12 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     mA = live_mask(bitsA, dmask_.p);   // (a replay does not run the body: the host's copies)
     mB = live_mask(bitsA, dmask_.p + 1);
     cur_mask_ = live_mask(bits_nodes, nullptr);
+    // the caller's read-back (the scalars that decide whether these nodes are refined at all) is taken NOW, with the start
+    // of the refinement already on the GPU: the stream never waits for that decision
+    if (confirm && !(*confirm)()) return false;
     seqA = fetch_seq_ - (spec ? 1 : 0);
   } else {
+    if (confirm && !(*confirm)()) return false;
     const bool have_sums = quad_model(X, base_ready);
     norms(nodes, true, have_sums);
   }
@@ -348,6 +353,7 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       mA = live_mask(bitsA, dmask_.p);
       mB = live_mask(bitsA, dmask_.p + 1);
       stepA(true);
+      mark_flag_event();
       seqA = fetch_seq_;
     }
     // The first step (enqueued above, or -- with `dev` -- in front of the loop).
@@ -376,6 +382,7 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     if (dev) tnt_speculate_ = !more_steps;   // speculate next time if nobody needed a second step this time
     if (more_steps) {
       stepB();
+      mark_flag_event();   // (polite waiting: an event behind every step whose outcome is waited for)
       unsigned long long seqB = fetch_seq_;
       for (;;) {
         if (!lag) {
@@ -383,7 +390,7 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
           if (!any_live()) break;
         }
         if (use_graph) graph_step();
-        else { stepA(false); stepB(); }
+        else { stepA(false); stepB(); mark_flag_event(); }
         const unsigned long long next = fetch_seq_;
         if (lag) {
           wait_flag(seqB);   // the outcome of the step before the one just enqueued
@@ -452,6 +459,7 @@ void Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     res_[a].tnt_status = S[a].status;
     res_[a].tnt_inner = S[a].inner_total;
   }
+  return true;
 }
 
 }  // namespace dpgo

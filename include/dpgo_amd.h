@@ -232,6 +232,16 @@ int dpgo_comm_exchange_kind(const dpgo_comm_t *comm);
 /* Bytes this rank hands to RCCL per dpgo_comm_exchange (neighbour to neighbour: the records its peers need; all-gather: one
  * padded block); -1 on error.  Reported per rank by bench.py's N > 1 line. */
 long dpgo_comm_bytes_sent(const dpgo_comm_t *comm);
+/* Measurement hooks (bench.py --emulate-world N --force-exchange; no counterpart in the reference, whose "exchange" is a
+ * memory copy, C++/DPGO/include/DPGO/DPGOHash.h:28-86):
+ * dpgo_comm_self_exchange: on a communicator of ONE rank, dpgo_comm_exchange from now on runs the neighbour-to-neighbour path
+ *   in its steady state with the rank as its own peer (pack, ncclGroupStart, ncclSend + ncclRecv of every exported record,
+ *   ncclGroupEnd, unpack into a scratch array, joined by update()): what that path costs an iteration, short of the wire;
+ * dpgo_comm_enable_timing / dpgo_comm_exchange_time: mean time in microseconds from "the iterate is final" on the group's
+ *   stream to "the neighbour rows are in place" on the communicator's, over the exchanges since timing was enabled. */
+int dpgo_comm_self_exchange(dpgo_comm_t *comm);
+int dpgo_comm_enable_timing(dpgo_comm_t *comm);
+int dpgo_comm_exchange_time(dpgo_comm_t *comm, double *mean_us, long *count);
 /* Test hook: the grouped ncclSend / ncclRecv path of dpgo_comm_exchange on a communicator of ONE rank that is its own peer
  * (legal inside ncclGroupStart / End): every row `grp` exports travels pack kernel -> group call -> unpack kernel on the
  * communicator's stream, on records that carry their own keys.  `grp` may host any subset of the nodes.  0 = every record

@@ -14,11 +14,12 @@ _ap = argparse.ArgumentParser()
 _ap.add_argument("--starve-host", type=int, default=-1, help="pin to one core with this many spinning siblings (tools/starve.py)")
 _ap.add_argument("--only", type=str, default="", help="substring of the configuration names to run")
 _ap.add_argument("--no-oracle", action="store_true", help="skip the oracle's side of the table")
+_ap.add_argument("--repeat", type=int, default=1, help="run this many times the iterations of the table (GPU side)")
 _args = _ap.parse_args()
 if _args.starve_host >= 0:      # (before anything touches the GPU)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import starve
-    starve.starve_host(_args.starve_host)
+    starve.prepare(_args.starve_host)     # (the spinners start with the first timed loop)
 import dpgo_amd                                                  # noqa: E402
 from oracle import g2o as og                                     # noqa: E402
 from oracle.hash import Options as OOptions                      # noqa: E402
@@ -49,14 +50,17 @@ for name, ds, nn, loss, acc, scheme, iters in CASES:
         orc = ODPGOStar(path, nn, OOptions.driver(loss, acc), mm=mm, num_poses=num_poses)
         orc.initialize(X0)
         gstep, ostep = gpu.step, orc.step
+    if _args.starve_host >= 0:
+        starve.release()
+        time.sleep(0.2)
     for _ in range(3):
         gstep()
     gpu.group.sync()
     t0 = time.perf_counter()
-    for _ in range(iters):
+    for _ in range(iters * _args.repeat):
         gstep()
     gpu.group.sync()
-    tg = time.perf_counter() - t0
+    tg = (time.perf_counter() - t0) / _args.repeat
     t0 = time.perf_counter()
     for _ in range(0 if _args.no_oracle else iters):
         ostep()

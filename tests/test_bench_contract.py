@@ -31,6 +31,8 @@ def _check(j, n1=True):
         assert c["kind"] == "port" and c["unit"] == j["unit"] and c["cores"] >= 1
         cv = j["convergence"]
         assert cv["iterations_to_1e-6"] > 0 and cv["seconds_to_1e-6"] > 0
+        if "iters_per_s_to_objective" in j:      # (lines committed before round 5 do not carry it)
+            assert abs(j["iters_per_s_to_objective"] - cv["iterations_to_1e-6"] / cv["seconds_to_1e-6"]) < 1e-6 * j["iters_per_s_to_objective"]
 
 
 def test_committed_bench_line():
@@ -84,6 +86,54 @@ def test_launcher_names_and_stops_ranks_that_hang_or_die():
     # (rank 1 sleeps, rank 0 waits for it in the barrier: both are named)
     assert "ranks [0, 1] still running after --rank-timeout 45 s" in hung.stderr, hung.stderr[-2000:]
     assert not [l for l in hung.stdout.splitlines() if l.startswith("{")]
+
+
+_CONV_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+import torch.distributed as dist
+import bench
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+# rank r's own clock and its four nodes' sums per iteration: the objective halves every iteration towards 100 (rank 0) /
+# 300 (rank 1); rank 1 is the slower one
+trace = [((k + 1) * (0.001 + 0.0005 * rank), (100.0 + 200.0 * rank) * (1.0 + 0.5 ** k), 8.0 * (k %% 3 == 0), 2.0 + rank) for k in range(30)]
+out = bench.reduce_trace(trace, dist, 8)
+conv = bench.summarize_convergence(out, 30, None)
+if rank == 0:
+    print(json.dumps({"trace": out, "convergence": conv}))
+dist.destroy_process_group()
+"""
+
+
+def test_convergence_block_of_the_two_rank_line():
+    """The second half of BASELINE's metric at N > 1 (missing item 1): every rank keeps its own per-iteration
+    clock and sums, bench.reduce_trace combines them (objective, CG steps, refined nodes: sums over the ranks; time: the
+    slowest rank's) and bench.summarize_convergence writes the same block the N = 1 line carries.  World 2, gloo, CPU."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", _CONV_WORKER % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[1][1][-2000:] + outs[0][1][-2000:]
+    j = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    tr, cv = j["trace"], j["convergence"]
+    assert len(tr) == 30
+    for k, (t, f, cg, ref) in enumerate(tr):
+        assert abs(t - (k + 1) * 0.0015) < 1e-12                          # the slower rank's clock
+        assert abs(f - 400.0 * (1.0 + 0.5 ** k)) < 1e-9                   # the objective is the sum over the ranks
+        assert ref == 5.0 and cg == (2.0 if k % 3 == 0 else 0.0)           # sums; CG steps per node of the 8
+    # the objective first comes within 1e-6 of the run's lowest (400 (1 + 2^-29)) at iteration 20: 2^-19 < 1e-6 < 2^-18
+    assert cv["target"] == "lowest objective of this run" and cv["iterations_to_1e-6"] == 21
+    assert abs(cv["seconds_to_1e-6"] - 21 * 0.0015) < 1e-12
+    assert abs(cv["iters_per_s_to_objective"] - 1.0 / 0.0015) < 1e-6
+    for k in ("mean_ms_per_iter_to_1e-6", "mean_ms_per_iter_whole_run", "last20_ms_per_iter", "objective_2F_at", "lowest_2F"):
+        assert k in cv
 
 
 @pytest.mark.gpu

@@ -274,7 +274,7 @@ def test_multiprocess_path_matches_single_process(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--grid", "10,10,8,2400", "--steps", "6", "--warmup", "2", "--no-prof", "--no-cpu"]
+    common = ["--grid", "10,10,8,2400", "--steps", "6", "--warmup", "2", "--no-prof", "--no-cpu", "--converge", "30"]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True,
                          timeout=600, cwd=root)
     assert one.returncode == 0, one.stderr[-2000:]
@@ -296,6 +296,12 @@ def test_multiprocess_path_matches_single_process(tmp_path):
         j2 = json.loads(lines[0])
         assert j2["n_gpus"] == 2 and j2["config"]["nodes_per_gpu"] == 4
         assert abs(j1["objective_2F"] - j2["objective_2F"]) <= 1e-10 * abs(j1["objective_2F"])
+        # round 5: the N > 1 line carries the second half of the metric too -- the same trajectory, so the same
+        # objectives at the same iterations as the one-rank line (the clocks differ)
+        c1, c2 = j1["convergence"], j2["convergence"]
+        assert c2["iterations_run"] == 30 and c2["iterations_to_1e-6"] == c1["iterations_to_1e-6"]
+        assert abs(c1["lowest_2F"] - c2["lowest_2F"]) <= 1e-10 * abs(c1["lowest_2F"])
+        assert c2["seconds_to_1e-6"] > 0 and abs(j2["iters_per_s_to_objective"] - c2["iterations_to_1e-6"] / c2["seconds_to_1e-6"]) < 1e-6 * j2["iters_per_s_to_objective"]
 
 
 @pytest.mark.parametrize("loss", [LOSS_NONE, LOSS_HUBER])
