@@ -156,10 +156,13 @@ def measure_traffic(args):
             cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--no-cpu", "--no-prof", "--converge", "0", "--steps", "5", "--warmup", "2",
                    "--traffic", "off", "--grid", args.grid, "--nodes", str(args.nodes), "--loss", args.loss]
+            if args.emulate_world:      # (the emulated rank of an N-GPU run: the same counters for its one node per GPU)
+                cmd += ["--emulate-world", str(args.emulate_world), "--emulate-rank", str(args.emulate_rank)]
             # (its own session: on a timeout the whole group goes -- rocprofv3 AND the python child under it, which would
             # otherwise keep the GPU busy during the timed run)
             child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd="/tmp",
-                                     env=dict(os.environ, TMPDIR="/tmp"), start_new_session=True)
+                                     env=dict(os.environ, TMPDIR="/tmp", DPGO_ITER_GRAPH="0"),   # (counters per eager dispatch)
+                                     start_new_session=True)
             try:
                 child.wait(timeout=150)
             except subprocess.TimeoutExpired:
@@ -240,6 +243,10 @@ def main():
                     help="diagnostic: pin this process (and every runtime thread it starts later) to ONE core and keep this many "
                          "busy-looping sibling processes on the same core (tools/starve.py) -- what a slow or crowded host does to "
                          "the step time; -1: off")
+    ap.add_argument("--windows", type=int, default=1,
+                    help="diagnostic: repeat the timed region this many times, each from the chordal initialisation again (the "
+                         "re-initialisation is not timed); value = all timed steps / all timed seconds -- a run long enough for "
+                         "what a crowded host does to it to show (--starve-host)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="diagnostic: run the boundary exchange (pack, all-gather, unpack) even with one rank, to see "
                          "what it adds to a step")
@@ -253,7 +260,7 @@ def main():
         starved = starve.prepare(args.starve_host)      # (the spinners start after the untimed set-up)
     measured_traffic = None
     if (args.traffic == "auto" and world == 1 and args.gpus == 1 and not args.no_prof and args.prof_steps > 0
-            and not args.emulate_world and not args.rendezvous_only):
+            and not args.rendezvous_only and args.starve_host < 0):
         measured_traffic = measure_traffic(args)       # (child processes; this one has not touched the GPU yet)
 
     import torch
@@ -404,11 +411,32 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    cpu0, wall0, spin0 = time.process_time(), time.perf_counter(), (starve.cpu_seconds() if starved is not None else None)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    window_ms = [1e3 * elapsed / args.steps]
+    for _ in range(args.windows - 1):          # (diagnostic: the same window again and again)
+        grp.initialize_global(X0)
+        grp.update()
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        window_ms.append(1e3 * (time.perf_counter() - t0) / args.steps)
+    if args.windows > 1:
+        elapsed = 1e-3 * sum(window_ms) * args.steps / args.windows     # (mean window)
+    if starved is not None:
+        # how much of the core this process got, and proof that the siblings ran: their CPU seconds over the same span
+        wall = time.perf_counter() - wall0
+        spin1 = starve.cpu_seconds()
+        starved = dict(starved, wall_s=wall, own_cpu_s=time.process_time() - cpu0,
+                       spinners_cpu_s=[(b - a) if a is not None and b is not None else None for a, b in zip(spin0, spin1)])
     per_rank = None
     if do_exchange:
         # every rank's own time over the timed region and what it hands to the transport per exchange (the N > 1 line
@@ -527,6 +555,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64" if not experiment else "f64 arithmetic, fp32-stored preconditioner panels",
             "experiment": experiment, "data": "synthetic",
             "diagnostic_starved_host": starved,
+            "diagnostic_windows_ms_per_step": window_ms if args.windows > 1 else None,
             "diagnostic_emulated_rank": ("%d of %d" % (args.emulate_rank, args.emulate_world)) if args.emulate_world else None,
             "config": {"workload": "synthetic SE(3) lattice %dx%dx%d, %d poses / %d edges, %s loss, AMM-PGO#, "
                                    "num_nodes=%d (%d per GPU), chordal init" % (nx, ny, nz, g["num_poses"], len(g["I"]),

@@ -710,10 +710,7 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   }
   HIP_CHECK(hipSetDevice(device));
   HIP_CHECK(hipStreamCreate(&st_));
-  if (const char *w = getenv("DPGO_WAIT")) {
-    wait_mode_ = std::string(w) == "spin" ? 1 : (std::string(w) == "block" ? 2 : 0);
-    polite_ = wait_mode_ == 2;
-  }
+  if (const char *w = getenv("DPGO_WAIT")) polite_ = std::string(w) == "block";
   const int L = (int)nodes_.size();
   const bool trivial = (opt.loss == 0);
   info_.resize(L);
@@ -1069,8 +1066,8 @@ Group::~Group() {
             num_local(), seg_replays_, t_graph_launch_, seg_replays_ ? 1e6 * t_graph_launch_ / seg_replays_ : 0.0, seg_eager_, t_eager_seg_,
             n_wait_, t_wait_, n_wait_ ? 1e6 * t_wait_ / n_wait_ : 0.0);
   if (host_timing_)
-    fprintf(stderr, "[host] waits: %ld slept on an event, %ld switches to polite waiting, %ld holes (longest %.0f us); waits of < 50 us / 200 us / 1 ms / 5 ms / 50 ms / longer: %ld %ld %ld %ld %ld %ld\n",
-            waits_polite_, polite_switches_, holes_total_, max_hole_us_, wait_hist_[0], wait_hist_[1], wait_hist_[2], wait_hist_[3], wait_hist_[4], wait_hist_[5]);
+    fprintf(stderr, "[host] waits: %ld slept on an event; waits of < 50 us / 200 us / 1 ms / 5 ms / 50 ms / longer: %ld %ld %ld %ld %ld %ld; segments replayed since the host was found to be the slower side: %s\n",
+            waits_polite_, wait_hist_[0], wait_hist_[1], wait_hist_[2], wait_hist_[3], wait_hist_[4], wait_hist_[5], host_bound_ ? "yes" : "no");
   const bool idle = drain(failed_ ? 2.0 : 60.0);
   if (idle)
     for (auto &e : wait_ev_)
@@ -1190,8 +1187,19 @@ bool Group::iter_graph_wanted() const {
   if (graphs_broken_ || force == 0 || prof_enabled() || Ltt_.flow || Lrr_.flow) return false;   // (never while launches are timed)
   if (force == 1) return true;
   // Where a segment streams gigabytes (the headline's eight nodes on one GPU) the host is never what bounds it, and its
-  // launches shrink with the set of nodes that still iterate, which a replay's frozen grids cannot do.
-  return P0_ <= 40000;
+  // launches shrink with the set of nodes that still iterate, which a replay's frozen grids cannot do.  Below that size:
+  // replays once the host has been seen to be the slower side (host_bound_tick).
+  return P0_ <= 40000 && host_bound_;
+}
+
+// Every 32 iterations: the share of the wall time this group's host thread spent waiting for read-backs.  Below a third,
+// the host is what bounds the group.
+void Group::host_bound_tick() {
+  if (host_bound_ || ++win_iters_ < 32) return;
+  if (win_lib_s_ > 0 && win_wait_s_ < 0.33 * win_lib_s_) host_bound_ = true;
+  win_iters_ = 0;
+  win_wait_s_ = 0;
+  win_lib_s_ = 0;
 }
 
 void Group::graphs_destroy() {
@@ -1224,7 +1232,7 @@ void Group::flush_deferred() {
   for (auto &f : d) f();
 }
 
-void Group::segment(int id, std::initializer_list<unsigned long long> extra, const std::function<void()> &body_in) {
+void Group::segment(int id, NodeBits bits, std::initializer_list<unsigned long long> extra, const std::function<void()> &body_in) {
   if (capturing_) { body_in(); return; }   // (a segment inside a segment is part of it)
   // launches that were waiting for a segment to carry them (step()) become its head
   std::vector<std::function<void()>> pro;
@@ -1236,7 +1244,7 @@ void Group::segment(int id, std::initializer_list<unsigned long long> extra, con
     body_in();
   };
   const std::function<void()> &body = pro.empty() ? body_in : with_pro;
-  if (!iter_graph_wanted()) {
+  if (!iter_graph_wanted() || bits != all_bits()) {
     seg_eager_++;
     const unsigned long long before = fetch_seq_;
     const auto t0 = std::chrono::steady_clock::now();
@@ -1257,6 +1265,14 @@ void Group::segment(int id, std::initializer_list<unsigned long long> extra, con
   SegGraph *hit = nullptr;
   for (auto &g : seg_graphs_)
     if (g.key == key) { hit = &g; break; }
+  if (!hit && seg_captures_ >= 256) {
+    // (more variants than a steady state has: whatever keeps changing, capturing it again and again is not the cure)
+    seg_eager_++;
+    const unsigned long long before = fetch_seq_;
+    body();
+    if (fetch_seq_ != before) mark_flag_event();
+    return;
+  }
   if (!hit) {
     hipGraph_t graph = nullptr;
     capturing_ = true;
@@ -1332,7 +1348,7 @@ void Group::fetch(int nslots, bool all_rows) {
   wait_flag(fetch_seq_);
 }
 
-// polite mode: an event behind the submission that raises the flag to fetch_seq_ (group.h)
+// DPGO_WAIT=block: an event behind the submission that raises the flag to fetch_seq_ (group.h)
 void Group::mark_flag_event() {
   if (!polite_ || capturing_) return;
   const int i = wait_ev_next_;
@@ -1343,23 +1359,23 @@ void Group::mark_flag_event() {
 }
 
 // Wait until the kernel that raises the pinned flag to `seq` (or a later one of the in-order stream) has run: seeing
-// the flag means everything enqueued before that kernel is done.  Polling, or -- on a host that keeps taking this thread
-// off its core -- sleeping on an event (group.h).
+// the flag means everything enqueued before that kernel is done.
 void Group::wait_flag(unsigned long long seq) {
   const auto t0 = std::chrono::steady_clock::now();
-  struct Acc {   // (DPGO_HOST_TIMING)
+  struct Acc {   // (what the host-bound test and DPGO_HOST_TIMING need: the time spent in here)
     Group *g; std::chrono::steady_clock::time_point t;
     ~Acc() {
-      if (!g->host_timing_) return;
       const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+      g->win_wait_s_ += dt;
+      if (!g->host_timing_) return;
       g->t_wait_ += dt; g->n_wait_++;
       g->wait_hist_[dt < 50e-6 ? 0 : dt < 200e-6 ? 1 : dt < 1e-3 ? 2 : dt < 5e-3 ? 3 : dt < 50e-3 ? 4 : 5]++;
     }
   } acc{this, t0};
   auto arrived = [&] { return __atomic_load_n(h_flag_, __ATOMIC_ACQUIRE) >= seq; };
   if (!arrived() && polite_) {
-    // the event recorded behind the submission that raises the flag to `seq` (the earliest one that covers it); none --
-    // the mode was switched on after that submission -- means one recorded now, behind everything enqueued so far
+    // the event recorded behind the submission that raises the flag to `seq` (the earliest one that covers it); none
+    // means one recorded now, behind everything enqueued so far
     int best = -1;
     for (int i = 0; i < WAIT_EVENTS; i++)
       if (wait_ev_[i] && wait_ev_seq_[i] >= seq && (best < 0 || wait_ev_seq_[i] < wait_ev_seq_[best])) best = i;
@@ -1367,30 +1383,21 @@ void Group::wait_flag(unsigned long long seq) {
       mark_flag_event();
       best = (wait_ev_next_ + WAIT_EVENTS - 1) % WAIT_EVENTS;
     }
-    // (bounded like the polling below: a stream that waits for an exchange whose peer is gone must not hold the host for ever)
     hipError_t q = hipEventQuery(wait_ev_[best]);
     if (q == hipErrorNotReady) {
       waits_polite_++;
       q = hipEventSynchronize(wait_ev_[best]);
     }
     if (q != hipSuccess) HIP_CHECK(q);
-    if (wait_mode_ == 0 && --polite_left_ <= 0) { polite_ = false; holes_recent_ = 0; waits_since_hole_ = 0; }   // probe the host again
   }
   auto last = t0;
-  int holes = 0;
-  bool long_hole = false;
   for (unsigned spins = 0; !arrived(); spins++) {
     __builtin_ia32_pause();
-    if ((spins & 15) != 15) continue;
+    if ((spins & 0xfffff) != 0xfffff) continue;
     const auto now = std::chrono::steady_clock::now();
-    if (now - last > std::chrono::microseconds(100)) {   // nobody pauses for 100 us: the thread was off its core
-      holes++;
-      holes_total_++;
-      long_hole = long_hole || now - last > std::chrono::milliseconds(1);
-      max_hole_us_ = std::max(max_hole_us_, 1e6 * std::chrono::duration<double>(now - last).count());
-    }
+    if (host_timing_ && now - last > std::chrono::milliseconds(1)) holes_total_++;   // (the thread was off its core: diagnostic)
     last = now;
-    if ((spins & 0xfffff) == 0xfffff && now - t0 > std::chrono::seconds(60)) {
+    if (now - t0 > std::chrono::seconds(60)) {
       // surfaces a kernel fault, if that is why the flag never came -- without waiting for ever on a stream that is itself
       // waiting for an exchange whose peer is gone
       hipError_t q = hipStreamQuery(st_);
@@ -1403,21 +1410,6 @@ void Group::wait_flag(unsigned long long seq) {
       fprintf(stderr, "[dpgo_amd] ERROR: read-back flag never arrived\n");
       throw DeviceError("read-back flag never arrived");
     }
-  }
-  if (wait_mode_ == 0 && !polite_ && std::chrono::steady_clock::now() - last > std::chrono::microseconds(100)) {
-    // (a thread that was off its core usually finds the flag raised when it comes back: the loop ends before its next look)
-    holes++;
-    holes_total_++;
-    long_hole = long_hole || std::chrono::steady_clock::now() - last > std::chrono::milliseconds(1);
-    max_hole_us_ = std::max(max_hole_us_, 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - last).count());
-  }
-  if (wait_mode_ == 0 && !polite_) {
-    // holes in two of the last few dozen waits: this host does not leave the thread on its core -- wait politely for the
-    // next few thousand read-backs, then look again
-    if (holes > 0) { holes_recent_++; waits_since_hole_ = 0; }
-    else if (++waits_since_hole_ > 64) holes_recent_ = 0;
-    // (a hole of a millisecond or more is a whole time slice given to somebody else: no need to see it twice)
-    if (holes_recent_ >= 2 || long_hole) { polite_ = true; polite_left_ = 4000; polite_switches_++; }
   }
   if (tt_verdict_pending_ && seq >= tt_verdict_seq_) check_tt_verdict(false);   // (the stream has passed the factorisation)
 }
@@ -1712,6 +1704,7 @@ int Group::initialize(int a, const double *X, int ld) {
     HIP_CHECK(hipMemset(dst + (size_t)own_off_[a] * RS_, 0, sizeof(double) * n0 * RS_));
   res_[a] = NodeResults();
   res_[a].updated = 0;
+  spec_refined_ = false;   // (a fresh start: nothing to guess the next iteration's refinements from)
   rescale_count_[a] = 0;   // DPGOResult::clear (DPGO_types.h:301); the scales belong to the problem and stay
   if (device_rescale_) HIP_CHECK(hipMemset(rs_count_.p + a, 0, sizeof(int)));
   return 0;
@@ -1829,6 +1822,8 @@ int Group::set_options(const Options &o) {
     return -1;
   }
   opt_ = o;
+  graphs_invalidate();   // (captured launches carry tolerances and iteration limits by value)
+  spec_refined_ = false;
   return 0;
 }
 
@@ -2210,6 +2205,7 @@ std::vector<int> Group::rescale_device(const std::vector<int> &set) {
 }
 
 int Group::update(const std::vector<int> &locals_in) {
+  InLib in_lib(this);
   if (failed_) { flush_deferred(); return -1; }
   finish_update();
   std::vector<int> locals;
@@ -2221,6 +2217,7 @@ int Group::update(const std::vector<int> &locals_in) {
     return 0;
   }
   const bool trivial = (opt_.loss == 0);
+  host_bound_tick();
   set_mask(locals);
   // history: X[iter-1] <- X[iter], X[iter] <- Xk ; same for g and Dfobj (masked nodes only).  A node whose
   // history already stands at this iteration (update() ran, then receive() cleared `updated`) only refreshes
@@ -2266,7 +2263,7 @@ int Group::update(const std::vector<int> &locals_in) {
     deferred_slots_ = 0;
     NodeBits bits = 0;
     for (int a : set) bits |= 1ull << a;
-    segment(seg_id, {bits, mask_locals_bits, variant, (unsigned long long)nslots}, [&] {
+    segment(seg_id, bits & mask_locals_bits, {bits, mask_locals_bits, variant, (unsigned long long)nslots}, [&] {
       launches();
       launch_reduce(st_, T_, num_local(), true, nslots, partials_.p, h_upd_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
     });
@@ -2425,6 +2422,7 @@ int Group::update(const std::vector<int> &locals_in) {
 // DPGOHash::iterate  (DPGOHash.cpp:583-628)
 // ---------------------------------------------------------------------------
 int Group::iterate(const std::vector<int> &locals) {
+  InLib in_lib(this);
   if (failed_) return -1;
   for (int a : locals)
     if (!res_[a].updated) {
@@ -2458,7 +2456,7 @@ int Group::iterate(const std::vector<int> &locals) {
 int Group::mm(const std::vector<int> &locals) {
   const Options &o = opt_;
   set_mask(locals);
-  segment(12, {cur_mask_.v}, [&] {
+  segment(12, cur_mask_.v, {}, [&] {
     launch_proximal(d_, st_, T_, cur_mask_, Zc_.p, Dfc_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, nullptr, nullptr, 0);
     recover_translations(Xakh_.p, gc_.p);
     copy_rows(Xak_.p, Xakh_.p, false);
@@ -2526,7 +2524,9 @@ int Group::amm(const std::vector<int> &locals) {
     launch_set_coefs(st_, gam, num_local(), coefs_dev_.p);
     gam_dev = coefs_dev_.p;
   }
-  segment(10, {cur_mask_.v}, [&] {
+  const NodeMask mask_locals = cur_mask_;
+  auto head_of_iteration = [&, gam_dev, mask_locals] {
+    cur_mask_ = mask_locals;
     prepare_extrapolated(gam_dev);
     // Xakh = proximal(Y, Df); Gkh = G(Xakh | g[k], f); |Xakh - Xak|^2    (:363-367)
     // (these three scalars sit in slots DS.. and are read back together with the first scalars of TNT)
@@ -2535,7 +2535,17 @@ int Group::amm(const std::vector<int> &locals) {
     // G gives both (T1_ = G [0 ; R] + gx, slot DS + 1 = <Xakh, 1/2 G Xakh + gc>), then the solve   (:363-372)
     launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xakh_.p, 2, gx_.p, T1_.p, Xakh_.p, 0.5, gc_.p, partials_.p, DS + 1);
     solve_tt(T1_.p, Xak_.p, -1.0);
-  });
+  };
+  // (where the refinement starts unasked -- below -- and segments are replayed, the two sequences are ONE segment: the
+  // head of the iteration rides at the front of the refinement's head, one graph launch and one start-up less)
+  static const bool spec_on = env_int("DPGO_SPEC_REFINE", 1) != 0;
+  const bool speculate = spec_on && spec_refined_ && (int)locals.size() == num_local() && pending_update_ && !star_ && !dynamic();
+  if (speculate && iter_graph_wanted() && deferred_.empty()) {
+    deferred_.push_back(head_of_iteration);
+    deferred_key_ = 0x68656164ull ^ mask_locals.v;
+  } else {
+    segment(10, cur_mask_.v, {}, head_of_iteration);
+  }
   // the scalars of the last update() are needed from here on: `refined` (:351-355)
   auto decide_refined = [&] {
     finish_update();
@@ -2553,9 +2563,8 @@ int Group::amm(const std::vector<int> &locals) {
   // solve, and only then does the host take update()'s read-back and decide whether the nodes are refined at all (they
   // are, for the whole early regime).  A wrong guess costs the GPU some work on scratch vectors; the stream never idles
   // waiting for the decision.  DPGO_SPEC_REFINE=0 switches it off (measurement hook).
-  static const bool spec_on = env_int("DPGO_SPEC_REFINE", 1) != 0;
   bool done_tnt = false, abandoned = false;
-  if (spec_on && spec_refined_ && (int)locals.size() == num_local() && pending_update_ && !star_ && !dynamic()) {
+  if (speculate) {
     const std::function<bool()> confirm = decide_refined;
     deferred_slots_ = DS + 3;
     done_tnt = run_tnt(locals, Xak_.p, gx_.p, gc_.p, true, &confirm);
@@ -2571,7 +2580,7 @@ int Group::amm(const std::vector<int> &locals) {
     for (int a : locals) (res_[a].refined ? ref : plain).push_back(a);
     // Gk for nodes that are not refined; refined nodes run TNT first (:374-383)
     if (ref.empty()) {   // (the regime once the gradient is small: the pass and its read-back as one segment)
-      segment(11, {cur_mask_.v}, [&] {
+      segment(11, cur_mask_.v, {}, [&] {
         eval_G(Xak_.p, gc_.p, DS + 2);
         launch_reduce(st_, T_, num_local(), false, DS + 3, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
       });
@@ -2828,6 +2837,7 @@ int Group::star_update() {
 }
 
 int Group::star_iterate() {
+  InLib in_lib(this);
   finish_update();
   if (!star_) return -1;
   const Options &o = opt_;

@@ -355,29 +355,36 @@ class Group {
   bool host_timing_ = getenv("DPGO_HOST_TIMING") != nullptr;
   double t_graph_launch_ = 0, t_eager_seg_ = 0, t_wait_ = 0;
   long n_wait_ = 0, holes_total_ = 0, wait_hist_[6] = {0, 0, 0, 0, 0, 0};   // waits of < 50 us, < 200 us, < 1 ms, < 5 ms, < 50 ms, longer
-  double max_hole_us_ = 0;
   // the sequence number the next flag-raising launch carries: a fresh one, or 0 under capture (the kernel then takes the
   // device's count + 1, and the host counts along when the graph is replayed)
   unsigned long long next_seq() {
     if (capturing_) { captured_flags_++; return 0ull; }
     return ++fetch_seq_;
   }
-  // ---- How the host waits for a read-back (wait_flag).  Polling the pinned flag is the fastest way to learn that the GPU
-  // is done -- as long as the host thread has a core to itself.  On a crowded host (eight ranks on a few cores, a box whose
-  // other tenants are busy) a thread that spins burns its time slice doing nothing and is then descheduled for several
-  // slices of the others, while a thread that SLEEPS until the GPU's interrupt wakes it stays under its fair share and is
-  // scheduled at once when it wakes.  So: spin by default; while spinning, watch the clock for holes (a gap of > 100 us
-  // between two looks means the thread was taken off the core); when holes keep coming, wait POLITELY for a while --
-  // an event recorded behind every flag-raising submission, hipEventSynchronize on a blocking event -- and probe again
-  // later.  DPGO_WAIT=spin / block forces either.
+  // ---- How the host waits for a read-back (wait_flag): it polls the pinned flag.  DPGO_WAIT=block makes it sleep on a
+  // blocking event recorded behind every flag-raising submission instead (measured, DESIGN 6a: 5-8 % slower on an idle
+  // host, no faster on a crowded one -- the HIP runtime's own threads need the core as well -- so it is an opt-in).
   enum { WAIT_EVENTS = 8 };
   hipEvent_t wait_ev_[WAIT_EVENTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned long long wait_ev_seq_[WAIT_EVENTS] = {0, 0, 0, 0, 0, 0, 0, 0};
   int wait_ev_next_ = 0;
-  int wait_mode_ = 0;            // 0 auto, 1 spin, 2 block
   bool polite_ = false;
-  long polite_left_ = 0, holes_recent_ = 0, waits_since_hole_ = 0, polite_switches_ = 0, waits_polite_ = 0;
-  void mark_flag_event();        // polite mode: an event behind the submission that raises the flag to fetch_seq_
+  long waits_polite_ = 0;
+  void mark_flag_event();        // DPGO_WAIT=block: an event behind the submission that raises the flag to fetch_seq_
+  // ---- Whether segments are replayed (iter_graph_wanted), decided by MEASUREMENT: a group starts with eager launches and
+  // keeps an eye on how much of the time it spends inside iterate() / update() is waiting for the GPU.  A host that waits most of the time keeps up
+  // with eager launches, which are the faster way then (a replay costs the GPU ~8 us of start-up); a host that hardly ever
+  // waits is what bounds the group -- a slow or busy box, a small graph whose kernels are shorter than a launch -- and its
+  // segments are replayed from then on.  Looked at every 32 iterations; DPGO_ITER_GRAPH=0 / 1 forces either.
+  bool host_bound_ = false;
+  double win_wait_s_ = 0, win_lib_s_ = 0;   // of the window: seconds waiting for read-backs / seconds inside iterate() and update()
+  int win_iters_ = 0;
+  void host_bound_tick();        // once per iteration (update())
+  struct InLib {                 // (the caller's own time between the calls is not the library's host being slow)
+    Group *g; std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    explicit InLib(Group *gg) : g(gg) {}
+    ~InLib() { g->win_lib_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); }
+  };
   // launches that wait for the next segment to carry them (step()): captured pointer values, launched in order
   std::vector<std::function<void()>> deferred_;
   unsigned long long deferred_key_ = 0;
@@ -385,7 +392,11 @@ class Group {
   void defer_or_launch(unsigned long long key, std::function<void()> fn);
   void flush_deferred();
   bool iter_graph_wanted() const;
-  void segment(int id, std::initializer_list<unsigned long long> extra, const std::function<void()> &body);
+  // bits: the nodes the sequence works on.  Only sequences over ALL the group's nodes are replayed: a partial set is a group
+  // whose nodes are taking different branches, where the sets change from one iteration to the next and every new set
+  // would be a new capture (measured: city10000 / 8 nodes with every subset captured ran 4 x slower than eagerly)
+  void segment(int id, NodeBits bits, std::initializer_list<unsigned long long> extra, const std::function<void()> &body);
+  NodeBits all_bits() const { const int L = num_local(); return L >= 64 ? ~0ull : ((1ull << L) - 1); }
   void graphs_invalidate();   // waits (bounded) for the stream, destroys every captured graph, bumps graph_gen_
   void graphs_destroy();      // (the stream is known to be idle)
   bool drain(double seconds) const;

@@ -1578,7 +1578,7 @@ __device__ __forceinline__ SpdItem load_item(const SpdItem *p) {
 // serialises at the L2 and made the solve 2.5x slower.
 template <bool COH>
 __device__ __forceinline__ double ldc(const double *p) {
-#ifdef SPD_FLOW_UNSAFE_LOADS   /* measurement only (may read stale lines): what the agent-scope loads cost */
+#if defined(SPD_FLOW_UNSAFE_LOADS)   /* measurement only (may read stale lines): what the agent-scope loads cost */
   return *p;
 #else
   if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1587,8 +1587,14 @@ __device__ __forceinline__ double ldc(const double *p) {
 }
 template <bool COH>
 __device__ __forceinline__ void stc(double *p, double v) {
+#ifdef SPD_FLOW_XCD   /* probe build (tools/build_variant.sh): hand-overs that stay inside one XCD's L2 -- plain stores (the line
+                         stays in the L2), L1-bypassing loads, counters at workgroup scope (executed in the L2).  Only right when a
+                         node's tiles all run on one XCD, which this build takes from the dispatch order: a TIMING probe */
+  *p = v;
+#else
   if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else *p = v;
+#endif
 }
 template <int D, int PB, bool COH = false>
 __device__ __forceinline__ void pull_updates(const SpdDev &S, int pos, double (&v)[D]) {
@@ -2155,6 +2161,7 @@ __global__ __launch_bounds__(256) void k_root_combine(SpdDev S, NodeMask mask, S
 __device__ __forceinline__ void flow_wait(unsigned *ctr, int idx, unsigned target, int nctr, int *host_err) {
   const unsigned *c = ctr + idx;
   int spins = 0;
+  // (SPD_FLOW_XCD: the same L1-bypassing load; the counter it reads was added to in this XCD's L2)
   while ((int)(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
     __builtin_amdgcn_s_sleep(2);
     if ((++spins & 255) == 0) {
@@ -2226,7 +2233,11 @@ __global__ __launch_bounds__(512, SPD_FLOW_WPE) void k_spd_flow(SpdDev S, NodeMa
   // and have arrived when the wave's store counter is back at zero: then the tile counts
   if (it.signal_ctr >= 0 && (!is_wide || wv == 0)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SPD_FLOW_XCD
+    if (lane == 0) __hip_atomic_fetch_add(A.ctr + it.signal_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
     if (lane == 0) __hip_atomic_fetch_add(A.ctr + it.signal_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
   }
 }
 
@@ -2362,11 +2373,23 @@ void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, co
                      const double *Rdot, double *out2, const double *rres, double *partials, const double *dg,
                      const double *dga, const double *ds, const double *dgrad, const double *dhs) {
   if (T.nseg_own == 0) return;
-  ProfScope ps(PK_BSR_TCOL, st, (double)A.nnzb * (8.0 * (d + 1) + 4 + 8.0 * d) + 2.0 * A.nrows * 8.0 * (d + 1) * d);
-  TcolDots E;
-  E.g = dg; E.ga = dga; E.s = ds; E.grad = dgrad; E.hs = dhs;
   // which epilogue sums are produced: mode 2 with rres (a CG step's four), mode 1 with dg (a refinement's start), mode 0 with ds (a trial point's six)
   const bool sums = partials && ((mode == 2 && rres) || (mode == 1 && dg) || (mode == 0 && ds));
+  // SURVEY 8(d)'s formula prices the bare pass (the blocks' first columns, the gathered translations, two vectors).  What
+  // the fused pass moves, operand by operand: per block its first column and index; per row the translation its
+  // neighbours gather (once: the rest are cache hits), `base`, y where it is stored, and the epilogue's vectors -- mode 1
+  // (a refinement's start): X, the tangent gradient written, g and g_alt for the sums; mode 2 (a Hessian product): X, the
+  // model gradient, the direction's and the residual's rotation rows read, the product written; mode 0 with sums (a trial
+  // point): the step's, the gradient's and H s's rotation rows, g, g_alt and the point's own record.
+  const double P = 8.0 * (d + 1) * d, Pr = 8.0 * d * d, Pt = 8.0 * d;
+  double per_row = Pt + P + (mode != 2 ? P : 0.0);
+  if (mode == 1) per_row += 2.0 * P + (sums ? (dg ? P : 0.0) + ((dga && dga != dg) ? P : 0.0) : 0.0);
+  if (mode == 2) per_row += 3.0 * P + Pr + (rres ? Pr : 0.0);
+  if (mode == 0 && sums) per_row += 3.0 * Pr + P + (dg ? P : 0.0) + ((dga && dga != dg) ? P : 0.0);
+  ProfScope ps(PK_BSR_TCOL, st, (double)A.nnzb * (8.0 * (d + 1) + 4 + 8.0 * d) + 2.0 * A.nrows * 8.0 * (d + 1) * d, 1,
+               (double)A.nnzb * (8.0 * (d + 1) + 4) + (double)A.nrows * per_row);
+  TcolDots E;
+  E.g = dg; E.ga = dga; E.s = ds; E.grad = dgrad; E.hs = dhs;
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_bsr_tcol<D>), dim3(own_grid(T, mask)), dim3(4 * SEG_ROWS), 0, st, T.segs, mask, A, tval,
                                         xt, base, y, mode, X, nabla, Rdot, out2, rres, sums ? partials : nullptr, T.nseg_all, E));
 }

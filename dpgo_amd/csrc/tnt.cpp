@@ -246,7 +246,7 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
   auto graph_step = [&]() {
     const NodeBits all = L >= 64 ? ~0ull : ((1ull << L) - 1);
     const NodeMask sA = mA, sB = mB;
-    segment(21, {K(X), kvar}, [&] {
+    segment(21, all, {K(X), kvar}, [&] {
       mA = NodeMask{all, dmask_.p};
       mB = NodeMask{all, dmask_.p + 1};
       stepA(false);
@@ -288,7 +288,7 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       nslots = std::max((int)NSUM, deferred_slots_);
       deferred_slots_ = 0;
     }
-    segment(20, {bits_nodes, K(X), kg, kga, kvar, spec ? 1ull : 0ull, (unsigned long long)nslots}, [&] {
+    segment(20, bits_nodes, {K(X), kg, kga, kvar, spec ? 1ull : 0ull, (unsigned long long)nslots}, [&] {
       cur_mask_ = live_mask(bits_nodes, nullptr);
       const bool have_sums = quad_model(X, base_ready);
       norms_enqueue(true, have_sums);
@@ -312,6 +312,7 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     if (confirm && !(*confirm)()) return false;
     seqA = fetch_seq_ - (spec ? 1 : 0);
   } else {
+    flush_deferred();   // (launches that were waiting for this refinement's first segment: there is none on this path)
     if (confirm && !(*confirm)()) return false;
     const bool have_sums = quad_model(X, base_ready);
     norms(nodes, true, have_sums);
@@ -416,7 +417,7 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       const NodeMask mrest = cur_mask_;
       int nslots = std::max((int)NSUM, deferred_slots_);
       deferred_slots_ = 0;
-      segment(22, {mrest.v, K(X), kg, kga, (unsigned long long)nslots}, [&] {
+      segment(22, mrest.v, {K(X), kg, kga, (unsigned long long)nslots}, [&] {
         enqueue_trial(mrest);
         launch_reduce(st_, T_, L, false, nslots, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
       });

@@ -65,6 +65,9 @@ def main():
             n0, o = len(g_index[a]), g_index[a][0]
             X0[o:o + n0] = Xa[:n0]
             X0[num_poses + d * o: num_poses + d * (o + n0)] = Xa[n0:(d + 1) * n0]
+        # (the warm start itself is committed: the GPU test starts from these very numbers, so that what it holds to 1e-6 is
+        # the AMM-PGO* trajectory, not the 1e-7 by which the device's own four stages differ from the oracle's)
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", name + "_X0.npz"), X0=X0)
         star = DPGOStar(path, nn, Options.driver(loss, True), mm=mm, num_poses=num_poses)
         star.initialize(X0)
         trace = [float(star.fobj)]

@@ -44,6 +44,19 @@ def release():
             pass
 
 
+def cpu_seconds():
+    """CPU time (user + system, seconds) every spinner has used so far -- proof that they run."""
+    out = []
+    tick = os.sysconf("SC_CLK_TCK")
+    for p in _procs:
+        try:
+            f = open("/proc/%d/stat" % p.pid).read().rsplit(")", 1)[1].split()
+            out.append((int(f[11]) + int(f[12])) / tick)
+        except Exception:
+            out.append(None)
+    return out
+
+
 def starve_host(n):
     info = prepare(n)
     release()
