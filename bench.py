@@ -342,11 +342,12 @@ def main():
             dist.broadcast_object_list(box, src=0)
             return box[0]
         try:
-            comm = dpgo_amd.Comm(grp, rank, world, bcast if world > 1 else None)
             if world == 1 and args.emulate_world:
                 # the emulated rank's neighbours live nowhere: run the neighbour-to-neighbour path against itself, in its
                 # steady state (pack, grouped send / recv of every exported record, unpack into a scratch array)
-                comm.self_exchange()
+                comm = dpgo_amd.Comm.self_exchange_only(grp)
+            else:
+                comm = dpgo_amd.Comm(grp, rank, world, bcast if world > 1 else None)
             comm.enable_timing()
             ok = 1
         except Exception as e:

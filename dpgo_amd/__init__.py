@@ -147,6 +147,7 @@ SYMBOLS = {
     "dpgo_comm_exchange_kind": (C.c_int, [C.c_void_p]),
     "dpgo_comm_bytes_sent": (C.c_long, [C.c_void_p]),
     "dpgo_comm_self_exchange": (C.c_int, [C.c_void_p]),
+    "dpgo_comm_create_self": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "dpgo_comm_enable_timing": (C.c_int, [C.c_void_p]),
     "dpgo_comm_exchange_time": (C.c_int, [C.c_void_p, _DP, C.POINTER(C.c_long)]),
     "dpgo_debug_comm_p2p_self": (C.c_int, [C.c_void_p]),
@@ -650,6 +651,18 @@ class Comm:
         if lib().dpgo_comm_create(group._h, rank, nranks, idb, C.byref(h)) != 0:
             raise RuntimeError("dpgo_comm_create failed")
         self._h = h
+
+    @classmethod
+    def self_exchange_only(cls, group):
+        """A one-rank communicator that serves exchange() alone, with the rank as its own peer (dpgo_comm_create_self): for a
+        group whose neighbours no rank hosts -- one rank of an N-GPU run emulated on one GPU."""
+        self = cls.__new__(cls)
+        self.group, self.rank, self.nranks = group, 0, 1
+        h = C.c_void_p()
+        if lib().dpgo_comm_create_self(group._h, C.byref(h)) != 0:
+            raise RuntimeError("dpgo_comm_create_self failed")
+        self._h = h
+        return self
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -423,7 +423,7 @@ int dpgo_prof_enable(int on) { dpgo::prof_enable(on != 0); if (on) dpgo::prof_re
 int dpgo_prof_num_kinds(void) { return dpgo::PK_COUNT; }
 const char *dpgo_prof_kind_name(int k) {
   static const char *names[] = {"k_bsr", "k_inter", "k_proximal", "k_axpby", "k_dot", "k_rot_op", "k_copy_indexed",
-                                "k_bdiag_dot", "k_reduce", "k_spd_fwd", "k_spd_bwd", "k_spd_flow", "k_bsr_tcol"};
+                                "k_bdiag_dot", "k_reduce", "k_spd_fwd", "k_spd_bwd", "k_bsr_tcol"};
   static_assert(sizeof(names) / sizeof(names[0]) == dpgo::PK_COUNT, "one name per profiled kernel family");
   return (k >= 0 && k < dpgo::PK_COUNT) ? names[k] : "";
 }
@@ -668,6 +668,21 @@ int dpgo_debug_comm_p2p_self(dpgo_group_t *h) {
   });
 }
 
+int dpgo_comm_create_self(dpgo_group_t *h, dpgo_comm_t **out) {
+  if (!out) return -1;
+  *out = nullptr;
+  if (!h) return -1;
+  return guarded([&] {
+    unsigned char id[128];
+    if (dpgo::Comm::unique_id(id) != 0) return -1;
+    std::unique_ptr<dpgo_comm> c(new dpgo_comm());
+    std::unique_ptr<dpgo::Comm> cc(new dpgo::Comm(h->grp, 0, 1, id, /*layout=*/false));
+    if (cc->enable_self_exchange() != 0) return -1;
+    c->c = cc.release();
+    *out = c.release();
+    return 0;
+  });
+}
 int dpgo_comm_self_exchange(dpgo_comm_t *c) {
   if (!c || !c->c) return -1;
   return guarded([&] { return c->c->enable_self_exchange(); });

@@ -490,7 +490,9 @@ int Comm::p2p_self_check() {
 }
 
 int Comm::enable_self_exchange() {
-  if (!ok_ || nranks_ != 1 || !comm_ || !cs_ || !(rccl().Send && rccl().Recv && rccl().GroupStart && rccl().GroupEnd)) return -1;
+  // (also on a communicator made without the exchange lay-out -- a group whose neighbours no rank hosts, the emulated rank of
+  // bench.py: exchange() is then all this communicator serves)
+  if (nranks_ != 1 || !comm_ || !cs_ || !(rccl().Send && rccl().Recv && rccl().GroupStart && rccl().GroupEnd)) return -1;
   Group *grp = grp_;
   const int RS = (grp->d() + 1) * grp->d();
   const auto &keys = grp->sent_keys();
@@ -513,6 +515,7 @@ int Comm::enable_self_exchange() {
   HIP_OK(hipDeviceSynchronize());
   p2p_ = true;
   self_ = true;
+  ok_ = true;
   return 0;
 }
 

@@ -55,7 +55,6 @@ template struct DevBuf<int64_t>;
 template struct DevBuf<int4>;
 template struct DevBuf<Seg>;
 template struct DevBuf<SpdItem>;
-template struct DevBuf<SpdFlowEntry>;
 template struct DevBuf<unsigned>;
 template struct DevBuf<CgNode>;
 template struct DevBuf<NodeBits>;
@@ -158,7 +157,6 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
   for (int a : node_of_unknown) nnodes = std::max(nnodes, a + 1);
   auto node_of_front = [&](int f) { return node_of_unknown[F.piv_idx[F.piv_ptr[f]]]; };   // a front never spans two nodes (they are disconnected)
   struct Tile { int f, first, count, rows; int64_t len; };   // rows: tile height of its class; len: panel rows
-  std::vector<SpdItem> h_fwd, h_bwd, h_root;   // (kept until the tiles' dependencies are known, below)
   auto sweep = [&](bool fwd, std::vector<Level> &out_levels, DevBuf<SpdItem> &items_dev, DevBuf<double> &panels_dev) {
     const auto &levels = fwd ? F.by_height : F.by_depth;
     std::vector<Tile> tiles;
@@ -223,7 +221,6 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
       items[i] = it;
       total += t.len * ld;
     }
-    (fwd ? h_fwd : h_bwd) = items;
     if (getenv("DPGO_SPD_DUMP")) {
       int64_t used = 0;
       for (const Tile &t : tiles) used += t.len * t.count;
@@ -287,7 +284,7 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
     for (int f = 0; f < F.nfronts; f++)
       if (is_root(f)) { roots.push_back(f); largest_mb = std::max(largest_mb, 8e-6 * (double)F.w[f] * F.w[f]); }
     const int force = env_int("DPGO_SPD_ROOT_SYM", -1);
-    root_sym = !roots.empty() && !want_f32 && env_int("DPGO_SPD_FLOW", 0) == 0 && nnodes <= MAX_LOCAL_NODES &&
+    root_sym = !roots.empty() && !want_f32 && nnodes <= MAX_LOCAL_NODES &&
                (force == 1 || (force != 0 && largest_mb >= env_int("DPGO_SPD_ROOT_SYM_MB", 32)));
   }
   if (fused_root && root_sym) {
@@ -362,7 +359,6 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
       root_rows_level.nwide += root_rows_level.wcount[a];
     }
     root_level = root_sym_level;   // (what the dumps and the byte counts look at)
-    h_root.clear();                // (no tile of the one-launch solve: it is off with this form)
     root_items.upload(items);
     root_pack.upload(pack);
     root_srcs.upload(srcs);
@@ -437,7 +433,6 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
       srcs[i] = PanelSrc{(long long)(p_off[f] + t.first), F.w[f], F.w[f]};   // columns first.. of the dense w x w product
       total += (int64_t)F.w[f] * ld;
     }
-    h_root = items;
     if (!tiles.empty()) {
       root_items.upload(items);
       root_srcs.upload(srcs);
@@ -501,64 +496,6 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
     }
     if (getenv("DPGO_SPD_DUMP"))
       fprintf(stderr, "[spd] dof %d fused roots: %zu fronts, %zu tiles x %d rows, %.1f MB of panels\n", dof, roots.size(), tiles.size(), rows, total * 8e-6);
-  }
-  // ---- the one-launch solve: what every tile waits for and whom it tells (kernels.h, k_spd_flow)
-  {
-    const int nfr = F.nfronts;
-    std::vector<int> nf(nfr, 0), nb(nfr, 0), nr(nfr, 0), needA(nfr, 0);
-    for (const SpdItem &it : h_fwd) nf[it.front]++;
-    for (const SpdItem &it : h_bwd) nb[it.front]++;
-    for (const SpdItem &it : h_root) nr[it.front]++;
-    for (int f = 0; f < nfr; f++)
-      if (F.parent[f] >= 0) needA[F.parent[f]] += nf[f];
-    // (an experiment that lost, DESIGN 3.4: handing results from tile to tile through memory-side counters costs more
-    // than the kernel boundary it replaces -- 1.40 against 1.27 ms per iteration with eight nodes, 0.60 against 0.37 with
-    // one -- so it is off unless asked for)
-    flow = env_int("DPGO_SPD_FLOW", 0) != 0 && nnodes <= MAX_LOCAL_NODES && !root_sym;
-    // (a front that passes contributions on without a tile of its own would break the chain of waits)
-    for (int f = 0; f < nfr; f++)
-      if (needA[f] > 0 && nf[f] + nr[f] == 0) flow = false;
-    auto A = [&](int f) { return f; };
-    auto B = [&](int f) { return nfr + f; };
-    auto C = [&](int f) { return 2 * nfr + f; };
-    for (SpdItem &it : h_fwd) {
-      const int f = it.front;
-      if (needA[f] > 0) { it.wait_ctr = A(f); it.wait_need = needA[f]; }
-      it.signal_ctr = F.parent[f] >= 0 ? A(F.parent[f]) : C(f);
-    }
-    for (SpdItem &it : h_root) {
-      const int f = it.front;
-      if (needA[f] > 0) { it.wait_ctr = A(f); it.wait_need = needA[f]; }
-      it.signal_ctr = B(f);
-    }
-    for (SpdItem &it : h_bwd) {
-      const int f = it.front, p = F.parent[f];
-      if (p >= 0) { it.wait_ctr = B(p); it.wait_need = is_root(p) ? nr[p] : nb[p]; }
-      else { it.wait_ctr = C(f); it.wait_need = nf[f]; }   // a root that keeps two sweeps: its own forward tiles
-      if (it.wait_need == 0) flow = false;
-      it.signal_ctr = B(f);
-    }
-    flow_stages.clear();
-    for (const Level &l : fwd_levels) if (l.nwide + l.nnarrow > 0) flow_stages.push_back({&l, 0});
-    if (fused_root && root_level.nwide > 0) flow_stages.push_back({&root_level, 2});
-    for (const Level &l : bwd_levels) if (l.nwide + l.nnarrow > 0) flow_stages.push_back({&l, 1});
-    if ((int)flow_stages.size() > SPD_FLOW_MAX_STAGES || flow_stages.empty()) flow = false;
-    if (flow) {
-      if (!h_fwd.empty()) fwd_items.upload(h_fwd);
-      if (!h_bwd.empty()) bwd_items.upload(h_bwd);
-      if (!h_root.empty()) root_items.upload(h_root);
-      std::vector<SpdFlowEntry> tab(flow_stages.size() * (size_t)nnodes);
-      for (size_t s = 0; s < flow_stages.size(); s++)
-        for (int a = 0; a < nnodes; a++) {
-          const Level &l = *flow_stages[s].lev;
-          tab[s * nnodes + a] = SpdFlowEntry{l.wstart[a], l.wcount[a], l.nstart[a], l.ncount[a]};
-        }
-      flow_table.upload(tab);
-      flow_nctr = 3 * nfr;
-      flow_ctr.alloc((size_t)flow_nctr + 1);   // (zeroed; the last word is the abort word)
-      flow_nnodes = nnodes;
-      flow_epoch.assign(nnodes, 0u);
-    }
   }
   spd_release_device(F);
   // the panels are on the device now: the host copy of the factor (gigabytes at the headline size) can go
@@ -1164,11 +1101,14 @@ NodeMask Group::live_mask(NodeBits bits, const NodeBits *p) const {
   const int L = num_local();
   static const bool on = env_int("DPGO_LIVE_GRIDS", 1) != 0;
   int n = 0, idle = -1;
+  if ((int)own_seg_ptr_host_.size() != L + 1) return m;
   for (int a = 0; a < L; a++) {
     if ((bits >> a) & 1ull) n++;
-    else if (idle < 0) idle = a;
+    // (the surplus workgroups of the launch land on the idle node's FIRST segment and leave at once: it must be a segment
+    // of that node -- a node without own rows has none, its "first" one would be the next node's)
+    else if (idle < 0 && own_seg_ptr_host_[a + 1] > own_seg_ptr_host_[a]) idle = a;
   }
-  if (!on || n == 0 || n > MAX_LIVE_SEGS || idle < 0 || (int)own_seg_ptr_host_.size() != L + 1) return m;   // (every node, or too many: the whole grid)
+  if (!on || n == 0 || n > MAX_LIVE_SEGS || idle < 0) return m;   // (every node, too many, or nowhere to park: the whole grid)
   for (int a = 0; a < L; a++)
     if ((bits >> a) & 1ull) {
       m.seg0[m.nlive] = own_seg_ptr_host_[a];
@@ -1184,7 +1124,7 @@ NodeMask Group::live_mask(NodeBits bits, const NodeBits *p) const {
 // ---------------------------------------------------------------------------
 bool Group::iter_graph_wanted() const {
   static const int force = env_int("DPGO_ITER_GRAPH", -1);
-  if (graphs_broken_ || force == 0 || prof_enabled() || Ltt_.flow || Lrr_.flow) return false;   // (never while launches are timed)
+  if (graphs_broken_ || force == 0 || prof_enabled()) return false;   // (never while launches are timed)
   if (force == 1) return true;
   // Where a segment streams gigabytes (the headline's eight nodes on one GPU) the host is never what bounds it, and its
   // launches shrink with the set of nodes that still iterate, which a replay's frozen grids cannot do.  Below that size:
@@ -1442,63 +1382,7 @@ bool SpdSolverDev::Level::map(NodeBits bits, SpdLevelMap &M, double *bytes) cons
   return M.nlive > 0;
 }
 
-// the pinned word a solve tile raises when a wait did not end (k_spd_flow): one per process
-static int *spd_flow_error_word() {
-  static int *w = [] {
-    int *p = nullptr;
-    HIP_CHECK(hipHostMalloc((void **)&p, sizeof(int), hipHostMallocMapped));
-    *p = 0;
-    return p;
-  }();
-  return w;
-}
-
-// every level of both sweeps as the stages of ONE launch; false: nothing to do for these nodes
-static bool spd_run_flow(int d, hipStream_t st, SpdSolverDev &S, NodeMask mask, double *in, double *out, double scale) {
-  int *err = spd_flow_error_word();
-  if (*err) throw DeviceError("spd_run: a tile of the one-launch solve waited for a result that never came (DPGO_SPD_FLOW=0 avoids it)");
-  SpdFlowArgs A;
-  A.nnodes = S.flow_nnodes;
-  for (int a = 0; a < S.flow_nnodes; a++)
-    if ((mask.v >> a) & 1ull) A.node[A.nlive++] = (unsigned char)a;
-  if (A.nlive == 0) return false;
-  double bytes = 0;
-  int wg = 0;
-  bool root_on = false;
-  for (size_t s = 0; s < S.flow_stages.size(); s++) {
-    const SpdSolverDev::Level &l = *S.flow_stages[s].lev;
-    int maxw = 0, maxn = 0;
-    for (int j = 0; j < A.nlive; j++) {
-      const int a = A.node[j];
-      maxw = std::max(maxw, l.wcount[a]);
-      maxn = std::max(maxn, l.ncount[a]);
-      bytes += l.node_bytes[a];
-    }
-    if (maxw + maxn == 0) continue;
-    if (S.flow_stages[s].mode == 2) root_on = true;
-    SpdFlowStage &g = A.st[A.nstages];
-    g.wide_wgs = A.nlive * maxw;
-    wg += g.wide_wgs + A.nlive * ((maxn + 7) / 8);
-    wg = (wg + 7) & ~7;   // a stage starts on a multiple of 8: with 8 live nodes slot j keeps to XCD j (round-robin dispatch)
-    g.wg_end = wg;
-    g.rows = l.rows;
-    g.mode = S.flow_stages[s].mode;
-    A.stage_id[A.nstages] = (unsigned char)s;
-    A.nstages++;
-  }
-  if (A.nstages == 0) return false;
-  if (root_on && in == out) throw DeviceError("spd_run: the fused root step cannot solve in place");
-  for (int j = 0; j < A.nlive; j++) A.epoch[j] = ++S.flow_epoch[A.node[j]];
-  A.table = S.flow_table.p;
-  A.ctr = S.flow_ctr.p;
-  A.nctr = S.flow_nctr;
-  A.host_err = err;
-  launch_spd_flow(d, S.dof, st, S.dev, A, in, out, S.ytmp.p, scale, bytes, S.stream_once, mask);
-  return true;
-}
-
 void spd_run(int d, hipStream_t st, SpdSolverDev &S, NodeMask mask, double *in, double *out, double scale) {
-  if (S.flow) { spd_run_flow(d, st, S, mask, in, out, scale); return; }
   // the launches of the nodes in mask.v (what the host knows); mask.p, if any, is the device's more recent word
   std::vector<SpdLevelMap> fm(S.fwd_levels.size()), bm(S.bwd_levels.size());
   std::vector<double> fby(fm.size(), 0.0), bby(bm.size(), 0.0);

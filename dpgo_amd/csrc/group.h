@@ -169,18 +169,6 @@ struct SpdSolverDev {
   int dof = 1;
   bool stream_once = true;   // panels read with non-temporal loads (see upload)
   void upload(int dcols, const std::vector<int> &node_of_unknown);   // node_of_unknown: local node of every row of A
-  // The whole solve in one launch (k_spd_flow, kernels.h): every level is a stage of one grid and a tile waits on a
-  // counter for the tiles it depends on.  flow_table: the stages' per-node tile ranges; flow_ctr: per front, the
-  // forward tiles of its children that are done / its own backward (or root) tiles / its own forward tiles (roots that
-  // keep two sweeps); flow_epoch: per node, the solves it has been part of (the counters are never reset).
-  // Measured SLOWER than one launch per level on this GPU, so it is an opt-in experiment: DPGO_SPD_FLOW=1.
-  bool flow = false;
-  struct FlowStage { const Level *lev; int mode; };
-  std::vector<FlowStage> flow_stages;
-  DevBuf<SpdFlowEntry> flow_table;
-  DevBuf<unsigned> flow_ctr;
-  int flow_nctr = 0, flow_nnodes = 0;
-  std::vector<unsigned> flow_epoch;
   DevBuf<PanelSrc> fwd_srcs, bwd_srcs, root_srcs;   // where every tile's panel comes from in the front-major factor
   int repack(hipStream_t st);   // the panels again from F.dev_W / F.dev_WT (same pattern, new values)
 };

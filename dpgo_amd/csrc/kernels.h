@@ -274,9 +274,7 @@ struct alignas(16) SpdItem {
   int u, ld, piv_ptr, upd_ptr;           // ld: doubles between consecutive rows of the tile's panel
   int pos_off, ubuf_off, node, wait_ctr; // node: local node the front belongs to (launch masks)
   int64_t mat_off;                       // offset of the tile's panel
-  // one-launch solve (k_spd_flow): the tile starts when counter wait_ctr has reached epoch * wait_need and adds 1 to
-  // counter signal_ctr when its results are visible (-1: no counter)
-  int wait_need, signal_ctr;
+  int wait_need, signal_ctr;             // (reserved: with wait_ctr, the counters of the one-launch solve that round 5 removed)
 };
 static_assert(sizeof(SpdItem) == 64, "SpdItem is loaded as four int4");
 
@@ -304,26 +302,6 @@ struct SpdLevelMap {
   int nstart[MAX_LOCAL_NODES], ncount[MAX_LOCAL_NODES];   // the same for the narrow tiles
   unsigned char node[MAX_LOCAL_NODES];                    // local node of the slot
 };
-// The whole solve in ONE launch (k_spd_flow): the levels of both sweeps are STAGES of one grid, in dependency order, and a
-// tile waits for the tiles it depends on -- its front's children (forward), its front's parent (backward) -- on a
-// counter in device memory instead of on a kernel boundary.  Workgroups are dispatched in index order, so whatever a
-// resident tile waits for is resident or done: no deadlock, and no level pays for the slowest tile of the one before.
-struct SpdFlowStage { int wg_end, wide_wgs, rows, mode; };   // workgroups [previous wg_end, wg_end); the first wide_wgs take wide tiles
-struct SpdFlowEntry { int wstart, wcount, nstart, ncount; }; // per (stage, local node): its tiles in the stage's item list
-constexpr int SPD_FLOW_MAX_STAGES = 44;
-struct SpdFlowArgs {
-  int nstages = 0, nlive = 0, nnodes = 0, pad = 0;
-  SpdFlowStage st[SPD_FLOW_MAX_STAGES];
-  unsigned epoch[MAX_LOCAL_NODES];       // per live slot: how many solves its node has been part of (counters are never reset)
-  unsigned char node[MAX_LOCAL_NODES];   // local node of the slot
-  unsigned char stage_id[SPD_FLOW_MAX_STAGES];   // row of `table` (a launch leaves out the stages without a live tile)
-  const SpdFlowEntry *table = nullptr;   // [stage_id * nnodes + node]
-  unsigned *ctr = nullptr;               // the counters; ctr[nctr] is the abort word
-  int nctr = 0;
-  int *host_err = nullptr;               // pinned: set when a wait gave up (a bug, never a state of a correct run)
-};
-void launch_spd_flow(int d, int dof, hipStream_t st, const SpdDev &S, const SpdFlowArgs &A, double *in, double *out, double *ytmp,
-                     double scale, double bytes, bool stream_once, NodeMask mask);
 // dof = 1: unknown i is the translation of pose i; dof = d: unknown i = (pose i / d, rotation row i % d).
 // vec is a record array: forward reads the right-hand side from vec and writes y to ytmp (n x d, the pivots
 // of a front consecutive); backward reads ytmp and writes scale * A^-1 b into vec (scale must be +1 or -1).
@@ -371,7 +349,7 @@ void launch_root_combine(int d, int dof, hipStream_t st, const SpdDev &S, const 
 
 // ---- optional per-launch timing (HIP events on the launch stream), off by default ----
 enum ProfKind { PK_BSR = 0, PK_INTER, PK_PROX, PK_AXPBY, PK_DOT, PK_ROTOP, PK_COPYIDX, PK_BDIAG, PK_REDUCE,
-                PK_SPD_FWD, PK_SPD_BWD, PK_SPD_FLOW, PK_BSR_TCOL, PK_COUNT };
+                PK_SPD_FWD, PK_SPD_BWD, PK_BSR_TCOL, PK_COUNT };
 void prof_enable(bool on);
 // One timing scope around the back-to-back launches of a solve sweep (profiling pass only; nothing otherwise)
 struct ProfSweep {

@@ -1572,31 +1572,7 @@ __device__ __forceinline__ SpdItem load_item(const SpdItem *p) {
 // v += the children's contributions to front position `pos`.  The update buffer is laid out in PULL order: the
 // rows a position receives are consecutive (rows asm_ptr[pos] .. asm_ptr[pos + 1]), in the fixed order of the
 // host's assembly lists; the children scatter their update rows there (ubuf_dst), which is off the critical path.
-// COH (the one-launch solve): what one tile hands to another -- update rows, y, x -- may cross XCDs, whose L2s are not
-// coherent with each other.  Such values are stored and loaded at AGENT scope (sc1: written through, never served from a
-// stale line), which costs nothing but the L2 hit; a cache-wide release / acquire per tile (buffer_wbl2 / buffer_inv)
-// serialises at the L2 and made the solve 2.5x slower.
-template <bool COH>
-__device__ __forceinline__ double ldc(const double *p) {
-#if defined(SPD_FLOW_UNSAFE_LOADS)   /* measurement only (may read stale lines): what the agent-scope loads cost */
-  return *p;
-#else
-  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else return *p;
-#endif
-}
-template <bool COH>
-__device__ __forceinline__ void stc(double *p, double v) {
-#ifdef SPD_FLOW_XCD   /* probe build (tools/build_variant.sh): hand-overs that stay inside one XCD's L2 -- plain stores (the line
-                         stays in the L2), L1-bypassing loads, counters at workgroup scope (executed in the L2).  Only right when a
-                         node's tiles all run on one XCD, which this build takes from the dispatch order: a TIMING probe */
-  *p = v;
-#else
-  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-#endif
-}
-template <int D, int PB, bool COH = false>
+template <int D, int PB>
 __device__ __forceinline__ void pull_updates(const SpdDev &S, int pos, double (&v)[D]) {
   const int a0 = S.asm_ptr[pos], a1 = S.asm_ptr[pos + 1];
   for (int a = a0; a < a1; a += PB) {
@@ -1605,7 +1581,7 @@ __device__ __forceinline__ void pull_updates(const SpdDev &S, int pos, double (&
     for (int q = 0; q < PB; q++)
       if (a + q < a1) {
 #pragma unroll
-        for (int c = 0; c < D; c++) t[q][c] = ldc<COH>(S.ubuf + (size_t)(a + q) * D + c);
+        for (int c = 0; c < D; c++) t[q][c] = S.ubuf[(size_t)(a + q) * D + c];
       }
 #pragma unroll
     for (int q = 0; q < PB; q++)
@@ -1686,7 +1662,7 @@ __device__ __forceinline__ int spd_chunk(int len) {
 // its forward step y = L11^-1 f is followed at once by its backward step x = L11^-T y: the tile streams rows of the
 // explicit product L11^-T L11^-1 (= the inverse of the root's Schur complement, S.Wroot) and writes scale * x straight
 // into `out` -- one launch instead of two, the same bytes (w^2 entries against two triangles).
-template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool NT, bool ROOT = false, typename PT = double, bool COH = false>
+template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool NT, bool ROOT = false, typename PT = double>
 __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it, const double *vec, double *ytmp,
                                              double *fw, double *red, const int wv, const int lane,
                                              int trace_slot = 0, unsigned long long trace_t0 = 0, double *out = nullptr,
@@ -1732,7 +1708,7 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
       const double *src = vec + vaddr<D, DOF>(piv[k]);
 #pragma unroll
       for (int c = 0; c < D; c++) v[c] = *(src + c);
-      pull_updates<D, PULLB, COH>(S, pos0 + k, v);
+      pull_updates<D, PULLB>(S, pos0 + k, v);
 #pragma unroll
       for (int c = 0; c < D; c++) fw[kk * D + c] = v[c];
     }
@@ -1760,7 +1736,7 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
   double extra[D];
 #pragma unroll
   for (int c = 0; c < D; c++) extra[c] = 0.0;
-  if (writer && p >= w) pull_updates<D, PULLB, COH>(S, pos0 + p, extra);
+  if (writer && p >= w) pull_updates<D, PULLB>(S, pos0 + p, extra);
   if constexpr (NW > 1) {
     if (kq == 0) {
 #pragma unroll
@@ -1782,24 +1758,24 @@ __device__ __forceinline__ void spd_fwd_tile(const SpdDev &S, const SpdItem &it,
     if (writer) {
       double *dst = out + vaddr<D, DOF>(piv[p]);
 #pragma unroll
-      for (int c = 0; c < D; c++) stc<COH>(dst + c, scale * acc[c]);
+      for (int c = 0; c < D; c++) dst[c] = scale * acc[c];
     }
   } else if (writer) {
     if (p < w) {
       double *dst = ytmp + (size_t)(it.piv_ptr + p) * D;   // y in front order: the backward sweep reads it back contiguously
 #pragma unroll
-      for (int c = 0; c < D; c++) stc<COH>(dst + c, acc[c]);
+      for (int c = 0; c < D; c++) dst[c] = acc[c];
     } else {
       double *dst = S.ubuf + (size_t)udst * D;
 #pragma unroll
-      for (int c = 0; c < D; c++) stc<COH>(dst + c, acc[c] + extra[c]);
+      for (int c = 0; c < D; c++) dst[c] = acc[c] + extra[c];
     }
   }
   SPD_T(5)
   SPD_TRACE_FLUSH(wv == 0 && lane == 0)
 }
 
-template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool NT, typename PT = double, bool COH = false>
+template <int D, int DOF, int NW, int SPD_CH, int ROWS, bool NT, typename PT = double>
 __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it, double scale, const double *ytmp,
                                              double *vec, double *fw, double *red, const int wv, const int lane,
                                              int trace_slot = 0, unsigned long long trace_t0 = 0) {
@@ -1836,7 +1812,7 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
       const double *src = p < w ? ytmp + (size_t)(it.piv_ptr + p) * D : vec + vaddr<D, DOF>(upd[p - w]);
 #endif
 #pragma unroll
-      for (int c = 0; c < D; c++) fw[pp * D + c] = sc * ldc<COH>(src + c);
+      for (int c = 0; c < D; c++) fw[pp * D + c] = sc * src[c];
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1876,7 +1852,7 @@ __device__ __forceinline__ void spd_bwd_tile(const SpdDev &S, const SpdItem &it,
   if (valid && kq == 0) {
     double *dst = vec + vaddr<D, DOF>(piv[k]);
 #pragma unroll
-    for (int c = 0; c < D; c++) stc<COH>(dst + c, scale * acc[c]);
+    for (int c = 0; c < D; c++) dst[c] = scale * acc[c];
   }
   SPD_T(5)
   SPD_TRACE_FLUSH(wv == 0 && lane == 0)
@@ -2150,95 +2126,6 @@ __global__ __launch_bounds__(256) void k_root_combine(SpdDev S, NodeMask mask, S
   double *dst = out + vaddr<D, DOF>(pidx);
 #pragma unroll
   for (int c = 0; c < D; c++) dst[c] = scale * (((red[0][lane * D + c] + red[1][lane * D + c]) + red[2][lane * D + c]) + red[3][lane * D + c]);
-}
-
-// ---- the whole solve in one launch -------------------------------------------------------------------------------
-// A wave waits until counter c has reached `target` (counters only grow: epoch * tiles-per-solve, compared modulo 2^32).
-// What the producers handed over was stored at agent scope and completed (s_waitcnt) before their count, and is loaded at
-// agent scope after this wait (ldc / stc above): no cache-wide fence.  A wait that does not end within ~1 s is a bug (a
-// tile list out of dependency order): it raises the abort word, which ends every other wait at once, and the host's
-// error flag.
-__device__ __forceinline__ void flow_wait(unsigned *ctr, int idx, unsigned target, int nctr, int *host_err) {
-  const unsigned *c = ctr + idx;
-  int spins = 0;
-  // (SPD_FLOW_XCD: the same L1-bypassing load; the counter it reads was added to in this XCD's L2)
-  while ((int)(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-    __builtin_amdgcn_s_sleep(2);
-    if ((++spins & 255) == 0) {
-      if (__hip_atomic_load(ctr + nctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-      if (spins > (1 << 19)) {
-        __hip_atomic_store(ctr + nctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(host_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        break;
-      }
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the tile's loads behind the wait)
-}
-
-#ifndef SPD_FLOW_WPE
-#define SPD_FLOW_WPE SPD_WPE
-#endif
-template <int D, int DOF, bool NT, typename PT>
-__global__ __launch_bounds__(512, SPD_FLOW_WPE) void k_spd_flow(SpdDev S, NodeMask mask, SpdFlowArgs A, double scale, double *in,
-                                                           double *out, double *ytmp) {
-  constexpr int CH = 128, NW = 8;
-  static_assert(SPD_NW(64) == 8 && SPD_NW(16) == 8 && SPD_NW(8) == 8, "one block size for every tile class");
-  __shared__ double f[NW][CH * D];
-  __shared__ double red[NW * 64 * D];
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  int b = blockIdx.x, s = 0;
-  while (b >= A.st[s].wg_end) s++;   // (the grid ends at the last stage's wg_end)
-  if (s > 0) b -= A.st[s - 1].wg_end;
-  const SpdFlowStage stg = A.st[s];
-  const bool is_wide = b < stg.wide_wgs;
-  if (!is_wide) b -= stg.wide_wgs;
-  const int j = b % A.nlive, r = b / A.nlive;
-  const int node = A.node[j];
-  const SpdFlowEntry e = A.table[(size_t)A.stage_id[s] * A.nnodes + node];
-  if (is_wide ? r >= e.wcount : r * NW + wv >= e.ncount) return;
-  const int mode = stg.mode;
-  const SpdItem *items = mode == 0 ? S.fwd_items : (mode == 1 ? S.bwd_items : S.root_items);
-  const SpdItem it = load_item(items + (is_wide ? e.wstart + r : e.nstart + r * NW + wv));
-  // a node that left the device-side mask after the host sized this launch: nothing of it is read, but its tiles are
-  // still counted (the counters of a node advance by the same amount in every solve it is part of)
-  const bool dead = mask.p && !((*mask.p >> node) & 1ull);
-  if (!dead) {
-    if (it.wait_ctr >= 0) {
-      const unsigned target = A.epoch[j] * (unsigned)it.wait_need;
-      if (is_wide) {
-        if (wv == 0) flow_wait(A.ctr, it.wait_ctr, target, A.nctr, A.host_err);
-        __syncthreads();
-      } else {
-        flow_wait(A.ctr, it.wait_ctr, target, A.nctr, A.host_err);
-      }
-    }
-    // (forward: right-hand side from `in`, y to ytmp; roots: `in` to `out`; backward: ytmp and `out` to `out`)
-    if (!is_wide) {
-      if (mode == 0) spd_fwd_tile<D, DOF, 1, CH, 64, NT, false, PT, true>(S, it, in, ytmp, f[wv], red, 0, lane, 0, 0ull);
-      else if (mode == 1) spd_bwd_tile<D, DOF, 1, CH, 64, NT, PT, true>(S, it, scale, ytmp, out, f[wv], red, 0, lane, 0, 0ull);
-    } else if (stg.rows == 64) {
-      if (mode == 0) spd_fwd_tile<D, DOF, NW, CH, 64, NT, false, PT, true>(S, it, in, ytmp, f[wv], red, wv, lane, 0, 0ull);
-      else if (mode == 1) spd_bwd_tile<D, DOF, NW, CH, 64, NT, PT, true>(S, it, scale, ytmp, out, f[wv], red, wv, lane, 0, 0ull);
-      else spd_fwd_tile<D, DOF, NW, CH, 64, NT, true, PT, true>(S, it, in, nullptr, f[wv], red, wv, lane, 0, 0ull, out, scale);
-    } else if (stg.rows == 16) {
-      if (mode == 0) spd_fwd_tile<D, DOF, NW, CH, 16, NT, false, PT, true>(S, it, in, ytmp, f[wv], red, wv, lane, 0, 0ull);
-      else if (mode == 1) spd_bwd_tile<D, DOF, NW, CH, 16, NT, PT, true>(S, it, scale, ytmp, out, f[wv], red, wv, lane, 0, 0ull);
-      else spd_fwd_tile<D, DOF, NW, CH, 16, NT, true, PT, true>(S, it, in, nullptr, f[wv], red, wv, lane, 0, 0ull, out, scale);
-    } else {
-      if constexpr (sizeof(PT) == 8) spd_fwd_tile<D, DOF, NW, CH, 8, NT, true, PT, true>(S, it, in, nullptr, f[wv], red, wv, lane, 0, 0ull, out, scale);
-    }
-  }
-  // the tile's results were written (through, at agent scope) by its first wave -- a narrow tile: by its only one --
-  // and have arrived when the wave's store counter is back at zero: then the tile counts
-  if (it.signal_ctr >= 0 && (!is_wide || wv == 0)) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef SPD_FLOW_XCD
-    if (lane == 0) __hip_atomic_fetch_add(A.ctr + it.signal_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-    if (lane == 0) __hip_atomic_fetch_add(A.ctr + it.signal_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-  }
 }
 
 }  // namespace
@@ -2755,35 +2642,6 @@ void spd_trace_set(unsigned long long *p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g
 void spd_trace_set(unsigned long long *) {}
 #endif
 int spd_waves(int rows) { return SPD_NW(rows); }
-void launch_spd_flow(int d, int dof, hipStream_t st, const SpdDev &S, const SpdFlowArgs &A, double *in, double *out, double *ytmp,
-                     double scale, double bytes, bool stream_once, NodeMask mask) {
-  if (A.nstages == 0 || A.nlive == 0) return;
-  const int grid = A.st[A.nstages - 1].wg_end;
-  if (grid == 0) return;
-  ProfScope ps(PK_SPD_FLOW, st, bytes);
-#define SPD_FLOW3(DOFV, NTV, PTV) hipLaunchKernelGGL((k_spd_flow<D, DOFV, NTV, PTV>), dim3(grid), dim3(512), 0, st, S, mask, A, scale, in, out, ytmp)
-#define SPD_FLOW2(DOFV, NTV)                                   \
-  do {                                                         \
-    if constexpr (DOFV != 1) {                                 \
-      if (S.f32) SPD_FLOW3(DOFV, NTV, float);                  \
-      else SPD_FLOW3(DOFV, NTV, double);                       \
-    } else {                                                   \
-      SPD_FLOW3(DOFV, NTV, double);                            \
-    }                                                          \
-  } while (0)
-#define SPD_FLOW(DOFV)                           \
-  do {                                           \
-    if (stream_once) SPD_FLOW2(DOFV, true);      \
-    else SPD_FLOW2(DOFV, false);                 \
-  } while (0)
-  DPGO_DISPATCH_D(d, {
-    if (dof == 1) SPD_FLOW(1);
-    else SPD_FLOW(D);
-  });
-#undef SPD_FLOW
-#undef SPD_FLOW2
-#undef SPD_FLOW3
-}
 void launch_root_sym(int d, int dof, hipStream_t st, const SpdDev &S, const SpdLevelMap &M, const double *vec, double *part,
                      double bytes, bool stream_once, NodeMask mask) {
   int maxn = 0;

@@ -240,6 +240,9 @@ long dpgo_comm_bytes_sent(const dpgo_comm_t *comm);
  * dpgo_comm_enable_timing / dpgo_comm_exchange_time: mean time in microseconds from "the iterate is final" on the group's
  *   stream to "the neighbour rows are in place" on the communicator's, over the exchanges since timing was enabled. */
 int dpgo_comm_self_exchange(dpgo_comm_t *comm);
+/* ... the same for a group whose neighbours NO rank hosts (one rank of an N-GPU run emulated on one GPU): a communicator of
+ * one rank without the exchange lay-out, serving dpgo_comm_exchange in the self-exchange mode only */
+int dpgo_comm_create_self(dpgo_group_t *grp, dpgo_comm_t **out);
 int dpgo_comm_enable_timing(dpgo_comm_t *comm);
 int dpgo_comm_exchange_time(dpgo_comm_t *comm, double *mean_us, long *count);
 /* Test hook: the grouped ncclSend / ncclRecv path of dpgo_comm_exchange on a communicator of ONE rank that is its own peer

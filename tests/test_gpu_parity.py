@@ -347,6 +347,51 @@ def test_per_node_calls_equal_batched_calls(fixtures_dir):
     assert b.group[0].iterate() == -1
 
 
+def test_replayed_cg_steps_serve_a_strict_subset_of_the_group(fixtures_dir, tmp_path):
+    """Per-node iterate() calls refine ONE node of an eight-node group at a time (city10000: several CG steps per refinement).  With replays forced, the CG steps of that
+    node go out as replays of a graph whose by-value node set is the whole group -- the device's own masks keep the other
+    seven nodes out -- while everything else of a partial node set is launched eagerly (Group::segment).  Bit for bit the
+    trajectory of eager launches, and of the batched calls."""
+    import subprocess
+    import sys
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import dpgo_amd
+G = dpgo_amd.read_g2o(%r, 8)
+drv = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(0, True))
+per_node = sys.argv[2] == "1"
+steps = 0
+for it in range(25):
+    if per_node:
+        for k in range(8):
+            assert drv.group[k].iterate() == 0
+        assert drv.group.communicate_local() == 0
+        for k in range(8):
+            assert drv.group[k].update() == 0
+    else:
+        assert drv.step() == 0
+    steps += sum(int(drv.group.results(k).tnt_inner_iterations) for k in range(8) if drv.group.results(k).refined)
+np.save(sys.argv[1], drv.X())
+print("STATS", drv.group.graph_stats(), steps)
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(fixtures_dir, "city10000.g2o"))
+
+    def run(tag, per_node, **env):
+        path = str(tmp_path / (tag + ".npy"))
+        out = subprocess.run([sys.executable, "-c", code, path, "1" if per_node else "0"], env=dict(os.environ, **env),
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-2000:]
+        stats = [l for l in out.stdout.splitlines() if l.startswith("STATS")][-1]
+        return np.load(path), stats
+
+    base, _ = run("batched_eager", False, DPGO_ITER_GRAPH="0")
+    got, stats = run("per_node_replayed", True, DPGO_ITER_GRAPH="1")
+    assert np.array_equal(got, base)
+    assert "'replays': 0" not in stats, stats          # (the per-node run did replay: its CG steps)
+    got, _ = run("per_node_eager", True, DPGO_ITER_GRAPH="0")
+    assert np.array_equal(got, base)
+
+
 def test_dist_pgo_cli_matches_oracle(fixtures_dir, tmp_path):
     """The C++ driver (reference flags / stdout / result files, dist_pgo.cpp:23-47, 493-568)."""
     import subprocess
@@ -917,8 +962,6 @@ np.save(sys.argv[1], drv.X())
     # ... own-segment launches that cover only the few nodes still in the CG (their segments dealt to all XCDs) against
     # whole-group grids
     assert np.array_equal(run("whole_grids", DPGO_LIVE_GRIDS="0"), base)
-    # the one-launch solve (an experiment that lost): the same tiles in the same order of operations
-    assert np.array_equal(run("flow", DPGO_SPD_FLOW="1"), base)
     for tag, env in (("hostfactor", dict(DPGO_SPD_HOST_FACTOR="1")), ("hostpanels", dict(DPGO_SPD_DEVICE_PANELS="0")),
                      ("scalarorder", dict(DPGO_SPD_QUOTIENT="0")),
                      # round 3: the refinement started by the host, the tree roots in two sweeps, G Y by a pass over the operator
