@@ -1762,6 +1762,10 @@ int Group::communicate_local() {
 }
 
 int Group::step(const std::vector<int> &locals, const std::function<int()> &exchange) {
+  struct Disarm {   // (whatever happens in between -- an error return, an exception on its way to the C ABI -- nothing stays deferred)
+    Group *g;
+    ~Disarm() { g->defer_armed_ = false; g->deferred_.clear(); g->deferred_key_ = 0; }
+  } disarm{this};
   defer_armed_ = !exchange && iter_graph_wanted();
   int rc = iterate(locals);
   if (rc == 0 && exchange) rc = exchange();
@@ -2453,10 +2457,17 @@ int Group::amm(const std::vector<int> &locals) {
     deferred_slots_ = DS + 3;
     done_tnt = run_tnt(locals, Xak_.p, gx_.p, gc_.p, true, &confirm);
     abandoned = !done_tnt;
-    if (done_tnt)
+    if (done_tnt) {
       for (int a : locals) res_[a].Gk = res_[a].Gk_alt;
-    else
-      deferred_slots_ = 0;   // (T1_ no longer holds the product of the translation solve: base_ready is false below)
+    } else {
+      // A wrong guess.  What the abandoned head wrote is scratch -- except T1_, which the trial point's translation recovery
+      // has overwritten and the refinement of the nodes that ARE refined starts from: the pass that made it runs again
+      // (same operands, same bits; its sum lands in the same slot), so that a guess, right or wrong, never changes a bit
+      // of the trajectory.
+      deferred_slots_ = 0;
+      cur_mask_ = mask_locals;
+      launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xakh_.p, 2, gx_.p, T1_.p, Xakh_.p, 0.5, gc_.p, partials_.p, DS + 1);
+    }
   }
   std::vector<int> plain, ref;
   if (!done_tnt) {
@@ -2473,7 +2484,7 @@ int Group::amm(const std::vector<int> &locals) {
       if (!plain.empty()) eval_G(Xak_.p, gc_.p, DS + 2);
       deferred_slots_ = DS + 3;
       // TNT minimises G(. | g extrapolated); Gk is G(. | g[k]) at the refined point (:377-383)
-      run_tnt(ref, Xak_.p, gx_.p, gc_.p, !abandoned);
+      run_tnt(ref, Xak_.p, gx_.p, gc_.p, true);
       for (int a : ref) res_[a].Gk = res_[a].Gk_alt;
     }
   }

@@ -65,7 +65,7 @@ for name, ds, nn, loss, acc, scheme, iters in CASES:
     for _ in range(0 if _args.no_oracle else iters):
         ostep()
     to = max(time.perf_counter() - t0, 1e-9)
-    out.append({"config": name, "poses": num_poses, "edges": len(mm), "iterations": iters,
+    out.append({"config": name, "poses": num_poses, "edges": len(mm), "iterations": iters, "gpu_iterations_timed": iters * _args.repeat,
                 "gpu_iters_per_s": iters / tg, "oracle_1core_iters_per_s": iters / to})
     print("%-48s GPU %8.1f it/s   oracle %7.2f it/s" % (name, iters / tg, iters / to), file=sys.stderr)
 print(json.dumps(out))

@@ -959,6 +959,12 @@ np.save(sys.argv[1], drv.X())
     assert np.array_equal(run("graph_forced", DPGO_ITER_GRAPH="1"), base)
     assert np.array_equal(run("nograph_lag0", DPGO_ITER_GRAPH="0", DPGO_CG_LAG="0"), base)
     assert np.array_equal(run("no_cg_graph", DPGO_CG_GRAPH="0"), base)
+    # ... the refinement started ahead of update()'s read-back (and, replayed, in one segment with the head of the
+    # iteration) against the refinement that waits for the decision: the same launches in the same order
+    assert np.array_equal(run("no_spec_refine", DPGO_SPEC_REFINE="0"), base)
+    assert np.array_equal(run("no_spec_refine_graph", DPGO_SPEC_REFINE="0", DPGO_ITER_GRAPH="1"), base)
+    # ... sleeping on an event instead of polling the flag
+    assert np.array_equal(run("wait_block", DPGO_WAIT="block", DPGO_ITER_GRAPH="1"), base)
     # ... own-segment launches that cover only the few nodes still in the CG (their segments dealt to all XCDs) against
     # whole-group grids
     assert np.array_equal(run("whole_grids", DPGO_LIVE_GRIDS="0"), base)

@@ -49,14 +49,14 @@ if has dynamic; then
   rm -rf gpurun_out/dyntr; tail -3 $out/${tag}_dynamic_headline.txt
 fi
 if has rates; then
-  for rep in 1 2 3 4 5; do python tests/config_rates.py $( [ $rep -gt 1 ] && echo --no-oracle ) > $out/rates_$rep.json 2>> $out/config_rates.err; done
+  for rep in 1 2 3 4 5; do python tests/config_rates.py --repeat 5 $( [ $rep -gt 1 ] && echo --no-oracle ) > $out/rates_$rep.json 2>> $out/config_rates.err; done
   python3 - > $out/${tag}_config_rates.json <<PY
 import json, statistics
 runs = [json.load(open("$out/rates_%d.json" % r)) for r in range(1, 6)]
 res = []
 for i, c in enumerate(runs[0]):
     g = [r[i]["gpu_iters_per_s"] for r in runs]
-    res.append(dict(c, gpu_iters_per_s=statistics.median(g), gpu_iters_per_s_runs=g, note="median of 5 runs of the same window on one box (DPGO_ITER_GRAPH unset: replays by measurement)"))
+    res.append(dict(c, gpu_iters_per_s=statistics.median(g), gpu_iters_per_s_runs=g, note="GPU: median of 5 runs on one box, each over 5 x the oracle's window after 3 warm-up iterations (DPGO_ITER_GRAPH unset: replays by measurement); oracle: one run of its window from the same initial point"))
 print(json.dumps(res))
 PY
   rm -f $out/rates_?.json
