@@ -541,7 +541,7 @@ def main():
                           float(sum(int(grp.results(k).refined) for k in range(len(grp))))))
         trace = reduce_trace(trace, dist if world > 1 else None, args.nodes)
         convergence = summarize_convergence(trace, args.converge, load_cpu_reference(args))
-    # DPGO_PRECON_FP32=1 (the opt-in experiment of DESIGN 7: the preconditioner's factor stored in fp32) must never pass for
+    # DPGO_PRECON_FP32=1 (the opt-in experiment of DESIGN 9: the preconditioner's factor stored in fp32) must never pass for
     # the headline: the line says so in `metric`, `dtype` and `experiment`
     experiment = None
     if os.environ.get("DPGO_PRECON_FP32", "0") not in ("", "0"):

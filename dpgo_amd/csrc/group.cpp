@@ -1132,11 +1132,14 @@ bool Group::iter_graph_wanted() const {
   return P0_ <= 40000 && host_bound_;
 }
 
-// Every 32 iterations: the share of the wall time this group's host thread spent waiting for read-backs.  Below a third,
-// the host is what bounds the group.
+// Every 32 iterations: the share of its time inside iterate() / update() that this group's host thread spent waiting for
+// read-backs.  Measured: 0.68 at one node per GPU of the headline on an idle host (eager launches are the faster way there:
+// replays cost 4-8 %), between 0.4 and 0.55 for the same on a slower box, 0.06-0.15 for sphere2500, city10000, M3500.  Below
+// 0.4 the host is what bounds the group.  (The CG steps of small multi-node groups are replayed whatever this says:
+// cg_graph_wanted.)
 void Group::host_bound_tick() {
   if (host_bound_ || ++win_iters_ < 32) return;
-  if (win_lib_s_ > 0 && win_wait_s_ < 0.33 * win_lib_s_) host_bound_ = true;
+  if (win_lib_s_ > 0 && win_wait_s_ < 0.40 * win_lib_s_) host_bound_ = true;
   win_iters_ = 0;
   win_wait_s_ = 0;
   win_lib_s_ = 0;
@@ -1172,7 +1175,8 @@ void Group::flush_deferred() {
   for (auto &f : d) f();
 }
 
-void Group::segment(int id, NodeBits bits, std::initializer_list<unsigned long long> extra, const std::function<void()> &body_in) {
+void Group::segment(int id, NodeBits bits, std::initializer_list<unsigned long long> extra, const std::function<void()> &body_in,
+                    int wanted_in) {
   if (capturing_) { body_in(); return; }   // (a segment inside a segment is part of it)
   // launches that were waiting for a segment to carry them (step()) become its head
   std::vector<std::function<void()>> pro;
@@ -1184,7 +1188,8 @@ void Group::segment(int id, NodeBits bits, std::initializer_list<unsigned long l
     body_in();
   };
   const std::function<void()> &body = pro.empty() ? body_in : with_pro;
-  if (!iter_graph_wanted() || bits != all_bits()) {
+  const bool wanted = wanted_in < 0 ? iter_graph_wanted() : wanted_in != 0;
+  if (!wanted || bits != all_bits()) {
     seg_eager_++;
     const unsigned long long before = fetch_seq_;
     const auto t0 = std::chrono::steady_clock::now();

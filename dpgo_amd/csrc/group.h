@@ -350,7 +350,7 @@ class Group {
     return ++fetch_seq_;
   }
   // ---- How the host waits for a read-back (wait_flag): it polls the pinned flag.  DPGO_WAIT=block makes it sleep on a
-  // blocking event recorded behind every flag-raising submission instead (measured, DESIGN 6a: 5-8 % slower on an idle
+  // blocking event recorded behind every flag-raising submission instead (measured, DESIGN 9: 5-8 % slower on an idle
   // host, no faster on a crowded one -- the HIP runtime's own threads need the core as well -- so it is an opt-in).
   enum { WAIT_EVENTS = 8 };
   hipEvent_t wait_ev_[WAIT_EVENTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -360,9 +360,9 @@ class Group {
   long waits_polite_ = 0;
   void mark_flag_event();        // DPGO_WAIT=block: an event behind the submission that raises the flag to fetch_seq_
   // ---- Whether segments are replayed (iter_graph_wanted), decided by MEASUREMENT: a group starts with eager launches and
-  // keeps an eye on how much of the time it spends inside iterate() / update() is waiting for the GPU.  A host that waits most of the time keeps up
-  // with eager launches, which are the faster way then (a replay costs the GPU ~8 us of start-up); a host that hardly ever
-  // waits is what bounds the group -- a slow or busy box, a small graph whose kernels are shorter than a launch -- and its
+  // keeps an eye on how much of the time it spends inside iterate() / update() is waiting for the GPU.  A host that waits most of the time (more than
+  // 40 % of it) keeps up with eager launches, which are the faster way then (a replay costs the GPU ~8 us of start-up); a
+  // host that waits less is what bounds the group -- a slow or busy box, a small graph whose kernels are shorter than a launch -- and its
   // segments are replayed from then on.  Looked at every 32 iterations; DPGO_ITER_GRAPH=0 / 1 forces either.
   bool host_bound_ = false;
   double win_wait_s_ = 0, win_lib_s_ = 0;   // of the window: seconds waiting for read-backs / seconds inside iterate() and update()
@@ -383,7 +383,9 @@ class Group {
   // bits: the nodes the sequence works on.  Only sequences over ALL the group's nodes are replayed: a partial set is a group
   // whose nodes are taking different branches, where the sets change from one iteration to the next and every new set
   // would be a new capture (measured: city10000 / 8 nodes with every subset captured ran 4 x slower than eagerly)
-  void segment(int id, NodeBits bits, std::initializer_list<unsigned long long> extra, const std::function<void()> &body);
+  // wanted: -1 = by iter_graph_wanted(), 0 / 1 = the caller's own policy (the CG steps: cg_graph_wanted)
+  void segment(int id, NodeBits bits, std::initializer_list<unsigned long long> extra, const std::function<void()> &body,
+               int wanted = -1);
   NodeBits all_bits() const { const int L = num_local(); return L >= 64 ? ~0ull : ((1ull << L) - 1); }
   void graphs_invalidate();   // waits (bounded) for the stream, destroys every captured graph, bumps graph_gen_
   void graphs_destroy();      // (the stream is known to be idle)

@@ -363,7 +363,7 @@ struct ProfSweep {
 void prof_reset();
 void prof_collect(double *ms, double *bytes, long *count);
 // ... and, for the fused passes (k_inter, k_proximal), the bytes of every operand the pass has to move, counted one by one
-// (DESIGN 7): SURVEY 8(d)'s formula prices a bare residual pass, the kernels also carry the surrogate's per-pose blocks
+// (DESIGN 7a): SURVEY 8(d)'s formula prices a bare residual pass, the kernels also carry the surrogate's per-pose blocks
 void prof_collect_operands(double *operand_bytes);
 
 }  // namespace dpgo

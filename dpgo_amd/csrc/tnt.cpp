@@ -62,11 +62,16 @@ struct NodeTnt {
 };
 }  // namespace
 
-// The CG steps of a group go out as one graph replay each wherever the segments of the iteration do (Group::segment,
-// iter_graph_wanted); DPGO_CG_GRAPH=0 keeps just these eager (A/B hook).
+// The CG steps of a group go out as one graph replay each (a step is 13-21 launches with fixed arguments): wherever the
+// segments of the iteration are replayed (Group::segment, iter_graph_wanted), and -- round 4's default, measured +8..13 % on
+// city10000 -- from the start for groups of at least two nodes and at most 40 000 poses, whose steps are bound by the host's
+// launch rate.  DPGO_CG_GRAPH=0 keeps just these eager (A/B hook), DPGO_ITER_GRAPH=0 everything.
 bool Group::cg_graph_wanted() const {
   static const int force = [] { const char *e = getenv("DPGO_CG_GRAPH"); return e ? atoi(e) : -1; }();
-  return force != 0 && iter_graph_wanted();
+  static const int iter_force = [] { const char *e = getenv("DPGO_ITER_GRAPH"); return e ? atoi(e) : -1; }();
+  if (force == 0 || iter_force == 0 || graphs_broken_ || prof_enabled()) return false;
+  if (iter_graph_wanted()) return true;
+  return P0_ <= 40000 && num_local() >= 2;
 }
 
 bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, const double *g_alt, bool base_ready,
@@ -251,7 +256,7 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       mB = NodeMask{all, dmask_.p + 1};
       stepA(false);
       stepB();
-    });
+    }, 1);
     mA = sA; mB = sB;
   };
   const bool use_graph = cg_graph_wanted();

@@ -928,7 +928,7 @@ np.savez(sys.argv[1], X=drv.X(), trace=np.array(trace))
 
 
 def test_engineering_switches_do_not_change_the_results(fixtures_dir, tmp_path):
-    """The switches of DESIGN 6b select HOW something is computed, never WHAT: lagged CG polling (DPGO_CG_LAG=0) is bit
+    """The switches of DESIGN 8 select HOW something is computed, never WHAT: lagged CG polling (DPGO_CG_LAG=0) is bit
     for bit the same run; the host numeric factorisation (DPGO_SPD_HOST_FACTOR=1), panels packed on the host
     (DPGO_SPD_DEVICE_PANELS=0) and the scalar-graph ordering (DPGO_SPD_QUOTIENT=0) are other exact factorisations of the
     same matrices, so the iterates agree to rounding (1e-9 after 25 iterations with refinements)."""
@@ -997,7 +997,7 @@ np.save(sys.argv[1], drv.X())
 
 
 def test_fp32_preconditioner_experiment_reaches_the_same_objective(fixtures_dir, monkeypatch):
-    """DPGO_PRECON_FP32=1 (an opt-in EXPERIMENT, never the default, never the headline: DESIGN 7) stores the panels of the
+    """DPGO_PRECON_FP32=1 (an opt-in EXPERIMENT, never the default, never the headline: DESIGN 9) stores the panels of the
     preconditioner's factor in fp32.  A preconditioner only steers the truncated CG: the surrogate, the acceptance test of
     every refined step and the objective stay fp64, so the run must reach the oracle's objective like the fp64 run does --
     by a different path (the inner iteration counts may differ), which is why this is not the reference's arithmetic."""
