@@ -1139,7 +1139,8 @@ bool Group::iter_graph_wanted() const {
 // cg_graph_wanted.)
 void Group::host_bound_tick() {
   if (host_bound_ || ++win_iters_ < 32) return;
-  if (win_lib_s_ > 0 && win_wait_s_ < 0.40 * win_lib_s_) host_bound_ = true;
+  static const double below = getenv("DPGO_HOST_BOUND_BELOW") ? atof(getenv("DPGO_HOST_BOUND_BELOW")) : 0.40;   // (test hook)
+  if (win_lib_s_ > 0 && win_wait_s_ < below * win_lib_s_) host_bound_ = true;
   win_iters_ = 0;
   win_wait_s_ = 0;
   win_lib_s_ = 0;

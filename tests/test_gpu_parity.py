@@ -392,6 +392,47 @@ print("STATS", drv.group.graph_stats(), steps)
     assert np.array_equal(got, base)
 
 
+def test_long_runs_replayed_or_switching_midway_equal_eager_runs(fixtures_dir, tmp_path):
+    """300 iterations of city10000 / 8 nodes / Huber -- through the early regime, the interior one (several CG steps per
+    refinement, nodes refining and not, rejected steps, restarts) and past convergence -- (i) eagerly, (ii) with every
+    segment replayed from the first iteration (the graph cache fills, evicts and hits its capture cap), (iii) starting
+    eagerly and switching to replays after 32 iterations, as a group does once its host is found to be the slower side
+    (DPGO_HOST_BOUND_BELOW=2: every host counts as slower).  Bit for bit the same trajectory."""
+    import subprocess
+    import sys
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import dpgo_amd
+G = dpgo_amd.read_g2o(%r, 8)
+drv = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(1, True))
+trace = []
+for it in range(300):
+    assert drv.step() == 0
+    trace.append(drv.sum_fobj())
+np.savez(sys.argv[1], X=drv.X(), trace=np.asarray(trace))
+print("STATS", drv.group.graph_stats())
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(fixtures_dir, "city10000.g2o"))
+
+    def run(tag, **env):
+        path = str(tmp_path / (tag + ".npz"))
+        base_env = {k: v for k, v in os.environ.items() if k not in ("DPGO_ITER_GRAPH", "DPGO_HOST_BOUND_BELOW")}
+        out = subprocess.run([sys.executable, "-c", code, path], env=dict(base_env, **env), capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-2000:]
+        stats = eval([l for l in out.stdout.splitlines() if l.startswith("STATS")][-1][6:])
+        return np.load(path), stats
+
+    eager, st = run("eager", DPGO_ITER_GRAPH="0")
+    assert st["replays"] == 0
+    for tag, env in (("replayed", dict(DPGO_ITER_GRAPH="1")), ("switching", dict(DPGO_HOST_BOUND_BELOW="2"))):
+        got, st = run(tag, **env)
+        assert st["replays"] > 300 and st["captures"] >= 4, (tag, st)
+        assert np.array_equal(got["trace"], eager["trace"]), tag
+        assert np.array_equal(got["X"], eager["X"]), tag
+        if tag == "switching":
+            assert st["eager"] >= 32, st            # (the first 32 iterations ran their segments eagerly)
+
+
 def test_dist_pgo_cli_matches_oracle(fixtures_dir, tmp_path):
     """The C++ driver (reference flags / stdout / result files, dist_pgo.cpp:23-47, 493-568)."""
     import subprocess
