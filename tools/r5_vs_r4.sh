@@ -1,5 +1,7 @@
 # same-box, interleaved: the round-4 tree (.ab/r4tree, its own library and python package) against the current one on the
-# parity configurations (the 40 / 60 / 200-iteration windows of tests/config_rates.py) and on the emulated rank
+# parity configurations (the 40 / 60 / 200-iteration windows of tests/config_rates.py) and on the emulated rank.
+# Before sending the repo to the GPU box:  git worktree add .ab/r4tree 93284b7 && make -C .ab/r4tree/dpgo_amd/csrc -j8
+# (and let its tests/config_rates.py skip the oracle when NO_ORACLE is set); afterwards: git worktree remove --force .ab/r4tree
 tag=${1:-r5/vs_r4}; mkdir -p gpurun_out/$tag
 for rep in 1 2 3 4; do
   echo "== rep $rep: round 4"
