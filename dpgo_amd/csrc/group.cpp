@@ -1249,11 +1249,12 @@ void Group::segment(int id, NodeBits bits, std::initializer_list<unsigned long l
       size_t old = 0;
       for (size_t i = 1; i < seg_graphs_.size(); i++)
         if (seg_graphs_[i].used < seg_graphs_[old].used) old = i;
-      // (the least recently used one was replayed many waits ago; still: never destroy a graph that may be executing)
-      if (drain(60.0)) (void)hipGraphExecDestroy(seg_graphs_[old].exec);
+      // (never destroy a graph that may be executing: the least recently used one was replayed many read-backs ago -- the
+      // flag says so -- and only if it does not is the stream waited for)
+      if (__atomic_load_n(h_flag_, __ATOMIC_ACQUIRE) >= seg_graphs_[old].done_seq || drain(60.0)) (void)hipGraphExecDestroy(seg_graphs_[old].exec);
       seg_graphs_.erase(seg_graphs_.begin() + old);
     }
-    seg_graphs_.push_back(SegGraph{key, exec, captured_flags_, 0});
+    seg_graphs_.push_back(SegGraph{key, exec, captured_flags_, 0, 0});
     hit = &seg_graphs_.back();
     seg_captures_++;
   }
@@ -1265,6 +1266,7 @@ void Group::segment(int id, NodeBits bits, std::initializer_list<unsigned long l
   } else
   HIP_CHECK(hipGraphLaunch(hit->exec, st_));
   fetch_seq_ += hit->flags;   // the flag-raising kernels of the replay count on from the device's own word
+  hit->done_seq = fetch_seq_ + 1;   // (a flag raised BEHIND the replay says it is over: its own flag need not be its last kernel)
   seg_replays_++;
   if (hit->flags) mark_flag_event();
 }

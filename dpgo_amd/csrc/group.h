@@ -332,7 +332,8 @@ class Group {
   // runs such a sequence eagerly, or -- when the host's launch rate is what bounds the group (iter_graph_wanted) -- captures
   // it once per key (the buffers it touches, which rotate; the node set; the variant) and replays it with ONE submission.
   // Rare branches (a rejected step, a restart, a fallback, a Dynamic rescale) stay eager.  Bitwise the same results.
-  struct SegGraph { std::vector<unsigned long long> key; hipGraphExec_t exec = nullptr; int flags = 0; unsigned long long used = 0; };
+  // done_seq: once the read-back flag has reached it, the graph's last replay is over (it may be destroyed)
+  struct SegGraph { std::vector<unsigned long long> key; hipGraphExec_t exec = nullptr; int flags = 0; unsigned long long used = 0, done_seq = 0; };
   std::vector<SegGraph> seg_graphs_;
   unsigned long long seg_clock_ = 0, graph_gen_ = 0;   // graph_gen_: bumped by whatever invalidates captured arguments
   bool capturing_ = false, graphs_broken_ = false;
