@@ -967,8 +967,15 @@ int Group::refactor_tt() {
   if (Ltt_.F.n == Att.n && Ltt_.F.nfronts > 0 && !Ltt_.F.children.empty()) {
     // same pattern, new values (a Dynamic rescale): numeric phase only, on the GPU
     if (spd_refactor(Att, Ltt_.F) != 0) return -1;
-  } else if (spd_factor(Att, Ltt_.F, env_int("DPGO_SPD_LEAF_TT", 128), env_int("DPGO_SPD_COLLAPSE_TT", 0), 1,
-                        env_int("DPGO_SPD_DEVICE_PANELS", 1) != 0) != 0) return -1;
+  } else {
+    // A factor that is re-done in every iteration (Dynamic) is ordered for the refactorisation, not for the three solves
+    // it serves: small leaves and NO merged levels keep the fronts at the top of the trees narrow, and the chain of
+    // dependent block columns there -- 33 at the merged roots of the headline, two launches each -- is what a
+    // refactorisation costs (5.29 -> 4.17 ms per iteration at the headline size; the cost model of
+    // spd_factor knows solves only).
+    const int leaf = env_int("DPGO_SPD_LEAF_TT", keep ? 64 : 128), collapse = env_int("DPGO_SPD_COLLAPSE_TT", keep ? 1 : 0);
+    if (spd_factor(Att, Ltt_.F, leaf, collapse, 1, env_int("DPGO_SPD_DEVICE_PANELS", 1) != 0) != 0) return -1;
+  }
   clk.lap("G_tt: ordering + symbolic + numeric factor");
   warn_conditioning("G_tt", Ltt_.F);
   Ltt_.dof = 1;

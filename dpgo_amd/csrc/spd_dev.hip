@@ -87,6 +87,41 @@ __global__ __launch_bounds__(256) void k_fa_extend(const FrontDesc *fd, const Ex
   }
 }
 
+// The same sums gathered by the PARENT's rows, every child of a level in ONE launch: a wave per parent row r walks the
+// parent's children in slot order and, from each child that has a row a with cmap[a] == r (inv: the inverse map, -1
+// where there is none), adds that row to its own.  Needs cmap to ascend with a (then row a's entries b <= a land in the
+// columns cmap[b] <= r of row r and nowhere else: one writer per entry, the children in the order of the per-slot
+// launches, so the bits are theirs); a tree where it does not keeps the per-slot launches.
+struct ExtendRow {
+  long long ubase;            // the child's Schur complement: Fm + ubase + a * cm
+  int cm, cmap_off, inv_off, pad;
+};
+__global__ __launch_bounds__(256) void k_fa_extend_rows(const FrontDesc *fd, const int *lvl, const int *row_ptr, const ExtendRow *rows,
+                                                        const int *cmap, const int *inv, double *Fm) {
+  const int fi = lvl[blockIdx.y];
+  const FrontDesc p = fd[fi];
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= p.m) return;
+  double *Prow = Fm + p.fm_off + (long long)r * p.m;
+  const int q0 = row_ptr[fi], q1 = row_ptr[fi + 1];
+  for (int qb = q0; qb < q1; qb += 4) {
+    // (the records and the inverse maps of up to four children are requested together: one memory latency, not four)
+    ExtendRow er[4];
+    int a[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      er[j] = rows[min(qb + j, q1 - 1)];
+      a[j] = qb + j < q1 ? inv[er[j].inv_off + r] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (a[j] < 0) continue;
+      const double *urow = Fm + er[j].ubase + (long long)a[j] * er[j].cm;
+      for (int b = lane; b <= a[j]; b += 64) Prow[cmap[er[j].cmap_off + b]] += urow[b];
+    }
+  }
+}
+
 // a double from lane `src` (uniform) to every lane
 __device__ __forceinline__ double bcast(double v, int src) {
   const long long b = __double_as_longlong(v);
@@ -500,10 +535,12 @@ __global__ __launch_bounds__(320) void k_fa_panel_ll(const FrontDesc *fd, const 
 //  last pivots.  Wide pass (wide = 1): K = the whole super-block [k_lo, k_hi = sb_end), columns right of it; only
 //  for fronts with pivots beyond the super-block.  The wide pass is what keeps the read-modify-write of the
 //  trailing matrix from bounding the kernel (K = 128 instead of 32).
+//  MODE 1 runs once, behind the last level, for every front at once (nobody reads W on the way up the tree: the parents
+//  take the Schur complements out of the fronts themselves): lvl = (front, tile) pairs, one per workgroup.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_fa_abt(const FrontDesc *fd, const int *lvl, int k_lo, int k_hi, int sb_end, int wide,
                                                 double *Fm, double *Wout, double *WTout) {
-  const FrontDesc f = fd[lvl[blockIdx.y]];
+  const FrontDesc f = fd[MODE == 1 ? lvl[2 * blockIdx.x] : lvl[blockIdx.y]];
   int r0, c0, nrt, nct, kbeg, kend, cend = 0;
   if (MODE == 0) {
     if (f.w <= k_lo) return;
@@ -523,7 +560,7 @@ __global__ __launch_bounds__(256) void k_fa_abt(const FrontDesc *fd, const int *
     nct = (f.w + TS - 1) / TS;
     kbeg = 0; kend = f.w;
   }
-  const int tile = blockIdx.x;
+  const int tile = MODE == 1 ? lvl[2 * blockIdx.x + 1] : (int)blockIdx.x;
   if (tile >= nrt * nct) return;
   const int ti = tile / nct, tj = tile % nct;
   const int i0 = r0 + ti * TS, j0 = c0 + tj * TS;          // first row of the A tile / of the B tile (rows of F)
@@ -594,16 +631,20 @@ __global__ __launch_bounds__(256) void k_fa_abt(const FrontDesc *fd, const int *
       }
 }
 
-// top of W: L11^-1 = (identity rows)^T; and its transpose into WT
-__global__ __launch_bounds__(256) void k_fa_wtop(const FrontDesc *fd, const int *lvl, const double *Fm, double *Wout, double *WTout) {
-  const FrontDesc f = fd[lvl[blockIdx.y]];
-  const int k = blockIdx.x;          // identity row k holds L11^-T[k, :] = column k of L11^-1
-  if (k >= f.w) return;
-  const double *row = Fm + f.fm_off + (long long)(f.m + k) * f.m;
-  for (int p = threadIdx.x; p < f.w; p += 256) {
-    const double v = p >= k ? row[p] : 0.0;
-    WTout[f.wt_off + (long long)k * f.ldm + p] = v;             // WT[k][p] = W[p][k]
-    if (p >= k) Wout[f.w_off + (long long)p * f.ldw + k] = v;   // W[p][k], lower triangle
+// top of W: L11^-1 = (identity rows)^T; and its transpose into WT.  Once for every front, behind the last level (as
+// MODE 1 of k_fa_abt): items = (front, first row) pairs, WTOP_ROWS identity rows per workgroup, a wave per row.
+constexpr int WTOP_ROWS = 8;
+__global__ __launch_bounds__(256) void k_fa_wtop(const FrontDesc *fd, const int *items, const double *Fm, double *Wout, double *WTout) {
+  const FrontDesc f = fd[items[2 * blockIdx.x]];
+  const int k0 = items[2 * blockIdx.x + 1], wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int kend = min(k0 + WTOP_ROWS, f.w);
+  for (int k = k0 + wv; k < kend; k += 4) {   // identity row k holds L11^-T[k, :] = column k of L11^-1
+    const double *row = Fm + f.fm_off + (long long)(f.m + k) * f.m;
+    for (int p = lane; p < f.w; p += 64) {
+      const double v = p >= k ? row[p] : 0.0;
+      WTout[f.wt_off + (long long)k * f.ldm + p] = v;             // WT[k][p] = W[p][k]
+      if (p >= k) Wout[f.w_off + (long long)p * f.ldw + k] = v;   // W[p][k], lower triangle
+    }
   }
 }
 }  // namespace
@@ -628,11 +669,16 @@ struct SpdNumericCtx {
   int *d_src = nullptr, *d_cmap = nullptr, *d_lvl = nullptr, *d_fail = nullptr;
   double *d_aval = nullptr, *d_Fm = nullptr, *d_dinv = nullptr, *d_W = nullptr, *d_WT = nullptr;
   ExtendPair *d_pairs = nullptr;
+  int *d_wtop_items = nullptr, *d_wbot_items = nullptr;   // (front, first row) / (front, tile): the outputs, all fronts at once
+  ExtendRow *d_xrows = nullptr;                           // k_fa_extend_rows: a parent's children in slot order, ...
+  int *d_xrow_ptr = nullptr, *d_inv = nullptr;            // ... where they start per front, the inverse maps
+  bool extend_by_rows = false;
+  int n_wtop_items = 0, n_wbot_items = 0, max_ent = 0;
   hipStream_t st = nullptr;
   bool outputs_zeroed = false;
   ~SpdNumericCtx() {
     for (void *q : {(void *)d_fd, (void *)d_dst, (void *)d_src, (void *)d_cmap, (void *)d_lvl, (void *)d_fail, (void *)d_aval,
-                    (void *)d_Fm, (void *)d_dinv, (void *)d_W, (void *)d_WT, (void *)d_pairs})
+                    (void *)d_Fm, (void *)d_dinv, (void *)d_W, (void *)d_WT, (void *)d_pairs, (void *)d_wtop_items, (void *)d_wbot_items, (void *)d_xrows, (void *)d_xrow_ptr, (void *)d_inv})
       if (q) (void)hipFree(q);
     if (st) (void)hipStreamDestroy(st);
     if (h_io) (void)hipHostFree(h_io);
@@ -728,7 +774,48 @@ int SpdNumericCtx::build(const CsrMatrix &A, const SpdFactor &F, const std::vect
       pair_maxu[h].push_back(mu);
     }
   }
+  // the children of a front in slot order with the inverse of their maps (k_fa_extend_rows), if every map ascends
+  std::vector<ExtendRow> xrows;
+  std::vector<int> xrow_ptr(nt + 1, 0), inv;
+  extend_by_rows = getenv("DPGO_SPD_EXTEND_SLOTS") == nullptr;
+  for (int f = 0; f < nt && extend_by_rows; f++) {
+    xrow_ptr[f] = (int)xrows.size();
+    for (int c : children[f]) {
+      if (F.u[c] == 0) continue;
+      if (inv.size() + (size_t)fd[f].m > (size_t)0x7fffffff) { extend_by_rows = false; break; }
+      const int off = (int)inv.size();
+      inv.resize(inv.size() + fd[f].m, -1);
+      for (int a = 0; a < F.u[c]; a++) {
+        const int la = cmap[cmap_off[c] + a];
+        if (la < 0 || la >= fd[f].m || (a > 0 && la <= cmap[cmap_off[c] + a - 1])) { extend_by_rows = false; break; }
+        inv[off + la] = a;
+      }
+      xrows.push_back({fd[c].fm_off + (long long)fd[c].w * fd[c].m + fd[c].w, fd[c].m, cmap_off[c], off, 0});
+    }
+  }
+  xrow_ptr[nt] = (int)xrows.size();
+  // the outputs are written once, behind the last level: a row list for the tops of W, a tile list for the bottoms
+  std::vector<int> wtop_items, wbot_items;
+  max_ent = 0;
+  for (int f : lvl_flat) {
+    const FrontDesc &d = fd[f];
+    max_ent = std::max(max_ent, d.ent_end - d.ent_ptr);
+    for (int k0 = 0; k0 < d.w; k0 += WTOP_ROWS) { wtop_items.push_back(f); wtop_items.push_back(k0); }
+    if (d.u > 0) {
+      const int tiles = ((d.u + TS - 1) / TS) * ((d.w + TS - 1) / TS);
+      for (int t = 0; t < tiles; t++) { wbot_items.push_back(f); wbot_items.push_back(t); }
+    }
+  }
+  n_wtop_items = (int)wtop_items.size() / 2;
+  n_wbot_items = (int)wbot_items.size() / 2;
   n_aval = A.val.size();
+  if (extend_by_rows) {
+    FA_OK(hipMalloc((void **)&d_xrows, sizeof(ExtendRow) * std::max<size_t>(xrows.size(), 1)));
+    FA_OK(hipMalloc((void **)&d_xrow_ptr, sizeof(int) * xrow_ptr.size()));
+    FA_OK(hipMalloc((void **)&d_inv, sizeof(int) * std::max<size_t>(inv.size(), 1)));
+  }
+  FA_OK(hipMalloc((void **)&d_wtop_items, sizeof(int) * std::max<size_t>(wtop_items.size(), 2)));
+  FA_OK(hipMalloc((void **)&d_wbot_items, sizeof(int) * std::max<size_t>(wbot_items.size(), 2)));
   FA_OK(hipMalloc((void **)&d_fd, sizeof(FrontDesc) * std::max(nt, 1)));
   FA_OK(hipMalloc((void **)&d_dst, sizeof(long long) * std::max<size_t>(dst.size(), 1)));
   FA_OK(hipMalloc((void **)&d_src, sizeof(int) * std::max<size_t>(src.size(), 1)));
@@ -748,6 +835,13 @@ int SpdNumericCtx::build(const CsrMatrix &A, const SpdFactor &F, const std::vect
   FA_OK(hipMemcpyAsync(d_cmap, cmap.data(), sizeof(int) * cmap.size(), hipMemcpyHostToDevice, st));
   FA_OK(hipMemcpyAsync(d_lvl, lvl_flat.data(), sizeof(int) * lvl_flat.size(), hipMemcpyHostToDevice, st));
   if (!pairs.empty()) FA_OK(hipMemcpyAsync(d_pairs, pairs.data(), sizeof(ExtendPair) * pairs.size(), hipMemcpyHostToDevice, st));
+  if (extend_by_rows) {
+    if (!xrows.empty()) FA_OK(hipMemcpyAsync(d_xrows, xrows.data(), sizeof(ExtendRow) * xrows.size(), hipMemcpyHostToDevice, st));
+    FA_OK(hipMemcpyAsync(d_xrow_ptr, xrow_ptr.data(), sizeof(int) * xrow_ptr.size(), hipMemcpyHostToDevice, st));
+    if (!inv.empty()) FA_OK(hipMemcpyAsync(d_inv, inv.data(), sizeof(int) * inv.size(), hipMemcpyHostToDevice, st));
+  }
+  if (!wtop_items.empty()) FA_OK(hipMemcpyAsync(d_wtop_items, wtop_items.data(), sizeof(int) * wtop_items.size(), hipMemcpyHostToDevice, st));
+  if (!wbot_items.empty()) FA_OK(hipMemcpyAsync(d_wbot_items, wbot_items.data(), sizeof(int) * wbot_items.size(), hipMemcpyHostToDevice, st));
   FA_OK(hipStreamSynchronize(st));   // (the host vectors go out of scope)
   return 0;
 }
@@ -782,22 +876,27 @@ int SpdNumericCtx::factor(SpdFactor &F, const double *aval_host, double *flops_o
   double flops = 0, mfma_ms = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
   {
+  // the entries of A and the ones of the identity rows, every front of every level at once (the children's Schur
+  // complements are ADDED later, level by level)
+  if (lvl_ptr.back() > 0 && max_ent > 0)
+    hipLaunchKernelGGL(k_fa_scatter, dim3((max_ent + 255) / 256, lvl_ptr.back()), dim3(256), 0, st, d_fd, d_lvl, d_dst, d_src, d_aval, d_Fm);
   for (int h = 0; h <= maxh; h++) {
     const int nf = (int)lvl[h].size();
     if (nf == 0) continue;
     const int *L = d_lvl + lvl_ptr[h];
-    int max_ent = 0, max_w = 0, max_m = 0, max_u = 0;
+    int max_w = 0, max_m = 0;
     for (int f : lvl[h]) {
-      max_ent = std::max(max_ent, fd[f].ent_end - fd[f].ent_ptr);
       max_w = std::max(max_w, fd[f].w);
       max_m = std::max(max_m, fd[f].m);
-      max_u = std::max(max_u, fd[f].u);
     }
-    hipLaunchKernelGGL(k_fa_scatter, dim3((max_ent + 255) / 256, nf), dim3(256), 0, st, d_fd, L, d_dst, d_src, d_aval, d_Fm);
-    for (size_t s = 0; s < pair_rng[h].size(); s++)
-      if (pair_rng[h][s].second > 0)
-        hipLaunchKernelGGL(k_fa_extend, dim3(pair_maxu[h][s], pair_rng[h][s].second), dim3(256), 0, st, d_fd,
-                           d_pairs + pair_rng[h][s].first, d_cmap, d_Fm);
+    if (extend_by_rows) {
+      if (h > 0) hipLaunchKernelGGL(k_fa_extend_rows, dim3((max_m + 3) / 4, nf), dim3(256), 0, st, d_fd, L, d_xrow_ptr, d_xrows, d_cmap, d_inv, d_Fm);
+    } else {
+      for (size_t s = 0; s < pair_rng[h].size(); s++)
+        if (pair_rng[h][s].second > 0)
+          hipLaunchKernelGGL(k_fa_extend, dim3(pair_maxu[h][s], pair_rng[h][s].second), dim3(256), 0, st, d_fd,
+                             d_pairs + pair_rng[h][s].first, d_cmap, d_Fm);
+    }
     auto abt0 = [&](int k_lo, int k_hi, int sb_end, int wide) -> int {
       // upper bounds over the fronts of the level (a front's block column may end before k_hi: columns from k_lo + 1 on)
       const int nrt = (max_m + TS - 1) / TS, nct = (max_m - k_lo + TS - 1) / TS;
@@ -865,19 +964,19 @@ int SpdNumericCtx::factor(SpdFactor &F, const double *aval_host, double *flops_o
         }
       }
     }
-    hipLaunchKernelGGL(k_fa_wtop, dim3(std::max(max_w, 1), nf), dim3(256), 0, st, d_fd, L, d_Fm, d_W, d_WT);
-    if (max_u > 0) {
-      const int nrt = (max_u + TS - 1) / TS, nct = (max_w + TS - 1) / TS;
-      if (mfma_ms_out) {
-        hipEvent_t a, b;
-        FA_OK(hipEventCreate(&a)); FA_OK(hipEventCreate(&b));
-        FA_OK(hipEventRecord(a, st));
-        hipLaunchKernelGGL((k_fa_abt<1>), dim3(nrt * nct, nf), dim3(256), 0, st, d_fd, L, 0, 0, 0, 0, d_Fm, d_W, d_WT);
-        FA_OK(hipEventRecord(b, st));
-        evs.push_back({a, b});
-      } else {
-        hipLaunchKernelGGL((k_fa_abt<1>), dim3(nrt * nct, nf), dim3(256), 0, st, d_fd, L, 0, 0, 0, 0, d_Fm, d_W, d_WT);
-      }
+  }
+  // the outputs: W = [L11^-1 ; -L21 L11^-1] and its transpose, of every front at once
+  if (n_wtop_items > 0) hipLaunchKernelGGL(k_fa_wtop, dim3(n_wtop_items), dim3(256), 0, st, d_fd, d_wtop_items, d_Fm, d_W, d_WT);
+  if (n_wbot_items > 0) {
+    hipEvent_t a = nullptr, b = nullptr;
+    if (mfma_ms_out) {
+      FA_OK(hipEventCreate(&a)); FA_OK(hipEventCreate(&b));
+      FA_OK(hipEventRecord(a, st));
+    }
+    hipLaunchKernelGGL((k_fa_abt<1>), dim3(n_wbot_items), dim3(256), 0, st, d_fd, d_wbot_items, 0, 0, 0, 0, d_Fm, d_W, d_WT);
+    if (mfma_ms_out) {
+      FA_OK(hipEventRecord(b, st));
+      evs.push_back({a, b});
     }
   }
   }

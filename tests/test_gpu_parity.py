@@ -1009,6 +1009,9 @@ np.save(sys.argv[1], drv.X())
     # ... own-segment launches that cover only the few nodes still in the CG (their segments dealt to all XCDs) against
     # whole-group grids
     assert np.array_equal(run("whole_grids", DPGO_LIVE_GRIDS="0"), base)
+    # ... the factorisation's assembly with a launch per child slot against all children of a level gathered by the
+    # parents' rows in one launch: the same additions in the same order
+    assert np.array_equal(run("extend_by_slots", DPGO_SPD_EXTEND_SLOTS="1"), base)
     for tag, env in (("hostfactor", dict(DPGO_SPD_HOST_FACTOR="1")), ("hostpanels", dict(DPGO_SPD_DEVICE_PANELS="0")),
                      ("scalarorder", dict(DPGO_SPD_QUOTIENT="0")),
                      # round 3: the refinement started by the host, the tree roots in two sweeps, G Y by a pass over the operator

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Iterations / s of ONE parity configuration under the current environment (for same-box A/B of switches).
-Usage: python tools/probes/config_one.py <dataset> <nodes> <loss 0|1> <iters>"""
+Usage: [RESCALE=1] python tools/probes/config_one.py <dataset> <nodes> <loss 0|1> <iters>   (RESCALE=1: Rescale::Dynamic)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -11,7 +11,7 @@ ds, nn, loss, iters = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.a
 path = os.path.join(ROOT, "fixtures", "g2o", ds + ".g2o")
 num_poses, mm = og.read_g2o_file(path)
 X0 = chordal_initialization(num_poses, mm)
-gpu = dpgo_amd.DistPGO(dpgo_amd.read_g2o(path, nn), dpgo_amd.Options.driver(loss, True), X0=X0)
+gpu = dpgo_amd.DistPGO(dpgo_amd.read_g2o(path, nn), dpgo_amd.Options.driver(loss, True, rescale=int(os.environ.get("RESCALE", "0"))), X0=X0)
 for _ in range(3):
     gpu.step()
 gpu.group.sync()

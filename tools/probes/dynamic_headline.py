@@ -9,7 +9,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 g = synthetic.grid(*dims, seed=synthetic.HEADLINE["seed"])
 G = dpgo_amd.graph_from_edges(3, g["num_poses"], g["I"], g["J"], g["R"], g["t"], g["kappa"], g["tau"], 8)
 X0 = G.chordal_initialization()
-for rescale in (0, 1):
+for rescale in ((1,) if os.environ.get("DYN_ONLY") else (0, 1)):
     opt = dpgo_amd.Options.driver(1, True, rescale=rescale)
     grp = dpgo_amd.NodeGroup(G, list(range(8)), opt)
     grp.initialize_global(X0)
