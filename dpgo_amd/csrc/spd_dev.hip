@@ -354,6 +354,11 @@ __global__ __launch_bounds__(FUSED ? 320 : 256) void k_fa_potrf_panel(const Fron
 //   rows of a workgroup: 128 (four waves x 32), of [ke, m + ke): the regular rows below the block and the identity rows.
 //   Bs: rows kb.. of the panels [sb, kb) (32 x K, K <= 96); Dg: the diagonal block, then its inverse; T / U: a wave's
 //   32 x 32 tile of the strip / of a panel.
+// LDS: 76 KB, and 51 KB for the first block column of a super-block (FIRST: no earlier panels, no Bs) -- two and three
+// workgroups per CU; a level of 600 - 1 200 workgroups ran in 2.4 - 4.9 rounds of one workgroup per CU with the 110 KB of a
+// strip tile and a panel tile of their own per wave (the panel chunks now pass through the strip's tile, which waits in
+// registers until the last of them is done).
+template <bool FIRST>
 __global__ __launch_bounds__(320) void k_fa_panel_ll(const FrontDesc *fd, const int *lvl, int sb, int kb, double *Fm, int *fail,
                                                      unsigned long long *pivr) {
   // five waves: four take 32 rows each, the fifth the diagonal block -- its 11 us run beside the rows' loads and updates,
@@ -363,11 +368,10 @@ __global__ __launch_bounds__(320) void k_fa_panel_ll(const FrontDesc *fd, const 
   const int nb = min(NB, f.w - kb), ke = kb + nb, K = kb - sb;
   const int nrows = f.m;   // rows [ke, m + ke)
   if ((int)blockIdx.x * 128 >= nrows) return;
-  __shared__ double Bs[NB][SB - NB + 1];
+  __shared__ double Bs[FIRST ? 1 : NB][FIRST ? 1 : SB - NB + 1];
   __shared__ double Dg[NB][LDT];
   __shared__ double Ls[NB][NB + 2];
   __shared__ double T[4][NB][NB + 1];
-  __shared__ double U[4][NB][NB + 1];
   __shared__ int bad;
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
   double *F = Fm + f.fm_off;
@@ -407,8 +411,10 @@ __global__ __launch_bounds__(320) void k_fa_panel_ll(const FrontDesc *fd, const 
         const int q = q0 + 2 * p + rr0;
         ua[ch][p] = (rows_on && ch * NB < K && q < nrows) ? F[(long long)(ke + q) * f.m + sb + ch * NB + c] : 0.0;
       }
+    if (!FIRST) {
 #pragma unroll
-    for (int j = 0; j < (SB - NB) / 8; j++) Bs[r][j * 8 + l8] = bq[j];
+      for (int j = 0; j < (SB - NB) / 8; j++) Bs[r][j * 8 + l8] = bq[j];
+    }
 #pragma unroll
     for (int j = 0; j < NB / 8; j++) Dg[r][j * 8 + l8] = dq[j];
   }
@@ -419,7 +425,7 @@ __global__ __launch_bounds__(320) void k_fa_panel_ll(const FrontDesc *fd, const 
 #pragma unroll
     for (int b = 0; b < 2; b++) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
   if (wv == 4) {
-    if (K > 0) {   // the diagonal block's share of the updates: Dg -= Bs Bs^T
+    if (!FIRST && K > 0) {   // the diagonal block's share of the updates: Dg -= Bs Bs^T
       for (int kk = 0; kk < K; kk += 4) {
         double av[2];
 #pragma unroll
@@ -455,11 +461,9 @@ __global__ __launch_bounds__(320) void k_fa_panel_ll(const FrontDesc *fd, const 
     }
   } else if (rows_on) {
     double (*Tw)[NB + 1] = T[wv];
-    double (*Uw)[NB + 1] = U[wv];
+    double (*Uw)[NB + 1] = T[wv];   // (the panel chunks go through the same tile: the strip's own waits in tq)
 #pragma unroll
-    for (int p = 0; p < 16; p++) Tw[2 * p + rr0][c] = tq[p];
-#pragma unroll
-    for (int ch = 0; ch < (SB - NB) / NB; ch++) {
+    for (int ch = 0; ch < (FIRST ? 0 : (SB - NB) / NB); ch++) {
       const int kc = ch * NB;
       if (kc >= K) break;
 #pragma unroll
@@ -479,8 +483,10 @@ __global__ __launch_bounds__(320) void k_fa_panel_ll(const FrontDesc *fd, const 
       }
       WAVE_SYNC();
     }
+#pragma unroll
+    for (int p = 0; p < 16; p++) Tw[2 * p + rr0][c] = tq[p];
     WAVE_SYNC();
-    if (K > 0) {
+    if (!FIRST && K > 0) {
 #pragma unroll
       for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -538,7 +544,7 @@ __global__ __launch_bounds__(320) void k_fa_panel_ll(const FrontDesc *fd, const 
 //  MODE 1 runs once, behind the last level, for every front at once (nobody reads W on the way up the tree: the parents
 //  take the Schur complements out of the fronts themselves): lvl = (front, tile) pairs, one per workgroup.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_fa_abt(const FrontDesc *fd, const int *lvl, int k_lo, int k_hi, int sb_end, int wide,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_fa_abt(const FrontDesc *fd, const int *lvl, int k_lo, int k_hi, int sb_end, int wide,
                                                 double *Fm, double *Wout, double *WTout) {
   const FrontDesc f = fd[MODE == 1 ? lvl[2 * blockIdx.x] : lvl[blockIdx.y]];
   int r0, c0, nrt, nct, kbeg, kend, cend = 0;
@@ -584,17 +590,45 @@ __global__ __launch_bounds__(256) void k_fa_abt(const FrontDesc *fd, const int *
   for (int a = 0; a < 2; a++)
 #pragma unroll
     for (int b = 0; b < 2; b++) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
-  for (int k0 = kbeg; k0 < kend; k0 += NB) {
+  // MODE 0: the entries this lane subtracts from are requested first of all (their latency passes behind the products
+  // instead of in front of the stores)
+  double cpre[2][2][4];
+  if (MODE == 0) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int ii = i0 + wr + a * 16 + (lane >> 4) + 4 * r, jj = j0 + wc + b * 16 + (lane & 15);
+          const bool on = (ii < f.m) ? (jj <= ii) : (ii < ilim && jj < f.w);
+          cpre[a][b][r] = (on && jj < cend) ? F[(long long)ii * f.m + jj] : 0.0;
+        }
+  }
+  // 64 rows x 32 columns of each operand per step, coalesced along the row; the next step's are in flight (registers)
+  // while this step's products run
+  double pa[TS * NB / 256], pb[TS * NB / 256];
+  auto fetch = [&](int k0) {
     const int kn = min(NB, kend - k0);
-    __syncthreads();
-    // 64 rows x 32 columns of each operand, coalesced along the row
-    for (int idx = t; idx < TS * NB; idx += 256) {
-      const int r = idx / NB, k = idx % NB;
+#pragma unroll
+    for (int j = 0; j < TS * NB / 256; j++) {
+      const int idx = t + 256 * j, r = idx / NB, k = idx % NB;
       const int ia = i0 + r, ib = j0 + r;
-      As[r][k] = (ia < ilim && k < kn) ? F[(long long)ia * f.m + k0 + k] : 0.0;
-      Bs[r][k] = (ib < jlim && k < kn) ? F[(long long)ib * f.m + k0 + k] : 0.0;
+      pa[j] = (ia < ilim && k < kn) ? F[(long long)ia * f.m + k0 + k] : 0.0;
+      pb[j] = (ib < jlim && k < kn) ? F[(long long)ib * f.m + k0 + k] : 0.0;
+    }
+  };
+  fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += NB) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TS * NB / 256; j++) {
+      const int idx = t + 256 * j;
+      As[idx / NB][idx % NB] = pa[j];
+      Bs[idx / NB][idx % NB] = pb[j];
     }
     __syncthreads();
+    if (k0 + NB < kend) fetch(k0 + NB);
 #pragma unroll
     for (int kk = 0; kk < NB; kk += 4) {
       const int kq = kk + (lane >> 4), rr = lane & 15;
@@ -620,7 +654,7 @@ __global__ __launch_bounds__(256) void k_fa_abt(const FrontDesc *fd, const int *
         const double v = acc[a][b][r];
         if (MODE == 0) {
           const bool on = (ii < f.m) ? (jj <= ii) : (ii < ilim && jj < f.w);
-          if (on && jj < cend) Fm[f.fm_off + (long long)ii * f.m + jj] -= v;
+          if (on && jj < cend) Fm[f.fm_off + (long long)ii * f.m + jj] = cpre[a][b][r] - v;
         } else {
           const int arow = ii - f.w, jcol = jj - f.m;
           if (ii < f.m && jcol < f.w) {
@@ -931,8 +965,12 @@ int SpdNumericCtx::factor(SpdFactor &F, const double *aval_host, double *flops_o
         if (left_looking) {
           // few workgroups in the level: the block column takes the super-block's pending updates itself (no k_fa_abt
           // per block column); the rest of the front gets them in the wide pass below
-          hipLaunchKernelGGL(k_fa_panel_ll, dim3((max_m + 127) / 128, nf), dim3(320), 0, st, d_fd, L, sb, kb, d_Fm, d_fail,
-                             reinterpret_cast<unsigned long long *>(d_fail) + 1);
+          if (kb == sb)
+            hipLaunchKernelGGL(k_fa_panel_ll<true>, dim3((max_m + 127) / 128, nf), dim3(320), 0, st, d_fd, L, sb, kb, d_Fm, d_fail,
+                               reinterpret_cast<unsigned long long *>(d_fail) + 1);
+          else
+            hipLaunchKernelGGL(k_fa_panel_ll<false>, dim3((max_m + 127) / 128, nf), dim3(320), 0, st, d_fd, L, sb, kb, d_Fm, d_fail,
+                               reinterpret_cast<unsigned long long *>(d_fail) + 1);
           continue;
         }
         if ((long long)bx * nf <= fuse_limit) {
