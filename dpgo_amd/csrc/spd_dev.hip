@@ -835,7 +835,14 @@ int SpdNumericCtx::build(const CsrMatrix &A, const SpdFactor &F, const std::vect
     const FrontDesc &d = fd[f];
     max_ent = std::max(max_ent, d.ent_end - d.ent_ptr);
     for (int k0 = 0; k0 < d.w; k0 += WTOP_ROWS) { wtop_items.push_back(f); wtop_items.push_back(k0); }
-    if (d.u > 0) {
+  }
+  {
+    // (the tiles with the longest sums first: a merged root's K is its 1 000 - 2 000 pivots, a leaf's 64 - 128)
+    std::vector<int> by_w(lvl_flat);
+    std::stable_sort(by_w.begin(), by_w.end(), [&](int a, int b) { return fd[a].w > fd[b].w; });
+    for (int f : by_w) {
+      const FrontDesc &d = fd[f];
+      if (d.u == 0) continue;
       const int tiles = ((d.u + TS - 1) / TS) * ((d.w + TS - 1) / TS);
       for (int t = 0; t < tiles; t++) { wbot_items.push_back(f); wbot_items.push_back(t); }
     }
