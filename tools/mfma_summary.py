@@ -28,7 +28,14 @@ for k, c in agg.items():
     e["launches"] = calls[k]
     busy, cu = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), c.get("SQ_BUSY_CU_CYCLES", 0.0)
     if cu > 0:
-        e["mfma_busy_over_cu_busy"] = busy / cu
+        # SQ_VALU_MFMA_BUSY_CYCLES sums the matrix pipes of all four SIMDs of a CU in shader cycles (check: it is 64 cycles per
+        # v_mfma_f64_16x16x4, 4 "MOPS" of 512 flops each), SQ_BUSY_CU_CYCLES counts a CU once: the pipes' share of the
+        # cycles in which their CU has work is busy / (4 cu)
+        e["mfma_pipe_busy_fraction_while_cu_busy"] = busy / (4.0 * cu)
+    mops = c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)
+    if mops > 0:
+        e["mfma_busy_cycles_per_instruction"] = busy / (mops / 4.0)
+        e["executed_GFLOP"] = mops * 512 / 1e9
     res["kernels"][k] = e
 rates = []
 for line in open(rate_txt):
