@@ -919,8 +919,9 @@ int SpdNumericCtx::factor(SpdFactor &F, const double *aval_host, double *flops_o
   {
   // the entries of A and the ones of the identity rows, every front of every level at once (the children's Schur
   // complements are ADDED later, level by level)
-  if (lvl_ptr.back() > 0 && max_ent > 0)
-    hipLaunchKernelGGL(k_fa_scatter, dim3((max_ent + 255) / 256, lvl_ptr.back()), dim3(256), 0, st, d_fd, d_lvl, d_dst, d_src, d_aval, d_Fm);
+  for (int f0 = 0; f0 < lvl_ptr.back() && max_ent > 0; f0 += 65535)   // (a grid's y extent ends at 65 535)
+    hipLaunchKernelGGL(k_fa_scatter, dim3((max_ent + 255) / 256, std::min(65535, lvl_ptr.back() - f0)), dim3(256), 0, st, d_fd,
+                       d_lvl + f0, d_dst, d_src, d_aval, d_Fm);
   for (int h = 0; h <= maxh; h++) {
     const int nf = (int)lvl[h].size();
     if (nf == 0) continue;
