@@ -699,6 +699,7 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
     segs_.upload(segs);
     own_seg_ptr_.upload(optr);
     own_seg_ptr_host_ = optr;
+    nbr_seg_ptr_host_ = nptr;
     nbr_seg_ptr_.upload(nptr);
     T_.segs = segs_.p;
     T_.nseg_own = nown;
@@ -725,6 +726,16 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   h_upd_ = h_rs_ + std::max(L, 1);   // update()'s sums have a block of their own: the next refinement's sums may arrive before the host has read them
   for (int i = 0; i < std::max(L, 1) * (CG_SUMMARY + TNT_SUMMARY + 1); i++) h_cg_[i] = 0.0;
   reduce_arrived_.alloc(1);
+  {   // the countdowns of the folded reductions (group.h: tail_ctr_)
+    std::vector<unsigned> ctr(2 * MAX_LOCAL_NODES, 0u);
+    for (int a = 0; a < L; a++) {
+      ctr[a] = (unsigned)(own_seg_ptr_host_[a + 1] - own_seg_ptr_host_[a]);
+      ctr[MAX_LOCAL_NODES + a] = ctr[a] + (unsigned)(nbr_seg_ptr_host_[a + 1] - nbr_seg_ptr_host_[a]);
+    }
+    tail_ctr_.upload(ctr);
+    fused_ = env_int("DPGO_FUSED", 1) != 0;
+    tails_ = env_int("DPGO_TAILS", fused_ ? 1 : 0) != 0;
+  }
   partials_.alloc((size_t)MAX_SLOTS * std::max(T_.nseg_all, 1));
   cg_.alloc(MAX_LOCAL_NODES);
   dmask_.alloc(4);
@@ -1124,6 +1135,37 @@ NodeMask Group::live_mask(NodeBits bits, const NodeBits *p) const {
     }
   m.idle_seg = own_seg_ptr_host_[idle];
   return m;
+}
+
+bool Group::make_tail(Tail &t, int kind, bool grid_all, bool all_rows, int nslots, double *host, NodeBits mask_v) {
+  t = Tail();
+  if (!tails_ || (int)own_seg_ptr_host_.size() != num_local() + 1) return false;
+  // sums parked by nodes outside this launch's set ride with the next reduction (deferred_slots_): only k_reduce, which sums
+  // for every node of the group, delivers those
+  if (kind == TAIL_REDUCE && (parked_bits_ & ~mask_v) != 0) return false;
+  int expected = 0;
+  for (int a = 0; a < num_local(); a++) {
+    if (!((mask_v >> a) & 1ull)) continue;
+    const int blocks = own_seg_ptr_host_[a + 1] - own_seg_ptr_host_[a] + (grid_all ? nbr_seg_ptr_host_[a + 1] - nbr_seg_ptr_host_[a] : 0);
+    if (blocks == 0) return false;   // (nobody would count this node off)
+    expected++;
+  }
+  if (expected == 0) return false;
+  t.kind = kind; t.all_rows = all_rows ? 1 : 0; t.grid_all = grid_all ? 1 : 0; t.nslots = nslots; t.expected = expected;
+  t.nseg_all = T_.nseg_all; t.own_ptr = T_.own_ptr; t.nbr_ptr = T_.nbr_ptr;
+  t.partials = partials_.p; t.host = host;
+  t.node_ctr = tail_ctr_.p + (grid_all ? MAX_LOCAL_NODES : 0);
+  t.arrived = reduce_arrived_.p; t.host_flag = h_flag_; t.dev_seq = dev_seq_.p;
+  t.cg = cg_.p; t.dmask = dmask_.p;
+  if (kind != TAIL_TNT) t.seq = next_seq();   // (the start of a refinement raises no flag)
+  return true;
+}
+
+void Group::flush_pending_tail() {
+  if (!pending_tail_.on) return;
+  const PendingTail p = pending_tail_;
+  pending_tail_.on = false;
+  launch_axpby(d_, st_, T_, false, p.m, 1.0, p.xak, 0.0, nullptr, p.xk, 0, p.z);
 }
 
 // ---------------------------------------------------------------------------
@@ -1550,14 +1592,14 @@ void Group::recover_translations(double *X, const double *g) {
 // y = base + G_{:,t} xt.t, with the row-local epilogues of launch_bsr_tcol
 void Group::apply_tcol(const double *xt, const double *base, double *y, int mode, const double *X, const double *nabla,
                        const double *Rdot, double *out2, const double *rres, double *partials, const double *dg,
-                       const double *dga, const double *ds, const double *dgrad, const double *dhs) {
+                       const double *dga, const double *ds, const double *dgrad, const double *dhs, const Tail *tail) {
   launch_bsr_tcol(d_, st_, T_, cur_mask_, G_.dev, G_.tcol.p, xt, base, y, mode, X, nabla, Rdot, out2, rres, partials, dg, dga,
-                  ds, dgrad, dhs);
+                  ds, dgrad, dhs, tail);
 }
 
 // partial[slot] = tr(X^T (g + 1/2 G X))     (DPGOProblem.cpp:180-205; + f on the host)
-void Group::eval_G(const double *X, const double *g, int slot) {
-  launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, X, false, nullptr, nullptr, X, 0.5, g, partials_.p, slot);
+void Group::eval_G(const double *X, const double *g, int slot, const Tail *tail) {
+  launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, X, false, nullptr, nullptr, X, 0.5, g, partials_.p, slot, nullptr, nullptr, tail);
 }
 
 // ---------------------------------------------------------------------------
@@ -1772,6 +1814,13 @@ int Group::scatter_global(double *X, int ld) const {
 int Group::communicate_local() {
   // neighbour rows whose owner lives in this group: one indexed device copy (DPGOHash.h:64-82)
   if (gather_dst_.n == 0) return 0;
+  if (pending_tail_.on) {
+    // Xk's own rows are still on their way (they ride on the next update()'s product with G): the neighbour rows come
+    // from Xak, which holds the same records
+    const double *src = pending_tail_.xak;
+    defer_or_launch(0x6c6f63ull, [this, src] { launch_copy_indexed(d_, st_, (int)gather_dst_.n, gather_dst_.p, gather_src_.p, src, Xk_.p); });
+    return 0;
+  }
   defer_or_launch(0x6c6f63ull, [this] { launch_copy_indexed(d_, st_, (int)gather_dst_.n, gather_dst_.p, gather_src_.p, Xk_.p, Xk_.p); });
   return 0;
 }
@@ -1779,15 +1828,18 @@ int Group::communicate_local() {
 int Group::step(const std::vector<int> &locals, const std::function<int()> &exchange) {
   struct Disarm {   // (whatever happens in between -- an error return, an exception on its way to the C ABI -- nothing stays deferred)
     Group *g;
-    ~Disarm() { g->defer_armed_ = false; g->deferred_.clear(); g->deferred_key_ = 0; }
+    ~Disarm() { g->defer_armed_ = false; g->tail_fusable_ = false; g->pending_tail_.on = false; g->deferred_.clear(); g->deferred_key_ = 0; }
   } disarm{this};
   defer_armed_ = !exchange && iter_graph_wanted();
+  tail_fusable_ = !exchange;
   int rc = iterate(locals);
+  tail_fusable_ = false;
   if (rc == 0 && exchange) rc = exchange();
   if (rc == 0) rc = communicate_local();
   defer_armed_ = false;
   if (rc == 0) rc = update(locals);
-  flush_deferred();   // (nothing, unless update() had nothing to do)
+  flush_pending_tail();   // (nothing, unless update() had nothing to do)
+  flush_deferred();
   return rc;
 }
 
@@ -2109,12 +2161,13 @@ std::vector<int> Group::rescale_device(const std::vector<int> &set) {
 
 int Group::update(const std::vector<int> &locals_in) {
   InLib in_lib(this);
-  if (failed_) { flush_deferred(); return -1; }
+  if (failed_) { flush_pending_tail(); flush_deferred(); return -1; }
   finish_update();
   std::vector<int> locals;
   for (int a : locals_in)
     if (!res_[a].updated) locals.push_back(a);
   if (locals.empty()) {
+    flush_pending_tail();
     flush_deferred();
     join_exchange();   // a pending exchange must still be ordered before whatever the caller does next on this stream
     return 0;
@@ -2129,8 +2182,18 @@ int Group::update(const std::vector<int> &locals_in) {
   for (int a : locals)
     if (res_[a].hist_iter != res_[a].iters) adv.push_back(a);
   bool zc_done = false;
+  NodeBits mask_locals_bits = 0;
+  for (int a : locals) mask_locals_bits |= 1ull << a;
   // (launches that wait for this update()'s first segment -- step() -- go now if something eager comes before it)
   if ((int)adv.size() != num_local() || !zc_ready_ || xchg_done_ || dynamic() || star_) flush_deferred();
+  // the tail of iterate() rides on the product with G (group.h: PendingTail) where that product reads the very records the
+  // tail copies: every node advances, the copy's second target is the buffer that becomes X[iter] below
+  bool fuse_copy = false;
+  if (pending_tail_.on) {
+    fuse_copy = !trivial && (int)adv.size() == num_local() && zc_ready_ && !xchg_done_ && !star_ && pending_tail_.m.v == mask_locals_bits &&
+                pending_tail_.z == Zp_.p && pending_tail_.xk == Xk_.p && pending_tail_.xak == Xak_.p;
+    if (!fuse_copy) flush_pending_tail();
+  }
   if ((int)adv.size() == num_local()) {
     // every node advances: rotate the buffers instead of copying them
     Zp_.swap(Zc_);
@@ -2155,20 +2218,19 @@ int Group::update(const std::vector<int> &locals_in) {
   // depends on it at once: not for AMM-PGO* (the master decides on the sums right away) nor with Dynamic rescale
   static const bool defer_enabled = env_int("DPGO_DEFER_UPDATE", 1) != 0;
   const bool can_defer = defer_enabled && !star_ && !dynamic() && (first.empty() != later.empty());
-  NodeBits mask_locals_bits = 0;
-  for (int a : locals) mask_locals_bits |= 1ull << a;
   // `launches`: the rest of the surrogate build of the nodes in `set`, ending with the reduction of its sums -- a branch-free
-  // sequence, replayed from a captured graph where the host's launch rate would bound it (segment()); it may be empty when
-  // the caller has already enqueued everything but the reduction
+  // sequence, replayed from a captured graph where the host's launch rate would bound it (segment()).  It is told how many
+  // sums the reduction carries and returns whether its last kernel took the reduction along (kernels.h: Tail); if not,
+  // k_reduce follows.
   auto end_with = [&](int seg_id, unsigned long long variant, int nslots, const std::vector<int> &set,
-                      const std::function<void()> &launches, std::function<void()> logic) {
+                      const std::function<bool(int)> &launches, std::function<void()> logic) {
     nslots = std::max(nslots, deferred_slots_);
     deferred_slots_ = 0;
     NodeBits bits = 0;
     for (int a : set) bits |= 1ull << a;
-    segment(seg_id, bits & mask_locals_bits, {bits, mask_locals_bits, variant, (unsigned long long)nslots}, [&] {
-      launches();
-      launch_reduce(st_, T_, num_local(), true, nslots, partials_.p, h_upd_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
+    segment(seg_id, bits & mask_locals_bits, {bits, mask_locals_bits, variant, (unsigned long long)nslots, fuse_copy ? 1ull : 0ull}, [&] {
+      if (!launches(nslots))
+        launch_reduce(st_, T_, num_local(), true, nslots, partials_.p, h_upd_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
     });
     if (can_defer) {
       pending_seq_ = fetch_seq_;
@@ -2182,6 +2244,13 @@ int Group::update(const std::vector<int> &locals_in) {
       logic();
     }
   };
+  // Dfobj = G X + g and |grad F|^2 as the last kernel of a sequence, the reduction riding on it
+  auto tangent_and_reduce = [&](const double *GXv, int slot, int nslots) {
+    Tail tl;
+    const bool rode = make_tail(tl, TAIL_REDUCE, false, true, nslots, h_upd_, cur_mask_.v);
+    launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, GXv, nullptr, partials_.p, slot, gc_.p, Dfc_.p, rode ? &tl : nullptr);
+    return rode;
+  };
   zc_ready_ = false;
   if (!zc_done) copy_rows(Zc_.p, Xk_.p, false);
   double *GX = (!trivial && keep_gx()) ? GXc_.p : T1_.p;
@@ -2191,7 +2260,11 @@ int Group::update(const std::vector<int> &locals_in) {
   auto product_with_G = [&] {
     if (trivial)   // T1 = G Xak and <Xak, 1/2 G Xak>   (half of evaluate_G, DPGOProblem.cpp:180-205)
       launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xak_.p, false, nullptr, T1_.p, Xak_.p, 0.5, nullptr, partials_.p, 5);
-    else           // T1 = G X and <X, 1/2 G X>  (kept as G X[k] where the next extrapolation reuses it)
+    else if (fuse_copy) {   // ... on Xak's records (the same numbers), which go to Xk and X[iter] on the way
+      const PendingTail pt = pending_tail_;
+      pending_tail_.on = false;
+      launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, pt.xak, false, nullptr, GX, pt.xak, 0.5, nullptr, partials_.p, 5, pt.xk, pt.z);
+    } else         // T1 = G X and <X, 1/2 G X>  (kept as G X[k] where the next extrapolation reuses it)
       launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Zc_.p, false, nullptr, GX, Zc_.p, 0.5, nullptr, partials_.p, 5);
   };
   const NodeMask mask_locals = cur_mask_;
@@ -2216,12 +2289,12 @@ int Group::update(const std::vector<int> &locals_in) {
     if (both) flush_deferred();
     if (both) common();   // (nodes at different iterations: two read-backs, nothing deferred, the shared part goes first)
     if (!first.empty()) {
-      end_with(1, (split ? 1ull : 0ull) | (both ? 2ull : 0ull), 6, first, [&] {
+      end_with(1, (split ? 1ull : 0ull) | (both ? 2ull : 0ull), 6, first, [&](int nslots) {
         if (!both) common();
         set_mask(first);
         launch_bsr(d_, st_, T_, true, cur_mask_, P0m_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 0);
         // fobj = G(Xak | g, f0) = f0 + <Xak, g> + <Xak, 1/2 G Xak>: slots 1 and 5; Dfobj = g + G Xak
-        launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, partials_.p, 2, gc_.p, Dfc_.p);
+        return tangent_and_reduce(T1_.p, 2, nslots);
       }, [this, first] {
         for (int a : first) {
           const double f0 = uscal(a, 0);
@@ -2230,13 +2303,13 @@ int Group::update(const std::vector<int> &locals_in) {
       });
     }
     if (!later.empty()) {
-      end_with(2, (split ? 1ull : 0ull) | (both ? 2ull : 0ull), 4, later, [&] {
+      end_with(2, (split ? 1ull : 0ull) | (both ? 2ull : 0ull), 4, later, [&](int nslots) {
         if (!both) common();
         set_mask(later);
         launch_axpby(d_, st_, T_, true, cur_mask_, 1.0, Zc_.p, -1.0, Zp_.p, Tall_.p, 0);
         launch_bsr(d_, st_, T_, true, cur_mask_, Q_.dev, Tall_.p, false, nullptr, nullptr, Tall_.p, 0.5, nullptr, partials_.p, 0);
         launch_bsr(d_, st_, T_, true, cur_mask_, P_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 3);
-        launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, partials_.p, 2, gc_.p, Dfc_.p);
+        return tangent_and_reduce(T1_.p, 2, nslots);
       }, [this, later] {
         for (int a : later) {
           const double fobj = res_[a].Gk + uscal(a, 0);
@@ -2256,13 +2329,14 @@ int Group::update(const std::vector<int> &locals_in) {
       const std::vector<int> &set = pass == 0 ? first : later;
       if (set.empty()) continue;
       std::vector<double> rho(num_local(), 0.0), gap(num_local(), 0.0);
-      auto inter_pass = [&] {
-        set_mask(set);
+      // fz: what the pass does on the way (Dfobj and |grad F|^2); tl: the reduction it takes along
+      auto inter_pass = [&](const InterFuse *fz, const Tail *tl) {
         launch_inter(d_, st_, T_, cur_mask_, E_, opt_.loss, opt_.loss_reg, 0, pass == 1, Zc_.p, Zp_.p, Qd_.p, Dd_.p, DfE_.p,
-                     gc_.p, partials_.p, dynamic() ? e_w_.p : nullptr, nullptr, nullptr, nullptr, nullptr, Xk_.p);   // slots 0, 1 and 2 = <X, g>
+                     gc_.p, partials_.p, dynamic() ? e_w_.p : nullptr, nullptr, nullptr, nullptr, nullptr, Xk_.p, nullptr, fz, tl);   // slots 0, 1 and 2 = <X, g>
       };
       if (dynamic()) {
-        inter_pass();
+        set_mask(set);
+        inter_pass(nullptr, nullptr);
         if (device_rescale_)   // the rescale test on the weights just computed; its verdict rides with the sums below
           launch_rescale_decide(st_, num_local(), cur_mask_.v, e_off_dev_.p, e_w_.p, e_scale_.p, rs_count_.p, opt_.max_rescale_count,
                                 rs_flags_.p, h_rs_);
@@ -2288,17 +2362,27 @@ int Group::update(const std::vector<int> &locals_in) {
       const bool dyn = dynamic();
       NodeBits fresh_bits = 0;
       for (int a : fresh) fresh_bits |= 1ull << a;
-      end_with(3 + pass, (split ? 1ull : 0ull) | (head_inside ? 2ull : 0ull) | (dyn ? 4ull : 0ull) | (fresh_bits << 3), 6, set, [&] {
+      end_with(3 + pass, (split ? 1ull : 0ull) | (head_inside ? 2ull : 0ull) | (dyn ? 4ull : 0ull) | (fused_ ? 8ull : 0ull) | (tails_ ? 16ull : 0ull) | (fresh_bits << 5), 6, set, [&](int nslots) {
         if (head_inside) head();
-        if (!dyn) inter_pass();
         set_mask(set);
-        if (pass == 0) launch_bdiag_dot(d_, st_, T_, cur_mask_, Dd_.p, Zc_.p, 0.5, DfE_.p, -1.0, partials_.p, 3);
-        launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, GX, nullptr, partials_.p, 4, gc_.p, Dfc_.p);   // Dfobj = G X + g
         if (!fresh.empty()) {
           set_mask(fresh);
           copy_rows(GXp_.p, GXc_.p, false);
           set_mask(set);
         }
+        const bool in_pass = !dyn && fused_;   // Dfobj = G X + g, its tangent projection and norm inside the inter-edge pass
+        if (!dyn) {
+          InterFuse fz;
+          fz.GX = GX; fz.X = Xak_.p; fz.Df = Dfc_.p; fz.gn_slot = 4;
+          Tail tl;
+          // (the reduction rides on the pass where nothing follows it: every update() but a node's first)
+          const bool rode = in_pass && pass == 1 && make_tail(tl, TAIL_REDUCE, true, true, nslots, h_upd_, cur_mask_.v);
+          inter_pass(in_pass ? &fz : nullptr, rode ? &tl : nullptr);
+          if (rode) return true;
+        }
+        if (pass == 0) launch_bdiag_dot(d_, st_, T_, cur_mask_, Dd_.p, Zc_.p, 0.5, DfE_.p, -1.0, partials_.p, 3);
+        if (!in_pass) return tangent_and_reduce(GX, 4, nslots);   // Dfobj = G X + g
+        return false;
       }, [this, set, pass, dyn, rho, gap] {
         for (int a : set) {
           NodeResults &r = res_[a];
@@ -2318,6 +2402,7 @@ int Group::update(const std::vector<int> &locals_in) {
       });
     }
   }
+  flush_pending_tail();   // (nothing, unless the product with G never came)
   return 0;
 }
 
@@ -2346,6 +2431,11 @@ int Group::iterate(const std::vector<int> &locals) {
     const NodeMask m = cur_mask_;
     const double *xak = Xak_.p;
     double *xk = Xk_.p, *z = zc_ready_ ? Zp_.p : nullptr;
+    flush_pending_tail();   // (an older one nobody took: iterate() twice without an update())
+    if (tail_fusable_ && fused_ && zc_ready_ && opt_.loss != 0) {
+      // the next update()'s product with G takes it along (group.h: PendingTail)
+      pending_tail_.on = true; pending_tail_.m = m; pending_tail_.xak = xak; pending_tail_.xk = xk; pending_tail_.z = z;
+    } else
     defer_or_launch(0x7461696cull ^ m.v, [this, m, xak, xk, z] { launch_axpby(d_, st_, T_, false, m, 1.0, xak, 0.0, nullptr, xk, 0, z); });
   }
   for (int a : locals) {
@@ -2396,6 +2486,21 @@ void Group::prepare_extrapolated(const double *gam_dev) {
   NodeCoefs gam;
   for (int a = 0; a < num_local(); a++) gam.a[a] = gam.b[a] = res_[a].gamma;
   // own AND neighbour rows are extrapolated with the local gamma (DPGOHash.cpp:255-256)
+  if (!trivial && fused_) {
+    // ... inside the inter-edge pass: it forms Y's records as it reads them (its own row, which it stores -- the proximal
+    // step reads Y's own rows --, and the pose at the other end of every incidence): no pass of its own over X[k], X[k-1]
+    InterFuse fz;
+    fz.Zc = Zc_.p; fz.Zp = Zp_.p; fz.Yout = Y_.p;
+    if (keep_gx()) {
+      launch_inter(d_, st_, T_, cur_mask_, E_, o.loss, o.loss_reg, 1, false, Y_.p, nullptr, nullptr, Dd_.p, nullptr, gx_.p,
+                   partials_.p, nullptr, GXc_.p, GXp_.p, &gam, Dfx_.p, nullptr, gam_dev, &fz);
+    } else {
+      launch_inter(d_, st_, T_, cur_mask_, E_, o.loss, o.loss_reg, 1, false, Y_.p, nullptr, nullptr, Dd_.p, nullptr, gx_.p,
+                   partials_.p, nullptr, nullptr, nullptr, &gam, nullptr, nullptr, gam_dev, &fz);
+      launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Y_.p, false, gx_.p, Dfx_.p, nullptr, 0, nullptr, nullptr, 0);
+    }
+    return;
+  }
   launch_extrapolate(d_, st_, T_, true, cur_mask_, gam, Zc_.p, Zp_.p, Y_.p, gam_dev);
   if (trivial) {
     launch_extrapolate(d_, st_, T_, false, cur_mask_, gam, gc_.p, gp_.p, gx_.p, gam_dev);      // :259-262
@@ -2470,6 +2575,7 @@ int Group::amm(const std::vector<int> &locals) {
   if (speculate) {
     const std::function<bool()> confirm = decide_refined;
     deferred_slots_ = DS + 3;
+    parked_bits_ = mask_locals.v;
     done_tnt = run_tnt(locals, Xak_.p, gx_.p, gc_.p, true, &confirm);
     abandoned = !done_tnt;
     if (done_tnt) {
@@ -2491,18 +2597,22 @@ int Group::amm(const std::vector<int> &locals) {
     // Gk for nodes that are not refined; refined nodes run TNT first (:374-383)
     if (ref.empty()) {   // (the regime once the gradient is small: the pass and its read-back as one segment)
       segment(11, cur_mask_.v, {}, [&] {
-        eval_G(Xak_.p, gc_.p, DS + 2);
-        launch_reduce(st_, T_, num_local(), false, DS + 3, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
+        Tail tl;
+        const bool rode = make_tail(tl, TAIL_REDUCE, false, false, DS + 3, h_scal_, cur_mask_.v);
+        eval_G(Xak_.p, gc_.p, DS + 2, rode ? &tl : nullptr);
+        if (!rode) launch_reduce(st_, T_, num_local(), false, DS + 3, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
       });
       wait_flag(fetch_seq_);
     } else {
       if (!plain.empty()) eval_G(Xak_.p, gc_.p, DS + 2);
       deferred_slots_ = DS + 3;
+      parked_bits_ = mask_locals.v;
       // TNT minimises G(. | g extrapolated); Gk is G(. | g[k]) at the refined point (:377-383)
       run_tnt(ref, Xak_.p, gx_.p, gc_.p, true);
       for (int a : ref) res_[a].Gk = res_[a].Gk_alt;
     }
   }
+  parked_bits_ = 0;
   spec_refined_ = true;
   for (int a : locals) spec_refined_ = spec_refined_ && res_[a].refined;
   spec_refined_ = spec_refined_ && (int)locals.size() == num_local();

@@ -399,7 +399,25 @@ class Group {
   // the mask of the nodes in `bits` (and-ed on the device with *p, if any) with the map that lets own-segment launches
   // cover these nodes only (kernels.h: NodeMask::nlive) when they are few
   NodeMask live_mask(NodeBits bits, const NodeBits *p) const;
-  std::vector<int> own_seg_ptr_host_;
+  std::vector<int> own_seg_ptr_host_, nbr_seg_ptr_host_;
+  // ---- reductions folded into their producers (kernels.h: Tail).  tail_ctr_: the countdowns of the nodes' workgroups, [a] for
+  // a grid over own segments, [MAX_LOCAL_NODES + a] for one over own and neighbour segments.  make_tail: the Tail of a launch
+  // over the nodes of mask_v (grid_all: its grid covers the neighbour segments too; all_rows: so do the sums); false -- the
+  // launch goes without, and the kernel it would have replaced is launched behind it -- when tails are switched off
+  // (DPGO_TAILS=0, A/B hook) or a node of the set has no workgroup in such a grid (it would never be counted off).
+  DevBuf<unsigned> tail_ctr_;
+  bool tails_ = true;
+  // the other fusions of round 6 (extrapolation and Dfobj inside the inter-edge pass, iterate()'s tail on the product with G,
+  // the first CG step's vector update with the retraction): DPGO_FUSED=0 gives round 5's launch sequence (A/B hook; same bits)
+  bool fused_ = true;
+  bool make_tail(Tail &t, int kind, bool grid_all, bool all_rows, int nslots, double *host, NodeBits mask_v);
+  // The tail of iterate() -- Xk <- Xak, and the buffer the next update() rotates into X[iter] -- waits for that update()'s
+  // product with G, which reads the same records anyway and stores them on the way (k_bsr's copy1 / copy2): armed by step()
+  // when no exchange stands between the two (the exchange's pack reads Xk); anything else launches it on its own.
+  struct PendingTail { bool on = false; NodeMask m = ALL_NODES; const double *xak = nullptr; double *xk = nullptr, *z = nullptr; };
+  PendingTail pending_tail_;
+  bool tail_fusable_ = false;
+  void flush_pending_tail();
   DevBuf<unsigned> reduce_arrived_;
   DevBuf<double> partials_;
   DevBuf<CgNode> cg_;       // device-resident state of the truncated CG (tnt.cpp, k_cg_scal)
@@ -477,6 +495,7 @@ class Group {
   void fetch(int nslots, bool all_rows);                  // -> h_scal_[local * MAX_SLOTS + s]
   void wait_flag(unsigned long long seq);
   int deferred_slots_ = 0;   // slots written earlier that ride along with the next fetch (saves a host round trip)
+  NodeBits parked_bits_ = 0; // ... and the nodes they belong to (make_tail: a folded reduction only sums for its own launch's nodes)
   double scal(int local, int s) const { return h_scal_[local * MAX_SLOTS + s]; }
   double *h_upd_ = nullptr;   // pinned (same allocation): the sums update() ends with
   double uscal(int local, int s) const { return h_upd_[local * MAX_SLOTS + s]; }
@@ -488,9 +507,9 @@ class Group {
                   const double *nabla = nullptr, const double *Rdot = nullptr, double *out2 = nullptr,
                   const double *rres = nullptr, double *partials = nullptr, const double *dg = nullptr,
                   const double *dga = nullptr, const double *ds = nullptr, const double *dgrad = nullptr,
-                  const double *dhs = nullptr);
+                  const double *dhs = nullptr, const Tail *tail = nullptr);
   void recover_translations(double *X, const double *g);  // X.t = -Gtt^-1 (g_t + G_tR X.R) for masked nodes
-  void eval_G(const double *X, const double *g, int slot);
+  void eval_G(const double *X, const double *g, int slot, const Tail *tail = nullptr);
   void host_update_logic(int local, double fobj, double f, double gradFnorm);
   // The read-back that ends update() is deferred where nothing has to be decided yet: update() enqueues the reduction,
   // advances the Nesterov sequence (host_update_pre: s, gamma -- they do not depend on the numbers read back) and

@@ -74,6 +74,32 @@ struct CgStart {
   double rv[MAX_LOCAL_NODES], Delta[MAX_LOCAL_NODES], target[MAX_LOCAL_NODES];
 };
 
+// ---- reductions folded into their producers ("the last workgroup of a node does it") ----------------------------------
+// The per-node sums of an iteration (k_reduce), the scalar steps of the truncated CG (k_cg_scal) and the start of a
+// refinement (k_tnt_begin) used to be launches of their own behind the kernel that writes the last partial sums.  A launch
+// that carries a Tail does their work itself: every workgroup of a node in mask.v, once its partial sums are stored,
+// fences and counts itself off the node's countdown (node_ctr[node]: the node's workgroups in this kind of grid, restored
+// by the workgroup that takes it to zero); the workgroup that does is the node's LAST one and runs the reduction -- the
+// partial sums in k_reduce's order, so the numbers are the same bits -- and the scalar logic; the last node to finish raises
+// the host's flag.  Nobody waits for anybody.  kind: 1 = k_reduce (nslots sums per node to host[node * MAX_SLOTS + s]),
+// 2 / 3 = k_cg_scal phase 0 / 1, 4 = k_tnt_begin.
+enum { TAIL_NONE = 0, TAIL_REDUCE = 1, TAIL_CG0 = 2, TAIL_CG1 = 3, TAIL_TNT = 4 };
+struct Tail {
+  int kind = TAIL_NONE, all_rows = 0, nslots = 0, expected = 0;   // all_rows: the sums cover the neighbour segments; expected: nodes in mask.v (they all arrive, live or not)
+  int nseg_all = 0, grid_all = 0;   // grid_all: the launch's grid covers the neighbour segments (what the countdown is restored to)
+  const int *own_ptr = nullptr, *nbr_ptr = nullptr;
+  const double *partials = nullptr;
+  double *host = nullptr;
+  unsigned *node_ctr = nullptr, *arrived = nullptr;
+  unsigned long long *host_flag = nullptr, seq = 0, *dev_seq = nullptr;
+  CgNode *cg = nullptr;
+  unsigned long long *dmask = nullptr;
+  // TAIL_TNT (k_tnt_begin's arguments; every candidate starts from the same radius, TNTParams::Delta0)
+  unsigned long long bits = 0;
+  int use_precon = 0, max_it = 0;
+  double grad_tol = 0, pgrad_tol = 0, kappa = 0, theta = 0, Delta = 0;
+};
+
 struct BsrDev {
   int nrows = 0, nnzb = 0;
   const int *ptr = nullptr, *col = nullptr;
@@ -114,7 +140,9 @@ struct SegTable {
 // dot product sees the full A x -- one pass for "G [0 ; R] + g" and "<x, 1/2 G x + g'>" (DPGOHash.cpp:363-372).
 void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask, const BsrDev &A,
                 const double *x, int mode, const double *addv, double *y, const double *dotv,
-                double coef, const double *dotadd, double *partials, int slot);
+                double coef, const double *dotadd, double *partials, int slot,
+                // copy1 / copy2: the own rows' records of x are stored there on the way (the tail of iterate(): Xk <- Xak)
+                double *copy1 = nullptr, double *copy2 = nullptr, const Tail *tail = nullptr);
 
 // y = base + A[:, translation column] t over own rows; tval: the first column of every block of A ((d+1) doubles per
 // block), xt: records whose translation row is t.  A quarter of the traffic of launch_bsr.
@@ -131,8 +159,20 @@ void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, co
                      const double *nabla = nullptr, const double *Rdot = nullptr, double *out2 = nullptr,
                      const double *rres = nullptr, double *partials = nullptr, const double *dg = nullptr,
                      const double *dga = nullptr, const double *ds = nullptr, const double *dgrad = nullptr,
-                     const double *dhs = nullptr);
+                     const double *dhs = nullptr, const Tail *tail = nullptr);
 
+// what the robust inter-edge pass does on the way, instead of a launch of its own
+struct InterFuse {
+  // mode 0 (update()): Dfobj = G X + g from the product that is there already, its tangent projection and |grad F|^2 into
+  // partial slot gn_slot -- k_tangent_full's job (DPGOProblem.cpp:145-162); X: the own rows' records
+  const double *GX = nullptr, *X = nullptr;
+  double *Df = nullptr;
+  int gn_slot = 0;
+  // mode 1 (iterate()): the point itself is formed on the way, Z = Zc + gamma (Zc - Zp) -- k_extrapolate's job
+  // (DPGOHash.cpp:255-256), for the row and for every pose its incidences reach; the own rows are stored to Yout
+  const double *Zc = nullptr, *Zp = nullptr;
+  double *Yout = nullptr;
+};
 // Robust inter-edge pass (B-form, DPGOProblem.cpp:634-725).
 //  mode 0 (update): all rows.  DfE <- B1^T W B1 Z; own rows also g <- DfE - D z.
 //     slot 0: sum of rho_e (tail incidences); if quad: slot 1 = sum tr(dZ^T (DfE_old + 1/2 Q dZ)); slot 2: <z, g> over
@@ -149,7 +189,8 @@ void launch_inter(int d, hipStream_t st, const SegTable &T, NodeMask mask, const
                   const double *Znbr = nullptr,
                   // gamma_dev: the same gammas in device memory (launch_set_coefs) -- read instead of `gamma` by a launch that may be
                   // replayed from a captured graph, whose by-value arguments are frozen
-                  const double *gamma_dev = nullptr);
+                  const double *gamma_dev = nullptr,
+                  const InterFuse *fuse = nullptr, const Tail *tail = nullptr);
 
 // ---- Rescale::Dynamic on the device (see k_rescale_decide / k_rescale_apply) ----
 // decide: flags[a] / host_flags[a] = node a (of `nodes`) is rescaled; its scales and counter are updated
@@ -201,7 +242,9 @@ void launch_dots(int d, hipStream_t st, const SegTable &T, NodeMask mask, int n,
 // one CG step (IterativeSolvers.h:340-390): s += C.a[node] p, hs += C.a[node] Hp, and r += C.b[node] Hp where C.b != 0
 void launch_cg_step(int d, hipStream_t st, const SegTable &T, NodeMask mask, const NodeCoefs &C, const double *p,
                     const double *Hp, double *s, double *hs, double *r, const CgNode *cg = nullptr,   // cg: coefficients from the device state
-                    const double *r0 = nullptr);   // r0: first step of a run -- s = hs = 0 (not read), r = r0
+                    const double *r0 = nullptr,    // r0: first step of a run -- s = hs = 0 (not read), r = r0
+                    // xprop: the nodes of *rmask (device) also get xprop.Y = proj_SO(d)(X.Y + s.Y), xprop.x = 0 (launch_retract_rot)
+                    const double *X = nullptr, double *xprop = nullptr, const NodeBits *rmask = nullptr);
 // start of a truncated CG (IterativeSolvers.h:230-260): s = 0, hs = 0, r = grad, v = pgrad, p = -pgrad; with s == nullptr
 // only p = -pgrad (the first launch_cg_step, given r0 = grad, supplies the rest)
 void launch_cg_init(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *grad, const double *pgrad,
@@ -210,7 +253,7 @@ void launch_cg_init(int d, hipStream_t st, const SegTable &T, NodeMask mask, con
 // with add: the vector is V + add, stored to sum_out if given (Dfobj = G X + g from its two halves)
 void launch_tangent_full(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
                          const double *V, double *out, double *partials, int slot, const double *add = nullptr,
-                         double *sum_out = nullptr);
+                         double *sum_out = nullptr, const Tail *tail = nullptr);
 // dst = src on the neighbour rows only
 void launch_copy_nbr_rows(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *src, double *dst);
 // out.Y = Proj_R(in.Y), out.x = 0                                       (DPGOProblem.cpp:164-178)
@@ -218,7 +261,7 @@ void launch_copy_nbr_rows(int d, hipStream_t st, const SegTable &T, NodeMask mas
 // neg: also neg = -out (the first CG direction)
 void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
                         const double *in, double *out, const double *dotv = nullptr, double *partials = nullptr,
-                        int slot = 0, bool two = false, double *neg = nullptr);
+                        int slot = 0, bool two = false, double *neg = nullptr, const Tail *tail = nullptr);
 // out.Y rows = dinv (one entry per rotation row) * in.Y rows: Preconditioner::Jacobi   (DPGOProblem.cpp:96-98, 583-585)
 void launch_rot_rowscale(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *dinv, const double *in, double *out);
 // out.Y = proj_SO(d)(X.Y + V.Y); out.x = 0                              (SOdProduct.h:111-116)

@@ -287,6 +287,15 @@ __device__ __forceinline__ void tangent_proj(const double *Y, const double *F, d
     }
 }
 
+// ---- reductions folded into their producers (kernels.h: Tail) --------------------------------------------------------
+// tail_arrive<W, KINDS>: called by EVERY thread of a workgroup (of W waves) that belongs to `node` once the workgroup's partial
+// sums are stored (workgroups of a node in mask.v that the device-side mask has switched off call it too: the countdown is sized
+// by the host).  The node's last workgroup runs the tail.  KINDS: the kinds the kernel is ever launched with (bit k = kind k),
+// so that a kernel carries only the code (and the registers) of the tails it can be asked for.  Defined behind k_cg_scal.
+template <int W, int KINDS>
+__device__ __forceinline__ void tail_arrive(const Tail &t, const NodeMask &mask, int node);
+constexpr int TK_REDUCE = 1 << TAIL_REDUCE, TK_CG0 = 1 << TAIL_CG0, TK_CG1 = 1 << TAIL_CG1, TK_TNT = 1 << TAIL_TNT;
+
 // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8).  Segment kernels therefore take segment
 // xcd_seg(blockIdx) instead of segment blockIdx: XCD x works on one contiguous eighth of the rows, so the
 // records its gathers touch (lattice neighbours, a few thousand rows away at most) stay in that XCD's own
@@ -316,7 +325,7 @@ __device__ __forceinline__ int seg_live(const NodeMask &m, int b, int n) {
 template <int D, int MODE>
 __global__ __launch_bounds__(BSR_LPR * SEG_ROWS) void k_bsr(const Seg *segs, NodeMask mask, BsrDev A, const double *x,
                                               const double *addv, double *y, const double *dotv, double coef,
-                                              const double *dotadd, double *partial) {
+                                              const double *dotadd, double *partial, double *copy1, double *copy2, Tail tail) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
   const int si = SEGM(mask);
   const Seg s = segs[si];
@@ -358,6 +367,12 @@ __global__ __launch_bounds__(BSR_LPR * SEG_ROWS) void k_bsr(const Seg *segs, Nod
         for (int o = 1; o < LPR; o <<= 1) acct[k] += __shfl_xor(acct[k], o, 64);
     }
     if (inrow && j == 0) {
+      if (copy1) {   // the row's own record goes to two more arrays on the way (the tail of iterate(): Xk <- Xak, X[iter] <- Xak)
+        double xr[RS];
+        load_vec<RS>(x + (size_t)row * RS, xr);
+        store_vec<RS>(copy1 + (size_t)row * RS, xr);
+        if (copy2) store_vec<RS>(copy2 + (size_t)row * RS, xr);
+      }
       if (dotv) {
         double v[RS], da[RS];
         load_vec<RS>(dotv + (size_t)row * RS, v);
@@ -382,6 +397,7 @@ __global__ __launch_bounds__(BSR_LPR * SEG_ROWS) void k_bsr(const Seg *segs, Nod
     }
   }
   if (partial && active) block_store<1, LPR * SEG_ROWS / 64>(part, partial + si, 0);
+  tail_arrive<LPR * SEG_ROWS / 64, TK_REDUCE>(tail, mask, s.node);
 }
 
 // out (d x d) = Proj_R(E - sym(nabla R^T) Rdot): the rotation rows of the Riemannian Hessian-vector product
@@ -427,11 +443,14 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr_tcol(const Seg *segs, Node
                                                          const double *xt, const double *base, double *y, int mode,
                                                          const double *X, const double *nabla, const double *Rdot,
                                                          double *out2, const double *rres, double *partial,
-                                                         int pstride, TcolDots E) {
+                                                         int pstride, TcolDots E, Tail tail) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
   const int si = SEGM(mask);
   const Seg s = segs[si];
-  if (!node_on(mask, s.node)) return;   // (partials of a node outside the mask are never read)
+  if (!node_on(mask, s.node)) {   // (partials of a node outside the mask are never read)
+    tail_arrive<4, TK_REDUCE | TK_CG0>(tail, mask, s.node);
+    return;
+  }
   const int row = s.begin + (threadIdx.x >> 2), j = threadIdx.x & 3;
   double pr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   double acc[RS];
@@ -522,6 +541,7 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr_tcol(const Seg *segs, Node
     }
   }
   if (partial) block_store<6, 4 * SEG_ROWS / 64>(pr, partial + si, pstride);
+  tail_arrive<4, TK_REDUCE | TK_CG0>(tail, mask, s.node);
 }
 
 // ---------------------------------------------------------------------------
@@ -556,20 +576,32 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask ma
                                                double dl, int mode, int quad, int nseg_own, const double *Z,
                                                const double *Zprev, const double *Qd, const double *Dd,
                                                double *DfE, double *g, double *partial, int pstride, double *wout,
-                                               InterLin lin, const double *Znbr) {
+                                               InterLin lin, const double *Znbr, InterFuse F, Tail tail) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
   const bool active = node_on(mask, s.node);
   const bool own = SEGB < nseg_own;
   double part[3] = {0.0, 0.0, 0.0};   // sum rho ; the quadratic term ; <z, g> over own rows
+  double gn[1] = {0.0};               // (F.Df) |grad F|^2 of the row
   const int row = s.begin + threadIdx.x;
   if (active && row < s.end) {
     double zp[RS], acc[RS];
+    const bool xfuse = F.Zc != nullptr;
+    const double gm = (xfuse || lin.out) ? (lin.gamma_dev ? lin.gamma_dev[s.node] : lin.gamma.a[s.node]) : 0.0;
     // Znbr (mode 0): the neighbour rows are taken from there (the iterate the exchange just delivered) and copied into Z
     // on the way -- update()'s halo copy without a launch of its own.  Nobody reads Z's neighbour rows in this pass.
     const bool from_nbr = Znbr && row >= E.nrows_own;
-    load_vec<RS>((from_nbr ? Znbr : Z) + (size_t)row * RS, zp);
-    if (from_nbr) store_vec<RS>(const_cast<double *>(Z) + (size_t)row * RS, zp);
+    if (xfuse) {
+      double zq[RS];
+      load_vec<RS>(F.Zc + (size_t)row * RS, zp);
+      load_vec<RS>(F.Zp + (size_t)row * RS, zq);
+#pragma unroll
+      for (int k = 0; k < RS; k++) zp[k] = fma(gm, zp[k] - zq[k], zp[k]);
+      store_vec<RS>(F.Yout + (size_t)row * RS, zp);
+    } else {
+      load_vec<RS>((from_nbr ? Znbr : Z) + (size_t)row * RS, zp);
+      if (from_nbr) store_vec<RS>(const_cast<double *>(Z) + (size_t)row * RS, zp);
+    }
 #pragma unroll
     for (int k = 0; k < RS; k++) acc[k] = 0.0;
     const int k0 = E.inc_ptr[row], k1 = E.inc_ptr[row + 1];
@@ -591,7 +623,15 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask ma
       const int code = u8.r.code, e = code >> 1, role = code & 1;
       const int other = u8.r.other;
       double zo[RS], Re[D * D], te[D];
-      load_vec<RS>(((Znbr && other >= E.nrows_own) ? Znbr : Z) + (size_t)other * RS, zo);
+      if (xfuse) {
+        double zq[RS];
+        load_vec<RS>(F.Zc + (size_t)other * RS, zo);
+        load_vec<RS>(F.Zp + (size_t)other * RS, zq);
+#pragma unroll
+        for (int i = 0; i < RS; i++) zo[i] = fma(gm, zo[i] - zq[i], zo[i]);
+      } else {
+        load_vec<RS>(((Znbr && other >= E.nrows_own) ? Znbr : Z) + (size_t)other * RS, zo);
+      }
       if (k + 1 < k1) {
         const double2 *rq = reinterpret_cast<const double2 *>(E.rec + k + 1);
 #pragma unroll
@@ -675,20 +715,39 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask ma
       }
       part[2] = zg;
       store_vec<RS>(g + (size_t)row * RS, acc);
+      if (F.Df) {
+        // Dfobj = G X + g, gradF = [Dfobj.x ; Proj_R(Dfobj.Y)], |gradF|^2 (k_tangent_full: the same operations in the same order)
+        double v[RS], x[RS], o[RS];
+        load_vec<RS>(F.GX + (size_t)row * RS, v);
+        load_vec<RS>(F.X + (size_t)row * RS, x);
+#pragma unroll
+        for (int k = 0; k < RS; k++) v[k] += acc[k];
+        store_vec<RS>(F.Df + (size_t)row * RS, v);
+#pragma unroll
+        for (int k = 0; k < D; k++) o[k] = v[k];
+        tangent_proj<D>(x + D, v + D, o + D);
+        double p = 0;
+#pragma unroll
+        for (int k = 0; k < RS; k++) p = fma(o[k], o[k], p);
+        gn[0] = p;
+      }
       if (lin.out) {
         // Df = g + G Y at the extrapolated point Y = X[k] + gamma (X[k] - X[k-1]), without another pass over G:
         // G Y = G X[k] + gamma (G X[k] - G X[k-1]), both products kept from the last two update()s
         double a[RS], b[RS];
         load_vec<RS>(lin.GXc + (size_t)row * RS, a);
         load_vec<RS>(lin.GXp + (size_t)row * RS, b);
-        const double gm = lin.gamma_dev ? lin.gamma_dev[s.node] : lin.gamma.a[s.node];
 #pragma unroll
         for (int k = 0; k < RS; k++) acc[k] += fma(gm, a[k] - b[k], a[k]);
         store_vec<RS>(lin.out + (size_t)row * RS, acc);
       }
     }
   }
-  if (active) block_store<3>(part, partial + SEGB, pstride);
+  if (active) {
+    block_store<3>(part, partial + SEGB, pstride);
+    if (F.Df && own) block_store<1>(gn, partial + (size_t)F.gn_slot * pstride + SEGB, 0);
+  }
+  tail_arrive<1, TK_REDUCE>(tail, mask, s.node);
 }
 
 // ---------------------------------------------------------------------------
@@ -1052,12 +1111,18 @@ __global__ __launch_bounds__(SEG_ROWS) void k_rot_rowscale(const Seg *segs, Node
 template <int D>
 __global__ __launch_bounds__(SEG_ROWS) void k_cg_step(const Seg *segs, NodeMask mask, NodeCoefs C, const double *p,
                                                       const double *Hp, double *s, double *hs, double *r,
-                                                      const CgNode *cg, const double *r0) {
+                                                      const CgNode *cg, const double *r0, const double *X, double *xprop,
+                                                      const NodeBits *rmask) {
   constexpr int RS = Dim<D>::RS;
   const Seg sg = segs[SEGM(mask)];
   if (!node_on(mask, sg.node)) return;
   const int row = sg.begin + threadIdx.x;
   if (row >= sg.end) return;
+  // xprop: the nodes of *rmask (their CG ended with this step) go straight on to their trial point's rotations,
+  // xprop.Y = proj_SO(d)(X.Y + s.Y) -- k_rot_op mode 2 without a launch of its own
+  const bool retract = xprop && ((*rmask >> sg.node) & 1ull);
+  double xr[RS];
+  if (retract) load_vec<RS>(X + (size_t)row * RS, xr);
   const double cc = cg ? cg[sg.node].c1 : C.a[sg.node], cc_r = cg ? cg[sg.node].cr : C.b[sg.node];
   double vp[RS], vh[RS], v[RS];
   load_vec<RS>(p + (size_t)row * RS, vp);
@@ -1072,6 +1137,15 @@ __global__ __launch_bounds__(SEG_ROWS) void k_cg_step(const Seg *segs, NodeMask 
 #pragma unroll
   for (int k = 0; k < RS; k++) v[k] = fma(cc, vp[k], 1.0 * v[k]);
   store_vec<RS>(s + (size_t)row * RS, v);
+  if (retract) {
+    double M[D * D], o[RS];
+#pragma unroll
+    for (int k = 0; k < D; k++) o[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < D * D; k++) M[k] = xr[D + k] + v[D + k];
+    project_sod<D>(M, o + D);
+    store_vec<RS>(xprop + (size_t)row * RS, o);
+  }
   if (r0) {
 #pragma unroll
     for (int k = 0; k < RS; k++) v[k] = 0.0;
@@ -1170,7 +1244,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_dots(const Seg *segs, NodeMask mas
 template <int D>
 __global__ __launch_bounds__(SEG_ROWS) void k_tangent_full(const Seg *segs, NodeMask mask, const double *X,
                                                       const double *V, const double *add, double *sum_out,
-                                                      double *out, double *partial) {
+                                                      double *out, double *partial, Tail tail) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
   const bool active = node_on(mask, s.node);
@@ -1197,6 +1271,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_tangent_full(const Seg *segs, Node
     if (out) store_vec<RS>(out + (size_t)row * RS, o);
   }
   if (partial && active) block_store<1>(pr, partial + SEGB, 0);
+  tail_arrive<1, TK_REDUCE>(tail, mask, s.node);
 }
 
 // mode 0: out.Y = Proj_R(in.Y)                         (reduced_tangent_space_projection)
@@ -1204,11 +1279,14 @@ __global__ __launch_bounds__(SEG_ROWS) void k_tangent_full(const Seg *segs, Node
 template <int D>
 __global__ __launch_bounds__(SEG_ROWS) void k_rot_op(const Seg *segs, NodeMask mask, int mode, const double *X,
                                                 const double *in, const double *dotv, double *partial,
-                                                double *out, int pstride, int two, double *neg) {
+                                                double *out, int pstride, int two, double *neg, Tail tail) {
   constexpr int RS = Dim<D>::RS;
   const int si = SEGM(mask);
   const Seg s = segs[si];
-  if (!node_on(mask, s.node)) return;
+  if (!node_on(mask, s.node)) {
+    tail_arrive<1, TK_CG1 | TK_TNT>(tail, mask, s.node);
+    return;
+  }
   const int row = s.begin + threadIdx.x;
   double pr[2] = {0.0, 0.0};
   if (row < s.end) {
@@ -1249,6 +1327,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_rot_op(const Seg *segs, NodeMask m
     if (two) block_store<2>(pr, partial + si, pstride);
     else block_store<1>(reinterpret_cast<const double(&)[1]>(pr), partial + si, 0);
   }
+  tail_arrive<1, TK_CG1 | TK_TNT>(tail, mask, s.node);
 }
 
 // dst[didx[k]] = src[sidx[k]]  (didx == nullptr: dst[k]); halo copies, pack and unpack
@@ -1360,6 +1439,40 @@ struct TntBegin {
   double grad_tol, pgrad_tol, kappa, theta;
   double Delta[MAX_LOCAL_NODES];
 };
+// the per-node part: v = the six sums (|grad|^2, <X, nabla>, <X, g>, <X, g_alt>, |P grad|^2, <grad, P grad>); one thread
+__device__ __forceinline__ void tnt_begin_node(int a, bool mine, const double (&v)[6], int use_precon, int max_it, double grad_tol,
+                                               double pgrad_tol, double kappa, double theta, double Delta, CgNode *cg,
+                                               NodeBits *dmask, double *host_tnt) {
+  bool active = false, live = false;
+  if (mine) {
+    const double gnorm = sqrt(v[0]), pgnorm = use_precon ? sqrt(v[4]) : gnorm, rv0 = use_precon ? v[5] : v[0];
+    active = !(gnorm < grad_tol) && !(pgnorm < pgrad_tol);
+    CgNode c;
+    c.sk_M_pk = 0.0; c.sk_M_2 = 0.0; c.pk_M_2 = rv0; c.rv = rv0;
+    c.Delta = Delta; c.Delta_2 = Delta * Delta;
+    const double r0 = sqrt(rv0);
+    c.target = r0 * fmin(kappa, pow(r0, theta));
+    c.h_M_norm = 0.0;
+    c.c1 = 0.0; c.cr = 0.0; c.al = 0.0; c.kap = 0.0; c.be = 0.0;
+    c.cg_it = 0; c.max_it = max_it; c.pad = 0;
+    c.live = active && !(c.cg_it >= max_it || sqrt(c.rv) <= c.target);
+    if (!c.live) c.h_M_norm = sqrt(c.sk_M_2);
+    cg[a] = c;
+    live = c.live;
+#pragma unroll
+    for (int q = 0; q < 6; q++) __hip_atomic_store(host_tnt + a * TNT_SUMMARY + q, v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(host_tnt + a * TNT_SUMMARY + 6, active ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // every node owns its bit of the three masks (a node outside `bits` clears it): no word is written as a whole, so the
+  // workgroups need not meet
+  const NodeBits bit = 1ull << a;
+  if (live) { atomicOr(dmask + 0, bit); atomicOr(dmask + 1, bit); atomicAnd(dmask + 2, ~bit); }
+  else {
+    atomicAnd(dmask + 0, ~bit); atomicAnd(dmask + 1, ~bit);
+    if (active) atomicOr(dmask + 2, bit);
+    else atomicAnd(dmask + 2, ~bit);
+  }
+}
 __global__ __launch_bounds__(384) void k_tnt_begin(SegTable T, int nnodes, TntBegin B, const double *partials, CgNode *cg,
                                                    NodeBits *dmask, double *host_tnt) {
   // one workgroup per node, one wave per sum (six independent reductions side by side; each in the order of k_reduce)
@@ -1378,38 +1491,10 @@ __global__ __launch_bounds__(384) void k_tnt_begin(SegTable T, int nnodes, TntBe
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
-  bool active = false, live = false;
-  if (mine) {
-    double v[6];
+  double v[6];
 #pragma unroll
-    for (int q = 0; q < 6; q++) v[q] = sums[q];
-    const double gnorm = sqrt(v[0]), pgnorm = B.use_precon ? sqrt(v[4]) : gnorm, rv0 = B.use_precon ? v[5] : v[0];
-    active = !(gnorm < B.grad_tol) && !(pgnorm < B.pgrad_tol);
-    CgNode c;
-    c.sk_M_pk = 0.0; c.sk_M_2 = 0.0; c.pk_M_2 = rv0; c.rv = rv0;
-    c.Delta = B.Delta[a]; c.Delta_2 = B.Delta[a] * B.Delta[a];
-    const double r0 = sqrt(rv0);
-    c.target = r0 * fmin(B.kappa, pow(r0, B.theta));
-    c.h_M_norm = 0.0;
-    c.c1 = 0.0; c.cr = 0.0; c.al = 0.0; c.kap = 0.0; c.be = 0.0;
-    c.cg_it = 0; c.max_it = B.max_it; c.pad = 0;
-    c.live = active && !(c.cg_it >= B.max_it || sqrt(c.rv) <= c.target);
-    if (!c.live) c.h_M_norm = sqrt(c.sk_M_2);
-    cg[a] = c;
-    live = c.live;
-#pragma unroll
-    for (int q = 0; q < 6; q++) __hip_atomic_store(host_tnt + a * TNT_SUMMARY + q, v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(host_tnt + a * TNT_SUMMARY + 6, active ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  // every node owns its bit of the three masks (a node outside `bits` clears it): no word is written as a whole, so the
-  // workgroups need not meet
-  const NodeBits bit = 1ull << a;
-  if (live) { atomicOr(dmask + 0, bit); atomicOr(dmask + 1, bit); atomicAnd(dmask + 2, ~bit); }
-  else {
-    atomicAnd(dmask + 0, ~bit); atomicAnd(dmask + 1, ~bit);
-    if (active) atomicOr(dmask + 2, bit);
-    else atomicAnd(dmask + 2, ~bit);
-  }
+  for (int q = 0; q < 6; q++) v[q] = sums[q];
+  tnt_begin_node(a, mine, v, B.use_precon, B.max_it, B.grad_tol, B.pgrad_tol, B.kappa, B.theta, B.Delta[a], cg, dmask, host_tnt);
 }
 
 // The scalar step of STPCG for one node from the sums of a phase (v[0..3]: phase 0 <p, H p>, <H p, H p>, <p, p>, <p, r>;
@@ -1451,10 +1536,44 @@ __device__ __forceinline__ void cg_scal_logic(int phase, const double (&v)[4], C
   }
 }
 
-// one wave per node; the partial sums are combined in the order of k_reduce
+// the per-node part of a scalar step: one thread.  `mine`: the node is part of this phase (its bit of dmask[phase])
+__device__ __forceinline__ void cg_scal_node(int a, int phase, bool mine, const double (&v)[4], CgNode *cg, NodeBits *dmask,
+                                             double *host_scalars) {
+  CgNode c = cg[a];
+  if (mine) {
+    cg_scal_logic(phase, v, c);
+    cg[a] = c;
+    // a node that stops leaves dmask[1] now; dmask[0] (the nodes of the step under way, which still take the
+    // s / H s update of this step) follows at the end of phase 1
+    if (!c.live) {
+      atomicAnd(dmask + 1, ~(1ull << a));
+      atomicOr(dmask + 2, 1ull << a);    // ... and joins the nodes whose trial point can be taken
+    }
+  }
+  // (the summary has its own pinned area, CG_SUMMARY doubles per node: it must survive the read-back of a trial point
+  // that was enqueued behind this step)
+  __hip_atomic_store(host_scalars + a * CG_SUMMARY + 0, (double)c.live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(host_scalars + a * CG_SUMMARY + 1, c.h_M_norm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(host_scalars + a * CG_SUMMARY + 2, (double)c.cg_it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// the last of `expected` arrivals raises the host's flag (shared by k_reduce's successors; one thread)
 // seq: the value the host's flag is raised to.  A launch replayed from a captured graph cannot carry a fresh value in its
 // arguments: with seq == 0 the value is the device word *dev_seq + 1; either way *dev_seq ends up holding the value used,
 // so that eager launches and replays can follow each other (the host counts along: Group::fetch_seq_).
+__device__ __forceinline__ void flag_arrive(unsigned *arrived, unsigned expected, int phase, NodeBits *dmask,
+                                            unsigned long long *host_flag, unsigned long long seq, unsigned long long *dev_seq) {
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+  const unsigned done = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (done == expected - 1) {
+    if (phase == 1) dmask[0] = __hip_atomic_load(dmask + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next step's nodes
+    __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seq == 0) seq = *dev_seq + 1;
+    *dev_seq = seq;
+    __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// one wave per node; the partial sums are combined in the order of k_reduce
 __global__ __launch_bounds__(256) void k_cg_scal(SegTable T, int phase, const double *partials, CgNode *cg,
                                                  NodeBits *dmask, double *host_scalars, unsigned *arrived,
                                                  unsigned long long *host_flag, unsigned long long seq,
@@ -1473,36 +1592,128 @@ __global__ __launch_bounds__(256) void k_cg_scal(SegTable T, int phase, const do
     if (lane == 0) sums[wv] = t;
   }
   __syncthreads();
+  if (threadIdx.x != 0) return;
   double v[4] = {0.0, 0.0, 0.0, 0.0};
-  if (mine && threadIdx.x == 0) {
+  if (mine)
     for (int q = 0; q < ns; q++) v[q] = sums[q];
+  cg_scal_node(a, phase, mine, v, cg, dmask, host_scalars);
+  flag_arrive(arrived, gridDim.x, phase, dmask, host_flag, seq, dev_seq);
+}
+
+// ---- the node's last workgroup (kernels.h: Tail).  A partial-sum slot of node a is summed in k_reduce's order: a lane's
+// segments own_ptr[a] + lane, + 64, ... then the neighbour segments likewise, then the shuffle tree; lane 0 ends up with the
+// total.  The loads of U consecutive positions of NS slots (slot0, slot0 + stride, ...) are in flight together (the tail is a
+// chain of memory round trips on the critical path of its launch); they bypass this XCD's L2, which may hold older lines of
+// the array (the partial sums come from workgroups on every XCD).
+template <int NS, int U>
+__device__ __forceinline__ void tail_range(const Tail &t, int slot0, int stride, int k0, int k1, int lane, double (&v)[NS]) {
+  // (a uniform base per slot and ONE 32-bit lane offset: the loads then need a scalar register pair per slot, not a vector pair)
+  const double *ps[NS];
+#pragma unroll
+  for (int q = 0; q < NS; q++) ps[q] = t.partials + (size_t)min(slot0 + q * stride, MAX_SLOTS - 1) * t.nseg_all;
+  for (unsigned k = (unsigned)(k0 + lane); k < (unsigned)k1; k += 64u * U) {
+    double x[U][NS];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int q = 0; q < NS; q++)
+        x[u][q] = k + 64u * u < (unsigned)k1 ? __hip_atomic_load(ps[q] + (k + 64u * u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (k + 64u * u < (unsigned)k1) {
+#pragma unroll
+        for (int q = 0; q < NS; q++) v[q] += x[u][q];
+      }
   }
-  if (threadIdx.x == 0) {
-    CgNode c = cg[a];
-    if (mine) cg_scal_logic(phase, v, c);
+}
+template <int NS>
+__device__ __forceinline__ void tail_sums(const Tail &t, int slot0, int stride, int o0, int o1, int n0, int n1, int lane, double (&v)[NS]) {
+#pragma unroll
+  for (int q = 0; q < NS; q++) v[q] = 0.0;
+  tail_range<NS, 4>(t, slot0, stride, o0, o1, lane, v);
+  tail_range<NS, 4>(t, slot0, stride, n0, n1, lane, v);
+#pragma unroll
+  for (int q = 0; q < NS; q++) v[q] = wave_sum(v[q]);
+}
+
+// what ONE thread does with the node's sums (sums[s] = slot s)
+template <int KINDS>
+__device__ __forceinline__ void tail_finish(const Tail &t, int a, bool mine, const double *sums) {
+  if ((KINDS & TK_REDUCE) && t.kind == TAIL_REDUCE) {
+    for (int q = 0; q < t.nslots; q++) __hip_atomic_store(t.host + a * MAX_SLOTS + q, sums[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    flag_arrive(t.arrived, (unsigned)t.expected, -1, nullptr, t.host_flag, t.seq, t.dev_seq);
+  }
+  if ((KINDS & (TK_CG0 | TK_CG1)) && (t.kind == TAIL_CG0 || t.kind == TAIL_CG1)) {
+    const int phase = t.kind == TAIL_CG0 ? 0 : 1;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
     if (mine) {
-      cg[a] = c;
-      // a node that stops leaves dmask[1] now; dmask[0] (the nodes of the step under way, which still take the
-      // s / H s update of this step) follows at the end of phase 1
-      if (!c.live) {
-        atomicAnd(dmask + 1, ~(1ull << a));
-        atomicOr(dmask + 2, 1ull << a);    // ... and joins the nodes whose trial point can be taken
+      v[0] = sums[0];
+      if (phase == 0) { v[1] = sums[1]; v[2] = sums[2]; v[3] = sums[3]; }
+    }
+    cg_scal_node(a, phase, mine, v, t.cg, t.dmask, t.host);
+    flag_arrive(t.arrived, (unsigned)t.expected, phase, t.dmask, t.host_flag, t.seq, t.dev_seq);
+  }
+  if ((KINDS & TK_TNT) && t.kind == TAIL_TNT) {
+    // (k_tnt_begin leaves the preconditioner's two sums at zero without one)
+    const double v[6] = {sums[0], sums[1], sums[2], sums[3], t.use_precon ? sums[MAX_DOTS] : 0.0, t.use_precon ? sums[MAX_DOTS + 1] : 0.0};
+    tnt_begin_node(a, true, v, t.use_precon, t.max_it, t.grad_tol, t.pgrad_tol, t.kappa, t.theta, t.Delta, t.cg, t.dmask, t.host);
+    // the nodes outside the candidates: their bits go (k_tnt_begin's workgroups of those nodes did it)
+    atomicAnd(t.dmask + 0, t.bits); atomicAnd(t.dmask + 1, t.bits); atomicAnd(t.dmask + 2, t.bits);
+  }
+}
+
+template <int W, int KINDS>
+__device__ __forceinline__ void tail_arrive(const Tail &t, const NodeMask &mask, int a) {
+  static_assert(W == 1 || W == 4, "one wave, or four that share the slots");
+  if (t.kind == TAIL_NONE || !((mask.v >> a) & 1ull)) return;   // (uniform over the workgroup)
+  __shared__ int elected;
+  __shared__ double sums[MAX_SLOTS];
+  int last = 0;
+  if (threadIdx.x == 0) {
+    __threadfence();   // the partial sums of this workgroup are visible to the agent before it counts itself off
+    last = __hip_atomic_fetch_sub(t.node_ctr + a, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == 1u;
+    if (W > 1) elected = last;
+  }
+  if constexpr (W > 1) {
+    __syncthreads();
+    last = elected;
+  } else {
+    last = __shfl(last, 0, 64);
+  }
+  if (!last) return;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int o0 = t.own_ptr[a], o1 = t.own_ptr[a + 1];
+  const int n0 = t.all_rows ? t.nbr_ptr[a] : 0, n1 = t.all_rows ? t.nbr_ptr[a + 1] : 0;
+  // the countdown of this node, for the next launch over the same kind of grid
+  if (threadIdx.x == 0)
+    __hip_atomic_store(t.node_ctr + a, (unsigned)((o1 - o0) + (t.grid_all ? t.nbr_ptr[a + 1] - t.nbr_ptr[a] : 0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // how many slots: a reduction's nslots; the four (one) of a CG phase; the eight that hold the six of a refinement's start
+  const int ns = t.kind == TAIL_REDUCE ? t.nslots : (t.kind == TAIL_TNT ? 8 : (t.kind == TAIL_CG0 ? 4 : 1));
+  bool mine = true;
+  if ((KINDS & (TK_CG0 | TK_CG1)) && (t.kind == TAIL_CG0 || t.kind == TAIL_CG1))
+    mine = (__hip_atomic_load(t.dmask + (t.kind == TAIL_CG0 ? 0 : 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> a) & 1ull;
+  if constexpr (W == 1) {
+    for (int s0 = 0; s0 < ns && mine; s0 += 8) {
+      double v[8];
+      tail_sums<8>(t, s0, 1, o0, o1, n0, n1, lane, v);
+      if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) sums[s0 + q] = v[q];
       }
     }
-    // (the summary has its own pinned area, CG_SUMMARY doubles per node: it must survive the read-back of a trial point
-    // that was enqueued behind this step)
-    __hip_atomic_store(host_scalars + a * CG_SUMMARY + 0, (double)c.live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(host_scalars + a * CG_SUMMARY + 1, c.h_M_norm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(host_scalars + a * CG_SUMMARY + 2, (double)c.cg_it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __atomic_thread_fence(__ATOMIC_RELEASE);
-    const unsigned done = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (done == gridDim.x - 1) {
-      if (phase == 1) dmask[0] = __hip_atomic_load(dmask + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next step's nodes
-      __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (seq == 0) seq = *dev_seq + 1;
-      *dev_seq = seq;
-      __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == 0) tail_finish<KINDS>(t, a, mine, sums);   // (written and read by the same thread)
+  } else {
+    // wave w takes slots w, w + 4, w + 8, w + 12: sixteen slots in one round trip
+    if (mine && wv < ns) {
+      double v[4];
+      tail_sums<4>(t, wv, 4, o0, o1, n0, n1, lane, v);
+      if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) sums[wv + 4 * q] = v[q];
+      }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) tail_finish<KINDS>(t, a, mine, sums);
   }
 }
 
@@ -2236,7 +2447,8 @@ static inline NodeMask whole_grid(NodeMask m) { m.nlive = 0; return m; }   // (l
 
 void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask, const BsrDev &A,
                 const double *x, int mode, const double *addv, double *y, const double *dotv,
-                double coef, const double *dotadd, double *partials, int slot) {
+                double coef, const double *dotadd, double *partials, int slot, double *copy1, double *copy2, const Tail *tail) {
+  const Tail tl = tail ? *tail : Tail();
   if (all_rows) mask = whole_grid(mask);
   const int nb = all_rows ? T.nseg_all : own_grid(T, mask);
   if (nb == 0) return;
@@ -2245,21 +2457,22 @@ void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMas
   DPGO_DISPATCH_D(d, {
     if (mode == 1)
       hipLaunchKernelGGL((k_bsr<D, 1>), dim3(nb), dim3(BSR_LPR * SEG_ROWS), 0, st, T.segs, mask, A, x, addv, y, dotv, coef, dotadd,
-                         part);
+                         part, copy1, copy2, tl);
     else if (mode == 2)
       hipLaunchKernelGGL((k_bsr<D, 2>), dim3(nb), dim3(BSR_LPR * SEG_ROWS), 0, st, T.segs, mask, A, x, addv, y, dotv, coef, dotadd,
-                         part);
+                         part, copy1, copy2, tl);
     else
       hipLaunchKernelGGL((k_bsr<D, 0>), dim3(nb), dim3(BSR_LPR * SEG_ROWS), 0, st, T.segs, mask, A, x, addv, y, dotv, coef, dotadd,
-                         part);
+                         part, copy1, copy2, tl);
   });
 }
 
 void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, const BsrDev &A, const double *tval,
                      const double *xt, const double *base, double *y, int mode, const double *X, const double *nabla,
                      const double *Rdot, double *out2, const double *rres, double *partials, const double *dg,
-                     const double *dga, const double *ds, const double *dgrad, const double *dhs) {
+                     const double *dga, const double *ds, const double *dgrad, const double *dhs, const Tail *tail) {
   if (T.nseg_own == 0) return;
+  const Tail tl = tail ? *tail : Tail();
   // which epilogue sums are produced: mode 2 with rres (a CG step's four), mode 1 with dg (a refinement's start), mode 0 with ds (a trial point's six)
   const bool sums = partials && ((mode == 2 && rres) || (mode == 1 && dg) || (mode == 0 && ds));
   // SURVEY 8(d)'s formula prices the bare pass (the blocks' first columns, the gathered translations, two vectors).  What
@@ -2278,32 +2491,41 @@ void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, co
   TcolDots E;
   E.g = dg; E.ga = dga; E.s = ds; E.grad = dgrad; E.hs = dhs;
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_bsr_tcol<D>), dim3(own_grid(T, mask)), dim3(4 * SEG_ROWS), 0, st, T.segs, mask, A, tval,
-                                        xt, base, y, mode, X, nabla, Rdot, out2, rres, sums ? partials : nullptr, T.nseg_all, E));
+                                        xt, base, y, mode, X, nabla, Rdot, out2, rres, sums ? partials : nullptr, T.nseg_all, E, tl));
 }
 
 void launch_inter(int d, hipStream_t st, const SegTable &T, NodeMask mask, const InterEdgesDev &E, int loss,
                   double loss_reg, int mode, bool quad, const double *Z, const double *Zprev,
                   const double *Qdiag, const double *Ddiag, double *DfE, double *g, double *partials, double *wout,
                   const double *GXc, const double *GXp, const NodeCoefs *gamma, double *Df_out, const double *Znbr,
-                  const double *gamma_dev) {
+                  const double *gamma_dev, const InterFuse *fuse, const Tail *tail) {
   const int nb = mode == 0 ? T.nseg_all : T.nseg_own;
   if (nb == 0) return;
+  const Tail tl = tail ? *tail : Tail();
+  InterFuse F;
+  if (fuse) {
+    if (mode == 0) { F.GX = fuse->GX; F.X = fuse->X; F.Df = fuse->Df; F.gn_slot = fuse->gn_slot; }
+    else { F.Zc = fuse->Zc; F.Zp = fuse->Zp; F.Yout = fuse->Yout; }
+  }
   // operand by operand: per incidence its 128-byte record and the other endpoint's pose; per own pose its record, the previous
   // iterate (majorisation gap), the previous DfobjE read and the new one written, the Q and D blocks, g written, the
   // incidence pointer, and (iterate()) the two kept products G X read and Df written; per neighbour row the same without
   // D and g but with the halo copy it performs on the way
   const double P = 8.0 * (d + 1) * d, B = 8.0 * (d + 1) * (d + 1);
   const double own_b = P + (Zprev ? P : 0) + (DfE ? 2 * P : 0) + (Qdiag ? B : 0) + (Ddiag ? B : 0) + (g ? P : 0) + 8 +
-                       ((mode == 1 && Df_out && GXc && GXp) ? 3 * P : 0);
+                       ((mode == 1 && Df_out && GXc && GXp) ? 3 * P : 0) +
+                       ((fuse && mode == 0 && fuse->Df) ? 3 * P : 0) +     // the product G X and the own record read, Dfobj written
+                       ((fuse && mode == 1 && fuse->Zc) ? 2 * P : 0);      // X[k-1] read, the extrapolated record written
   const double nbr_b = P + (Zprev ? P : 0) + (DfE ? 2 * P : 0) + (Qdiag ? B : 0) + 8 + (Znbr ? 2 * P : 0);
-  const double operands = (double)E.m * (mode == 0 ? 2 : 1) * (128.0 + P) + (double)E.nrows_own * own_b +
+  const double operands = (double)E.m * (mode == 0 ? 2 : 1) * (128.0 + ((fuse && mode == 1 && fuse->Zc) ? 2 * P : P)) + (double)E.nrows_own * own_b +
                           (mode == 0 ? (double)(E.nrows_all - E.nrows_own) * nbr_b : 0.0);
   ProfScope ps(PK_INTER, st, (double)E.m * (8.0 * (d * d + d + 2) + 8) + 2.0 * (mode == 0 ? E.nrows_all : E.nrows_own) * 8.0 * (d + 1) * d, 1, operands);
   InterLin lin;
   if (mode == 1 && Df_out && GXc && GXp && gamma) { lin.GXc = GXc; lin.GXp = GXp; lin.out = Df_out; lin.gamma = *gamma; lin.gamma_dev = gamma_dev; }
+  else if (mode == 1 && F.Zc && gamma) { lin.gamma = *gamma; lin.gamma_dev = gamma_dev; }   // (the extrapolation's gamma alone)
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_inter<D>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, E, loss, loss_reg,
                                         mode, quad ? 1 : 0, T.nseg_own, Z, Zprev, Qdiag, Ddiag, DfE, g, partials,
-                                        T.nseg_all, mode == 0 ? wout : nullptr, lin, mode == 0 ? Znbr : nullptr));
+                                        T.nseg_all, mode == 0 ? wout : nullptr, lin, mode == 0 ? Znbr : nullptr, F, tl));
 }
 
 void launch_rescale_decide(hipStream_t st, int nnodes, NodeBits nodes, const int *e_off, const double *w, double *scale,
@@ -2386,11 +2608,12 @@ void launch_rot_rowscale(int d, hipStream_t st, const SegTable &T, NodeMask mask
 }
 
 void launch_cg_step(int d, hipStream_t st, const SegTable &T, NodeMask mask, const NodeCoefs &C, const double *p,
-                    const double *Hp, double *s, double *hs, double *r, const CgNode *cg, const double *r0) {
+                    const double *Hp, double *s, double *hs, double *r, const CgNode *cg, const double *r0, const double *X,
+                    double *xprop, const NodeBits *rmask) {
   if (T.nseg_own == 0) return;
-  ProfScope ps(PK_AXPBY, st, (r0 ? 6.0 : 8.0) * T.rows_own * 8.0 * (d + 1) * d);
+  ProfScope ps(PK_AXPBY, st, ((r0 ? 6.0 : 8.0) + (xprop ? 2.0 : 0.0)) * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_cg_step<D>), dim3(own_grid(T, mask)), dim3(SEG_ROWS), 0, st, T.segs, mask, C, p, Hp, s, hs,
-                                        r, cg, r0));
+                                        r, cg, r0, X, xprop, rmask));
 }
 
 void launch_cg_dir(int d, hipStream_t st, const SegTable &T, NodeMask mask, const CgNode *cg, const double *v, double *p) {
@@ -2446,12 +2669,14 @@ void launch_cg_init(int d, hipStream_t st, const SegTable &T, NodeMask mask, con
 }
 
 void launch_tangent_full(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
-                         const double *V, double *out, double *partials, int slot, const double *add, double *sum_out) {
+                         const double *V, double *out, double *partials, int slot, const double *add, double *sum_out,
+                         const Tail *tail) {
   if (T.nseg_own == 0) return;
+  const Tail tl = tail ? *tail : Tail();
   double *part = partials ? partials + (size_t)slot * T.nseg_all : nullptr;
   ProfScope ps(PK_ROTOP, st, (add ? 4.0 : 2.0) * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_tangent_full<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, X,
-                                        V, add, sum_out, out, part));
+                                        V, add, sum_out, out, part, tl));
 }
 
 void launch_copy_nbr_rows(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *src, double *dst) {
@@ -2463,12 +2688,14 @@ void launch_copy_nbr_rows(int d, hipStream_t st, const SegTable &T, NodeMask mas
 }
 
 void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
-                        const double *in, double *out, const double *dotv, double *partials, int slot, bool two, double *neg) {
+                        const double *in, double *out, const double *dotv, double *partials, int slot, bool two, double *neg,
+                        const Tail *tail) {
   if (T.nseg_own == 0) return;
+  const Tail tl = tail ? *tail : Tail();
   ProfScope ps(PK_ROTOP, st, (dotv ? 4.0 : 3.0) * T.rows_own * 8.0 * (d + 1) * d);
   double *part = (dotv && partials) ? partials + (size_t)slot * T.nseg_all : nullptr;
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(own_grid(T, mask)), dim3(SEG_ROWS), 0, st, T.segs, mask, 0, X, in,
-                                        dotv, part, out, T.nseg_all, two ? 1 : 0, neg));
+                                        dotv, part, out, T.nseg_all, two ? 1 : 0, neg, tl));
 }
 
 void launch_retract_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
@@ -2476,7 +2703,7 @@ void launch_retract_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask,
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_ROTOP, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(own_grid(T, mask)), dim3(SEG_ROWS), 0, st, T.segs, mask, 2, X, V,
-                                        nullptr, nullptr, out, 0, 0, nullptr));
+                                        nullptr, nullptr, out, 0, 0, nullptr, Tail()));
 }
 
 void launch_copy_indexed(int d, hipStream_t st, int count, const int *didx, const int *sidx, const double *src,
