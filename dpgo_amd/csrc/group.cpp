@@ -699,7 +699,6 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
     segs_.upload(segs);
     own_seg_ptr_.upload(optr);
     own_seg_ptr_host_ = optr;
-    nbr_seg_ptr_host_ = nptr;
     nbr_seg_ptr_.upload(nptr);
     T_.segs = segs_.p;
     T_.nseg_own = nown;
@@ -726,16 +725,7 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   h_upd_ = h_rs_ + std::max(L, 1);   // update()'s sums have a block of their own: the next refinement's sums may arrive before the host has read them
   for (int i = 0; i < std::max(L, 1) * (CG_SUMMARY + TNT_SUMMARY + 1); i++) h_cg_[i] = 0.0;
   reduce_arrived_.alloc(1);
-  {   // the countdowns of the folded reductions (group.h: tail_ctr_)
-    std::vector<unsigned> ctr(2 * MAX_LOCAL_NODES, 0u);
-    for (int a = 0; a < L; a++) {
-      ctr[a] = (unsigned)(own_seg_ptr_host_[a + 1] - own_seg_ptr_host_[a]);
-      ctr[MAX_LOCAL_NODES + a] = ctr[a] + (unsigned)(nbr_seg_ptr_host_[a + 1] - nbr_seg_ptr_host_[a]);
-    }
-    tail_ctr_.upload(ctr);
-    fused_ = env_int("DPGO_FUSED", 1) != 0;
-    tails_ = env_int("DPGO_TAILS", fused_ ? 1 : 0) != 0;
-  }
+  fused_ = env_int("DPGO_FUSED", 1) != 0;
   partials_.alloc((size_t)MAX_SLOTS * std::max(T_.nseg_all, 1));
   cg_.alloc(MAX_LOCAL_NODES);
   dmask_.alloc(4);
@@ -1135,30 +1125,6 @@ NodeMask Group::live_mask(NodeBits bits, const NodeBits *p) const {
     }
   m.idle_seg = own_seg_ptr_host_[idle];
   return m;
-}
-
-bool Group::make_tail(Tail &t, int kind, bool grid_all, bool all_rows, int nslots, double *host, NodeBits mask_v) {
-  t = Tail();
-  if (!tails_ || (int)own_seg_ptr_host_.size() != num_local() + 1) return false;
-  // sums parked by nodes outside this launch's set ride with the next reduction (deferred_slots_): only k_reduce, which sums
-  // for every node of the group, delivers those
-  if (kind == TAIL_REDUCE && (parked_bits_ & ~mask_v) != 0) return false;
-  int expected = 0;
-  for (int a = 0; a < num_local(); a++) {
-    if (!((mask_v >> a) & 1ull)) continue;
-    const int blocks = own_seg_ptr_host_[a + 1] - own_seg_ptr_host_[a] + (grid_all ? nbr_seg_ptr_host_[a + 1] - nbr_seg_ptr_host_[a] : 0);
-    if (blocks == 0) return false;   // (nobody would count this node off)
-    expected++;
-  }
-  if (expected == 0) return false;
-  t.kind = kind; t.all_rows = all_rows ? 1 : 0; t.grid_all = grid_all ? 1 : 0; t.nslots = nslots; t.expected = expected;
-  t.nseg_all = T_.nseg_all; t.own_ptr = T_.own_ptr; t.nbr_ptr = T_.nbr_ptr;
-  t.partials = partials_.p; t.host = host;
-  t.node_ctr = tail_ctr_.p + (grid_all ? MAX_LOCAL_NODES : 0);
-  t.arrived = reduce_arrived_.p; t.host_flag = h_flag_; t.dev_seq = dev_seq_.p;
-  t.cg = cg_.p; t.dmask = dmask_.p;
-  if (kind != TAIL_TNT) t.seq = next_seq();   // (the start of a refinement raises no flag)
-  return true;
 }
 
 void Group::flush_pending_tail() {
@@ -1592,14 +1558,14 @@ void Group::recover_translations(double *X, const double *g) {
 // y = base + G_{:,t} xt.t, with the row-local epilogues of launch_bsr_tcol
 void Group::apply_tcol(const double *xt, const double *base, double *y, int mode, const double *X, const double *nabla,
                        const double *Rdot, double *out2, const double *rres, double *partials, const double *dg,
-                       const double *dga, const double *ds, const double *dgrad, const double *dhs, const Tail *tail) {
+                       const double *dga, const double *ds, const double *dgrad, const double *dhs) {
   launch_bsr_tcol(d_, st_, T_, cur_mask_, G_.dev, G_.tcol.p, xt, base, y, mode, X, nabla, Rdot, out2, rres, partials, dg, dga,
-                  ds, dgrad, dhs, tail);
+                  ds, dgrad, dhs);
 }
 
 // partial[slot] = tr(X^T (g + 1/2 G X))     (DPGOProblem.cpp:180-205; + f on the host)
-void Group::eval_G(const double *X, const double *g, int slot, const Tail *tail) {
-  launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, X, false, nullptr, nullptr, X, 0.5, g, partials_.p, slot, nullptr, nullptr, tail);
+void Group::eval_G(const double *X, const double *g, int slot) {
+  launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, X, false, nullptr, nullptr, X, 0.5, g, partials_.p, slot);
 }
 
 // ---------------------------------------------------------------------------
@@ -2219,18 +2185,17 @@ int Group::update(const std::vector<int> &locals_in) {
   static const bool defer_enabled = env_int("DPGO_DEFER_UPDATE", 1) != 0;
   const bool can_defer = defer_enabled && !star_ && !dynamic() && (first.empty() != later.empty());
   // `launches`: the rest of the surrogate build of the nodes in `set`, ending with the reduction of its sums -- a branch-free
-  // sequence, replayed from a captured graph where the host's launch rate would bound it (segment()).  It is told how many
-  // sums the reduction carries and returns whether its last kernel took the reduction along (kernels.h: Tail); if not,
-  // k_reduce follows.
+  // sequence, replayed from a captured graph where the host's launch rate would bound it (segment()); it may be empty when
+  // the caller has already enqueued everything but the reduction
   auto end_with = [&](int seg_id, unsigned long long variant, int nslots, const std::vector<int> &set,
-                      const std::function<bool(int)> &launches, std::function<void()> logic) {
+                      const std::function<void()> &launches, std::function<void()> logic) {
     nslots = std::max(nslots, deferred_slots_);
     deferred_slots_ = 0;
     NodeBits bits = 0;
     for (int a : set) bits |= 1ull << a;
     segment(seg_id, bits & mask_locals_bits, {bits, mask_locals_bits, variant, (unsigned long long)nslots, fuse_copy ? 1ull : 0ull}, [&] {
-      if (!launches(nslots))
-        launch_reduce(st_, T_, num_local(), true, nslots, partials_.p, h_upd_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
+      launches();
+      launch_reduce(st_, T_, num_local(), true, nslots, partials_.p, h_upd_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
     });
     if (can_defer) {
       pending_seq_ = fetch_seq_;
@@ -2243,13 +2208,6 @@ int Group::update(const std::vector<int> &locals_in) {
       wait_flag(fetch_seq_);
       logic();
     }
-  };
-  // Dfobj = G X + g and |grad F|^2 as the last kernel of a sequence, the reduction riding on it
-  auto tangent_and_reduce = [&](const double *GXv, int slot, int nslots) {
-    Tail tl;
-    const bool rode = make_tail(tl, TAIL_REDUCE, false, true, nslots, h_upd_, cur_mask_.v);
-    launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, GXv, nullptr, partials_.p, slot, gc_.p, Dfc_.p, rode ? &tl : nullptr);
-    return rode;
   };
   zc_ready_ = false;
   if (!zc_done) copy_rows(Zc_.p, Xk_.p, false);
@@ -2289,12 +2247,12 @@ int Group::update(const std::vector<int> &locals_in) {
     if (both) flush_deferred();
     if (both) common();   // (nodes at different iterations: two read-backs, nothing deferred, the shared part goes first)
     if (!first.empty()) {
-      end_with(1, (split ? 1ull : 0ull) | (both ? 2ull : 0ull), 6, first, [&](int nslots) {
+      end_with(1, (split ? 1ull : 0ull) | (both ? 2ull : 0ull), 6, first, [&] {
         if (!both) common();
         set_mask(first);
         launch_bsr(d_, st_, T_, true, cur_mask_, P0m_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 0);
         // fobj = G(Xak | g, f0) = f0 + <Xak, g> + <Xak, 1/2 G Xak>: slots 1 and 5; Dfobj = g + G Xak
-        return tangent_and_reduce(T1_.p, 2, nslots);
+        launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, partials_.p, 2, gc_.p, Dfc_.p);
       }, [this, first] {
         for (int a : first) {
           const double f0 = uscal(a, 0);
@@ -2303,13 +2261,13 @@ int Group::update(const std::vector<int> &locals_in) {
       });
     }
     if (!later.empty()) {
-      end_with(2, (split ? 1ull : 0ull) | (both ? 2ull : 0ull), 4, later, [&](int nslots) {
+      end_with(2, (split ? 1ull : 0ull) | (both ? 2ull : 0ull), 4, later, [&] {
         if (!both) common();
         set_mask(later);
         launch_axpby(d_, st_, T_, true, cur_mask_, 1.0, Zc_.p, -1.0, Zp_.p, Tall_.p, 0);
         launch_bsr(d_, st_, T_, true, cur_mask_, Q_.dev, Tall_.p, false, nullptr, nullptr, Tall_.p, 0.5, nullptr, partials_.p, 0);
         launch_bsr(d_, st_, T_, true, cur_mask_, P_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 3);
-        return tangent_and_reduce(T1_.p, 2, nslots);
+        launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, partials_.p, 2, gc_.p, Dfc_.p);
       }, [this, later] {
         for (int a : later) {
           const double fobj = res_[a].Gk + uscal(a, 0);
@@ -2329,14 +2287,14 @@ int Group::update(const std::vector<int> &locals_in) {
       const std::vector<int> &set = pass == 0 ? first : later;
       if (set.empty()) continue;
       std::vector<double> rho(num_local(), 0.0), gap(num_local(), 0.0);
-      // fz: what the pass does on the way (Dfobj and |grad F|^2); tl: the reduction it takes along
-      auto inter_pass = [&](const InterFuse *fz, const Tail *tl) {
+      // fz: what the pass does on the way (Dfobj and |grad F|^2)
+      auto inter_pass = [&](const InterFuse *fz) {
         launch_inter(d_, st_, T_, cur_mask_, E_, opt_.loss, opt_.loss_reg, 0, pass == 1, Zc_.p, Zp_.p, Qd_.p, Dd_.p, DfE_.p,
-                     gc_.p, partials_.p, dynamic() ? e_w_.p : nullptr, nullptr, nullptr, nullptr, nullptr, Xk_.p, nullptr, fz, tl);   // slots 0, 1 and 2 = <X, g>
+                     gc_.p, partials_.p, dynamic() ? e_w_.p : nullptr, nullptr, nullptr, nullptr, nullptr, Xk_.p, nullptr, fz);   // slots 0, 1 and 2 = <X, g>
       };
       if (dynamic()) {
         set_mask(set);
-        inter_pass(nullptr, nullptr);
+        inter_pass(nullptr);
         if (device_rescale_)   // the rescale test on the weights just computed; its verdict rides with the sums below
           launch_rescale_decide(st_, num_local(), cur_mask_.v, e_off_dev_.p, e_w_.p, e_scale_.p, rs_count_.p, opt_.max_rescale_count,
                                 rs_flags_.p, h_rs_);
@@ -2362,27 +2320,23 @@ int Group::update(const std::vector<int> &locals_in) {
       const bool dyn = dynamic();
       NodeBits fresh_bits = 0;
       for (int a : fresh) fresh_bits |= 1ull << a;
-      end_with(3 + pass, (split ? 1ull : 0ull) | (head_inside ? 2ull : 0ull) | (dyn ? 4ull : 0ull) | (fused_ ? 8ull : 0ull) | (tails_ ? 16ull : 0ull) | (fresh_bits << 5), 6, set, [&](int nslots) {
+      end_with(3 + pass, (split ? 1ull : 0ull) | (head_inside ? 2ull : 0ull) | (dyn ? 4ull : 0ull) | (fused_ ? 8ull : 0ull) | (fresh_bits << 4), 6, set, [&] {
         if (head_inside) head();
         set_mask(set);
+        // Dfobj = G X + g, its tangent projection and norm: inside the inter-edge pass (kernels.h: InterFuse), or k_tangent_full
+        const bool in_pass = !dyn && fused_;
+        if (!dyn) {
+          InterFuse fz;
+          fz.GX = GX; fz.X = Xak_.p; fz.Df = Dfc_.p; fz.gn_slot = 4;
+          inter_pass(in_pass ? &fz : nullptr);
+        }
+        if (pass == 0) launch_bdiag_dot(d_, st_, T_, cur_mask_, Dd_.p, Zc_.p, 0.5, DfE_.p, -1.0, partials_.p, 3);
+        if (!in_pass) launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, GX, nullptr, partials_.p, 4, gc_.p, Dfc_.p);   // Dfobj = G X + g
         if (!fresh.empty()) {
           set_mask(fresh);
           copy_rows(GXp_.p, GXc_.p, false);
           set_mask(set);
         }
-        const bool in_pass = !dyn && fused_;   // Dfobj = G X + g, its tangent projection and norm inside the inter-edge pass
-        if (!dyn) {
-          InterFuse fz;
-          fz.GX = GX; fz.X = Xak_.p; fz.Df = Dfc_.p; fz.gn_slot = 4;
-          Tail tl;
-          // (the reduction rides on the pass where nothing follows it: every update() but a node's first)
-          const bool rode = in_pass && pass == 1 && make_tail(tl, TAIL_REDUCE, true, true, nslots, h_upd_, cur_mask_.v);
-          inter_pass(in_pass ? &fz : nullptr, rode ? &tl : nullptr);
-          if (rode) return true;
-        }
-        if (pass == 0) launch_bdiag_dot(d_, st_, T_, cur_mask_, Dd_.p, Zc_.p, 0.5, DfE_.p, -1.0, partials_.p, 3);
-        if (!in_pass) return tangent_and_reduce(GX, 4, nslots);   // Dfobj = G X + g
-        return false;
       }, [this, set, pass, dyn, rho, gap] {
         for (int a : set) {
           NodeResults &r = res_[a];
@@ -2480,7 +2434,9 @@ int Group::mm(const std::vector<int> &locals) {
 // Y = X[k] + gamma (X[k] - X[k-1]) and the surrogate gradient data at Y, for the masked nodes
 // (gam_dev: the same gammas in device memory -- the launches may be replayed from a captured graph, whose by-value
 // arguments are frozen: amm())
-void Group::prepare_extrapolated(const double *gam_dev) {
+// prox_slot >= 0: the caller's next step is Xakh = proximal(Y, Df) with |Xakh - Xak|^2 into that partial slot and Xak's
+// rotations <- Xakh's (amm()); returns true when the inter-edge pass took it along (kernels.h: InterFuse::Xout)
+bool Group::prepare_extrapolated(const double *gam_dev, int prox_slot) {
   const Options &o = opt_;
   const bool trivial = (o.loss == 0);
   NodeCoefs gam;
@@ -2492,14 +2448,17 @@ void Group::prepare_extrapolated(const double *gam_dev) {
     InterFuse fz;
     fz.Zc = Zc_.p; fz.Zp = Zp_.p; fz.Yout = Y_.p;
     if (keep_gx()) {
+      const bool prox = prox_slot >= 0;
+      if (prox) { fz.Xout = Xakh_.p; fz.Xref = Xak_.p; fz.Tinv = Tinv_.p; fz.Nv = N_.p; fz.Vb = V_.p; fz.gn_slot = prox_slot; }
       launch_inter(d_, st_, T_, cur_mask_, E_, o.loss, o.loss_reg, 1, false, Y_.p, nullptr, nullptr, Dd_.p, nullptr, gx_.p,
-                   partials_.p, nullptr, GXc_.p, GXp_.p, &gam, Dfx_.p, nullptr, gam_dev, &fz);
+                   partials_.p, nullptr, GXc_.p, GXp_.p, &gam, prox ? nullptr : Dfx_.p, nullptr, gam_dev, &fz);
+      return prox;
     } else {
       launch_inter(d_, st_, T_, cur_mask_, E_, o.loss, o.loss_reg, 1, false, Y_.p, nullptr, nullptr, Dd_.p, nullptr, gx_.p,
                    partials_.p, nullptr, nullptr, nullptr, &gam, nullptr, nullptr, gam_dev, &fz);
       launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Y_.p, false, gx_.p, Dfx_.p, nullptr, 0, nullptr, nullptr, 0);
     }
-    return;
+    return false;
   }
   launch_extrapolate(d_, st_, T_, true, cur_mask_, gam, Zc_.p, Zp_.p, Y_.p, gam_dev);
   if (trivial) {
@@ -2516,6 +2475,7 @@ void Group::prepare_extrapolated(const double *gam_dev) {
       launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Y_.p, false, gx_.p, Dfx_.p, nullptr, 0, nullptr, nullptr, 0);
     }
   }
+  return false;
 }
 
 // DPGOHash::amm_pgo  (DPGOHash.cpp:230-444)
@@ -2535,10 +2495,10 @@ int Group::amm(const std::vector<int> &locals) {
   const NodeMask mask_locals = cur_mask_;
   auto head_of_iteration = [&, gam_dev, mask_locals] {
     cur_mask_ = mask_locals;
-    prepare_extrapolated(gam_dev);
     // Xakh = proximal(Y, Df); Gkh = G(Xakh | g[k], f); |Xakh - Xak|^2    (:363-367)
     // (these three scalars sit in slots DS.. and are read back together with the first scalars of TNT)
-    launch_proximal(d_, st_, T_, cur_mask_, Y_.p, Dfx_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, Xak_.p, partials_.p, DS);
+    if (!prepare_extrapolated(gam_dev, DS))
+      launch_proximal(d_, st_, T_, cur_mask_, Y_.p, Dfx_.p, Tinv_.p, N_.p, V_.p, Xakh_.p, Xak_.p, partials_.p, DS);
     // Gkh = G(Xakh | g[k]) needs G Xakh; the translations of Xak = [. ; Xakh.R] need G [0 ; Xakh.R] + g: one pass over
     // G gives both (T1_ = G [0 ; R] + gx, slot DS + 1 = <Xakh, 1/2 G Xakh + gc>), then the solve   (:363-372)
     launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xakh_.p, 2, gx_.p, T1_.p, Xakh_.p, 0.5, gc_.p, partials_.p, DS + 1);
@@ -2575,7 +2535,6 @@ int Group::amm(const std::vector<int> &locals) {
   if (speculate) {
     const std::function<bool()> confirm = decide_refined;
     deferred_slots_ = DS + 3;
-    parked_bits_ = mask_locals.v;
     done_tnt = run_tnt(locals, Xak_.p, gx_.p, gc_.p, true, &confirm);
     abandoned = !done_tnt;
     if (done_tnt) {
@@ -2597,22 +2556,18 @@ int Group::amm(const std::vector<int> &locals) {
     // Gk for nodes that are not refined; refined nodes run TNT first (:374-383)
     if (ref.empty()) {   // (the regime once the gradient is small: the pass and its read-back as one segment)
       segment(11, cur_mask_.v, {}, [&] {
-        Tail tl;
-        const bool rode = make_tail(tl, TAIL_REDUCE, false, false, DS + 3, h_scal_, cur_mask_.v);
-        eval_G(Xak_.p, gc_.p, DS + 2, rode ? &tl : nullptr);
-        if (!rode) launch_reduce(st_, T_, num_local(), false, DS + 3, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
+        eval_G(Xak_.p, gc_.p, DS + 2);
+        launch_reduce(st_, T_, num_local(), false, DS + 3, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
       });
       wait_flag(fetch_seq_);
     } else {
       if (!plain.empty()) eval_G(Xak_.p, gc_.p, DS + 2);
       deferred_slots_ = DS + 3;
-      parked_bits_ = mask_locals.v;
       // TNT minimises G(. | g extrapolated); Gk is G(. | g[k]) at the refined point (:377-383)
       run_tnt(ref, Xak_.p, gx_.p, gc_.p, true);
       for (int a : ref) res_[a].Gk = res_[a].Gk_alt;
     }
   }
-  parked_bits_ = 0;
   spec_refined_ = true;
   for (int a : locals) spec_refined_ = spec_refined_ && res_[a].refined;
   spec_refined_ = spec_refined_ && (int)locals.size() == num_local();

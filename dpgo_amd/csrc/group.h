@@ -399,18 +399,10 @@ class Group {
   // the mask of the nodes in `bits` (and-ed on the device with *p, if any) with the map that lets own-segment launches
   // cover these nodes only (kernels.h: NodeMask::nlive) when they are few
   NodeMask live_mask(NodeBits bits, const NodeBits *p) const;
-  std::vector<int> own_seg_ptr_host_, nbr_seg_ptr_host_;
-  // ---- reductions folded into their producers (kernels.h: Tail).  tail_ctr_: the countdowns of the nodes' workgroups, [a] for
-  // a grid over own segments, [MAX_LOCAL_NODES + a] for one over own and neighbour segments.  make_tail: the Tail of a launch
-  // over the nodes of mask_v (grid_all: its grid covers the neighbour segments too; all_rows: so do the sums); false -- the
-  // launch goes without, and the kernel it would have replaced is launched behind it -- when tails are switched off
-  // (DPGO_TAILS=0, A/B hook) or a node of the set has no workgroup in such a grid (it would never be counted off).
-  DevBuf<unsigned> tail_ctr_;
-  bool tails_ = true;
-  // the other fusions of round 6 (extrapolation and Dfobj inside the inter-edge pass, iterate()'s tail on the product with G,
-  // the first CG step's vector update with the retraction): DPGO_FUSED=0 gives round 5's launch sequence (A/B hook; same bits)
+  std::vector<int> own_seg_ptr_host_;
+  // the fusions of round 6 (extrapolation and Dfobj inside the inter-edge pass, iterate()'s tail on the product with G, the
+  // first CG step's vector update with the retraction): DPGO_FUSED=0 gives round 5's launch sequence (A/B hook; same bits)
   bool fused_ = true;
-  bool make_tail(Tail &t, int kind, bool grid_all, bool all_rows, int nslots, double *host, NodeBits mask_v);
   // The tail of iterate() -- Xk <- Xak, and the buffer the next update() rotates into X[iter] -- waits for that update()'s
   // product with G, which reads the same records anyway and stores them on the way (k_bsr's copy1 / copy2): armed by step()
   // when no exchange stands between the two (the exchange's pack reads Xk); anything else launches it on its own.
@@ -463,7 +455,7 @@ class Group {
   double starF_ = 0, star_fobj_ = 0, star_fobjh_ = 0;
   int star_branches_ = 0;
   void node_rows_of_global(int a, const double *X, int ld, std::vector<double> &Z) const;
-  void prepare_extrapolated(const double *gam_dev = nullptr);   // Y, g_x, Df_x for the masked nodes
+  bool prepare_extrapolated(const double *gam_dev = nullptr, int prox_slot = -1);   // Y, g_x, Df_x for the masked nodes (+ the proximal step)
   double global_objective(const double *X_own);           // F at the point whose own rows are X_own
   // the master's numbers in ONE read-back: F(X1) [, F(X2)] [, |X1 - ref|^2, |X2 - ref|^2] (null pointers: not wanted)
   int star_sums(const double *X1_own, const double *X2_own, const double *ref_own, double *F1, double *F2, double *d1, double *d2);
@@ -495,7 +487,6 @@ class Group {
   void fetch(int nslots, bool all_rows);                  // -> h_scal_[local * MAX_SLOTS + s]
   void wait_flag(unsigned long long seq);
   int deferred_slots_ = 0;   // slots written earlier that ride along with the next fetch (saves a host round trip)
-  NodeBits parked_bits_ = 0; // ... and the nodes they belong to (make_tail: a folded reduction only sums for its own launch's nodes)
   double scal(int local, int s) const { return h_scal_[local * MAX_SLOTS + s]; }
   double *h_upd_ = nullptr;   // pinned (same allocation): the sums update() ends with
   double uscal(int local, int s) const { return h_upd_[local * MAX_SLOTS + s]; }
@@ -507,9 +498,9 @@ class Group {
                   const double *nabla = nullptr, const double *Rdot = nullptr, double *out2 = nullptr,
                   const double *rres = nullptr, double *partials = nullptr, const double *dg = nullptr,
                   const double *dga = nullptr, const double *ds = nullptr, const double *dgrad = nullptr,
-                  const double *dhs = nullptr, const Tail *tail = nullptr);
+                  const double *dhs = nullptr);
   void recover_translations(double *X, const double *g);  // X.t = -Gtt^-1 (g_t + G_tR X.R) for masked nodes
-  void eval_G(const double *X, const double *g, int slot, const Tail *tail = nullptr);
+  void eval_G(const double *X, const double *g, int slot);
   void host_update_logic(int local, double fobj, double f, double gradFnorm);
   // The read-back that ends update() is deferred where nothing has to be decided yet: update() enqueues the reduction,
   // advances the Nesterov sequence (host_update_pre: s, gamma -- they do not depend on the numbers read back) and

@@ -30,7 +30,7 @@ constexpr int SEG_ROWS = 64;
 #define DPGO_BSR_LPR 4   // (8 lanes per row measured 5 % slower at the headline size, equal at one node per GPU)
 #endif
 constexpr int BSR_LPR = DPGO_BSR_LPR;
-constexpr int MAX_SLOTS = 16;   // per-node scalars one read-back can carry
+constexpr int MAX_SLOTS = 24;   // per-node scalars one read-back can carry; slots 16.. hold the first CG step's sums (k_cg_scal_begin)
 constexpr int MAX_DOTS = 6;     // dot products per k_dots launch (it stores MAX_DOTS consecutive slots)
 
 struct Seg {
@@ -72,32 +72,6 @@ struct alignas(16) CgNode {
 // start values of a CG run, by value (the host knows them from the read-back of the gradient norms)
 struct CgStart {
   double rv[MAX_LOCAL_NODES], Delta[MAX_LOCAL_NODES], target[MAX_LOCAL_NODES];
-};
-
-// ---- reductions folded into their producers ("the last workgroup of a node does it") ----------------------------------
-// The per-node sums of an iteration (k_reduce), the scalar steps of the truncated CG (k_cg_scal) and the start of a
-// refinement (k_tnt_begin) used to be launches of their own behind the kernel that writes the last partial sums.  A launch
-// that carries a Tail does their work itself: every workgroup of a node in mask.v, once its partial sums are stored,
-// fences and counts itself off the node's countdown (node_ctr[node]: the node's workgroups in this kind of grid, restored
-// by the workgroup that takes it to zero); the workgroup that does is the node's LAST one and runs the reduction -- the
-// partial sums in k_reduce's order, so the numbers are the same bits -- and the scalar logic; the last node to finish raises
-// the host's flag.  Nobody waits for anybody.  kind: 1 = k_reduce (nslots sums per node to host[node * MAX_SLOTS + s]),
-// 2 / 3 = k_cg_scal phase 0 / 1, 4 = k_tnt_begin.
-enum { TAIL_NONE = 0, TAIL_REDUCE = 1, TAIL_CG0 = 2, TAIL_CG1 = 3, TAIL_TNT = 4 };
-struct Tail {
-  int kind = TAIL_NONE, all_rows = 0, nslots = 0, expected = 0;   // all_rows: the sums cover the neighbour segments; expected: nodes in mask.v (they all arrive, live or not)
-  int nseg_all = 0, grid_all = 0;   // grid_all: the launch's grid covers the neighbour segments (what the countdown is restored to)
-  const int *own_ptr = nullptr, *nbr_ptr = nullptr;
-  const double *partials = nullptr;
-  double *host = nullptr;
-  unsigned *node_ctr = nullptr, *arrived = nullptr;
-  unsigned long long *host_flag = nullptr, seq = 0, *dev_seq = nullptr;
-  CgNode *cg = nullptr;
-  unsigned long long *dmask = nullptr;
-  // TAIL_TNT (k_tnt_begin's arguments; every candidate starts from the same radius, TNTParams::Delta0)
-  unsigned long long bits = 0;
-  int use_precon = 0, max_it = 0;
-  double grad_tol = 0, pgrad_tol = 0, kappa = 0, theta = 0, Delta = 0;
 };
 
 struct BsrDev {
@@ -142,7 +116,7 @@ void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMas
                 const double *x, int mode, const double *addv, double *y, const double *dotv,
                 double coef, const double *dotadd, double *partials, int slot,
                 // copy1 / copy2: the own rows' records of x are stored there on the way (the tail of iterate(): Xk <- Xak)
-                double *copy1 = nullptr, double *copy2 = nullptr, const Tail *tail = nullptr);
+                double *copy1 = nullptr, double *copy2 = nullptr);
 
 // y = base + A[:, translation column] t over own rows; tval: the first column of every block of A ((d+1) doubles per
 // block), xt: records whose translation row is t.  A quarter of the traffic of launch_bsr.
@@ -159,7 +133,7 @@ void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, co
                      const double *nabla = nullptr, const double *Rdot = nullptr, double *out2 = nullptr,
                      const double *rres = nullptr, double *partials = nullptr, const double *dg = nullptr,
                      const double *dga = nullptr, const double *ds = nullptr, const double *dgrad = nullptr,
-                     const double *dhs = nullptr, const Tail *tail = nullptr);
+                     const double *dhs = nullptr);
 
 // what the robust inter-edge pass does on the way, instead of a launch of its own
 struct InterFuse {
@@ -172,6 +146,11 @@ struct InterFuse {
   // (DPGOHash.cpp:255-256), for the row and for every pose its incidences reach; the own rows are stored to Yout
   const double *Zc = nullptr, *Zp = nullptr;
   double *Yout = nullptr;
+  // mode 1 with the kept products (GXc / GXp: the pass forms Df itself): the proximal half step on the way -- k_proximal's job
+  // (DPGOProblem.cpp:600-632): Xout = proximal(Y, Df), |Xout - Xref|^2 into partial slot gn_slot, Xref's rotations <- Xout's;
+  // Df itself is then only stored if the caller asks for it
+  double *Xout = nullptr, *Xref = nullptr;
+  const double *Tinv = nullptr, *Nv = nullptr, *Vb = nullptr;
 };
 // Robust inter-edge pass (B-form, DPGOProblem.cpp:634-725).
 //  mode 0 (update): all rows.  DfE <- B1^T W B1 Z; own rows also g <- DfE - D z.
@@ -190,7 +169,7 @@ void launch_inter(int d, hipStream_t st, const SegTable &T, NodeMask mask, const
                   // gamma_dev: the same gammas in device memory (launch_set_coefs) -- read instead of `gamma` by a launch that may be
                   // replayed from a captured graph, whose by-value arguments are frozen
                   const double *gamma_dev = nullptr,
-                  const InterFuse *fuse = nullptr, const Tail *tail = nullptr);
+                  const InterFuse *fuse = nullptr);
 
 // ---- Rescale::Dynamic on the device (see k_rescale_decide / k_rescale_apply) ----
 // decide: flags[a] / host_flags[a] = node a (of `nodes`) is rescaled; its scales and counter are updated
@@ -253,7 +232,7 @@ void launch_cg_init(int d, hipStream_t st, const SegTable &T, NodeMask mask, con
 // with add: the vector is V + add, stored to sum_out if given (Dfobj = G X + g from its two halves)
 void launch_tangent_full(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
                          const double *V, double *out, double *partials, int slot, const double *add = nullptr,
-                         double *sum_out = nullptr, const Tail *tail = nullptr);
+                         double *sum_out = nullptr);
 // dst = src on the neighbour rows only
 void launch_copy_nbr_rows(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *src, double *dst);
 // out.Y = Proj_R(in.Y), out.x = 0                                       (DPGOProblem.cpp:164-178)
@@ -261,7 +240,7 @@ void launch_copy_nbr_rows(int d, hipStream_t st, const SegTable &T, NodeMask mas
 // neg: also neg = -out (the first CG direction)
 void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
                         const double *in, double *out, const double *dotv = nullptr, double *partials = nullptr,
-                        int slot = 0, bool two = false, double *neg = nullptr, const Tail *tail = nullptr);
+                        int slot = 0, bool two = false, double *neg = nullptr);
 // out.Y rows = dinv (one entry per rotation row) * in.Y rows: Preconditioner::Jacobi   (DPGOProblem.cpp:96-98, 583-585)
 void launch_rot_rowscale(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *dinv, const double *in, double *out);
 // out.Y = proj_SO(d)(X.Y + V.Y); out.x = 0                              (SOdProduct.h:111-116)
@@ -294,6 +273,13 @@ constexpr int TNT_SUMMARY = 8;   // doubles per node k_tnt_begin writes: the six
 void launch_tnt_begin(hipStream_t st, const SegTable &T, int nnodes, NodeBits bits, bool use_precon, int max_it, double grad_tol,
                       double pgrad_tol, double kappa, double theta, const double *Delta, const double *partials, CgNode *cg,
                       NodeBits *dmask, double *host_tnt);
+// tnt_begin and the phase-0 step of the first CG step in one launch (k_cg_scal_begin): the refinement's six sums in the partial
+// slots 0..3 and MAX_DOTS.., the step's four from slot cg_first_slot() on; the flag protocol of launch_cg_scal
+void launch_cg_scal_begin(hipStream_t st, const SegTable &T, int nnodes, NodeBits bits, bool use_precon, int max_it, double grad_tol,
+                           double pgrad_tol, double kappa, double theta, const double *Delta, const double *partials, CgNode *cg,
+                           NodeBits *dmask, double *host_tnt, double *host_scalars, unsigned *arrived, unsigned long long *host_flag,
+                           unsigned long long seq, unsigned long long *dev_seq);
+int cg_first_slot();
 // cg_begin: state of the nodes in `bits` from the start values; dmask[0] = dmask[1] = the live ones, dmask[2] = the others.
 void launch_cg_begin(hipStream_t st, int nnodes, NodeBits bits, const CgStart &S, int max_it, CgNode *cg, NodeBits *dmask);
 // dmask[0]: the nodes of the step under way; dmask[1]: the nodes that go on after it.

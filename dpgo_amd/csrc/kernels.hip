@@ -287,15 +287,6 @@ __device__ __forceinline__ void tangent_proj(const double *Y, const double *F, d
     }
 }
 
-// ---- reductions folded into their producers (kernels.h: Tail) --------------------------------------------------------
-// tail_arrive<W, KINDS>: called by EVERY thread of a workgroup (of W waves) that belongs to `node` once the workgroup's partial
-// sums are stored (workgroups of a node in mask.v that the device-side mask has switched off call it too: the countdown is sized
-// by the host).  The node's last workgroup runs the tail.  KINDS: the kinds the kernel is ever launched with (bit k = kind k),
-// so that a kernel carries only the code (and the registers) of the tails it can be asked for.  Defined behind k_cg_scal.
-template <int W, int KINDS>
-__device__ __forceinline__ void tail_arrive(const Tail &t, const NodeMask &mask, int node);
-constexpr int TK_REDUCE = 1 << TAIL_REDUCE, TK_CG0 = 1 << TAIL_CG0, TK_CG1 = 1 << TAIL_CG1, TK_TNT = 1 << TAIL_TNT;
-
 // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8).  Segment kernels therefore take segment
 // xcd_seg(blockIdx) instead of segment blockIdx: XCD x works on one contiguous eighth of the rows, so the
 // records its gathers touch (lattice neighbours, a few thousand rows away at most) stay in that XCD's own
@@ -325,7 +316,7 @@ __device__ __forceinline__ int seg_live(const NodeMask &m, int b, int n) {
 template <int D, int MODE>
 __global__ __launch_bounds__(BSR_LPR * SEG_ROWS) void k_bsr(const Seg *segs, NodeMask mask, BsrDev A, const double *x,
                                               const double *addv, double *y, const double *dotv, double coef,
-                                              const double *dotadd, double *partial, double *copy1, double *copy2, Tail tail) {
+                                              const double *dotadd, double *partial, double *copy1, double *copy2) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
   const int si = SEGM(mask);
   const Seg s = segs[si];
@@ -397,7 +388,6 @@ __global__ __launch_bounds__(BSR_LPR * SEG_ROWS) void k_bsr(const Seg *segs, Nod
     }
   }
   if (partial && active) block_store<1, LPR * SEG_ROWS / 64>(part, partial + si, 0);
-  tail_arrive<LPR * SEG_ROWS / 64, TK_REDUCE>(tail, mask, s.node);
 }
 
 // out (d x d) = Proj_R(E - sym(nabla R^T) Rdot): the rotation rows of the Riemannian Hessian-vector product
@@ -443,14 +433,11 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr_tcol(const Seg *segs, Node
                                                          const double *xt, const double *base, double *y, int mode,
                                                          const double *X, const double *nabla, const double *Rdot,
                                                          double *out2, const double *rres, double *partial,
-                                                         int pstride, TcolDots E, Tail tail) {
+                                                         int pstride, TcolDots E) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
   const int si = SEGM(mask);
   const Seg s = segs[si];
-  if (!node_on(mask, s.node)) {   // (partials of a node outside the mask are never read)
-    tail_arrive<4, TK_REDUCE | TK_CG0>(tail, mask, s.node);
-    return;
-  }
+  if (!node_on(mask, s.node)) return;   // (partials of a node outside the mask are never read)
   const int row = s.begin + (threadIdx.x >> 2), j = threadIdx.x & 3;
   double pr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   double acc[RS];
@@ -541,7 +528,6 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr_tcol(const Seg *segs, Node
     }
   }
   if (partial) block_store<6, 4 * SEG_ROWS / 64>(pr, partial + si, pstride);
-  tail_arrive<4, TK_REDUCE | TK_CG0>(tail, mask, s.node);
 }
 
 // ---------------------------------------------------------------------------
@@ -565,6 +551,55 @@ __device__ __forceinline__ void loss_weight(int loss, double dl, double s, doubl
   }
 }
 
+// The proximal step of one pose (DPGOProblem.cpp:600-632): Xout = proximal(z, df); with Xref, returns |Xout - Xref|^2, after
+// which Xref takes over the new rotations (its translations follow from a solve: DPGOHash.cpp:369-372).  Shared by k_proximal
+// and by the inter-edge pass that forms df itself (k_inter, InterFuse::Xout).
+template <int D>
+__device__ __forceinline__ double proximal_row(int row, const double *z, const double *df, const double *Tinv, const double *Nv,
+                                               const double *Vb, double *Xout, double *Xref) {
+  constexpr int RS = Dim<D>::RS;
+  double N[D], V[D * D], M[D * D], R[D * D], out[RS];
+#pragma unroll
+  for (int k = 0; k < D; k++) N[k] = Nv[(size_t)row * D + k];
+#pragma unroll
+  for (int k = 0; k < D * D; k++) V[k] = Vb[(size_t)row * D * D + k];
+  const double T = Tinv[row];
+  // M = -Df_R + N^T Df_t + V R0      (DPGOProblem.cpp:618-620)
+#pragma unroll
+  for (int r = 0; r < D; r++)
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+      double a = fma(N[r], df[c], -df[D + r * D + c]);
+#pragma unroll
+      for (int k = 0; k < D; k++) a = fma(V[r * D + k], z[D + k * D + c], a);
+      M[r * D + c] = a;
+    }
+  project_sod<D>(M, R);
+  // t = t0 - N (R - R0) - T Df_t     (:627-629)
+#pragma unroll
+  for (int c = 0; c < D; c++) {
+    double a = fma(-T, df[c], z[c]);
+#pragma unroll
+    for (int k = 0; k < D; k++) a = fma(-N[k], R[k * D + c] - z[D + k * D + c], a);
+    out[c] = a;
+  }
+#pragma unroll
+  for (int k = 0; k < D * D; k++) out[D + k] = R[k];
+  store_vec<RS>(Xout + (size_t)row * RS, out);
+  double p = 0;
+  if (Xref) {
+    double ref[RS];
+    load_vec<RS>(Xref + (size_t)row * RS, ref);
+#pragma unroll
+    for (int k = 0; k < RS; k++) { const double dd = out[k] - ref[k]; p = fma(dd, dd, p); }
+    // the reference point takes over the new rotations
+#pragma unroll
+    for (int k = D; k < RS; k++) ref[k] = out[k];
+    store_vec<RS>(Xref + (size_t)row * RS, ref);
+  }
+  return p;
+}
+
 struct InterLin {   // (k_inter mode 1) Df at the extrapolated point from the kept products G X[k], G X[k-1]
   const double *GXc = nullptr, *GXp = nullptr;
   double *out = nullptr;
@@ -576,7 +611,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask ma
                                                double dl, int mode, int quad, int nseg_own, const double *Z,
                                                const double *Zprev, const double *Qd, const double *Dd,
                                                double *DfE, double *g, double *partial, int pstride, double *wout,
-                                               InterLin lin, const double *Znbr, InterFuse F, Tail tail) {
+                                               InterLin lin, const double *Znbr, InterFuse F) {
   constexpr int B = Dim<D>::B, RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
   const bool active = node_on(mask, s.node);
@@ -587,7 +622,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask ma
   if (active && row < s.end) {
     double zp[RS], acc[RS];
     const bool xfuse = F.Zc != nullptr;
-    const double gm = (xfuse || lin.out) ? (lin.gamma_dev ? lin.gamma_dev[s.node] : lin.gamma.a[s.node]) : 0.0;
+    const double gm = (xfuse || lin.GXc) ? (lin.gamma_dev ? lin.gamma_dev[s.node] : lin.gamma.a[s.node]) : 0.0;
     // Znbr (mode 0): the neighbour rows are taken from there (the iterate the exchange just delivered) and copied into Z
     // on the way -- update()'s halo copy without a launch of its own.  Nobody reads Z's neighbour rows in this pass.
     const bool from_nbr = Znbr && row >= E.nrows_own;
@@ -731,7 +766,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask ma
         for (int k = 0; k < RS; k++) p = fma(o[k], o[k], p);
         gn[0] = p;
       }
-      if (lin.out) {
+      if (lin.GXc) {
         // Df = g + G Y at the extrapolated point Y = X[k] + gamma (X[k] - X[k-1]), without another pass over G:
         // G Y = G X[k] + gamma (G X[k] - G X[k-1]), both products kept from the last two update()s
         double a[RS], b[RS];
@@ -739,15 +774,18 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask ma
         load_vec<RS>(lin.GXp + (size_t)row * RS, b);
 #pragma unroll
         for (int k = 0; k < RS; k++) acc[k] += fma(gm, a[k] - b[k], a[k]);
-        store_vec<RS>(lin.out + (size_t)row * RS, acc);
+        if (lin.out) store_vec<RS>(lin.out + (size_t)row * RS, acc);
+        if (F.Xout) {
+          // the proximal half step at this row -- k_proximal's operations in its order, on the Df just formed
+          gn[0] = proximal_row<D>(row, zp, acc, F.Tinv, F.Nv, F.Vb, F.Xout, F.Xref);
+        }
       }
     }
   }
   if (active) {
     block_store<3>(part, partial + SEGB, pstride);
-    if (F.Df && own) block_store<1>(gn, partial + (size_t)F.gn_slot * pstride + SEGB, 0);
+    if ((F.Df || F.Xout) && own) block_store<1>(gn, partial + (size_t)F.gn_slot * pstride + SEGB, 0);
   }
-  tail_arrive<1, TK_REDUCE>(tail, mask, s.node);
 }
 
 // ---------------------------------------------------------------------------
@@ -984,48 +1022,10 @@ __global__ __launch_bounds__(SEG_ROWS) void k_proximal(const Seg *segs, NodeMask
   double part[1] = {0.0};
   const int row = s.begin + threadIdx.x;
   if (active && row < s.end) {
-    double z[RS], df[RS], N[D], V[D * D], M[D * D], R[D * D], out[RS];
+    double z[RS], df[RS];
     load_vec<RS>(Z + (size_t)row * RS, z);
     load_vec<RS>(Df + (size_t)row * RS, df);
-#pragma unroll
-    for (int k = 0; k < D; k++) N[k] = Nv[(size_t)row * D + k];
-#pragma unroll
-    for (int k = 0; k < D * D; k++) V[k] = Vb[(size_t)row * D * D + k];
-    const double T = Tinv[row];
-    // M = -Df_R + N^T Df_t + V R0      (DPGOProblem.cpp:618-620)
-#pragma unroll
-    for (int r = 0; r < D; r++)
-#pragma unroll
-      for (int c = 0; c < D; c++) {
-        double a = fma(N[r], df[c], -df[D + r * D + c]);
-#pragma unroll
-        for (int k = 0; k < D; k++) a = fma(V[r * D + k], z[D + k * D + c], a);
-        M[r * D + c] = a;
-      }
-    project_sod<D>(M, R);
-    // t = t0 - N (R - R0) - T Df_t     (:627-629)
-#pragma unroll
-    for (int c = 0; c < D; c++) {
-      double a = fma(-T, df[c], z[c]);
-#pragma unroll
-      for (int k = 0; k < D; k++) a = fma(-N[k], R[k * D + c] - z[D + k * D + c], a);
-      out[c] = a;
-    }
-#pragma unroll
-    for (int k = 0; k < D * D; k++) out[D + k] = R[k];
-    store_vec<RS>(Xout + (size_t)row * RS, out);
-    if (Xref) {
-      double ref[RS];
-      load_vec<RS>(Xref + (size_t)row * RS, ref);
-      double p = 0;
-#pragma unroll
-      for (int k = 0; k < RS; k++) { const double dd = out[k] - ref[k]; p = fma(dd, dd, p); }
-      part[0] = p;
-      // the reference point takes over the new rotations (its translations follow from a solve: DPGOHash.cpp:369-372)
-#pragma unroll
-      for (int k = D; k < RS; k++) ref[k] = out[k];
-      store_vec<RS>(Xref + (size_t)row * RS, ref);
-    }
+    part[0] = proximal_row<D>(row, z, df, Tinv, Nv, Vb, Xout, Xref);
   }
   if (partial && active) block_store<1>(part, partial + SEGB, 0);
 }
@@ -1244,7 +1244,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_dots(const Seg *segs, NodeMask mas
 template <int D>
 __global__ __launch_bounds__(SEG_ROWS) void k_tangent_full(const Seg *segs, NodeMask mask, const double *X,
                                                       const double *V, const double *add, double *sum_out,
-                                                      double *out, double *partial, Tail tail) {
+                                                      double *out, double *partial) {
   constexpr int RS = Dim<D>::RS;
   const Seg s = segs[SEGB];
   const bool active = node_on(mask, s.node);
@@ -1271,7 +1271,6 @@ __global__ __launch_bounds__(SEG_ROWS) void k_tangent_full(const Seg *segs, Node
     if (out) store_vec<RS>(out + (size_t)row * RS, o);
   }
   if (partial && active) block_store<1>(pr, partial + SEGB, 0);
-  tail_arrive<1, TK_REDUCE>(tail, mask, s.node);
 }
 
 // mode 0: out.Y = Proj_R(in.Y)                         (reduced_tangent_space_projection)
@@ -1279,14 +1278,11 @@ __global__ __launch_bounds__(SEG_ROWS) void k_tangent_full(const Seg *segs, Node
 template <int D>
 __global__ __launch_bounds__(SEG_ROWS) void k_rot_op(const Seg *segs, NodeMask mask, int mode, const double *X,
                                                 const double *in, const double *dotv, double *partial,
-                                                double *out, int pstride, int two, double *neg, Tail tail) {
+                                                double *out, int pstride, int two, double *neg) {
   constexpr int RS = Dim<D>::RS;
   const int si = SEGM(mask);
   const Seg s = segs[si];
-  if (!node_on(mask, s.node)) {
-    tail_arrive<1, TK_CG1 | TK_TNT>(tail, mask, s.node);
-    return;
-  }
+  if (!node_on(mask, s.node)) return;
   const int row = s.begin + threadIdx.x;
   double pr[2] = {0.0, 0.0};
   if (row < s.end) {
@@ -1327,7 +1323,6 @@ __global__ __launch_bounds__(SEG_ROWS) void k_rot_op(const Seg *segs, NodeMask m
     if (two) block_store<2>(pr, partial + si, pstride);
     else block_store<1>(reinterpret_cast<const double(&)[1]>(pr), partial + si, 0);
   }
-  tail_arrive<1, TK_CG1 | TK_TNT>(tail, mask, s.node);
 }
 
 // dst[didx[k]] = src[sidx[k]]  (didx == nullptr: dst[k]); halo copies, pack and unpack
@@ -1600,121 +1595,43 @@ __global__ __launch_bounds__(256) void k_cg_scal(SegTable T, int phase, const do
   flag_arrive(arrived, gridDim.x, phase, dmask, host_flag, seq, dev_seq);
 }
 
-// ---- the node's last workgroup (kernels.h: Tail).  A partial-sum slot of node a is summed in k_reduce's order: a lane's
-// segments own_ptr[a] + lane, + 64, ... then the neighbour segments likewise, then the shuffle tree; lane 0 ends up with the
-// total.  The loads of U consecutive positions of NS slots (slot0, slot0 + stride, ...) are in flight together (the tail is a
-// chain of memory round trips on the critical path of its launch); they bypass this XCD's L2, which may hold older lines of
-// the array (the partial sums come from workgroups on every XCD).
-template <int NS, int U>
-__device__ __forceinline__ void tail_range(const Tail &t, int slot0, int stride, int k0, int k1, int lane, double (&v)[NS]) {
-  // (a uniform base per slot and ONE 32-bit lane offset: the loads then need a scalar register pair per slot, not a vector pair)
-  const double *ps[NS];
-#pragma unroll
-  for (int q = 0; q < NS; q++) ps[q] = t.partials + (size_t)min(slot0 + q * stride, MAX_SLOTS - 1) * t.nseg_all;
-  for (unsigned k = (unsigned)(k0 + lane); k < (unsigned)k1; k += 64u * U) {
-    double x[U][NS];
-#pragma unroll
-    for (int u = 0; u < U; u++)
-#pragma unroll
-      for (int q = 0; q < NS; q++)
-        x[u][q] = k + 64u * u < (unsigned)k1 ? __hip_atomic_load(ps[q] + (k + 64u * u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-#pragma unroll
-    for (int u = 0; u < U; u++)
-      if (k + 64u * u < (unsigned)k1) {
-#pragma unroll
-        for (int q = 0; q < NS; q++) v[q] += x[u][q];
-      }
+// k_tnt_begin and the first step's k_cg_scal in one launch: the start of a refinement (norms, gradient tests, CG start
+// values) is only needed from the step-length logic of the first CG step on -- the first Hessian product runs for every
+// candidate (one that fails the gradient tests has done it for nothing; it happens at the very end of a run) -- so both sit
+// behind that product: ten sums per node side by side (the refinement's six from slots 0..3 and MAX_DOTS.., the step's four
+// from slot cg_slot0 on: the product must not overwrite the refinement's), then tnt_begin_node and, for a node whose CG runs,
+// the phase-0 logic.  One workgroup per node, a wave per sum.
+constexpr int CG_FIRST_SLOT = 16;   // (six consecutive slots nobody else uses: the product's epilogue always stores six)
+__global__ __launch_bounds__(640) void k_cg_scal_begin(SegTable T, TntBegin B, const double *partials, CgNode *cg, NodeBits *dmask,
+                                                       double *host_tnt, double *host_scalars, unsigned *arrived,
+                                                       unsigned long long *host_flag, unsigned long long seq,
+                                                       unsigned long long *dev_seq) {
+  __shared__ double sums[10];
+  const int a = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool cand = (B.bits >> a) & 1ull;
+  if (cand && (wv < 4 || wv >= 6 || B.use_precon)) {
+    const int slot = wv < 4 ? wv : (wv < 6 ? MAX_DOTS + (wv - 4) : CG_FIRST_SLOT + (wv - 6));
+    const double *p = partials + (size_t)slot * T.nseg_all;
+    double t = 0;
+    for (int k = T.own_ptr[a] + lane; k < T.own_ptr[a + 1]; k += 64) t += p[k];
+    t = wave_sum(t);
+    if (lane == 0) sums[wv] = t;
+  } else if (lane == 0) {
+    sums[wv] = 0.0;
   }
-}
-template <int NS>
-__device__ __forceinline__ void tail_sums(const Tail &t, int slot0, int stride, int o0, int o1, int n0, int n1, int lane, double (&v)[NS]) {
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double v6[6];
 #pragma unroll
-  for (int q = 0; q < NS; q++) v[q] = 0.0;
-  tail_range<NS, 4>(t, slot0, stride, o0, o1, lane, v);
-  tail_range<NS, 4>(t, slot0, stride, n0, n1, lane, v);
-#pragma unroll
-  for (int q = 0; q < NS; q++) v[q] = wave_sum(v[q]);
-}
-
-// what ONE thread does with the node's sums (sums[s] = slot s)
-template <int KINDS>
-__device__ __forceinline__ void tail_finish(const Tail &t, int a, bool mine, const double *sums) {
-  if ((KINDS & TK_REDUCE) && t.kind == TAIL_REDUCE) {
-    for (int q = 0; q < t.nslots; q++) __hip_atomic_store(t.host + a * MAX_SLOTS + q, sums[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    flag_arrive(t.arrived, (unsigned)t.expected, -1, nullptr, t.host_flag, t.seq, t.dev_seq);
-  }
-  if ((KINDS & (TK_CG0 | TK_CG1)) && (t.kind == TAIL_CG0 || t.kind == TAIL_CG1)) {
-    const int phase = t.kind == TAIL_CG0 ? 0 : 1;
-    double v[4] = {0.0, 0.0, 0.0, 0.0};
-    if (mine) {
-      v[0] = sums[0];
-      if (phase == 0) { v[1] = sums[1]; v[2] = sums[2]; v[3] = sums[3]; }
-    }
-    cg_scal_node(a, phase, mine, v, t.cg, t.dmask, t.host);
-    flag_arrive(t.arrived, (unsigned)t.expected, phase, t.dmask, t.host_flag, t.seq, t.dev_seq);
-  }
-  if ((KINDS & TK_TNT) && t.kind == TAIL_TNT) {
-    // (k_tnt_begin leaves the preconditioner's two sums at zero without one)
-    const double v[6] = {sums[0], sums[1], sums[2], sums[3], t.use_precon ? sums[MAX_DOTS] : 0.0, t.use_precon ? sums[MAX_DOTS + 1] : 0.0};
-    tnt_begin_node(a, true, v, t.use_precon, t.max_it, t.grad_tol, t.pgrad_tol, t.kappa, t.theta, t.Delta, t.cg, t.dmask, t.host);
-    // the nodes outside the candidates: their bits go (k_tnt_begin's workgroups of those nodes did it)
-    atomicAnd(t.dmask + 0, t.bits); atomicAnd(t.dmask + 1, t.bits); atomicAnd(t.dmask + 2, t.bits);
-  }
-}
-
-template <int W, int KINDS>
-__device__ __forceinline__ void tail_arrive(const Tail &t, const NodeMask &mask, int a) {
-  static_assert(W == 1 || W == 4, "one wave, or four that share the slots");
-  if (t.kind == TAIL_NONE || !((mask.v >> a) & 1ull)) return;   // (uniform over the workgroup)
-  __shared__ int elected;
-  __shared__ double sums[MAX_SLOTS];
-  int last = 0;
-  if (threadIdx.x == 0) {
-    __threadfence();   // the partial sums of this workgroup are visible to the agent before it counts itself off
-    last = __hip_atomic_fetch_sub(t.node_ctr + a, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == 1u;
-    if (W > 1) elected = last;
-  }
-  if constexpr (W > 1) {
-    __syncthreads();
-    last = elected;
-  } else {
-    last = __shfl(last, 0, 64);
-  }
-  if (!last) return;
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int o0 = t.own_ptr[a], o1 = t.own_ptr[a + 1];
-  const int n0 = t.all_rows ? t.nbr_ptr[a] : 0, n1 = t.all_rows ? t.nbr_ptr[a + 1] : 0;
-  // the countdown of this node, for the next launch over the same kind of grid
-  if (threadIdx.x == 0)
-    __hip_atomic_store(t.node_ctr + a, (unsigned)((o1 - o0) + (t.grid_all ? t.nbr_ptr[a + 1] - t.nbr_ptr[a] : 0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // how many slots: a reduction's nslots; the four (one) of a CG phase; the eight that hold the six of a refinement's start
-  const int ns = t.kind == TAIL_REDUCE ? t.nslots : (t.kind == TAIL_TNT ? 8 : (t.kind == TAIL_CG0 ? 4 : 1));
-  bool mine = true;
-  if ((KINDS & (TK_CG0 | TK_CG1)) && (t.kind == TAIL_CG0 || t.kind == TAIL_CG1))
-    mine = (__hip_atomic_load(t.dmask + (t.kind == TAIL_CG0 ? 0 : 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> a) & 1ull;
-  if constexpr (W == 1) {
-    for (int s0 = 0; s0 < ns && mine; s0 += 8) {
-      double v[8];
-      tail_sums<8>(t, s0, 1, o0, o1, n0, n1, lane, v);
-      if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < 8; q++) sums[s0 + q] = v[q];
-      }
-    }
-    if (lane == 0) tail_finish<KINDS>(t, a, mine, sums);   // (written and read by the same thread)
-  } else {
-    // wave w takes slots w, w + 4, w + 8, w + 12: sixteen slots in one round trip
-    if (mine && wv < ns) {
-      double v[4];
-      tail_sums<4>(t, wv, 4, o0, o1, n0, n1, lane, v);
-      if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) sums[wv + 4 * q] = v[q];
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) tail_finish<KINDS>(t, a, mine, sums);
-  }
+  for (int q = 0; q < 6; q++) v6[q] = sums[q];
+  tnt_begin_node(a, cand, v6, B.use_precon, B.max_it, B.grad_tol, B.pgrad_tol, B.kappa, B.theta, B.Delta[a], cg, dmask, host_tnt);
+  // (the node's own bit of dmask[0], as tnt_begin_node has just left it: nobody else writes it)
+  const bool mine = cand && cg[a].live;
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  if (mine)
+    for (int q = 0; q < 4; q++) v[q] = sums[6 + q];
+  cg_scal_node(a, 0, mine, v, cg, dmask, host_scalars);
+  flag_arrive(arrived, gridDim.x, 0, dmask, host_flag, seq, dev_seq);
 }
 
 #ifdef SPD_TRACE   /* measurement build only: per-tile phase timestamps (100 MHz wall clock), see spd_profile() */
@@ -2447,8 +2364,7 @@ static inline NodeMask whole_grid(NodeMask m) { m.nlive = 0; return m; }   // (l
 
 void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask, const BsrDev &A,
                 const double *x, int mode, const double *addv, double *y, const double *dotv,
-                double coef, const double *dotadd, double *partials, int slot, double *copy1, double *copy2, const Tail *tail) {
-  const Tail tl = tail ? *tail : Tail();
+                double coef, const double *dotadd, double *partials, int slot, double *copy1, double *copy2) {
   if (all_rows) mask = whole_grid(mask);
   const int nb = all_rows ? T.nseg_all : own_grid(T, mask);
   if (nb == 0) return;
@@ -2457,22 +2373,21 @@ void launch_bsr(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMas
   DPGO_DISPATCH_D(d, {
     if (mode == 1)
       hipLaunchKernelGGL((k_bsr<D, 1>), dim3(nb), dim3(BSR_LPR * SEG_ROWS), 0, st, T.segs, mask, A, x, addv, y, dotv, coef, dotadd,
-                         part, copy1, copy2, tl);
+                         part, copy1, copy2);
     else if (mode == 2)
       hipLaunchKernelGGL((k_bsr<D, 2>), dim3(nb), dim3(BSR_LPR * SEG_ROWS), 0, st, T.segs, mask, A, x, addv, y, dotv, coef, dotadd,
-                         part, copy1, copy2, tl);
+                         part, copy1, copy2);
     else
       hipLaunchKernelGGL((k_bsr<D, 0>), dim3(nb), dim3(BSR_LPR * SEG_ROWS), 0, st, T.segs, mask, A, x, addv, y, dotv, coef, dotadd,
-                         part, copy1, copy2, tl);
+                         part, copy1, copy2);
   });
 }
 
 void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, const BsrDev &A, const double *tval,
                      const double *xt, const double *base, double *y, int mode, const double *X, const double *nabla,
                      const double *Rdot, double *out2, const double *rres, double *partials, const double *dg,
-                     const double *dga, const double *ds, const double *dgrad, const double *dhs, const Tail *tail) {
+                     const double *dga, const double *ds, const double *dgrad, const double *dhs) {
   if (T.nseg_own == 0) return;
-  const Tail tl = tail ? *tail : Tail();
   // which epilogue sums are produced: mode 2 with rres (a CG step's four), mode 1 with dg (a refinement's start), mode 0 with ds (a trial point's six)
   const bool sums = partials && ((mode == 2 && rres) || (mode == 1 && dg) || (mode == 0 && ds));
   // SURVEY 8(d)'s formula prices the bare pass (the blocks' first columns, the gathered translations, two vectors).  What
@@ -2491,21 +2406,25 @@ void launch_bsr_tcol(int d, hipStream_t st, const SegTable &T, NodeMask mask, co
   TcolDots E;
   E.g = dg; E.ga = dga; E.s = ds; E.grad = dgrad; E.hs = dhs;
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_bsr_tcol<D>), dim3(own_grid(T, mask)), dim3(4 * SEG_ROWS), 0, st, T.segs, mask, A, tval,
-                                        xt, base, y, mode, X, nabla, Rdot, out2, rres, sums ? partials : nullptr, T.nseg_all, E, tl));
+                                        xt, base, y, mode, X, nabla, Rdot, out2, rres, sums ? partials : nullptr, T.nseg_all, E));
 }
 
 void launch_inter(int d, hipStream_t st, const SegTable &T, NodeMask mask, const InterEdgesDev &E, int loss,
                   double loss_reg, int mode, bool quad, const double *Z, const double *Zprev,
                   const double *Qdiag, const double *Ddiag, double *DfE, double *g, double *partials, double *wout,
                   const double *GXc, const double *GXp, const NodeCoefs *gamma, double *Df_out, const double *Znbr,
-                  const double *gamma_dev, const InterFuse *fuse, const Tail *tail) {
+                  const double *gamma_dev, const InterFuse *fuse) {
   const int nb = mode == 0 ? T.nseg_all : T.nseg_own;
   if (nb == 0) return;
-  const Tail tl = tail ? *tail : Tail();
   InterFuse F;
   if (fuse) {
     if (mode == 0) { F.GX = fuse->GX; F.X = fuse->X; F.Df = fuse->Df; F.gn_slot = fuse->gn_slot; }
-    else { F.Zc = fuse->Zc; F.Zp = fuse->Zp; F.Yout = fuse->Yout; }
+    else {
+      F.Zc = fuse->Zc; F.Zp = fuse->Zp; F.Yout = fuse->Yout;
+      if (fuse->Xout && Df_out == nullptr && GXc && GXp && gamma) {   // (the proximal step needs the Df this pass forms)
+        F.Xout = fuse->Xout; F.Xref = fuse->Xref; F.Tinv = fuse->Tinv; F.Nv = fuse->Nv; F.Vb = fuse->Vb; F.gn_slot = fuse->gn_slot;
+      }
+    }
   }
   // operand by operand: per incidence its 128-byte record and the other endpoint's pose; per own pose its record, the previous
   // iterate (majorisation gap), the previous DfobjE read and the new one written, the Q and D blocks, g written, the
@@ -2516,16 +2435,17 @@ void launch_inter(int d, hipStream_t st, const SegTable &T, NodeMask mask, const
                        ((mode == 1 && Df_out && GXc && GXp) ? 3 * P : 0) +
                        ((fuse && mode == 0 && fuse->Df) ? 3 * P : 0) +     // the product G X and the own record read, Dfobj written
                        ((fuse && mode == 1 && fuse->Zc) ? 2 * P : 0);      // X[k-1] read, the extrapolated record written
+  const double prox_b = (fuse && mode == 1 && fuse->Xout) ? (2 * P + 8.0 * (1 + d + d * d) + 8.0 * d * d - P) : 0.0;   // Xakh written, Xak read and its rotations written, T / N / V; Df no longer written
   const double nbr_b = P + (Zprev ? P : 0) + (DfE ? 2 * P : 0) + (Qdiag ? B : 0) + 8 + (Znbr ? 2 * P : 0);
-  const double operands = (double)E.m * (mode == 0 ? 2 : 1) * (128.0 + ((fuse && mode == 1 && fuse->Zc) ? 2 * P : P)) + (double)E.nrows_own * own_b +
+  const double operands = (double)E.m * (mode == 0 ? 2 : 1) * (128.0 + ((fuse && mode == 1 && fuse->Zc) ? 2 * P : P)) + (double)E.nrows_own * (own_b + prox_b) +
                           (mode == 0 ? (double)(E.nrows_all - E.nrows_own) * nbr_b : 0.0);
   ProfScope ps(PK_INTER, st, (double)E.m * (8.0 * (d * d + d + 2) + 8) + 2.0 * (mode == 0 ? E.nrows_all : E.nrows_own) * 8.0 * (d + 1) * d, 1, operands);
   InterLin lin;
-  if (mode == 1 && Df_out && GXc && GXp && gamma) { lin.GXc = GXc; lin.GXp = GXp; lin.out = Df_out; lin.gamma = *gamma; lin.gamma_dev = gamma_dev; }
+  if (mode == 1 && (Df_out || F.Xout) && GXc && GXp && gamma) { lin.GXc = GXc; lin.GXp = GXp; lin.out = Df_out; lin.gamma = *gamma; lin.gamma_dev = gamma_dev; }
   else if (mode == 1 && F.Zc && gamma) { lin.gamma = *gamma; lin.gamma_dev = gamma_dev; }   // (the extrapolation's gamma alone)
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_inter<D>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, E, loss, loss_reg,
                                         mode, quad ? 1 : 0, T.nseg_own, Z, Zprev, Qdiag, Ddiag, DfE, g, partials,
-                                        T.nseg_all, mode == 0 ? wout : nullptr, lin, mode == 0 ? Znbr : nullptr, F, tl));
+                                        T.nseg_all, mode == 0 ? wout : nullptr, lin, mode == 0 ? Znbr : nullptr, F));
 }
 
 void launch_rescale_decide(hipStream_t st, int nnodes, NodeBits nodes, const int *e_off, const double *w, double *scale,
@@ -2637,6 +2557,20 @@ void launch_tnt_begin(hipStream_t st, const SegTable &T, int nnodes, NodeBits bi
   hipLaunchKernelGGL(k_tnt_begin, dim3(nnodes), dim3(384), 0, st, T, nnodes, B, partials, cg, dmask, host_tnt);
 }
 
+void launch_cg_scal_begin(hipStream_t st, const SegTable &T, int nnodes, NodeBits bits, bool use_precon, int max_it, double grad_tol,
+                           double pgrad_tol, double kappa, double theta, const double *Delta, const double *partials, CgNode *cg,
+                           NodeBits *dmask, double *host_tnt, double *host_scalars, unsigned *arrived, unsigned long long *host_flag,
+                           unsigned long long seq, unsigned long long *dev_seq) {
+  TntBegin B;
+  B.bits = bits; B.use_precon = use_precon; B.max_it = max_it;
+  B.grad_tol = grad_tol; B.pgrad_tol = pgrad_tol; B.kappa = kappa; B.theta = theta;
+  for (int a = 0; a < MAX_LOCAL_NODES; a++) B.Delta[a] = a < nnodes ? Delta[a] : 0.0;
+  ProfScope ps(PK_REDUCE, st, 8.0 * 10 * T.nseg_own);
+  hipLaunchKernelGGL(k_cg_scal_begin, dim3(nnodes), dim3(640), 0, st, T, B, partials, cg, dmask, host_tnt, host_scalars, arrived,
+                     host_flag, seq, dev_seq);
+}
+int cg_first_slot() { return CG_FIRST_SLOT; }
+
 void launch_cg_scal(hipStream_t st, const SegTable &T, int nnodes, int phase, const double *partials, CgNode *cg,
                     NodeBits *dmask, double *host_scalars, unsigned *arrived, unsigned long long *host_flag,
                     unsigned long long seq, unsigned long long *dev_seq) {
@@ -2669,14 +2603,12 @@ void launch_cg_init(int d, hipStream_t st, const SegTable &T, NodeMask mask, con
 }
 
 void launch_tangent_full(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
-                         const double *V, double *out, double *partials, int slot, const double *add, double *sum_out,
-                         const Tail *tail) {
+                         const double *V, double *out, double *partials, int slot, const double *add, double *sum_out) {
   if (T.nseg_own == 0) return;
-  const Tail tl = tail ? *tail : Tail();
   double *part = partials ? partials + (size_t)slot * T.nseg_all : nullptr;
   ProfScope ps(PK_ROTOP, st, (add ? 4.0 : 2.0) * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_tangent_full<D>), dim3(T.nseg_own), dim3(SEG_ROWS), 0, st, T.segs, mask, X,
-                                        V, add, sum_out, out, part, tl));
+                                        V, add, sum_out, out, part));
 }
 
 void launch_copy_nbr_rows(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *src, double *dst) {
@@ -2688,14 +2620,12 @@ void launch_copy_nbr_rows(int d, hipStream_t st, const SegTable &T, NodeMask mas
 }
 
 void launch_tangent_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
-                        const double *in, double *out, const double *dotv, double *partials, int slot, bool two, double *neg,
-                        const Tail *tail) {
+                        const double *in, double *out, const double *dotv, double *partials, int slot, bool two, double *neg) {
   if (T.nseg_own == 0) return;
-  const Tail tl = tail ? *tail : Tail();
   ProfScope ps(PK_ROTOP, st, (dotv ? 4.0 : 3.0) * T.rows_own * 8.0 * (d + 1) * d);
   double *part = (dotv && partials) ? partials + (size_t)slot * T.nseg_all : nullptr;
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(own_grid(T, mask)), dim3(SEG_ROWS), 0, st, T.segs, mask, 0, X, in,
-                                        dotv, part, out, T.nseg_all, two ? 1 : 0, neg, tl));
+                                        dotv, part, out, T.nseg_all, two ? 1 : 0, neg));
 }
 
 void launch_retract_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *X,
@@ -2703,7 +2633,7 @@ void launch_retract_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask,
   if (T.nseg_own == 0) return;
   ProfScope ps(PK_ROTOP, st, 3.0 * T.rows_own * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_rot_op<D>), dim3(own_grid(T, mask)), dim3(SEG_ROWS), 0, st, T.segs, mask, 2, X, V,
-                                        nullptr, nullptr, out, 0, 0, nullptr, Tail()));
+                                        nullptr, nullptr, out, 0, 0, nullptr));
 }
 
 void launch_copy_indexed(int d, hipStream_t st, int count, const int *didx, const int *sidx, const double *src,

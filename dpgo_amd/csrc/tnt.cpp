@@ -108,10 +108,10 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
   };
   // out = P(v) = Proj_Y(M^-1 v) with |out|^2 and <v, out> in the partial slots MAX_DOTS, MAX_DOTS + 1, and -out in pk
   // (the first CG direction); only called with a preconditioner
-  auto precon_with_sums = [&](const double *Y, const double *v, double *out, const Tail *tail = nullptr) {
+  auto precon_with_sums = [&](const double *Y, const double *v, double *out) {
     if (jacobi) launch_rot_rowscale(d_, st_, T_, cur_mask_, jacobi_.p, v, w1);
     else solve_rr(const_cast<double *>(v), w1, 1.0);   // w1.R = (G_RR + lambda I)^-1 v.R; the forward sweep only reads v
-    launch_tangent_rot(d_, st_, T_, cur_mask_, Y, w1, out, v, partials_.p, MAX_DOTS, true, pk, tail);
+    launch_tangent_rot(d_, st_, T_, cur_mask_, Y, w1, out, v, partials_.p, MAX_DOTS, true, pk);
   };
   // gnorm, pgnorm (and rv0 = <grad, P grad>, the first CG scalar) of the nodes in `set` (mask == set).
   // with_f: f(X | g) in the same read-back, from the model gradient nabla = G X + g that is there anyway:
@@ -121,17 +121,14 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
   // the dot products (partial slots 0..3 and MAX_DOTS, MAX_DOTS + 1) and the first CG direction pk = -P(grad); who
   // reduces the sums is the caller's choice: k_reduce + wait (norms) or k_tnt_begin (no wait).
   // have_sums: slots 0..3 were already left there by quad_model's epilogue
-  // tail: what the last kernel of the sequence takes along (the start of the refinement, k_tnt_begin's work); returns
-  // whether it did (only the preconditioned path ends with a kernel that leaves sums)
-  auto norms_enqueue = [&](bool with_f, bool have_sums, const Tail *tail = nullptr) {
+  auto norms_enqueue = [&](bool with_f, bool have_sums) {
     if (!have_sums) {
       const double *pa[MAX_DOTS] = {grad, X, X, X}, *pb[MAX_DOTS] = {grad, nabla, g, ga};
       const int parts[MAX_DOTS] = {2, 0, 0, 0, 0, 0};
       launch_dots(d_, st_, T_, cur_mask_, with_f ? 4 : 1, pa, pb, parts, partials_.p, 0);
     }
-    if (use_precon) precon_with_sums(X, grad, pg, tail);
+    if (use_precon) precon_with_sums(X, grad, pg);
     else launch_cg_init(d_, st_, T_, cur_mask_, grad, grad, nullptr, nullptr, nullptr, nullptr, pk);
-    return use_precon && tail != nullptr;
   };
   auto norms_take = [&](int a, bool with_f, double g2, double xn, double xg, double xga, double pg2, double gpg) {
     S[a].gnorm = S[a].pgnorm = std::sqrt(g2);
@@ -163,18 +160,15 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
   const double eta1 = .05, eta2 = .9, alpha1 = .25, alpha2 = 2.5, Delta_tol = 1e-6;   // TNT.h:83-97,129
   constexpr int NSUM = 6;   // the sums a trial point needs (TNT.h:505-536)
   // trial point of the nodes in `m`: x+ = retract(x, s), f(x+) and, for an accepted step, the next model gradient
-  // retracted: the rotations of x+ are there already (the CG step's vector update took them along, stepA); nslots: the sums
-  // the closing reduction carries -- it rides on the last kernel (kernels.h: Tail), or k_reduce follows
+  // retracted: the rotations of x+ are there already (the CG step's vector update took them along, stepA)
   auto enqueue_trial = [&](NodeMask m, bool retracted, int nslots) {
     cur_mask_ = m;
     if (!retracted) launch_retract_rot(d_, st_, T_, cur_mask_, X, sk, xprop);
     recover_translations(xprop, g);
     // nprop = G xprop + g: gives f(xprop) and, if accepted, the next model; its epilogue leaves the six sums
     // <s,s>, <grad,s>, <s,Hs>, <x+,g>, <x+,g_alt>, <x+,nprop> in the partial slots 0..5
-    Tail tl;
-    const bool rode = make_tail(tl, TAIL_REDUCE, false, false, nslots, h_scal_, cur_mask_.v);
-    apply_tcol(xprop, T1_.p, nprop, 0, nullptr, nullptr, nullptr, nullptr, nullptr, partials_.p, g, ga, sk, grad, hh, rode ? &tl : nullptr);
-    if (!rode) launch_reduce(st_, T_, L, false, nslots, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
+    apply_tcol(xprop, T1_.p, nprop, 0, nullptr, nullptr, nullptr, nullptr, nullptr, partials_.p, g, ga, sk, grad, hh);
+    launch_reduce(st_, T_, L, false, nslots, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
   };
   // acceptance test and trust-region update of node a from the sums of its trial point (TNT.h:537-607)
   std::vector<int> acc, requad;
@@ -225,17 +219,18 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
   // it runs for every node of the run, live or not: a node that stops before its first step has c1 = 0 and gets its
   // s = H s = 0 written here
   // retract: the nodes whose CG ends with this step (dmask[2]) get the rotations of their trial point from the vector
-  // update (k_cg_step) instead of a launch of their own
-  auto stepA = [&](bool first, bool retract = false) {
-    cur_mask_ = mA;
+  // update (k_cg_step) instead of a launch of their own.  begin: the start of the refinement -- the norms, the gradient tests,
+  // the CG's start values (k_tnt_begin) -- has not been taken yet and rides with this step's scalar kernel (k_cg_scal_begin):
+  // the product then runs for every candidate, and leaves its sums where the refinement's are not
+  auto stepA = [&](bool first, bool retract = false, const std::function<void(const double *)> *begin = nullptr) {
+    cur_mask_ = begin ? live_mask(bitsA, nullptr) : mA;
     launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, pk, true, nullptr, w1, nullptr, 0, nullptr, nullptr, 0);   // G [0 ; p.R]
     solve_tt(w1, w3, -1.0);
-    // Hp and <p,Hp>, <Hp,Hp>, <p,p>, <p,r>; then the step-length logic -- on the product's last workgroups (kernels.h: Tail),
-    // or k_cg_scal
-    Tail tl;
-    const bool rode = make_tail(tl, TAIL_CG0, false, false, 4, h_cg_, cur_mask_.v);
-    apply_tcol(w3, w1, nullptr, 2, X, nabla, pk, Hp, first ? grad : rk, partials_.p, nullptr, nullptr, nullptr, nullptr, nullptr, rode ? &tl : nullptr);
-    if (!rode) launch_cg_scal(st_, T_, L, 0, partials_.p, cg_.p, dmask_.p, h_cg_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
+    double *sums = partials_.p + (begin ? (size_t)cg_first_slot() * T_.nseg_all : 0);
+    apply_tcol(w3, w1, nullptr, 2, X, nabla, pk, Hp, first ? grad : rk, sums);   // Hp and <p,Hp>, <Hp,Hp>, <p,p>, <p,r>
+    // the step-length logic
+    if (begin) (*begin)(sums);
+    else launch_cg_scal(st_, T_, L, 0, partials_.p, cg_.p, dmask_.p, h_cg_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
     // s += c1 p, H s += c1 H p for every node of the step (a node that stops here takes its boundary step), r += alpha H p
     // for those that go on
     launch_cg_step(d_, st_, T_, first ? NodeMask{bitsA, nullptr} : mA, NodeCoefs(), pk, Hp, sk, hh, rk, cg_.p, first ? grad : nullptr,
@@ -244,20 +239,16 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
   // second half: preconditioner; beta and the recurrences, next stopping test (:364-390, :285-291)
   auto stepB = [&]() {
     cur_mask_ = mB;
-    bool rode = false;
     if (use_precon) {
       if (jacobi) launch_rot_rowscale(d_, st_, T_, cur_mask_, jacobi_.p, rk, w1);
       else solve_rr(rk, w1, 1.0);
-      // v = Proj(M^-1 r) and <r, v>; beta and the next stopping test on its last workgroups, or k_cg_scal
-      Tail tl;
-      rode = make_tail(tl, TAIL_CG1, false, false, 1, h_cg_, cur_mask_.v);
-      launch_tangent_rot(d_, st_, T_, cur_mask_, X, w1, vk, rk, partials_.p, 0, false, nullptr, rode ? &tl : nullptr);
+      launch_tangent_rot(d_, st_, T_, cur_mask_, X, w1, vk, rk, partials_.p, 0);   // v = Proj(M^-1 r) and <r, v>
     } else {
       copy_rows(vk, rk, false, 0);
       const double *pa[MAX_DOTS] = {rk}, *pb[MAX_DOTS] = {vk};
       launch_dots(d_, st_, T_, cur_mask_, 1, pa, pb, P2, partials_.p, 0);
     }
-    if (!rode) launch_cg_scal(st_, T_, L, 1, partials_.p, cg_.p, dmask_.p, h_cg_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
+    launch_cg_scal(st_, T_, L, 1, partials_.p, cg_.p, dmask_.p, h_cg_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
     launch_cg_dir(d_, st_, T_, cur_mask_, cg_.p, vk, pk);
   };
   // what a segment's key must hold beside the rotating buffers (segment()): the vectors of this call and its variant
@@ -315,25 +306,21 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     segment(20, bits_nodes, {K(X), kg, kga, kvar, spec ? 1ull : 0ull, (unsigned long long)nslots}, [&] {
       cur_mask_ = live_mask(bits_nodes, nullptr);
       const bool have_sums = quad_model(X, base_ready);
-      // the norms, the gradient tests and the CG's start values: on the last workgroups of the preconditioned gradient's pass
-      // (kernels.h: Tail), or -- no preconditioner, tails switched off -- k_tnt_begin
-      Tail tl;
-      bool begun = use_precon && make_tail(tl, TAIL_TNT, false, false, 8, h_tnt_, cur_mask_.v);
-      if (begun) {
-        tl.bits = bitsA; tl.use_precon = 1; tl.max_it = o.max_tCG_iterations; tl.grad_tol = o.grad_norm_tol;
-        tl.pgrad_tol = o.preconditioned_grad_norm_tol; tl.kappa = o.STPCG_kappa; tl.theta = o.STPCG_theta;
-        tl.Delta = S[nodes[0]].Delta;   // (every candidate starts from TNTParams::Delta0)
-      }
-      norms_enqueue(true, have_sums, begun ? &tl : nullptr);
-      if (!begun) {
-        std::vector<double> Delta(L, 0.0);
-        for (int a : nodes) Delta[a] = S[a].Delta;
+      norms_enqueue(true, have_sums);
+      std::vector<double> Delta(L, 0.0);
+      for (int a : nodes) Delta[a] = S[a].Delta;
+      const std::function<void(const double *)> begin = [&](const double *) {
+        launch_cg_scal_begin(st_, T_, L, bitsA, use_precon, o.max_tCG_iterations, o.grad_norm_tol, o.preconditioned_grad_norm_tol,
+                             o.STPCG_kappa, o.STPCG_theta, Delta.data(), partials_.p, cg_.p, dmask_.p, h_tnt_, h_cg_, reduce_arrived_.p,
+                             h_flag_, next_seq(), dev_seq_.p);
+      };
+      const bool merged = fused_;
+      if (!merged)
         launch_tnt_begin(st_, T_, L, bitsA, use_precon, o.max_tCG_iterations, o.grad_norm_tol, o.preconditioned_grad_norm_tol,
                          o.STPCG_kappa, o.STPCG_theta, Delta.data(), partials_.p, cg_.p, dmask_.p, h_tnt_);
-      }
       mA = live_mask(bitsA, dmask_.p);
       mB = live_mask(bitsA, dmask_.p + 1);
-      stepA(true, spec && fused_);
+      stepA(true, spec && fused_, merged ? &begin : nullptr);
       if (spec) enqueue_trial(NodeMask{bitsA, dmask_.p + 2}, fused_, nslots);
     });
     mA = live_mask(bitsA, dmask_.p);   // (a replay does not run the body: the host's copies)
