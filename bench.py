@@ -374,7 +374,7 @@ def main():
 
     def exchange():
         if comm is not None:
-            comm.exchange()            # pack -> ncclAllGather -> unpack on the communicator's stream; update() joins it
+            comm.exchange()            # neighbour to neighbour on the group's stream, or pack -> ncclAllGather -> unpack on the communicator's; update() joins it
         grp.communicate_local()
         if do_exchange and host_staged:
             with torch.cuda.stream(ext):
@@ -567,7 +567,8 @@ def main():
             "objective_2F": 2 * fsum,
             "exchange": None if not do_exchange else ("gloo, staged through the host" if host_staged else
                                                      (("RCCL, neighbour to neighbour (grouped ncclSend / ncclRecv)" + (", THIS RANK AS ITS OWN PEER (measurement mode)" if world == 1 and args.emulate_world else ""))
-                                                      if comm.exchange_kind() == "p2p" else "RCCL all-gather") + " behind the C ABI (dpgo_comm_exchange) on the communicator's stream, joined in update()"),
+                                                      + " behind the C ABI (dpgo_comm_exchange) on the group's own stream: pack on the tail of iterate(), unpack inside update()'s inter-edge pass"
+                                                      if comm.exchange_kind() == "p2p" else "RCCL all-gather behind the C ABI (dpgo_comm_exchange) on the communicator's stream, joined in update()")),
             "exchange_us_ready_to_done": (lambda t: {"mean_us": t[0], "exchanges": t[1]})(comm.exchange_time()) if comm is not None else None,
             "ranks": per_rank,
             "setup_s": {"graph+chordal_init": t_init, "operators+factorizations": t_group},

@@ -206,6 +206,12 @@ void Comm::release() {
     if (ev_done_ && !broken_) (void)hipEventSynchronize(ev_done_);
     // (only what THIS communicator lent the group is taken back: a lay-out-free one, p2p_self_check's, lent nothing, and
     // the group may be working with another communicator's collectives)
+    if (attached_) {
+      grp_->flush_pending_recv();   // (a lazy unpack reads this communicator's receive buffer)
+      grp_->set_exchange_pack(nullptr, 0, nullptr);
+      grp_->set_stuck_handler(nullptr, nullptr);
+      attached_ = false;
+    }
     if (lent_) {
       grp_->set_pending_exchange(nullptr);
       grp_->set_collectives(nullptr, nullptr, nullptr, nullptr, nullptr);
@@ -359,6 +365,7 @@ int Comm::setup_p2p(const std::vector<std::vector<PoseKey>> &exported) {
     return -1;
   }
   p2p_ = true;
+  attach_p2p();
   return 0;
 }
 
@@ -383,8 +390,9 @@ int Comm::p2p_refused(const char *why) {
 // pack the send keys' rows of src_records -> grouped send / recv with the real neighbours -> unpack into dst_records
 // (null record arrays: the messages alone).  Between GroupStart and GroupEnd nothing returns early: a Send or Recv that
 // fails is remembered and GroupEnd is still called, so the group is never left open.
-int Comm::run_p2p(P2P &x, const double *src_records, double *dst_records) {
+int Comm::run_p2p(P2P &x, const double *src_records, double *dst_records, hipStream_t st) {
   const int RS = (grp_->d() + 1) * grp_->d();
+  hipStream_t cs_ = st ? st : this->cs_;   // (the stream of this exchange: the communicator's own, or the caller's)
   if (src_records && x.send_rows.n > 0) grp_->copy_records(cs_, (int)x.send_rows.n, nullptr, x.send_rows.p, src_records, x.send.p);
   ncclResult_t bad = ncclSuccess;
   NCCL_OK(rccl().GroupStart());
@@ -511,10 +519,10 @@ int Comm::enable_self_exchange() {
   x.recv_src.upload(ident);
   x.send.alloc((size_t)n * RS);
   x.recv.alloc((size_t)n * RS);
-  self_scratch_.alloc((size_t)grp->num_records() * RS);
   HIP_OK(hipDeviceSynchronize());
   p2p_ = true;
   self_ = true;
+  attach_p2p();
   ok_ = true;
   return 0;
 }
@@ -543,7 +551,11 @@ void Comm::take_time() {
 
 int Comm::exchange_time(double *mean_us, long *count) {
   if (!timing_) return -1;
-  if (timed_pending_) { sync_comm_stream(); take_time(); }
+  if (timed_pending_) {
+    if (p2p_) (void)hipEventSynchronize(ev_done_);   // (recorded on the group's stream)
+    else sync_comm_stream();
+    take_time();
+  }
   if (mean_us) *mean_us = time_n_ ? time_sum_us_ / time_n_ : 0.0;
   if (count) *count = time_n_;
   return 0;
@@ -553,6 +565,21 @@ size_t Comm::bytes_sent_per_exchange() const {
   const size_t RS = (size_t)(grp_->d() + 1) * grp_->d();
   if (p2p_) return p2p_state_.plan.send_keys.size() * RS * sizeof(double);
   return (size_t)stride_ * RS * sizeof(double);
+}
+
+// What the neighbour-to-neighbour exchange asks of the group it serves: the pack rides on the tail of iterate(), and a
+// collective of ours that never ends on the group's stream (a peer is gone) is aborted when the group's wait for that
+// stream runs into its deadline (Group::wait_flag), as sync_stream() does for the communicator's own stream.
+void Comm::attach_p2p() {
+  grp_->set_exchange_pack(p2p_state_.send_rows.p, (int)p2p_state_.send_rows.n, p2p_state_.send.p);
+  grp_->set_stuck_handler(&Comm::cb_stuck, this);
+  attached_ = true;
+}
+void Comm::cb_stuck(void *user) {
+  Comm *c = static_cast<Comm *>(user);
+  fprintf(stderr, "[dpgo_amd] ERROR: rank %d: the boundary exchange did not finish (a peer is gone or never joined); the communicator "
+                  "is abandoned.\n", c->rank_);
+  c->abandon(c->grp_->stream());
 }
 
 // DPGOHash::communicate for the neighbours hosted by other ranks (DPGOHash.h:64-82), asynchronous: the group's
@@ -565,11 +592,30 @@ int Comm::exchange() {
     if (timed_pending_ && hipEventQuery(ev_done_) != hipSuccess) sync_comm_stream();
     take_time();
   }
+  if (p2p_) {
+    // Neighbour to neighbour: the whole exchange on the GROUP's own stream (round 6).  On a stream of its own it paid two event
+    // hand-overs (31-40 us from "iterate final" to "rows in place" against 24 in line, measured with this rank as its own
+    // peer; profiles/r06_exchange_streams.txt) to hide one 9 us kernel.  The pack has ridden on the tail of iterate()
+    // (Group::set_exchange_pack) unless that ran before this communicator existed; the unpack is the next update()'s
+    // inter-edge pass reading the receive buffer (Group::set_pending_recv), or -- trivial loss -- one indexed copy.
+    hipStream_t gs = grp_->stream();
+    if (timing_) HIP_OK(hipEventRecord(ev_ready_, gs));
+    const bool packed = grp_->take_packed();
+    P2P &x = p2p_state_;
+    if (run_p2p(x, packed ? nullptr : grp_->Xk_records(), nullptr, gs) != 0) return -1;
+    if (self_) {
+      // (measurement mode: what arrived are this rank's own rows -- nothing for the inter-edge pass to read; the trajectory stays
+      // that of the run without an exchange)
+    } else if (x.recv_dst.n > 0 && grp_->set_pending_recv(x.recv.p, (int)x.recv_dst.n, x.recv_dst.p, x.recv_src.p) != 0) {
+      grp_->copy_records(gs, (int)x.recv_dst.n, x.recv_dst.p, x.recv_src.p, x.recv.p, grp_->Xk_records());
+    }
+    if (timing_) HIP_OK(hipEventRecord(ev_done_, gs));
+    timed_pending_ = timing_;
+    return 0;
+  }
   HIP_OK(hipEventRecord(ev_ready_, grp_->stream()));      // Xk of this iteration is final
   HIP_OK(hipStreamWaitEvent(cs_, ev_ready_, 0));
-  if (p2p_) {
-    if (run_p2p(p2p_state_, grp_->Xk_records(), self_ ? self_scratch_.p : grp_->Xk_records()) != 0) return -1;
-  } else {
+  {
     grp_->pack_sent(send_.p, cs_);
     NCCL_OK(rccl().AllGather(send_.p, gathered_.p, (size_t)stride_ * RS, ncclFloat64, (ncclComm_t)comm_, cs_));
     grp_->unpack_recv(gathered_.p, cs_);

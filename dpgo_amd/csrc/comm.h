@@ -43,10 +43,11 @@ class Comm {
   // Send + Recv to self, GroupEnd, unpack, on records that carry their own keys; 0 = every record arrived where it should
   int p2p_self_check();
   // Measurement mode for a communicator of ONE rank (bench.py --emulate-world N --force-exchange): from now on exchange()
-  // runs the neighbour-to-neighbour path in its steady state with this rank as its own peer -- pack kernel, ncclGroupStart,
-  // one ncclSend + ncclRecv of every exported record, ncclGroupEnd, unpack kernel, on the communicator's stream, joined by
-  // update() -- the unpack going to a scratch record array, so that the iterate's trajectory is that of the run without
-  // it.  What the p2p path costs an iteration, short of the wire.
+  // runs the neighbour-to-neighbour path in its steady state with this rank as its own peer -- the pack on the tail of
+  // iterate(), ncclGroupStart, one ncclSend + ncclRecv of every exported record, ncclGroupEnd, on the group's stream; what
+  // arrives (this rank's own rows) is not unpacked, so that the iterate's trajectory is that of the run without it.  What
+  // the p2p path costs an iteration, short of the wire and of the inter-edge pass reading its neighbour rows through the
+  // receive buffer.
   int enable_self_exchange();
   // time from "Xk is final" (ev_ready_, the group's stream) to "the neighbour rows are in place" (ev_done_, the
   // communicator's stream), mean over the exchanges since enable_timing(); events carry time stamps only in this mode
@@ -78,7 +79,9 @@ class Comm {
   double time_sum_us_ = 0;
   long time_n_ = 0;
   void take_time();
-  DevBuf<double> self_scratch_;
+  bool attached_ = false;   // attach_p2p(): the group packs for us and knows whom to call when its stream is stuck
+  void attach_p2p();
+  static void cb_stuck(void *user);
   struct P2P {            // one neighbour-to-neighbour exchange: the plan, its message buffers, its pack / unpack lists
     P2PPlan plan;
     DevBuf<double> send, recv;
@@ -86,7 +89,7 @@ class Comm {
   };
   P2P p2p_state_;
   int setup_p2p(const std::vector<std::vector<PoseKey>> &exported);
-  int run_p2p(P2P &x, const double *src_records, double *dst_records);   // pack from / unpack into record arrays, on cs_
+  int run_p2p(P2P &x, const double *src_records, double *dst_records, hipStream_t st = nullptr);   // pack from / unpack into record arrays, on cs_ (or st)
   void sync_comm_stream();   // hipStreamSynchronize(cs_) with a deadline (DPGO_COMM_TIMEOUT seconds, default 120)
   void sync_stream(hipStream_t st);
   void abandon(hipStream_t st);                             // a wait timed out: abort the communicator NOW (comm.cpp)

@@ -765,12 +765,14 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
         const int e = iv[k] >> 1, role = iv[k] & 1;
         InterInc &r = rec[k];
         r.other = role ? tail[e] : head[e];
+        r.osrc = -1;
         r.code = iv[k];
         r.tau = tau[e]; r.kappa = kap[e];
         for (int i = 0; i < d_; i++) r.t[i] = t[(size_t)e * d_ + i];
         for (int i = 0; i < d_ * d_; i++) r.R[i] = R[(size_t)e * d_ * d_ + i];
       }
       e_rec_.upload(rec);
+      e_rec_host_ = rec;
       E_.rec = e_rec_.p;
     }
     E_.nrows_own = P0_; E_.nrows_all = P0_ + P1_;
@@ -1080,6 +1082,7 @@ void Group::upload_bsr(const std::vector<const BsrMatrix *> &per_node, bool rows
 }
 
 void Group::sync() const {
+  const_cast<Group *>(this)->flush_pending_recv();   // (whoever reads Xk next must find the neighbour rows in it)
   if (xchg_done_) HIP_CHECK(hipEventSynchronize(xchg_done_));   // an exchange on the communicator's stream
   HIP_CHECK(hipStreamSynchronize(st_));
   check_tt_verdict(false);
@@ -1371,6 +1374,7 @@ void Group::wait_flag(unsigned long long seq) {
       if (q != hipErrorNotReady) HIP_CHECK(q);
       if (arrived()) break;
       fprintf(stderr, "[dpgo_amd] ERROR: read-back flag never arrived\n");
+      if (stuck_fn_) stuck_fn_(stuck_user_);   // (a collective on this stream that never ends: its communicator aborts it now)
       throw DeviceError("read-back flag never arrived");
     }
   }
@@ -1592,6 +1596,7 @@ static void from_records(int d, int n, const double *rec, double *X, int ld, int
 int Group::initialize(int a, const double *X, int ld) {
   finish_update();
   zc_ready_ = false;   // (whatever an earlier iterate() left in the history buffers is overwritten here)
+  packed_ = false;     // (... and whatever it packed for an exchange)
   if (a < 0 || a >= num_local()) return -1;
   const int n0 = info_[a].n[0], n1 = info_[a].n[1];
   if (ld < (d_ + 1) * (n0 + n1)) {
@@ -1901,8 +1906,47 @@ int Group::set_recv_layout(int nranks, int stride, const int *counts, const int 
 }
 
 int Group::unpack_recv(const double *dev_gathered, hipStream_t st) {
+  if ((!st || st == st_) && set_pending_recv(dev_gathered, (int)recv_dst_.n, recv_dst_.p, recv_src_.p) == 0) return 0;   // (lazily: below)
   launch_copy_indexed(d_, st ? st : st_, (int)recv_dst_.n, recv_dst_.p, recv_src_.p, dev_gathered, Xk_.p);
   return 0;
+}
+
+// A LAZY unpack: the neighbour rows an exchange on the group's own stream delivered stay in its receive buffer; the next
+// update()'s inter-edge pass reads them from there and stores them into Xk on the way (kernels.h: InterEdgesDev::recv) -- no
+// unpack kernel.  Whoever else looks at Xk's neighbour rows first (flush_pending_recv) gets the plain indexed copy.  The
+// lists (dst: neighbour rows, src: slots of the buffer; device arrays that outlive the exchange) are digested once per list:
+// a slot per neighbour row, and per incidence record the slot of its other pose.  Robust losses only (the trivial loss has
+// no inter-edge pass); -1: not taken, the caller unpacks as before.
+int Group::set_pending_recv(const double *buf, int count, const int *dst_dev, const int *src_dev) {
+  flush_pending_recv();
+  static const bool lazy = env_int("DPGO_LAZY_UNPACK", 1) != 0;   // (A/B hook)
+  if (!lazy || !fused_ || opt_.loss == 0 || star_ || count <= 0 || e_rec_host_.empty()) return -1;
+  if (recv_key_ != dst_dev || recv_count_ != count) {
+    std::vector<int> dst(count), src(count), nsrc((size_t)std::max(P1_, 1), -1);
+    HIP_CHECK(hipMemcpy(dst.data(), dst_dev, sizeof(int) * count, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(src.data(), src_dev, sizeof(int) * count, hipMemcpyDeviceToHost));
+    for (int k = 0; k < count; k++) {
+      if (dst[k] < P0_ || dst[k] >= P0_ + P1_) return -1;   // (not a neighbour row: not ours to interpret)
+      nsrc[dst[k] - P0_] = src[k];
+    }
+    std::vector<InterInc> rec = e_rec_host_;
+    for (auto &r : rec) r.osrc = r.other >= P0_ ? nsrc[r.other - P0_] : -1;
+    graphs_invalidate();   // (captured launches carry the records' address -- unchanged -- but let nothing replay mid-upload)
+    HIP_CHECK(hipMemcpyAsync(e_rec_.p, rec.data(), sizeof(InterInc) * rec.size(), hipMemcpyHostToDevice, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+    recv_nsrc_.upload(nsrc);
+    recv_key_ = dst_dev; recv_count_ = count;
+    recv_dst_dev_ = dst_dev; recv_src_dev_ = src_dev;
+  }
+  pending_recv_ = buf;
+  return 0;
+}
+
+void Group::flush_pending_recv() {
+  if (!pending_recv_) return;
+  const double *buf = pending_recv_;
+  pending_recv_ = nullptr;
+  launch_copy_indexed(d_, st_, recv_count_, recv_dst_dev_, recv_src_dev_, buf, Xk_.p);
 }
 
 void Group::needed_keys(std::vector<std::pair<int, int>> &keys, std::vector<int> &rows) const {
@@ -2127,7 +2171,7 @@ std::vector<int> Group::rescale_device(const std::vector<int> &set) {
 
 int Group::update(const std::vector<int> &locals_in) {
   InLib in_lib(this);
-  if (failed_) { flush_pending_tail(); flush_deferred(); return -1; }
+  if (failed_) { flush_pending_tail(); flush_deferred(); pending_recv_ = nullptr; return -1; }
   finish_update();
   std::vector<int> locals;
   for (int a : locals_in)
@@ -2135,6 +2179,7 @@ int Group::update(const std::vector<int> &locals_in) {
   if (locals.empty()) {
     flush_pending_tail();
     flush_deferred();
+    flush_pending_recv();
     join_exchange();   // a pending exchange must still be ordered before whatever the caller does next on this stream
     return 0;
   }
@@ -2152,6 +2197,7 @@ int Group::update(const std::vector<int> &locals_in) {
   for (int a : locals) mask_locals_bits |= 1ull << a;
   // (launches that wait for this update()'s first segment -- step() -- go now if something eager comes before it)
   if ((int)adv.size() != num_local() || !zc_ready_ || xchg_done_ || dynamic() || star_) flush_deferred();
+  const double *lazy_recv = nullptr;   // (robust losses: the receive buffer the inter-edge pass unpacks on the way)
   // the tail of iterate() rides on the product with G (group.h: PendingTail) where that product reads the very records the
   // tail copies: every node advances, the copy's second target is the buffer that becomes X[iter] below
   bool fuse_copy = false;
@@ -2193,7 +2239,7 @@ int Group::update(const std::vector<int> &locals_in) {
     deferred_slots_ = 0;
     NodeBits bits = 0;
     for (int a : set) bits |= 1ull << a;
-    segment(seg_id, bits & mask_locals_bits, {bits, mask_locals_bits, variant, (unsigned long long)nslots, fuse_copy ? 1ull : 0ull}, [&] {
+    segment(seg_id, bits & mask_locals_bits, {bits, mask_locals_bits, variant, (unsigned long long)nslots, fuse_copy ? 1ull : 0ull, (unsigned long long)(uintptr_t)lazy_recv}, [&] {
       launches();
       launch_reduce(st_, T_, num_local(), true, nslots, partials_.p, h_upd_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
     });
@@ -2234,6 +2280,7 @@ int Group::update(const std::vector<int> &locals_in) {
     if (!split) { cur_mask_ = mask_locals; product_with_G(); }
   };
   if (trivial) {
+    flush_pending_recv();
     // X[iter]'s neighbour rows <- Xk's: a launch of its own for the trivial loss; the robust losses' inter-edge pass does it
     // on the way (it reads the neighbour rows from Xk and stores them)
     // g = S Z  (evaluate_none_g_and_f0 / _f, DPGOProblem.cpp:269-287, 516-542), with <Xak, g> alongside
@@ -2278,6 +2325,12 @@ int Group::update(const std::vector<int> &locals_in) {
   } else {
     // evaluate_g_and_f0 / evaluate_g_and_f (DPGOProblem.cpp:222-267, 360-424); _rescale variants (:289-358, :426-514)
     const bool both = !first.empty() && !later.empty();
+    // a lazy unpack is taken by the one inter-edge pass that covers every node of the group (it delivers all neighbour rows
+    // at once); anything else gets the plain copy first
+    if (pending_recv_) {
+      if (!both && !dynamic() && mask_locals_bits == all_bits()) { lazy_recv = pending_recv_; pending_recv_ = nullptr; }
+      else flush_pending_recv();
+    }
     if (both || dynamic()) {   // (the product covers every node of `locals`: it cannot sit inside one of two segments)
       flush_deferred();
       head();
@@ -2289,7 +2342,9 @@ int Group::update(const std::vector<int> &locals_in) {
       std::vector<double> rho(num_local(), 0.0), gap(num_local(), 0.0);
       // fz: what the pass does on the way (Dfobj and |grad F|^2)
       auto inter_pass = [&](const InterFuse *fz) {
-        launch_inter(d_, st_, T_, cur_mask_, E_, opt_.loss, opt_.loss_reg, 0, pass == 1, Zc_.p, Zp_.p, Qd_.p, Dd_.p, DfE_.p,
+        InterEdgesDev E = E_;
+        if (lazy_recv) { E.recv = lazy_recv; E.nsrc = recv_nsrc_.p; }
+        launch_inter(d_, st_, T_, cur_mask_, E, opt_.loss, opt_.loss_reg, 0, pass == 1, Zc_.p, Zp_.p, Qd_.p, Dd_.p, DfE_.p,
                      gc_.p, partials_.p, dynamic() ? e_w_.p : nullptr, nullptr, nullptr, nullptr, nullptr, Xk_.p, nullptr, fz);   // slots 0, 1 and 2 = <X, g>
       };
       if (dynamic()) {
@@ -2320,7 +2375,7 @@ int Group::update(const std::vector<int> &locals_in) {
       const bool dyn = dynamic();
       NodeBits fresh_bits = 0;
       for (int a : fresh) fresh_bits |= 1ull << a;
-      end_with(3 + pass, (split ? 1ull : 0ull) | (head_inside ? 2ull : 0ull) | (dyn ? 4ull : 0ull) | (fused_ ? 8ull : 0ull) | (fresh_bits << 4), 6, set, [&] {
+      end_with(3 + pass, (split ? 1ull : 0ull) | (head_inside ? 2ull : 0ull) | (dyn ? 4ull : 0ull) | (fused_ ? 8ull : 0ull) | (lazy_recv ? 16ull : 0ull) | (fresh_bits << 5), 6, set, [&] {
         if (head_inside) head();
         set_mask(set);
         // Dfobj = G X + g, its tangent projection and norm: inside the inter-edge pass (kernels.h: InterFuse), or k_tangent_full
@@ -2389,6 +2444,10 @@ int Group::iterate(const std::vector<int> &locals) {
     if (tail_fusable_ && fused_ && zc_ready_ && opt_.loss != 0) {
       // the next update()'s product with G takes it along (group.h: PendingTail)
       pending_tail_.on = true; pending_tail_.m = m; pending_tail_.xak = xak; pending_tail_.xk = xk; pending_tail_.z = z;
+    } else if (pack_dst_ && !defer_armed_) {
+      // an exchange follows (step()): its pack rides on this launch (kernels.h: launch_tail_pack), Comm::exchange() finds it done
+      launch_tail_pack(d_, st_, T_, m, xak, xk, z, pack_rows_, pack_n_, pack_dst_);
+      packed_ = true;
     } else
     defer_or_launch(0x7461696cull ^ m.v, [this, m, xak, xk, z] { launch_axpby(d_, st_, T_, false, m, 1.0, xak, 0.0, nullptr, xk, 0, z); });
   }

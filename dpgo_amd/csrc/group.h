@@ -243,6 +243,15 @@ class Group {
   // counts[r] keys of rank r (concatenated in nodes/poses); slot of key k of rank r = r*stride + k
   int set_recv_layout(int nranks, int stride, const int *counts, const int *nodes, const int *poses);
   int unpack_recv(const double *dev_gathered, hipStream_t st = nullptr);   // gathered buffer of all groups
+  // a lazy unpack of buf through the lists dst (neighbour rows) / src (slots), device arrays (group.cpp); -1: not taken
+  int set_pending_recv(const double *buf, int count, const int *dst_dev, const int *src_dev);
+  void flush_pending_recv();
+  // the exchange's pack rides on the tail of iterate(): rows (device) of the records to pack, how many, where to (null: off);
+  // take_packed(): whether the last iterate() did it (and forgets it)
+  void set_exchange_pack(const int *rows_dev, int n, double *dst) { pack_rows_ = rows_dev; pack_n_ = n; pack_dst_ = dst; packed_ = false; }
+  bool take_packed() { const bool p = packed_; packed_ = false; return p; }
+  // a wait for the group's stream ran into its deadline (a collective enqueued on it never ends): called before the error is raised
+  void set_stuck_handler(void (*fn)(void *), void *user) { stuck_fn_ = fn; stuck_user_ = user; }
   // an exchange running on another stream (comm.cpp): `done` is recorded behind its unpack.  update() queues the
   // part of the surrogate build that needs no neighbour row, then makes the group's stream wait for it.
   void set_pending_exchange(hipEvent_t done) { xchg_done_ = done; }
@@ -432,6 +441,17 @@ class Group {
   std::vector<std::pair<int, int>> sent_keys_;   // (node, pose) of each exported row
   DevBuf<int> sent_rows_dev_;
   DevBuf<int> recv_dst_, recv_src_;       // remote halo: nbr row <- gathered slot
+  const double *pending_recv_ = nullptr;  // a lazy unpack nobody has consumed yet (set_pending_recv)
+  const int *recv_key_ = nullptr, *recv_dst_dev_ = nullptr, *recv_src_dev_ = nullptr;
+  int recv_count_ = 0;
+  DevBuf<int> recv_nsrc_;                 // per neighbour row: its slot in the receive buffer, -1: none
+  std::vector<InterInc> e_rec_host_;      // host copy of the incidence records (their osrc field follows the receive lay-out)
+  const int *pack_rows_ = nullptr;
+  int pack_n_ = 0;
+  double *pack_dst_ = nullptr;
+  bool packed_ = false;
+  void (*stuck_fn_)(void *) = nullptr;
+  void *stuck_user_ = nullptr;
   // vectors (records)
   DevBuf<double> Xk_, Zc_, Zp_, Y_, DfE_, Tall_;                 // P0+P1 rows
   DevBuf<double> Xak_, Xakh_, gc_, gp_, Dfc_, Dfp_, gx_, Dfx_, T1_;   // P0 rows

@@ -87,7 +87,8 @@ struct BsrDev {
 // costs one cache line instead of the six that tail/head, R, t, kappa, tau in separate arrays touch.
 struct alignas(16) InterInc {
   int other, code;
-  double tau, kappa, t[3], R[9], pad;
+  double tau, kappa, t[3], R[9];
+  int osrc, pad;   // osrc: where the other pose's record is in the receive buffer of a lazy unpack (InterEdgesDev::recv), -1: in the record array
 };
 static_assert(sizeof(InterInc) == 128, "InterInc is loaded as eight 16-byte quads");
 struct InterEdgesDev {
@@ -99,6 +100,11 @@ struct InterEdgesDev {
   const double *kappa = nullptr, *tau = nullptr;
   const int *inc_ptr = nullptr;                 // per unified row
   const int *inc = nullptr;                     // edge*2 + (0 tail | 1 head)
+  // a lazy unpack (Group::set_pending_recv): the neighbour rows the last exchange delivered are still in its receive buffer;
+  // k_inter mode 0 takes them from there -- nsrc[r]: slot of neighbour row nrows_own + r, -1: not delivered by this exchange --
+  // and stores them where an unpack kernel would have (the record array it is given as Znbr)
+  const double *recv = nullptr;
+  const int *nsrc = nullptr;
 };
 
 struct SegTable {
@@ -205,6 +211,11 @@ void launch_extrapolate(int d, hipStream_t st, const SegTable &T, bool all_rows,
                         const NodeCoefs &gamma, const double *a, const double *b, double *out, const double *gamma_dev = nullptr);
 // dev[a] = C.a[a], a < n: the per-iteration coefficients where replayed launches find them (k_set_coefs)
 void launch_set_coefs(hipStream_t st, const NodeCoefs &C, int n, double *dev);
+// The tail of iterate() with the exchange's pack on the way: xk = xak (and z = xak, if given) over the own rows of the masked
+// nodes, and -- further workgroups of the same launch -- pack[k] = xak[pack_rows[k]], k < npack, whatever the mask (the send
+// buffer of the boundary exchange, DPGOHash.h:64-82: own rows of nodes outside the mask have not changed, and xak holds them)
+void launch_tail_pack(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *xak, double *xk, double *z,
+                      const int *pack_rows, int npack, double *pack);
 // out = alpha * a + beta * b  (b may be null); parts: 0 whole record, 1 translation only, 2 rotation only
 // out2 (part 0 only): a second copy of the result
 void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask, double alpha,

@@ -633,9 +633,14 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask ma
 #pragma unroll
       for (int k = 0; k < RS; k++) zp[k] = fma(gm, zp[k] - zq[k], zp[k]);
       store_vec<RS>(F.Yout + (size_t)row * RS, zp);
+    } else if (from_nbr) {
+      // (a lazy unpack: the row may still be in the exchange's receive buffer; it then also goes where an unpack would have put it)
+      const int src = E.recv ? E.nsrc[row - E.nrows_own] : -1;
+      load_vec<RS>(src >= 0 ? E.recv + (size_t)src * RS : Znbr + (size_t)row * RS, zp);
+      store_vec<RS>(const_cast<double *>(Z) + (size_t)row * RS, zp);
+      if (src >= 0) store_vec<RS>(const_cast<double *>(Znbr) + (size_t)row * RS, zp);
     } else {
-      load_vec<RS>((from_nbr ? Znbr : Z) + (size_t)row * RS, zp);
-      if (from_nbr) store_vec<RS>(const_cast<double *>(Z) + (size_t)row * RS, zp);
+      load_vec<RS>(Z + (size_t)row * RS, zp);
     }
 #pragma unroll
     for (int k = 0; k < RS; k++) acc[k] = 0.0;
@@ -665,7 +670,10 @@ __global__ __launch_bounds__(SEG_ROWS) void k_inter(const Seg *segs, NodeMask ma
 #pragma unroll
         for (int i = 0; i < RS; i++) zo[i] = fma(gm, zo[i] - zq[i], zo[i]);
       } else {
-        load_vec<RS>(((Znbr && other >= E.nrows_own) ? Znbr : Z) + (size_t)other * RS, zo);
+        const int osrc = u8.r.osrc;
+        const double *po = (Znbr && other >= E.nrows_own) ? ((E.recv && osrc >= 0) ? E.recv + (size_t)osrc * RS : Znbr + (size_t)other * RS)
+                                                          : Z + (size_t)other * RS;
+        load_vec<RS>(po, zo);
       }
       if (k + 1 < k1) {
         const double2 *rq = reinterpret_cast<const double2 *>(E.rec + k + 1);
@@ -1069,6 +1077,29 @@ __global__ __launch_bounds__(SEG_ROWS) void k_axpby(const Seg *segs, NodeMask ma
   }
   store_vec<RS>(out + (size_t)row * RS, va);
   if (PART == 0 && out2) store_vec<RS>(out2 + (size_t)row * RS, va);   // a second copy of the result
+}
+
+// the tail of iterate() and the exchange's pack in one launch (kernels.h: launch_tail_pack): workgroups [0, nseg_own) copy
+// the masked nodes' own records xak -> xk (and z), the rest copy the exported records xak[pack_rows[k]] -> pack[k]
+template <int D>
+__global__ __launch_bounds__(SEG_ROWS) void k_tail_pack(const Seg *segs, NodeMask mask, int nseg_own, const double *xak, double *xk,
+                                                        double *z, const int *pack_rows, int npack, double *pack) {
+  constexpr int RS = Dim<D>::RS;
+  double v[RS];
+  if ((int)blockIdx.x >= nseg_own) {
+    const int k = ((int)blockIdx.x - nseg_own) * SEG_ROWS + (int)threadIdx.x;
+    if (k >= npack) return;
+    load_vec<RS>(xak + (size_t)pack_rows[k] * RS, v);
+    store_vec<RS>(pack + (size_t)k * RS, v);
+    return;
+  }
+  const Seg s = segs[xcd_seg((int)blockIdx.x, nseg_own)];
+  if (!node_on(mask, s.node)) return;
+  const int row = s.begin + threadIdx.x;
+  if (row >= s.end) return;
+  load_vec<RS>(xak + (size_t)row * RS, v);
+  store_vec<RS>(xk + (size_t)row * RS, v);
+  if (z) store_vec<RS>(z + (size_t)row * RS, v);
 }
 
 // out = alpha[node] * a + beta[node] * b  (per-node coefficients: batched CG updates)
@@ -2511,6 +2542,15 @@ void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeM
     else if (part == 1) hipLaunchKernelGGL((k_axpby<D, 1>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, alpha, a, beta, b, out, nullptr);
     else hipLaunchKernelGGL((k_axpby<D, 2>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, alpha, a, beta, b, out, nullptr);
   });
+}
+
+void launch_tail_pack(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *xak, double *xk, double *z,
+                      const int *pack_rows, int npack, double *pack) {
+  const int nb = T.nseg_own + (npack + SEG_ROWS - 1) / SEG_ROWS;
+  if (nb == 0) return;
+  ProfScope ps(PK_AXPBY, st, (2.0 * T.rows_own + 2.0 * npack) * 8.0 * (d + 1) * d);
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_tail_pack<D>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, whole_grid(mask), T.nseg_own, xak, xk, z,
+                                        pack_rows, npack, pack));
 }
 
 void launch_axpby_node(int d, hipStream_t st, const SegTable &T, NodeMask mask, const NodeCoefs &C, const double *a,

@@ -302,6 +302,13 @@ def test_multiprocess_path_matches_single_process(tmp_path):
         assert c2["iterations_run"] == 30 and c2["iterations_to_1e-6"] == c1["iterations_to_1e-6"]
         assert abs(c1["lowest_2F"] - c2["lowest_2F"]) <= 1e-10 * abs(c1["lowest_2F"])
         assert c2["seconds_to_1e-6"] > 0 and abs(j2["iters_per_s_to_objective"] - c2["iterations_to_1e-6"] / c2["seconds_to_1e-6"]) < 1e-6 * j2["iters_per_s_to_objective"]
+    # round 6: the unpack is lazy -- update()'s inter-edge pass reads the neighbour rows out of the gathered buffer and stores
+    # them into Xk on the way (Group::set_pending_recv); with the plain unpack kernel (DPGO_LAZY_UNPACK=0) the same bits
+    two0 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu"] + common,
+                          capture_output=True, text=True, timeout=900, cwd=root, env=dict(env, DPGO_LAZY_UNPACK="0"))
+    assert two0.returncode == 0, two0.stderr[-3000:]
+    j0 = json.loads([l for l in two0.stdout.splitlines() if l.startswith("{")][-1])
+    assert j0["objective_2F"] == j2["objective_2F"] and j0["convergence"]["lowest_2F"] == j2["convergence"]["lowest_2F"]
 
 
 @pytest.mark.parametrize("loss", [LOSS_NONE, LOSS_HUBER])
