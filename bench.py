@@ -335,82 +335,127 @@ def main():
 
     RS = (G.d + 1) * G.d
     send = gathered = ext = comm = None
-    if do_exchange and not host_staged:
-        # RCCL behind the C ABI; the ranks agree on the outcome, so that nobody is left waiting in a collective
-        def bcast(raw):
-            box = [raw]
-            dist.broadcast_object_list(box, src=0)
-            return box[0]
-        try:
-            if world == 1 and args.emulate_world:
-                # the emulated rank's neighbours live nowhere: run the neighbour-to-neighbour path against itself, in its
-                # steady state (pack, grouped send / recv of every exported record, unpack into a scratch array)
-                comm = dpgo_amd.Comm.self_exchange_only(grp)
-            else:
-                comm = dpgo_amd.Comm(grp, rank, world, bcast if world > 1 else None)
-            comm.enable_timing()
-            ok = 1
-        except Exception as e:
-            sys.stderr.write("[bench] rank %d: RCCL communicator failed (%r)\n" % (rank, e))
-            ok = 0
-        vote = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(vote, op=dist.ReduceOp.MIN)
-        if int(vote.item()) == 0:
-            sys.stderr.write("[bench] RCCL unavailable on some rank: falling back to the gloo host-staged exchange\n")
-            comm = None
-            host_staged = True
-    if do_exchange and host_staged:
-        ext = torch.cuda.ExternalStream(grp.stream())
-        keys = grp.sent_keys()
-        allkeys = [None] * world
-        dist.all_gather_object(allkeys, (keys[0].tolist(), keys[1].tolist()))
-        stride = max(max(len(k[0]) for k in allkeys), 1)
-        grp.set_recv_layout(stride, [(np.asarray(k[0], np.int32), np.asarray(k[1], np.int32)) for k in allkeys])
-        send = torch.zeros(stride * RS, dtype=torch.float64, device="cuda")
-        gathered = torch.zeros(world * stride * RS, dtype=torch.float64, device="cuda")
-        send_h = torch.zeros(stride * RS, dtype=torch.float64)
-        gathered_h = torch.zeros(world * stride * RS, dtype=torch.float64)
-        torch.cuda.synchronize()
-
-    def exchange():
-        if comm is not None:
-            comm.exchange()            # neighbour to neighbour on the group's stream, or pack -> ncclAllGather -> unpack on the communicator's; update() joins it
-        grp.communicate_local()
+    exchange_fallback = None     # why the exchange of the line is not the one that was asked for (None: it is)
+    # Bring-up, at most twice: the exchange that was asked for (RCCL behind the C ABI) through the warm-up iterations -- the
+    # first real use of the neighbour-to-neighbour path on a multi-GPU box -- and, if a step fails on ANY rank there (an RCCL
+    # error, an exchange that never completes: the library's deadlines turn that into an error return), once more from the
+    # initial point with the gloo host-staged exchange, so that the line is still emitted and says which exchange it timed.
+    # The ranks vote after the warm-up (gloo): nobody goes on alone.
+    released = False
+    while True:
+        if do_exchange and not host_staged:
+            # RCCL behind the C ABI; the ranks agree on the outcome, so that nobody is left waiting in a collective
+            def bcast(raw):
+                box = [raw]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+            try:
+                if world == 1 and args.emulate_world:
+                    # the emulated rank's neighbours live nowhere: run the neighbour-to-neighbour path against itself, in its
+                    # steady state (pack, grouped send / recv of every exported record, unpack into a scratch array)
+                    comm = dpgo_amd.Comm.self_exchange_only(grp)
+                else:
+                    comm = dpgo_amd.Comm(grp, rank, world, bcast if world > 1 else None)
+                comm.enable_timing()
+                ok = 1
+            except Exception as e:
+                sys.stderr.write("[bench] rank %d: RCCL communicator failed (%r)\n" % (rank, e))
+                ok = 0
+            vote = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+            if int(vote.item()) == 0:
+                sys.stderr.write("[bench] RCCL unavailable on some rank: falling back to the gloo host-staged exchange\n")
+                comm = None
+                host_staged = True
         if do_exchange and host_staged:
-            with torch.cuda.stream(ext):
-                grp.pack_sent(send.data_ptr())
-                send_h.copy_(send)
-                dist.all_gather_into_tensor(gathered_h, send_h)
-                gathered.copy_(gathered_h)
-                grp.unpack_recv(gathered.data_ptr())
+            ext = torch.cuda.ExternalStream(grp.stream())
+            keys = grp.sent_keys()
+            allkeys = [None] * world
+            dist.all_gather_object(allkeys, (keys[0].tolist(), keys[1].tolist()))
+            stride = max(max(len(k[0]) for k in allkeys), 1)
+            grp.set_recv_layout(stride, [(np.asarray(k[0], np.int32), np.asarray(k[1], np.int32)) for k in allkeys])
+            send = torch.zeros(stride * RS, dtype=torch.float64, device="cuda")
+            gathered = torch.zeros(world * stride * RS, dtype=torch.float64, device="cuda")
+            send_h = torch.zeros(stride * RS, dtype=torch.float64)
+            gathered_h = torch.zeros(world * stride * RS, dtype=torch.float64)
+            torch.cuda.synchronize()
 
-    native_step = not (do_exchange and host_staged) and os.environ.get("DPGO_BENCH_PY_STEP") != "1"   # (A/B switch)
+        def exchange():
+            if comm is not None:
+                comm.exchange()            # neighbour to neighbour on the group's stream, or pack -> ncclAllGather -> unpack on the communicator's; update() joins it
+            grp.communicate_local()
+            if do_exchange and host_staged:
+                with torch.cuda.stream(ext):
+                    grp.pack_sent(send.data_ptr())
+                    send_h.copy_(send)
+                    dist.all_gather_into_tensor(gathered_h, send_h)
+                    gathered.copy_(gathered_h)
+                    grp.unpack_recv(gathered.data_ptr())
 
-    def step():
-        if native_step:
-            # iterate -> exchange (the communicator's own stream) -> communicate -> update in one native call, as the
-            # C++ driver's loop does: no interpreter overhead between the launches
-            rc = grp.step(comm)
+        native_step = not (do_exchange and host_staged) and os.environ.get("DPGO_BENCH_PY_STEP") != "1"   # (A/B switch)
+
+        def step():
+            if native_step:
+                # iterate -> exchange (the communicator's own stream) -> communicate -> update in one native call, as the
+                # C++ driver's loop does: no interpreter overhead between the launches
+                rc = grp.step(comm)
+            else:
+                rc = grp.iterate()
+                exchange()
+                rc |= grp.update()
+            if rc != 0:
+                raise SystemExit("step failed")
+
+        def barrier_local():
+            grp.sync()
+            torch.cuda.synchronize()
+
+        def barrier():
+            barrier_local()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        grp.update()
+        if starved is not None and not released:
+            starve.release()
+            released = True
+            time.sleep(0.2)
+        warm_ok, warm_err = 1, None
+        try:
+            for _ in range(args.warmup):
+                step()
+            barrier_local()
+        except (SystemExit, Exception) as e:
+            warm_ok, warm_err = 0, repr(e)
+            sys.stderr.write("[bench] rank %d: the warm-up failed (%s)\n" % (rank, warm_err))
+        if do_exchange and dist is not None:
+            vote = torch.tensor([warm_ok], dtype=torch.int32)
+            dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+            warm_ok_all = int(vote.item())
         else:
-            rc = grp.iterate()
-            exchange()
-            rc |= grp.update()
-        if rc != 0:
+            warm_ok_all = warm_ok
+        if warm_ok_all:
+            break
+        if not do_exchange or host_staged or exchange_fallback is not None:
             raise SystemExit("step failed")
-
-    def barrier():
-        grp.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    grp.update()
-    if starved is not None:
-        starve.release()
-        time.sleep(0.2)
-    for _ in range(args.warmup):
-        step()
+        # a failed group cannot go on (its stream may hold a collective that was aborted): a new group, the initial point, the
+        # host-staged exchange
+        exchange_fallback = "the RCCL exchange failed during the warm-up on some rank" + ((": " + warm_err) if warm_err else "")
+        sys.stderr.write("[bench] rank %d: falling back to the gloo host-staged exchange\n" % rank)
+        try:
+            if comm is not None:
+                comm.close()
+        except Exception:
+            pass
+        comm = None
+        if world == 1:
+            do_exchange = False     # (an emulated rank: its neighbours live nowhere, there is nothing to stage through the host)
+        else:
+            host_staged = True
+        grp = dpgo_amd.NodeGroup(G, my_nodes, opt, device=local_rank)
+        if grp.initialize_global(X0) != 0:
+            raise SystemExit("initialize failed")
     barrier()
     cpu0, wall0, spin0 = time.process_time(), time.perf_counter(), (starve.cpu_seconds() if starved is not None else None)
     t0 = time.perf_counter()
@@ -565,7 +610,8 @@ def main():
                        "iterations_before_timed_region": args.warmup,
                        "refined_nodes_last_step": refined, "tnt_inner_iterations_last_step": inner},
             "objective_2F": 2 * fsum,
-            "exchange": None if not do_exchange else ("gloo, staged through the host" if host_staged else
+            "exchange_fallback": exchange_fallback,
+            "exchange": None if not do_exchange else (("gloo, staged through the host" + (" (FALLBACK: %s)" % exchange_fallback if exchange_fallback else "")) if host_staged else
                                                      (("RCCL, neighbour to neighbour (grouped ncclSend / ncclRecv)" + (", THIS RANK AS ITS OWN PEER (measurement mode)" if world == 1 and args.emulate_world else ""))
                                                       + " behind the C ABI (dpgo_comm_exchange) on the group's own stream: pack on the tail of iterate(), unpack inside update()'s inter-edge pass"
                                                       if comm.exchange_kind() == "p2p" else "RCCL all-gather behind the C ABI (dpgo_comm_exchange) on the communicator's stream, joined in update()")),

@@ -586,6 +586,14 @@ void Comm::cb_stuck(void *user) {
 // stream is not held up; Group::update() joins (Group::pending_exchange).
 int Comm::exchange() {
   if (!ok_) return -1;
+  {   // DPGO_DEBUG_FAIL_EXCHANGE=n (test hook): the n-th exchange of this process fails the way an RCCL error would
+    static const int fail_at = getenv("DPGO_DEBUG_FAIL_EXCHANGE") ? atoi(getenv("DPGO_DEBUG_FAIL_EXCHANGE")) : 0;
+    static int calls = 0;
+    if (fail_at > 0 && ++calls == fail_at) {
+      fprintf(stderr, "[dpgo_amd] ERROR: rank %d: exchange %d failed (DPGO_DEBUG_FAIL_EXCHANGE)\n", rank_, calls);
+      return -1;
+    }
+  }
   const int RS = (grp_->d() + 1) * grp_->d();
   if (timing_) {
     // (the previous exchange was joined by an update() long ago; its events are about to be recorded again)

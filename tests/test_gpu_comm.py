@@ -100,3 +100,28 @@ def test_grouped_send_recv_path_runs_on_the_device_with_one_rank(fixtures_dir, n
     # a group that hosts every node exports nothing: the hook says so instead of passing vacuously
     whole = dpgo_amd.NodeGroup(G, list(range(nodes)), dpgo_amd.Options.driver(LOSS_HUBER, True))
     assert whole.p2p_self_check() == -1
+
+
+@pytest.mark.gpu
+def test_bench_line_survives_an_exchange_that_fails_during_the_warm_up():
+    """the first multi-GPU run is also the first real use of the RCCL exchange.  If it fails on some rank
+    during the warm-up iterations (here: the second exchange of the one rank, DPGO_DEBUG_FAIL_EXCHANGE -- the error return an
+    RCCL failure or the library's deadline on a stuck collective produces), the ranks vote, start again from the initial
+    point with the fallback and the line is still emitted, naming what it timed and why."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--grid", "10,10,8,2400", "--emulate-world", "8", "--emulate-rank", "3",
+           "--force-exchange", "--steps", "4", "--warmup", "3", "--no-prof", "--no-cpu", "--converge", "0"]
+    ok = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    j = json.loads([l for l in ok.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["exchange_fallback"] is None and "neighbour to neighbour" in j["exchange"] and j["exchange_us_ready_to_done"]["exchanges"] > 0
+    bad = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, DPGO_DEBUG_FAIL_EXCHANGE="2"))
+    assert bad.returncode == 0, bad.stderr[-2000:]
+    jb = json.loads([l for l in bad.stdout.splitlines() if l.startswith("{")][-1])
+    assert jb["exchange_fallback"] and "warm-up" in jb["exchange_fallback"] and jb["exchange"] is None
+    assert "exchange 2 failed" in bad.stderr and "falling back" in bad.stderr
+    # the same trajectory either way (an emulated rank's neighbours are frozen: the exchange never changes the numbers)
+    assert jb["objective_2F"] == j["objective_2F"]
