@@ -114,7 +114,7 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
   // two classes of tiles: small fronts (one wave per tile) and wide fronts (8 waves per tile, the columns /
   // rows of the reduction split between the waves).
   // The reduction length decides: columns (w) in the forward sweep, rows (w+u) in the backward sweep.
-  const int wide_above = env_int("DPGO_SPD_WIDE", 96);   // (<= 128: a narrow tile's reduction is one LDS chunk)
+  const int wide_above = 96;   // (<= 128: a narrow tile's reduction is one LDS chunk)
   auto wide = [&](int f, bool fwd) { return (fwd ? F.w[f] : F.w[f] + F.u[f]) > wide_above; };
   // a small narrow class joins the wide class (whole workgroups are cheap when there are few of them)
   auto tiles64 = [&](const std::vector<int> &lvl, bool fwd, bool want_wide) {
@@ -284,7 +284,7 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
     for (int f = 0; f < F.nfronts; f++)
       if (is_root(f)) { roots.push_back(f); largest_mb = std::max(largest_mb, 8e-6 * (double)F.w[f] * F.w[f]); }
     const int force = env_int("DPGO_SPD_ROOT_SYM", -1);
-    root_sym = !roots.empty() && !want_f32 && nnodes <= MAX_LOCAL_NODES &&
+    root_sym = !roots.empty() && nnodes <= MAX_LOCAL_NODES &&
                (force == 1 || (force != 0 && largest_mb >= env_int("DPGO_SPD_ROOT_SYM_MB", 32)));
   }
   if (fused_root && root_sym) {
@@ -383,8 +383,7 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
     int t64 = 0;
     for (int f : roots) t64 += (F.w[f] + 63) / 64;
     // few tiles: 16-row tiles reach 4x more CUs; a single root per GPU (one node per GPU): 8-row tiles, 8x
-    const bool f32 = want_f32 && !F.keep_numeric;
-    const int rows = (t64 < env_int("DPGO_SPD_FINE_ROOT8", 64) && !f32) ? 8 : (t64 < env_int("DPGO_SPD_FINE_ROOT", 192) ? 16 : 64);
+    const int rows = (t64 < env_int("DPGO_SPD_FINE_ROOT8", 64)) ? 8 : (t64 < env_int("DPGO_SPD_FINE_ROOT", 192) ? 16 : 64);
     root_level.rows = rows;
     std::vector<Tile> tiles;
     for (int a = 0; a < nnodes; a++) {
@@ -451,7 +450,7 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
       root_fine_items.release();
       Wroot_fine.release();
       const int fine = rows == 64 ? 16 : (rows == 16 ? 8 : 0);
-      if (fine && nnodes > 1 && !F.keep_numeric && !f32 && env_int("DPGO_SPD_ROOT_FINE_LIVE", 1) != 0) {
+      if (fine && nnodes > 1 && !F.keep_numeric) {
         std::vector<Tile> ft;
         root_fine_level = Level{0, 0, 0, fine, std::vector<int>(nnodes, 0), std::vector<int>(nnodes, 0), std::vector<int>(nnodes, 0),
                                 std::vector<int>(nnodes, 0), root_level.node_bytes};
@@ -509,29 +508,6 @@ void SpdSolverDev::upload(int dcols, const std::vector<int> &node_of_unknown) {
   dev.piv_idx = piv_idx.p; dev.upd_idx = upd_idx.p; dev.asm_ptr = asm_ptr.p; dev.ubuf_dst = ubuf_dst.p;
   dev.W = W.p; dev.WT = WT.p; dev.fwd_items = fwd_items.p; dev.bwd_items = bwd_items.p; dev.ubuf = ubuf.p;
   dev.root_items = root_items.p; dev.Wroot = Wroot.p;
-  dev.f32 = 0;
-  if (want_f32 && !F.keep_numeric) {
-    // the experiment: fp32 copies of the panels, the fp64 ones are dropped
-    W32.alloc(std::max<size_t>(W.n, 1), false);
-    WT32.alloc(std::max<size_t>(WT.n, 1), false);
-    Wroot32.alloc(std::max<size_t>(Wroot.n, 1), false);
-    launch_to_f32(nullptr, W.p, W32.p, W.n);
-    launch_to_f32(nullptr, WT.p, WT32.p, WT.n);
-    launch_to_f32(nullptr, Wroot.p, Wroot32.p, Wroot.n);
-    HIP_CHECK(hipDeviceSynchronize());
-    stream_once = sizeof(float) * (W.n + WT.n + Wroot.n) > keep;
-    W.release(); WT.release(); Wroot.release();
-    dev.W = reinterpret_cast<const double *>(W32.p);
-    dev.WT = reinterpret_cast<const double *>(WT32.p);
-    dev.Wroot = reinterpret_cast<const double *>(Wroot32.p);
-    dev.f32 = 1;
-    for (double &b : fwd_level_bytes) b *= 0.5;   // (approximately: the vectors stay fp64)
-    for (double &b : bwd_level_bytes) b *= 0.5;
-    for (auto *lv : {&fwd_levels, &bwd_levels})
-      for (auto &l : *lv)
-        for (double &b : l.node_bytes) b *= 0.5;
-    for (double &b : root_level.node_bytes) b *= 0.5;
-  }
 }
 
 static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec);
@@ -647,7 +623,6 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   }
   HIP_CHECK(hipSetDevice(device));
   HIP_CHECK(hipStreamCreate(&st_));
-  if (const char *w = getenv("DPGO_WAIT")) polite_ = std::string(w) == "block";
   const int L = (int)nodes_.size();
   const bool trivial = (opt.loss == 0);
   info_.resize(L);
@@ -843,7 +818,6 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
       std::vector<int> node_of_row((size_t)P0_ * d_);
       for (int a = 0; a < L; a++)
         for (int p = 0; p < info_[a].n[0] * d_; p++) node_of_row[(size_t)own_off_[a] * d_ + p] = a;
-      Lrr_.want_f32 = env_int("DPGO_PRECON_FP32", 0) != 0;   // (experiment, see SpdSolverDev::want_f32)
       Lrr_.upload(d_, node_of_row);
       clk.lap("G_RR: panels (pack + upload)");
     }
@@ -888,7 +862,6 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   const size_t nall = (size_t)(P0_ + P1_) * RS_, nown = (size_t)P0_ * RS_;
   for (DevBuf<double> *b : {&Xk_, &Zc_, &Zp_, &Y_, &DfE_, &Tall_}) b->alloc(nall);
   for (DevBuf<double> *b : {&Xak_, &Xakh_, &gc_, &gp_, &Dfc_, &Dfp_, &gx_, &Dfx_, &T1_}) b->alloc(nown);
-  gx_lin_ = env_int("DPGO_GX_LINEAR", 1) != 0;
   if (keep_gx()) { GXc_.alloc(nown); GXp_.alloc(nown); }
   for (auto &b : tmp_) b.alloc(nown);
   if (getenv("DPGO_SPD_DUMP")) {
@@ -1013,12 +986,10 @@ Group::~Group() {
             num_local(), seg_replays_, t_graph_launch_, seg_replays_ ? 1e6 * t_graph_launch_ / seg_replays_ : 0.0, seg_eager_, t_eager_seg_,
             n_wait_, t_wait_, n_wait_ ? 1e6 * t_wait_ / n_wait_ : 0.0);
   if (host_timing_)
-    fprintf(stderr, "[host] waits: %ld slept on an event; waits of < 50 us / 200 us / 1 ms / 5 ms / 50 ms / longer: %ld %ld %ld %ld %ld %ld; segments replayed since the host was found to be the slower side: %s\n",
-            waits_polite_, wait_hist_[0], wait_hist_[1], wait_hist_[2], wait_hist_[3], wait_hist_[4], wait_hist_[5], host_bound_ ? "yes" : "no");
+    fprintf(stderr, "[host] waits of < 50 us / 200 us / 1 ms / 5 ms / 50 ms / longer: %ld %ld %ld %ld %ld %ld; segments replayed since the host was found to be the slower side: %s\n",
+            wait_hist_[0], wait_hist_[1], wait_hist_[2], wait_hist_[3], wait_hist_[4], wait_hist_[5], host_bound_ ? "yes" : "no");
   const bool idle = drain(failed_ ? 2.0 : 60.0);
-  if (idle)
-    for (auto &e : wait_ev_)
-      if (e) (void)hipEventDestroy(e);
+  if (!idle) dev_leak_buffers(true);   // (the members' buffers are destroyed after this body: hipFree would wait for the stuck stream)
   if (idle) {
     graphs_destroy();
   } else {
@@ -1110,7 +1081,6 @@ void Group::set_mask(const std::vector<int> &locals) {
 NodeMask Group::live_mask(NodeBits bits, const NodeBits *p) const {
   NodeMask m{bits, p};
   const int L = num_local();
-  static const bool on = env_int("DPGO_LIVE_GRIDS", 1) != 0;
   int n = 0, idle = -1;
   if ((int)own_seg_ptr_host_.size() != L + 1) return m;
   for (int a = 0; a < L; a++) {
@@ -1119,7 +1089,7 @@ NodeMask Group::live_mask(NodeBits bits, const NodeBits *p) const {
     // of that node -- a node without own rows has none, its "first" one would be the next node's)
     else if (idle < 0 && own_seg_ptr_host_[a + 1] > own_seg_ptr_host_[a]) idle = a;
   }
-  if (!on || n == 0 || n > MAX_LIVE_SEGS || idle < 0) return m;   // (every node, too many, or nowhere to park: the whole grid)
+  if (n == 0 || n > MAX_LIVE_SEGS || idle < 0) return m;   // (every node, too many, or nowhere to park: the whole grid)
   for (int a = 0; a < L; a++)
     if ((bits >> a) & 1ull) {
       m.seg0[m.nlive] = own_seg_ptr_host_[a];
@@ -1175,6 +1145,7 @@ void Group::graphs_destroy() {
 // a stream that never drains keeps (leaks) its graphs.
 void Group::graphs_invalidate() {
   graph_gen_++;
+  seg_captures_live_ = 0;   // (the cap below is on captures of one generation of arguments, not of the group's life)
   if (seg_graphs_.empty()) return;
   if (drain(60.0)) graphs_destroy();
   else seg_graphs_.clear();
@@ -1210,11 +1181,9 @@ void Group::segment(int id, NodeBits bits, std::initializer_list<unsigned long l
   const bool wanted = wanted_in < 0 ? iter_graph_wanted() : wanted_in != 0;
   if (!wanted || bits != all_bits()) {
     seg_eager_++;
-    const unsigned long long before = fetch_seq_;
     const auto t0 = std::chrono::steady_clock::now();
     body();
     if (host_timing_) t_eager_seg_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (fetch_seq_ != before) mark_flag_event();
     return;
   }
   std::vector<unsigned long long> key;
@@ -1229,12 +1198,15 @@ void Group::segment(int id, NodeBits bits, std::initializer_list<unsigned long l
   SegGraph *hit = nullptr;
   for (auto &g : seg_graphs_)
     if (g.key == key) { hit = &g; break; }
-  if (!hit && seg_captures_ >= 256) {
+  if (!hit && seg_captures_live_ >= 256) {
+    if (!capture_cap_warned_) {
+      capture_cap_warned_ = true;
+      fprintf(stderr, "[dpgo_amd] WARNING: more than 256 segment variants captured without the arguments changing; further new variants "
+                      "run eagerly (the replayed ones stay).\n");
+    }
     // (more variants than a steady state has: whatever keeps changing, capturing it again and again is not the cure)
     seg_eager_++;
-    const unsigned long long before = fetch_seq_;
     body();
-    if (fetch_seq_ != before) mark_flag_event();
     return;
   }
   if (!hit) {
@@ -1275,6 +1247,7 @@ void Group::segment(int id, NodeBits bits, std::initializer_list<unsigned long l
     seg_graphs_.push_back(SegGraph{key, exec, captured_flags_, 0, 0});
     hit = &seg_graphs_.back();
     seg_captures_++;
+    seg_captures_live_++;
   }
   hit->used = ++seg_clock_;
   if (host_timing_) {
@@ -1286,7 +1259,6 @@ void Group::segment(int id, NodeBits bits, std::initializer_list<unsigned long l
   fetch_seq_ += hit->flags;   // the flag-raising kernels of the replay count on from the device's own word
   hit->done_seq = fetch_seq_ + 1;   // (a flag raised BEHIND the replay says it is over: its own flag need not be its last kernel)
   seg_replays_++;
-  if (hit->flags) mark_flag_event();
 }
 
 unsigned long long Group::fetch_async(int nslots, bool all_rows) {
@@ -1314,16 +1286,6 @@ void Group::fetch(int nslots, bool all_rows) {
   wait_flag(fetch_seq_);
 }
 
-// DPGO_WAIT=block: an event behind the submission that raises the flag to fetch_seq_ (group.h)
-void Group::mark_flag_event() {
-  if (!polite_ || capturing_) return;
-  const int i = wait_ev_next_;
-  wait_ev_next_ = (i + 1) % WAIT_EVENTS;
-  if (!wait_ev_[i]) HIP_CHECK(hipEventCreateWithFlags(&wait_ev_[i], hipEventBlockingSync | hipEventDisableTiming));
-  HIP_CHECK(hipEventRecord(wait_ev_[i], st_));
-  wait_ev_seq_[i] = fetch_seq_;
-}
-
 // Wait until the kernel that raises the pinned flag to `seq` (or a later one of the in-order stream) has run: seeing
 // the flag means everything enqueued before that kernel is done.
 void Group::wait_flag(unsigned long long seq) {
@@ -1339,23 +1301,6 @@ void Group::wait_flag(unsigned long long seq) {
     }
   } acc{this, t0};
   auto arrived = [&] { return __atomic_load_n(h_flag_, __ATOMIC_ACQUIRE) >= seq; };
-  if (!arrived() && polite_) {
-    // the event recorded behind the submission that raises the flag to `seq` (the earliest one that covers it); none
-    // means one recorded now, behind everything enqueued so far
-    int best = -1;
-    for (int i = 0; i < WAIT_EVENTS; i++)
-      if (wait_ev_[i] && wait_ev_seq_[i] >= seq && (best < 0 || wait_ev_seq_[i] < wait_ev_seq_[best])) best = i;
-    if (best < 0) {
-      mark_flag_event();
-      best = (wait_ev_next_ + WAIT_EVENTS - 1) % WAIT_EVENTS;
-    }
-    hipError_t q = hipEventQuery(wait_ev_[best]);
-    if (q == hipErrorNotReady) {
-      waits_polite_++;
-      q = hipEventSynchronize(wait_ev_[best]);
-    }
-    if (q != hipSuccess) HIP_CHECK(q);
-  }
   auto last = t0;
   for (unsigned spins = 0; !arrived(); spins++) {
     __builtin_ia32_pause();
@@ -2567,9 +2512,16 @@ int Group::amm(const std::vector<int> &locals) {
   // head of the iteration rides at the front of the refinement's head, one graph launch and one start-up less)
   static const bool spec_on = env_int("DPGO_SPEC_REFINE", 1) != 0;
   const bool speculate = spec_on && spec_refined_ && (int)locals.size() == num_local() && pending_update_ && !star_ && !dynamic();
+  // (the closure below refers to this frame: whatever happens -- an exception on its way to the C ABI before a segment has
+  // taken it -- it does not outlive the frame)
+  struct DropHead {
+    Group *g; bool armed = false;
+    ~DropHead() { if (armed && !g->deferred_.empty()) { g->deferred_.clear(); g->deferred_key_ = 0; } }
+  } drop_head{this};
   if (speculate && iter_graph_wanted() && deferred_.empty()) {
     deferred_.push_back(head_of_iteration);
     deferred_key_ = 0x68656164ull ^ mask_locals.v;
+    drop_head.armed = true;
   } else {
     segment(10, cur_mask_.v, {}, head_of_iteration);
   }

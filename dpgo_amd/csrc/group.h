@@ -140,11 +140,6 @@ struct SpdSolverDev {
   // complement (k_spd_level MODE 2); DPGO_SPD_FUSE_ROOT=0 keeps them in the two sweeps
   Level root_level{0, 0, 0, 64, {}, {}, {}, {}, {}};
   bool fused_root = false;
-  // EXPERIMENT, never the default and never part of the headline: the panels of this factor stored in fp32 (half the
-  // bytes of every solve; the arithmetic stays fp64).  Only offered for the preconditioner's factor (DPGO_PRECON_FP32=1),
-  // where SURVEY 7 allows mixed precision: it changes the CG's path, not the surrogate or the accepted steps' test.
-  bool want_f32 = false;
-  DevBuf<float> W32, WT32, Wroot32;
   DevBuf<SpdItem> root_items;
   // The fused roots stored as ONE TRIANGLE of 64 x 64 blocks (kernels.h: RootRow; k_root_sym + k_root_combine): half the
   // bytes of the level for one small launch more, taken when a single root holds at least DPGO_SPD_ROOT_SYM_MB (32) megabytes
@@ -347,7 +342,8 @@ class Group {
   unsigned long long seg_clock_ = 0, graph_gen_ = 0;   // graph_gen_: bumped by whatever invalidates captured arguments
   bool capturing_ = false, graphs_broken_ = false;
   int captured_flags_ = 0;
-  long seg_replays_ = 0, seg_captures_ = 0, seg_eager_ = 0;
+  long seg_replays_ = 0, seg_captures_ = 0, seg_eager_ = 0, seg_captures_live_ = 0;   // _live_: since the last graphs_invalidate()
+  bool capture_cap_warned_ = false;
   // DPGO_HOST_TIMING=1: where the host's time goes (seconds in hipGraphLaunch, in eagerly launched segments, in waits), on
   // stderr when the group goes
   bool host_timing_ = getenv("DPGO_HOST_TIMING") != nullptr;
@@ -359,16 +355,6 @@ class Group {
     if (capturing_) { captured_flags_++; return 0ull; }
     return ++fetch_seq_;
   }
-  // ---- How the host waits for a read-back (wait_flag): it polls the pinned flag.  DPGO_WAIT=block makes it sleep on a
-  // blocking event recorded behind every flag-raising submission instead (measured, DESIGN 9: 5-8 % slower on an idle
-  // host, no faster on a crowded one -- the HIP runtime's own threads need the core as well -- so it is an opt-in).
-  enum { WAIT_EVENTS = 8 };
-  hipEvent_t wait_ev_[WAIT_EVENTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  unsigned long long wait_ev_seq_[WAIT_EVENTS] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int wait_ev_next_ = 0;
-  bool polite_ = false;
-  long waits_polite_ = 0;
-  void mark_flag_event();        // DPGO_WAIT=block: an event behind the submission that raises the flag to fetch_seq_
   // ---- Whether segments are replayed (iter_graph_wanted), decided by MEASUREMENT: a group starts with eager launches and
   // keeps an eye on how much of the time it spends inside iterate() / update() is waiting for the GPU.  A host that waits most of the time (more than
   // 40 % of it) keeps up with eager launches, which are the faster way then (a replay costs the GPU ~8 us of start-up); a
@@ -458,8 +444,7 @@ class Group {
   // robust loss, Static rescale: G X[k] and G X[k-1] (own rows), rotated with the history of X: the product with G at the
   // extrapolated point is their linear combination (prepare_extrapolated), one pass over the operator less per iteration
   DevBuf<double> GXc_, GXp_;
-  bool keep_gx() const { return opt_.loss != 0 && !dynamic() && gx_lin_; }
-  bool gx_lin_ = true;   // DPGO_GX_LINEAR=0 switches it off (measurement hook)
+  bool keep_gx() const { return opt_.loss != 0 && !dynamic(); }
   DevBuf<double> tmp_[14];                                       // P0 rows, TNT work vectors
   hipEvent_t xchg_done_ = nullptr;   // pending boundary exchange (not owned)
   void join_exchange();              // the group's stream waits for it

@@ -326,7 +326,6 @@ struct SpdDev {
   const SpdItem *fwd_items = nullptr, *bwd_items = nullptr;
   const SpdItem *root_items = nullptr;   // the fused root tiles (k_spd_level MODE 2) and their panels
   const double *Wroot = nullptr;
-  int f32 = 0;   // experiment (DPGO_PRECON_FP32=1, rotation factor only): W / WT / Wroot point at fp32 copies of the panels
   double *ubuf = nullptr;
 };
 // One level of the forward / backward sweep.  The tiles of a level are stored node by node -- a node's wide tiles
@@ -349,7 +348,6 @@ struct SpdLevelMap {
 // len rows of `count` entries, src_ld apart, starting at src + src_off, to panels + items[i].mat_off (rows items[i].ld apart).
 struct PanelSrc { long long src_off; int src_ld; int len; };
 void launch_pack_panels(hipStream_t st, const SpdItem *items, const PanelSrc *srcs, int ntiles, const double *src, double *panels);
-void launch_to_f32(hipStream_t st, const double *src, float *dst, size_t n);
 // measurement builds (-DSPD_TRACE) only: where the solve tiles write their phase timestamps (6 per tile); no-op otherwise
 void spd_trace_set(unsigned long long *p);
 int spd_waves(int rows);   // waves (= narrow tiles) per workgroup of the class with `rows`-high wide tiles

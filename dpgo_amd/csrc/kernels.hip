@@ -1692,7 +1692,7 @@ __device__ unsigned long long *g_spd_trace = nullptr;
 // NT: the panels are read once per solve; non-temporal loads keep a factor that cannot stay in the Infinity
 // Cache anyway from displacing what the kernels between two solves re-read (operators, vectors, and a
 // smaller factor that does fit)
-#define LDW(p) ((double)(NT ? __builtin_nontemporal_load(p) : *(p)))   // (panels in fp64, or -- an opt-in experiment -- fp32)
+#define LDW(p) ((double)(NT ? __builtin_nontemporal_load(p) : *(p)))
 // waves per workgroup of the 16-row class (16 waves per tile measured 5 % slower than 8)
 #ifndef SPD_NW16
 #define SPD_NW16 8
@@ -2822,13 +2822,6 @@ void launch_root_syrk(hipStream_t st, const RootDesc *rd, int nroots, int max_w,
   if (nroots > 0 && nt > 0) hipLaunchKernelGGL(k_root_syrk, dim3(nt, nt, nroots), dim3(256), 0, st, rd, src, dst);
 }
 
-__global__ __launch_bounds__(256) void k_to_f32(const double *src, float *dst, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = (float)src[i];
-}
-void launch_to_f32(hipStream_t st, const double *src, float *dst, size_t n) {
-  if (n) hipLaunchKernelGGL(k_to_f32, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65536)), dim3(256), 0, st, src, dst, n);
-}
-
 void launch_pack_panels(hipStream_t st, const SpdItem *items, const PanelSrc *srcs, int ntiles, const double *src, double *panels) {
   if (ntiles > 0) hipLaunchKernelGGL(k_pack_panels, dim3(ntiles), dim3(256), 0, st, items, srcs, src, panels);
 }
@@ -2880,16 +2873,7 @@ void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, int mode,
     else                                                                                                       \
       hipLaunchKernelGGL((k_spd_level<D, DOFV, ROWSV, 2, NTV, PTV>), dim3(npacks), dim3(64 * SPD_NW(ROWSV)), 0, st, S, mask, M, scale, vec, ytmp); \
   } while (0)
-/* fp32 panels exist for the rotation factor only (the preconditioner experiment, SpdDev::f32) */
-#define SPD_LAUNCH2(DOFV, ROWSV, NTV)                                  \
-  do {                                                                 \
-    if constexpr (DOFV != 1) {                                         \
-      if (S.f32) SPD_LAUNCH3(DOFV, ROWSV, NTV, float);                 \
-      else SPD_LAUNCH3(DOFV, ROWSV, NTV, double);                      \
-    } else {                                                           \
-      SPD_LAUNCH3(DOFV, ROWSV, NTV, double);                           \
-    }                                                                  \
-  } while (0)
+#define SPD_LAUNCH2(DOFV, ROWSV, NTV) SPD_LAUNCH3(DOFV, ROWSV, NTV, double)
 #define SPD_LAUNCH(DOFV, ROWSV)                \
   do {                                         \
     if (stream_once) SPD_LAUNCH2(DOFV, ROWSV, true); \
@@ -2901,7 +2885,7 @@ void launch_spd_level(int d, int dof, hipStream_t st, const SpdDev &S, int mode,
 #define SPD_PICK(DOFV)                  \
   do {                                  \
     if (rows == 8) {                    \
-      if (mode != 2 || S.f32) { fprintf(stderr, "[dpgo_amd] ERROR: 8-row solve tiles are a root-level class.\n"); return; } \
+      if (mode != 2) { fprintf(stderr, "[dpgo_amd] ERROR: 8-row solve tiles are a root-level class.\n"); return; } \
       if (stream_once) SPD_ROOT8(DOFV, true); \
       else SPD_ROOT8(DOFV, false);      \
     } else if (rows == 16) SPD_LAUNCH(DOFV, 16); \

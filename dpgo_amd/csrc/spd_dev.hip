@@ -117,6 +117,10 @@ __global__ __launch_bounds__(256) void k_fa_extend_rows(const FrontDesc *fd, con
     for (int j = 0; j < 4; j++) {
       if (a[j] < 0) continue;
       const double *urow = Fm + er[j].ubase + (long long)a[j] * er[j].cm;
+      // (two children may add into the same entry of the parent's row from different lanes: the additions stay in child order
+      // because a wave's loads and stores of one address are performed in the order the wave issues them, and the compiler
+      // keeps may-alias accesses in program order; tests/test_gpu_parity.py holds this launch to the bits of the per-slot
+      // launches, DPGO_SPD_EXTEND_SLOTS=1, where every child is a kernel of its own)
       for (int b = lane; b <= a[j]; b += 64) Prow[cmap[er[j].cmap_off + b]] += urow[b];
     }
   }
@@ -785,6 +789,14 @@ int SpdNumericCtx::build(const CsrMatrix &A, const SpdFactor &F, const std::vect
   }
   max_lvl = 1;
   for (const auto &l : lvl) max_lvl = std::max(max_lvl, l.size());
+  if (max_lvl > 65535) {
+    // the per-level launches index the fronts of a level with the grid's y extent (only the scatter over ALL fronts is cut
+    // into slices): a tree with more fronts in one level -- about 8 M unknowns at the default leaf size -- is refused here,
+    // with a message, rather than at the first launch, as a HIP error
+    fprintf(stderr, "[dpgo_amd] ERROR: the elimination tree has %zu fronts in one level; the device factorisation handles at most 65535 "
+                    "(larger leaves -- DPGO_SPD_LEAF_TT / _RR -- give fewer fronts).\n", max_lvl);
+    return -1;
+  }
   std::vector<int> lvl_flat;
   lvl_ptr.assign(1, 0);
   for (const auto &l : lvl) { lvl_flat.insert(lvl_flat.end(), l.begin(), l.end()); lvl_ptr.push_back((int)lvl_flat.size()); }

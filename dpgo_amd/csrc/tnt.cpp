@@ -38,16 +38,6 @@ namespace dpgo {
   } while (0)
 
 namespace {
-// DPGO_CG_LAG=0: wait for every CG step's outcome before enqueueing the next (measurement hook)
-int env_lag() {
-  const char *e = getenv("DPGO_CG_LAG");
-  return e ? atoi(e) : 1;
-}
-// DPGO_TNT_DEVICE_START=0: the host takes the norms and starts the CG (one more read-back per refinement; measurement hook)
-bool env_device_start() {
-  static const bool on = !(getenv("DPGO_TNT_DEVICE_START") && atoi(getenv("DPGO_TNT_DEVICE_START")) == 0);
-  return on;
-}
 enum { ST_GRADIENT = 0, ST_PRECON_GRADIENT, ST_REL_DECREASE, ST_STEPSIZE, ST_TRUST_REGION, ST_ITER_LIMIT };
 
 struct NodeTnt {
@@ -281,11 +271,10 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     mB = live_mask(live, dmask_.p + 1);
     return live != 0;
   };
-  static const int lag = env_lag();
 
   // The first trust-region iteration starts without a host round trip: the norms, the gradient tests and the start
   // values of the CG are taken on the device (k_tnt_begin); the host reads the same sums at its first wait below.
-  const bool device_start = o.max_iterations > 0 && o.max_iterations_accepted > 0 && env_device_start();
+  const bool device_start = o.max_iterations > 0 && o.max_iterations_accepted > 0;
   // In the early regime every node ends its first CG step on the trust-region boundary, so -- as long as that was the case
   // the last time -- the trial point of the nodes whose CG is over (dmask[2]) is enqueued right behind that step and ONE
   // wait brings the norms, the CG summary and the trial point's sums.  Otherwise the step is awaited at once.
@@ -373,7 +362,6 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       mA = live_mask(bitsA, dmask_.p);
       mB = live_mask(bitsA, dmask_.p + 1);
       stepA(true);
-      mark_flag_event();
       seqA = fetch_seq_;
     }
     // The first step (enqueued above, or -- with `dev` -- in front of the loop).
@@ -402,20 +390,13 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     if (dev) tnt_speculate_ = !more_steps;   // speculate next time if nobody needed a second step this time
     if (more_steps) {
       stepB();
-      mark_flag_event();   // (polite waiting: an event behind every step whose outcome is waited for)
       unsigned long long seqB = fetch_seq_;
       for (;;) {
-        if (!lag) {
-          wait_flag(seqB);
-          if (!any_live()) break;
-        }
         if (use_graph) graph_step();
-        else { stepA(false); stepB(); mark_flag_event(); }
+        else { stepA(false); stepB(); }
         const unsigned long long next = fetch_seq_;
-        if (lag) {
-          wait_flag(seqB);   // the outcome of the step before the one just enqueued
-          if (!any_live()) break;
-        }
+        wait_flag(seqB);   // the outcome of the step before the one just enqueued
+        if (!any_live()) break;
         seqB = next;
       }
     }

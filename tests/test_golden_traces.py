@@ -64,7 +64,15 @@ def test_gpu_hits_golden_trace(fixtures_dir, golden_dir, name):
     # ... and past the first 60 iterations -- the traces run to convergence since round 5 -- the gradient norm of an
     # iterate that already has the objective to 1e-6 follows the rounding of the inner CG steps (measured: up to 1 % on
     # city10000 / Huber in 12 of 300 iterations, with the objective equal to 1e-6 in all of them)
-    np.testing.assert_allclose(got[61:, 1], ref[61:, 1], rtol=3e-2, atol=1e-6 * ref[0, 1], err_msg="gradient norm trace (late)")
+    # Round 6 (advisor): the loose bound only where it was measured to be needed -- below 1e-3 of the initial norm, and on
+    # city10000 / Huber; everywhere else the late iterations are held to 1e-4 like the early ones.
+    late_got, late_ref = got[61:, 1], ref[61:, 1]
+    if name == "config3_city10000_amm_huber_8nodes":
+        np.testing.assert_allclose(late_got, late_ref, rtol=3e-2, atol=1e-6 * ref[0, 1], err_msg="gradient norm trace (late)")
+    else:
+        big = late_ref > 1e-3 * ref[0, 1]
+        np.testing.assert_allclose(late_got[big], late_ref[big], rtol=1e-4, atol=1e-6 * ref[0, 1], err_msg="gradient norm trace (late, above the floor)")
+        np.testing.assert_allclose(late_got[~big], late_ref[~big], rtol=3e-2, atol=1e-6 * ref[0, 1], err_msg="gradient norm trace (late, below the floor)")
     # north_star: "converging to the same objective as the CPU reference within 1e-6 relative" -- at the END of the run
     assert abs(got[-1, 0] - ref[-1, 0]) <= 1e-6 * abs(ref[-1, 0])
 

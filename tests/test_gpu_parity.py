@@ -976,8 +976,9 @@ np.savez(sys.argv[1], X=drv.X(), trace=np.array(trace))
 
 
 def test_engineering_switches_do_not_change_the_results(fixtures_dir, tmp_path):
-    """The switches of DESIGN 8 select HOW something is computed, never WHAT: lagged CG polling (DPGO_CG_LAG=0) is bit
-    for bit the same run; the host numeric factorisation (DPGO_SPD_HOST_FACTOR=1), panels packed on the host
+    """The switches of DESIGN 8 select HOW something is computed, never WHAT: round 5's launch sequence (DPGO_FUSED=0: the
+    extrapolation, the proximal step, Dfobj, iterate()'s tail, the retraction and the start of a refinement as launches of their
+    own) is bit for bit the same run as round 6's fused one; the host numeric factorisation (DPGO_SPD_HOST_FACTOR=1), panels packed on the host
     (DPGO_SPD_DEVICE_PANELS=0) and the scalar-graph ordering (DPGO_SPD_QUOTIENT=0) are other exact factorisations of the
     same matrices, so the iterates agree to rounding (1e-9 after 25 iterations with refinements)."""
     import subprocess
@@ -999,35 +1000,28 @@ np.save(sys.argv[1], drv.X())
         return np.load(path)
 
     base = run("base")
-    assert np.array_equal(run("lag0", DPGO_CG_LAG="0"), base)
+    # round 6: the fused launch sequence against round 5's (eager and replayed)
+    assert np.array_equal(run("unfused", DPGO_FUSED="0"), base)
+    assert np.array_equal(run("unfused_graph", DPGO_FUSED="0", DPGO_ITER_GRAPH="1"), base)
     # round 5: the branch-free segments of an iteration (update() behind the exchange, the head of iterate(), a refinement
     # up to its trial point, every further CG step) replayed from captured HIP graphs -- the default for a group this
     # small -- against eager launches; and just the CG steps eager (round 4's switch)
     assert np.array_equal(run("nograph", DPGO_ITER_GRAPH="0"), base)
     assert np.array_equal(run("graph_forced", DPGO_ITER_GRAPH="1"), base)
-    assert np.array_equal(run("nograph_lag0", DPGO_ITER_GRAPH="0", DPGO_CG_LAG="0"), base)
     assert np.array_equal(run("no_cg_graph", DPGO_CG_GRAPH="0"), base)
     # ... the refinement started ahead of update()'s read-back (and, replayed, in one segment with the head of the
     # iteration) against the refinement that waits for the decision: the same launches in the same order
     assert np.array_equal(run("no_spec_refine", DPGO_SPEC_REFINE="0"), base)
     assert np.array_equal(run("no_spec_refine_graph", DPGO_SPEC_REFINE="0", DPGO_ITER_GRAPH="1"), base)
-    # ... sleeping on an event instead of polling the flag
-    assert np.array_equal(run("wait_block", DPGO_WAIT="block", DPGO_ITER_GRAPH="1"), base)
-    # ... own-segment launches that cover only the few nodes still in the CG (their segments dealt to all XCDs) against
-    # whole-group grids
-    assert np.array_equal(run("whole_grids", DPGO_LIVE_GRIDS="0"), base)
     # ... the factorisation's assembly with a launch per child slot against all children of a level gathered by the
     # parents' rows in one launch: the same additions in the same order
     assert np.array_equal(run("extend_by_slots", DPGO_SPD_EXTEND_SLOTS="1"), base)
     for tag, env in (("hostfactor", dict(DPGO_SPD_HOST_FACTOR="1")), ("hostpanels", dict(DPGO_SPD_DEVICE_PANELS="0")),
                      ("scalarorder", dict(DPGO_SPD_QUOTIENT="0")),
-                     # round 3: the refinement started by the host, the tree roots in two sweeps, G Y by a pass over the operator
-                     ("hoststart", dict(DPGO_TNT_DEVICE_START="0")), ("tworootsweeps", dict(DPGO_SPD_FUSE_ROOT="0")),
-                     ("gy_by_pass", dict(DPGO_GX_LINEAR="0")),
+                     # round 3: the tree roots in two sweeps
+                     ("tworootsweeps", dict(DPGO_SPD_FUSE_ROOT="0")),
                      # round 4: the fused roots stored as one triangle (forced on: these roots are below its size threshold)
                      ("roots_one_triangle_2_blocks", dict(DPGO_SPD_ROOT_SYM="1", DPGO_SPD_ROOT_SYM_BLOCKS="2")),
-                     # one tile class for the roots whatever the number of live nodes (another split of the same sums)
-                     ("one_root_class", dict(DPGO_SPD_ROOT_FINE_LIVE="0")),
                      ("roots_one_triangle_8_blocks", dict(DPGO_SPD_ROOT_SYM="1", DPGO_SPD_ROOT_SYM_BLOCKS="8")),
                      # the factorisation's block columns right-looking at every level (another order of the same updates)
                      ("rightlooking", dict(DPGO_SPD_LEFT_LOOKING="0")),
@@ -1045,32 +1039,6 @@ np.save(sys.argv[1], drv.X())
         return np.load(path)
 
     np.testing.assert_allclose(run_dyn("dyn_host", DPGO_RESCALE_HOST="1"), run_dyn("dyn_dev"), rtol=0, atol=1e-9, err_msg="dynamic")
-
-
-def test_fp32_preconditioner_experiment_reaches_the_same_objective(fixtures_dir, monkeypatch):
-    """DPGO_PRECON_FP32=1 (an opt-in EXPERIMENT, never the default, never the headline: DESIGN 9) stores the panels of the
-    preconditioner's factor in fp32.  A preconditioner only steers the truncated CG: the surrogate, the acceptance test of
-    every refined step and the objective stay fp64, so the run must reach the oracle's objective like the fp64 run does --
-    by a different path (the inner iteration counts may differ), which is why this is not the reference's arithmetic."""
-    name, nn, loss = "torus3D", 8, LOSS_HUBER
-    path = os.path.join(fixtures_dir, name + ".g2o")
-    num_poses, mm = og.read_g2o_file(path)
-    X0 = chordal_initialization(num_poses, mm)
-    orc = ODistPGO(path, nn, _oracle_opts(loss, True), X0=X0, mm=mm, num_poses=num_poses)
-    G = dpgo_amd.read_g2o(path, nn)
-    finals = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("DPGO_PRECON_FP32", flag)
-        gpu = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(loss, True), X0=X0)
-        for _ in range(150):
-            assert gpu.step() == 0
-        finals[flag] = orc.star.evaluate_f(gpu.X())
-    monkeypatch.delenv("DPGO_PRECON_FP32")
-    for _ in range(150):
-        orc.step(evaluate=False)
-    Fo = orc.star.evaluate_f(orc.gather())
-    assert abs(finals["0"] - Fo) <= 1e-6 * abs(Fo)
-    assert abs(finals["1"] - Fo) <= 1e-6 * abs(Fo)
 
 
 def test_failed_refactorisation_after_a_rescale_fails_the_group(fixtures_dir, tmp_path):

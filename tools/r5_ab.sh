@@ -1,7 +1,8 @@
 # same-box A/B of the host-side mechanisms on an idle host: segments eager / replayed / by measurement, waiting by polling /
 # sleeping; the emulated rank of the 8-GPU run and the small parity configurations.  usage: bash tools/r5_ab.sh <tag> [reps]
 tag=${1:-r5/ab}; reps=${2:-1}; mkdir -p gpurun_out/$tag
-for rep in $(seq $reps); do for g in 0 1 auto; do for w in spin block; do
+# (DPGO_WAIT=block, the sleeping wait, was removed in round 6: DESIGN 9)
+for rep in $(seq $reps); do for g in 0 1 auto; do for w in spin; do
   [ $g = auto ] && [ $w = block ] && continue
   export DPGO_HOST_TIMING=1 DPGO_WAIT=$w
   [ $g = auto ] && unset DPGO_ITER_GRAPH || export DPGO_ITER_GRAPH=$g

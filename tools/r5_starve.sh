@@ -4,7 +4,8 @@
 # then -- and is not a starved run)
 tag=${1:-r5/st}; mkdir -p gpurun_out/$tag
 export DPGO_HOST_TIMING=1
-for rep in 1 2; do for w in spin block; do for g in 0 1; do
+# (DPGO_WAIT=block, the sleeping wait, was removed in round 6: DESIGN 9)
+for rep in 1 2; do for w in spin; do for g in 0 1; do
   export DPGO_ITER_GRAPH=$g DPGO_WAIT=$w
   echo "== DPGO_ITER_GRAPH=$g DPGO_WAIT=$w, 7 spinning siblings on the one core, rep=$rep"
   timeout 400 python bench.py --emulate-world 8 --emulate-rank 3 --no-cpu --no-prof --converge 0 --steps 60 --warmup 10 --windows 15 --starve-host 7 2>gpurun_out/$tag/emu.err | python3 -c "
