@@ -2464,6 +2464,10 @@ bool Group::prepare_extrapolated(const double *gam_dev, int prox_slot) {
     }
     return false;
   }
+  if (trivial && fused_) {   // Y, g and Dfobj at the extrapolated point in one launch (:255-262)
+    launch_extrapolate3(d_, st_, T_, cur_mask_, gam, gam_dev, Zc_.p, Zp_.p, Y_.p, gc_.p, gp_.p, gx_.p, Dfc_.p, Dfp_.p, Dfx_.p);
+    return false;
+  }
   launch_extrapolate(d_, st_, T_, true, cur_mask_, gam, Zc_.p, Zp_.p, Y_.p, gam_dev);
   if (trivial) {
     launch_extrapolate(d_, st_, T_, false, cur_mask_, gam, gc_.p, gp_.p, gx_.p, gam_dev);      // :259-262

@@ -209,6 +209,10 @@ void launch_proximal(int d, hipStream_t st, const SegTable &T, NodeMask mask, co
 // out = a + gamma[node] * (a - b) over all rows (own + neighbour)      (DPGOHash.cpp:255-262)
 void launch_extrapolate(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask,
                         const NodeCoefs &gamma, const double *a, const double *b, double *out, const double *gamma_dev = nullptr);
+// the same for three pairs in one launch: (za, zb) -> zout over all rows, (ga, gb) -> gout and (da, db) -> dout over the own rows
+void launch_extrapolate3(int d, hipStream_t st, const SegTable &T, NodeMask mask, const NodeCoefs &gamma, const double *gamma_dev,
+                         const double *za, const double *zb, double *zout, const double *ga, const double *gb, double *gout,
+                         const double *da, const double *db, double *dout);
 // dev[a] = C.a[a], a < n: the per-iteration coefficients where replayed launches find them (k_set_coefs)
 void launch_set_coefs(hipStream_t st, const NodeCoefs &C, int n, double *dev);
 // The tail of iterate() with the exchange's pack on the way: xk = xak (and z = xak, if given) over the own rows of the masked

@@ -1055,6 +1055,34 @@ __global__ __launch_bounds__(SEG_ROWS) void k_extrapolate(const Seg *segs, NodeM
   store_vec<RS>(out + (size_t)row * RS, va);
 }
 
+// the trivial loss's extrapolated point in ONE launch (DPGOHash.cpp:255-262): Y = X[k] + gamma (X[k] - X[k-1]) over all rows,
+// and over the own rows also g and Dfobj (three launches of k_extrapolate before round 6: the same operations)
+struct Extrap3 {
+  const double *a[3], *b[3];
+  double *out[3];
+};
+template <int D>
+__global__ __launch_bounds__(SEG_ROWS) void k_extrapolate3(const Seg *segs, NodeMask mask, NodeCoefs gamma, const double *gamma_dev,
+                                                      int nseg_own, Extrap3 E) {
+  constexpr int RS = Dim<D>::RS;
+  const Seg s = segs[SEGB];
+  if (!node_on(mask, s.node)) return;
+  const int row = s.begin + threadIdx.x;
+  if (row >= s.end) return;
+  const double gm = gamma_dev ? gamma_dev[s.node] : gamma.a[s.node];
+  const int n = SEGB < nseg_own ? 3 : 1;
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+    if (q < n) {
+      double va[RS], vb[RS];
+      load_vec<RS>(E.a[q] + (size_t)row * RS, va);
+      load_vec<RS>(E.b[q] + (size_t)row * RS, vb);
+#pragma unroll
+      for (int k = 0; k < RS; k++) va[k] = fma(gm, va[k] - vb[k], va[k]);
+      store_vec<RS>(E.out[q] + (size_t)row * RS, va);
+    }
+}
+
 // out = alpha a + beta b on the whole record (PART 0), the translation row (1) or the rotation rows (2);
 // whole 16-byte loads and stores, the untouched part of `out` is carried through registers
 template <int D, int PART>
@@ -2530,6 +2558,19 @@ void launch_extrapolate(int d, hipStream_t st, const SegTable &T, bool all_rows,
   ProfScope ps(PK_AXPBY, st, 3.0 * (all_rows ? T.rows_all : T.rows_own) * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_extrapolate<D>), dim3(nb), dim3(SEG_ROWS), 0, st, T.segs, mask, gamma, gamma_dev,
                                         a, b, out));
+}
+
+void launch_extrapolate3(int d, hipStream_t st, const SegTable &T, NodeMask mask, const NodeCoefs &gamma, const double *gamma_dev,
+                         const double *za, const double *zb, double *zout, const double *ga, const double *gb, double *gout,
+                         const double *da, const double *db, double *dout) {
+  if (T.nseg_all == 0) return;
+  Extrap3 E;
+  E.a[0] = za; E.b[0] = zb; E.out[0] = zout;
+  E.a[1] = ga; E.b[1] = gb; E.out[1] = gout;
+  E.a[2] = da; E.b[2] = db; E.out[2] = dout;
+  ProfScope ps(PK_AXPBY, st, 3.0 * (T.rows_all + 2.0 * T.rows_own) * 8.0 * (d + 1) * d);
+  DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_extrapolate3<D>), dim3(T.nseg_all), dim3(SEG_ROWS), 0, st, T.segs, whole_grid(mask), gamma,
+                                        gamma_dev, T.nseg_own, E));
 }
 
 void launch_axpby(int d, hipStream_t st, const SegTable &T, bool all_rows, NodeMask mask, double alpha,
