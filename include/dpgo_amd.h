@@ -188,7 +188,12 @@ int dpgo_group_star_iterate(dpgo_group_t *grp);
 int dpgo_group_star_state(const dpgo_group_t *grp, double *F, double *fobj, double *fobjh, int *branches);
 /* Boundary exchange with other groups (the message of DPGOHash::receive, DPGOHash.cpp:45-82):
  * pack this group's exported poses into a device buffer of num_sent * (d+1)*d doubles, all-gather
- * the buffers of all groups (RCCL), then unpack.  Keys are (node, pose). */
+ * the buffers of all groups (RCCL), then unpack.  Keys are (node, pose).
+ * dpgo_group_unpack_recv is LAZY for the robust losses (round 6): the neighbour rows stay in `device_gathered` until the
+ * group next looks at them -- the next dpgo_group_update reads them from there inside its inter-edge pass and stores them
+ * into Xk on the way (no unpack kernel); any other reader (dpgo_group_get_Xk, ...) gets the plain indexed copy first.  The
+ * buffer must therefore stay untouched until that update (or any call that reads the group's state) has been made;
+ * everything is ordered on dpgo_group_stream(). */
 int dpgo_group_num_sent(const dpgo_group_t *grp);
 int dpgo_group_sent_keys(const dpgo_group_t *grp, int *nodes, int *poses);
 int dpgo_group_set_recv_layout(dpgo_group_t *grp, int nranks, int stride, const int *counts, const int *nodes,
@@ -214,9 +219,13 @@ int dpgo_group_get_options(const dpgo_group_t *grp, dpgo_options_t *opt);
  *   MPI, torch.distributed -- any channel).
  * dpgo_comm_create: ncclCommInitRank + the exchange lay-out (the ranks all-gather their exported (node, pose) keys);
  *   also connects the group's AMM-PGO* / global-evaluation collectives (dpgo_group_set_collectives) to RCCL.
- * dpgo_comm_exchange: communicate() for neighbours hosted by other ranks -- pack, ncclAllGather, unpack on the
- *   communicator's own stream; returns at once, the group's next update() joins it after queueing the part of the
- *   surrogate build that needs no neighbour data.  Call after dpgo_group_iterate, every rank, every iteration.
+ * dpgo_comm_exchange: communicate() for neighbours hosted by other ranks; returns at once.  Neighbour to neighbour (the
+ *   default with several ranks): ncclGroupStart, one ncclSend + ncclRecv per real neighbour, ncclGroupEnd on the GROUP's own
+ *   stream -- the pack has ridden on the tail of dpgo_group_iterate, the unpack is the next dpgo_group_update's inter-edge
+ *   pass reading the receive buffer (round 6; on a stream of its own the exchange paid two event hand-overs to hide one
+ *   9 us kernel: profiles/r06_exchange_streams.txt).  All-gather (the fallback): pack, ncclAllGather, unpack on the
+ *   communicator's own stream; the group's next update() joins it after queueing the part of the surrogate build that
+ *   needs no neighbour data.  Call after dpgo_group_iterate, every rank, every iteration.
  * dpgo_comm_allreduce_sum: in-place sum of n host doubles over the ranks (bit-identical on every rank).
  * The library binds RCCL at run time (librccl.so.1); these calls return -1 when it cannot be loaded. */
 typedef struct dpgo_comm dpgo_comm_t;
@@ -235,10 +244,12 @@ long dpgo_comm_bytes_sent(const dpgo_comm_t *comm);
 /* Measurement hooks (bench.py --emulate-world N --force-exchange; no counterpart in the reference, whose "exchange" is a
  * memory copy, C++/DPGO/include/DPGO/DPGOHash.h:28-86):
  * dpgo_comm_self_exchange: on a communicator of ONE rank, dpgo_comm_exchange from now on runs the neighbour-to-neighbour path
- *   in its steady state with the rank as its own peer (pack, ncclGroupStart, ncclSend + ncclRecv of every exported record,
- *   ncclGroupEnd, unpack into a scratch array, joined by update()): what that path costs an iteration, short of the wire;
- * dpgo_comm_enable_timing / dpgo_comm_exchange_time: mean time in microseconds from "the iterate is final" on the group's
- *   stream to "the neighbour rows are in place" on the communicator's, over the exchanges since timing was enabled. */
+ *   in its steady state with the rank as its own peer (the pack on the tail of iterate(), ncclGroupStart, ncclSend + ncclRecv
+ *   of every exported record, ncclGroupEnd on the group's stream; what arrives -- the rank's own rows -- is not unpacked, the
+ *   trajectory stays that of the run without an exchange): what that path costs an iteration, short of the wire;
+ * dpgo_comm_enable_timing / dpgo_comm_exchange_time: mean time in microseconds between an event recorded in front of the
+ *   exchange ("the iterate is final") and one behind it ("the neighbour rows have arrived"), over the exchanges since timing
+ *   was enabled. */
 int dpgo_comm_self_exchange(dpgo_comm_t *comm);
 /* ... the same for a group whose neighbours NO rank hosts (one rank of an N-GPU run emulated on one GPU): a communicator of
  * one rank without the exchange lay-out, serving dpgo_comm_exchange in the self-exchange mode only */
@@ -247,7 +258,7 @@ int dpgo_comm_enable_timing(dpgo_comm_t *comm);
 int dpgo_comm_exchange_time(dpgo_comm_t *comm, double *mean_us, long *count);
 /* Test hook: the grouped ncclSend / ncclRecv path of dpgo_comm_exchange on a communicator of ONE rank that is its own peer
  * (legal inside ncclGroupStart / End): every row `grp` exports travels pack kernel -> group call -> unpack kernel on the
- * communicator's stream, on records that carry their own keys.  `grp` may host any subset of the nodes.  0 = every record
+ * communicator's stream (the form of the creation-time check), on records that carry their own keys.  `grp` may host any subset of the nodes.  0 = every record
  * arrived in its row and no other row was touched; -1 otherwise (also when the group exports nothing). */
 int dpgo_debug_comm_p2p_self(dpgo_group_t *grp);
 /* The same pack / unpack on host matrices (no GPU needed; what a host-staged transport or a test uses): records

@@ -6,9 +6,9 @@
 #   levels   per-level solve tables (N = 1 and one node per GPU), the one-node timeline
 #   dynamic  Dynamic-rescale probe and the launches of one refactorisation
 #   rates    parity-configuration rates (5 repetitions, median), every emulated rank of the 8 / 4 / 2-GPU splits
-#   host     round 5: HIP API calls per iteration (eager / replayed), the exchange against itself, the starved-host study
+#   host     HIP API calls per iteration (eager / replayed), the exchange against itself, round 6's launch sequence against round 5's
 #   cpu      the CPU side of the convergence metric (5 minutes of box time)
-tag=${1:-r05}; shift
+tag=${1:-r06}; shift
 stages="${*:-bench stats mfma levels dynamic rates host cpu}"
 out=gpurun_out/final
 mkdir -p $out
@@ -79,9 +79,13 @@ import json,sys; j=json.loads(sys.stdin.read()); print('2 GPUs, rank $r: %.4f ms
 fi
 if has host; then
   bash tools/r5_api.sh final; cat gpurun_out/final/api_emulated_rank_graph0.txt gpurun_out/final/api_emulated_rank_graph1.txt > $out/${tag}_api_calls_per_iteration.txt
-  bash tools/r5_xchg.sh final; cp gpurun_out/final/self_exchange.txt $out/${tag}_emulated_rank_self_exchange.txt
-  bash tools/r5_starve.sh final > /dev/null 2>&1; cp gpurun_out/final/summary.txt $out/${tag}_starved_host.txt
-  bash tools/r5_ab.sh final 1 > /dev/null 2>&1; cp gpurun_out/final/summary.txt $out/${tag}_host_mechanisms_ab.txt
+  bash tools/r6_xchg.sh final "DPGO_X=0" > /dev/null 2>&1; cp gpurun_out/final/self_exchange.txt $out/${tag}_self_exchange_runs.txt
+  # per-iteration view of the emulated rank's kernels: round 6's launch sequence and round 5's (DPGO_FUSED=0), same box
+  bash tools/r6_prof.sh final 60 "DPGO_X=0" "DPGO_FUSED=0"
+  { cat gpurun_out/final/iter_1.txt; echo; cat gpurun_out/final/iter_2.txt; } > $out/${tag}_kernels_per_iteration_one_node.txt
+  # the early regime, five windows per run, three runs each, interleaved: round 6's sequence against round 5's
+  bash tools/r6_windows.sh --emulate-world 8 --emulate-rank 3 -- "DPGO_X=0" "DPGO_FUSED=0" > $out/${tag}_fused_vs_unfused_one_node.txt 2>&1
+  bash tools/r6_windows.sh -- "DPGO_X=0" "DPGO_FUSED=0" > $out/${tag}_fused_vs_unfused_n1.txt 2>&1
 fi
 if has cpu; then
   python tools/cpu_convergence.py > $out/${tag}_cpu_convergence.json 2> $out/cpu_conv.err
