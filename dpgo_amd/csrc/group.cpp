@@ -1,4 +1,6 @@
 #include "group.h"
+
+#include <limits>
 #include "graph.h"
 
 #include <algorithm>
@@ -690,7 +692,7 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   cur_mask_ = ALL_NODES;
   // pinned: [scalars of k_reduce | a cache line | the flag's cache line | CG summaries | TNT summaries]
   const size_t nsc = (size_t)std::max(L, 1) * MAX_SLOTS;
-  HIP_CHECK(hipHostMalloc((void **)&h_scal_, sizeof(double) * (nsc + 16 + (size_t)std::max(L, 1) * (CG_SUMMARY + TNT_SUMMARY + 1) + nsc),
+  HIP_CHECK(hipHostMalloc((void **)&h_scal_, sizeof(double) * (nsc + 16 + (size_t)std::max(L, 1) * (CG_SUMMARY + TNT_SUMMARY + 1) + nsc + 8),
                           hipHostMallocMapped | hipHostMallocCoherent));
   h_flag_ = reinterpret_cast<unsigned long long *>(h_scal_ + nsc + 8);
   *h_flag_ = 0;
@@ -698,6 +700,8 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   h_tnt_ = h_cg_ + (size_t)std::max(L, 1) * CG_SUMMARY;
   h_rs_ = h_tnt_ + (size_t)std::max(L, 1) * TNT_SUMMARY;
   h_upd_ = h_rs_ + std::max(L, 1);   // update()'s sums have a block of their own: the next refinement's sums may arrive before the host has read them
+  h_gate_ = h_upd_ + nsc;            // the verdict of k_amm_gate (group.h: SpecUpdate)
+  h_gate_[0] = -1.0;
   for (int i = 0; i < std::max(L, 1) * (CG_SUMMARY + TNT_SUMMARY + 1); i++) h_cg_[i] = 0.0;
   reduce_arrived_.alloc(1);
   fused_ = env_int("DPGO_FUSED", 1) != 0;
@@ -705,6 +709,10 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   cg_.alloc(MAX_LOCAL_NODES);
   dmask_.alloc(4);
   dev_seq_.alloc(1);
+  go_.alloc(1);
+  dev_sums_.alloc((size_t)MAX_LOCAL_NODES * MAX_SLOTS);
+  dev_tnt_.alloc((size_t)MAX_LOCAL_NODES * TNT_SUMMARY);
+  spec_update_enabled_ = env_int("DPGO_SPEC_UPDATE", 1) != 0;
   coefs_dev_.alloc(MAX_LOCAL_NODES);
 
   upload_operators();
@@ -986,6 +994,8 @@ Group::~Group() {
             num_local(), seg_replays_, t_graph_launch_, seg_replays_ ? 1e6 * t_graph_launch_ / seg_replays_ : 0.0, seg_eager_, t_eager_seg_,
             n_wait_, t_wait_, n_wait_ ? 1e6 * t_wait_ / n_wait_ : 0.0);
   if (host_timing_)
+    fprintf(stderr, "[host] updates enqueued ahead of the host's decision: %ld, of which the decision let stand: %ld\n", n_spec_enqueued_, n_spec_stood_);
+  if (host_timing_)
     fprintf(stderr, "[host] waits of < 50 us / 200 us / 1 ms / 5 ms / 50 ms / longer: %ld %ld %ld %ld %ld %ld; segments replayed since the host was found to be the slower side: %s\n",
             wait_hist_[0], wait_hist_[1], wait_hist_[2], wait_hist_[3], wait_hist_[4], wait_hist_[5], host_bound_ ? "yes" : "no");
   const bool idle = drain(failed_ ? 2.0 : 60.0);
@@ -1098,6 +1108,57 @@ NodeMask Group::live_mask(NodeBits bits, const NodeBits *p) const {
     }
   m.idle_seg = own_seg_ptr_host_[idle];
   return m;
+}
+
+// group.h: SpecUpdate.  Called by run_tnt() with the trial point's reduction enqueued and update(k-1)'s scalars taken.
+bool Group::speculate_update(const double *xprop) {
+  spec_upd_ = SpecUpdate();
+  const int L = num_local();
+  if (!spec_update_armed_ || !spec_update_enabled_ || !fused_ || !keep_gx() || star_ || capturing_ || iter_graph_wanted() ||
+      xchg_done_ || pending_recv_ || !deferred_.empty() || pending_tail_.on || deferred_slots_ != 0 || xprop != tmp_[7].p || L == 0)
+    return false;
+  for (int a = 0; a < L; a++)
+    if (res_[a].iters < 1 || res_[a].hist_iter != res_[a].iters || !res_[a].updated) return false;   // (every node: a later update of a node in step with its history)
+  AmmGate G;
+  G.nnodes = L; G.ds = 2 * MAX_DOTS; G.max_it = opt_.max_iterations; G.max_acc = opt_.max_iterations_accepted;
+  G.max_hits0 = opt_.max_soft_restart_hits[0]; G.max_hits1 = opt_.max_soft_restart_hits[1];
+  G.sqrt_eps = std::sqrt(std::numeric_limits<double>::epsilon()); G.eta1 = .05;   // TNT.h:83 (run_tnt's constants)
+  G.rel_tol = opt_.rel_func_decrease_tol; G.step_tol = opt_.stepsize_tol; G.psi = opt_.psi; G.phi = opt_.phi;
+  for (int a = 0; a < MAX_LOCAL_NODES; a++) {
+    const bool in = a < L;
+    G.f[a] = in ? res_[a].f : 0.0; G.Fk0[a] = in ? res_[a].Fk[0] : 0.0; G.Fk1[a] = in ? res_[a].Fk[1] : 0.0;
+    G.fobj[a] = in ? res_[a].fobj : 0.0;
+    G.hits0[a] = in ? res_[a].soft_restart_hits[0] : 0; G.hits1[a] = in ? res_[a].soft_restart_hits[1] : 0;
+  }
+  launch_amm_gate(st_, G, dev_sums_.p, dev_tnt_.p, cg_.p, go_.p, h_gate_);
+  // the common course from here: the accepted point is the trial buffer; iterate()'s tail and the local halo copy; the history
+  // rotates (X[iter] <- what is X[iter-1] now, and so on); update()'s later-iteration sequence for the static robust surrogate
+  const double *nxak = xprop, *zp = Zc_.p;
+  double *zc = Zp_.p, *gc = gp_.p, *dfc = Dfp_.p, *gx = GXp_.p;
+  const NodeMask m{all_bits(), go_.p};
+  if (gather_dst_.n > 0) launch_copy_indexed(d_, st_, (int)gather_dst_.n, gather_dst_.p, gather_src_.p, nxak, Xk_.p, go_.p);
+  launch_bsr(d_, st_, T_, false, m, G_.dev, nxak, false, nullptr, gx, nxak, 0.5, nullptr, partials_.p, 5, Xk_.p, zc);
+  InterFuse fz;
+  fz.GX = gx; fz.X = nxak; fz.Df = dfc; fz.gn_slot = 4;
+  launch_inter(d_, st_, T_, m, E_, opt_.loss, opt_.loss_reg, 0, true, zc, zp, Qd_.p, Dd_.p, DfE_.p, gc, partials_.p, nullptr, nullptr, nullptr,
+               nullptr, nullptr, Xk_.p, nullptr, &fz);
+  launch_reduce(st_, T_, L, true, 6, partials_.p, h_upd_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
+  n_spec_enqueued_++;
+  spec_upd_.on = true; spec_upd_.seq_upd = fetch_seq_;
+  spec_upd_.xak = nxak; spec_upd_.zc = zc; spec_upd_.gc = gc; spec_upd_.dfc = dfc; spec_upd_.gx = gx;
+  return true;
+}
+
+// The host has taken its decision: the enqueued continuation stands (the common course) or is forgotten (its launches fell
+// through); either way the gate's verdict, which arrives behind the trial point's flag, is compared at the next wait that
+// covers it.
+void Group::check_gate(bool host_common) {
+  if (!spec_upd_.on) return;
+  spec_verdict_pending_ = true;
+  spec_verdict_expected_ = host_common;
+  spec_verdict_seq_ = spec_upd_.seq_upd;
+  if (!host_common) spec_upd_ = SpecUpdate();
+  else n_spec_stood_++;
 }
 
 void Group::flush_pending_tail() {
@@ -1324,6 +1385,16 @@ void Group::wait_flag(unsigned long long seq) {
     }
   }
   if (tt_verdict_pending_ && seq >= tt_verdict_seq_) check_tt_verdict(false);   // (the stream has passed the factorisation)
+  if (spec_verdict_pending_ && seq >= spec_verdict_seq_) {   // (... and the gate of a speculative update)
+    spec_verdict_pending_ = false;
+    const double v = h_gate_[0];
+    if ((v == 1.0) != spec_verdict_expected_) {
+      failed_ = true;
+      fprintf(stderr, "[dpgo_amd] ERROR: the device-side gate of the speculative update (%.0f) and the host (%d) disagree; the group cannot go on.\n",
+              v, (int)spec_verdict_expected_);
+      throw DeviceError("gate / host verdicts differ");
+    }
+  }
 }
 
 void Group::copy_rows(double *dst, const double *src, bool all_rows, int part) {
@@ -1730,6 +1801,7 @@ int Group::scatter_global(double *X, int ld) const {
 int Group::communicate_local() {
   // neighbour rows whose owner lives in this group: one indexed device copy (DPGOHash.h:64-82)
   if (gather_dst_.n == 0) return 0;
+  if (spec_upd_.on) return 0;   // (enqueued ahead, under the gate: speculate_update)
   if (pending_tail_.on) {
     // Xk's own rows are still on their way (they ride on the next update()'s product with G): the neighbour rows come
     // from Xak, which holds the same records
@@ -1744,10 +1816,11 @@ int Group::communicate_local() {
 int Group::step(const std::vector<int> &locals, const std::function<int()> &exchange) {
   struct Disarm {   // (whatever happens in between -- an error return, an exception on its way to the C ABI -- nothing stays deferred)
     Group *g;
-    ~Disarm() { g->defer_armed_ = false; g->tail_fusable_ = false; g->pending_tail_.on = false; g->deferred_.clear(); g->deferred_key_ = 0; }
+    ~Disarm() { g->defer_armed_ = false; g->tail_fusable_ = false; g->spec_update_armed_ = false; g->pending_tail_.on = false; g->deferred_.clear(); g->deferred_key_ = 0; }
   } disarm{this};
   defer_armed_ = !exchange && iter_graph_wanted();
   tail_fusable_ = !exchange;
+  spec_update_armed_ = !exchange;
   int rc = iterate(locals);
   tail_fusable_ = false;
   if (rc == 0 && exchange) rc = exchange();
@@ -2184,6 +2257,19 @@ int Group::update(const std::vector<int> &locals_in) {
     deferred_slots_ = 0;
     NodeBits bits = 0;
     for (int a : set) bits |= 1ull << a;
+    if (spec_upd_.on) {
+      // the launches of this sequence went out ahead of the host's decision (speculate_update) and the decision was the
+      // common one: what they were given must be what this call would have given them
+      const SpecUpdate sp = spec_upd_;
+      spec_upd_ = SpecUpdate();
+      const bool same = seg_id == 4 && fuse_copy && nslots == 6 && bits == all_bits() && !xchg_done_ && !lazy_recv && sp.seq_upd == fetch_seq_ &&
+                        sp.xak == Xak_.p && sp.zc == Zc_.p && sp.gc == gc_.p && sp.dfc == Dfc_.p && sp.gx == GXc_.p && pending_tail_.on;
+      if (!same) {
+        failed_ = true;
+        throw DeviceError("a speculative update was enqueued for another state than update() found");
+      }
+      pending_tail_.on = false;   // (it rode on the enqueued product with G)
+    } else
     segment(seg_id, bits & mask_locals_bits, {bits, mask_locals_bits, variant, (unsigned long long)nslots, fuse_copy ? 1ull : 0ull, (unsigned long long)(uintptr_t)lazy_recv}, [&] {
       launches();
       launch_reduce(st_, T_, num_local(), true, nslots, partials_.p, h_upd_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
@@ -2672,6 +2758,8 @@ int Group::amm(const std::vector<int> &locals) {
     for (int a : set) res_[a].Gk = scal(a, 0) + res_[a].f;
   }
   for (int a : locals) res_[a].Gkh = Gkh[a];
+  // (a speculative update stands only if the iteration took the common course: group.h)
+  check_gate(done_tnt && tnt_common_ && redo.empty() && restart.empty() && fb_x.empty() && fb_c.empty());
   return 0;
 }
 

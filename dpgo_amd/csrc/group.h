@@ -403,6 +403,34 @@ class Group {
   // when no exchange stands between the two (the exchange's pack reads Xk); anything else launches it on its own.
   struct PendingTail { bool on = false; NodeMask m = ALL_NODES; const double *xak = nullptr; double *xk = nullptr, *z = nullptr; };
   PendingTail pending_tail_;
+  // ---- The next update() enqueued AHEAD of the host's decision (round 6).  Between the trial point's read-back and the first
+  // launch of update() the GPU used to idle for the host's acceptance test and bookkeeping (~13-17 us of an iteration of
+  // 0.35-1.25 ms).  In the regime where that decision always comes out the same way -- every node refined, its CG over after
+  // one step, the step accepted, no redo, no restart, no fallback: the whole early regime -- run_tnt() enqueues, right behind
+  // the trial point's reduction and before it waits for it: a GATE kernel (k_amm_gate) that takes that very decision on the
+  // device from the same sums, and the launches the common course leads to -- the local halo copy, update()'s product with G
+  // (which carries iterate()'s tail) and its inter-edge pass and reduction, with the buffers in the roles they will have
+  // after the accepted step and the rotation of the history -- under the device word the gate sets.  The host then takes its
+  // decision as ever; if it is the common one, iterate() / communicate_local() / update() find their launches done and only
+  // do their bookkeeping; if not, those launches have fallen through (they touched nothing) and the normal path runs.  The
+  // two verdicts come from the same bits through the same operations; the host checks that they agree when it next waits
+  // (finish_update).  Armed by step() without an exchange; eager launches only; DPGO_SPEC_UPDATE=0 switches it off.
+  struct SpecUpdate {
+    bool on = false, consumed_copy = false;
+    unsigned long long seq_upd = 0;
+    const double *xak = nullptr; double *zc = nullptr, *gc = nullptr, *dfc = nullptr, *gx = nullptr;   // the roles it was enqueued with
+  };
+  SpecUpdate spec_upd_;
+  long n_spec_enqueued_ = 0, n_spec_stood_ = 0;   // (DPGO_HOST_TIMING=1 prints them)
+  bool spec_update_armed_ = false, spec_update_enabled_ = true;
+  bool tnt_common_ = false;          // run_tnt: the refinement took the common course (one step, accepted by every node, over)
+  DevBuf<NodeBits> go_;              // the gate's word
+  DevBuf<double> dev_sums_, dev_tnt_;   // the trial point's sums / the refinement's start, per node, in device memory
+  double *h_gate_ = nullptr;         // pinned (same allocation as h_scal_): the gate's verdict
+  bool spec_verdict_pending_ = false, spec_verdict_expected_ = false;   // the host acted on its own verdict; the gate's is compared at the next wait
+  unsigned long long spec_verdict_seq_ = 0;
+  bool speculate_update(const double *xprop);   // run_tnt: enqueue gate + continuation; false: conditions not met, nothing enqueued
+  void check_gate(bool host_common);
   bool tail_fusable_ = false;
   void flush_pending_tail();
   DevBuf<unsigned> reduce_arrived_;

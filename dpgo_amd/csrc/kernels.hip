@@ -1387,10 +1387,10 @@ __global__ __launch_bounds__(SEG_ROWS) void k_rot_op(const Seg *segs, NodeMask m
 // dst[didx[k]] = src[sidx[k]]  (didx == nullptr: dst[k]); halo copies, pack and unpack
 template <int D>
 __global__ __launch_bounds__(256) void k_copy_indexed(int count, const int *didx, const int *sidx,
-                                                      const double *src, double *dst) {
+                                                      const double *src, double *dst, const NodeBits *gate) {
   constexpr int RS = Dim<D>::RS;
   const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= count) return;
+  if (k >= count || (gate && *gate == 0ull)) return;   // gate: a device word that switches the whole launch off (k_amm_gate)
   double r[RS];
   load_vec<RS>(src + (size_t)sidx[k] * RS, r);
   store_vec<RS>(dst + (size_t)(didx ? didx[k] : k) * RS, r);
@@ -1426,7 +1426,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_bdiag_dot(const Seg *segs, NodeMas
 // host gets the numbers by polling a cache line instead of a copy + stream synchronisation.
 __global__ __launch_bounds__(64) void k_reduce(SegTable T, int all_rows, int nslots, const double *partials,
                                                double *host_scalars, unsigned *arrived, unsigned long long *host_flag,
-                                               unsigned long long seq, unsigned long long *dev_seq) {
+                                               unsigned long long seq, unsigned long long *dev_seq, double *dev_scalars) {
   const int a = blockIdx.x / nslots, s = blockIdx.x % nslots, lane = threadIdx.x;
   const double *p = partials + (size_t)s * T.nseg_all;
   double v = 0;
@@ -1436,6 +1436,7 @@ __global__ __launch_bounds__(64) void k_reduce(SegTable T, int all_rows, int nsl
   v = wave_sum(v);
   if (lane == 0) {
     __hip_atomic_store(host_scalars + a * MAX_SLOTS + s, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (dev_scalars) dev_scalars[a * MAX_SLOTS + s] = v;   // (the gate of a speculative update reads them there: k_amm_gate)
     __atomic_thread_fence(__ATOMIC_RELEASE);   // system scope: the scalar is on its way before the count
     const unsigned done = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
     if (done == gridDim.x - 1) {
@@ -1496,7 +1497,7 @@ struct TntBegin {
 // the per-node part: v = the six sums (|grad|^2, <X, nabla>, <X, g>, <X, g_alt>, |P grad|^2, <grad, P grad>); one thread
 __device__ __forceinline__ void tnt_begin_node(int a, bool mine, const double (&v)[6], int use_precon, int max_it, double grad_tol,
                                                double pgrad_tol, double kappa, double theta, double Delta, CgNode *cg,
-                                               NodeBits *dmask, double *host_tnt) {
+                                               NodeBits *dmask, double *host_tnt, double *dev_tnt = nullptr) {
   bool active = false, live = false;
   if (mine) {
     const double gnorm = sqrt(v[0]), pgnorm = use_precon ? sqrt(v[4]) : gnorm, rv0 = use_precon ? v[5] : v[0];
@@ -1516,6 +1517,11 @@ __device__ __forceinline__ void tnt_begin_node(int a, bool mine, const double (&
 #pragma unroll
     for (int q = 0; q < 6; q++) __hip_atomic_store(host_tnt + a * TNT_SUMMARY + q, v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(host_tnt + a * TNT_SUMMARY + 6, active ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (dev_tnt) {   // (k_amm_gate)
+#pragma unroll
+      for (int q = 0; q < 6; q++) dev_tnt[a * TNT_SUMMARY + q] = v[q];
+      dev_tnt[a * TNT_SUMMARY + 6] = active ? 1.0 : 0.0;
+    }
   }
   // every node owns its bit of the three masks (a node outside `bits` clears it): no word is written as a whole, so the
   // workgroups need not meet
@@ -1664,7 +1670,7 @@ constexpr int CG_FIRST_SLOT = 16;   // (six consecutive slots nobody else uses: 
 __global__ __launch_bounds__(640) void k_cg_scal_begin(SegTable T, TntBegin B, const double *partials, CgNode *cg, NodeBits *dmask,
                                                        double *host_tnt, double *host_scalars, unsigned *arrived,
                                                        unsigned long long *host_flag, unsigned long long seq,
-                                                       unsigned long long *dev_seq) {
+                                                       unsigned long long *dev_seq, double *dev_tnt) {
   __shared__ double sums[10];
   const int a = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool cand = (B.bits >> a) & 1ull;
@@ -1683,7 +1689,7 @@ __global__ __launch_bounds__(640) void k_cg_scal_begin(SegTable T, TntBegin B, c
   double v6[6];
 #pragma unroll
   for (int q = 0; q < 6; q++) v6[q] = sums[q];
-  tnt_begin_node(a, cand, v6, B.use_precon, B.max_it, B.grad_tol, B.pgrad_tol, B.kappa, B.theta, B.Delta[a], cg, dmask, host_tnt);
+  tnt_begin_node(a, cand, v6, B.use_precon, B.max_it, B.grad_tol, B.pgrad_tol, B.kappa, B.theta, B.Delta[a], cg, dmask, host_tnt, dev_tnt);
   // (the node's own bit of dmask[0], as tnt_begin_node has just left it: nobody else writes it)
   const bool mine = cand && cg[a].live;
   double v[4] = {0.0, 0.0, 0.0, 0.0};
@@ -2641,14 +2647,14 @@ void launch_tnt_begin(hipStream_t st, const SegTable &T, int nnodes, NodeBits bi
 void launch_cg_scal_begin(hipStream_t st, const SegTable &T, int nnodes, NodeBits bits, bool use_precon, int max_it, double grad_tol,
                            double pgrad_tol, double kappa, double theta, const double *Delta, const double *partials, CgNode *cg,
                            NodeBits *dmask, double *host_tnt, double *host_scalars, unsigned *arrived, unsigned long long *host_flag,
-                           unsigned long long seq, unsigned long long *dev_seq) {
+                           unsigned long long seq, unsigned long long *dev_seq, double *dev_tnt) {
   TntBegin B;
   B.bits = bits; B.use_precon = use_precon; B.max_it = max_it;
   B.grad_tol = grad_tol; B.pgrad_tol = pgrad_tol; B.kappa = kappa; B.theta = theta;
   for (int a = 0; a < MAX_LOCAL_NODES; a++) B.Delta[a] = a < nnodes ? Delta[a] : 0.0;
   ProfScope ps(PK_REDUCE, st, 8.0 * 10 * T.nseg_own);
   hipLaunchKernelGGL(k_cg_scal_begin, dim3(nnodes), dim3(640), 0, st, T, B, partials, cg, dmask, host_tnt, host_scalars, arrived,
-                     host_flag, seq, dev_seq);
+                     host_flag, seq, dev_seq, dev_tnt);
 }
 int cg_first_slot() { return CG_FIRST_SLOT; }
 
@@ -2718,11 +2724,11 @@ void launch_retract_rot(int d, hipStream_t st, const SegTable &T, NodeMask mask,
 }
 
 void launch_copy_indexed(int d, hipStream_t st, int count, const int *didx, const int *sidx, const double *src,
-                         double *dst) {
+                         double *dst, const NodeBits *gate) {
   if (count == 0) return;
   ProfScope ps(PK_COPYIDX, st, 2.0 * count * 8.0 * (d + 1) * d);
   DPGO_DISPATCH_D(d, hipLaunchKernelGGL((k_copy_indexed<D>), dim3((count + 255) / 256), dim3(256), 0, st, count,
-                                        didx, sidx, src, dst));
+                                        didx, sidx, src, dst, gate));
 }
 
 void launch_bdiag_dot(int d, hipStream_t st, const SegTable &T, NodeMask mask, const double *Dd, const double *x,
@@ -2791,12 +2797,58 @@ void launch_publish(hipStream_t st, const double *vals, int n, double *host, uns
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, vals, n, host, host_flag, seq, dev_seq);
 }
 
+// ---- the gate of a speculative update (Group::speculate_update): one thread per node evaluates, from the sums the trial
+// point's k_reduce left in device memory, the refinement's start (k_cg_scal_begin) and the CG's state, whether the iteration
+// takes its COMMON course -- the node was refined, its CG ended with the first step, the step is accepted and ends the
+// refinement (TNT.h:537-607), the half step needs no redo, there is no restart and no fallback (DPGOHash.cpp:386-441) -- with
+// the host's expressions in the host's order (amm(), run_tnt()'s judge): the two must reach the same verdict from the same
+// bits, and the host checks that they did.  *go = all ones if every node does, else 0: the launches of the next update(),
+// enqueued behind this kernel under that word, run or fall through.
+__global__ __launch_bounds__(64) void k_amm_gate(AmmGate G, const double *sums, const double *tnt, const CgNode *cg, NodeBits *go,
+                                                 double *host_out) {
+#pragma clang fp contract(off)   // (the host rounds every product before it adds: so must this)
+  const int a = threadIdx.x;
+  bool common = true;
+  if (a < G.nnodes) {
+    const double *t = sums + a * MAX_SLOTS, *b = tnt + a * TNT_SUMMARY;
+    const double f = G.f[a], Fk0 = G.Fk0[a], Fk1 = G.Fk1[a], fobj = G.fobj[a];
+    const bool active = b[6] != 0.0, cg_over = cg[a].live == 0;
+    const double fx = 0.5 * (b[1] + b[2]) + f;                 // norms_take
+    const double fx_prop = 0.5 * (t[5] + t[3]) + f;            // judge
+    const double h_norm = sqrt(t[0]);
+    const double dm = -t[1] - 0.5 * t[2];
+    const double df = fx - fx_prop;
+    const double rel_dec = df / (G.sqrt_eps + fabs(fx));
+    const double rho = df / dm;
+    const bool ok = (!isnan(rho)) && rho > G.eta1;
+    const bool stop = rel_dec < G.rel_tol || h_norm < G.step_tol;
+    const bool ends = stop || !(1 < G.max_it && 1 < G.max_acc);   // no further trust-region iteration behind the accepted one
+    const double Gk = fx_prop - t[3] + t[4];                    // f(X | g[k]): only the linear term depends on g
+    const double Gkh = t[G.ds + 1] + f;
+    const double minG = Fk0 - G.psi * t[G.ds];
+    const bool redo = Gkh > minG;
+    const bool hr = Gk > Fk0;
+    const bool sr = (Gk > Fk1 && G.hits0[a] >= G.max_hits0) || (Gk > fobj && G.hits1[a] > G.max_hits1);
+    const bool fb = (Fk0 - Gk) < G.phi * (Fk0 - Gkh);
+    common = active && cg_over && ok && ends && !redo && !(hr || sr) && !fb;
+  }
+  const bool all = __all(common);
+  if (threadIdx.x == 0) {
+    *go = all ? ~0ull : 0ull;
+    __hip_atomic_store(host_out, all ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+void launch_amm_gate(hipStream_t st, const AmmGate &G, const double *sums, const double *tnt, const CgNode *cg, NodeBits *go,
+                     double *host_out) {
+  hipLaunchKernelGGL(k_amm_gate, dim3(1), dim3(64), 0, st, G, sums, tnt, cg, go, host_out);
+}
+
 void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows, int nslots, const double *partials,
                    double *host_scalars, unsigned *arrived, unsigned long long *host_flag, unsigned long long seq,
-                   unsigned long long *dev_seq) {
+                   unsigned long long *dev_seq, double *dev_scalars) {
   ProfScope ps(PK_REDUCE, st, 8.0 * nslots * T.nseg_all);
   hipLaunchKernelGGL(k_reduce, dim3(nnodes * nslots), dim3(64), 0, st, T, all_rows ? 1 : 0, nslots, partials, host_scalars,
-                     arrived, host_flag, seq, dev_seq);
+                     arrived, host_flag, seq, dev_seq, dev_scalars);
 }
 
 void launch_set_coefs(hipStream_t st, const NodeCoefs &C, int n, double *dev) {

@@ -158,7 +158,7 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     // nprop = G xprop + g: gives f(xprop) and, if accepted, the next model; its epilogue leaves the six sums
     // <s,s>, <grad,s>, <s,Hs>, <x+,g>, <x+,g_alt>, <x+,nprop> in the partial slots 0..5
     apply_tcol(xprop, T1_.p, nprop, 0, nullptr, nullptr, nullptr, nullptr, nullptr, partials_.p, g, ga, sk, grad, hh);
-    launch_reduce(st_, T_, L, false, nslots, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
+    launch_reduce(st_, T_, L, false, nslots, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p, dev_sums_.p);
   };
   // acceptance test and trust-region update of node a from the sums of its trial point (TNT.h:537-607)
   std::vector<int> acc, requad;
@@ -281,7 +281,10 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
   const bool spec = device_start && tnt_speculate_;
   set_mask(nodes);
   const NodeBits bits_nodes = cur_mask_.v;
-  unsigned long long seqA = 0;
+  unsigned long long seqA = 0, seq_first = 0;
+  bool merged = false;
+  tnt_common_ = false;
+  int tr_rounds = 0;
   if (device_start) {
     // Everything from the model gradient to the first wait is branch-free: ONE segment (a replay where the host's launch
     // rate would bound it).  Every node of `nodes` is a candidate (the iteration limits allow a first iteration), the radii
@@ -301,9 +304,9 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       const std::function<void(const double *)> begin = [&](const double *) {
         launch_cg_scal_begin(st_, T_, L, bitsA, use_precon, o.max_tCG_iterations, o.grad_norm_tol, o.preconditioned_grad_norm_tol,
                              o.STPCG_kappa, o.STPCG_theta, Delta.data(), partials_.p, cg_.p, dmask_.p, h_tnt_, h_cg_, reduce_arrived_.p,
-                             h_flag_, next_seq(), dev_seq_.p);
+                             h_flag_, next_seq(), dev_seq_.p, dev_tnt_.p);
       };
-      const bool merged = fused_;
+      merged = fused_;
       if (!merged)
         launch_tnt_begin(st_, T_, L, bitsA, use_precon, o.max_tCG_iterations, o.grad_norm_tol, o.preconditioned_grad_norm_tol,
                          o.STPCG_kappa, o.STPCG_theta, Delta.data(), partials_.p, cg_.p, dmask_.p, h_tnt_);
@@ -315,10 +318,14 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     mA = live_mask(bitsA, dmask_.p);   // (a replay does not run the body: the host's copies)
     mB = live_mask(bitsA, dmask_.p + 1);
     cur_mask_ = live_mask(bits_nodes, nullptr);
+    seq_first = fetch_seq_;   // (the flag of the last launch of the segment: the trial point's reduction, or the first step's scalars)
     // the caller's read-back (the scalars that decide whether these nodes are refined at all) is taken NOW, with the start
     // of the refinement already on the GPU: the stream never waits for that decision
     if (confirm && !(*confirm)()) return false;
-    seqA = fetch_seq_ - (spec ? 1 : 0);
+    seqA = seq_first - (spec ? 1 : 0);
+    // ... and where every node of the group is in here and the trial point is on its way, the update() that the common
+    // outcome leads to goes out as well, under a gate that takes the decision on the device (group.h: SpecUpdate)
+    if (confirm && spec && merged && (int)nodes.size() == L && base_ready && X == Xak_.p) speculate_update(xprop);
   } else {
     flush_deferred();   // (launches that were waiting for this refinement's first segment: there is none on this path)
     if (confirm && !(*confirm)()) return false;
@@ -342,6 +349,8 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       A.push_back(a);
     }
     if (A.empty()) break;
+    tr_rounds++;
+    if (tr_rounds > 1) tnt_common_ = false;   // (a further round: not the common course)
     std::vector<double> tsum((size_t)L * NSUM, 0.0);
     std::vector<char> tried(L, 0);
     if (!dev) {
@@ -365,7 +374,7 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       seqA = fetch_seq_;
     }
     // The first step (enqueued above, or -- with `dev` -- in front of the loop).
-    if (dev && spec) wait_flag(fetch_seq_);   // (the trial point's reduction: everything before it is there too)
+    if (dev && spec) wait_flag(seq_first);   // (the trial point's reduction: everything before it is there too)
     else wait_flag(seqA);
     if (dev) {
       // the sums k_tnt_begin reduced, and its verdict on the gradient tests
@@ -430,6 +439,11 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       Xak_.swap(tmp_[7]);
       X = Xak_.p;
       xprop = tmp_[7].p;
+      // the common course (group.h: SpecUpdate): the first round, every node's trial point taken behind its first CG step,
+      // every step accepted, no further round
+      bool all_tried = dev && spec;
+      for (int a = 0; a < L; a++) all_tried = all_tried && tried[a];
+      tnt_common_ = all_tried && tr_rounds == 1 && requad.empty();
     } else if (!acc.empty()) {
       set_mask(acc);
       copy_rows(X, xprop, false, 0);

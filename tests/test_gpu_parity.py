@@ -1003,6 +1003,9 @@ np.save(sys.argv[1], drv.X())
     # round 6: the fused launch sequence against round 5's (eager and replayed)
     assert np.array_equal(run("unfused", DPGO_FUSED="0"), base)
     assert np.array_equal(run("unfused_graph", DPGO_FUSED="0", DPGO_ITER_GRAPH="1"), base)
+    # ... update()'s launches enqueued ahead of the host's acceptance decision, under the device-side gate (Group::SpecUpdate),
+    # against the host deciding first
+    assert np.array_equal(run("no_spec_update", DPGO_SPEC_UPDATE="0"), base)
     # round 5: the branch-free segments of an iteration (update() behind the exchange, the head of iterate(), a refinement
     # up to its trial point, every further CG step) replayed from captured HIP graphs -- the default for a group this
     # small -- against eager launches; and just the CG steps eager (round 4's switch)
