@@ -700,7 +700,7 @@ Group::Group(const Graph &g, const std::vector<int> &node_ids, const Options &op
   h_tnt_ = h_cg_ + (size_t)std::max(L, 1) * CG_SUMMARY;
   h_rs_ = h_tnt_ + (size_t)std::max(L, 1) * TNT_SUMMARY;
   h_upd_ = h_rs_ + std::max(L, 1);   // update()'s sums have a block of their own: the next refinement's sums may arrive before the host has read them
-  h_gate_ = h_upd_ + nsc;            // the verdict of k_amm_gate (group.h: SpecUpdate)
+  h_gate_ = h_upd_ + nsc;            // the verdict of k_reduce_gate (group.h: SpecUpdate)
   h_gate_[0] = -1.0;
   for (int i = 0; i < std::max(L, 1) * (CG_SUMMARY + TNT_SUMMARY + 1); i++) h_cg_[i] = 0.0;
   reduce_arrived_.alloc(1);
@@ -1110,15 +1110,22 @@ NodeMask Group::live_mask(NodeBits bits, const NodeBits *p) const {
   return m;
 }
 
-// group.h: SpecUpdate.  Called by run_tnt() with the trial point's reduction enqueued and update(k-1)'s scalars taken.
-bool Group::speculate_update(const double *xprop) {
-  spec_upd_ = SpecUpdate();
+// group.h: SpecUpdate.  spec_update_possible: asked by run_tnt() before it enqueues the head of a refinement -- the trial
+// point's reduction then waits for speculate_update(), which is called once update(k-1)'s scalars are taken (the gate gets
+// them by value) and enqueues that reduction WITH the gate in one launch, then the continuation.
+bool Group::spec_update_possible(const double *xprop) const {
   const int L = num_local();
   if (!spec_update_armed_ || !spec_update_enabled_ || !fused_ || !keep_gx() || star_ || capturing_ || iter_graph_wanted() ||
-      xchg_done_ || pending_recv_ || !deferred_.empty() || pending_tail_.on || deferred_slots_ != 0 || xprop != tmp_[7].p || L == 0)
+      xchg_done_ || pending_recv_ || !deferred_.empty() || pending_tail_.on || xprop != tmp_[7].p || L == 0)
     return false;
   for (int a = 0; a < L; a++)
-    if (res_[a].iters < 1 || res_[a].hist_iter != res_[a].iters || !res_[a].updated) return false;   // (every node: a later update of a node in step with its history)
+    if (res_[a].iters < 1 || !res_[a].updated) return false;   // (every node: a later update, never a node's first)
+  return true;
+}
+
+void Group::speculate_update(const double *xprop, int nslots_trial) {
+  spec_upd_ = SpecUpdate();
+  const int L = num_local();
   AmmGate G;
   G.nnodes = L; G.ds = 2 * MAX_DOTS; G.max_it = opt_.max_iterations; G.max_acc = opt_.max_iterations_accepted;
   G.max_hits0 = opt_.max_soft_restart_hits[0]; G.max_hits1 = opt_.max_soft_restart_hits[1];
@@ -1130,7 +1137,10 @@ bool Group::speculate_update(const double *xprop) {
     G.fobj[a] = in ? res_[a].fobj : 0.0;
     G.hits0[a] = in ? res_[a].soft_restart_hits[0] : 0; G.hits1[a] = in ? res_[a].soft_restart_hits[1] : 0;
   }
-  launch_amm_gate(st_, G, dev_sums_.p, dev_tnt_.p, cg_.p, go_.p, h_gate_);
+  // the trial point's sums to the host (k_reduce's work, its flag) and the gate's verdict, one launch
+  launch_reduce_gate(st_, T_, L, nslots_trial, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p, dev_sums_.p, G,
+                     dev_tnt_.p, cg_.p, go_.p, h_gate_);
+  spec_upd_.seq_trial = fetch_seq_;
   // the common course from here: the accepted point is the trial buffer; iterate()'s tail and the local halo copy; the history
   // rotates (X[iter] <- what is X[iter-1] now, and so on); update()'s later-iteration sequence for the static robust surrogate
   const double *nxak = xprop, *zp = Zc_.p;
@@ -1146,7 +1156,6 @@ bool Group::speculate_update(const double *xprop) {
   n_spec_enqueued_++;
   spec_upd_.on = true; spec_upd_.seq_upd = fetch_seq_;
   spec_upd_.xak = nxak; spec_upd_.zc = zc; spec_upd_.gc = gc; spec_upd_.dfc = dfc; spec_upd_.gx = gx;
-  return true;
 }
 
 // The host has taken its decision: the enqueued continuation stands (the common course) or is forgotten (its launches fell

@@ -407,8 +407,8 @@ class Group {
   // launch of update() the GPU used to idle for the host's acceptance test and bookkeeping (~13-17 us of an iteration of
   // 0.35-1.25 ms).  In the regime where that decision always comes out the same way -- every node refined, its CG over after
   // one step, the step accepted, no redo, no restart, no fallback: the whole early regime -- run_tnt() enqueues, right behind
-  // the trial point's reduction and before it waits for it: a GATE kernel (k_amm_gate) that takes that very decision on the
-  // device from the same sums, and the launches the common course leads to -- the local halo copy, update()'s product with G
+  // the last kernel of the trial point and before it waits for it: the trial point's reduction with a GATE in the same launch
+  // (k_reduce_gate) that takes that very decision on the device from the same sums, and the launches the common course leads to -- the local halo copy, update()'s product with G
   // (which carries iterate()'s tail) and its inter-edge pass and reduction, with the buffers in the roles they will have
   // after the accepted step and the rotation of the history -- under the device word the gate sets.  The host then takes its
   // decision as ever; if it is the common one, iterate() / communicate_local() / update() find their launches done and only
@@ -417,7 +417,7 @@ class Group {
   // (finish_update).  Armed by step() without an exchange; eager launches only; DPGO_SPEC_UPDATE=0 switches it off.
   struct SpecUpdate {
     bool on = false, consumed_copy = false;
-    unsigned long long seq_upd = 0;
+    unsigned long long seq_trial = 0, seq_upd = 0;   // the flags of the trial point's reduction (+ gate) and of update()'s
     const double *xak = nullptr; double *zc = nullptr, *gc = nullptr, *dfc = nullptr, *gx = nullptr;   // the roles it was enqueued with
   };
   SpecUpdate spec_upd_;
@@ -429,7 +429,8 @@ class Group {
   double *h_gate_ = nullptr;         // pinned (same allocation as h_scal_): the gate's verdict
   bool spec_verdict_pending_ = false, spec_verdict_expected_ = false;   // the host acted on its own verdict; the gate's is compared at the next wait
   unsigned long long spec_verdict_seq_ = 0;
-  bool speculate_update(const double *xprop);   // run_tnt: enqueue gate + continuation; false: conditions not met, nothing enqueued
+  bool spec_update_possible(const double *xprop) const;
+  void speculate_update(const double *xprop, int nslots_trial);   // run_tnt: the trial point's reduction + gate, then the continuation
   void check_gate(bool host_common);
   bool tail_fusable_ = false;
   void flush_pending_tail();

@@ -272,20 +272,21 @@ void launch_bdiag_dot(int d, hipStream_t st, const SegTable &T, NodeMask mask, c
 // memory; *host_flag = seq once all of them are there (arrived: a zeroed device counter)
 void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows, int nslots, const double *partials,
                    double *host_scalars, unsigned *arrived, unsigned long long *host_flag, unsigned long long seq,
-                   unsigned long long *dev_seq,    // seq == 0: *dev_seq + 1 (a replayed launch); *dev_seq ends up holding the value used
-                   double *dev_scalars = nullptr); // the same sums once more, in device memory (launch_amm_gate reads them)
+                   unsigned long long *dev_seq);   // seq == 0: *dev_seq + 1 (a replayed launch); *dev_seq ends up holding the value used
 
-// ---- the gate of a speculative update (k_amm_gate): the per-node scalars the host knows when it enqueues the gate, by value
+// ---- the gate of a speculative update (k_reduce_gate): the per-node scalars the host knows when it enqueues the gate, by value
 struct AmmGate {
   int nnodes = 0, ds = 0, max_it = 0, max_acc = 0, max_hits0 = 0, max_hits1 = 0;
   double sqrt_eps = 0, eta1 = 0, rel_tol = 0, step_tol = 0, psi = 0, phi = 0;
   double f[MAX_LOCAL_NODES], Fk0[MAX_LOCAL_NODES], Fk1[MAX_LOCAL_NODES], fobj[MAX_LOCAL_NODES];
   int hits0[MAX_LOCAL_NODES], hits1[MAX_LOCAL_NODES];
 };
-// sums: the trial point's sums per node (MAX_SLOTS each, launch_reduce's dev_scalars), tnt: the refinement's start per node
-// (TNT_SUMMARY each, launch_cg_scal_begin's dev_tnt); *go = ~0 / 0, host_out[0] = 1.0 / 0.0 (pinned)
-void launch_amm_gate(hipStream_t st, const AmmGate &G, const double *sums, const double *tnt, const CgNode *cg, NodeBits *go,
-                     double *host_out);
+// launch_reduce (own rows, nslots sums per node -> host_scalars and dev_scalars) with the gate behind it in the same launch:
+// tnt: the refinement's start per node (TNT_SUMMARY each, launch_cg_scal_begin's dev_tnt); *go = ~0 / 0, host_out[0] = 1.0 / 0.0
+// (pinned), both set before the flag is raised
+void launch_reduce_gate(hipStream_t st, const SegTable &T, int nnodes, int nslots, const double *partials, double *host_scalars,
+                        unsigned *arrived, unsigned long long *host_flag, unsigned long long seq, unsigned long long *dev_seq,
+                        double *dev_scalars, const AmmGate &G, const double *tnt, const CgNode *cg, NodeBits *go, double *host_out);
 
 // AMM-PGO*'s master sums (k_star_sums): out[0..3] (device) from the partial slots 0..5; launch_publish: n <= 64 device values
 // to pinned host memory, then *host_flag = seq

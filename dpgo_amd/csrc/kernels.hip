@@ -1390,7 +1390,7 @@ __global__ __launch_bounds__(256) void k_copy_indexed(int count, const int *didx
                                                       const double *src, double *dst, const NodeBits *gate) {
   constexpr int RS = Dim<D>::RS;
   const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= count || (gate && *gate == 0ull)) return;   // gate: a device word that switches the whole launch off (k_amm_gate)
+  if (k >= count || (gate && *gate == 0ull)) return;   // gate: a device word that switches the whole launch off (k_reduce_gate)
   double r[RS];
   load_vec<RS>(src + (size_t)sidx[k] * RS, r);
   store_vec<RS>(dst + (size_t)(didx ? didx[k] : k) * RS, r);
@@ -1426,7 +1426,7 @@ __global__ __launch_bounds__(SEG_ROWS) void k_bdiag_dot(const Seg *segs, NodeMas
 // host gets the numbers by polling a cache line instead of a copy + stream synchronisation.
 __global__ __launch_bounds__(64) void k_reduce(SegTable T, int all_rows, int nslots, const double *partials,
                                                double *host_scalars, unsigned *arrived, unsigned long long *host_flag,
-                                               unsigned long long seq, unsigned long long *dev_seq, double *dev_scalars) {
+                                               unsigned long long seq, unsigned long long *dev_seq) {
   const int a = blockIdx.x / nslots, s = blockIdx.x % nslots, lane = threadIdx.x;
   const double *p = partials + (size_t)s * T.nseg_all;
   double v = 0;
@@ -1436,7 +1436,6 @@ __global__ __launch_bounds__(64) void k_reduce(SegTable T, int all_rows, int nsl
   v = wave_sum(v);
   if (lane == 0) {
     __hip_atomic_store(host_scalars + a * MAX_SLOTS + s, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (dev_scalars) dev_scalars[a * MAX_SLOTS + s] = v;   // (the gate of a speculative update reads them there: k_amm_gate)
     __atomic_thread_fence(__ATOMIC_RELEASE);   // system scope: the scalar is on its way before the count
     const unsigned done = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
     if (done == gridDim.x - 1) {
@@ -1517,7 +1516,7 @@ __device__ __forceinline__ void tnt_begin_node(int a, bool mine, const double (&
 #pragma unroll
     for (int q = 0; q < 6; q++) __hip_atomic_store(host_tnt + a * TNT_SUMMARY + q, v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(host_tnt + a * TNT_SUMMARY + 6, active ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (dev_tnt) {   // (k_amm_gate)
+    if (dev_tnt) {   // (k_reduce_gate)
 #pragma unroll
       for (int q = 0; q < 6; q++) dev_tnt[a * TNT_SUMMARY + q] = v[q];
       dev_tnt[a * TNT_SUMMARY + 6] = active ? 1.0 : 0.0;
@@ -2797,58 +2796,87 @@ void launch_publish(hipStream_t st, const double *vals, int n, double *host, uns
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, vals, n, host, host_flag, seq, dev_seq);
 }
 
-// ---- the gate of a speculative update (Group::speculate_update): one thread per node evaluates, from the sums the trial
-// point's k_reduce left in device memory, the refinement's start (k_cg_scal_begin) and the CG's state, whether the iteration
+// ---- the gate of a speculative update (Group::speculate_update): one lane per node evaluates, from the trial point's sums, the refinement's start (k_cg_scal_begin) and the CG's state, whether the iteration
 // takes its COMMON course -- the node was refined, its CG ended with the first step, the step is accepted and ends the
 // refinement (TNT.h:537-607), the half step needs no redo, there is no restart and no fallback (DPGOHash.cpp:386-441) -- with
 // the host's expressions in the host's order (amm(), run_tnt()'s judge): the two must reach the same verdict from the same
 // bits, and the host checks that they did.  *go = all ones if every node does, else 0: the launches of the next update(),
 // enqueued behind this kernel under that word, run or fall through.
-__global__ __launch_bounds__(64) void k_amm_gate(AmmGate G, const double *sums, const double *tnt, const CgNode *cg, NodeBits *go,
-                                                 double *host_out) {
+__device__ __forceinline__ bool amm_gate_node(const AmmGate &G, int a, const double *sums, const double *tnt, const CgNode *cg) {
 #pragma clang fp contract(off)   // (the host rounds every product before it adds: so must this)
-  const int a = threadIdx.x;
-  bool common = true;
-  if (a < G.nnodes) {
-    const double *t = sums + a * MAX_SLOTS, *b = tnt + a * TNT_SUMMARY;
-    const double f = G.f[a], Fk0 = G.Fk0[a], Fk1 = G.Fk1[a], fobj = G.fobj[a];
-    const bool active = b[6] != 0.0, cg_over = cg[a].live == 0;
-    const double fx = 0.5 * (b[1] + b[2]) + f;                 // norms_take
-    const double fx_prop = 0.5 * (t[5] + t[3]) + f;            // judge
-    const double h_norm = sqrt(t[0]);
-    const double dm = -t[1] - 0.5 * t[2];
-    const double df = fx - fx_prop;
-    const double rel_dec = df / (G.sqrt_eps + fabs(fx));
-    const double rho = df / dm;
-    const bool ok = (!isnan(rho)) && rho > G.eta1;
-    const bool stop = rel_dec < G.rel_tol || h_norm < G.step_tol;
-    const bool ends = stop || !(1 < G.max_it && 1 < G.max_acc);   // no further trust-region iteration behind the accepted one
-    const double Gk = fx_prop - t[3] + t[4];                    // f(X | g[k]): only the linear term depends on g
-    const double Gkh = t[G.ds + 1] + f;
-    const double minG = Fk0 - G.psi * t[G.ds];
-    const bool redo = Gkh > minG;
-    const bool hr = Gk > Fk0;
-    const bool sr = (Gk > Fk1 && G.hits0[a] >= G.max_hits0) || (Gk > fobj && G.hits1[a] > G.max_hits1);
-    const bool fb = (Fk0 - Gk) < G.phi * (Fk0 - Gkh);
-    common = active && cg_over && ok && ends && !redo && !(hr || sr) && !fb;
+  double t[MAX_SLOTS], b[TNT_SUMMARY];
+  // (written by other workgroups of this launch, or by an earlier one: read past this XCD's L2)
+#pragma unroll
+  for (int q = 0; q < MAX_SLOTS; q++) t[q] = __hip_atomic_load(sums + a * MAX_SLOTS + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int q = 0; q < TNT_SUMMARY; q++) b[q] = tnt[a * TNT_SUMMARY + q];
+  const double f = G.f[a], Fk0 = G.Fk0[a], Fk1 = G.Fk1[a], fobj = G.fobj[a];
+  const bool active = b[6] != 0.0, cg_over = cg[a].live == 0;
+  const double fx = 0.5 * (b[1] + b[2]) + f;                 // norms_take
+  const double fx_prop = 0.5 * (t[5] + t[3]) + f;            // judge
+  const double h_norm = sqrt(t[0]);
+  const double dm = -t[1] - 0.5 * t[2];
+  const double df = fx - fx_prop;
+  const double rel_dec = df / (G.sqrt_eps + fabs(fx));
+  const double rho = df / dm;
+  const bool ok = (!isnan(rho)) && rho > G.eta1;
+  const bool stop = rel_dec < G.rel_tol || h_norm < G.step_tol;
+  const bool ends = stop || !(1 < G.max_it && 1 < G.max_acc);   // no further trust-region iteration behind the accepted one
+  const double Gk = fx_prop - t[3] + t[4];                    // f(X | g[k]): only the linear term depends on g
+  const double Gkh = t[G.ds + 1] + f;
+  const double minG = Fk0 - G.psi * t[G.ds];
+  const bool redo = Gkh > minG;
+  const bool hr = Gk > Fk0;
+  const bool sr = (Gk > Fk1 && G.hits0[a] >= G.max_hits0) || (Gk > fobj && G.hits1[a] > G.max_hits1);
+  const bool fb = (Fk0 - Gk) < G.phi * (Fk0 - Gkh);
+  return active && cg_over && ok && ends && !redo && !(hr || sr) && !fb;
+}
+// The trial point's k_reduce and the gate in ONE launch: every (node, slot) workgroup sums its slot exactly as k_reduce does
+// (host scalars, and the copy in device memory); the last one to arrive -- the sums of every node are there -- takes the
+// verdict, a lane per node, sets *go and the host's copy of it, and raises the flag.
+__global__ __launch_bounds__(64) void k_reduce_gate(SegTable T, int nslots, const double *partials, double *host_scalars,
+                                                    unsigned *arrived, unsigned long long *host_flag, unsigned long long seq,
+                                                    unsigned long long *dev_seq, double *dev_scalars, AmmGate G, const double *tnt,
+                                                    const CgNode *cg, NodeBits *go, double *host_out) {
+  const int a = blockIdx.x / nslots, s = blockIdx.x % nslots, lane = threadIdx.x;
+  const double *p = partials + (size_t)s * T.nseg_all;
+  double v = 0;
+  for (int k = T.own_ptr[a] + lane; k < T.own_ptr[a + 1]; k += 64) v += p[k];
+  v = wave_sum(v);
+  int last = 0;
+  if (lane == 0) {
+    __hip_atomic_store(host_scalars + a * MAX_SLOTS + s, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dev_scalars + a * MAX_SLOTS + s, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    last = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM) == gridDim.x - 1;
   }
+  last = __shfl(last, 0, 64);
+  if (!last) return;
+  const bool common = lane < G.nnodes ? amm_gate_node(G, lane, dev_scalars, tnt, cg) : true;
   const bool all = __all(common);
-  if (threadIdx.x == 0) {
+  if (lane == 0) {
     *go = all ? ~0ull : 0ull;
     __hip_atomic_store(host_out, all ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seq == 0) seq = *dev_seq + 1;
+    *dev_seq = seq;
+    __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
-void launch_amm_gate(hipStream_t st, const AmmGate &G, const double *sums, const double *tnt, const CgNode *cg, NodeBits *go,
-                     double *host_out) {
-  hipLaunchKernelGGL(k_amm_gate, dim3(1), dim3(64), 0, st, G, sums, tnt, cg, go, host_out);
+void launch_reduce_gate(hipStream_t st, const SegTable &T, int nnodes, int nslots, const double *partials, double *host_scalars,
+                        unsigned *arrived, unsigned long long *host_flag, unsigned long long seq, unsigned long long *dev_seq,
+                        double *dev_scalars, const AmmGate &G, const double *tnt, const CgNode *cg, NodeBits *go, double *host_out) {
+  ProfScope ps(PK_REDUCE, st, 8.0 * nslots * T.nseg_own);
+  hipLaunchKernelGGL(k_reduce_gate, dim3(nnodes * nslots), dim3(64), 0, st, T, nslots, partials, host_scalars, arrived, host_flag, seq,
+                     dev_seq, dev_scalars, G, tnt, cg, go, host_out);
 }
-
 void launch_reduce(hipStream_t st, const SegTable &T, int nnodes, bool all_rows, int nslots, const double *partials,
                    double *host_scalars, unsigned *arrived, unsigned long long *host_flag, unsigned long long seq,
-                   unsigned long long *dev_seq, double *dev_scalars) {
+                   unsigned long long *dev_seq) {
   ProfScope ps(PK_REDUCE, st, 8.0 * nslots * T.nseg_all);
   hipLaunchKernelGGL(k_reduce, dim3(nnodes * nslots), dim3(64), 0, st, T, all_rows ? 1 : 0, nslots, partials, host_scalars,
-                     arrived, host_flag, seq, dev_seq, dev_scalars);
+                     arrived, host_flag, seq, dev_seq);
 }
 
 void launch_set_coefs(hipStream_t st, const NodeCoefs &C, int n, double *dev) {

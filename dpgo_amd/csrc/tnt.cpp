@@ -151,14 +151,15 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
   constexpr int NSUM = 6;   // the sums a trial point needs (TNT.h:505-536)
   // trial point of the nodes in `m`: x+ = retract(x, s), f(x+) and, for an accepted step, the next model gradient
   // retracted: the rotations of x+ are there already (the CG step's vector update took them along, stepA)
-  auto enqueue_trial = [&](NodeMask m, bool retracted, int nslots) {
+  auto enqueue_trial = [&](NodeMask m, bool retracted, int nslots, bool with_reduce = true) {
     cur_mask_ = m;
     if (!retracted) launch_retract_rot(d_, st_, T_, cur_mask_, X, sk, xprop);
     recover_translations(xprop, g);
     // nprop = G xprop + g: gives f(xprop) and, if accepted, the next model; its epilogue leaves the six sums
     // <s,s>, <grad,s>, <s,Hs>, <x+,g>, <x+,g_alt>, <x+,nprop> in the partial slots 0..5
     apply_tcol(xprop, T1_.p, nprop, 0, nullptr, nullptr, nullptr, nullptr, nullptr, partials_.p, g, ga, sk, grad, hh);
-    launch_reduce(st_, T_, L, false, nslots, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p, dev_sums_.p);
+    // (with_reduce = false: the caller launches the reduction itself, with the gate of a speculative update: group.h)
+    if (with_reduce) launch_reduce(st_, T_, L, false, nslots, partials_.p, h_scal_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
   };
   // acceptance test and trust-region update of node a from the sums of its trial point (TNT.h:537-607)
   std::vector<int> acc, requad;
@@ -295,7 +296,11 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       nslots = std::max((int)NSUM, deferred_slots_);
       deferred_slots_ = 0;
     }
-    segment(20, bits_nodes, {K(X), kg, kga, kvar, spec ? 1ull : 0ull, (unsigned long long)nslots}, [&] {
+    // where every node of the group is in here and the trial point follows unasked, the update() that the common outcome
+    // leads to goes out as well, under a gate that takes the decision on the device (group.h: SpecUpdate); the trial point's
+    // reduction then waits for the gate's inputs (below)
+    const bool plan_spec = confirm && spec && fused_ && (int)nodes.size() == L && base_ready && X == Xak_.p && spec_update_possible(xprop);
+    segment(20, bits_nodes, {K(X), kg, kga, kvar, spec ? 1ull : 0ull, (unsigned long long)nslots, plan_spec ? 1ull : 0ull}, [&] {
       cur_mask_ = live_mask(bits_nodes, nullptr);
       const bool have_sums = quad_model(X, base_ready);
       norms_enqueue(true, have_sums);
@@ -313,7 +318,7 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       mA = live_mask(bitsA, dmask_.p);
       mB = live_mask(bitsA, dmask_.p + 1);
       stepA(true, spec && fused_, merged ? &begin : nullptr);
-      if (spec) enqueue_trial(NodeMask{bitsA, dmask_.p + 2}, fused_, nslots);
+      if (spec) enqueue_trial(NodeMask{bitsA, dmask_.p + 2}, fused_, nslots, !plan_spec);
     });
     mA = live_mask(bitsA, dmask_.p);   // (a replay does not run the body: the host's copies)
     mB = live_mask(bitsA, dmask_.p + 1);
@@ -322,10 +327,11 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     // the caller's read-back (the scalars that decide whether these nodes are refined at all) is taken NOW, with the start
     // of the refinement already on the GPU: the stream never waits for that decision
     if (confirm && !(*confirm)()) return false;
-    seqA = seq_first - (spec ? 1 : 0);
-    // ... and where every node of the group is in here and the trial point is on its way, the update() that the common
-    // outcome leads to goes out as well, under a gate that takes the decision on the device (group.h: SpecUpdate)
-    if (confirm && spec && merged && (int)nodes.size() == L && base_ready && X == Xak_.p) speculate_update(xprop);
+    if (plan_spec) {
+      seqA = seq_first;                      // (the first step's scalars: the segment's last flag)
+      speculate_update(xprop, nslots);       // the trial point's reduction with the gate, then the continuation
+      seq_first = spec_upd_.seq_trial;
+    } else seqA = seq_first - (spec ? 1 : 0);
   } else {
     flush_deferred();   // (launches that were waiting for this refinement's first segment: there is none on this path)
     if (confirm && !(*confirm)()) return false;
