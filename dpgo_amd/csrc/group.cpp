@@ -1147,14 +1147,17 @@ void Group::speculate_update(const double *xprop, int nslots_trial) {
   double *zc = Zp_.p, *gc = gp_.p, *dfc = Dfp_.p, *gx = GXp_.p;
   const NodeMask m{all_bits(), go_.p};
   if (gather_dst_.n > 0) launch_copy_indexed(d_, st_, (int)gather_dst_.n, gather_dst_.p, gather_src_.p, nxak, Xk_.p, go_.p);
-  launch_bsr(d_, st_, T_, false, m, G_.dev, nxak, false, nullptr, gx, nxak, 0.5, nullptr, partials_.p, 5, Xk_.p, zc);
+  double *const pupd = partials_.p + (size_t)UPD_SLOT0 * T_.nseg_all;   // (update()'s own slots: deferred_slots_ is 0 here, Dynamic is off)
+  launch_bsr(d_, st_, T_, false, m, G_.dev, nxak, false, nullptr, gx, nxak, 0.5, nullptr, pupd, 5, Xk_.p, zc);
   InterFuse fz;
   fz.GX = gx; fz.X = nxak; fz.Df = dfc; fz.gn_slot = 4;
-  launch_inter(d_, st_, T_, m, E_, opt_.loss, opt_.loss_reg, 0, true, zc, zp, Qd_.p, Dd_.p, DfE_.p, gc, partials_.p, nullptr, nullptr, nullptr,
+  launch_inter(d_, st_, T_, m, E_, opt_.loss, opt_.loss_reg, 0, true, zc, zp, Qd_.p, Dd_.p, DfE_.p, gc, pupd, nullptr, nullptr, nullptr,
                nullptr, nullptr, Xk_.p, nullptr, &fz);
-  launch_reduce(st_, T_, L, true, 6, partials_.p, h_upd_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
+  // (the closing reduction: left to the next refinement where update() itself would leave it, group.h: UpdLazy)
+  spec_upd_.lazy = lazy_update_reduce();
+  if (!spec_upd_.lazy) launch_reduce(st_, T_, L, true, 6, pupd, h_upd_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
   n_spec_enqueued_++;
-  spec_upd_.on = true; spec_upd_.seq_upd = fetch_seq_;
+  spec_upd_.on = true; spec_upd_.seq_last = fetch_seq_;
   spec_upd_.xak = nxak; spec_upd_.zc = zc; spec_upd_.gc = gc; spec_upd_.dfc = dfc; spec_upd_.gx = gx;
 }
 
@@ -1165,9 +1168,16 @@ void Group::check_gate(bool host_common) {
   if (!spec_upd_.on) return;
   spec_verdict_pending_ = true;
   spec_verdict_expected_ = host_common;
-  spec_verdict_seq_ = spec_upd_.seq_upd;
+  spec_verdict_seq_ = spec_upd_.seq_trial;   // (the verdict is written in front of that flag)
   if (!host_common) spec_upd_ = SpecUpdate();
   else n_spec_stood_++;
+}
+
+// update()'s closing reduction left for the next refinement's k_cg_scal_begin (group.h: UpdLazy): eager launches of the fused
+// sequence only (a replayed segment is a fixed list of launches)
+bool Group::lazy_update_reduce() const {
+  static const bool on = env_int("DPGO_LAZY_UPDATE_REDUCE", 1) != 0;   // (A/B hook)
+  return on && fused_ && keep_gx() && !star_ && !capturing_ && !iter_graph_wanted();
 }
 
 void Group::flush_pending_tail() {
@@ -1342,6 +1352,12 @@ unsigned long long Group::fetch_async(int nslots, bool all_rows) {
 // The deferred end of update(): wait for its reduction, then the scalar logic that needs the numbers.
 void Group::finish_update() {
   if (!pending_update_) return;
+  if (upd_lazy_.pending) {   // (nobody has taken update()'s reduction along: launch it now)
+    upd_lazy_.pending = false;
+    launch_reduce(st_, T_, num_local(), true, upd_lazy_.nslots, partials_.p + (size_t)UPD_SLOT0 * T_.nseg_all, h_upd_, reduce_arrived_.p, h_flag_,
+                  next_seq(), dev_seq_.p);
+    pending_seq_ = fetch_seq_;
+  }
   std::function<void()> f;
   f.swap(pending_update_);
   wait_flag(pending_seq_);
@@ -2211,6 +2227,10 @@ int Group::update(const std::vector<int> &locals_in) {
     return 0;
   }
   const bool trivial = (opt_.loss == 0);
+  // update()'s partial sums have slots of their own (UPD_SLOT0 ..): they may wait there for the next refinement's
+  // k_cg_scal_begin to reduce them (`lazy` below) while that refinement's passes use the first slots.  Not with Dynamic
+  // rescale (its fetch() in the middle reads the first slots) nor when parked sums ride along (they are in the first slots)
+  double *const pupd = (dynamic() || deferred_slots_ != 0) ? partials_.p : partials_.p + (size_t)UPD_SLOT0 * T_.nseg_all;
   host_bound_tick();
   set_mask(locals);
   // history: X[iter-1] <- X[iter], X[iter] <- Xk ; same for g and Dfobj (masked nodes only).  A node whose
@@ -2266,12 +2286,17 @@ int Group::update(const std::vector<int> &locals_in) {
     deferred_slots_ = 0;
     NodeBits bits = 0;
     for (int a : set) bits |= 1ull << a;
+    // the closing reduction is left to the next refinement's k_cg_scal_begin (group.h: UpdLazy) where the read-back is
+    // deferred anyway and the launches are eager: one launch less on the stream
+    // (only where the next iterate() starts its refinement unasked -- every node was refined in this one: otherwise the host
+    // wants these sums before it enqueues anything that could carry them)
+    const bool lazy = can_defer && lazy_update_reduce() && spec_refined_ && pupd != partials_.p && nslots <= 6 && bits == all_bits();
     if (spec_upd_.on) {
       // the launches of this sequence went out ahead of the host's decision (speculate_update) and the decision was the
       // common one: what they were given must be what this call would have given them
       const SpecUpdate sp = spec_upd_;
       spec_upd_ = SpecUpdate();
-      const bool same = seg_id == 4 && fuse_copy && nslots == 6 && bits == all_bits() && !xchg_done_ && !lazy_recv && sp.seq_upd == fetch_seq_ &&
+      const bool same = seg_id == 4 && fuse_copy && nslots == 6 && bits == all_bits() && !xchg_done_ && !lazy_recv && sp.seq_last == fetch_seq_ && sp.lazy == lazy &&
                         sp.xak == Xak_.p && sp.zc == Zc_.p && sp.gc == gc_.p && sp.dfc == Dfc_.p && sp.gx == GXc_.p && pending_tail_.on;
       if (!same) {
         failed_ = true;
@@ -2281,10 +2306,11 @@ int Group::update(const std::vector<int> &locals_in) {
     } else
     segment(seg_id, bits & mask_locals_bits, {bits, mask_locals_bits, variant, (unsigned long long)nslots, fuse_copy ? 1ull : 0ull, (unsigned long long)(uintptr_t)lazy_recv}, [&] {
       launches();
-      launch_reduce(st_, T_, num_local(), true, nslots, partials_.p, h_upd_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
+      if (!lazy) launch_reduce(st_, T_, num_local(), true, nslots, pupd, h_upd_, reduce_arrived_.p, h_flag_, next_seq(), dev_seq_.p);
     });
+    if (lazy) { upd_lazy_.pending = true; upd_lazy_.nslots = nslots; }
     if (can_defer) {
-      pending_seq_ = fetch_seq_;
+      pending_seq_ = lazy ? 0ull : fetch_seq_;   // (lazy: whoever launches the reduction sets it -- run_tnt, or finish_update)
       for (int a : set) {
         host_update_pre(a);
         res_[a].updated = 1;
@@ -2303,13 +2329,13 @@ int Group::update(const std::vector<int> &locals_in) {
   const bool split = xchg_done_ != nullptr;
   auto product_with_G = [&] {
     if (trivial)   // T1 = G Xak and <Xak, 1/2 G Xak>   (half of evaluate_G, DPGOProblem.cpp:180-205)
-      launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xak_.p, false, nullptr, T1_.p, Xak_.p, 0.5, nullptr, partials_.p, 5);
+      launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Xak_.p, false, nullptr, T1_.p, Xak_.p, 0.5, nullptr, pupd, 5);
     else if (fuse_copy) {   // ... on Xak's records (the same numbers), which go to Xk and X[iter] on the way
       const PendingTail pt = pending_tail_;
       pending_tail_.on = false;
-      launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, pt.xak, false, nullptr, GX, pt.xak, 0.5, nullptr, partials_.p, 5, pt.xk, pt.z);
+      launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, pt.xak, false, nullptr, GX, pt.xak, 0.5, nullptr, pupd, 5, pt.xk, pt.z);
     } else         // T1 = G X and <X, 1/2 G X>  (kept as G X[k] where the next extrapolation reuses it)
-      launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Zc_.p, false, nullptr, GX, Zc_.p, 0.5, nullptr, partials_.p, 5);
+      launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Zc_.p, false, nullptr, GX, Zc_.p, 0.5, nullptr, pupd, 5);
   };
   const NodeMask mask_locals = cur_mask_;
   if (split) {
@@ -2328,7 +2354,7 @@ int Group::update(const std::vector<int> &locals_in) {
       head();
       cur_mask_ = mask_locals;
       launch_copy_nbr_rows(d_, st_, T_, cur_mask_, Xk_.p, Zc_.p);
-      launch_bsr(d_, st_, T_, false, cur_mask_, S_.dev, Zc_.p, false, nullptr, gc_.p, Xak_.p, 1.0, nullptr, partials_.p, 1);
+      launch_bsr(d_, st_, T_, false, cur_mask_, S_.dev, Zc_.p, false, nullptr, gc_.p, Xak_.p, 1.0, nullptr, pupd, 1);
     };
     const bool both = !first.empty() && !later.empty();
     if (both) flush_deferred();
@@ -2337,9 +2363,9 @@ int Group::update(const std::vector<int> &locals_in) {
       end_with(1, (split ? 1ull : 0ull) | (both ? 2ull : 0ull), 6, first, [&] {
         if (!both) common();
         set_mask(first);
-        launch_bsr(d_, st_, T_, true, cur_mask_, P0m_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 0);
+        launch_bsr(d_, st_, T_, true, cur_mask_, P0m_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, pupd, 0);
         // fobj = G(Xak | g, f0) = f0 + <Xak, g> + <Xak, 1/2 G Xak>: slots 1 and 5; Dfobj = g + G Xak
-        launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, partials_.p, 2, gc_.p, Dfc_.p);
+        launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, pupd, 2, gc_.p, Dfc_.p);
       }, [this, first] {
         for (int a : first) {
           const double f0 = uscal(a, 0);
@@ -2352,9 +2378,9 @@ int Group::update(const std::vector<int> &locals_in) {
         if (!both) common();
         set_mask(later);
         launch_axpby(d_, st_, T_, true, cur_mask_, 1.0, Zc_.p, -1.0, Zp_.p, Tall_.p, 0);
-        launch_bsr(d_, st_, T_, true, cur_mask_, Q_.dev, Tall_.p, false, nullptr, nullptr, Tall_.p, 0.5, nullptr, partials_.p, 0);
-        launch_bsr(d_, st_, T_, true, cur_mask_, P_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, partials_.p, 3);
-        launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, partials_.p, 2, gc_.p, Dfc_.p);
+        launch_bsr(d_, st_, T_, true, cur_mask_, Q_.dev, Tall_.p, false, nullptr, nullptr, Tall_.p, 0.5, nullptr, pupd, 0);
+        launch_bsr(d_, st_, T_, true, cur_mask_, P_.dev, Zc_.p, false, nullptr, nullptr, Zc_.p, 0.5, nullptr, pupd, 3);
+        launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, T1_.p, nullptr, pupd, 2, gc_.p, Dfc_.p);
       }, [this, later] {
         for (int a : later) {
           const double fobj = res_[a].Gk + uscal(a, 0);
@@ -2385,7 +2411,7 @@ int Group::update(const std::vector<int> &locals_in) {
         InterEdgesDev E = E_;
         if (lazy_recv) { E.recv = lazy_recv; E.nsrc = recv_nsrc_.p; }
         launch_inter(d_, st_, T_, cur_mask_, E, opt_.loss, opt_.loss_reg, 0, pass == 1, Zc_.p, Zp_.p, Qd_.p, Dd_.p, DfE_.p,
-                     gc_.p, partials_.p, dynamic() ? e_w_.p : nullptr, nullptr, nullptr, nullptr, nullptr, Xk_.p, nullptr, fz);   // slots 0, 1 and 2 = <X, g>
+                     gc_.p, pupd, dynamic() ? e_w_.p : nullptr, nullptr, nullptr, nullptr, nullptr, Xk_.p, nullptr, fz);   // slots 0, 1 and 2 = <X, g>
       };
       if (dynamic()) {
         set_mask(set);
@@ -2401,9 +2427,9 @@ int Group::update(const std::vector<int> &locals_in) {
         const std::vector<int> changed = device_rescale_ ? rescale_device(set) : maybe_rescale(set);
         if (!changed.empty()) {
           set_mask(changed);
-          launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Zc_.p, false, nullptr, GX, Zc_.p, 0.5, nullptr, partials_.p, 5);
+          launch_bsr(d_, st_, T_, false, cur_mask_, G_.dev, Zc_.p, false, nullptr, GX, Zc_.p, 0.5, nullptr, pupd, 5);
           launch_inter(d_, st_, T_, cur_mask_, E_, opt_.loss, opt_.loss_reg, 1, false, Zc_.p, nullptr, nullptr, Dd_.p, nullptr,
-                       gc_.p, partials_.p);   // g = DfobjE_own - D X with the new D (slot 2 = <X, g> again)
+                       gc_.p, pupd);   // g = DfobjE_own - D X with the new D (slot 2 = <X, g> again)
           set_mask(set);
         }
       }
@@ -2425,8 +2451,8 @@ int Group::update(const std::vector<int> &locals_in) {
           fz.GX = GX; fz.X = Xak_.p; fz.Df = Dfc_.p; fz.gn_slot = 4;
           inter_pass(in_pass ? &fz : nullptr);
         }
-        if (pass == 0) launch_bdiag_dot(d_, st_, T_, cur_mask_, Dd_.p, Zc_.p, 0.5, DfE_.p, -1.0, partials_.p, 3);
-        if (!in_pass) launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, GX, nullptr, partials_.p, 4, gc_.p, Dfc_.p);   // Dfobj = G X + g
+        if (pass == 0) launch_bdiag_dot(d_, st_, T_, cur_mask_, Dd_.p, Zc_.p, 0.5, DfE_.p, -1.0, pupd, 3);
+        if (!in_pass) launch_tangent_full(d_, st_, T_, cur_mask_, Xak_.p, GX, nullptr, pupd, 4, gc_.p, Dfc_.p);   // Dfobj = G X + g
         if (!fresh.empty()) {
           set_mask(fresh);
           copy_rows(GXp_.p, GXc_.p, false);

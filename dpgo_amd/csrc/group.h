@@ -417,10 +417,17 @@ class Group {
   // (finish_update).  Armed by step() without an exchange; eager launches only; DPGO_SPEC_UPDATE=0 switches it off.
   struct SpecUpdate {
     bool on = false, consumed_copy = false;
-    unsigned long long seq_trial = 0, seq_upd = 0;   // the flags of the trial point's reduction (+ gate) and of update()'s
+    unsigned long long seq_trial = 0, seq_last = 0;  // the flags of the trial point's reduction (+ gate) and of the continuation's last flag-raising launch
+    bool lazy = false;                               // the continuation left update()'s reduction to the next refinement (UpdLazy)
     const double *xak = nullptr; double *zc = nullptr, *gc = nullptr, *dfc = nullptr, *gx = nullptr;   // the roles it was enqueued with
   };
   SpecUpdate spec_upd_;
+  // update()'s closing reduction is only read by the host, late (finish_update): where the read-back is deferred the
+  // reduction is not launched at all but rides on the next refinement's k_cg_scal_begin (one workgroup per node anyway),
+  // from partial-sum slots of its own; if no refinement comes, finish_update() launches it
+  struct UpdLazy { bool pending = false; int nslots = 0; };
+  UpdLazy upd_lazy_;
+  bool lazy_update_reduce() const;
   long n_spec_enqueued_ = 0, n_spec_stood_ = 0;   // (DPGO_HOST_TIMING=1 prints them)
   bool spec_update_armed_ = false, spec_update_enabled_ = true;
   bool tnt_common_ = false;          // run_tnt: the refinement took the common course (one step, accepted by every node, over)

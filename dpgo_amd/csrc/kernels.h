@@ -30,7 +30,8 @@ constexpr int SEG_ROWS = 64;
 #define DPGO_BSR_LPR 4   // (8 lanes per row measured 5 % slower at the headline size, equal at one node per GPU)
 #endif
 constexpr int BSR_LPR = DPGO_BSR_LPR;
-constexpr int MAX_SLOTS = 24;   // per-node scalars one read-back can carry; slots 16.. hold the first CG step's sums (k_cg_scal_begin)
+constexpr int MAX_SLOTS = 32;   // per-node scalars one read-back can carry; slots 16.. hold the first CG step's sums (k_cg_scal_begin),
+constexpr int UPD_SLOT0 = 24;   // slots 24.. the sums of update(): they wait there for the next refinement's k_cg_scal_begin to reduce them
 constexpr int MAX_DOTS = 6;     // dot products per k_dots launch (it stores MAX_DOTS consecutive slots)
 
 struct Seg {
@@ -307,7 +308,10 @@ void launch_tnt_begin(hipStream_t st, const SegTable &T, int nnodes, NodeBits bi
 void launch_cg_scal_begin(hipStream_t st, const SegTable &T, int nnodes, NodeBits bits, bool use_precon, int max_it, double grad_tol,
                            double pgrad_tol, double kappa, double theta, const double *Delta, const double *partials, CgNode *cg,
                            NodeBits *dmask, double *host_tnt, double *host_scalars, unsigned *arrived, unsigned long long *host_flag,
-                           unsigned long long seq, unsigned long long *dev_seq, double *dev_tnt = nullptr);   // dev_tnt: host_tnt's numbers in device memory too
+                           unsigned long long seq, unsigned long long *dev_seq, double *dev_tnt = nullptr,   // dev_tnt: host_tnt's numbers in device memory too
+                           // carry: the reduction that closes the LAST update() rides along (k_reduce's work: upd_nslots sums per node over
+                           // own and neighbour segments of the partial sums from slot UPD_SLOT0 on, to upd_host[node * MAX_SLOTS + s])
+                           int upd_nslots = 0, double *upd_host = nullptr);
 int cg_first_slot();
 // cg_begin: state of the nodes in `bits` from the start values; dmask[0] = dmask[1] = the live ones, dmask[2] = the others.
 void launch_cg_begin(hipStream_t st, int nnodes, NodeBits bits, const CgStart &S, int max_it, CgNode *cg, NodeBits *dmask);

@@ -1666,14 +1666,26 @@ __global__ __launch_bounds__(256) void k_cg_scal(SegTable T, int phase, const do
 // from slot cg_slot0 on: the product must not overwrite the refinement's), then tnt_begin_node and, for a node whose CG runs,
 // the phase-0 logic.  One workgroup per node, a wave per sum.
 constexpr int CG_FIRST_SLOT = 16;   // (six consecutive slots nobody else uses: the product's epilogue always stores six)
-__global__ __launch_bounds__(640) void k_cg_scal_begin(SegTable T, TntBegin B, const double *partials, CgNode *cg, NodeBits *dmask,
-                                                       double *host_tnt, double *host_scalars, unsigned *arrived,
-                                                       unsigned long long *host_flag, unsigned long long seq,
-                                                       unsigned long long *dev_seq, double *dev_tnt) {
-  __shared__ double sums[10];
+__global__ __launch_bounds__(1024) void k_cg_scal_begin(SegTable T, TntBegin B, const double *partials, CgNode *cg, NodeBits *dmask,
+                                                        double *host_tnt, double *host_scalars, unsigned *arrived,
+                                                        unsigned long long *host_flag, unsigned long long seq,
+                                                        unsigned long long *dev_seq, double *dev_tnt, int upd_nslots, double *upd_host) {
+  // waves 0..9: the refinement's six sums and the step's four; waves 10..: the sums of the last update() (own AND neighbour
+  // segments, k_reduce's order), for every node -- update() covers the whole group whatever the refinement's candidates are
+  __shared__ double sums[16];
   const int a = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool cand = (B.bits >> a) & 1ull;
-  if (cand && (wv < 4 || wv >= 6 || B.use_precon)) {
+  if (wv >= 10) {
+    const int q = wv - 10;
+    if (q < upd_nslots) {
+      const double *p = partials + (size_t)(UPD_SLOT0 + q) * T.nseg_all;
+      double t = 0;
+      for (int k = T.own_ptr[a] + lane; k < T.own_ptr[a + 1]; k += 64) t += p[k];
+      for (int k = T.nbr_ptr[a] + lane; k < T.nbr_ptr[a + 1]; k += 64) t += p[k];
+      t = wave_sum(t);
+      if (lane == 0) sums[wv] = t;
+    }
+  } else if (cand && (wv < 4 || wv >= 6 || B.use_precon)) {
     const int slot = wv < 4 ? wv : (wv < 6 ? MAX_DOTS + (wv - 4) : CG_FIRST_SLOT + (wv - 6));
     const double *p = partials + (size_t)slot * T.nseg_all;
     double t = 0;
@@ -1685,6 +1697,7 @@ __global__ __launch_bounds__(640) void k_cg_scal_begin(SegTable T, TntBegin B, c
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
+  for (int q = 0; q < upd_nslots; q++) __hip_atomic_store(upd_host + a * MAX_SLOTS + q, sums[10 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   double v6[6];
 #pragma unroll
   for (int q = 0; q < 6; q++) v6[q] = sums[q];
@@ -2646,14 +2659,15 @@ void launch_tnt_begin(hipStream_t st, const SegTable &T, int nnodes, NodeBits bi
 void launch_cg_scal_begin(hipStream_t st, const SegTable &T, int nnodes, NodeBits bits, bool use_precon, int max_it, double grad_tol,
                            double pgrad_tol, double kappa, double theta, const double *Delta, const double *partials, CgNode *cg,
                            NodeBits *dmask, double *host_tnt, double *host_scalars, unsigned *arrived, unsigned long long *host_flag,
-                           unsigned long long seq, unsigned long long *dev_seq, double *dev_tnt) {
+                           unsigned long long seq, unsigned long long *dev_seq, double *dev_tnt, int upd_nslots, double *upd_host) {
   TntBegin B;
   B.bits = bits; B.use_precon = use_precon; B.max_it = max_it;
   B.grad_tol = grad_tol; B.pgrad_tol = pgrad_tol; B.kappa = kappa; B.theta = theta;
   for (int a = 0; a < MAX_LOCAL_NODES; a++) B.Delta[a] = a < nnodes ? Delta[a] : 0.0;
-  ProfScope ps(PK_REDUCE, st, 8.0 * 10 * T.nseg_own);
-  hipLaunchKernelGGL(k_cg_scal_begin, dim3(nnodes), dim3(640), 0, st, T, B, partials, cg, dmask, host_tnt, host_scalars, arrived,
-                     host_flag, seq, dev_seq, dev_tnt);
+  if (upd_nslots > 6) { fprintf(stderr, "[dpgo_amd] ERROR: k_cg_scal_begin carries at most six sums of an update.\n"); return; }
+  ProfScope ps(PK_REDUCE, st, 8.0 * (10 * T.nseg_own + upd_nslots * T.nseg_all));
+  hipLaunchKernelGGL(k_cg_scal_begin, dim3(nnodes), dim3(upd_nslots > 0 ? 1024 : 640), 0, st, T, B, partials, cg, dmask, host_tnt, host_scalars,
+                     arrived, host_flag, seq, dev_seq, dev_tnt, upd_nslots, upd_host);
 }
 int cg_first_slot() { return CG_FIRST_SLOT; }
 
@@ -2804,10 +2818,11 @@ void launch_publish(hipStream_t st, const double *vals, int n, double *host, uns
 // enqueued behind this kernel under that word, run or fall through.
 __device__ __forceinline__ bool amm_gate_node(const AmmGate &G, int a, const double *sums, const double *tnt, const CgNode *cg) {
 #pragma clang fp contract(off)   // (the host rounds every product before it adds: so must this)
-  double t[MAX_SLOTS], b[TNT_SUMMARY];
-  // (written by other workgroups of this launch, or by an earlier one: read past this XCD's L2)
+  double t[16], b[TNT_SUMMARY];   // (the trial point's six sums and the half step's parked ones, slots 2 * MAX_DOTS ..)
+  static_assert(2 * MAX_DOTS + 2 <= 16, "the gate's slots");
+  // (written by other workgroups of this launch: read past this XCD's L2)
 #pragma unroll
-  for (int q = 0; q < MAX_SLOTS; q++) t[q] = __hip_atomic_load(sums + a * MAX_SLOTS + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int q = 0; q < 16; q++) t[q] = __hip_atomic_load(sums + a * MAX_SLOTS + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
   for (int q = 0; q < TNT_SUMMARY; q++) b[q] = tnt[a * TNT_SUMMARY + q];
   const double f = G.f[a], Fk0 = G.Fk0[a], Fk1 = G.Fk1[a], fobj = G.fobj[a];

@@ -307,9 +307,12 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
       std::vector<double> Delta(L, 0.0);
       for (int a : nodes) Delta[a] = S[a].Delta;
       const std::function<void(const double *)> begin = [&](const double *) {
+        // (update()'s reduction, if it is still waiting for somebody to take it along: group.h, UpdLazy)
+        const int carry = (upd_lazy_.pending && !capturing_) ? upd_lazy_.nslots : 0;
         launch_cg_scal_begin(st_, T_, L, bitsA, use_precon, o.max_tCG_iterations, o.grad_norm_tol, o.preconditioned_grad_norm_tol,
                              o.STPCG_kappa, o.STPCG_theta, Delta.data(), partials_.p, cg_.p, dmask_.p, h_tnt_, h_cg_, reduce_arrived_.p,
-                             h_flag_, next_seq(), dev_seq_.p, dev_tnt_.p);
+                             h_flag_, next_seq(), dev_seq_.p, dev_tnt_.p, carry, h_upd_);
+        if (carry) { upd_lazy_.pending = false; pending_seq_ = fetch_seq_; }
       };
       merged = fused_;
       if (!merged)
