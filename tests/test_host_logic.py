@@ -258,7 +258,8 @@ def test_chordal_initialization_does_not_depend_on_the_thread_count(fixtures_dir
 
 def test_documented_switches_exist_in_the_sources():
     """Every DPGO_* environment switch DESIGN.md names is read somewhere in the library, the driver, bench.py or the
-    tools (a table that outlives its switches misleads whoever tunes next)."""
+    tools (a table that outlives its switches misleads whoever tunes next; removed switches are named in DESIGN 9 without the
+    code quotes this test looks for)."""
     import glob
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -266,7 +267,7 @@ def test_documented_switches_exist_in_the_sources():
     names = set(re.findall(r"`(DPGO_[A-Z0-9_]+)", doc))
     assert len(names) > 20
     src = ""
-    for pat in ("dpgo_amd/**/*", "tools/**/*", "tests/*.py", "bench.py"):
+    for pat in ("dpgo_amd/**/*", "tools/**/*", "tests/*.py", "bench.py", "__graft_entry__.py"):
         for f in glob.glob(os.path.join(root, pat), recursive=True):
             if f.endswith((".cpp", ".h", ".hpp", ".hip", ".py", ".sh")):
                 src += open(f, errors="ignore").read()
