@@ -1208,10 +1208,14 @@ bool Group::iter_graph_wanted() const {
 void Group::host_bound_tick() {
   if (host_bound_ || ++win_iters_ < 32) return;
   static const double below = getenv("DPGO_HOST_BOUND_BELOW") ? atof(getenv("DPGO_HOST_BOUND_BELOW")) : 0.40;   // (test hook)
-  if (win_lib_s_ > 0 && win_wait_s_ < below * win_lib_s_) host_bound_ = true;
+  // (round 6: ... and at least half of its waits found the flag already raised -- the GPU had been waiting for the HOST.  A host
+  // that enqueues ahead of the GPU's decisions -- SpecUpdate -- spends less of its time waiting without being the slower side)
+  const bool late = below >= 1.0 || 2 * win_nlate_ >= win_nwait_;
+  if (win_lib_s_ > 0 && win_wait_s_ < below * win_lib_s_ && late) host_bound_ = true;
   win_iters_ = 0;
   win_wait_s_ = 0;
   win_lib_s_ = 0;
+  win_nwait_ = win_nlate_ = 0;
 }
 
 void Group::graphs_destroy() {
@@ -1387,6 +1391,8 @@ void Group::wait_flag(unsigned long long seq) {
     }
   } acc{this, t0};
   auto arrived = [&] { return __atomic_load_n(h_flag_, __ATOMIC_ACQUIRE) >= seq; };
+  win_nwait_++;
+  if (arrived()) win_nlate_++;
   auto last = t0;
   for (unsigned spins = 0; !arrived(); spins++) {
     __builtin_ia32_pause();
@@ -2290,16 +2296,23 @@ int Group::update(const std::vector<int> &locals_in) {
     // deferred anyway and the launches are eager: one launch less on the stream
     // (only where the next iterate() starts its refinement unasked -- every node was refined in this one: otherwise the host
     // wants these sums before it enqueues anything that could carry them)
-    const bool lazy = can_defer && lazy_update_reduce() && spec_refined_ && pupd != partials_.p && nslots <= 6 && bits == all_bits();
+    bool lazy = can_defer && lazy_update_reduce() && spec_refined_ && pupd != partials_.p && nslots <= 6 && bits == all_bits();
+    // (launches that went out ahead decided for themselves: the policy may have changed since -- host_bound_tick above)
+    if (spec_upd_.on) lazy = spec_upd_.lazy;
     if (spec_upd_.on) {
       // the launches of this sequence went out ahead of the host's decision (speculate_update) and the decision was the
       // common one: what they were given must be what this call would have given them
       const SpecUpdate sp = spec_upd_;
       spec_upd_ = SpecUpdate();
-      const bool same = seg_id == 4 && fuse_copy && nslots == 6 && bits == all_bits() && !xchg_done_ && !lazy_recv && sp.seq_last == fetch_seq_ && sp.lazy == lazy &&
+      const bool same = seg_id == 4 && fuse_copy && nslots == 6 && bits == all_bits() && !xchg_done_ && !lazy_recv && sp.seq_last == fetch_seq_ && can_defer && pupd != partials_.p &&
                         sp.xak == Xak_.p && sp.zc == Zc_.p && sp.gc == gc_.p && sp.dfc == Dfc_.p && sp.gx == GXc_.p && pending_tail_.on;
       if (!same) {
         failed_ = true;
+        fprintf(stderr, "[dpgo_amd] ERROR: a speculative update was enqueued for another state than update() found (segment %d, copy %d, slots %d, "
+                        "nodes %d, exchange %d, receive %d, flags %llu / %llu, deferred %d, own slots %d, tail %d, buffers %d %d %d %d %d)\n",
+                seg_id, (int)fuse_copy, nslots, (int)(bits == all_bits()), (int)(xchg_done_ != nullptr), (int)(lazy_recv != nullptr), sp.seq_last,
+                fetch_seq_, (int)can_defer, (int)(pupd != partials_.p), (int)pending_tail_.on, (int)(sp.xak == Xak_.p), (int)(sp.zc == Zc_.p),
+                (int)(sp.gc == gc_.p), (int)(sp.dfc == Dfc_.p), (int)(sp.gx == GXc_.p));
         throw DeviceError("a speculative update was enqueued for another state than update() found");
       }
       pending_tail_.on = false;   // (it rode on the enqueued product with G)

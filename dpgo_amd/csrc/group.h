@@ -363,6 +363,7 @@ class Group {
   bool host_bound_ = false;
   double win_wait_s_ = 0, win_lib_s_ = 0;   // of the window: seconds waiting for read-backs / seconds inside iterate() and update()
   int win_iters_ = 0;
+  long win_nwait_ = 0, win_nlate_ = 0;   // of the window: waits for a read-back, and those that found it there already
   void host_bound_tick();        // once per iteration (update())
   struct InLib {                 // (the caller's own time between the calls is not the library's host being slow)
     Group *g; std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-iteration view of a rocprofv3 --kernel-trace run of bench.py: the last N iterations (an iteration ends with the
-k_reduce that closes update(): the second k_reduce of every pair), for every kernel name the launches, the mean duration and
+last kernel of update(): its k_reduce, or -- round 6 -- the k_inter behind the iteration's k_reduce_gate), for every kernel name the launches, the mean duration and
 the mean gap in front of it per iteration; totals per iteration.  Usage: trace_iter.py <dir> [N]"""
 import csv, glob, sys
 from collections import defaultdict
@@ -13,6 +13,16 @@ E = [int(r["End_Timestamp"]) for r in rows]
 names = [r["Kernel_Name"].split("(dpgo")[0].split("::")[-1].split("<")[0].split("(")[0].strip()[:24] for r in rows]
 # iteration boundaries: every k_inter that is followed (within 3 dispatches) by a k_reduce closes an update()
 ends = [i for i in range(len(rows)) if names[i] == "k_reduce" and i >= 1 and names[i - 1] in ("k_inter", "k_tangent_full", "k_bdiag_dot", "k_axpby")]
+# (round 6: update()'s reduction rides on the next refinement; an iteration then ends with the k_inter behind its k_reduce_gate)
+gate = [i for i in range(len(rows)) if names[i] == "k_reduce_gate"]
+if len(gate) > len(ends):
+    ends = []
+    for g in gate:
+        j = g + 1
+        while j < len(rows) and j < g + 6 and names[j] != "k_inter":
+            j += 1
+        if j < len(rows) and names[j] == "k_inter":
+            ends.append(j)
 ends = ends[-(N + 1):]
 if len(ends) < 2:
     sys.exit("no iterations found")
