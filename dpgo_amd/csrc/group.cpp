@@ -1415,6 +1415,13 @@ void Group::wait_flag(unsigned long long seq) {
       throw DeviceError("read-back flag never arrived");
     }
   }
+  // (debug hook: a host that comes late to every read-back -- the stream runs ahead of it by that much; the results must not
+  // depend on it, tests/test_gpu_parity.py)
+  static const int late_us = [] { const char *e = getenv("DPGO_DEBUG_LATE_HOST_US"); return e ? atoi(e) : 0; }();
+  if (late_us > 0) {
+    const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(late_us);
+    while (std::chrono::steady_clock::now() < until) __builtin_ia32_pause();
+  }
   if (tt_verdict_pending_ && seq >= tt_verdict_seq_) check_tt_verdict(false);   // (the stream has passed the factorisation)
   if (spec_verdict_pending_ && seq >= spec_verdict_seq_) {   // (... and the gate of a speculative update)
     spec_verdict_pending_ = false;
@@ -1456,7 +1463,20 @@ bool SpdSolverDev::Level::map(NodeBits bits, SpdLevelMap &M, double *bytes) cons
   return M.nlive > 0;
 }
 
-void spd_run(int d, hipStream_t st, SpdSolverDev &S, NodeMask mask, double *in, double *out, double scale) {
+// The tile class of the fused roots for a launch over the nodes `v`: the finer one where few roots are live.  The two classes
+// split a row's sum differently (their results differ in the last bits), so the choice must be a function of what the
+// ALGORITHM knows -- the nodes live after the last step the host has read (tnt.cpp: live_after) -- never of the launch's
+// geometry: a captured CG step, whose launches cover every node, asks with the eager step's node set (class_of below).
+bool SpdSolverDev::fine_root_for(NodeBits v) const {
+  if (root_sym || !root_fine_rows) return false;
+  SpdLevelMap rm;
+  if (!root_level.map(v, rm)) return false;
+  int live_tiles = 0;
+  for (int j = 0; j < rm.nlive; j++) live_tiles += rm.wcount[j];
+  return live_tiles * root_level.rows / 64 < root_fine_below;
+}
+
+void spd_run(int d, hipStream_t st, SpdSolverDev &S, NodeMask mask, double *in, double *out, double scale, const NodeBits *class_of) {
   // the launches of the nodes in mask.v (what the host knows); mask.p, if any, is the device's more recent word
   std::vector<SpdLevelMap> fm(S.fwd_levels.size()), bm(S.bwd_levels.size());
   std::vector<double> fby(fm.size(), 0.0), bby(bm.size(), 0.0);
@@ -1472,13 +1492,9 @@ void spd_run(int d, hipStream_t st, SpdSolverDev &S, NodeMask mask, double *in, 
   bool ron = S.root_sym ? (S.root_sym_level.map(mask.v, rm, &rby) && S.root_rows_level.map(mask.v, rrm)) : S.root_level.map(mask.v, rm, &rby);
   // few live roots: the finer tile class (upload()), counted in 64-row tiles as the classes are chosen
   bool fine_root = false;
-  if (ron && !S.root_sym && S.root_fine_rows) {
-    int live_tiles = 0;
-    for (int j = 0; j < rm.nlive; j++) live_tiles += rm.wcount[j];
-    if (live_tiles * S.root_level.rows / 64 < S.root_fine_below) {
-      fine_root = S.root_fine_level.map(mask.v, rm, &rby);
-      ron = fine_root;
-    }
+  if (ron && S.fine_root_for(class_of ? *class_of : mask.v)) {
+    fine_root = S.root_fine_level.map(mask.v, rm, &rby);
+    ron = fine_root;
   }
   if (ron && in == out) throw DeviceError("spd_run: the fused root step cannot solve in place");
   {
@@ -1594,8 +1610,8 @@ static void spd_profile(int d, hipStream_t st, SpdSolverDev &S, double *vec) {
 }
 
 // (fronts of nodes outside the current mask are skipped: their entries of `out` stay as they are)
-void Group::solve_tt(double *in, double *out, double scale) { spd_run(d_, st_, Ltt_, cur_mask_, in, out, scale); }
-void Group::solve_rr(double *in, double *out, double scale) { spd_run(d_, st_, Lrr_, cur_mask_, in, out, scale); }
+void Group::solve_tt(double *in, double *out, double scale) { spd_run(d_, st_, Ltt_, cur_mask_, in, out, scale, class_tt_); }
+void Group::solve_rr(double *in, double *out, double scale) { spd_run(d_, st_, Lrr_, cur_mask_, in, out, scale, class_rr_); }
 
 // X.t = -G_tt^-1 (g_t + G_tR X.R)    (DPGOProblem.h:275-294)
 // Leaves T1_ = G [0 ; X.R] + g on all rows (its translation rows are the right-hand side of the solve):

@@ -151,6 +151,7 @@ struct SpdSolverDev {
   DevBuf<SpdItem> root_fine_items;
   DevBuf<double> Wroot_fine;
   int root_fine_rows = 0, root_fine_below = 0;
+  bool fine_root_for(NodeBits v) const;
   bool root_sym = false;
   Level root_sym_level{0, 0, 0, 64, {}, {}, {}, {}, {}}, root_rows_level{0, 0, 0, 64, {}, {}, {}, {}, {}};
   DevBuf<RootRow> root_rows;
@@ -169,7 +170,8 @@ struct SpdSolverDev {
 };
 
 // out <- scale * A^-1 in on the unknowns' entries of the records (everything else in `out` is left alone); in != out
-void spd_run(int d, hipStream_t st, SpdSolverDev &S, NodeMask mask, double *in, double *out, double scale);
+// class_of: the node set the roots' tile class is chosen for, if not mask.v (SpdSolverDev::fine_root_for)
+void spd_run(int d, hipStream_t st, SpdSolverDev &S, NodeMask mask, double *in, double *out, double scale, const NodeBits *class_of = nullptr);
 
 class Group {
  public:
@@ -534,6 +536,8 @@ class Group {
   double uscal(int local, int s) const { return h_upd_[local * MAX_SLOTS + s]; }
   bool spec_refined_ = false; // amm(): every node of the group was refined in the last iteration (the next one starts its refinement unasked)
   void copy_rows(double *dst, const double *src, bool all_rows, int part = 0);
+  // (a captured CG step launches over every node but takes the tile classes of the eager step's node sets: tnt.cpp, graph_step)
+  const NodeBits *class_tt_ = nullptr, *class_rr_ = nullptr;
   void solve_tt(double *in, double *out, double scale);   // out.t <- scale * G_tt^-1 in.t
   void solve_rr(double *in, double *out, double scale);   // out.R <- scale * (G_RR + lambda I)^-1 in.R
   void apply_tcol(const double *xt, const double *base, double *y, int mode = 0, const double *X = nullptr,

@@ -68,7 +68,8 @@ struct alignas(16) CgNode {
   double sk_M_pk, sk_M_2, pk_M_2, rv, Delta, Delta_2, target, h_M_norm;
   double c1, cr;        // s += c1 p, H s += c1 H p, r += cr H p   (cr = 0: the node stops after this step)
   double al, kap, be;   // alpha_k, kappa_k (kept for beta), beta_k
-  int cg_it, max_it, live, pad;
+  int cg_it, max_it, live;
+  int stop_ord;         // which scalar step ended the run: 2 j - 1 / 2 j for phase 0 / 1 of step j, 0: never started (CG_LIVE_ORD while live)
 };
 // start values of a CG run, by value (the host knows them from the read-back of the gradient norms)
 struct CgStart {
@@ -297,7 +298,12 @@ void launch_publish(hipStream_t st, const double *vals, int n, double *host, uns
                     unsigned long long *dev_seq);
 
 // ---- device-side control of the truncated CG (tnt.cpp) ----
-constexpr int CG_SUMMARY = 4;    // doubles per node k_cg_scal writes to pinned memory: live, |h|_M, iterations
+constexpr int CG_SUMMARY = 4;    // doubles per node k_cg_scal writes to pinned memory: stop ordinal, |h|_M, iterations
+// Summary word 0 is the ordinal of the scalar step that ended the node's CG (CgNode::stop_ord), or CG_LIVE_ORD while it runs: the
+// host asks "was the node live after scalar step w" as word0 > w, and gets the same answer whether it reads the summary of
+// step w or that of a later step already written over it -- what it launches next (node sets, tile classes) must not depend
+// on how far the stream has run ahead of it.
+constexpr double CG_LIVE_ORD = 1e18;
 constexpr int TNT_SUMMARY = 8;   // doubles per node k_tnt_begin writes: the six sums it reduced, then `active`
 // tnt_begin: the first trust-region iteration's norms, gradient tests and CG start values, all on the device (see k_tnt_begin)
 void launch_tnt_begin(hipStream_t st, const SegTable &T, int nnodes, NodeBits bits, bool use_precon, int max_it, double grad_tol,
@@ -321,7 +327,7 @@ void launch_cg_begin(hipStream_t st, int nnodes, NodeBits bits, const CgStart &S
 // phase 1 (after the preconditioner and <r, v>, partial slot 0): beta and the recurrences (:364-390), then the
 // stopping test of the next step (:285-291); nodes that stop are cleared from dmask[1], then dmask[0] = dmask[1].
 // dmask[2] collects the nodes whose CG has ended (their trial point may be taken).
-// Either phase ends by writing, per node, (live, h_M_norm, cg_it) to host_scalars[node * CG_SUMMARY + 0..2] and
+// Either phase ends by writing, per node, (stop ordinal or CG_LIVE_ORD, h_M_norm, cg_it) to host_scalars[node * CG_SUMMARY + 0..2] and
 // raising *host_flag to seq (same protocol as launch_reduce).
 // seq == 0 (a launch captured into a graph): the flag is raised to *dev_seq + 1; *dev_seq always ends up holding the value used.
 void launch_cg_scal(hipStream_t st, const SegTable &T, int nnodes, int phase, const double *partials, CgNode *cg,

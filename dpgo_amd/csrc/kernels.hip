@@ -1470,7 +1470,7 @@ __global__ __launch_bounds__(64) void k_cg_begin(int nnodes, NodeBits bits, CgSt
     c.sk_M_pk = 0.0; c.sk_M_2 = 0.0; c.pk_M_2 = S.rv[a]; c.rv = S.rv[a];
     c.Delta = S.Delta[a]; c.Delta_2 = S.Delta[a] * S.Delta[a]; c.target = S.target[a]; c.h_M_norm = 0.0;
     c.c1 = 0.0; c.cr = 0.0; c.al = 0.0; c.kap = 0.0; c.be = 0.0;
-    c.cg_it = 0; c.max_it = max_it; c.pad = 0;
+    c.cg_it = 0; c.max_it = max_it; c.stop_ord = 0;
     // the stopping test of the first step (:285-291)
     c.live = !(c.cg_it >= max_it || sqrt(c.rv) <= c.target);
     if (!c.live) c.h_M_norm = sqrt(c.sk_M_2);
@@ -1508,7 +1508,7 @@ __device__ __forceinline__ void tnt_begin_node(int a, bool mine, const double (&
     c.target = r0 * fmin(kappa, pow(r0, theta));
     c.h_M_norm = 0.0;
     c.c1 = 0.0; c.cr = 0.0; c.al = 0.0; c.kap = 0.0; c.be = 0.0;
-    c.cg_it = 0; c.max_it = max_it; c.pad = 0;
+    c.cg_it = 0; c.max_it = max_it; c.stop_ord = 0;
     c.live = active && !(c.cg_it >= max_it || sqrt(c.rv) <= c.target);
     if (!c.live) c.h_M_norm = sqrt(c.sk_M_2);
     cg[a] = c;
@@ -1579,7 +1579,7 @@ __device__ __forceinline__ void cg_scal_logic(int phase, const double (&v)[4], C
         c.c1 = alpha; c.cr = alpha; c.al = alpha; c.kap = kappa_k; c.sk_M_2 = skp1;
       }
     }
-    if (stop) { c.cr = 0.0; c.h_M_norm = c.Delta; c.live = 0; }
+    if (stop) { c.cr = 0.0; c.h_M_norm = c.Delta; c.live = 0; c.stop_ord = 2 * c.cg_it + 1; }
   } else {
     const double rk_vk = v[0];
     const double be = rk_vk / (c.al * c.kap);   // (:364-390)
@@ -1591,6 +1591,7 @@ __device__ __forceinline__ void cg_scal_logic(int phase, const double (&v)[4], C
     if (c.cg_it >= c.max_it || sqrt(c.rv) <= c.target) {   // the stopping test of the next step (:285-291)
       c.h_M_norm = sqrt(c.sk_M_2);
       c.live = 0;
+      c.stop_ord = 2 * c.cg_it;
     }
   }
 }
@@ -1611,7 +1612,7 @@ __device__ __forceinline__ void cg_scal_node(int a, int phase, bool mine, const 
   }
   // (the summary has its own pinned area, CG_SUMMARY doubles per node: it must survive the read-back of a trial point
   // that was enqueued behind this step)
-  __hip_atomic_store(host_scalars + a * CG_SUMMARY + 0, (double)c.live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(host_scalars + a * CG_SUMMARY + 0, c.live ? CG_LIVE_ORD : (double)c.stop_ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(host_scalars + a * CG_SUMMARY + 1, c.h_M_norm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(host_scalars + a * CG_SUMMARY + 2, (double)c.cg_it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -252,22 +252,33 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
   auto graph_step = [&]() {
     const NodeBits all = L >= 64 ? ~0ull : ((1ull << L) - 1);
     const NodeMask sA = mA, sB = mB;
-    segment(21, all, {K(X), kvar}, [&] {
+    // (the roots' tile classes are the eager step's: they are part of the arithmetic, and so of the key)
+    const unsigned long long cls = (Ltt_.fine_root_for(sA.v) ? 1ull : 0ull) | (use_precon && !jacobi && Lrr_.fine_root_for(sB.v) ? 2ull : 0ull);
+    segment(21, all, {K(X), kvar, cls}, [&] {
       mA = NodeMask{all, dmask_.p};
       mB = NodeMask{all, dmask_.p + 1};
+      struct Classes {
+        Group *g;
+        ~Classes() { g->class_tt_ = g->class_rr_ = nullptr; }
+      } classes{this};
+      class_tt_ = &sA.v;
+      class_rr_ = &sB.v;
       stepA(false);
       stepB();
     }, 1);
     mA = sA; mB = sB;
   };
   const bool use_graph = cg_graph_wanted();
-  // (the summary of a later step may already have overwritten the one waited for: the set only shrinks, so whatever
-  // is read is a superset of the nodes that will still be live when the next launches run)
+  // The nodes still iterating after scalar step `w` of this run (phase 0 / 1 of step j: 2 j - 1 / 2 j).  The summary of a
+  // later step may already have overwritten the one waited for; it carries the ordinal each node stopped at (kernels.h,
+  // CG_LIVE_ORD), so the answer -- and with it the node sets and tile classes of the next launches -- is the same however
+  // late the host comes.
   std::vector<int> A;
-  auto any_live = [&]() {
+  auto live_after = [&](int a, int w) { return cgs(a, 0) > (double)w; };
+  auto any_live = [&](int w) {
     NodeBits live = 0;
     for (int a : A)
-      if (cgs(a, 0) != 0.0) live |= 1ull << a;
+      if (live_after(a, w)) live |= 1ull << a;
     mA = live_mask(live, dmask_.p);       // (few live nodes: the own-segment launches cover them alone)
     mB = live_mask(live, dmask_.p + 1);
     return live != 0;
@@ -398,23 +409,23 @@ bool Group::run_tnt(const std::vector<int> &nodes, double *X, const double *g, c
     }
     if (dev && spec)
       for (int a : A)
-        if (cgs(a, 0) == 0.0) {   // its CG ended with (or before) the first step: the sums just read are its trial point's
+        if (!live_after(a, 1)) {   // its CG ended with (or before) the first step: the sums just read are its trial point's
           tried[a] = 1;
           for (int q = 0; q < NSUM; q++) tsum[(size_t)a * NSUM + q] = scal(a, q);
           S[a].h_M_norm = cgs(a, 1);
           S[a].cg_it = (int)cgs(a, 2);
         }
-    const bool more_steps = any_live();
+    const bool more_steps = any_live(1);
     if (dev) tnt_speculate_ = !more_steps;   // speculate next time if nobody needed a second step this time
     if (more_steps) {
       stepB();
       unsigned long long seqB = fetch_seq_;
-      for (;;) {
+      for (int w = 2;; w += 2) {
         if (use_graph) graph_step();
         else { stepA(false); stepB(); }
         const unsigned long long next = fetch_seq_;
-        wait_flag(seqB);   // the outcome of the step before the one just enqueued
-        if (!any_live()) break;
+        wait_flag(seqB);   // the outcome of the step before the one just enqueued (its phase 1: scalar step w)
+        if (!any_live(w)) break;
         seqB = next;
       }
     }

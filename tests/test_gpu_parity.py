@@ -1066,3 +1066,57 @@ print("failed at step", first)
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DPGO_DEBUG_FAIL_REFACTOR="1"), capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "failed at step" in out.stdout and "not positive definite after a rescale" in out.stderr
+
+
+def test_update_goes_out_ahead_of_the_hosts_decision_and_falls_back(tmp_path):
+    """Round 6 (Group::SpecUpdate): in the early regime of a robust, statically scaled run driven through step(), update()'s
+    launches are enqueued ahead of the host's acceptance decision under the device-side gate; where the iteration leaves the
+    common course (a node needs a second CG step, a restart, ...) the gated launches fall through and the host path runs.
+    The lattice run below does both (the counters of DPGO_HOST_TIMING=1 say so), and its trajectory is bit for bit the one
+    of the run in which the host always decides first."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import dpgo_amd
+from dpgo_amd import synthetic
+g = synthetic.grid(20, 20, 16, 25600)
+G = dpgo_amd.graph_from_edges(3, g["num_poses"], g["I"], g["J"], g["R"], g["t"], g["kappa"], g["tau"], 8)
+drv = dpgo_amd.DistPGO(G, dpgo_amd.Options.driver(1, True), X0=G.chordal_initialization())
+tr = []
+for it in range(90):
+    assert drv.step() == 0
+    tr.append([drv.group.results(a).fobj for a in range(8)] if it %% 10 == 9 else [0.0] * 8)
+np.savez(sys.argv[1], X=drv.X(), tr=np.array(tr))
+del drv
+""" % root
+
+    def run(tag, **env):
+        path = str(tmp_path / (tag + ".npz"))
+        p = subprocess.run([sys.executable, "-c", code, path], env=dict(dict(os.environ, DPGO_HOST_TIMING="1", DPGO_ITER_GRAPH="0"), **env),
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [l for l in p.stderr.splitlines() if "updates enqueued ahead" in l]
+        assert line, p.stderr[-2000:]
+        nums = [int(x) for x in line[-1].replace(",", " ").replace(":", " ").split() if x.isdigit()]
+        return np.load(path), nums[-2], nums[-1]
+
+    spec, enq, stood = run("spec")
+    host, enq0, stood0 = run("host", DPGO_SPEC_UPDATE="0")
+    assert enq0 == 0 and stood0 == 0
+    assert enq >= 10 and 0 < stood <= enq, (enq, stood)
+    assert np.array_equal(spec["X"], host["X"]) and np.array_equal(spec["tr"], host["tr"])
+    # The results do not depend on how far the stream runs ahead of the host, nor on whether the CG steps go out as graph
+    # replays (whose launches cover every node) or eagerly (sized for the live ones).  The multi-step CG of this run has few
+    # live nodes at its late steps, where the fused roots of the solves take a finer tile class with a different summation
+    # order: the class must follow from the nodes live after the step the host WAITED for (the summary carries each node's
+    # stop ordinal), not from whatever later summary a late host happens to read (rounds <= 5 did that: a run with a cold
+    # host parted from a warm one at iteration ~26), and a captured step must take the eager step's class.
+    late, _, _ = run("late", DPGO_DEBUG_LATE_HOST_US="200")
+    assert np.array_equal(spec["X"], late["X"]) and np.array_equal(spec["tr"], late["tr"])
+    replay, _, _ = run("replay", DPGO_ITER_GRAPH="1")
+    assert np.array_equal(spec["X"], replay["X"]) and np.array_equal(spec["tr"], replay["tr"])
+    replay_late, _, _ = run("replay_late", DPGO_ITER_GRAPH="1", DPGO_DEBUG_LATE_HOST_US="60")
+    assert np.array_equal(spec["X"], replay_late["X"])
