@@ -26,7 +26,11 @@ FIX = os.path.join(ROOT, "fixtures", "g2o")
 out = {}
 
 
+SCALE = float(os.environ.get("AB_ITERS_SCALE", "1"))   # (longer runs: deeper into the interior regime)
+
+
 def run(tag, G, opt, iters, X0=None):
+    iters = int(iters * SCALE)
     drv = dpgo_amd.DistPGO(G, opt, X0=G.chordal_initialization() if X0 is None else X0)
     n = G.num_nodes
     tr = []
@@ -51,7 +55,7 @@ Gs = dpgo_amd.read_g2o(os.path.join(FIX, "M3500.g2o"), 4)
 st = dpgo_amd.DPGOStar(Gs, dpgo_amd.Options.driver(1, True))
 assert st.initialize(Gs.chordal_initialization()) == 0
 trs = []
-for it in range(30):
+for it in range(int(30 * SCALE)):
     assert st.step() == 0
     s_ = st.state()
     trs.append([st.group.results(a).fobj for a in range(4)] + [s_["F"], s_["fobj"], s_["fobjh"], float(s_["branches"])])
