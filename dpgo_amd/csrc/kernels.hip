@@ -313,6 +313,9 @@ __device__ __forceinline__ int seg_live(const NodeMask &m, int b, int n) {
 // row by 4x, which is what bounds this kernel when a GPU holds a single node (12.5 k rows).
 // MODE 0: y = A x.  MODE 1: the translation row of x counts as zero (y = A [0 ; x.R]).  MODE 2: both at once --
 // y = A [0 ; x.R] (+ add), while the fused dot product sees the full A x (one pass over A instead of two).
+#ifndef BSR_UNROLL
+#define BSR_UNROLL 2   // blocks of a lane in flight together (k_bsr)
+#endif
 template <int D, int MODE>
 __global__ __launch_bounds__(BSR_LPR * SEG_ROWS) void k_bsr(const Seg *segs, NodeMask mask, BsrDev A, const double *x,
                                               const double *addv, double *y, const double *dotv, double coef,
@@ -334,17 +337,36 @@ __global__ __launch_bounds__(BSR_LPR * SEG_ROWS) void k_bsr(const Seg *segs, Nod
     }
     const bool inrow = row < s.end;
     const int k1 = inrow ? A.ptr[row + 1] : 0;
-    for (int k = (inrow ? A.ptr[row] : 0) + j; k < k1; k += LPR) {
-      const int q = A.col[k];
-      double xb[RS], blk[B * B];
-      load_vec<RS>(x + (size_t)q * RS, xb);
-      load_block<B * B>(A.val + (size_t)(k - j) * B * B, min(LPR, k1 - (k - j)), j, blk);
-      blk_mul_acc<D, MODE != 0>(blk, xb, acc);
-      if constexpr (MODE == 2) {   // what the translation row of x adds: first column of the block
+    // A lane's blocks in groups of U: the group's records and block values are requested together, the column indices of
+    // the NEXT group with them -- a group costs one round trip instead of two per block (index, then record); the products
+    // run in the order of the row, the sums as before.
+    constexpr int U = BSR_UNROLL;
+    int kk = (inrow ? A.ptr[row] : 0) + j;
+    int qn[U];
 #pragma unroll
-        for (int r = 0; r < B; r++)
+    for (int u = 0; u < U; u++) qn[u] = kk + u * LPR < k1 ? A.col[kk + u * LPR] : 0;
+    for (; kk < k1; kk += U * LPR) {
+      double xb[U][RS], blk[U][B * B];
 #pragma unroll
-          for (int c = 0; c < D; c++) acct[r * D + c] = fma(blk[r * B], xb[c], acct[r * D + c]);
+      for (int u = 0; u < U; u++) {
+        const int k = kk + u * LPR;
+        if (k < k1) {
+          load_vec<RS>(x + (size_t)qn[u] * RS, xb[u]);
+          load_block<B * B>(A.val + (size_t)(k - j) * B * B, min(LPR, k1 - (k - j)), j, blk[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) qn[u] = kk + (U + u) * LPR < k1 ? A.col[kk + (U + u) * LPR] : 0;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (kk + u * LPR >= k1) break;
+        blk_mul_acc<D, MODE != 0>(blk[u], xb[u], acc);
+        if constexpr (MODE == 2) {   // what the translation row of x adds: first column of the block
+#pragma unroll
+          for (int r = 0; r < B; r++)
+#pragma unroll
+            for (int c = 0; c < D; c++) acct[r * D + c] = fma(blk[u][r * B], xb[u][c], acct[r * D + c]);
+        }
       }
     }
 #pragma unroll
@@ -428,6 +450,9 @@ struct TcolDots {
 // Row-local epilogues (mode): 1 = also out2 = [0 ; Proj_X(y.R)] (the reduced Riemannian gradient when y is the
 // model gradient); 2 = y is not stored, out2 = [0 ; Proj_X(y.R - sym(nabla.R X.R^T) Rdot.R)] (the Hessian-vector
 // product when y = G [tdot ; Rdot]).
+#ifndef TCOL_UNROLL
+#define TCOL_UNROLL 4
+#endif
 template <int D>
 __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr_tcol(const Seg *segs, NodeMask mask, BsrDev A, const double *tval,
                                                          const double *xt, const double *base, double *y, int mode,
@@ -445,15 +470,33 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr_tcol(const Seg *segs, Node
   for (int k = 0; k < RS; k++) acc[k] = 0.0;
   const bool inrow = row < s.end;
   const int k1 = inrow ? A.ptr[row + 1] : 0;
-  for (int k = (inrow ? A.ptr[row] : 0) + j; k < k1; k += 4) {
-    const int q = A.col[k];
-    double t[D], c0[B];
-    load_vec<D>(xt + (size_t)q * RS, t);
-    load_vec<B>(tval + (size_t)k * B, c0);
+  // (a lane's blocks in groups of U, the next group's column indices requested with this group's operands: k_bsr)
+  constexpr int U = TCOL_UNROLL;
+  int kk = (inrow ? A.ptr[row] : 0) + j;
+  int qn[U];
 #pragma unroll
-    for (int r = 0; r < B; r++)
+  for (int u = 0; u < U; u++) qn[u] = kk + 4 * u < k1 ? A.col[kk + 4 * u] : 0;
+  // (the row's own record of `base`: nothing in the loop depends on it)
+  double bv[RS];
+  if (inrow && j == 0) load_vec<RS>(base + (size_t)row * RS, bv);
+  for (; kk < k1; kk += 4 * U) {
+    double t[U][D], c0[U][B];
 #pragma unroll
-      for (int c = 0; c < D; c++) acc[r * D + c] = fma(c0[r], t[c], acc[r * D + c]);
+    for (int u = 0; u < U; u++)
+      if (kk + 4 * u < k1) {
+        load_vec<D>(xt + (size_t)qn[u] * RS, t[u]);
+        load_vec<B>(tval + (size_t)(kk + 4 * u) * B, c0[u]);
+      }
+#pragma unroll
+    for (int u = 0; u < U; u++) qn[u] = kk + 4 * (U + u) < k1 ? A.col[kk + 4 * (U + u)] : 0;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (kk + 4 * u >= k1) break;
+#pragma unroll
+      for (int r = 0; r < B; r++)
+#pragma unroll
+        for (int c = 0; c < D; c++) acc[r * D + c] = fma(c0[u][r], t[u][c], acc[r * D + c]);
+    }
   }
 #pragma unroll
   for (int k = 0; k < RS; k++) {
@@ -461,8 +504,6 @@ __global__ __launch_bounds__(4 * SEG_ROWS) void k_bsr_tcol(const Seg *segs, Node
     acc[k] += __shfl_xor(acc[k], 2, 64);
   }
   if (inrow && j == 0) {
-    double bv[RS];
-    load_vec<RS>(base + (size_t)row * RS, bv);
 #pragma unroll
     for (int k = 0; k < RS; k++) acc[k] += bv[k];
     if (mode != 2) store_vec<RS>(y + (size_t)row * RS, acc);
