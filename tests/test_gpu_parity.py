@@ -309,6 +309,12 @@ def test_multiprocess_path_matches_single_process(tmp_path):
     assert two0.returncode == 0, two0.stderr[-3000:]
     j0 = json.loads([l for l in two0.stdout.splitlines() if l.startswith("{")][-1])
     assert j0["objective_2F"] == j2["objective_2F"] and j0["convergence"]["lowest_2F"] == j2["convergence"]["lowest_2F"]
+    # ... and with both ranks' hosts 150 us late to every read-back (the streams run that far ahead of them): the same bits
+    late = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu"] + common,
+                          capture_output=True, text=True, timeout=900, cwd=root, env=dict(env, DPGO_DEBUG_LATE_HOST_US="150"))
+    assert late.returncode == 0, late.stderr[-3000:]
+    jl = json.loads([l for l in late.stdout.splitlines() if l.startswith("{")][-1])
+    assert jl["objective_2F"] == j2["objective_2F"] and jl["convergence"]["lowest_2F"] == j2["convergence"]["lowest_2F"]
 
 
 @pytest.mark.parametrize("loss", [LOSS_NONE, LOSS_HUBER])
