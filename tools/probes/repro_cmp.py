@@ -1,3 +1,5 @@
+"""First iteration at which two or more traces of tools/probes/repro_run.py differ, and in which fields.
+Usage: repro_cmp.py <tag> run0.npy run1.npy [...]"""
 import sys, numpy as np
 names = ["fobj"] * 8 + ["Gk"] * 8 + ["inner"] * 8 + ["restarts"] * 8 + ["X"] * 8
 def first(x, y):
