@@ -1785,7 +1785,10 @@ __device__ unsigned long long *g_spd_trace = nullptr;
 #ifndef SPD_NW16
 #define SPD_NW16 8
 #endif
-#define SPD_NW(ROWS) ((ROWS) == 16 ? SPD_NW16 : 8)
+#ifndef SPD_NW64
+#define SPD_NW64 8   // (4 waves per 64-row tile, six workgroups per CU: +2 % at the headline and at one node per GPU, round 6)
+#endif
+#define SPD_NW(ROWS) ((ROWS) == 16 ? SPD_NW16 : SPD_NW64)
 // loads per half-batch of the streaming loop (a lane has HB..2 HB loads in flight)
 #ifndef SPD_HB
 #define SPD_HB 8
